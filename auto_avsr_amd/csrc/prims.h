@@ -1,0 +1,230 @@
+// prims.h -- device primitives shared by every kernel of libavsr_hip.so (gfx950 / CDNA4).
+//
+// The kernels are written once, for the 64-wide CDNA4 wavefront and its MFMA
+// units.  The only conditional in the tree is the AVSR_EMU hook below: with
+// -DAVSR_EMU the same sources compile against tests/emu/hip_emu.h, a host-side
+// SIMT emulator used by the CPU unit tests to debug indexing.  The shipped
+// library is always the hipcc --offload-arch=gfx950 build.
+#pragma once
+
+#ifdef AVSR_EMU
+#include "hip_emu.h"
+#define AVSR_LAUNCH(kern, grid, block, smem, stream, ...) \
+    emu::launch((grid), (block), (smem), [=]() { kern(__VA_ARGS__); })
+#define AVSR_DYN_SMEM(name) char* name = emu::dyn_smem()
+#else
+#include <hip/hip_runtime.h>
+#define AVSR_LAUNCH(kern, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__)
+#define AVSR_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#endif
+
+#include <stdint.h>
+
+#define AVSR_DEV __device__ __forceinline__
+#define AVSR_WAVE 64
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------- bf16 <-> f32
+AVSR_DEV float bf2f(bf16_t h) {
+    uint32_t u = ((uint32_t)h) << 16;
+    return __builtin_bit_cast(float, u);
+}
+AVSR_DEV bf16_t f2bf(float f) {  // round to nearest even, NaN preserved
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+// Storage-type traits: activations live in HBM either as bf16 (bench mode) or
+// as f32 (parity mode, where GEMM operands are split into hi+lo bf16 halves).
+template <class T> struct Elem;
+template <> struct Elem<float> {
+    static AVSR_DEV float ld(const float* p) { return *p; }
+    static AVSR_DEV void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static AVSR_DEV float ld(const bf16_t* p) { return bf2f(*p); }
+    static AVSR_DEV void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// 8 consecutive elements -> 8 floats (16-byte / 32-byte vector loads)
+AVSR_DEV void load8(const bf16_t* p, float* out) {
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = bf2f((bf16_t)v[i]);
+}
+AVSR_DEV void load8(const float* p, float* out) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        out[i] = a[i];
+        out[i + 4] = b[i];
+    }
+}
+AVSR_DEV void store8(bf16_t* p, const float* v) {
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o[i] = (short)f2bf(v[i]);
+    *reinterpret_cast<bf16x8*>(p) = o;
+}
+AVSR_DEV void store8(float* p, const float* v) {
+    f32x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        a[i] = v[i];
+        b[i] = v[i + 4];
+    }
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+
+// ---------------------------------------------------------------- math
+AVSR_DEV float avsr_exp(float x) {
+#ifdef AVSR_EMU
+    return expf(x);
+#else
+    return __expf(x);
+#endif
+}
+AVSR_DEV float avsr_sigmoid(float x) { return 1.0f / (1.0f + avsr_exp(-x)); }
+AVSR_DEV float avsr_silu(float x) { return x * avsr_sigmoid(x); }
+
+// ---------------------------------------------------------------- wave reductions (64 lanes)
+AVSR_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+AVSR_DEV float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+
+// ---------------------------------------------------------------- MFMA
+// v_mfma_f32_32x32x16_bf16: A lane l holds row (l&31), k = 8*(l>>5)+e; B lane l
+// holds col (l&31), same k; D reg r of lane l is row (r&3)+8*(r>>2)+4*(l>>5), col l&31.
+AVSR_DEV f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+#ifdef AVSR_EMU
+    struct P { bf16x8 a, b; } mine{a, b};
+    size_t stride;
+    const unsigned char* all = emu::wave_gather(&mine, sizeof(P), &stride);
+    const int l = emu::lane_id();
+    const int j = l & 31;
+    for (int r = 0; r < 16; r++) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int kb = 0; kb < 2; kb++) {
+            P pa, pb;
+            memcpy(&pa, all + (size_t)(i + 32 * kb) * stride, sizeof(P));
+            memcpy(&pb, all + (size_t)(j + 32 * kb) * stride, sizeof(P));
+            for (int e = 0; e < 8; e++) acc += bf2f((bf16_t)pa.a[e]) * bf2f((bf16_t)pb.b[e]);
+        }
+        c[r] = acc;
+    }
+    return c;
+#else
+    typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, a),
+                                                   __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+#endif
+}
+// v_mfma_f32_16x16x32_bf16: A lane l holds row (l&15), k = 8*(l>>4)+e; B lane l
+// holds col (l&15); D reg r of lane l is row 4*(l>>4)+r, col l&15.
+AVSR_DEV f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+#ifdef AVSR_EMU
+    struct P { bf16x8 a, b; } mine{a, b};
+    size_t stride;
+    const unsigned char* all = emu::wave_gather(&mine, sizeof(P), &stride);
+    const int l = emu::lane_id();
+    const int j = l & 15;
+    for (int r = 0; r < 4; r++) {
+        const int i = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int kb = 0; kb < 4; kb++) {
+            P pa, pb;
+            memcpy(&pa, all + (size_t)(i + 16 * kb) * stride, sizeof(P));
+            memcpy(&pb, all + (size_t)(j + 16 * kb) * stride, sizeof(P));
+            for (int e = 0; e < 8; e++) acc += bf2f((bf16_t)pa.a[e]) * bf2f((bf16_t)pb.b[e]);
+        }
+        c[r] = acc;
+    }
+    return c;
+#else
+    typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a),
+                                                   __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+#endif
+}
+
+// Split-precision operands.  NS = 1: plain bf16.  NS = 2: value = hi + lo with
+// both halves bf16 (16 mantissa bits); a product uses the three significant
+// cross terms, giving ~2^-16 relative error -- the "parity mode" of DESIGN.md.
+template <int NS> struct Frag { bf16x8 p[NS]; };
+
+template <int NS>
+AVSR_DEV f32x16 mma32(const Frag<NS>& a, const Frag<NS>& b, f32x16 c) {
+    if (NS == 2) {
+        c = mfma32(a.p[NS - 1], b.p[0], c);  // lo*hi
+        c = mfma32(a.p[0], b.p[NS - 1], c);  // hi*lo
+    }
+    return mfma32(a.p[0], b.p[0], c);
+}
+template <int NS>
+AVSR_DEV f32x4 mma16(const Frag<NS>& a, const Frag<NS>& b, f32x4 c) {
+    if (NS == 2) {
+        c = mfma16(a.p[NS - 1], b.p[0], c);
+        c = mfma16(a.p[0], b.p[NS - 1], c);
+    }
+    return mfma16(a.p[0], b.p[0], c);
+}
+
+// split a float into NS bf16 planes
+template <int NS> AVSR_DEV void split_bf16(float x, bf16_t* out) {
+    bf16_t h = f2bf(x);
+    out[0] = h;
+    if (NS == 2) out[NS - 1] = f2bf(x - bf2f(h));
+}
+
+// ---------------------------------------------------------------- stateless dropout RNG
+// keep-mask for element `idx` of a tensor under (seed, p): a 32-bit mix of the
+// 64-bit (seed, idx) counter; forward and backward recompute the same bits.
+AVSR_DEV uint32_t avsr_hash(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+// returns scale to apply: 0 if dropped, 1/(1-p) if kept; p == 0 -> 1
+AVSR_DEV float dropout_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
+    if (p <= 0.f) return 1.f;
+    const float u = (float)(avsr_hash(seed, idx) >> 8) * (1.0f / 16777216.0f);
+    return u < p ? 0.f : inv_keep;
+}
+
+// ---------------------------------------------------------------- status plumbing
+extern "C" void avsr_set_error(const char* msg);
+#define AVSR_CHECK_LAUNCH(name)                                   \
+    do {                                                          \
+        hipError_t e__ = hipGetLastError();                       \
+        if (e__ != hipSuccess) {                                  \
+            avsr_set_error(name);                                 \
+            return 2;                                             \
+        }                                                         \
+    } while (0)
+#define AVSR_REQUIRE(cond, msg)         \
+    do {                                \
+        if (!(cond)) {                  \
+            avsr_set_error(msg);        \
+            return 1;                   \
+        }                               \
+    } while (0)

@@ -1,0 +1,46 @@
+/* avsr_hip.h -- C ABI of libavsr_hip.so: the MI355X (gfx950) kernels behind the
+ * auto_avsr training hot path  E2E.forward / backward
+ * (reference: espnet/nets/pytorch_backend/e2e_asr_conformer.py:63-87).
+ *
+ * The reference has no FFI of its own (it is 100 % Python on ATen); every entry
+ * point below replaces the implicit ATen/cuDNN/cuBLAS op sequence of the cited
+ * reference lines.  Conventions:
+ *   - plain pointers + sizes, caller-owned device buffers, no allocation, no
+ *     synchronisation; work is enqueued on `stream`;
+ *   - return 0 on success, non-zero on error (avsr_last_error() has the text);
+ *   - dtype codes: 0 = float32, 1 = bfloat16 (raw 16-bit);
+ *   - row-major tensors; "ld" arguments are leading dimensions in elements.
+ */
+#ifndef AVSR_HIP_H
+#define AVSR_HIP_H
+#include <stdint.h>
+
+#if defined(__HIP__) || defined(AVSR_EMU)
+typedef hipStream_t avsr_stream_t;
+#else
+typedef void* avsr_stream_t; /* a hipStream_t */
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library / status ------------------------------------------------------------------ */
+int avsr_abi_version(void);
+int avsr_is_emulator(void);
+const char* avsr_last_error(void);
+
+/* ---- LayerNorm (layer_norm.py:12-33, eps 1e-12) ------------------------------------------ */
+/* y = (x-mean)*rstd*gamma+beta ; x f32 [rows,cols]; y dtype selectable; saves mean/rstd [rows] */
+int avsr_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype,
+                       float* mean, float* rstd, int rows, int cols, float eps,
+                       avsr_stream_t stream);
+/* dx = LN'(dy) (+ dres if non-null); dgamma/dbeta are accumulated into */
+int avsr_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma,
+                       const float* mean, const float* rstd, const float* dres, float* dx,
+                       float* dgamma, float* dbeta, int rows, int cols, avsr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVSR_HIP_H */
