@@ -1,0 +1,47 @@
+// gemm.hip -- C-ABI entry point of the MFMA GEMM family (kernels in gemm_core.h).
+//
+// Replaces every torch.nn.Linear / k=1 Conv1d contraction of the hot path and
+// their autograd counterparts:
+//   FFN w_1/w_2            positionwise_feed_forward.py:24-30
+//   linear_q/k/v/out/pos   attention.py:31-34,123
+//   pointwise_cov1/2       conformer_encoder.py:24,27
+//   proj_encoder           e2e_asr_conformer.py:31
+//   ctc_lo / output_layer  ctc.py:21, transformer_decoder.py:225
+#include "gemm_core.h"
+#include "avsr_hip.h"
+
+namespace avsr_gemm_impl {
+int run_nt(const Params&, int, int, int, int, int, hipStream_t);
+int run_nn(const Params&, int, int, int, int, int, hipStream_t);
+int run_tn(const Params&, int, int, int, int, int, hipStream_t);
+}  // namespace avsr_gemm_impl
+
+extern "C" int avsr_gemm(int layout, const void* A, int a_dtype, int lda, const void* B, int b_dtype,
+                         int ldb, int M, int N, int K, int precise, const float* bias, int act,
+                         const void* gate, int gate_dtype, int ldg, float gate_scale, float drop_p,
+                         uint64_t seed, float alpha, const float* resid, int ldr, void* C, int c_dtype,
+                         int ldc, int accumulate, int split_k, int force_tile, hipStream_t stream) {
+    AVSR_REQUIRE(layout >= 0 && layout <= 2, "gemm: layout must be 0 (NT), 1 (NN) or 2 (TN)");
+    AVSR_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "gemm: lda/ldb must be multiples of 8 elements");
+    AVSR_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "gemm: operands must be 16-byte aligned");
+    AVSR_REQUIRE(!(accumulate && c_dtype != 0), "gemm: accumulate needs an f32 output");
+    AVSR_REQUIRE(!(split_k > 1 && !accumulate), "gemm: split-K needs accumulate=1");
+    AVSR_REQUIRE(!(precise && (a_dtype != 0 || b_dtype != 0)), "gemm: precise mode needs f32 operands");
+    if (M <= 0 || N <= 0) return 0;
+    AVSR_REQUIRE(K > 0, "gemm: K must be positive");
+    avsr_gemm_impl::Params p;
+    p.A = A; p.B = B; p.lda = lda; p.ldb = ldb;
+    p.M = M; p.N = N; p.K = K; p.k_chunk = K;
+    p.bias = bias; p.act = act;
+    p.gate = gate; p.gate_dtype = gate_dtype; p.ldg = ldg; p.gate_scale = gate_scale;
+    p.drop_p = drop_p; p.seed = seed;
+    p.alpha = alpha; p.resid = resid; p.ldr = ldr;
+    p.C = C; p.c_dtype = c_dtype; p.ldc = ldc; p.accumulate = accumulate;
+    int rc;
+    if (layout == 0) rc = avsr_gemm_impl::run_nt(p, a_dtype, b_dtype, precise, force_tile, split_k, stream);
+    else if (layout == 1) rc = avsr_gemm_impl::run_nn(p, a_dtype, b_dtype, precise, force_tile, split_k, stream);
+    else rc = avsr_gemm_impl::run_tn(p, a_dtype, b_dtype, precise, force_tile, split_k, stream);
+    AVSR_REQUIRE(rc == 0, "gemm: unsupported dtype combination");
+    AVSR_CHECK_LAUNCH("gemm");
+    return 0;
+}

@@ -1,0 +1,312 @@
+// gemm_core.h -- LDS-tiled MFMA GEMM for gfx950 (v_mfma_f32_32x32x16_bf16), templated on
+// operand storage, operand memory layout and tile shape.
+//
+//   C[M,N] = epilogue( sum_k A[m,k] * B[n,k] )
+//
+// Operand layouts (what is contiguous in HBM):
+//   LA = 0: A stored [M][K]  (k contiguous; activations x, dY in dgrad)
+//   LA = 1: A stored [K][M]  (m contiguous; dY^T in wgrad)
+//   LB = 0: B stored [N][K]  (k contiguous; torch Linear weight [out,in] in forward)
+//   LB = 1: B stored [K][N]  (n contiguous; the same weight used for dgrad, x in wgrad)
+//
+// This one kernel therefore covers every dense contraction of the hot path:
+// Linear forward (LA0,LB0), its data gradient (LA0,LB1) and weight gradient
+// (LA1,LB1) -- the k=1 Conv1d "pointwise" layers of ConvolutionModule included
+// (conformer_encoder.py:24,27), since (B,T,D) activations make them plain GEMMs.
+//
+// Structure: 256 threads = 4 waves in a 2x2 grid, each wave owns (BM/2)x(BN/2)
+// of the tile as 32x32 MFMA accumulators; operands are staged HBM -> registers
+// -> LDS ([rows][BK+8] bf16, 144-byte pitch: conflict-free ds_read_b128) with
+// the next tile's global loads in flight while the current one is multiplied.
+// NS = 2 keeps a hi and a lo bf16 plane per operand (f32-class accuracy).
+#pragma once
+#include "prims.h"
+
+namespace avsr_gemm_impl {
+
+struct Params {
+    const void* A;
+    const void* B;
+    int lda, ldb;
+    int M, N, K;
+    int k_chunk;  // K range handled per blockIdx.z (split-K); == K when not split
+    // epilogue, applied in this order:
+    const float* bias;  // [N] or null
+    int act;            // 0 none, 1 relu, 2 silu
+    const void* gate;   // saved activation [M,ldg]: v = gate>0 ? v*gate_scale : 0 (ReLU/dropout backward)
+    int gate_dtype, ldg;
+    float gate_scale;
+    float drop_p;  // dropout on v (forward); keep-mask from (seed, m*N+n)
+    uint64_t seed;
+    float alpha;         // v *= alpha
+    const float* resid;  // v += resid[m,ldr]
+    int ldr;
+    void* C;
+    int c_dtype, ldc;
+    int accumulate;  // f32 C only: atomicAdd (needed for split-K; also "+=" semantics)
+};
+
+template <class T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+    bf16x8 v;
+    AVSR_DEV void zero() { v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
+    AVSR_DEV void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+    AVSR_DEV void set(int e, const bf16_t* p) { v[e] = (short)*p; }
+    AVSR_DEV float get(int e) const { return bf2f((bf16_t)v[e]); }
+};
+template <> struct Raw8<float> {
+    f32x4 a, b;
+    AVSR_DEV void zero() { a = f32x4{0, 0, 0, 0}; b = a; }
+    AVSR_DEV void load(const float* p) {
+        a = *reinterpret_cast<const f32x4*>(p);
+        b = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+    AVSR_DEV void set(int e, const float* p) {
+        if (e < 4) a[e] = *p; else b[e - 4] = *p;
+    }
+    AVSR_DEV float get(int e) const { return e < 4 ? a[e] : b[e - 4]; }
+};
+
+// 8 consecutive elements starting at (r, c) of a row-major matrix, zero outside [r_lim) x [c_lim)
+template <class T>
+AVSR_DEV Raw8<T> load_chunk(const T* base, int ld, int r, int c, int r_lim, int c_lim) {
+    Raw8<T> out;
+    if (r < r_lim && c + 8 <= c_lim) {
+        out.load(base + (size_t)r * ld + c);
+    } else {
+        out.zero();
+        if (r < r_lim) {
+            for (int e = 0; e < 8; e++)
+                if (c + e < c_lim) out.set(e, base + (size_t)r * ld + c + e);
+        }
+    }
+    return out;
+}
+
+template <class TA, class TB, int NS, int LA, int LB, int BM, int BN, int BK>
+struct Kernel {
+    static constexpr int PITCH = BK + 8;  // bf16 elements per LDS row
+    static constexpr int NT = 256;
+    static constexpr int WM = BM / 2, WN = BN / 2;  // per-wave sub-tile
+    static constexpr int TM = WM / 32, TN = WN / 32;
+    // items staged per thread
+    static constexpr int A_ITEMS = (LA == 0) ? (BM * (BK / 8) / NT) : ((BK / 2) * (BM / 8) / NT);
+    static constexpr int B_ITEMS = (LB == 0) ? (BN * (BK / 8) / NT) : ((BK / 2) * (BN / 8) / NT);
+    static constexpr int A_RAW = (LA == 0) ? A_ITEMS : 2 * A_ITEMS;
+    static constexpr int B_RAW = (LB == 0) ? B_ITEMS : 2 * B_ITEMS;
+    static constexpr size_t LDS_BYTES = (size_t)NS * (BM + BN) * PITCH * sizeof(bf16_t);
+    static_assert(A_ITEMS >= 1 && B_ITEMS >= 1, "tile too small for 256 threads");
+
+    // ---- HBM -> registers
+    template <class T, int L, int ROWS, int ITEMS, int NRAW>
+    static AVSR_DEV void fetch(Raw8<T> (&raw)[NRAW], const T* base, int ld, int row0, int row_lim, int k0,
+                        int k_lim) {
+        const int tid = threadIdx.x;
+        if (L == 0) {
+            constexpr int CH = BK / 8;
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) {
+                const int id = tid + NT * i;
+                const int r = id / CH, kc = (id % CH) * 8;
+                raw[i] = load_chunk<T>(base, ld, row0 + r, k0 + kc, row_lim, k_lim);
+            }
+        } else {
+            constexpr int KP = BK / 2;
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) {
+                const int id = tid + NT * i;
+                const int kp = id % KP, mc = (id / KP) * 8;
+                // matrix is [K][rows]: "row" index of the load is k, column is the m/n index
+                raw[2 * i] = load_chunk<T>(base, ld, k0 + 2 * kp, row0 + mc, k_lim, row_lim);
+                raw[2 * i + 1] = load_chunk<T>(base, ld, k0 + 2 * kp + 1, row0 + mc, k_lim, row_lim);
+            }
+        }
+    }
+    // ---- registers -> LDS ([NS][ROWS][PITCH] bf16)
+    template <class T, int L, int ROWS, int ITEMS, int NRAW>
+    static AVSR_DEV void stash(const Raw8<T> (&raw)[NRAW], bf16_t* lds) {
+        const int tid = threadIdx.x;
+        if (L == 0) {
+            constexpr int CH = BK / 8;
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) {
+                const int id = tid + NT * i;
+                const int r = id / CH, kc = (id % CH) * 8;
+                bf16x8 pl[NS];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    bf16_t s[NS];
+                    split_bf16<NS>(raw[i].get(e), s);
+#pragma unroll
+                    for (int p = 0; p < NS; p++) pl[p][e] = (short)s[p];
+                }
+#pragma unroll
+                for (int p = 0; p < NS; p++)
+                    *reinterpret_cast<bf16x8*>(lds + (size_t)p * ROWS * PITCH + r * PITCH + kc) = pl[p];
+            }
+        } else {
+            constexpr int KP = BK / 2;
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) {
+                const int id = tid + NT * i;
+                const int kp = id % KP, mc = (id / KP) * 8;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    bf16_t s0[NS], s1[NS];
+                    split_bf16<NS>(raw[2 * i].get(e), s0);
+                    split_bf16<NS>(raw[2 * i + 1].get(e), s1);
+#pragma unroll
+                    for (int p = 0; p < NS; p++) {
+                        const uint32_t w = (uint32_t)s0[p] | ((uint32_t)s1[p] << 16);
+                        *reinterpret_cast<uint32_t*>(lds + (size_t)p * ROWS * PITCH + (mc + e) * PITCH +
+                                                     2 * kp) = w;
+                    }
+                }
+            }
+        }
+    }
+
+    static AVSR_DEV void run(const Params& p, char* smem) {
+        bf16_t* As = reinterpret_cast<bf16_t*>(smem);
+        bf16_t* Bs = As + (size_t)NS * BM * PITCH;
+        const TA* A = reinterpret_cast<const TA*>(p.A);
+        const TB* B = reinterpret_cast<const TB*>(p.B);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int wm = wave >> 1, wn = wave & 1;
+        const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+        const int kbeg = blockIdx.z * p.k_chunk;
+        const int kend = min(p.K, kbeg + p.k_chunk);
+
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+        Raw8<TA> ra[A_RAW];
+        Raw8<TB> rb[B_RAW];
+        fetch<TA, LA, BM, A_ITEMS, A_RAW>(ra, A, p.lda, m0, p.M, kbeg, kend);
+        fetch<TB, LB, BN, B_ITEMS, B_RAW>(rb, B, p.ldb, n0, p.N, kbeg, kend);
+        stash<TA, LA, BM, A_ITEMS, A_RAW>(ra, As);
+        stash<TB, LB, BN, B_ITEMS, B_RAW>(rb, Bs);
+        __syncthreads();
+
+        for (int k0 = kbeg; k0 < kend; k0 += BK) {
+            const bool more = (k0 + BK) < kend;
+            if (more) {
+                fetch<TA, LA, BM, A_ITEMS, A_RAW>(ra, A, p.lda, m0, p.M, k0 + BK, kend);
+                fetch<TB, LB, BN, B_ITEMS, B_RAW>(rb, B, p.ldb, n0, p.N, k0 + BK, kend);
+            }
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ks++) {
+                Frag<NS> fa[TM], fb[TN];
+                const int koff = ks * 16 + 8 * (lane >> 5);
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int pl = 0; pl < NS; pl++)
+                        fa[i].p[pl] = *reinterpret_cast<const bf16x8*>(
+                            As + (size_t)pl * BM * PITCH + (wm * WM + i * 32 + (lane & 31)) * PITCH + koff);
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int pl = 0; pl < NS; pl++)
+                        fb[j].p[pl] = *reinterpret_cast<const bf16x8*>(
+                            Bs + (size_t)pl * BN * PITCH + (wn * WN + j * 32 + (lane & 31)) * PITCH + koff);
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) acc[i][j] = mma32<NS>(fa[i], fb[j], acc[i][j]);
+            }
+            __syncthreads();
+            if (more) {
+                stash<TA, LA, BM, A_ITEMS, A_RAW>(ra, As);
+                stash<TB, LB, BN, B_ITEMS, B_RAW>(rb, Bs);
+                __syncthreads();
+            }
+        }
+
+        // ---- epilogue
+        const float inv_keep = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                const int col = n0 + wn * WN + j * 32 + (lane & 31);
+                if (col >= p.N) continue;
+                const float bias = (p.bias && blockIdx.z == 0) ? p.bias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row >= p.M) continue;
+                    float v = acc[i][j][r] + bias;
+                    if (p.act == 1) v = fmaxf(v, 0.f);
+                    else if (p.act == 2) v = avsr_silu(v);
+                    if (p.gate) {
+                        const float g = p.gate_dtype == 0
+                                            ? reinterpret_cast<const float*>(p.gate)[(size_t)row * p.ldg + col]
+                                            : bf2f(reinterpret_cast<const bf16_t*>(p.gate)[(size_t)row * p.ldg + col]);
+                        v = g > 0.f ? v * p.gate_scale : 0.f;
+                    }
+                    if (p.drop_p > 0.f)
+                        v *= dropout_scale(p.seed, (uint64_t)row * (uint64_t)p.N + col, p.drop_p, inv_keep);
+                    v *= p.alpha;
+                    if (p.resid && blockIdx.z == 0) v += p.resid[(size_t)row * p.ldr + col];
+                    if (p.c_dtype == 0) {
+                        float* c = reinterpret_cast<float*>(p.C) + (size_t)row * p.ldc + col;
+                        if (p.accumulate) atomicAdd(c, v); else *c = v;
+                    } else {
+                        reinterpret_cast<bf16_t*>(p.C)[(size_t)row * p.ldc + col] = f2bf(v);
+                    }
+                }
+            }
+    }
+};
+
+template <class TA, class TB, int NS, int LA, int LB, int BM, int BN, int BK>
+__global__ __launch_bounds__(256) void gemm_kernel(Params p) {
+    AVSR_DYN_SMEM(smem);
+    Kernel<TA, TB, NS, LA, LB, BM, BN, BK>::run(p, smem);
+}
+
+// host-side launch of one (layout, dtype) family: picks the tile shape
+template <class TA, class TB, int NS, int LA, int LB>
+int launch(const Params& p0, int force_tile, int split_k, hipStream_t stream) {
+    Params p = p0;
+    constexpr int BK = 64;
+    const long big_tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    const bool big = force_tile == 128 || (force_tile == 0 && big_tiles >= 192);
+    const int BMN = big ? 128 : 64;
+    if (split_k < 1) split_k = 1;
+    int kc = (p.K + split_k - 1) / split_k;
+    kc = ((kc + BK - 1) / BK) * BK;
+    split_k = (p.K + kc - 1) / kc;
+    p.k_chunk = kc;
+    dim3 grid((p.N + BMN - 1) / BMN, (p.M + BMN - 1) / BMN, split_k), block(256);
+    if (big) {
+        using K = Kernel<TA, TB, NS, LA, LB, 128, 128, BK>;
+        AVSR_LAUNCH((gemm_kernel<TA, TB, NS, LA, LB, 128, 128, BK>), grid, block, K::LDS_BYTES, stream, p);
+    } else {
+        using K = Kernel<TA, TB, NS, LA, LB, 64, 64, BK>;
+        AVSR_LAUNCH((gemm_kernel<TA, TB, NS, LA, LB, 64, 64, BK>), grid, block, K::LDS_BYTES, stream, p);
+    }
+    return 0;
+}
+
+// dtype dispatch for one layout
+template <int LA, int LB>
+int dispatch(const Params& p, int a_dtype, int b_dtype, int precise, int force_tile, int split_k,
+             hipStream_t stream) {
+    if (precise) {
+        if (a_dtype != 0 || b_dtype != 0) return -1;
+        return launch<float, float, 2, LA, LB>(p, force_tile, split_k, stream);
+    }
+    if (a_dtype == 1 && b_dtype == 1) return launch<bf16_t, bf16_t, 1, LA, LB>(p, force_tile, split_k, stream);
+    if (a_dtype == 0 && b_dtype == 1) return launch<float, bf16_t, 1, LA, LB>(p, force_tile, split_k, stream);
+    if (a_dtype == 1 && b_dtype == 0) return launch<bf16_t, float, 1, LA, LB>(p, force_tile, split_k, stream);
+    return launch<float, float, 1, LA, LB>(p, force_tile, split_k, stream);
+}
+
+}  // namespace avsr_gemm_impl

@@ -40,6 +40,20 @@ int avsr_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float
                        const float* mean, const float* rstd, const float* dres, float* dx,
                        float* dgamma, float* dbeta, int rows, int cols, avsr_stream_t stream);
 
+/* ---- MFMA GEMM family (Linear / pointwise conv and their gradients) ---------------------- */
+/* C[M,N] = epi(sum_k A[m,k]*B[n,k]);  layout 0 "NT": A [M][K], B [N][K] (Linear forward, B = weight)
+ *                                     layout 1 "NN": A [M][K], B [K][N] (data gradient, B = weight)
+ *                                     layout 2 "TN": A [K][M], B [K][N] (weight gradient: A = dY, B = x)
+ * precise=1: f32 operands split into hi+lo bf16 planes (3 MFMAs per product, ~1e-5 rel error).
+ * epilogue order: +bias[n] -> act (0 none,1 relu,2 silu) -> gate (v = gate[m,n]>0 ? v*gate_scale : 0)
+ *   -> dropout(drop_p, seed) -> *alpha -> +resid[m,n] -> store (c_dtype) or atomicAdd (accumulate=1, f32).
+ * split_k>1 requires accumulate=1.  force_tile: 0 auto, 64 or 128. */
+int avsr_gemm(int layout, const void* A, int a_dtype, int lda, const void* B, int b_dtype, int ldb,
+              int M, int N, int K, int precise, const float* bias, int act, const void* gate,
+              int gate_dtype, int ldg, float gate_scale, float drop_p, uint64_t seed, float alpha,
+              const float* resid, int ldr, void* C, int c_dtype, int ldc, int accumulate, int split_k,
+              int force_tile, avsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
