@@ -20,6 +20,7 @@ _SCALARS = {
     "uint64_t": ctypes.c_uint64,
     "int64_t": ctypes.c_int64,
     "avsr_stream_t": ctypes.c_void_p,
+    "uint8_t": ctypes.c_uint8,
 }
 
 

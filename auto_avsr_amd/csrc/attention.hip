@@ -1,0 +1,521 @@
+// attention.hip -- fused (flash-style) multi-head attention for gfx950, with the
+// Transformer-XL relative-position term of the Conformer encoder.
+//
+// Replaces the op sequence of
+//   RelPositionMultiHeadedAttention.forward   attention.py:153-193  (+ rel_shift :131-151)
+//   MultiHeadedAttention.forward_attention    attention.py:59-88    (mask -> softmax -> zero -> dropout -> @V)
+//   MultiHeadedAttention.forward              attention.py:90-104   (decoder self / source attention)
+// without ever materialising the (B,H,T,T) score or (B,H,T,2T-1) position tensors in the forward pass:
+//   scores[i,j] = ( (q_i+u).k_j + (q_i+v).p[j-i+T-1] ) / sqrt(d_k)
+// The rel_shift of the reference is the index map  bd[i,j] = G[i, j-i+T-1]  with G = (q+v) p^T; per
+// (64-query, 64-key) tile only a 127-row band of p is needed, G is produced by MFMA into LDS and read
+// back skewed.
+//
+// Work decomposition: grid (ceil(Tq/64), H, B); 256 threads = 4 waves, each wave owns 16 query rows and
+// runs v_mfma_f32_16x16x32_bf16; online softmax with per-row statistics reduced by wave shuffles inside
+// 16-lane groups; K, V^T and the position band are staged in LDS per key tile.  d_k is fixed to 64 (the
+// only head size of the reference model).  NS = 2 runs every contraction on split hi/lo bf16 planes.
+//
+// The backward "dq" kernel recomputes the probabilities from the saved log-sum-exp, produces dQu / dQv
+// and writes the (dropout-applied) probabilities and the scaled score gradients dS to HBM; dK, dV and the
+// position-projection gradient are then batched TN GEMMs over those (gemm_core.h).
+#include "prims.h"
+#include "avsr_hip.h"
+
+namespace {
+
+constexpr int DK = 64;
+constexpr int QT = 64;        // query rows per block
+constexpr int KT = 64;        // keys per tile
+constexpr int PITCH = DK + 8; // bf16 row pitch of k-contiguous LDS tiles (144 B)
+constexpr int PB_ROWS = 144;  // staged position band rows (127 used, zero padded)
+constexpr int G_PITCH = 84;   // f32 pitch of the per-wave G scratch (80 used)
+constexpr int DG_PITCH = 104; // bf16 pitch of the per-wave skewed dS scratch (96 used)
+constexpr float NEG_BIG = -1e30f;
+
+struct AttnParams {
+    const void* qu;   // [B,Tq,H,64] (q + pos_bias_u, or plain q when !RELPOS)
+    const void* qv;   // [B,Tq,H,64] (q + pos_bias_v)
+    const void* k;    // [B,Tk,H,64]
+    const void* v;    // [B,Tk,H,64]
+    const void* pos;  // [2*Tq-1, H*64] projected positional embeddings
+    const uint8_t* mask;  // mask[b*mask_sb + i*mask_sq + j] != 0 means "attend"; null = no mask
+    long mask_sb, mask_sq;
+    void* out;   // [B,Tq,H,64]
+    float* lse;  // [B,H,Tq]
+    int B, H, Tq, Tk;
+    int ldq, ldk, ldv, ldp, ldo;       // row strides (elements)
+    long sbq, sbk, sbv, sbo;           // batch strides (elements)
+    float scale, drop_p;
+    uint64_t seed;
+    // backward only
+    const void* dout;  // [B,Tq,H,64] strides as out
+    void* dqu;         // [B,Tq,H,64] strides as qu
+    void* dqv;
+    void* pd;          // [B,H,Tq,lds] dropout-applied probabilities
+    void* ds;          // [B,H,Tq,lds] scale * dS
+    int lds;           // row pitch of pd/ds (multiple of 8, >= Tk)
+};
+
+AVSR_DEV void wave_sync() {
+#ifdef AVSR_EMU
+    size_t st;
+    char z = 0;
+    (void)emu::wave_gather(&z, 1, &st);
+#else
+    __builtin_amdgcn_wave_barrier();
+#endif
+}
+
+// ---- block-cooperative staging of a [ROWS][64] k-contiguous tile: row r comes from src row (row0+r) if
+// 0 <= row0+r < row_lim, else zeros.  LDS image [NS][ROWS][PITCH].
+template <class T, int NS, int ROWS>
+AVSR_DEV void stage_rows(bf16_t* lds, const T* src, long ld, int row0, int row_lim) {
+    for (int id = threadIdx.x; id < ROWS * 8; id += 256) {
+        const int r = id >> 3, c = (id & 7) * 8;
+        const int gr = row0 + r;
+        float v[8];
+        if (gr >= 0 && gr < row_lim) {
+            load8(src + (long)gr * ld + c, v);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = 0.f;
+        }
+        bf16x8 pl[NS];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            bf16_t s[NS];
+            split_bf16<NS>(v[e], s);
+#pragma unroll
+            for (int p = 0; p < NS; p++) pl[p][e] = (short)s[p];
+        }
+#pragma unroll
+        for (int p = 0; p < NS; p++)
+            *reinterpret_cast<bf16x8*>(lds + (size_t)p * ROWS * PITCH + r * PITCH + c) = pl[p];
+    }
+}
+// ---- transposed staging of a [64 keys][64 d] tile into [NS][64 d][KT+8]: (key pairs packed per dword)
+template <class T, int NS>
+AVSR_DEV void stage_rows_T(bf16_t* lds, const T* src, long ld, int row0, int row_lim) {
+    constexpr int TP = KT + 8;
+    for (int id = threadIdx.x; id < (KT / 2) * 8; id += 256) {
+        const int kp = id & 31, c = (id >> 5) * 8;  // key pair, d chunk
+        float v0[8], v1[8];
+        const int g0 = row0 + 2 * kp, g1 = g0 + 1;
+        if (g0 < row_lim) load8(src + (long)g0 * ld + c, v0);
+        else
+#pragma unroll
+            for (int e = 0; e < 8; e++) v0[e] = 0.f;
+        if (g1 < row_lim) load8(src + (long)g1 * ld + c, v1);
+        else
+#pragma unroll
+            for (int e = 0; e < 8; e++) v1[e] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            bf16_t s0[NS], s1[NS];
+            split_bf16<NS>(v0[e], s0);
+            split_bf16<NS>(v1[e], s1);
+#pragma unroll
+            for (int p = 0; p < NS; p++)
+                *reinterpret_cast<uint32_t*>(lds + (size_t)p * DK * TP + (c + e) * TP + 2 * kp) =
+                    (uint32_t)s0[p] | ((uint32_t)s1[p] << 16);
+        }
+    }
+}
+
+template <int NS>
+AVSR_DEV Frag<NS> ldfrag(const bf16_t* lds, int plane_elems, int pitch, int row, int koff) {
+    Frag<NS> f;
+#pragma unroll
+    for (int p = 0; p < NS; p++)
+        f.p[p] = *reinterpret_cast<const bf16x8*>(lds + (size_t)p * plane_elems + row * pitch + koff);
+    return f;
+}
+// fragment whose 8 k-values are strided by `pitch` (element [k0+e][col])
+template <int NS>
+AVSR_DEV Frag<NS> ldfrag_strided(const bf16_t* lds, int plane_elems, int pitch, int k0, int col) {
+    Frag<NS> f;
+#pragma unroll
+    for (int p = 0; p < NS; p++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) f.p[p][e] = (short)lds[(size_t)p * plane_elems + (k0 + e) * pitch + col];
+    return f;
+}
+// A fragment straight from HBM: 8 consecutive elements of one row
+template <class T, int NS>
+AVSR_DEV Frag<NS> gfrag(const T* p, bool valid) {
+    float v[8];
+    if (valid) load8(p, v);
+    else
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = 0.f;
+    Frag<NS> f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        bf16_t s[NS];
+        split_bf16<NS>(v[e], s);
+#pragma unroll
+        for (int q = 0; q < NS; q++) f.p[q][e] = (short)s[q];
+    }
+    return f;
+}
+
+AVSR_DEV float group16_max(float v) {
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+AVSR_DEV float group16_sum(float v) {
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+template <class T, int NS, bool RELPOS, bool BWD>
+struct Attn {
+    // LDS carve (bf16 elements unless noted)
+    static constexpr int KS_E = NS * KT * PITCH;               // K tile  [key][d]
+    static constexpr int VS_E = NS * KT * PITCH;               // fwd: V^T [d][key]; bwd: V [key][d]
+    static constexpr int PB_E = RELPOS ? NS * PB_ROWS * PITCH : 0;
+    static constexpr int PS_E = 4 * NS * 16 * PITCH;           // per wave P (fwd) / dS (bwd) as A operand
+    static constexpr int DG_E = (RELPOS && BWD) ? 4 * NS * 16 * DG_PITCH : 0;
+    static constexpr int G_F = RELPOS ? 4 * 16 * G_PITCH : 0;  // f32
+    static constexpr size_t LDS_BYTES = (size_t)(KS_E + VS_E + PB_E + PS_E + DG_E) * 2 + (size_t)G_F * 4;
+
+    static AVSR_DEV void run(const AttnParams& p, char* smem) {
+        bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
+        bf16_t* Vs = Ks + KS_E;
+        bf16_t* Pb = Vs + VS_E;
+        bf16_t* Ps = Pb + PB_E;
+        bf16_t* DG = Ps + PS_E;
+        float* Gs = reinterpret_cast<float*>(DG + DG_E);
+
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const int quad = lane >> 4, lc = lane & 15;
+        const int i0 = blockIdx.x * QT, h = blockIdx.y, b = blockIdx.z;
+        const int Tq = p.Tq, Tk = p.Tk;
+        const T* qu = reinterpret_cast<const T*>(p.qu) + b * p.sbq + h * DK;
+        const T* qv = RELPOS ? reinterpret_cast<const T*>(p.qv) + b * p.sbq + h * DK : nullptr;
+        const T* kk = reinterpret_cast<const T*>(p.k) + b * p.sbk + h * DK;
+        const T* vv = reinterpret_cast<const T*>(p.v) + b * p.sbv + h * DK;
+        const T* pos = RELPOS ? reinterpret_cast<const T*>(p.pos) + h * DK : nullptr;
+        const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+
+        // ---- per-wave A fragments (rows i0 + 16w + lc)
+        const int arow = i0 + 16 * w + lc;
+        Frag<NS> fa_u[2], fa_v[2], fa_do[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            fa_u[ks] = gfrag<T, NS>(qu + (long)arow * p.ldq + ks * 32 + 8 * quad, arow < Tq);
+            if (RELPOS) fa_v[ks] = gfrag<T, NS>(qv + (long)arow * p.ldq + ks * 32 + 8 * quad, arow < Tq);
+        }
+        // ---- per-row state; C-layout rows of this lane: rr = 4*quad + r
+        float m_run[4], l_run[4], lse_r[4], delta[4];
+        f32x4 acc0[4], acc1[4];  // fwd: acc0 = O ; bwd: acc0 = dQu, acc1 = dQv  (4 d-tiles of 16)
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            acc0[n] = f32x4{0, 0, 0, 0};
+            acc1[n] = f32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            m_run[r] = NEG_BIG;
+            l_run[r] = 0.f;
+            lse_r[r] = 0.f;
+            delta[r] = 0.f;
+        }
+        if (BWD) {
+            const T* dout = reinterpret_cast<const T*>(p.dout) + b * p.sbo + h * DK;
+            const T* outp = reinterpret_cast<const T*>(p.out) + b * p.sbo + h * DK;
+            float part = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                fa_do[ks] = gfrag<T, NS>(dout + (long)arow * p.ldo + ks * 32 + 8 * quad, arow < Tq);
+                if (arow < Tq) {
+                    float a[8], c[8];
+                    load8(dout + (long)arow * p.ldo + ks * 32 + 8 * quad, a);
+                    load8(outp + (long)arow * p.ldo + ks * 32 + 8 * quad, c);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) part += a[e] * c[e];
+                }
+            }
+            part += __shfl_xor(part, 16);
+            part += __shfl_xor(part, 32);  // every lane with the same lc now holds delta(row lc)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                delta[r] = __shfl(part, 4 * quad + r);
+                const int ig = i0 + 16 * w + 4 * quad + r;
+                lse_r[r] = ig < Tq ? p.lse[((long)b * p.H + h) * Tq + ig] : 0.f;
+            }
+        }
+
+        const int ntiles = (Tk + KT - 1) / KT;
+        for (int kt = 0; kt < ntiles; kt++) {
+            const int j0 = kt * KT;
+            __syncthreads();
+            stage_rows<T, NS, KT>(Ks, kk, p.ldk, j0, Tk);
+            if (BWD) stage_rows<T, NS, KT>(Vs, vv, p.ldv, j0, Tk);
+            else stage_rows_T<T, NS>(Vs, vv, p.ldv, j0, Tk);
+            if (RELPOS) stage_rows<T, NS, PB_ROWS>(Pb, pos, p.ldp, j0 - i0 + Tq - 1 - 63, 2 * Tq - 1);
+            __syncthreads();
+
+            // ---- scores: (q+u).k
+            f32x4 s[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                s[j] = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++)
+                    s[j] = mma16<NS>(fa_u[ks], ldfrag<NS>(Ks, KT * PITCH, PITCH, j * 16 + lc, ks * 32 + 8 * quad), s[j]);
+            }
+            // ---- (q+v).p band, skewed through LDS
+            const int sb = 48 - 16 * w;
+            float* Gw = Gs + w * 16 * G_PITCH;
+            if (RELPOS) {
+#pragma unroll
+                for (int t = 0; t < 5; t++) {
+                    f32x4 g = f32x4{0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++)
+                        g = mma16<NS>(fa_v[ks],
+                                      ldfrag<NS>(Pb, PB_ROWS * PITCH, PITCH, sb + t * 16 + lc, ks * 32 + 8 * quad), g);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) Gw[(4 * quad + r) * G_PITCH + t * 16 + lc] = g[r];
+                }
+                wave_sync();
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int rr = 4 * quad + r;
+                        s[j][r] += Gw[rr * G_PITCH + (j * 16 + lc) - rr + 15];
+                    }
+            }
+            // ---- mask + softmax pieces
+            bool valid[4][4];
+            float pr[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int ig = i0 + 16 * w + 4 * quad + r;
+                const long mrow = p.mask ? (long)b * p.mask_sb + (long)(ig < Tq ? ig : 0) * p.mask_sq : 0;
+                float mx = NEG_BIG;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int jg = j0 + j * 16 + lc;
+                    bool ok = jg < Tk;
+                    if (ok && p.mask) ok = p.mask[mrow + jg] != 0;
+                    valid[j][r] = ok;
+                    s[j][r] = ok ? s[j][r] * p.scale : NEG_BIG;
+                    mx = fmaxf(mx, s[j][r]);
+                }
+                if (!BWD) {
+                    mx = group16_max(mx);
+                    const float m_new = fmaxf(m_run[r], mx);
+                    const float corr = avsr_exp(m_run[r] - m_new);
+                    float rs = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        pr[j][r] = valid[j][r] ? avsr_exp(s[j][r] - m_new) : 0.f;
+                        rs += pr[j][r];
+                    }
+                    rs = group16_sum(rs);
+                    l_run[r] = l_run[r] * corr + rs;
+                    m_run[r] = m_new;
+#pragma unroll
+                    for (int n = 0; n < 4; n++) acc0[n][r] *= corr;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) pr[j][r] = valid[j][r] ? avsr_exp(s[j][r] - lse_r[r]) : 0.f;
+                }
+            }
+            // dropout keep-scale per element (1 when p == 0)
+            float keep[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int ig = i0 + 16 * w + 4 * quad + r;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int jg = j0 + j * 16 + lc;
+                    keep[j][r] = dropout_scale(p.seed, (((uint64_t)b * p.H + h) * Tq + ig) * (uint64_t)Tk + jg,
+                                               p.drop_p, inv_keep);
+                }
+            }
+            bf16_t* Pw = Ps + (size_t)w * 16 * PITCH;  // plane stride = 4*16*PITCH
+            constexpr int PS_PLANE = 4 * 16 * PITCH;
+            if (!BWD) {
+                // ---- P (dropout applied) -> LDS as A operand, then O += P V
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        bf16_t sp[NS];
+                        split_bf16<NS>(pr[j][r] * keep[j][r], sp);
+#pragma unroll
+                        for (int q = 0; q < NS; q++) Pw[(size_t)q * PS_PLANE + (4 * quad + r) * PITCH + j * 16 + lc] = sp[q];
+                    }
+                wave_sync();
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) {
+                    const Frag<NS> fa = ldfrag<NS>(Pw, PS_PLANE, PITCH, lc, ks * 32 + 8 * quad);
+#pragma unroll
+                    for (int n = 0; n < 4; n++)
+                        acc0[n] = mma16<NS>(fa, ldfrag<NS>(Vs, DK * (KT + 8), KT + 8, n * 16 + lc, ks * 32 + 8 * quad), acc0[n]);
+                }
+            } else {
+                // ---- dP = dO V^T ; dS = P * (keep*dP - delta) * scale
+                f32x4 dp[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    dp[j] = f32x4{0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++)
+                        dp[j] = mma16<NS>(fa_do[ks], ldfrag<NS>(Vs, KT * PITCH, PITCH, j * 16 + lc, ks * 32 + 8 * quad), dp[j]);
+                }
+                T* pd_g = reinterpret_cast<T*>(p.pd) + (((long)b * p.H + h) * Tq) * p.lds;
+                T* ds_g = reinterpret_cast<T*>(p.ds) + (((long)b * p.H + h) * Tq) * p.lds;
+                bf16_t* DGw = DG + (size_t)w * 16 * DG_PITCH;
+                constexpr int DG_PLANE = 4 * 16 * DG_PITCH;
+                if (RELPOS) {  // zero the skew scratch (16 x 104 per plane per wave)
+                    for (int q = 0; q < NS; q++)
+                        for (int id = lane; id < 16 * DG_PITCH / 8; id += 64)
+                            *reinterpret_cast<bf16x8*>(DGw + (size_t)q * DG_PLANE + id * 8) = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    wave_sync();
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int rr = 4 * quad + r, jj = j * 16 + lc;
+                        const int ig = i0 + 16 * w + rr, jg = j0 + jj;
+                        const float dsv = pr[j][r] * (keep[j][r] * dp[j][r] - delta[r]) * p.scale;
+                        if (ig < Tq && jg < Tk) {
+                            Elem<T>::st(pd_g + (long)ig * p.lds + jg, pr[j][r] * keep[j][r]);
+                            Elem<T>::st(ds_g + (long)ig * p.lds + jg, dsv);
+                        }
+                        bf16_t sp[NS];
+                        split_bf16<NS>(dsv, sp);
+#pragma unroll
+                        for (int q = 0; q < NS; q++) {
+                            Pw[(size_t)q * PS_PLANE + rr * PITCH + jj] = sp[q];
+                            if (RELPOS) DGw[(size_t)q * DG_PLANE + rr * DG_PITCH + jj - rr + 15] = sp[q];
+                        }
+                    }
+                wave_sync();
+                // dQu += dS K   (contraction over keys: K fragments are key-strided in LDS)
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) {
+                    const Frag<NS> fa = ldfrag<NS>(Pw, PS_PLANE, PITCH, lc, ks * 32 + 8 * quad);
+#pragma unroll
+                    for (int n = 0; n < 4; n++)
+                        acc0[n] = mma16<NS>(fa, ldfrag_strided<NS>(Ks, KT * PITCH, PITCH, ks * 32 + 8 * quad, n * 16 + lc), acc0[n]);
+                }
+                if (RELPOS) {  // dQv += dG Pband
+#pragma unroll
+                    for (int ks = 0; ks < 3; ks++) {
+                        const Frag<NS> fa = ldfrag<NS>(DGw, DG_PLANE, DG_PITCH, lc, ks * 32 + 8 * quad);
+#pragma unroll
+                        for (int n = 0; n < 4; n++)
+                            acc1[n] = mma16<NS>(fa, ldfrag_strided<NS>(Pb, PB_ROWS * PITCH, PITCH, sb + ks * 32 + 8 * quad, n * 16 + lc), acc1[n]);
+                    }
+                }
+            }
+        }
+
+        // ---- epilogue
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int ig = i0 + 16 * w + 4 * quad + r;
+            if (ig >= Tq) continue;
+            if (!BWD) {
+                const float inv = l_run[r] > 0.f ? 1.f / l_run[r] : 0.f;
+                T* o = reinterpret_cast<T*>(p.out) + b * p.sbo + (long)ig * p.ldo + h * DK;
+#pragma unroll
+                for (int n = 0; n < 4; n++) Elem<T>::st(o + n * 16 + lc, acc0[n][r] * inv);
+                if (lc == 0) p.lse[((long)b * p.H + h) * Tq + ig] = l_run[r] > 0.f ? m_run[r] + logf(l_run[r]) : 0.f;
+            } else {
+                T* dqu = reinterpret_cast<T*>(p.dqu) + b * p.sbq + (long)ig * p.ldq + h * DK;
+#pragma unroll
+                for (int n = 0; n < 4; n++) Elem<T>::st(dqu + n * 16 + lc, acc0[n][r]);
+                if (RELPOS) {
+                    T* dqv = reinterpret_cast<T*>(p.dqv) + b * p.sbq + (long)ig * p.ldq + h * DK;
+#pragma unroll
+                    for (int n = 0; n < 4; n++) Elem<T>::st(dqv + n * 16 + lc, acc1[n][r]);
+                }
+            }
+        }
+    }
+};
+
+template <class T, int NS, bool RELPOS, bool BWD>
+__global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
+    AVSR_DYN_SMEM(smem);
+    Attn<T, NS, RELPOS, BWD>::run(p, smem);
+}
+
+template <bool BWD>
+int launch_attn(const AttnParams& p, int dtype, int precise, bool relpos, hipStream_t stream) {
+    dim3 grid((p.Tq + QT - 1) / QT, p.H, p.B), block(256);
+#define AVSR_ATTN_GO(TT, NSV, RP)                                                                        \
+    AVSR_LAUNCH((attn_kernel<TT, NSV, RP, BWD>), grid, block, (Attn<TT, NSV, RP, BWD>::LDS_BYTES), stream, p)
+    if (precise) {
+        if (dtype != 0) return -1;
+        if (relpos) AVSR_ATTN_GO(float, 2, true); else AVSR_ATTN_GO(float, 2, false);
+    } else if (dtype == 1) {
+        if (relpos) AVSR_ATTN_GO(bf16_t, 1, true); else AVSR_ATTN_GO(bf16_t, 1, false);
+    } else {
+        if (relpos) AVSR_ATTN_GO(float, 1, true); else AVSR_ATTN_GO(float, 1, false);
+    }
+#undef AVSR_ATTN_GO
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int avsr_attention_fwd(const void* qu, const void* qv, const void* k, const void* v, const void* pos,
+                                  int dtype, int precise, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq,
+                                  void* out, float* lse, int B, int H, int Tq, int Tk, int dk, int ldq, int ldk,
+                                  int ldv, int ldp, int ldo, int64_t sbq, int64_t sbk, int64_t sbv, int64_t sbo,
+                                  float scale, float drop_p, uint64_t seed, hipStream_t stream) {
+    AVSR_REQUIRE(dk == DK, "attention: d_k must be 64");
+    AVSR_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && (pos == nullptr || ldp % 8 == 0),
+                 "attention: row strides must be multiples of 8");
+    AVSR_REQUIRE(pos == nullptr || Tq == Tk, "attention: relative-position form needs Tq == Tk");
+    if (B == 0 || Tq == 0) return 0;
+    AttnParams p{};
+    p.qu = qu; p.qv = qv; p.k = k; p.v = v; p.pos = pos;
+    p.mask = mask; p.mask_sb = mask_sb; p.mask_sq = mask_sq;
+    p.out = out; p.lse = lse;
+    p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk;
+    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldp = ldp; p.ldo = ldo;
+    p.sbq = sbq; p.sbk = sbk; p.sbv = sbv; p.sbo = sbo;
+    p.scale = scale; p.drop_p = drop_p; p.seed = seed;
+    AVSR_REQUIRE(launch_attn<false>(p, dtype, precise, pos != nullptr, stream) == 0, "attention: bad dtype/precise combination");
+    AVSR_CHECK_LAUNCH("attention_fwd");
+    return 0;
+}
+
+extern "C" int avsr_attention_bwd_dq(const void* qu, const void* qv, const void* k, const void* v, const void* pos,
+                                     int dtype, int precise, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq,
+                                     const void* out, const float* lse, const void* dout, void* dqu, void* dqv,
+                                     void* pd, void* ds, int lds, int B, int H, int Tq, int Tk, int dk, int ldq,
+                                     int ldk, int ldv, int ldp, int ldo, int64_t sbq, int64_t sbk, int64_t sbv,
+                                     int64_t sbo, float scale, float drop_p, uint64_t seed, hipStream_t stream) {
+    AVSR_REQUIRE(dk == DK, "attention: d_k must be 64");
+    AVSR_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && (pos == nullptr || ldp % 8 == 0),
+                 "attention: row strides must be multiples of 8");
+    AVSR_REQUIRE(pos == nullptr || Tq == Tk, "attention: relative-position form needs Tq == Tk");
+    AVSR_REQUIRE(lds >= Tk, "attention: lds must cover Tk");
+    if (B == 0 || Tq == 0) return 0;
+    AttnParams p{};
+    p.qu = qu; p.qv = qv; p.k = k; p.v = v; p.pos = pos;
+    p.mask = mask; p.mask_sb = mask_sb; p.mask_sq = mask_sq;
+    p.out = const_cast<void*>(out); p.lse = const_cast<float*>(lse);
+    p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk;
+    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldp = ldp; p.ldo = ldo;
+    p.sbq = sbq; p.sbk = sbk; p.sbv = sbv; p.sbo = sbo;
+    p.scale = scale; p.drop_p = drop_p; p.seed = seed;
+    p.dout = dout; p.dqu = dqu; p.dqv = dqv; p.pd = pd; p.ds = ds; p.lds = lds;
+    AVSR_REQUIRE(launch_attn<true>(p, dtype, precise, pos != nullptr, stream) == 0, "attention: bad dtype/precise combination");
+    AVSR_CHECK_LAUNCH("attention_bwd_dq");
+    return 0;
+}

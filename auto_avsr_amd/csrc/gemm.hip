@@ -37,11 +37,40 @@ extern "C" int avsr_gemm(int layout, const void* A, int a_dtype, int lda, const 
     p.drop_p = drop_p; p.seed = seed;
     p.alpha = alpha; p.resid = resid; p.ldr = ldr;
     p.C = C; p.c_dtype = c_dtype; p.ldc = ldc; p.accumulate = accumulate;
+    p.nsplit = 1; p.batch_h = 1; p.nbatch = 1;
+    p.sAb = p.sAh = p.sBb = p.sBh = p.sCb = p.sCh = 0;
+    p.a_skew = 0; p.skew_off = 0; p.skew_lim = 0;
     int rc;
     if (layout == 0) rc = avsr_gemm_impl::run_nt(p, a_dtype, b_dtype, precise, force_tile, split_k, stream);
     else if (layout == 1) rc = avsr_gemm_impl::run_nn(p, a_dtype, b_dtype, precise, force_tile, split_k, stream);
     else rc = avsr_gemm_impl::run_tn(p, a_dtype, b_dtype, precise, force_tile, split_k, stream);
     AVSR_REQUIRE(rc == 0, "gemm: unsupported dtype combination");
     AVSR_CHECK_LAUNCH("gemm");
+    return 0;
+}
+
+// Batched TN contraction over (b, h) used by the attention backward:
+//   C[b,h] (MxN) (+)= A[b,h]^T-view (KxM, m contiguous) . B[b,h] (KxN, n contiguous)
+// with two-level element strides per operand.  a_skew != 0 reads A through the inverse rel_shift index map
+// (A[m][k] = src[k*lda + m + k - skew_off]), which turns dS into the gradient of the (q+v) p^T band matrix.
+extern "C" int avsr_gemm_tn_batched(const void* A, int a_dtype, int lda, int64_t sAb, int64_t sAh, const void* B,
+                                    int b_dtype, int ldb, int64_t sBb, int64_t sBh, void* C, int c_dtype, int ldc,
+                                    int64_t sCb, int64_t sCh, int nb, int nh, int M, int N, int K, int precise,
+                                    int accumulate, int a_skew, int skew_off, int skew_lim, hipStream_t stream) {
+    AVSR_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "gemm_tn_batched: lda/ldb must be multiples of 8 elements");
+    AVSR_REQUIRE(!(accumulate && c_dtype != 0), "gemm_tn_batched: accumulate needs an f32 output");
+    if (M <= 0 || N <= 0 || nb <= 0 || nh <= 0) return 0;
+    AVSR_REQUIRE(K > 0, "gemm_tn_batched: K must be positive");
+    avsr_gemm_impl::Params p{};
+    p.A = A; p.B = B; p.lda = lda; p.ldb = ldb;
+    p.M = M; p.N = N; p.K = K; p.k_chunk = K;
+    p.alpha = 1.f; p.gate_scale = 1.f;
+    p.C = C; p.c_dtype = c_dtype; p.ldc = ldc; p.accumulate = accumulate;
+    p.nsplit = 1; p.batch_h = nh; p.nbatch = nb * nh;
+    p.sAb = sAb; p.sAh = sAh; p.sBb = sBb; p.sBh = sBh; p.sCb = sCb; p.sCh = sCh;
+    p.a_skew = a_skew; p.skew_off = skew_off; p.skew_lim = skew_lim;
+    int rc = avsr_gemm_impl::run_tn(p, a_dtype, b_dtype, precise, 64, 1, stream);
+    AVSR_REQUIRE(rc == 0, "gemm_tn_batched: unsupported dtype combination");
+    AVSR_CHECK_LAUNCH("gemm_tn_batched");
     return 0;
 }

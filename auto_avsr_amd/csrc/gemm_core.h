@@ -44,6 +44,13 @@ struct Params {
     void* C;
     int c_dtype, ldc;
     int accumulate;  // f32 C only: atomicAdd (needed for split-K; also "+=" semantics)
+    // batching over (b, h): blockIdx.z = (b*batch_h + h)*nsplit + ksplit; strides in elements
+    int nsplit, batch_h, nbatch;
+    long sAb, sAh, sBb, sBh, sCb, sCh;
+    // skewed A (LA = 1 only): A[m][k] = src[k*lda + m + k - skew_off], valid iff 0 <= m+k-skew_off < skew_lim.
+    // This is the transpose of the reference's rel_shift (attention.py:131-151) applied to dS, so that the
+    // gradient of the projected positions is an ordinary TN contraction.
+    int a_skew, skew_off, skew_lim;
 };
 
 template <class T> struct Raw8;
@@ -83,6 +90,21 @@ AVSR_DEV Raw8<T> load_chunk(const T* base, int ld, int r, int c, int r_lim, int 
     return out;
 }
 
+// skewed variant: element e of the chunk is src[r*ld + c + e + r - off] when m = c+e < m_lim and the shifted
+// column lies in [0, lim)
+template <class T>
+AVSR_DEV Raw8<T> load_chunk_skew(const T* base, int ld, int r, int c, int r_lim, int m_lim, int off, int lim) {
+    Raw8<T> out;
+    out.zero();
+    if (r < r_lim) {
+        for (int e = 0; e < 8; e++) {
+            const int j = c + e + r - off;
+            if (c + e < m_lim && j >= 0 && j < lim) out.set(e, base + (size_t)r * ld + j);
+        }
+    }
+    return out;
+}
+
 template <class TA, class TB, int NS, int LA, int LB, int BM, int BN, int BK>
 struct Kernel {
     static constexpr int PITCH = BK + 8;  // bf16 elements per LDS row
@@ -100,7 +122,7 @@ struct Kernel {
     // ---- HBM -> registers
     template <class T, int L, int ROWS, int ITEMS, int NRAW>
     static AVSR_DEV void fetch(Raw8<T> (&raw)[NRAW], const T* base, int ld, int row0, int row_lim, int k0,
-                        int k_lim) {
+                        int k_lim, int skew = 0, int skew_off = 0, int skew_lim = 0) {
         const int tid = threadIdx.x;
         if (L == 0) {
             constexpr int CH = BK / 8;
@@ -117,8 +139,13 @@ struct Kernel {
                 const int id = tid + NT * i;
                 const int kp = id % KP, mc = (id / KP) * 8;
                 // matrix is [K][rows]: "row" index of the load is k, column is the m/n index
-                raw[2 * i] = load_chunk<T>(base, ld, k0 + 2 * kp, row0 + mc, k_lim, row_lim);
-                raw[2 * i + 1] = load_chunk<T>(base, ld, k0 + 2 * kp + 1, row0 + mc, k_lim, row_lim);
+                if (skew) {
+                    raw[2 * i] = load_chunk_skew<T>(base, ld, k0 + 2 * kp, row0 + mc, k_lim, row_lim, skew_off, skew_lim);
+                    raw[2 * i + 1] = load_chunk_skew<T>(base, ld, k0 + 2 * kp + 1, row0 + mc, k_lim, row_lim, skew_off, skew_lim);
+                } else {
+                    raw[2 * i] = load_chunk<T>(base, ld, k0 + 2 * kp, row0 + mc, k_lim, row_lim);
+                    raw[2 * i + 1] = load_chunk<T>(base, ld, k0 + 2 * kp + 1, row0 + mc, k_lim, row_lim);
+                }
             }
         }
     }
@@ -169,12 +196,15 @@ struct Kernel {
     static AVSR_DEV void run(const Params& p, char* smem) {
         bf16_t* As = reinterpret_cast<bf16_t*>(smem);
         bf16_t* Bs = As + (size_t)NS * BM * PITCH;
-        const TA* A = reinterpret_cast<const TA*>(p.A);
-        const TB* B = reinterpret_cast<const TB*>(p.B);
+        const int zb = blockIdx.z / p.nsplit, zs = blockIdx.z % p.nsplit;
+        const int zbb = zb / p.batch_h, zbh = zb % p.batch_h;
+        const TA* A = reinterpret_cast<const TA*>(p.A) + zbb * p.sAb + zbh * p.sAh;
+        const TB* B = reinterpret_cast<const TB*>(p.B) + zbb * p.sBb + zbh * p.sBh;
+        const long c_off = zbb * p.sCb + zbh * p.sCh;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int wm = wave >> 1, wn = wave & 1;
         const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-        const int kbeg = blockIdx.z * p.k_chunk;
+        const int kbeg = zs * p.k_chunk;
         const int kend = min(p.K, kbeg + p.k_chunk);
 
         f32x16 acc[TM][TN];
@@ -187,7 +217,7 @@ struct Kernel {
 
         Raw8<TA> ra[A_RAW];
         Raw8<TB> rb[B_RAW];
-        fetch<TA, LA, BM, A_ITEMS, A_RAW>(ra, A, p.lda, m0, p.M, kbeg, kend);
+        fetch<TA, LA, BM, A_ITEMS, A_RAW>(ra, A, p.lda, m0, p.M, kbeg, kend, p.a_skew, p.skew_off, p.skew_lim);
         fetch<TB, LB, BN, B_ITEMS, B_RAW>(rb, B, p.ldb, n0, p.N, kbeg, kend);
         stash<TA, LA, BM, A_ITEMS, A_RAW>(ra, As);
         stash<TB, LB, BN, B_ITEMS, B_RAW>(rb, Bs);
@@ -196,7 +226,7 @@ struct Kernel {
         for (int k0 = kbeg; k0 < kend; k0 += BK) {
             const bool more = (k0 + BK) < kend;
             if (more) {
-                fetch<TA, LA, BM, A_ITEMS, A_RAW>(ra, A, p.lda, m0, p.M, k0 + BK, kend);
+                fetch<TA, LA, BM, A_ITEMS, A_RAW>(ra, A, p.lda, m0, p.M, k0 + BK, kend, p.a_skew, p.skew_off, p.skew_lim);
                 fetch<TB, LB, BN, B_ITEMS, B_RAW>(rb, B, p.ldb, n0, p.N, k0 + BK, kend);
             }
 #pragma unroll
@@ -236,7 +266,7 @@ struct Kernel {
             for (int j = 0; j < TN; j++) {
                 const int col = n0 + wn * WN + j * 32 + (lane & 31);
                 if (col >= p.N) continue;
-                const float bias = (p.bias && blockIdx.z == 0) ? p.bias[col] : 0.f;
+                const float bias = (p.bias && zs == 0) ? p.bias[col] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -253,12 +283,12 @@ struct Kernel {
                     if (p.drop_p > 0.f)
                         v *= dropout_scale(p.seed, (uint64_t)row * (uint64_t)p.N + col, p.drop_p, inv_keep);
                     v *= p.alpha;
-                    if (p.resid && blockIdx.z == 0) v += p.resid[(size_t)row * p.ldr + col];
+                    if (p.resid && zs == 0) v += p.resid[(size_t)row * p.ldr + col];
                     if (p.c_dtype == 0) {
-                        float* c = reinterpret_cast<float*>(p.C) + (size_t)row * p.ldc + col;
+                        float* c = reinterpret_cast<float*>(p.C) + c_off + (size_t)row * p.ldc + col;
                         if (p.accumulate) atomicAdd(c, v); else *c = v;
                     } else {
-                        reinterpret_cast<bf16_t*>(p.C)[(size_t)row * p.ldc + col] = f2bf(v);
+                        reinterpret_cast<bf16_t*>(p.C)[c_off + (size_t)row * p.ldc + col] = f2bf(v);
                     }
                 }
             }
@@ -284,7 +314,10 @@ int launch(const Params& p0, int force_tile, int split_k, hipStream_t stream) {
     kc = ((kc + BK - 1) / BK) * BK;
     split_k = (p.K + kc - 1) / kc;
     p.k_chunk = kc;
-    dim3 grid((p.N + BMN - 1) / BMN, (p.M + BMN - 1) / BMN, split_k), block(256);
+    p.nsplit = split_k;
+    if (p.batch_h < 1) p.batch_h = 1;
+    const int nbatch = p.nbatch < 1 ? 1 : p.nbatch;
+    dim3 grid((p.N + BMN - 1) / BMN, (p.M + BMN - 1) / BMN, split_k * nbatch), block(256);
     if (big) {
         using K = Kernel<TA, TB, NS, LA, LB, 128, 128, BK>;
         AVSR_LAUNCH((gemm_kernel<TA, TB, NS, LA, LB, 128, 128, BK>), grid, block, K::LDS_BYTES, stream, p);

@@ -63,3 +63,75 @@ def gemm(layout, A, lda, B, ldb, M, N, K, C, ldc, *, precise=False, bias=None, a
          _ptr(gate), dt(gate) if gate is not None else 0, ldg, gate_scale, drop_p, seed, alpha, _ptr(resid), ldr,
          _ptr(C), dt(C), ldc, int(accumulate), split_k, force_tile, _stream(A))
     return C
+
+
+def attention_fwd(qu, qv, k, v, pos, mask, scale, *, precise=False, drop_p=0.0, seed=0):
+    """qu/qv/k/v: [B,T,H,64] (possibly strided views with contiguous last two dims); pos: [2T-1, H*64] or None;
+    mask: uint8/bool [B,1,Tk] or [B,Tq,Tk] or None.  Returns (out [B,Tq,H*64], lse [B,H,Tq])."""
+    B, Tq, H, dk = qu.shape
+    Tk = k.shape[1]
+    out = torch.empty(B, Tq, H * dk, dtype=qu.dtype, device=qu.device)
+    lse = torch.empty(B, H, Tq, dtype=torch.float32, device=qu.device)
+    msb = msq = 0
+    if mask is not None:
+        assert mask.dtype in (torch.uint8, torch.bool) and mask.is_contiguous() and mask.dim() == 3
+        msb = mask.shape[1] * mask.shape[2]
+        msq = mask.shape[2] if mask.shape[1] > 1 else 0
+    call("avsr_attention_fwd", _ptr(qu), _ptr(qv), _ptr(k), _ptr(v), _ptr(pos), dt(qu), int(precise), _ptr(mask),
+         msb, msq, _ptr(out), _ptr(lse), B, H, Tq, Tk, dk, qu.stride(1), k.stride(1), v.stride(1),
+         pos.stride(0) if pos is not None else 0, out.stride(1), qu.stride(0), k.stride(0), v.stride(0),
+         out.stride(0), scale, drop_p, seed, _stream(qu))
+    return out, lse
+
+
+def attention_bwd_dq(qu, qv, k, v, pos, mask, out, lse, dout, scale, *, precise=False, drop_p=0.0, seed=0):
+    B, Tq, H, dk = qu.shape
+    Tk = k.shape[1]
+    lds = (Tk + 7) // 8 * 8
+    dqu = torch.empty(B, Tq, H, dk, dtype=qu.dtype, device=qu.device)
+    dqv = torch.empty_like(dqu) if pos is not None else None
+    pd = torch.zeros(B, H, Tq, lds, dtype=qu.dtype, device=qu.device)
+    ds = torch.zeros(B, H, Tq, lds, dtype=qu.dtype, device=qu.device)
+    msb = msq = 0
+    if mask is not None:
+        msb = mask.shape[1] * mask.shape[2]
+        msq = mask.shape[2] if mask.shape[1] > 1 else 0
+    # dqu/dqv are laid out like a contiguous [B,Tq,H,64]; the kernel uses qu's strides for them, so require equality
+    assert qu.stride(1) == H * dk and qu.stride(0) == Tq * H * dk, "bwd expects contiguous qu/qv"
+    call("avsr_attention_bwd_dq", _ptr(qu), _ptr(qv), _ptr(k), _ptr(v), _ptr(pos), dt(qu), int(precise), _ptr(mask),
+         msb, msq, _ptr(out), _ptr(lse), _ptr(dout), _ptr(dqu), _ptr(dqv), _ptr(pd), _ptr(ds), lds, B, H, Tq, Tk, dk,
+         qu.stride(1), k.stride(1), v.stride(1), pos.stride(0) if pos is not None else 0, out.stride(1),
+         qu.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, drop_p, seed, _stream(qu))
+    return dqu, dqv, pd, ds
+
+
+def gemm_tn_batched(A, lda, sAb, sAh, Bm, ldb, sBb, sBh, C, ldc, sCb, sCh, nb, nh, M, N, K, *, precise=False,
+                    accumulate=False, a_skew=False, skew_off=0, skew_lim=0):
+    call("avsr_gemm_tn_batched", _ptr(A), dt(A), lda, sAb, sAh, _ptr(Bm), dt(Bm), ldb, sBb, sBh, _ptr(C), dt(C), ldc,
+         sCb, sCh, nb, nh, M, N, K, int(precise), int(accumulate), int(a_skew), skew_off, skew_lim, _stream(A))
+    return C
+
+
+def attention_bwd(qu, qv, k, v, pos, mask, out, lse, dout, scale, *, precise=False, drop_p=0.0, seed=0):
+    """Full attention backward.  Returns dqu, dqv (or None), dk, dv, dpos (f32 [2T-1, H*64] or None)."""
+    B, Tq, H, dk = qu.shape
+    Tk = k.shape[1]
+    D = H * dk
+    dqu, dqv, pd, ds = attention_bwd_dq(qu, qv, k, v, pos, mask, out, lse, dout, scale, precise=precise,
+                                        drop_p=drop_p, seed=seed)
+    lds = pd.shape[-1]
+    dkk = torch.empty(B, Tk, H, dk, dtype=qu.dtype, device=qu.device)
+    dvv = torch.empty(B, Tk, H, dk, dtype=qu.dtype, device=qu.device)
+    do4 = dout.view(B, Tq, H, dk)
+    # dV[b,h] = Pd[b,h]^T dO[b,h] ; dK[b,h] = dS[b,h]^T Qu[b,h]
+    gemm_tn_batched(pd, lds, H * Tq * lds, Tq * lds, do4, do4.stride(1), do4.stride(0), dk, dvv, D, Tk * D, dk,
+                    B, H, Tk, dk, Tq, precise=precise)
+    gemm_tn_batched(ds, lds, H * Tq * lds, Tq * lds, qu, qu.stride(1), qu.stride(0), dk, dkk, D, Tk * D, dk,
+                    B, H, Tk, dk, Tq, precise=precise)
+    dpos = None
+    if pos is not None:
+        dpos = torch.zeros(2 * Tq - 1, D, dtype=torch.float32, device=qu.device)
+        gemm_tn_batched(ds, lds, H * Tq * lds, Tq * lds, qv, qv.stride(1), qv.stride(0), dk, dpos, D, 0, dk,
+                        B, H, 2 * Tq - 1, dk, Tq, precise=precise, accumulate=True, a_skew=True,
+                        skew_off=Tq - 1, skew_lim=Tk)
+    return dqu, dqv, dkk, dvv, dpos

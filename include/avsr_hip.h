@@ -54,6 +54,34 @@ int avsr_gemm(int layout, const void* A, int a_dtype, int lda, const void* B, in
               const float* resid, int ldr, void* C, int c_dtype, int ldc, int accumulate, int split_k,
               int force_tile, avsr_stream_t stream);
 
+/* ---- fused multi-head attention (attention.py:59-104,131-193) ----------------------------- */
+/* out[b,i,h,:] = softmax_j( scale*(qu_i.k_j + [pos!=NULL] qv_i.pos[j-i+Tq-1]) , mask ) @ v ; d_k = 64.
+ * qu/qv/k/v/out are [B,T,H,64] views: element (b,t,h,d) at b*sb + t*ld + h*64 + d.  pos: [2Tq-1, H*64]
+ * (ldp).  mask[b*mask_sb + i*mask_sq + j] != 0 -> attend (NULL: none); fully masked rows give zeros
+ * (attention.py:71-77).  drop_p: dropout on the probabilities (attention.py:79).  lse: [B,H,Tq]. */
+int avsr_attention_fwd(const void* qu, const void* qv, const void* k, const void* v, const void* pos,
+                       int dtype, int precise, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq,
+                       void* out, float* lse, int B, int H, int Tq, int Tk, int dk, int ldq, int ldk,
+                       int ldv, int ldp, int ldo, int64_t sbq, int64_t sbk, int64_t sbv, int64_t sbo,
+                       float scale, float drop_p, uint64_t seed, avsr_stream_t stream);
+/* backward, query side: recomputes P from lse; writes dqu (and dqv), plus pd = dropout(P) and
+ * ds = scale*dS as [B,H,Tq,lds] tensors from which dK, dV and dpos follow as batched TN GEMMs. */
+int avsr_attention_bwd_dq(const void* qu, const void* qv, const void* k, const void* v, const void* pos,
+                          int dtype, int precise, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq,
+                          const void* out, const float* lse, const void* dout, void* dqu, void* dqv,
+                          void* pd, void* ds, int lds, int B, int H, int Tq, int Tk, int dk, int ldq,
+                          int ldk, int ldv, int ldp, int ldo, int64_t sbq, int64_t sbk, int64_t sbv,
+                          int64_t sbo, float scale, float drop_p, uint64_t seed, avsr_stream_t stream);
+
+/* batched TN contraction over (b,h) for the attention backward (dV = Pd^T dO, dK = dS^T Qu, dpos = skew(dS)^T Qv):
+ * C[b,h][M,N] (+)= sum_k A[b,h][k,m] * B[b,h][k,n]; operand (b,h) slices start at b*s?b + h*s?h elements.
+ * a_skew: A[m][k] = src[k*lda + m + k - skew_off], valid iff that column lies in [0, skew_lim)  (inverse of
+ * rel_shift, attention.py:131-151). */
+int avsr_gemm_tn_batched(const void* A, int a_dtype, int lda, int64_t sAb, int64_t sAh, const void* B,
+                         int b_dtype, int ldb, int64_t sBb, int64_t sBh, void* C, int c_dtype, int ldc,
+                         int64_t sCb, int64_t sCh, int nb, int nh, int M, int N, int K, int precise,
+                         int accumulate, int a_skew, int skew_off, int skew_lim, avsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
