@@ -1,0 +1,298 @@
+// batchnorm.hip -- training-mode BatchNorm over the rows of a channels-last [rows, C] tensor, fused with
+// the activation (SiLU) and an optional residual add, forward and backward.
+//
+// Replaces BatchNorm1d of the ConvolutionModule (conformer_encoder.py:26,33 + SiLU :28) and
+// BatchNorm2d/3d of the visual front-end (resnet.py:34,61,77,212).  Statistics are taken over every row
+// including padded frames (the reference does not mask them).
+//
+// Structure = what the cross-rank synchronisation of `sync_batchnorm=True` (train.py:31) needs:
+//   bn_stats      per-column partial sums of (x - shift), (x - shift)^2 with shift = x[0, c]   (local)
+//   [all-gather of the 3C+1 floats across ranks -- done by the caller through RCCL]
+//   bn_finalize   Chan merge of the per-rank partials -> mean, invstd, running-stat update
+//   bn_act_fwd    y = act(gamma * (x-mean)*invstd + beta (+ add))
+//   bn_bwd_reduce per-column sums of dz and dz*xhat                                            (local)
+//   [all-reduce of the 2C floats]
+//   bn_bwd_apply  dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)), dadd = dz
+#include "prims.h"
+#include "avsr_hip.h"
+
+namespace {
+
+constexpr int BN_THREADS = 256;
+
+AVSR_DEV float act_fwd(float z, int act) { return act == 1 ? avsr_silu(z) : z; }
+AVSR_DEV float act_grad(float z, int act) {
+    if (act != 1) return 1.f;
+    const float s = avsr_sigmoid(z);
+    return s * (1.f + z * (1.f - s));
+}
+
+// Column reduction skeleton: thread = (column chunk of 8, row lane); MODE 0: stats, MODE 1: backward sums
+template <class T, int MODE>
+__global__ __launch_bounds__(BN_THREADS) void bn_colreduce_kernel(
+    const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ add, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ out /* MODE0: [3][C] shift,s1,s2 ; MODE1: [2][C] sum dz, sum dz*xhat */, long rows, int C,
+    int CL, int rows_per_block, int act) {
+    __shared__ float red[BN_THREADS * 16];
+    const int cv = C >> 3;
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL, RL = BN_THREADS / CL;
+    const int cc = blockIdx.x * CL + cl;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float a[8], b[8], sh[8], mu[8], is[8], ga[8], be[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) a[e] = b[e] = sh[e] = mu[e] = is[e] = ga[e] = be[e] = 0.f;
+    if (cc < cv) {
+        if (MODE == 0) load8(x + cc * 8, sh);
+        else {
+            load8(mean + cc * 8, mu);
+            load8(invstd + cc * 8, is);
+            load8(gamma + cc * 8, ga);
+            load8(beta + cc * 8, be);
+        }
+        for (long r = r0 + rl; r < r1; r += RL) {
+            float v[8];
+            load8(x + r * C + cc * 8, v);
+            if (MODE == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const float d = v[e] - sh[e];
+                    a[e] += d;
+                    b[e] += d * d;
+                }
+            } else {
+                float g[8], ad[8];
+                load8(dy + r * C + cc * 8, g);
+                if (add) load8(add + r * C + cc * 8, ad);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const float xh = (v[e] - mu[e]) * is[e];
+                    const float z = xh * ga[e] + be[e] + (add ? ad[e] : 0.f);
+                    const float dz = g[e] * act_grad(z, act);
+                    a[e] += dz;
+                    b[e] += dz * xh;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        red[threadIdx.x * 16 + e] = a[e];
+        red[threadIdx.x * 16 + 8 + e] = b[e];
+    }
+    __syncthreads();
+    if (rl == 0 && cc < cv) {
+        for (int q = 1; q < RL; q++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                a[e] += red[(q * CL + cl) * 16 + e];
+                b[e] += red[(q * CL + cl) * 16 + 8 + e];
+            }
+        const int base = MODE == 0 ? 1 : 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            atomicAdd(out + (long)(base + 0) * C + cc * 8 + e, a[e]);
+            atomicAdd(out + (long)(base + 1) * C + cc * 8 + e, b[e]);
+        }
+        if (MODE == 0 && blockIdx.y == 0)
+#pragma unroll
+            for (int e = 0; e < 8; e++) out[cc * 8 + e] = sh[e];
+    }
+}
+
+// stats: [W][3][C] (shift, s1, s2), counts [W]; one thread per channel
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ counts, int W, int C,
+                                   float eps, float momentum, float* __restrict__ mean_out,
+                                   float* __restrict__ invstd_out, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double n_tot = 0.0, mean = 0.0;
+    for (int w = 0; w < W; w++) {
+        const double n = counts[w];
+        if (n <= 0.0) continue;
+        const double mw = (double)stats[((long)w * 3 + 0) * C + c] + (double)stats[((long)w * 3 + 1) * C + c] / n;
+        mean += n * mw;
+        n_tot += n;
+    }
+    mean /= n_tot;
+    double m2 = 0.0;
+    for (int w = 0; w < W; w++) {
+        const double n = counts[w];
+        if (n <= 0.0) continue;
+        const double s1 = stats[((long)w * 3 + 1) * C + c], s2 = stats[((long)w * 3 + 2) * C + c];
+        const double mw = (double)stats[((long)w * 3 + 0) * C + c] + s1 / n;
+        m2 += (s2 - s1 * s1 / n) + n * (mw - mean) * (mw - mean);
+    }
+    const double var = m2 / n_tot;
+    mean_out[c] = (float)mean;
+    invstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = n_tot > 1.0 ? m2 / (n_tot - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+}
+
+__global__ void bn_eval_params_kernel(const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                      float eps, int C, float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    mean_out[c] = running_mean[c];
+    invstd_out[c] = 1.0f / sqrtf(running_var[c] + eps);
+}
+
+template <class T>
+__global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(const T* __restrict__ x, const T* __restrict__ add,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, T* __restrict__ y,
+                                                                long rows, int C, int act) {
+    const int cv = C >> 3;
+    const long nvec = rows * cv;
+    for (long i = (long)blockIdx.x * BN_THREADS + threadIdx.x; i < nvec; i += (long)gridDim.x * BN_THREADS) {
+        const int c = (int)(i % cv) * 8;
+        float v[8], mu[8], is[8], ga[8], be[8], ad[8], o[8];
+        load8(x + i * 8, v);
+        load8(mean + c, mu);
+        load8(invstd + c, is);
+        load8(gamma + c, ga);
+        load8(beta + c, be);
+        if (add) load8(add + i * 8, ad);
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = act_fwd((v[e] - mu[e]) * is[e] * ga[e] + be[e] + (add ? ad[e] : 0.f), act);
+        store8(y + i * 8, o);
+    }
+}
+
+// sums: [2][C] all-reduced (sum dz, sum dz*xhat); n = global row count
+template <class T>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
+    const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ add, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ sums, float inv_n, T* __restrict__ dx, T* __restrict__ dadd, long rows, int C, int act) {
+    const int cv = C >> 3;
+    const long nvec = rows * cv;
+    for (long i = (long)blockIdx.x * BN_THREADS + threadIdx.x; i < nvec; i += (long)gridDim.x * BN_THREADS) {
+        const int c = (int)(i % cv) * 8;
+        float v[8], g[8], mu[8], is[8], ga[8], be[8], ad[8], s1[8], s2[8], o[8], oz[8];
+        load8(x + i * 8, v);
+        load8(dy + i * 8, g);
+        load8(mean + c, mu);
+        load8(invstd + c, is);
+        load8(gamma + c, ga);
+        load8(beta + c, be);
+        load8(sums + c, s1);
+        load8(sums + C + c, s2);
+        if (add) load8(add + i * 8, ad);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float xh = (v[e] - mu[e]) * is[e];
+            const float z = xh * ga[e] + be[e] + (add ? ad[e] : 0.f);
+            const float dz = g[e] * act_grad(z, act);
+            oz[e] = dz;
+            o[e] = ga[e] * is[e] * (dz - s1[e] * inv_n - xh * s2[e] * inv_n);
+        }
+        store8(dx + i * 8, o);
+        if (dadd) store8(dadd + i * 8, oz);
+    }
+}
+
+static inline int pick_cl(int cv) { return cv >= 32 ? 32 : (cv >= 16 ? 16 : 8); }
+static inline int ew_grid(long nvec) {
+    long b = (nvec + BN_THREADS - 1) / BN_THREADS;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace
+
+// stats: [3][C] f32, must be zeroed by the caller (rows 1,2 are accumulated with atomics)
+extern "C" int avsr_bn_stats(const void* x, int dtype, float* stats, int64_t rows, int C, hipStream_t stream) {
+    AVSR_REQUIRE(C % 8 == 0, "batchnorm: C must be a multiple of 8");
+    if (rows <= 0) return 0;
+    const int cv = C >> 3, CL = pick_cl(cv);
+    const int rpb = 128 * (BN_THREADS / CL) / 8;
+    dim3 grid((cv + CL - 1) / CL, (unsigned)((rows + rpb - 1) / rpb)), block(BN_THREADS);
+    if (dtype == 0)
+        AVSR_LAUNCH((bn_colreduce_kernel<float, 0>), grid, block, 0, stream, (const float*)x, (const float*)nullptr,
+                    (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                    (const float*)nullptr, stats, (long)rows, C, CL, rpb, 0);
+    else
+        AVSR_LAUNCH((bn_colreduce_kernel<bf16_t, 0>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)nullptr,
+                    (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                    (const float*)nullptr, stats, (long)rows, C, CL, rpb, 0);
+    AVSR_CHECK_LAUNCH("bn_stats");
+    return 0;
+}
+
+extern "C" int avsr_bn_finalize(const float* stats, const float* counts, int world, int C, float eps, float momentum,
+                                float* mean, float* invstd, float* running_mean, float* running_var,
+                                hipStream_t stream) {
+    dim3 grid((C + 127) / 128), block(128);
+    AVSR_LAUNCH(bn_finalize_kernel, grid, block, 0, stream, stats, counts, world, C, eps, momentum, mean, invstd,
+                running_mean, running_var);
+    AVSR_CHECK_LAUNCH("bn_finalize");
+    return 0;
+}
+
+extern "C" int avsr_bn_eval_params(const float* running_mean, const float* running_var, float eps, int C, float* mean,
+                                   float* invstd, hipStream_t stream) {
+    dim3 grid((C + 127) / 128), block(128);
+    AVSR_LAUNCH(bn_eval_params_kernel, grid, block, 0, stream, running_mean, running_var, eps, C, mean, invstd);
+    AVSR_CHECK_LAUNCH("bn_eval_params");
+    return 0;
+}
+
+extern "C" int avsr_bn_act_fwd(const void* x, const void* add, int dtype, const float* mean, const float* invstd,
+                               const float* gamma, const float* beta, void* y, int64_t rows, int C, int act,
+                               hipStream_t stream) {
+    AVSR_REQUIRE(C % 8 == 0, "batchnorm: C must be a multiple of 8");
+    if (rows <= 0) return 0;
+    dim3 grid(ew_grid(rows * (C >> 3))), block(BN_THREADS);
+    if (dtype == 0)
+        AVSR_LAUNCH((bn_act_fwd_kernel<float>), grid, block, 0, stream, (const float*)x, (const float*)add, mean, invstd,
+                    gamma, beta, (float*)y, (long)rows, C, act);
+    else
+        AVSR_LAUNCH((bn_act_fwd_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)add, mean,
+                    invstd, gamma, beta, (bf16_t*)y, (long)rows, C, act);
+    AVSR_CHECK_LAUNCH("bn_act_fwd");
+    return 0;
+}
+
+// sums: [2][C] f32 zeroed by the caller
+extern "C" int avsr_bn_bwd_reduce(const void* x, const void* dy, const void* add, int dtype, const float* mean,
+                                  const float* invstd, const float* gamma, const float* beta, float* sums,
+                                  int64_t rows, int C, int act, hipStream_t stream) {
+    AVSR_REQUIRE(C % 8 == 0, "batchnorm: C must be a multiple of 8");
+    if (rows <= 0) return 0;
+    const int cv = C >> 3, CL = pick_cl(cv);
+    const int rpb = 128 * (BN_THREADS / CL) / 8;
+    dim3 grid((cv + CL - 1) / CL, (unsigned)((rows + rpb - 1) / rpb)), block(BN_THREADS);
+    if (dtype == 0)
+        AVSR_LAUNCH((bn_colreduce_kernel<float, 1>), grid, block, 0, stream, (const float*)x, (const float*)dy,
+                    (const float*)add, mean, invstd, gamma, beta, sums, (long)rows, C, CL, rpb, act);
+    else
+        AVSR_LAUNCH((bn_colreduce_kernel<bf16_t, 1>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dy,
+                    (const bf16_t*)add, mean, invstd, gamma, beta, sums, (long)rows, C, CL, rpb, act);
+    AVSR_CHECK_LAUNCH("bn_bwd_reduce");
+    return 0;
+}
+
+extern "C" int avsr_bn_bwd_apply(const void* x, const void* dy, const void* add, int dtype, const float* mean,
+                                 const float* invstd, const float* gamma, const float* beta, const float* sums,
+                                 float inv_n, void* dx, void* dadd, int64_t rows, int C, int act,
+                                 hipStream_t stream) {
+    AVSR_REQUIRE(C % 8 == 0, "batchnorm: C must be a multiple of 8");
+    if (rows <= 0) return 0;
+    dim3 grid(ew_grid(rows * (C >> 3))), block(BN_THREADS);
+    if (dtype == 0)
+        AVSR_LAUNCH((bn_bwd_apply_kernel<float>), grid, block, 0, stream, (const float*)x, (const float*)dy,
+                    (const float*)add, mean, invstd, gamma, beta, sums, inv_n, (float*)dx, (float*)dadd, (long)rows, C, act);
+    else
+        AVSR_LAUNCH((bn_bwd_apply_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dy,
+                    (const bf16_t*)add, mean, invstd, gamma, beta, sums, inv_n, (bf16_t*)dx, (bf16_t*)dadd, (long)rows, C, act);
+    AVSR_CHECK_LAUNCH("bn_bwd_apply");
+    return 0;
+}

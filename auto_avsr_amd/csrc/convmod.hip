@@ -1,0 +1,119 @@
+// convmod.hip -- depthwise 1-D convolution of the Conformer ConvolutionModule on (B,T,C) activations.
+//
+// Replaces  torch.nn.Conv1d(C, C, K, padding=(K-1)//2, groups=C)  of conformer_encoder.py:25,33 and its
+// gradients.  The reference transposes to (B,C,T) first (conformer_encoder.py:31,35); here the channel
+// dimension stays innermost so that lanes read consecutive channels (coalesced) and the K-tap window over
+// time is staged once in LDS and re-used by every output of the tile.  HBM-bound: 2 B/element in, 2 out.
+#include "prims.h"
+#include "avsr_hip.h"
+
+namespace {
+
+constexpr int DW_CH = 64;     // channels per block (one per lane)
+constexpr int DW_TT = 32;     // outputs per block along time (forward / data gradient)
+constexpr int DW_TW = 64;     // time steps per block (weight gradient)
+constexpr int DW_MAXK = 31;
+
+template <class T>
+AVSR_DEV void stage_time_tile(float* xs, const T* x, int b, int t_first, int nrows, int Tlen, int C, int c0) {
+    for (int id = threadIdx.x; id < nrows * (DW_CH / 8); id += 256) {
+        const int r = id / (DW_CH / 8), cc = (id % (DW_CH / 8)) * 8;
+        const int t = t_first + r;
+        float v[8];
+        if (t >= 0 && t < Tlen && c0 + cc < C) load8(x + ((long)b * Tlen + t) * C + c0 + cc, v);
+        else
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) xs[r * DW_CH + cc + e] = v[e];
+    }
+}
+
+// y[b,t,c] = bias[c] + sum_k w[c,k] x[b,t+k-pad,c]      (flip=1: taps reversed -> data gradient)
+template <class T>
+__global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, T* __restrict__ y, int Tlen,
+                                                     int C, int K, int flip) {
+    __shared__ float xs[(DW_TT + DW_MAXK - 1) * DW_CH];
+    __shared__ float ws[DW_MAXK * DW_CH];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * DW_CH, t0 = blockIdx.y * DW_TT, b = blockIdx.z;
+    const int pad = (K - 1) / 2;
+    stage_time_tile<T>(xs, x, b, t0 - pad, DW_TT + K - 1, Tlen, C, c0);
+    for (int k = ty; k < K; k += 4) ws[k * DW_CH + tx] = (c0 + tx < C) ? w[(long)(c0 + tx) * K + (flip ? K - 1 - k : k)] : 0.f;
+    __syncthreads();
+    const float bv = (bias && c0 + tx < C) ? bias[c0 + tx] : 0.f;
+#pragma unroll
+    for (int o = 0; o < DW_TT / 4; o++) {
+        const int t = ty * (DW_TT / 4) + o;
+        float acc = bv;
+        for (int k = 0; k < K; k++) acc += ws[k * DW_CH + tx] * xs[(t + k) * DW_CH + tx];
+        if (t0 + t < Tlen && c0 + tx < C) Elem<T>::st(y + ((long)b * Tlen + t0 + t) * C + c0 + tx, acc);
+    }
+}
+
+// dw[c,k] += sum_{b,t} dy[b,t,c] x[b,t+k-pad,c] ;  db[c] += sum dy
+template <class T>
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                           float* __restrict__ dw, float* __restrict__ db, int Tlen,
+                                                           int C, int K) {
+    __shared__ float xs[(DW_TW + DW_MAXK - 1) * DW_CH];
+    __shared__ float ds[DW_TW * DW_CH];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * DW_CH, t0 = blockIdx.y * DW_TW, b = blockIdx.z;
+    const int pad = (K - 1) / 2;
+    stage_time_tile<T>(xs, x, b, t0 - pad, DW_TW + K - 1, Tlen, C, c0);
+    stage_time_tile<T>(ds, dy, b, t0, DW_TW, Tlen, C, c0);
+    __syncthreads();
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[i] = 0.f;
+    float sb = 0.f;
+    for (int t = 0; t < DW_TW; t++) {
+        const float g = ds[t * DW_CH + tx];
+        sb += g;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int k = ty + 4 * i;
+            if (k < K) acc[i] += g * xs[(t + k) * DW_CH + tx];
+        }
+    }
+    if (c0 + tx < C) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int k = ty + 4 * i;
+            if (k < K) atomicAdd(dw + (long)(c0 + tx) * K + k, acc[i]);
+        }
+        if (ty == 0 && db) atomicAdd(db + c0 + tx, sb);
+    }
+}
+
+}  // namespace
+
+extern "C" int avsr_dwconv_fwd(const void* x, int dtype, const float* w, const float* bias, void* y, int B, int T,
+                               int C, int K, int flip, hipStream_t stream) {
+    AVSR_REQUIRE(K >= 1 && K <= DW_MAXK && (K & 1), "dwconv: K must be odd and <= 31");
+    AVSR_REQUIRE(C % 8 == 0, "dwconv: C must be a multiple of 8");
+    if (B <= 0 || T <= 0) return 0;
+    dim3 grid((C + DW_CH - 1) / DW_CH, (T + DW_TT - 1) / DW_TT, B), block(256);
+    if (dtype == 0)
+        AVSR_LAUNCH((dwconv_kernel<float>), grid, block, 0, stream, (const float*)x, w, bias, (float*)y, T, C, K, flip);
+    else
+        AVSR_LAUNCH((dwconv_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, w, bias, (bf16_t*)y, T, C, K, flip);
+    AVSR_CHECK_LAUNCH("dwconv_fwd");
+    return 0;
+}
+
+extern "C" int avsr_dwconv_wgrad(const void* x, const void* dy, int dtype, float* dw, float* db, int B, int T, int C,
+                                 int K, hipStream_t stream) {
+    AVSR_REQUIRE(K >= 1 && K <= DW_MAXK && (K & 1), "dwconv: K must be odd and <= 31");
+    AVSR_REQUIRE(C % 8 == 0, "dwconv: C must be a multiple of 8");
+    if (B <= 0 || T <= 0) return 0;
+    dim3 grid((C + DW_CH - 1) / DW_CH, (T + DW_TW - 1) / DW_TW, B), block(256);
+    if (dtype == 0)
+        AVSR_LAUNCH((dwconv_wgrad_kernel<float>), grid, block, 0, stream, (const float*)x, (const float*)dy, dw, db, T, C, K);
+    else
+        AVSR_LAUNCH((dwconv_wgrad_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dy, dw, db, T, C, K);
+    AVSR_CHECK_LAUNCH("dwconv_wgrad");
+    return 0;
+}

@@ -135,3 +135,93 @@ def attention_bwd(qu, qv, k, v, pos, mask, out, lse, dout, scale, *, precise=Fal
                         B, H, 2 * Tq - 1, dk, Tq, precise=precise, accumulate=True, a_skew=True,
                         skew_off=Tq - 1, skew_lim=Tk)
     return dqu, dqv, dkk, dvv, dpos
+
+
+def scale_dropout(x, out_dtype, alpha=1.0, drop_p=0.0, seed=0):
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    call("avsr_scale_dropout", _ptr(x), dt(x), _ptr(out), dt(out), x.numel(), alpha, drop_p, seed, _stream(x))
+    return out
+
+
+def head_bias_fwd(x, ldx, rows, cols, b1, b2):
+    o1 = torch.empty(rows, cols, dtype=x.dtype, device=x.device)
+    o2 = torch.empty(rows, cols, dtype=x.dtype, device=x.device)
+    call("avsr_head_bias_fwd", _ptr(x), dt(x), ldx, _ptr(b1), _ptr(b2), _ptr(o1), _ptr(o2), rows, cols, _stream(x))
+    return o1, o2
+
+
+def head_bias_bwd(d1, d2, dq, ldo, db1, db2, rows, cols):
+    call("avsr_head_bias_bwd", _ptr(d1), _ptr(d2), dt(d1), _ptr(dq), ldo, _ptr(db1), _ptr(db2), rows, cols,
+         _stream(d1))
+
+
+def colsum_into(d, db, rows, cols):
+    """db[c] += sum_r d[r, c]  (bias gradient)."""
+    head_bias_bwd(d, None, None, 0, db, None, rows, cols)
+
+
+def glu_fwd(a, rows, C):
+    g = torch.empty(rows, C, dtype=a.dtype, device=a.device)
+    call("avsr_glu_fwd", _ptr(a), _ptr(g), dt(a), rows, C, _stream(a))
+    return g
+
+
+def glu_bwd(a, dg, rows, C):
+    da = torch.empty(rows, 2 * C, dtype=a.dtype, device=a.device)
+    call("avsr_glu_bwd", _ptr(a), _ptr(dg), _ptr(da), dt(a), rows, C, _stream(a))
+    return da
+
+
+def dwconv(x, w, bias, B, T, C, K, flip=False):
+    y = torch.empty(B, T, C, dtype=x.dtype, device=x.device)
+    call("avsr_dwconv_fwd", _ptr(x), dt(x), _ptr(w), _ptr(bias), _ptr(y), B, T, C, K, int(flip), _stream(x))
+    return y
+
+
+def dwconv_wgrad(x, dy, dw, db, B, T, C, K):
+    call("avsr_dwconv_wgrad", _ptr(x), _ptr(dy), dt(x), _ptr(dw), _ptr(db), B, T, C, K, _stream(x))
+
+
+def bn_stats(x, rows, C):
+    stats = torch.zeros(3, C, dtype=torch.float32, device=x.device)
+    call("avsr_bn_stats", _ptr(x), dt(x), _ptr(stats), rows, C, _stream(x))
+    return stats
+
+
+def bn_finalize(stats, counts, world, C, eps, momentum, running_mean, running_var):
+    mean = torch.empty(C, dtype=torch.float32, device=stats.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=stats.device)
+    call("avsr_bn_finalize", _ptr(stats), _ptr(counts), world, C, eps, momentum, _ptr(mean), _ptr(invstd),
+         _ptr(running_mean), _ptr(running_var), _stream(stats))
+    return mean, invstd
+
+
+def bn_eval_params(running_mean, running_var, eps):
+    C = running_mean.numel()
+    mean = torch.empty_like(running_mean)
+    invstd = torch.empty_like(running_mean)
+    call("avsr_bn_eval_params", _ptr(running_mean), _ptr(running_var), eps, C, _ptr(mean), _ptr(invstd),
+         _stream(running_mean))
+    return mean, invstd
+
+
+def bn_act_fwd(x, add, mean, invstd, gamma, beta, rows, C, act):
+    y = torch.empty_like(x)
+    call("avsr_bn_act_fwd", _ptr(x), _ptr(add), dt(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y),
+         rows, C, act, _stream(x))
+    return y
+
+
+def bn_bwd_reduce(x, dy, add, mean, invstd, gamma, beta, rows, C, act):
+    sums = torch.zeros(2, C, dtype=torch.float32, device=x.device)
+    call("avsr_bn_bwd_reduce", _ptr(x), _ptr(dy), _ptr(add), dt(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
+         _ptr(sums), rows, C, act, _stream(x))
+    return sums
+
+
+def bn_bwd_apply(x, dy, add, mean, invstd, gamma, beta, sums, inv_n, rows, C, act, want_dadd):
+    dx = torch.empty_like(x)
+    dadd = torch.empty_like(x) if want_dadd else None
+    call("avsr_bn_bwd_apply", _ptr(x), _ptr(dy), _ptr(add), dt(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
+         _ptr(sums), inv_n, _ptr(dx), _ptr(dadd), rows, C, act, _stream(x))
+    return dx, dadd

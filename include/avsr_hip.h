@@ -82,6 +82,52 @@ int avsr_gemm_tn_batched(const void* A, int a_dtype, int lda, int64_t sAb, int64
                          int64_t sCb, int64_t sCh, int nb, int nh, int M, int N, int K, int precise,
                          int accumulate, int a_skew, int skew_off, int skew_lim, avsr_stream_t stream);
 
+/* ---- elementwise glue (elementwise.hip) --------------------------------------------------- */
+/* out = alpha * dropout(x)   (embedding.py:179-184; dropout branches of conformer_encoder.py:114-157, ctc.py:54) */
+int avsr_scale_dropout(const void* x, int x_dtype, void* out, int out_dtype, int64_t n, float alpha,
+                       float drop_p, uint64_t seed, avsr_stream_t stream);
+/* o1 = x + b1[col], o2 = x + b2[col]  (q + pos_bias_u / q + pos_bias_v, attention.py:176-178); o1,o2 dense */
+int avsr_head_bias_fwd(const void* x, int dtype, int64_t ldx, const float* b1, const float* b2, void* o1,
+                       void* o2, int64_t rows, int cols, avsr_stream_t stream);
+/* dq = d1 + d2 (row stride ldo; d2/dq may be NULL); db1 += colsum(d1); db2 += colsum(d2) (NULL skips) */
+int avsr_head_bias_bwd(const void* d1, const void* d2, int dtype, void* dq, int64_t ldo, float* db1,
+                       float* db2, int64_t rows, int cols, avsr_stream_t stream);
+/* GLU over channel halves of a [rows, 2C] tensor (conformer_encoder.py:32) */
+int avsr_glu_fwd(const void* a, void* g, int dtype, int64_t rows, int C, avsr_stream_t stream);
+int avsr_glu_bwd(const void* a, const void* dg, void* da, int dtype, int64_t rows, int C,
+                 avsr_stream_t stream);
+
+/* ---- depthwise conv over time on (B,T,C) (conformer_encoder.py:25,33) ------------------------ */
+/* y[b,t,c] = bias[c] + sum_k w[c,k] x[b,t+k-(K-1)/2,c]; flip=1 reverses taps (= data gradient, bias NULL) */
+int avsr_dwconv_fwd(const void* x, int dtype, const float* w, const float* bias, void* y, int B, int T,
+                    int C, int K, int flip, avsr_stream_t stream);
+/* dw[c,k] += sum dy[b,t,c] x[b,t+k-pad,c]; db[c] += sum dy */
+int avsr_dwconv_wgrad(const void* x, const void* dy, int dtype, float* dw, float* db, int B, int T, int C,
+                      int K, avsr_stream_t stream);
+
+/* ---- training-mode BatchNorm (+SiLU, + residual add) on channels-last [rows, C] ------------------- */
+/* stats [3][C] (shift, sum(x-shift), sum((x-shift)^2)); caller zeroes it */
+int avsr_bn_stats(const void* x, int dtype, float* stats, int64_t rows, int C, avsr_stream_t stream);
+/* merge `world` per-rank partials [world][3][C] + counts[world] -> mean, invstd; momentum update of the
+ * running stats (unbiased variance) when running_mean != NULL */
+int avsr_bn_finalize(const float* stats, const float* counts, int world, int C, float eps, float momentum,
+                     float* mean, float* invstd, float* running_mean, float* running_var,
+                     avsr_stream_t stream);
+int avsr_bn_eval_params(const float* running_mean, const float* running_var, float eps, int C, float* mean,
+                        float* invstd, avsr_stream_t stream);
+/* y = act(gamma*(x-mean)*invstd + beta (+ add)); act 0 none, 1 SiLU */
+int avsr_bn_act_fwd(const void* x, const void* add, int dtype, const float* mean, const float* invstd,
+                    const float* gamma, const float* beta, void* y, int64_t rows, int C, int act,
+                    avsr_stream_t stream);
+/* sums [2][C] += (sum dz, sum dz*xhat), dz = dy*act'(z) */
+int avsr_bn_bwd_reduce(const void* x, const void* dy, const void* add, int dtype, const float* mean,
+                       const float* invstd, const float* gamma, const float* beta, float* sums, int64_t rows,
+                       int C, int act, avsr_stream_t stream);
+/* dx = gamma*invstd*(dz - sums0*inv_n - xhat*sums1*inv_n); dadd = dz (NULL skips) */
+int avsr_bn_bwd_apply(const void* x, const void* dy, const void* add, int dtype, const float* mean,
+                      const float* invstd, const float* gamma, const float* beta, const float* sums,
+                      float inv_n, void* dx, void* dadd, int64_t rows, int C, int act, avsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,116 @@
+"""Elementwise / depthwise-conv / BatchNorm kernels vs torch fp32/fp64 math (conformer_encoder.py:24-35)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from auto_avsr_amd import ops
+
+
+def test_scale_dropout(dev):
+    torch.manual_seed(0)
+    x = torch.randn(1003)
+    y = ops.scale_dropout(x.to(dev), torch.float32, alpha=2.5).cpu()
+    assert (y - 2.5 * x).abs().max() < 1e-6
+    x = torch.randn(64, 256)
+    y = ops.scale_dropout(x.to(dev), torch.float32, alpha=1.0, drop_p=0.25, seed=77).cpu()
+    kept = y != 0
+    assert 0.70 < kept.float().mean() < 0.80
+    assert (y[kept] - x[kept] / 0.75).abs().max() < 1e-5
+    y2 = ops.scale_dropout(x.to(dev).bfloat16(), torch.bfloat16, alpha=1.0, drop_p=0.25, seed=77).cpu()
+    assert ((y2 != 0) == kept).all(), "same (seed, index) must give the same mask for any dtype"
+
+
+def test_head_bias_and_glu(dev):
+    torch.manual_seed(1)
+    rows, cols = 50, 128
+    x3 = torch.randn(rows, 3 * cols)  # q lives inside a wider (fused qkv) row
+    b1, b2 = torch.randn(cols), torch.randn(cols)
+    o1, o2 = ops.head_bias_fwd(x3.to(dev), 3 * cols, rows, cols, b1.to(dev), b2.to(dev))
+    assert (o1.cpu() - (x3[:, :cols] + b1)).abs().max() < 1e-6
+    assert (o2.cpu() - (x3[:, :cols] + b2)).abs().max() < 1e-6
+    d1, d2 = torch.randn(rows, cols), torch.randn(rows, cols)
+    dq = torch.zeros(rows, 3 * cols, device=dev)
+    db1, db2 = torch.zeros(cols, device=dev), torch.zeros(cols, device=dev)
+    ops.head_bias_bwd(d1.to(dev), d2.to(dev), dq, 3 * cols, db1, db2, rows, cols)
+    assert (dq.cpu()[:, :cols] - (d1 + d2)).abs().max() < 1e-6 and dq.cpu()[:, cols:].abs().max() == 0
+    assert (db1.cpu() - d1.sum(0)).abs().max() < 1e-4 and (db2.cpu() - d2.sum(0)).abs().max() < 1e-4
+    a = torch.randn(rows, 2 * cols, requires_grad=True)
+    g_ref = F.glu(a, dim=1)
+    dg = torch.randn(rows, cols)
+    g_ref.backward(dg)
+    g = ops.glu_fwd(a.detach().to(dev), rows, cols)
+    da = ops.glu_bwd(a.detach().to(dev), dg.to(dev), rows, cols)
+    assert (g.cpu() - g_ref).abs().max() < 1e-5 and (da.cpu() - a.grad).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("K", [31, 7])
+def test_dwconv(dev, K):
+    torch.manual_seed(2)
+    B, T, C = 2, 75, 136
+    x = torch.randn(B, T, C, requires_grad=True)
+    w = torch.randn(C, 1, K, requires_grad=True)
+    bias = torch.randn(C, requires_grad=True)
+    y_ref = F.conv1d(x.transpose(1, 2), w, bias, padding=(K - 1) // 2, groups=C).transpose(1, 2)
+    dy = torch.randn(B, T, C)
+    y_ref.backward(dy)
+    wd = w.detach().reshape(C, K).contiguous().to(dev)
+    y = ops.dwconv(x.detach().to(dev), wd, bias.detach().to(dev), B, T, C, K)
+    assert (y.cpu() - y_ref).abs().max() < 1e-4
+    dx = ops.dwconv(dy.to(dev), wd, None, B, T, C, K, flip=True)
+    assert (dx.cpu() - x.grad).abs().max() < 1e-4
+    dw, db = torch.zeros(C, K, device=dev), torch.zeros(C, device=dev)
+    ops.dwconv_wgrad(x.detach().to(dev), dy.to(dev), dw, db, B, T, C, K)
+    assert (dw.cpu() - w.grad.reshape(C, K)).abs().max() < 1e-3
+    assert (db.cpu() - bias.grad).abs().max() < 1e-3
+
+
+@pytest.mark.parametrize("C,with_add,act", [(128, False, 1), (64, True, 1), (256, False, 0)])
+def test_batchnorm_train(dev, C, with_add, act):
+    torch.manual_seed(3)
+    rows = 777
+    x = (torch.randn(rows, C) * 2 + 3).requires_grad_()
+    add = torch.randn(rows, C, requires_grad=True) if with_add else None
+    bn = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bn.weight.normal_(1, 0.3)
+        bn.bias.normal_(0, 0.3)
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.5, 2)
+    rm, rv = bn.running_mean.clone(), bn.running_var.clone()
+    bn.train()
+    z = bn(x)
+    if with_add:
+        z = z + add
+    y_ref = F.silu(z) if act == 1 else z
+    dy = torch.randn(rows, C)
+    y_ref.backward(dy)
+    xd = x.detach().to(dev)
+    addd = add.detach().to(dev) if with_add else None
+    stats = ops.bn_stats(xd, rows, C)
+    counts = torch.tensor([float(rows)], device=dev)
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    mean, invstd = ops.bn_finalize(stats.unsqueeze(0), counts, 1, C, bn.eps, bn.momentum, rmd, rvd)
+    assert (rmd.cpu() - bn.running_mean).abs().max() < 1e-4 and (rvd.cpu() - bn.running_var).abs().max() < 1e-3
+    g, b = bn.weight.detach().to(dev), bn.bias.detach().to(dev)
+    y = ops.bn_act_fwd(xd, addd, mean, invstd, g, b, rows, C, act)
+    assert (y.cpu() - y_ref).abs().max() < 1e-4
+    sums = ops.bn_bwd_reduce(xd, dy.to(dev), addd, mean, invstd, g, b, rows, C, act)
+    dx, dadd = ops.bn_bwd_apply(xd, dy.to(dev), addd, mean, invstd, g, b, sums, 1.0 / rows, rows, C, act, with_add)
+    assert (dx.cpu() - x.grad).abs().max() < 1e-4
+    assert (sums.cpu()[1] - bn.weight.grad).abs().max() < 2e-3 and (sums.cpu()[0] - bn.bias.grad).abs().max() < 2e-3
+    if with_add:
+        assert (dadd.cpu() - add.grad).abs().max() < 1e-4
+
+
+def test_batchnorm_two_rank_merge(dev):
+    """bn_finalize merges per-rank partial statistics exactly like one big batch (SyncBatchNorm semantics)."""
+    torch.manual_seed(4)
+    C = 64
+    xa, xb = torch.randn(300, C) + 1.0, torch.randn(500, C) * 3 - 2.0
+    sa, sb = ops.bn_stats(xa.to(dev), 300, C), ops.bn_stats(xb.to(dev), 500, C)
+    stats = torch.stack([sa, sb])
+    counts = torch.tensor([300.0, 500.0], device=dev)
+    mean, invstd = ops.bn_finalize(stats, counts, 2, C, 1e-5, 0.1, None, None)
+    allx = torch.cat([xa, xb]).double()
+    assert (mean.cpu() - allx.mean(0)).abs().max() < 1e-5
+    assert (invstd.cpu() - 1 / torch.sqrt(allx.var(0, unbiased=False) + 1e-5)).abs().max() < 1e-5
