@@ -34,7 +34,7 @@ def parse_header(path=HEADER):
         ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
         if ret.startswith("typedef"):
             continue
-        restype = ctypes.c_char_p if "char" in ret else ctypes.c_int
+        restype = ctypes.c_char_p if "char" in ret else (ctypes.c_int64 if "int64_t" in ret else ctypes.c_int)
         argtypes, argnames = [], []
         if args and args != "void":
             for a in args.split(","):
@@ -75,6 +75,8 @@ class _Lib:
 
     def call(self, name, *args):
         rc = getattr(self.cdll, name)(*args)
+        if self.protos[name][0] is not ctypes.c_int:
+            return rc
         if rc != 0:
             raise AvsrLibraryError(f"{name} failed ({rc}): {self.cdll.avsr_last_error().decode()}")
 

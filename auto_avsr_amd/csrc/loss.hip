@@ -1,0 +1,449 @@
+// loss.hip -- the joint CTC / attention loss heads and the decoder input embedding.
+//
+//   CTC          ctc.py:32-38,54-63: log_softmax over V -> torch.nn.CTCLoss(blank=0, reduction="sum",
+//                zero_infinity=True) -> / B.  Here: row log-sum-exp (wave per row), gather of the 2L+1
+//                extended-label log-probs, alpha and beta recursions (one 64-lane wave per utterance and
+//                direction, states in registers, neighbours by wave shuffle -- no barriers in the T loop),
+//                then the dense gradient  softmax - occupancy  written once.
+//   label-smoothing CE + token accuracy
+//                label_smoothing_loss.py:41-63 (KLDiv against conf/eps-smoothed one-hot, sum / B) and
+//                nets_utils.py:272-292 (argmax accuracy); one block per target row, one pass for the
+//                statistics and one for the gradient; the smoothed target is never materialised.
+//   embedding    transformer_decoder.py:186-189 + embedding.py:78-87: table[id]*sqrt(d) + pe[pos], dropout.
+//
+// Gradients of the heads are produced in the forward pass, unscaled; the upstream scalar is applied by the
+// consuming GEMMs through their device-side alpha (avsr_gemm alpha_dev).
+#include "prims.h"
+#include "avsr_hip.h"
+
+namespace {
+
+constexpr float LOG_ZERO = -1e30f;
+constexpr int CTC_MAXSPL = 8;  // states per lane -> S <= 512, L <= 255
+
+AVSR_DEV float log_add(float a, float b) {
+    const float m = fmaxf(a, b);
+    if (m <= LOG_ZERO) return LOG_ZERO;
+    return m + logf(avsr_exp(a - m) + avsr_exp(b - m));
+}
+
+// ---- row-wise log-sum-exp over the first V columns: one wave per row
+template <class T>
+__global__ __launch_bounds__(256) void row_lse_kernel(const T* __restrict__ x, long ld, float* __restrict__ lse,
+                                                      long rows, int V) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* xr = x + row * ld;
+    float m = LOG_ZERO, s = 0.f;
+    const int nvec = V >> 3;
+    for (int c = lane; c < nvec; c += 64) {
+        float v[8];
+        load8(xr + c * 8, v);
+        float mx = v[0];
+#pragma unroll
+        for (int e = 1; e < 8; e++) mx = fmaxf(mx, v[e]);
+        const float mn = fmaxf(m, mx);
+        float acc = s * avsr_exp(m - mn);
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc += avsr_exp(v[e] - mn);
+        s = acc;
+        m = mn;
+    }
+    for (int c = nvec * 8 + lane; c < V; c += 64) {
+        const float v = Elem<T>::ld(xr + c);
+        const float mn = fmaxf(m, v);
+        s = s * avsr_exp(m - mn) + avsr_exp(v - mn);
+        m = mn;
+    }
+    const float gm = wave_max(m);
+    s = wave_sum(s * avsr_exp(m - gm));
+    if (lane == 0) lse[row] = gm + logf(s);
+}
+
+// ---- per utterance: strip ignore_id from the padded label row, build the blank-interleaved sequence
+__global__ void ctc_prepare_kernel(const int64_t* __restrict__ labels, int Lmax, int ignore_id, int* __restrict__ ext,
+                                   int Smax, int* __restrict__ lens /* [B]: L_b */) {
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    int L = 0;
+    int* e = ext + (long)b * Smax;
+    e[0] = 0;
+    for (int i = 0; i < Lmax; i++) {
+        const int64_t y = labels[(long)b * Lmax + i];
+        if (y == ignore_id) continue;
+        e[2 * L + 1] = (int)y;
+        e[2 * L + 2] = 0;
+        L++;
+    }
+    lens[b] = L;
+}
+
+// ---- lpg[b,t,s] = logit[b,t,ext[b,s]] - lse[b,t]
+template <class T>
+__global__ __launch_bounds__(256) void ctc_gather_kernel(const T* __restrict__ logits, long ld,
+                                                         const float* __restrict__ lse, const int* __restrict__ ext,
+                                                         const int* __restrict__ lens, float* __restrict__ lpg, int Tlen,
+                                                         int Smax) {
+    const long bt = blockIdx.x;
+    const int b = (int)(bt / Tlen);
+    const int S = 2 * lens[b] + 1;
+    const float l = lse[bt];
+    for (int s = threadIdx.x; s < S; s += 256)
+        lpg[bt * Smax + s] = Elem<T>::ld(logits + bt * ld + ext[(long)b * Smax + s]) - l;
+}
+
+// ---- alpha (blockIdx.y == 0) / beta (== 1) recursions: one wave per utterance, lane owns SPL contiguous states
+__global__ __launch_bounds__(64) void ctc_alphabeta_kernel(const float* __restrict__ lpg, const int* __restrict__ ext,
+                                                           const int* __restrict__ lens,
+                                                           const int64_t* __restrict__ in_lens, float* __restrict__ alpha,
+                                                           float* __restrict__ beta, float* __restrict__ nll, int Tlen,
+                                                           int Smax) {
+    const int b = blockIdx.x, dir = blockIdx.y, lane = threadIdx.x;
+    const int L = lens[b], S = 2 * L + 1;
+    int Tb = (int)in_lens[b];
+    if (Tb > Tlen) Tb = Tlen;
+    const int* e = ext + (long)b * Smax;
+    const float* lp = lpg + (long)b * Tlen * Smax;
+    float* out = (dir == 0 ? alpha : beta) + (long)b * Tlen * Smax;
+    const int spl = (S + 63) / 64;  // states per lane (<= CTC_MAXSPL)
+    const int s0 = lane * spl;
+    // can state s take the skip transition from s-2 (alpha) / to s+2 (beta)?
+    bool skip[CTC_MAXSPL];
+    float cur[CTC_MAXSPL];
+#pragma unroll
+    for (int i = 0; i < CTC_MAXSPL; i++) {
+        const int s = s0 + i;
+        skip[i] = false;
+        cur[i] = LOG_ZERO;
+        if (i < spl && s < S) {
+            if (dir == 0) skip[i] = (s >= 2) && (e[s] != 0) && (e[s] != e[s - 2]);
+            else skip[i] = (s + 2 < S) && (e[s] != 0) && (e[s] != e[s + 2]);
+        }
+    }
+    if (Tb <= 0) {
+        if (dir == 0 && lane == 0) nll[b] = (L == 0) ? 0.f : INFINITY;
+        return;
+    }
+    // t = first step
+    const int tfirst = dir == 0 ? 0 : Tb - 1;
+#pragma unroll
+    for (int i = 0; i < CTC_MAXSPL; i++) {
+        const int s = s0 + i;
+        if (i < spl && s < S) {
+            const bool start = dir == 0 ? (s < 2) : (s >= S - 2);
+            cur[i] = start ? lp[(long)tfirst * Smax + s] : LOG_ZERO;
+            out[(long)tfirst * Smax + s] = cur[i];
+        }
+    }
+    for (int step = 1; step < Tb; step++) {
+        const int t = dir == 0 ? step : Tb - 1 - step;
+        // values owned by the neighbouring lanes: n1 = state one step away, n2 = two steps away
+        float edge1 = LOG_ZERO, edge2 = LOG_ZERO;  // what this lane exports
+        if (dir == 0) {
+#pragma unroll
+            for (int i = 0; i < CTC_MAXSPL; i++) {
+                if (i == spl - 1) edge1 = cur[i];
+                if (i == spl - 2) edge2 = cur[i];
+            }
+        } else {
+            edge1 = cur[0];
+            edge2 = cur[1];
+        }
+        float n1, n2;
+        if (dir == 0) {
+            n1 = __shfl_up(edge1, 1);
+            n2 = spl >= 2 ? __shfl_up(edge2, 1) : __shfl_up(edge1, 2);
+            if (lane < 1) n1 = LOG_ZERO;
+            if (lane < (spl >= 2 ? 1 : 2)) n2 = LOG_ZERO;
+        } else {
+            n1 = __shfl_down(edge1, 1);
+            n2 = spl >= 2 ? __shfl_down(edge2, 1) : __shfl_down(edge1, 2);
+            if (lane > 62) n1 = LOG_ZERO;
+            if (lane > (spl >= 2 ? 62 : 61)) n2 = LOG_ZERO;
+        }
+        float nxt[CTC_MAXSPL];
+#pragma unroll
+        for (int i = 0; i < CTC_MAXSPL; i++) {
+            nxt[i] = LOG_ZERO;
+            const int s = s0 + i;
+            if (i < spl && s < S) {
+                float a1, a2;
+                if (dir == 0) {
+                    a1 = i >= 1 ? cur[i >= 1 ? i - 1 : 0] : n1;
+                    a2 = i >= 2 ? cur[i >= 2 ? i - 2 : 0] : (i == 1 ? n1 : n2);
+                } else {
+                    const float c1 = (i + 1 < CTC_MAXSPL) ? cur[(i + 1 < CTC_MAXSPL) ? i + 1 : 0] : LOG_ZERO;
+                    const float c2 = (i + 2 < CTC_MAXSPL) ? cur[(i + 2 < CTC_MAXSPL) ? i + 2 : 0] : LOG_ZERO;
+                    a1 = (i + 1 < spl) ? c1 : n1;
+                    a2 = (i + 2 < spl) ? c2 : ((i + 1 < spl) ? n1 : n2);
+                }
+                float v = log_add(cur[i], a1);
+                if (skip[i]) v = log_add(v, a2);
+                nxt[i] = v + lp[(long)t * Smax + s];
+                if (nxt[i] < LOG_ZERO) nxt[i] = LOG_ZERO;
+                out[(long)t * Smax + s] = nxt[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CTC_MAXSPL; i++) cur[i] = nxt[i];
+    }
+    if (dir == 0) {
+        // log P = logaddexp(alpha_{Tb-1}(S-1), alpha_{Tb-1}(S-2)); gather from the owning lanes
+        float mine = LOG_ZERO;
+#pragma unroll
+        for (int i = 0; i < CTC_MAXSPL; i++) {
+            const int s = s0 + i;
+            if (i < spl && s < S && (s == S - 1 || s == S - 2)) mine = log_add(mine, cur[i]);
+        }
+        // combine across lanes (at most two lanes hold a contribution)
+        float tot = mine;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) tot = log_add(tot, __shfl_xor(tot, m));
+        if (lane == 0) nll[b] = tot <= LOG_ZERO * 0.5f ? INFINITY : -tot;
+    }
+}
+
+// ---- dense gradient: g[b,t,v] = softmax[b,t,v] - occupancy[b,t,v]   (zero for t >= T_b or infeasible targets)
+template <class T>
+__global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ logits, long ld,
+                                                       const float* __restrict__ lse, const float* __restrict__ lpg,
+                                                       const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                       const float* __restrict__ nll, const int* __restrict__ ext,
+                                                       const int* __restrict__ lens, const int64_t* __restrict__ in_lens,
+                                                       T* __restrict__ grad, long ldg, int Tlen, int V, int Smax) {
+    AVSR_DYN_SMEM(smem);
+    float* occ = reinterpret_cast<float*>(smem);  // [V]
+    const long bt = blockIdx.x;
+    const int b = (int)(bt / Tlen), t = (int)(bt % Tlen);
+    T* g = grad + bt * ldg;
+    const float nl = nll[b];
+    const bool live = t < (int)in_lens[b] && nl < INFINITY;  // zero_infinity=True
+    if (!live) {
+        for (int v = threadIdx.x; v < V; v += 256) Elem<T>::st(g + v, 0.f);
+        return;
+    }
+    for (int v = threadIdx.x; v < V; v += 256) occ[v] = 0.f;
+    __syncthreads();
+    const int S = 2 * lens[b] + 1;
+    for (int s = threadIdx.x; s < S; s += 256) {
+        const long o = bt * Smax + s;
+        const float lo = alpha[o] + beta[o] - lpg[o] + nl;  // log occupancy of state s at time t
+        if (lo > -80.f) atomicAdd(&occ[ext[(long)b * Smax + s]], avsr_exp(lo));
+    }
+    __syncthreads();
+    const float l = lse[bt];
+    const T* x = logits + bt * ld;
+    for (int v = threadIdx.x; v < V; v += 256) Elem<T>::st(g + v, avsr_exp(Elem<T>::ld(x + v) - l) - occ[v]);
+}
+
+// ---- label-smoothing CE: one block per row
+template <class T>
+__global__ __launch_bounds__(256) void ce_smooth_kernel(const T* __restrict__ logits, long ld,
+                                                        const int64_t* __restrict__ target, int ignore_id, int V,
+                                                        float smoothing, float* __restrict__ row_loss,
+                                                        float* __restrict__ row_hit, T* __restrict__ grad, long ldg) {
+    __shared__ float red[4][4];
+    __shared__ int redi[4];
+    const long r = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const T* x = logits + r * ld;
+    const int64_t y = target[r];
+    float m = LOG_ZERO, s = 0.f, sum = 0.f;
+    int am = 0;
+    for (int v = threadIdx.x; v < V; v += 256) {
+        const float z = Elem<T>::ld(x + v);
+        sum += z;
+        if (z > m) {  // strict: keeps the first maximum within this thread's (ascending) stride
+            s = s * avsr_exp(m - z) + 1.f;
+            m = z;
+            am = v;
+        } else {
+            s += avsr_exp(z - m);
+        }
+    }
+    // wave then block reduction of (max, argmax-with-smallest-index, scaled sum, plain sum)
+    float gm = wave_max(m);
+    s = wave_sum(s * avsr_exp(m - gm));
+    sum = wave_sum(sum);
+    int cand = (m == gm) ? am : 0x7fffffff;
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) cand = min(cand, __shfl_xor(cand, k));
+    if (lane == 0) {
+        red[wave][0] = gm;
+        red[wave][1] = s;
+        red[wave][2] = sum;
+        redi[wave] = cand;
+    }
+    __syncthreads();
+    float bm = red[0][0];
+    for (int w = 1; w < 4; w++) bm = fmaxf(bm, red[w][0]);
+    float bs = 0.f, bsum = 0.f;
+    int bam = 0x7fffffff;
+    for (int w = 0; w < 4; w++) {
+        bs += red[w][1] * avsr_exp(red[w][0] - bm);
+        bsum += red[w][2];
+        if (red[w][0] == bm) bam = min(bam, redi[w]);
+    }
+    const float lse = bm + logf(bs);
+    const bool ignored = (y == ignore_id);
+    const float conf = 1.f - smoothing, eps = smoothing / (float)(V - 1);
+    if (threadIdx.x == 0) {
+        if (ignored) {
+            row_loss[r] = 0.f;
+            row_hit[r] = 0.f;
+        } else {
+            const float lpy = Elem<T>::ld(x + y) - lse;
+            const float sum_lp = bsum - (float)V * lse;
+            float c = 0.f;  // sum td*log(td) with 0*log0 = 0
+            if (eps > 0.f) c += (float)(V - 1) * eps * logf(eps);
+            if (conf > 0.f) c += conf * logf(conf);
+            row_loss[r] = c - eps * (sum_lp - lpy) - conf * lpy;
+            row_hit[r] = (bam == (int)y) ? 1.f : 0.f;
+        }
+    }
+    if (grad) {
+        T* g = grad + r * ldg;
+        for (int v = threadIdx.x; v < V; v += 256) {
+            float gv = 0.f;
+            if (!ignored) gv = avsr_exp(Elem<T>::ld(x + v) - lse) - (v == (int)y ? conf : eps);
+            Elem<T>::st(g + v, gv);
+        }
+    }
+}
+
+// out[0] = sum(a[0..n)) * scale ; generic small reduction (one block)
+__global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict__ a, int n, float scale,
+                                                        float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += a[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (red[0] + red[1] + red[2] + red[3]) * scale;
+}
+
+// ---- decoder input embedding: out[r,:] = table[id[r],:]*scale + pe[r % L,:], inverted dropout
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
+                                                        const float* __restrict__ pe, float* __restrict__ out, long rows,
+                                                        int L, int D, float scale, float p, uint64_t seed) {
+    const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    const int dv = D >> 3;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * dv; i += (long)gridDim.x * 256) {
+        const long r = i / dv;
+        const int c = (int)(i % dv) * 8;
+        float e[8], q[8], o[8];
+        load8(table + ids[r] * D + c, e);
+        load8(pe + (r % L) * D + c, q);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            o[k] = (e[k] * scale + q[k]) * dropout_scale(seed, (uint64_t)(r * D + c + k), p, inv_keep);
+        store8(out + r * D + c, o);
+    }
+}
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dout,
+                                                        float* __restrict__ dtable, long rows, int D, float scale,
+                                                        float p, uint64_t seed) {
+    const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * D; i += (long)gridDim.x * 256) {
+        const long r = i / D;
+        const int c = (int)(i % D);
+        const float g = dout[i] * scale * dropout_scale(seed, (uint64_t)i, p, inv_keep);
+        atomicAdd(dtable + ids[r] * D + c, g);
+    }
+}
+
+}  // namespace
+
+extern "C" int avsr_row_lse(const void* x, int dtype, int64_t ld, float* lse, int64_t rows, int V, hipStream_t stream) {
+    AVSR_REQUIRE(ld % 8 == 0, "row_lse: ld must be a multiple of 8");
+    if (rows <= 0) return 0;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (dtype == 0) AVSR_LAUNCH((row_lse_kernel<float>), grid, block, 0, stream, (const float*)x, (long)ld, lse, (long)rows, V);
+    else AVSR_LAUNCH((row_lse_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, (long)ld, lse, (long)rows, V);
+    AVSR_CHECK_LAUNCH("row_lse");
+    return 0;
+}
+
+// Workspace layout (f32 words): lse[B*T] | lpg[B*T*Smax] | alpha[B*T*Smax] | beta[B*T*Smax] ; ints: ext[B*Smax] | lens[B]
+extern "C" int64_t avsr_ctc_workspace_bytes(int B, int T, int Lmax) {
+    const int64_t Smax = 2 * (int64_t)Lmax + 1;
+    return ((int64_t)B * T * (1 + 3 * Smax)) * 4 + ((int64_t)B * Smax + B) * 4 + 64;
+}
+
+// nll[b] = -log p(labels_b | logits_b) (+inf kept; the caller's sum applies zero_infinity), grad = d nll / d logits
+extern "C" int avsr_ctc_loss(const void* logits, int dtype, int64_t ld, const int64_t* labels, int Lmax, int ignore_id,
+                             const int64_t* in_lens, float* nll, void* grad, int64_t ldg, void* workspace, int B, int T,
+                             int V, hipStream_t stream) {
+    AVSR_REQUIRE(Lmax <= 255, "ctc: at most 255 labels per utterance");
+    AVSR_REQUIRE(ld % 8 == 0 && ldg % 8 == 0, "ctc: ld must be a multiple of 8");
+    if (B <= 0 || T <= 0) return 0;
+    const int Smax = 2 * Lmax + 1;
+    float* lse = reinterpret_cast<float*>(workspace);
+    float* lpg = lse + (long)B * T;
+    float* alpha = lpg + (long)B * T * Smax;
+    float* beta = alpha + (long)B * T * Smax;
+    int* ext = reinterpret_cast<int*>(beta + (long)B * T * Smax);
+    int* lens = ext + (long)B * Smax;
+    int rc = avsr_row_lse(logits, dtype, ld, lse, (int64_t)B * T, V, stream);
+    if (rc) return rc;
+    AVSR_LAUNCH(ctc_prepare_kernel, dim3(B), dim3(64), 0, stream, labels, Lmax, ignore_id, ext, Smax, lens);
+    if (dtype == 0)
+        AVSR_LAUNCH((ctc_gather_kernel<float>), dim3(B * T), dim3(256), 0, stream, (const float*)logits, (long)ld, lse, ext, lens, lpg, T, Smax);
+    else
+        AVSR_LAUNCH((ctc_gather_kernel<bf16_t>), dim3(B * T), dim3(256), 0, stream, (const bf16_t*)logits, (long)ld, lse, ext, lens, lpg, T, Smax);
+    AVSR_LAUNCH(ctc_alphabeta_kernel, dim3(B, 2), dim3(64), 0, stream, lpg, ext, lens, in_lens, alpha, beta, nll, T, Smax);
+    if (grad) {
+        const size_t sm = (size_t)V * sizeof(float);
+        if (dtype == 0)
+            AVSR_LAUNCH((ctc_grad_kernel<float>), dim3(B * T), dim3(256), sm, stream, (const float*)logits, (long)ld, lse, lpg, alpha, beta,
+                        nll, ext, lens, in_lens, (float*)grad, (long)ldg, T, V, Smax);
+        else
+            AVSR_LAUNCH((ctc_grad_kernel<bf16_t>), dim3(B * T), dim3(256), sm, stream, (const bf16_t*)logits, (long)ld, lse, lpg, alpha, beta,
+                        nll, ext, lens, in_lens, (bf16_t*)grad, (long)ldg, T, V, Smax);
+    }
+    AVSR_CHECK_LAUNCH("ctc_loss");
+    return 0;
+}
+
+extern "C" int avsr_ce_smooth(const void* logits, int dtype, int64_t ld, const int64_t* target, int ignore_id, int V,
+                              float smoothing, float* row_loss, float* row_hit, void* grad, int64_t ldg, int64_t rows,
+                              hipStream_t stream) {
+    if (rows <= 0) return 0;
+    if (dtype == 0)
+        AVSR_LAUNCH((ce_smooth_kernel<float>), dim3((unsigned)rows), dim3(256), 0, stream, (const float*)logits, (long)ld, target, ignore_id, V,
+                    smoothing, row_loss, row_hit, (float*)grad, (long)ldg);
+    else
+        AVSR_LAUNCH((ce_smooth_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, stream, (const bf16_t*)logits, (long)ld, target, ignore_id, V,
+                    smoothing, row_loss, row_hit, (bf16_t*)grad, (long)ldg);
+    AVSR_CHECK_LAUNCH("ce_smooth");
+    return 0;
+}
+
+extern "C" int avsr_sum_scale(const float* a, int n, float scale, float* out, hipStream_t stream) {
+    AVSR_LAUNCH(sum_scale_kernel, dim3(1), dim3(256), 0, stream, a, n, scale, out);
+    AVSR_CHECK_LAUNCH("sum_scale");
+    return 0;
+}
+
+extern "C" int avsr_embed_fwd(const int64_t* ids, const float* table, const float* pe, float* out, int64_t rows, int L,
+                              int D, float scale, float drop_p, uint64_t seed, hipStream_t stream) {
+    AVSR_REQUIRE(D % 8 == 0, "embed: D must be a multiple of 8");
+    if (rows <= 0) return 0;
+    long nb = (rows * (D >> 3) + 255) / 256;
+    AVSR_LAUNCH(embed_fwd_kernel, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, stream, ids, table, pe, out, (long)rows, L, D, scale,
+                drop_p, seed);
+    AVSR_CHECK_LAUNCH("embed_fwd");
+    return 0;
+}
+
+extern "C" int avsr_embed_bwd(const int64_t* ids, const float* dout, float* dtable, int64_t rows, int D, float scale,
+                              float drop_p, uint64_t seed, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    long nb = (rows * D + 255) / 256;
+    AVSR_LAUNCH(embed_bwd_kernel, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, stream, ids, dout, dtable, (long)rows, D, scale, drop_p,
+                seed);
+    AVSR_CHECK_LAUNCH("embed_bwd");
+    return 0;
+}

@@ -35,7 +35,7 @@ def _stream(*ts):
 
 
 def call(name, *args):
-    _lib.lib().call(name, *args)
+    return _lib.lib().call(name, *args)
 
 
 def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-12):
@@ -225,3 +225,44 @@ def bn_bwd_apply(x, dy, add, mean, invstd, gamma, beta, sums, inv_n, rows, C, ac
     call("avsr_bn_bwd_apply", _ptr(x), _ptr(dy), _ptr(add), dt(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
          _ptr(sums), inv_n, _ptr(dx), _ptr(dadd), rows, C, act, _stream(x))
     return dx, dadd
+
+
+def ctc_loss(logits, ld, labels, in_lens, B, T, V, want_grad=True, ignore_id=-1):
+    """logits: [B*T, ld] (f32/bf16); labels int64 [B, Lmax]; in_lens int64 [B].
+    Returns nll [B] f32 (inf = infeasible) and grad [B*T, ld] (same dtype) or None."""
+    Lmax = labels.shape[1]
+    ws_bytes = call("avsr_ctc_workspace_bytes", B, T, Lmax)
+    ws = torch.empty(ws_bytes // 4 + 1, dtype=torch.float32, device=logits.device)
+    nll = torch.empty(B, dtype=torch.float32, device=logits.device)
+    grad = torch.empty_like(logits) if want_grad else None
+    call("avsr_ctc_loss", _ptr(logits), dt(logits), ld, _ptr(labels), Lmax, ignore_id, _ptr(in_lens), _ptr(nll),
+         _ptr(grad), ld, _ptr(ws), B, T, V, _stream(logits))
+    return nll, grad
+
+
+def ce_smooth(logits, ld, target, V, smoothing, want_grad=True, ignore_id=-1):
+    rows = target.numel()
+    row_loss = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    row_hit = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    grad = torch.empty_like(logits) if want_grad else None
+    call("avsr_ce_smooth", _ptr(logits), dt(logits), ld, _ptr(target), ignore_id, V, smoothing, _ptr(row_loss),
+         _ptr(row_hit), _ptr(grad), ld, rows, _stream(logits))
+    return row_loss, row_hit, grad
+
+
+def sum_scale(a, scale):
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    call("avsr_sum_scale", _ptr(a), a.numel(), scale, _ptr(out), _stream(a))
+    return out
+
+
+def embed_fwd(ids, table, pe, L, scale, drop_p=0.0, seed=0):
+    rows, D = ids.numel(), table.shape[1]
+    out = torch.empty(*ids.shape, D, dtype=torch.float32, device=table.device)
+    call("avsr_embed_fwd", _ptr(ids), _ptr(table), _ptr(pe), _ptr(out), rows, L, D, scale, drop_p, seed, _stream(table))
+    return out
+
+
+def embed_bwd(ids, dout, dtable, scale, drop_p=0.0, seed=0):
+    rows, D = ids.numel(), dtable.shape[1]
+    call("avsr_embed_bwd", _ptr(ids), _ptr(dout), _ptr(dtable), rows, D, scale, drop_p, seed, _stream(dout))

@@ -128,6 +128,27 @@ int avsr_bn_bwd_apply(const void* x, const void* dy, const void* add, int dtype,
                       const float* invstd, const float* gamma, const float* beta, const float* sums,
                       float inv_n, void* dx, void* dadd, int64_t rows, int C, int act, avsr_stream_t stream);
 
+/* ---- loss heads and decoder embedding (loss.hip) ------------------------------------------- */
+int avsr_row_lse(const void* x, int dtype, int64_t ld, float* lse, int64_t rows, int V, avsr_stream_t stream);
+int64_t avsr_ctc_workspace_bytes(int B, int T, int Lmax);
+/* CTC (ctc.py:32-38,54-63; blank 0): logits [B,T,V] rows of pitch ld; labels int64 [B,Lmax] padded with
+ * ignore_id; in_lens int64 [B].  nll[b] = -log p (inf if infeasible); grad (same dtype, pitch ldg, may be
+ * NULL) = d nll[b]/d logits, zero for t >= in_lens[b] and for infeasible targets (zero_infinity). */
+int avsr_ctc_loss(const void* logits, int dtype, int64_t ld, const int64_t* labels, int Lmax, int ignore_id,
+                  const int64_t* in_lens, float* nll, void* grad, int64_t ldg, void* workspace, int B, int T,
+                  int V, avsr_stream_t stream);
+/* label-smoothing KL (label_smoothing_loss.py:41-63) per row + argmax hit (nets_utils.py:272-292);
+ * grad = softmax - smoothed target (zero rows for ignored targets), may be NULL */
+int avsr_ce_smooth(const void* logits, int dtype, int64_t ld, const int64_t* target, int ignore_id, int V,
+                   float smoothing, float* row_loss, float* row_hit, void* grad, int64_t ldg, int64_t rows,
+                   avsr_stream_t stream);
+int avsr_sum_scale(const float* a, int n, float scale, float* out, avsr_stream_t stream);
+/* out[r,:] = dropout(table[ids[r],:]*scale + pe[r % L,:])  (transformer_decoder.py:186-189, embedding.py:78-87) */
+int avsr_embed_fwd(const int64_t* ids, const float* table, const float* pe, float* out, int64_t rows, int L,
+                   int D, float scale, float drop_p, uint64_t seed, avsr_stream_t stream);
+int avsr_embed_bwd(const int64_t* ids, const float* dout, float* dtable, int64_t rows, int D, float scale,
+                   float drop_p, uint64_t seed, avsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,88 @@
+"""CTC / label-smoothing / embedding kernels against torch (ctc.py:32-38, label_smoothing_loss.py:41-63)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from auto_avsr_amd import ops
+
+
+def _pad_cols(x, ld):
+    out = torch.zeros(x.shape[0], ld, dtype=x.dtype)
+    out[:, : x.shape[1]] = x
+    return out
+
+
+@pytest.mark.parametrize("B,T,V,L", [(3, 40, 53, 9), (2, 150, 301, 70), (2, 12, 20, 1), (1, 300, 64, 140)])
+def test_ctc(dev, B, T, V, L):
+    torch.manual_seed(B * 100 + T)
+    logits = torch.randn(B, T, V) * 2
+    labels = torch.randint(1, V, (B, L))
+    if B > 1 and L > 3:
+        labels[1, L - 3:] = -1
+    if L > 4:
+        labels[0, 2] = labels[0, 1]  # repeated label -> mandatory blank
+    in_lens = torch.full((B,), T, dtype=torch.int64)
+    if B > 1:
+        in_lens[1] = max(T - 7, 1)
+    if B > 2:
+        in_lens[2] = 3  # infeasible: fewer frames than labels -> inf -> zero_infinity
+    lg = logits.clone().requires_grad_()
+    lp = lg.transpose(0, 1).log_softmax(2)
+    ys = [y[y != -1] for y in labels]
+    olens = torch.tensor([len(y) for y in ys])
+    ref_rows = F.ctc_loss(lp, torch.cat(ys), in_lens, olens, blank=0, reduction="none", zero_infinity=True)
+    ref_rows.sum().backward()
+    ld = (V + 7) // 8 * 8
+    x = _pad_cols(logits.reshape(B * T, V), ld).to(dev)
+    nll, grad = ops.ctc_loss(x, ld, labels.to(dev), in_lens.to(dev), B, T, V)
+    nll = nll.cpu()
+    nll = torch.where(torch.isinf(nll), torch.zeros_like(nll), nll)
+    assert (nll - ref_rows).abs().max() < 2e-3 * max(1.0, ref_rows.abs().max().item()), (nll, ref_rows)
+    g = grad.cpu()[:, :V].reshape(B, T, V)
+    # log-space f32 recursions over T steps: both sides carry ~1e-3 relative noise at T=300, L=140
+    assert (g - lg.grad).abs().max() < (2e-4 if T <= 150 else 2e-3)
+
+
+def test_ce_smooth(dev):
+    torch.manual_seed(0)
+    R, V = 37, 203
+    logits = torch.randn(R, V) * 3
+    target = torch.randint(0, V, (R,))
+    target[5] = -1
+    target[20] = -1
+    logits[3, 7] = logits[3].max() + 1.0
+    target[3] = 7
+    lg = logits.clone().requires_grad_()
+    # reference restatement: label_smoothing_loss.py:52-63 with size=V, smoothing=0.1, normalize_length=False
+    with torch.no_grad():
+        td = torch.full_like(logits, 0.1 / (V - 1))
+        ign = target == -1
+        td.scatter_(1, target.masked_fill(ign, 0).unsqueeze(1), 0.9)
+    kl = F.kl_div(torch.log_softmax(lg, 1), td, reduction="none").masked_fill(ign.unsqueeze(1), 0)
+    kl.sum().backward()
+    ld = (V + 7) // 8 * 8
+    row_loss, row_hit, grad = ops.ce_smooth(_pad_cols(logits, ld).to(dev), ld, target.to(dev), V, 0.1)
+    assert (row_loss.cpu() - kl.sum(1)).abs().max() < 1e-4
+    assert (grad.cpu()[:, :V] - lg.grad).abs().max() < 1e-5
+    hits = (logits.argmax(1) == target) & ~ign
+    assert (row_hit.cpu() == hits.float()).all()
+    tot = ops.sum_scale(row_loss, 0.25).cpu()
+    assert abs(tot.item() - 0.25 * kl.sum().item()) < 1e-3
+
+
+def test_embedding(dev):
+    torch.manual_seed(1)
+    B, L, V, D = 3, 9, 50, 64
+    ids = torch.randint(0, V, (B, L))
+    table = torch.randn(V, D, requires_grad=True)
+    pe = torch.randn(L, D)
+    ref = table[ids] * math.sqrt(D) + pe[None]
+    dout = torch.randn(B, L, D)
+    ref.backward(dout)
+    out = ops.embed_fwd(ids.to(dev), table.detach().to(dev), pe.to(dev), L, math.sqrt(D))
+    assert (out.cpu() - ref).abs().max() < 1e-5
+    dt = torch.zeros(V, D, device=dev)
+    ops.embed_bwd(ids.to(dev), dout.to(dev), dt, math.sqrt(D))
+    assert (dt.cpu() - table.grad).abs().max() < 1e-4
