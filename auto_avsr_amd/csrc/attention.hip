@@ -48,6 +48,7 @@ struct AttnParams {
     long sbq, sbk, sbv, sbo;           // batch strides (elements)
     float scale, drop_p;
     uint64_t seed;
+    const uint64_t* seed_dev;
     // backward only
     const void* dout;  // [B,Tq,H,64] strides as out
     void* dqu;         // [B,Tq,H,64] strides as qu
@@ -200,6 +201,7 @@ struct Attn {
         const T* vv = reinterpret_cast<const T*>(p.v) + b * p.sbv + h * DK;
         const T* pos = RELPOS ? reinterpret_cast<const T*>(p.pos) + h * DK : nullptr;
         const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+        const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
 
         // ---- per-wave A fragments (rows i0 + 16w + lc)
         const int arow = i0 + 16 * w + lc;
@@ -336,7 +338,7 @@ struct Attn {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int jg = j0 + j * 16 + lc;
-                    keep[j][r] = dropout_scale(p.seed, (((uint64_t)b * p.H + h) * Tq + ig) * (uint64_t)Tk + jg,
+                    keep[j][r] = dropout_scale(seed, (((uint64_t)b * p.H + h) * Tq + ig) * (uint64_t)Tk + jg,
                                                p.drop_p, inv_keep);
                 }
             }
@@ -475,7 +477,7 @@ extern "C" int avsr_attention_fwd(const void* qu, const void* qv, const void* k,
                                   int dtype, int precise, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq,
                                   void* out, float* lse, int B, int H, int Tq, int Tk, int dk, int ldq, int ldk,
                                   int ldv, int ldp, int ldo, int64_t sbq, int64_t sbk, int64_t sbv, int64_t sbo,
-                                  float scale, float drop_p, uint64_t seed, hipStream_t stream) {
+                                  float scale, float drop_p, uint64_t seed, const uint64_t* seed_dev, hipStream_t stream) {
     AVSR_REQUIRE(dk == DK, "attention: d_k must be 64");
     AVSR_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && (pos == nullptr || ldp % 8 == 0),
                  "attention: row strides must be multiples of 8");
@@ -488,7 +490,7 @@ extern "C" int avsr_attention_fwd(const void* qu, const void* qv, const void* k,
     p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldp = ldp; p.ldo = ldo;
     p.sbq = sbq; p.sbk = sbk; p.sbv = sbv; p.sbo = sbo;
-    p.scale = scale; p.drop_p = drop_p; p.seed = seed;
+    p.scale = scale; p.drop_p = drop_p; p.seed = seed; p.seed_dev = seed_dev;
     AVSR_REQUIRE(launch_attn<false>(p, dtype, precise, pos != nullptr, stream) == 0, "attention: bad dtype/precise combination");
     AVSR_CHECK_LAUNCH("attention_fwd");
     return 0;
@@ -499,7 +501,8 @@ extern "C" int avsr_attention_bwd_dq(const void* qu, const void* qv, const void*
                                      const void* out, const float* lse, const void* dout, void* dqu, void* dqv,
                                      void* pd, void* ds, int lds, int B, int H, int Tq, int Tk, int dk, int ldq,
                                      int ldk, int ldv, int ldp, int ldo, int64_t sbq, int64_t sbk, int64_t sbv,
-                                     int64_t sbo, float scale, float drop_p, uint64_t seed, hipStream_t stream) {
+                                     int64_t sbo, float scale, float drop_p, uint64_t seed, const uint64_t* seed_dev,
+                                     hipStream_t stream) {
     AVSR_REQUIRE(dk == DK, "attention: d_k must be 64");
     AVSR_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && (pos == nullptr || ldp % 8 == 0),
                  "attention: row strides must be multiples of 8");
@@ -513,7 +516,7 @@ extern "C" int avsr_attention_bwd_dq(const void* qu, const void* qv, const void*
     p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldp = ldp; p.ldo = ldo;
     p.sbq = sbq; p.sbk = sbk; p.sbv = sbv; p.sbo = sbo;
-    p.scale = scale; p.drop_p = drop_p; p.seed = seed;
+    p.scale = scale; p.drop_p = drop_p; p.seed = seed; p.seed_dev = seed_dev;
     p.dout = dout; p.dqu = dqu; p.dqv = dqv; p.pd = pd; p.ds = ds; p.lds = lds;
     AVSR_REQUIRE(launch_attn<true>(p, dtype, precise, pos != nullptr, stream) == 0, "attention: bad dtype/precise combination");
     AVSR_CHECK_LAUNCH("attention_bwd_dq");

@@ -172,7 +172,9 @@ template <class T>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
     const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ add, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ sums, float inv_n, T* __restrict__ dx, T* __restrict__ dadd, long rows, int C, int act) {
+    const float* __restrict__ sums, float inv_n0, const float* __restrict__ n_dev, T* __restrict__ dx,
+    T* __restrict__ dadd, long rows, int C, int act) {
+    const float inv_n = n_dev ? 1.0f / *n_dev : inv_n0;
     const int cv = C >> 3;
     const long nvec = rows * cv;
     for (long i = (long)blockIdx.x * BN_THREADS + threadIdx.x; i < nvec; i += (long)gridDim.x * BN_THREADS) {
@@ -282,17 +284,17 @@ extern "C" int avsr_bn_bwd_reduce(const void* x, const void* dy, const void* add
 
 extern "C" int avsr_bn_bwd_apply(const void* x, const void* dy, const void* add, int dtype, const float* mean,
                                  const float* invstd, const float* gamma, const float* beta, const float* sums,
-                                 float inv_n, void* dx, void* dadd, int64_t rows, int C, int act,
-                                 hipStream_t stream) {
+                                 float inv_n, const float* n_dev, void* dx, void* dadd, int64_t rows, int C,
+                                 int act, hipStream_t stream) {
     AVSR_REQUIRE(C % 8 == 0, "batchnorm: C must be a multiple of 8");
     if (rows <= 0) return 0;
     dim3 grid(ew_grid(rows * (C >> 3))), block(BN_THREADS);
     if (dtype == 0)
         AVSR_LAUNCH((bn_bwd_apply_kernel<float>), grid, block, 0, stream, (const float*)x, (const float*)dy,
-                    (const float*)add, mean, invstd, gamma, beta, sums, inv_n, (float*)dx, (float*)dadd, (long)rows, C, act);
+                    (const float*)add, mean, invstd, gamma, beta, sums, inv_n, n_dev, (float*)dx, (float*)dadd, (long)rows, C, act);
     else
         AVSR_LAUNCH((bn_bwd_apply_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dy,
-                    (const bf16_t*)add, mean, invstd, gamma, beta, sums, inv_n, (bf16_t*)dx, (bf16_t*)dadd, (long)rows, C, act);
+                    (const bf16_t*)add, mean, invstd, gamma, beta, sums, inv_n, n_dev, (bf16_t*)dx, (bf16_t*)dadd, (long)rows, C, act);
     AVSR_CHECK_LAUNCH("bn_bwd_apply");
     return 0;
 }

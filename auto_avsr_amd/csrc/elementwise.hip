@@ -22,19 +22,26 @@ static inline int ew_grid(long nvec) {
 
 template <class TI, class TO>
 __global__ __launch_bounds__(EW_THREADS) void scale_dropout_kernel(const TI* __restrict__ x, TO* __restrict__ out,
-                                                                   long n, float alpha, float p, uint64_t seed) {
+                                                                   long n, float alpha0, const float* alpha_dev, float p, uint64_t seed0,
+                                                                   const uint64_t* seed_dev, const float* __restrict__ add,
+                                                                   long period) {
+    const float alpha = alpha0 * (alpha_dev ? *alpha_dev : 1.f);
+    const uint64_t seed = seed0 + (seed_dev ? *seed_dev : 0ull);
     const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
     const long nvec = n >> 3;
     for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < nvec; i += (long)gridDim.x * EW_THREADS) {
-        float v[8];
+        float v[8], a[8];
         load8(x + i * 8, v);
+        if (add) load8(add + (i * 8) % period, a);  // period % 8 == 0
 #pragma unroll
-        for (int e = 0; e < 8; e++) v[e] *= alpha * dropout_scale(seed, (uint64_t)(i * 8 + e), p, inv_keep);
+        for (int e = 0; e < 8; e++)
+            v[e] = (v[e] * alpha + (add ? a[e] : 0.f)) * dropout_scale(seed, (uint64_t)(i * 8 + e), p, inv_keep);
         store8(out + i * 8, v);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
         for (long i = nvec * 8; i < n; i++)
-            Elem<TO>::st(out + i, Elem<TI>::ld(x + i) * alpha * dropout_scale(seed, (uint64_t)i, p, inv_keep));
+            Elem<TO>::st(out + i, (Elem<TI>::ld(x + i) * alpha + (add ? add[i % period] : 0.f)) *
+                                      dropout_scale(seed, (uint64_t)i, p, inv_keep));
 }
 
 // out1 = x + b1[col], out2 = x + b2[col]   (cols % 8 == 0)
@@ -142,20 +149,22 @@ __global__ __launch_bounds__(EW_THREADS) void glu_bwd_kernel(const T* __restrict
 
 
 template <class TI, class TO>
-static void launch_scale_dropout(const void* x, void* out, long n, float alpha, float p, uint64_t seed,
-                                 hipStream_t stream) {
+static void launch_scale_dropout(const void* x, void* out, long n, float alpha, const float* alpha_dev, float p,
+                                 uint64_t seed, const uint64_t* seed_dev, const float* add, long period, hipStream_t stream) {
     dim3 grid(ew_grid(n >> 3)), block(EW_THREADS);
-    AVSR_LAUNCH((scale_dropout_kernel<TI, TO>), grid, block, 0, stream, (const TI*)x, (TO*)out, n, alpha, p, seed);
+    AVSR_LAUNCH((scale_dropout_kernel<TI, TO>), grid, block, 0, stream, (const TI*)x, (TO*)out, n, alpha, alpha_dev, p, seed, seed_dev, add, period);
 }
 
 extern "C" int avsr_scale_dropout(const void* x, int x_dtype, void* out, int out_dtype, int64_t n, float alpha,
-                                  float drop_p, uint64_t seed, hipStream_t stream) {
+                                  const float* alpha_dev, float drop_p, uint64_t seed, const uint64_t* seed_dev,
+                                  const float* add, int64_t add_period, hipStream_t stream) {
     if (n <= 0) return 0;
+    AVSR_REQUIRE(add == nullptr || (add_period > 0 && add_period % 8 == 0), "scale_dropout: add_period must be a positive multiple of 8");
     AVSR_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0, "scale_dropout: 16-byte alignment");
-    if (x_dtype == 0 && out_dtype == 0) launch_scale_dropout<float, float>(x, out, n, alpha, drop_p, seed, stream);
-    else if (x_dtype == 0) launch_scale_dropout<float, bf16_t>(x, out, n, alpha, drop_p, seed, stream);
-    else if (out_dtype == 0) launch_scale_dropout<bf16_t, float>(x, out, n, alpha, drop_p, seed, stream);
-    else launch_scale_dropout<bf16_t, bf16_t>(x, out, n, alpha, drop_p, seed, stream);
+    if (x_dtype == 0 && out_dtype == 0) launch_scale_dropout<float, float>(x, out, n, alpha, alpha_dev, drop_p, seed, seed_dev, add, (long)add_period, stream);
+    else if (x_dtype == 0) launch_scale_dropout<float, bf16_t>(x, out, n, alpha, alpha_dev, drop_p, seed, seed_dev, add, (long)add_period, stream);
+    else if (out_dtype == 0) launch_scale_dropout<bf16_t, float>(x, out, n, alpha, alpha_dev, drop_p, seed, seed_dev, add, (long)add_period, stream);
+    else launch_scale_dropout<bf16_t, bf16_t>(x, out, n, alpha, alpha_dev, drop_p, seed, seed_dev, add, (long)add_period, stream);
     AVSR_CHECK_LAUNCH("scale_dropout");
     return 0;
 }

@@ -19,8 +19,9 @@ int run_tn(const Params&, int, int, int, int, int, hipStream_t);
 extern "C" int avsr_gemm(int layout, const void* A, int a_dtype, int lda, const void* B, int b_dtype,
                          int ldb, int M, int N, int K, int precise, const float* bias, int act,
                          const void* gate, int gate_dtype, int ldg, float gate_scale, float drop_p,
-                         uint64_t seed, float alpha, const float* resid, int ldr, void* C, int c_dtype,
-                         int ldc, int accumulate, int split_k, int force_tile, hipStream_t stream) {
+                         uint64_t seed, const uint64_t* seed_dev, float alpha, const float* alpha_dev,
+                         const float* resid, int ldr, void* C, int c_dtype, int ldc, int accumulate, int split_k,
+                         int force_tile, hipStream_t stream) {
     AVSR_REQUIRE(layout >= 0 && layout <= 2, "gemm: layout must be 0 (NT), 1 (NN) or 2 (TN)");
     AVSR_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "gemm: lda/ldb must be multiples of 8 elements");
     AVSR_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "gemm: operands must be 16-byte aligned");
@@ -34,7 +35,7 @@ extern "C" int avsr_gemm(int layout, const void* A, int a_dtype, int lda, const 
     p.M = M; p.N = N; p.K = K; p.k_chunk = K;
     p.bias = bias; p.act = act;
     p.gate = gate; p.gate_dtype = gate_dtype; p.ldg = ldg; p.gate_scale = gate_scale;
-    p.drop_p = drop_p; p.seed = seed;
+    p.drop_p = drop_p; p.seed = seed; p.seed_dev = seed_dev; p.alpha_dev = alpha_dev;
     p.alpha = alpha; p.resid = resid; p.ldr = ldr;
     p.C = C; p.c_dtype = c_dtype; p.ldc = ldc; p.accumulate = accumulate;
     p.nsplit = 1; p.batch_h = 1; p.nbatch = 1;

@@ -38,7 +38,9 @@ struct Params {
     float gate_scale;
     float drop_p;  // dropout on v (forward); keep-mask from (seed, m*N+n)
     uint64_t seed;
-    float alpha;         // v *= alpha
+    float alpha;         // v *= alpha (* *alpha_dev when given: device-side scalar, e.g. an upstream loss gradient)
+    const float* alpha_dev;
+    const uint64_t* seed_dev;  // added to seed when given (graph-replay safe dropout)
     const float* resid;  // v += resid[m,ldr]
     int ldr;
     void* C;
@@ -260,6 +262,8 @@ struct Kernel {
 
         // ---- epilogue
         const float inv_keep = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+        const float alpha = p.alpha * (p.alpha_dev ? *p.alpha_dev : 1.f);
+        const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -281,8 +285,8 @@ struct Kernel {
                         v = g > 0.f ? v * p.gate_scale : 0.f;
                     }
                     if (p.drop_p > 0.f)
-                        v *= dropout_scale(p.seed, (uint64_t)row * (uint64_t)p.N + col, p.drop_p, inv_keep);
-                    v *= p.alpha;
+                        v *= dropout_scale(seed, (uint64_t)row * (uint64_t)p.N + col, p.drop_p, inv_keep);
+                    v *= alpha;
                     if (p.resid && zs == 0) v += p.resid[(size_t)row * p.ldr + col];
                     if (p.c_dtype == 0) {
                         float* c = reinterpret_cast<float*>(p.C) + c_off + (size_t)row * p.ldc + col;

@@ -61,6 +61,15 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const T* __restrict__ x, l
     if (lane == 0) lse[row] = gm + logf(s);
 }
 
+// out[r, v] = x[r, v] - lse[r]
+__global__ __launch_bounds__(256) void sub_row_scalar_kernel(const float* __restrict__ x, long ld,
+                                                             const float* __restrict__ lse, float* __restrict__ out,
+                                                             long rows, int V) {
+    const long r = blockIdx.x;
+    const float l = lse[r];
+    for (int v = threadIdx.x; v < V; v += 256) out[r * ld + v] = x[r * ld + v] - l;
+}
+
 // ---- per utterance: strip ignore_id from the padded label row, build the blank-interleaved sequence
 __global__ void ctc_prepare_kernel(const int64_t* __restrict__ labels, int Lmax, int ignore_id, int* __restrict__ ext,
                                    int Smax, int* __restrict__ lens /* [B]: L_b */) {
@@ -314,10 +323,13 @@ __global__ __launch_bounds__(256) void ce_smooth_kernel(const T* __restrict__ lo
 
 // out[0] = sum(a[0..n)) * scale ; generic small reduction (one block)
 __global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict__ a, int n, float scale,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, int finite_only) {
     __shared__ float red[4];
     float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) s += a[i];
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float v = a[i];
+        if (!finite_only || (v < INFINITY && v > -INFINITY)) s += v;  // zero_infinity=True (ctc.py:26-28)
+    }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -327,7 +339,9 @@ __global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict_
 // ---- decoder input embedding: out[r,:] = table[id[r],:]*scale + pe[r % L,:], inverted dropout
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
                                                         const float* __restrict__ pe, float* __restrict__ out, long rows,
-                                                        int L, int D, float scale, float p, uint64_t seed) {
+                                                        int L, int D, float scale, float p, uint64_t seed0,
+                                                        const uint64_t* seed_dev) {
+    const uint64_t seed = seed0 + (seed_dev ? *seed_dev : 0ull);
     const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
     const int dv = D >> 3;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * dv; i += (long)gridDim.x * 256) {
@@ -344,7 +358,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
 }
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dout,
                                                         float* __restrict__ dtable, long rows, int D, float scale,
-                                                        float p, uint64_t seed) {
+                                                        float p, uint64_t seed0, const uint64_t* seed_dev) {
+    const uint64_t seed = seed0 + (seed_dev ? *seed_dev : 0ull);
     const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * D; i += (long)gridDim.x * 256) {
         const long r = i / D;
@@ -421,29 +436,39 @@ extern "C" int avsr_ce_smooth(const void* logits, int dtype, int64_t ld, const i
     return 0;
 }
 
-extern "C" int avsr_sum_scale(const float* a, int n, float scale, float* out, hipStream_t stream) {
-    AVSR_LAUNCH(sum_scale_kernel, dim3(1), dim3(256), 0, stream, a, n, scale, out);
+extern "C" int avsr_sum_scale(const float* a, int n, float scale, float* out, int finite_only, hipStream_t stream) {
+    AVSR_LAUNCH(sum_scale_kernel, dim3(1), dim3(256), 0, stream, a, n, scale, out, finite_only);
     AVSR_CHECK_LAUNCH("sum_scale");
     return 0;
 }
 
 extern "C" int avsr_embed_fwd(const int64_t* ids, const float* table, const float* pe, float* out, int64_t rows, int L,
-                              int D, float scale, float drop_p, uint64_t seed, hipStream_t stream) {
+                              int D, float scale, float drop_p, uint64_t seed, const uint64_t* seed_dev, hipStream_t stream) {
     AVSR_REQUIRE(D % 8 == 0, "embed: D must be a multiple of 8");
     if (rows <= 0) return 0;
     long nb = (rows * (D >> 3) + 255) / 256;
     AVSR_LAUNCH(embed_fwd_kernel, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, stream, ids, table, pe, out, (long)rows, L, D, scale,
-                drop_p, seed);
+                drop_p, seed, seed_dev);
     AVSR_CHECK_LAUNCH("embed_fwd");
     return 0;
 }
 
 extern "C" int avsr_embed_bwd(const int64_t* ids, const float* dout, float* dtable, int64_t rows, int D, float scale,
-                              float drop_p, uint64_t seed, hipStream_t stream) {
+                              float drop_p, uint64_t seed, const uint64_t* seed_dev, hipStream_t stream) {
     if (rows <= 0) return 0;
     long nb = (rows * D + 255) / 256;
     AVSR_LAUNCH(embed_bwd_kernel, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, stream, ids, dout, dtable, (long)rows, D, scale, drop_p,
-                seed);
+                seed, seed_dev);
     AVSR_CHECK_LAUNCH("embed_bwd");
+    return 0;
+}
+
+extern "C" int avsr_log_softmax(const float* x, int64_t ld, float* lse_ws, float* out, int64_t rows, int V,
+                                hipStream_t stream) {
+    if (rows <= 0) return 0;
+    int rc = avsr_row_lse(x, 0, ld, lse_ws, rows, V, stream);
+    if (rc) return rc;
+    AVSR_LAUNCH(sub_row_scalar_kernel, dim3((unsigned)rows), dim3(256), 0, stream, x, (long)ld, lse_ws, out, (long)rows, V);
+    AVSR_CHECK_LAUNCH("log_softmax");
     return 0;
 }

@@ -1,0 +1,65 @@
+"""E2E: front-end -> Linear(512, D) -> Conformer encoder -> {CTC, Transformer decoder + label smoothing}.
+
+Mirror of espnet/nets/pytorch_backend/e2e_asr_conformer.py:21-87.  The constructor keeps the reference
+signature ``E2E(odim, modality, ctc_weight=0.1, ignore_id=-1)`` and its hard-coded 768/12/3072/12+6 sizes as
+defaults; the extra keyword arguments (not in the reference) only exist so that tests can build
+small instances of the same graph."""
+import torch
+from torch import nn
+
+from . import functional as AF
+from . import nets
+from .frontend import audio_resnet, video_resnet
+
+
+class E2E(nn.Module):
+    def __init__(self, odim, modality, ctc_weight=0.1, ignore_id=-1, *, adim=768, aheads=12, eunits=3072, elayers=12,
+                 dunits=3072, dlayers=6, cnn_module_kernel=31):
+        super().__init__()
+        self.modality = modality
+        if modality == "audio":
+            self.frontend = audio_resnet()
+        elif modality == "video":
+            self.frontend = video_resnet()
+        self.proj_encoder = nn.Linear(512, adim)
+        self.encoder = nets.ConformerEncoder(attention_dim=adim, attention_heads=aheads, linear_units=eunits,
+                                             num_blocks=elayers, cnn_module_kernel=cnn_module_kernel)
+        self.decoder = nets.TransformerDecoder(odim=odim, attention_dim=adim, attention_heads=aheads,
+                                               linear_units=dunits, num_blocks=dlayers)
+        self.blank = 0
+        self.sos = odim - 1
+        self.eos = odim - 1
+        self.odim = odim
+        self.ignore_id = ignore_id
+        self.ctc_weight = ctc_weight
+        self.ctc = nets.CTC(odim, adim, 0.1, reduce=True)
+        self.criterion = nets.LabelSmoothingLoss(self.odim, self.ignore_id, 0.1, False)
+
+    def scorers(self):
+        from .scorers import CTCPrefixScorer
+
+        return dict(decoder=self.decoder, ctc=CTCPrefixScorer(self.ctc, self.eos))
+
+    def forward_tensors(self, x, lengths, label):
+        """The training hot path with no host synchronisation: returns device scalars
+        (loss, loss_ctc, loss_att, n_correct, n_tokens)."""
+        if self.modality == "audio":
+            lengths = torch.div(lengths, 640, rounding_mode="trunc")
+        feats = self.frontend(x)
+        lengths = lengths.to(feats.device)
+        padding_mask = nets.non_pad_mask_device(lengths, feats.shape[1])
+        h = AF.linear(feats, self.proj_encoder.weight, self.proj_encoder.bias, out_dtype=torch.float32)
+        enc, _ = self.encoder(h, padding_mask)
+        loss_ctc, _ = self.ctc(enc, lengths, label)
+        ys_in, ys_out = nets.add_sos_eos_static(label.to(feats.device), self.sos, self.eos, self.ignore_id)
+        ys_mask = nets.target_mask(ys_in, self.ignore_id)
+        pred, _ = self.decoder(ys_in, ys_mask, enc, padding_mask)
+        loss_att = self.criterion(pred, ys_out)
+        loss = self.ctc_weight * loss_ctc + (1 - self.ctc_weight) * loss_att
+        n_tok = (ys_out != self.ignore_id).sum()
+        return loss, loss_ctc, loss_att, self.criterion.last_hits, n_tok
+
+    def forward(self, x, lengths, label):
+        loss, loss_ctc, loss_att, hits, n_tok = self.forward_tensors(x, lengths, label)
+        acc = float(hits.detach()) / float(n_tok)  # the reference returns a python float too (nets_utils.py:292)
+        return loss, loss_ctc, loss_att, acc

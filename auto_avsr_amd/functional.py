@@ -1,0 +1,805 @@
+"""Autograd glue between the reference's nn.Module surface and the HIP kernels (include/avsr_hip.h).
+
+Every ``torch.autograd.Function`` here only sequences C-ABI calls (auto_avsr_amd.ops) over torch-owned device
+buffers: forward and backward arithmetic both run in libavsr_hip.so.  The residual stream is f32; tensors that
+feed contractions are stored in the *activation dtype*: bf16 in the default (bench) mode, f32 in ``precise``
+mode, where every contraction runs on split hi/lo bf16 planes (about 1e-5 relative error) for parity runs.
+
+Sub-layer functions (``ffn_sublayer``, ``relpos_mha_sublayer``, ``conv_sublayer``, ``mha_sublayer``) implement
+one pre-LN residual branch each, ``x + scale * dropout(f(LN(x)))``, forward and backward, so that the residual
+add, the dropout masks, bias / activation and the LayerNorm gradient are all fused into kernel epilogues.
+"""
+import contextlib
+import math
+
+import torch
+
+from . import ops
+from .ops import NN, NT, TN
+
+_state = {"precise": False, "seed": 0x5EED, "counter": 0, "seed_dev": None, "bn_sync": None}
+
+
+def set_precise(flag: bool):
+    _state["precise"] = bool(flag)
+
+
+def is_precise() -> bool:
+    return _state["precise"]
+
+
+@contextlib.contextmanager
+def precise(flag=True):
+    old = _state["precise"]
+    _state["precise"] = bool(flag)
+    try:
+        yield
+    finally:
+        _state["precise"] = old
+
+
+def act_dtype():
+    return torch.float32 if _state["precise"] else torch.bfloat16
+
+
+def manual_seed(seed: int):
+    _state["seed"] = int(seed) & 0xFFFFFFFF
+    _state["counter"] = 0
+
+
+def set_seed_tensor(t):
+    """Device-resident uint64 (stored as int64[1]) added to every dropout seed; bump it once per step so that a
+    captured hipGraph draws fresh masks on replay."""
+    _state["seed_dev"] = t
+
+
+def set_bn_sync(group_or_none):
+    """Cross-rank BatchNorm statistics (train.py:31 sync_batchnorm=True): a torch.distributed process group, or
+    None for single-process statistics."""
+    _state["bn_sync"] = group_or_none
+
+
+def _next_seed():
+    _state["counter"] += 1
+    return ((_state["seed"] * 0x9E3779B1) ^ (_state["counter"] * 0x85EBCA77)) & 0x7FFFFFFFFFFF
+
+
+def _drop_args(p, ref):
+    """(drop_p, seed, seed_dev) for one dropout site of one forward call."""
+    if p <= 0.0:
+        return 0.0, 0, None
+    t = _state["seed_dev"]
+    return float(p), _next_seed(), (t if (t is not None and t.device == ref.device) else None)
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def _rows(x):
+    return x.numel() // x.shape[-1]
+
+
+def _gemm_nt(a, w, M, N, K, out, *, lda=None, ldc=None, **kw):
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T)."""
+    return ops.gemm(NT, a, lda or K, w, K, M, N, K, out, ldc or N, precise=_state["precise"], **kw)
+
+
+def _gemm_nn(a, w, M, N, K, out, *, lda=None, ldb=None, ldc=None, **kw):
+    """out[M,N] = epi(a[M,K] @ w[K,N])  (data gradient: w is the [out=K, in=N] weight)."""
+    return ops.gemm(NN, a, lda or K, w, ldb or N, M, N, K, out, ldc or N, precise=_state["precise"], **kw)
+
+
+def _wgrad(dy, x, rows, n_out, n_in, lda=None, ldb=None):
+    """dW[n_out, n_in] = dy[rows, n_out]^T x[rows, n_in] (f32).  Small outputs are split along the token
+    dimension so that the launch still fills the 256 CUs."""
+    tiles = ((n_out + 63) // 64) * ((n_in + 63) // 64)
+    split = 1
+    if tiles < 192 and rows >= 512:
+        split = max(1, min(8, 256 // max(tiles, 1), rows // 256))
+    if split > 1:
+        dw = torch.zeros(n_out, n_in, dtype=torch.float32, device=dy.device)
+    else:
+        dw = torch.empty(n_out, n_in, dtype=torch.float32, device=dy.device)
+    ops.gemm(TN, dy, lda or n_out, x, ldb or n_in, n_out, n_in, rows, dw, n_in, precise=_state["precise"],
+             accumulate=split > 1, split_k=split)
+    return dw
+
+
+def _bgrad(dy, rows, n):
+    db = torch.zeros(n, dtype=torch.float32, device=dy.device)
+    ops.colsum_into(dy, db, rows, n)
+    return db
+
+
+def _to_act(x):
+    """Dense copy of x in the activation dtype, through the cast kernel (identity if nothing to do)."""
+    if x.dtype == act_dtype() and x.is_contiguous():
+        return x
+    return ops.scale_dropout(x.contiguous(), act_dtype())
+
+
+def _to_f32(x):
+    if x.dtype == torch.float32 and x.is_contiguous():
+        return x
+    return ops.scale_dropout(x.contiguous(), torch.float32)
+
+
+def _mask_arg(mask):
+    if mask is None:
+        return None
+    m = mask if mask.dtype in (torch.bool, torch.uint8) else (mask != 0)
+    assert m.dim() == 3, "mask must be (B,1,Tk) or (B,Tq,Tk)"
+    return m.contiguous()
+
+
+def padded_cols(n):
+    return (n + 7) // 8 * 8
+
+
+def _pitched_2d(t, rows, n):
+    """View `t` (logical [rows, n]) as a row-pitched matrix usable by the kernels: returns (tensor, ld) or None."""
+    if t.dim() < 2 or t.stride(-1) != 1:
+        return None
+    try:
+        t2 = t.view(rows, n) if t.is_contiguous() else t.reshape(rows, n) if t.dim() == 2 else None
+    except RuntimeError:
+        t2 = None
+    if t2 is None:
+        # a [..., :n] slice of a padded buffer: collapse leading dims when they are evenly pitched
+        ld = t.stride(-2)
+        lead = t.shape[:-1]
+        exp = ld
+        for size, stride in zip(reversed(lead), reversed(t.stride()[:-1])):
+            if size != 1 and stride != exp:
+                return None
+            exp *= size
+        t2 = t.as_strided((rows, n), (ld, 1))
+    ld = t2.stride(0)
+    if ld % 8 or t2.data_ptr() % 16:
+        return None
+    return t2, ld
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+class LayerNormFn(torch.autograd.Function):
+    """layer_norm.py:12-33 on an f32 input; output dtype selectable."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, out_dtype):
+        x = x.contiguous()
+        y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, out_dtype, eps)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        D = x.shape[-1]
+        dg = torch.zeros(D, dtype=torch.float32, device=x.device)
+        db = torch.zeros(D, dtype=torch.float32, device=x.device)
+        dx = ops.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dg, db)
+        return dx, dg, db, None, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-12, out_dtype=torch.float32):
+    return LayerNormFn.apply(_to_f32(x), gamma, beta, eps, out_dtype)
+
+
+# ------------------------------------------------------------------------------------------------ Linear
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b ; x (rows x in) any float dtype, W f32 [out, in].  With pad_out the result is a [..., :out]
+    view of a buffer whose row pitch is rounded up to 8 elements (vocabulary-sized heads)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, out_dtype, pad_out):
+        x2 = x.contiguous()
+        rows, K = _rows(x2), x2.shape[-1]
+        N = w.shape[0]
+        ldc = padded_cols(N) if pad_out else N
+        alloc = torch.zeros if ldc != N else torch.empty
+        y = alloc(x.shape[:-1] + (ldc,), dtype=out_dtype, device=x.device)
+        _gemm_nt(x2, w, rows, N, K, y, ldc=ldc, bias=b)
+        ctx.save_for_backward(x2, w)
+        ctx.meta = (b is not None, x.shape)
+        return y if ldc == N else y[..., :N]
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        has_b, xshape = ctx.meta
+        rows, K = _rows(x2), x2.shape[-1]
+        N = w.shape[0]
+        pit = _pitched_2d(dy, rows, N) if dy.dtype in (torch.float32, torch.bfloat16) else None
+        if pit is None:
+            ld = padded_cols(N)
+            buf = torch.zeros(rows, ld, dtype=dy.dtype if dy.dtype in (torch.float32, torch.bfloat16) else torch.float32,
+                              device=dy.device)
+            buf[:, :N].copy_(dy.reshape(rows, N))  # re-pitch (data movement only)
+            pit = (buf, ld)
+        d2, ldy = pit
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(xshape, dtype=torch.float32 if x2.dtype == torch.float32 else act_dtype(), device=dy.device)
+            _gemm_nn(d2, w, rows, K, N, dx, lda=ldy, ldb=K)
+        dw = _wgrad(d2, x2, rows, N, K, lda=ldy, ldb=K)
+        db = None
+        if has_b:
+            if ldy == N:
+                db = _bgrad(d2, rows, N)
+            else:  # padded columns hold zeros: summing the whole pitch is exact
+                db = _bgrad(d2, rows, ldy)[:N]
+        return dx, dw, db, None, None
+
+
+def linear(x, w, b=None, out_dtype=None, pad_out=False):
+    return LinearFn.apply(x, w, b, out_dtype or act_dtype(), pad_out)
+
+
+# ------------------------------------------------------------------------------------------------ FFN branch
+class FfnSublayerFn(torch.autograd.Function):
+    """x + scale * dropout(W2 dropout(relu(W1 LN(x) + b1)) + b2)
+    = conformer_encoder.py:110-116,154-159 / transformer_decoder.py:120-125 with
+      positionwise_feed_forward.py:28-30 (ReLU)."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, scale, p, eps):
+        x = x.contiguous()
+        rows, D = _rows(x), x.shape[-1]
+        Fh = w1.shape[0]
+        T = act_dtype()
+        h, mean, rstd = ops.layernorm_fwd(x, ln_w, ln_b, T, eps)
+        p1, s1, sd1 = _drop_args(p, x)
+        u = torch.empty(rows, Fh, dtype=T, device=x.device)
+        _gemm_nt(h, w1, rows, Fh, D, u, bias=b1, act=1, drop_p=p1, seed=s1, seed_dev=sd1)
+        p2, s2, sd2 = _drop_args(p, x)
+        y = torch.empty_like(x)
+        _gemm_nt(u, w2, rows, D, Fh, y, bias=b2, drop_p=p2, seed=s2, seed_dev=sd2, alpha=scale, resid=x, ldr=D)
+        ctx.save_for_backward(x, ln_w, mean, rstd, h, u, w1, w2)
+        ctx.meta = (scale, p1, p2, s2, sd2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, ln_w, mean, rstd, h, u, w1, w2 = ctx.saved_tensors
+        scale, p1, p2, s2, sd2 = ctx.meta
+        dy = dy.contiguous()
+        rows, D = _rows(x), x.shape[-1]
+        Fh = w1.shape[0]
+        T = act_dtype()
+        g = ops.scale_dropout(dy, T, alpha=scale, drop_p=p2, seed=s2, seed_dev=sd2)  # grad of the W2 output
+        db2 = _bgrad(g, rows, D)
+        dw2 = _wgrad(g, u, rows, D, Fh)
+        du = torch.empty(rows, Fh, dtype=T, device=x.device)
+        # relu' and the hidden dropout mask are both "u > 0" on the saved post-dropout activation
+        _gemm_nn(g, w2, rows, Fh, D, du, gate=u, ldg=Fh, gate_scale=1.0 / (1.0 - p1) if p1 > 0 else 1.0)
+        db1 = _bgrad(du, rows, Fh)
+        dw1 = _wgrad(du, h, rows, Fh, D)
+        dh = torch.empty(rows, D, dtype=T, device=x.device)
+        _gemm_nn(du, w1, rows, D, Fh, dh)
+        dg = torch.zeros(D, dtype=torch.float32, device=x.device)
+        dbt = torch.zeros(D, dtype=torch.float32, device=x.device)
+        dx = ops.layernorm_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dres=dy)
+        return dx, dg, dbt, dw1, db1, dw2, db2, None, None, None
+
+
+def ffn_sublayer(x, ln_w, ln_b, w1, b1, w2, b2, scale, p, eps=1e-12):
+    return FfnSublayerFn.apply(_to_f32(x), ln_w, ln_b, w1, b1, w2, b2, float(scale), float(p), eps)
+
+
+class FfnFn(torch.autograd.Function):
+    """Stand-alone positionwise_feed_forward.py:28-30 (no LayerNorm / residual): W2 dropout(relu(W1 x + b1)) + b2."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, p):
+        x2 = _to_act(x)
+        rows, D = _rows(x2), x2.shape[-1]
+        Fh = w1.shape[0]
+        T = act_dtype()
+        p1, s1, sd1 = _drop_args(p, x)
+        u = torch.empty(rows, Fh, dtype=T, device=x.device)
+        _gemm_nt(x2, w1, rows, Fh, D, u, bias=b1, act=1, drop_p=p1, seed=s1, seed_dev=sd1)
+        y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        _gemm_nt(u, w2, rows, D, Fh, y, bias=b2)
+        ctx.save_for_backward(x2, u, w1, w2)
+        ctx.p1 = p1
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, u, w1, w2 = ctx.saved_tensors
+        p1 = ctx.p1
+        rows, D = _rows(x2), x2.shape[-1]
+        Fh = w1.shape[0]
+        T = act_dtype()
+        g = _to_act(dy)
+        db2 = _bgrad(g, rows, D)
+        dw2 = _wgrad(g, u, rows, D, Fh)
+        du = torch.empty(rows, Fh, dtype=T, device=g.device)
+        _gemm_nn(g, w2, rows, Fh, D, du, gate=u, ldg=Fh, gate_scale=1.0 / (1.0 - p1) if p1 > 0 else 1.0)
+        db1 = _bgrad(du, rows, Fh)
+        dw1 = _wgrad(du, x2, rows, Fh, D)
+        dx = torch.empty(x2.shape, dtype=torch.float32, device=g.device)
+        _gemm_nn(du, w1, rows, D, Fh, dx)
+        return dx, dw1, db1, dw2, db2, None
+
+
+# ------------------------------------------------------------------------------------------------ attention cores
+def _proj(h, w, b, rows, D):
+    out = torch.empty(rows, w.shape[0], dtype=act_dtype(), device=h.device)
+    _gemm_nt(h, w, rows, w.shape[0], D, out, bias=b)
+    return out
+
+
+class AttentionCoreFn(torch.autograd.Function):
+    """Projections + fused attention + output projection of attention.py:90-104 / 153-193, *without* residual:
+    returns linear_out(softmax(...) v) as f32.  q_in / kv_in are activation-dtype or f32 (rows x D) inputs."""
+
+    @staticmethod
+    def forward(ctx, q_in, kv_in, pos_emb, mask, wq, bq, wk, bk, wv, bv, wo, bo, wpos, bias_u, bias_v, H, p_attn,
+                same_kv):
+        B, Tq, D = q_in.shape
+        Tk = kv_in.shape[1]
+        dk = D // H
+        T = act_dtype()
+        qa = _to_act(q_in)
+        ka = qa if same_kv else _to_act(kv_in)
+        q = _proj(qa, wq, bq, B * Tq, D)
+        k = _proj(ka, wk, bk, B * Tk, D)
+        v = _proj(ka, wv, bv, B * Tk, D)
+        relpos = pos_emb is not None
+        pe = pproj = qv = None
+        if relpos:
+            pe = _to_act(pos_emb.reshape(-1, D))
+            pproj = torch.empty(pe.shape[0], D, dtype=T, device=q.device)
+            _gemm_nt(pe, wpos, pe.shape[0], D, D, pproj)
+            qu, qv = ops.head_bias_fwd(q, D, B * Tq, D, bias_u.reshape(-1), bias_v.reshape(-1))
+        else:
+            qu = q
+        pa, sa, sda = _drop_args(p_attn, q_in)
+        m = _mask_arg(mask)
+        ctxv, lse = ops.attention_fwd(qu.view(B, Tq, H, dk), qv.view(B, Tq, H, dk) if relpos else None,
+                                      k.view(B, Tk, H, dk), v.view(B, Tk, H, dk), pproj, m, 1.0 / math.sqrt(dk),
+                                      precise=_state["precise"], drop_p=pa, seed=sa, seed_dev=sda)
+        y = torch.empty(B, Tq, D, dtype=torch.float32, device=q.device)
+        _gemm_nt(ctxv, wo, B * Tq, D, D, y, bias=bo)
+        ctx.save_for_backward(qa, ka, pe, m, wq, wk, wv, wo, wpos, qu, qv, k, v, pproj, ctxv, lse)
+        ctx.meta = (H, pa, sa, sda, same_kv, relpos, bq is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        qa, ka, pe, m, wq, wk, wv, wo, wpos, qu, qv, k, v, pproj, ctxv, lse = ctx.saved_tensors
+        H, pa, sa, sda, same_kv, relpos, has_b = ctx.meta
+        B, Tq, D = qa.shape
+        Tk = ka.shape[1]
+        dk = D // H
+        T = act_dtype()
+        g = _to_act(dy)
+        dbo = _bgrad(g, B * Tq, D)
+        dwo = _wgrad(g, ctxv, B * Tq, D, D)
+        dctx = torch.empty(B, Tq, D, dtype=T, device=g.device)
+        _gemm_nn(g, wo, B * Tq, D, D, dctx)
+        dqu, dqv, dk_, dv_, dpos = ops.attention_bwd(
+            qu.view(B, Tq, H, dk), qv.view(B, Tq, H, dk) if relpos else None, k.view(B, Tk, H, dk),
+            v.view(B, Tk, H, dk), pproj, m, ctxv, lse, dctx, 1.0 / math.sqrt(dk), precise=_state["precise"],
+            drop_p=pa, seed=sa, seed_dev=sda)
+        du = dv_bias = dwpos = None
+        if relpos:
+            dq = torch.empty(B * Tq, D, dtype=T, device=g.device)
+            du = torch.zeros(D, dtype=torch.float32, device=g.device)
+            dv_bias = torch.zeros(D, dtype=torch.float32, device=g.device)
+            ops.head_bias_bwd(dqu, dqv, dq, D, du, dv_bias, B * Tq, D)
+            du, dv_bias = du.view(H, dk), dv_bias.view(H, dk)
+            dwpos = _wgrad(dpos, pe, pe.shape[0], D, D)
+        else:
+            dq = dqu.view(B * Tq, D)
+        dk2, dv2 = dk_.view(B * Tk, D), dv_.view(B * Tk, D)
+        dwq, dwk, dwv = _wgrad(dq, qa, B * Tq, D, D), _wgrad(dk2, ka, B * Tk, D, D), _wgrad(dv2, ka, B * Tk, D, D)
+        dbq = dbk = dbv = None
+        if has_b:
+            dbq, dbk, dbv = _bgrad(dq, B * Tq, D), _bgrad(dk2, B * Tk, D), _bgrad(dv2, B * Tk, D)
+        dq_in = dkv_in = None
+        if same_kv:
+            t1 = torch.empty(B * Tq, D, dtype=torch.float32, device=g.device)
+            _gemm_nn(dq, wq, B * Tq, D, D, t1)
+            t2 = torch.empty_like(t1)
+            _gemm_nn(dk2, wk, B * Tk, D, D, t2, resid=t1, ldr=D)
+            dq_in = torch.empty(B, Tq, D, dtype=torch.float32, device=g.device)
+            _gemm_nn(dv2, wv, B * Tk, D, D, dq_in, resid=t2, ldr=D)
+        else:
+            if ctx.needs_input_grad[0]:
+                dq_in = torch.empty(B, Tq, D, dtype=torch.float32, device=g.device)
+                _gemm_nn(dq, wq, B * Tq, D, D, dq_in)
+            if ctx.needs_input_grad[1]:
+                t2 = torch.empty(B * Tk, D, dtype=torch.float32, device=g.device)
+                _gemm_nn(dk2, wk, B * Tk, D, D, t2)
+                dkv_in = torch.empty(B, Tk, D, dtype=torch.float32, device=g.device)
+                _gemm_nn(dv2, wv, B * Tk, D, D, dkv_in, resid=t2, ldr=D)
+        return (dq_in, dkv_in, None, None, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dwpos, du, dv_bias, None, None,
+                None)
+
+
+def attention_core(q_in, kv_in, pos_emb, mask, wq, bq, wk, bk, wv, bv, wo, bo, wpos, bias_u, bias_v, H, p_attn):
+    same = kv_in is q_in
+    return AttentionCoreFn.apply(q_in, q_in if same else kv_in, pos_emb, mask, wq, bq, wk, bk, wv, bv, wo, bo, wpos,
+                                 bias_u, bias_v, H, float(p_attn), same)
+
+
+class MhaSublayerFn(torch.autograd.Function):
+    """x + dropout(MHA(LN(x), kv, kv)):  conformer_encoder.py:119-142 (rel-pos self attention, kv = LN(x)) and
+    transformer_decoder.py:65-118 (self attention with kv = LN(x); source attention with kv = memory)."""
+
+    @staticmethod
+    def forward(ctx, x, memory, pos_emb, mask, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, wpos, bias_u, bias_v, H,
+                p_attn, p_out, eps):
+        x = x.contiguous()
+        B, Tq, D = x.shape
+        dk = D // H
+        T = act_dtype()
+        h, mean, rstd = ops.layernorm_fwd(x, ln_w, ln_b, T, eps)
+        cross = memory is not None
+        ka = _to_act(memory) if cross else h
+        Tk = ka.shape[1]
+        q = _proj(h, wq, bq, B * Tq, D)
+        k = _proj(ka, wk, bk, B * Tk, D)
+        v = _proj(ka, wv, bv, B * Tk, D)
+        relpos = pos_emb is not None
+        pe = pproj = qv = None
+        if relpos:
+            pe = _to_act(pos_emb.reshape(-1, D))
+            pproj = torch.empty(pe.shape[0], D, dtype=T, device=x.device)
+            _gemm_nt(pe, wpos, pe.shape[0], D, D, pproj)
+            qu, qv = ops.head_bias_fwd(q, D, B * Tq, D, bias_u.reshape(-1), bias_v.reshape(-1))
+        else:
+            qu = q
+        pa, sa, sda = _drop_args(p_attn, x)
+        m = _mask_arg(mask)
+        ctxv, lse = ops.attention_fwd(qu.view(B, Tq, H, dk), qv.view(B, Tq, H, dk) if relpos else None,
+                                      k.view(B, Tk, H, dk), v.view(B, Tk, H, dk), pproj, m, 1.0 / math.sqrt(dk),
+                                      precise=_state["precise"], drop_p=pa, seed=sa, seed_dev=sda)
+        po, so, sdo = _drop_args(p_out, x)
+        y = torch.empty_like(x)
+        _gemm_nt(ctxv, wo, B * Tq, D, D, y, bias=bo, drop_p=po, seed=so, seed_dev=sdo, resid=x, ldr=D)
+        ctx.save_for_backward(x, ln_w, mean, rstd, h, ka if cross else None, pe, m, wq, wk, wv, wo, wpos, qu, qv, k, v,
+                              pproj, ctxv, lse)
+        ctx.meta = (H, pa, sa, sda, po, so, sdo, cross, relpos)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x, ln_w, mean, rstd, h, ka, pe, m, wq, wk, wv, wo, wpos, qu, qv, k, v, pproj, ctxv, lse) = ctx.saved_tensors
+        H, pa, sa, sda, po, so, sdo, cross, relpos = ctx.meta
+        dy = dy.contiguous()
+        B, Tq, D = x.shape
+        if not cross:
+            ka = h
+        Tk = ka.shape[1]
+        dk = D // H
+        T = act_dtype()
+        g = ops.scale_dropout(dy, T, drop_p=po, seed=so, seed_dev=sdo)
+        dbo = _bgrad(g, B * Tq, D)
+        dwo = _wgrad(g, ctxv, B * Tq, D, D)
+        dctx = torch.empty(B, Tq, D, dtype=T, device=x.device)
+        _gemm_nn(g, wo, B * Tq, D, D, dctx)
+        dqu, dqv, dk_, dv_, dpos = ops.attention_bwd(
+            qu.view(B, Tq, H, dk), qv.view(B, Tq, H, dk) if relpos else None, k.view(B, Tk, H, dk),
+            v.view(B, Tk, H, dk), pproj, m, ctxv, lse, dctx, 1.0 / math.sqrt(dk), precise=_state["precise"],
+            drop_p=pa, seed=sa, seed_dev=sda)
+        du = dv_bias = dwpos = None
+        if relpos:
+            dq = torch.empty(B * Tq, D, dtype=T, device=x.device)
+            du = torch.zeros(D, dtype=torch.float32, device=x.device)
+            dv_bias = torch.zeros(D, dtype=torch.float32, device=x.device)
+            ops.head_bias_bwd(dqu, dqv, dq, D, du, dv_bias, B * Tq, D)
+            du, dv_bias = du.view(H, dk), dv_bias.view(H, dk)
+            dwpos = _wgrad(dpos, pe, pe.shape[0], D, D)
+        else:
+            dq = dqu.view(B * Tq, D)
+        dk2, dv2 = dk_.view(B * Tk, D), dv_.view(B * Tk, D)
+        dwq, dbq = _wgrad(dq, h, B * Tq, D, D), _bgrad(dq, B * Tq, D)
+        dwk, dbk = _wgrad(dk2, ka, B * Tk, D, D), _bgrad(dk2, B * Tk, D)
+        dwv, dbv = _wgrad(dv2, ka, B * Tk, D, D), _bgrad(dv2, B * Tk, D)
+        dmem = None
+        if cross:
+            dh = torch.empty(B * Tq, D, dtype=T, device=x.device)
+            _gemm_nn(dq, wq, B * Tq, D, D, dh)
+            if ctx.needs_input_grad[1]:
+                t2 = torch.empty(B * Tk, D, dtype=torch.float32, device=x.device)
+                _gemm_nn(dk2, wk, B * Tk, D, D, t2)
+                dmem = torch.empty(B, Tk, D, dtype=torch.float32, device=x.device)
+                _gemm_nn(dv2, wv, B * Tk, D, D, dmem, resid=t2, ldr=D)
+        else:
+            t1 = torch.empty(B * Tq, D, dtype=torch.float32, device=x.device)
+            _gemm_nn(dq, wq, B * Tq, D, D, t1)
+            t2 = torch.empty_like(t1)
+            _gemm_nn(dk2, wk, B * Tq, D, D, t2, resid=t1, ldr=D)
+            dh = torch.empty_like(t1)
+            _gemm_nn(dv2, wv, B * Tq, D, D, dh, resid=t2, ldr=D)
+        dg = torch.zeros(D, dtype=torch.float32, device=x.device)
+        dbt = torch.zeros(D, dtype=torch.float32, device=x.device)
+        dx = ops.layernorm_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dres=dy)
+        return (dx, dmem, None, None, dg, dbt, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dwpos, du, dv_bias, None, None,
+                None, None)
+
+
+def mha_sublayer(x, memory, pos_emb, mask, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, wpos, bias_u, bias_v, H, p_attn,
+                 p_out, eps=1e-12):
+    return MhaSublayerFn.apply(_to_f32(x), memory, pos_emb, mask, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, wpos,
+                               bias_u, bias_v, H, float(p_attn), float(p_out), eps)
+
+
+# ------------------------------------------------------------------------------------------------ BatchNorm plumbing
+def _bn_train_stats(c2, rows, C, eps, momentum, running_mean, running_var):
+    """Batch statistics (+ running-stat update) of a [rows, C] activation; merged across ranks when set_bn_sync()."""
+    stats = ops.bn_stats(c2, rows, C)
+    group = _state["bn_sync"]
+    if group is not None:
+        import torch.distributed as dist
+
+        W = dist.get_world_size(group)
+        mine = torch.cat([stats.reshape(-1), torch.tensor([float(rows)], device=c2.device)])
+        allv = torch.empty(W, mine.numel(), dtype=torch.float32, device=c2.device)
+        dist.all_gather_into_tensor(allv, mine, group=group)
+        counts = allv[:, -1].contiguous()
+        stats_all = allv[:, :-1].contiguous().view(W, 3, C)
+        mean, invstd = ops.bn_finalize(stats_all, counts, W, C, eps, momentum, running_mean, running_var)
+        n_total = None  # read on device below
+        return mean, invstd, counts
+    counts = torch.tensor([float(rows)], device=c2.device)
+    mean, invstd = ops.bn_finalize(stats.unsqueeze(0), counts, 1, C, eps, momentum, running_mean, running_var)
+    return mean, invstd, counts
+
+
+def _bn_bwd_sums(sums, counts, rows):
+    """All-reduce the backward sums across the sync group; returns (sums_for_dx, inv_n, n_dev)."""
+    group = _state["bn_sync"]
+    if group is None:
+        return sums, 1.0 / rows, None
+    import torch.distributed as dist
+
+    tot = sums.clone()
+    dist.all_reduce(tot, group=group)
+    return tot, 0.0, ops.sum_scale(counts, 1.0)  # global row count stays on the device (no host sync)
+
+
+class ConvSublayerFn(torch.autograd.Function):
+    """x + dropout(ConvolutionModule(LN(x))):  conformer_encoder.py:145-151,30-35.
+    pointwise(D->2D) -> GLU -> depthwise(K) -> BatchNorm1d (batch stats over every frame) -> SiLU -> pointwise."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w_pw1, b_pw1, w_dw, b_dw, bn_w, bn_b, bn_rm, bn_rv, w_pw2, b_pw2, training,
+                momentum, bn_eps, p_out, eps):
+        x = x.contiguous()
+        B, Tn, D = x.shape
+        rows = B * Tn
+        K = w_dw.shape[-1]
+        T = act_dtype()
+        fused = ln_w is not None  # False: bare ConvolutionModule.forward (no LayerNorm, no residual)
+        if fused:
+            h, mean, rstd = ops.layernorm_fwd(x, ln_w, ln_b, T, eps)
+        else:
+            h, mean, rstd = _to_act(x), None, None
+        a = torch.empty(rows, 2 * D, dtype=T, device=x.device)
+        _gemm_nt(h, w_pw1.view(2 * D, D), rows, 2 * D, D, a, bias=b_pw1)
+        gl = ops.glu_fwd(a, rows, D)
+        wdw = w_dw.view(D, K)
+        c = ops.dwconv(gl, wdw, b_dw, B, Tn, D, K)
+        if training:
+            bmean, binv, counts = _bn_train_stats(c, rows, D, bn_eps, momentum, bn_rm, bn_rv)
+        else:
+            bmean, binv = ops.bn_eval_params(bn_rm, bn_rv, bn_eps)
+            counts = None
+        s = ops.bn_act_fwd(c, None, bmean, binv, bn_w, bn_b, rows, D, 1)
+        po, so, sdo = _drop_args(p_out, x)
+        y = torch.empty_like(x)
+        _gemm_nt(s, w_pw2.view(D, D), rows, D, D, y, bias=b_pw2, drop_p=po, seed=so, seed_dev=sdo,
+                 resid=x if fused else None, ldr=D)
+        ctx.save_for_backward(x, ln_w, mean, rstd, h, a, gl, c, bmean, binv, bn_w, bn_b, s, w_pw1, wdw, w_pw2, counts)
+        ctx.meta = (training, po, so, sdo, K, fused)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x, ln_w, mean, rstd, h, a, gl, c, bmean, binv, bn_w, bn_b, s, w_pw1, wdw, w_pw2, counts) = ctx.saved_tensors
+        training, po, so, sdo, K, fused = ctx.meta
+        dy = dy.contiguous()
+        B, Tn, D = x.shape
+        rows = B * Tn
+        T = act_dtype()
+        g = ops.scale_dropout(dy, T, drop_p=po, seed=so, seed_dev=sdo)
+        db2 = _bgrad(g, rows, D)
+        dw2 = _wgrad(g, s, rows, D, D).view(D, D, 1)
+        ds = torch.empty(rows, D, dtype=T, device=x.device)
+        _gemm_nn(g, w_pw2.view(D, D), rows, D, D, ds)
+        sums = ops.bn_bwd_reduce(c, ds, None, bmean, binv, bn_w, bn_b, rows, D, 1)
+        dbn_w, dbn_b = sums[1].clone(), sums[0].clone()
+        if training:
+            sums_dx, inv_n, n_dev = _bn_bwd_sums(sums, counts, rows)
+        else:
+            sums_dx, inv_n, n_dev = torch.zeros_like(sums), 0.0, None
+        dc, _ = ops.bn_bwd_apply(c, ds, None, bmean, binv, bn_w, bn_b, sums_dx, inv_n, rows, D, 1, False, n_dev=n_dev)
+        dwdw = torch.zeros(D, K, dtype=torch.float32, device=x.device)
+        dbdw = torch.zeros(D, dtype=torch.float32, device=x.device)
+        ops.dwconv_wgrad(gl, dc, dwdw, dbdw, B, Tn, D, K)
+        dgl = ops.dwconv(dc, wdw, None, B, Tn, D, K, flip=True)
+        da = ops.glu_bwd(a, dgl, rows, D)
+        db1 = _bgrad(da, rows, 2 * D)
+        dw1 = _wgrad(da, h, rows, 2 * D, D).view(2 * D, D, 1)
+        if fused:
+            dh = torch.empty(rows, D, dtype=T, device=x.device)
+            _gemm_nn(da, w_pw1.view(2 * D, D), rows, D, 2 * D, dh)
+            dg = torch.zeros(D, dtype=torch.float32, device=x.device)
+            dbt = torch.zeros(D, dtype=torch.float32, device=x.device)
+            dx = ops.layernorm_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dres=dy)
+        else:
+            dg = dbt = None
+            dx = torch.empty(B, Tn, D, dtype=torch.float32, device=x.device)
+            _gemm_nn(da, w_pw1.view(2 * D, D), rows, D, 2 * D, dx)
+        return (dx, dg, dbt, dw1, db1, dwdw.view(D, 1, K), dbdw, dbn_w, dbn_b, None, None, dw2, db2, None, None, None,
+                None, None)
+
+
+def conv_sublayer(x, ln_w, ln_b, w_pw1, b_pw1, w_dw, b_dw, bn, w_pw2, b_pw2, p_out, eps=1e-12):
+    """bn: the torch.nn.BatchNorm1d module holding weight / bias / running stats (updated in place in training).
+    ln_w = ln_b = None gives the bare module (no LayerNorm, no residual, no output dropout)."""
+    training = bn.training
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    momentum = bn.momentum if bn.momentum is not None else 0.1
+    return ConvSublayerFn.apply(_to_f32(x), ln_w, ln_b, w_pw1, b_pw1, w_dw, b_dw, bn.weight, bn.bias, bn.running_mean,
+                                bn.running_var, w_pw2, b_pw2, training, float(momentum), float(bn.eps), float(p_out),
+                                eps)
+
+
+# ------------------------------------------------------------------------------------------------ misc
+class ScaleDropoutFn(torch.autograd.Function):
+    """alpha * dropout(x) -> f32   (embedding.py:179-184: x*sqrt(d) then dropout; ctc.py:54 dropout)."""
+
+    @staticmethod
+    def forward(ctx, x, alpha, p, out_dtype):
+        pp, s, sd = _drop_args(p, x)
+        ctx.meta = (alpha, pp, s, sd, x.dtype)
+        return ops.scale_dropout(x.contiguous(), out_dtype, alpha=alpha, drop_p=pp, seed=s, seed_dev=sd)
+
+    @staticmethod
+    def backward(ctx, dy):
+        alpha, pp, s, sd, in_dtype = ctx.meta
+        out = torch.float32 if in_dtype == torch.float32 else act_dtype()
+        return ops.scale_dropout(dy.contiguous(), out, alpha=alpha, drop_p=pp, seed=s, seed_dev=sd), None, None, None
+
+
+def scale_dropout(x, alpha=1.0, p=0.0, out_dtype=torch.float32):
+    return ScaleDropoutFn.apply(x, float(alpha), float(p), out_dtype)
+
+
+class EmbedFn(torch.autograd.Function):
+    """dropout(table[ids]*sqrt(d) + pe[pos])   transformer_decoder.py:186-189 + embedding.py:78-87."""
+
+    @staticmethod
+    def forward(ctx, ids, table, pe, scale, p):
+        L = ids.shape[-1]
+        pp, s, sd = _drop_args(p, table)
+        ids = ids.contiguous()
+        ctx.save_for_backward(ids)
+        ctx.meta = (scale, pp, s, sd, table.shape)
+        return ops.embed_fwd(ids, table, pe[:L].contiguous(), L, scale, pp, s, sd)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ids,) = ctx.saved_tensors
+        scale, pp, s, sd, tshape = ctx.meta
+        dt = torch.zeros(tshape, dtype=torch.float32, device=dy.device)
+        ops.embed_bwd(ids, _to_f32(dy), dt, scale, pp, s, sd)
+        return None, dt, None, None, None
+
+
+def embed(ids, table, pe, scale, p):
+    return EmbedFn.apply(ids, table, pe, float(scale), float(p))
+
+
+# ------------------------------------------------------------------------------------------------ loss heads
+class CtcLossFn(torch.autograd.Function):
+    """ctc.py:32-38: log_softmax + CTCLoss(sum, zero_infinity) / B on f32 logits [B,T,V] (possibly a [..., :V]
+    view of a pitch-padded buffer).  The gradient is produced by the forward kernels."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, in_lens, ignore_id):
+        B, Tn, V = logits.shape
+        pit = _pitched_2d(logits, B * Tn, V)
+        if pit is None or logits.dtype != torch.float32:
+            ld = padded_cols(V)
+            buf = torch.zeros(B * Tn, ld, dtype=torch.float32, device=logits.device)
+            buf[:, :V].copy_(logits.reshape(B * Tn, V))
+            pit = (buf, ld)
+        l2, ld = pit
+        lab = labels.reshape(B, -1).contiguous()
+        nll, grad = ops.ctc_loss(l2, ld, lab, in_lens.to(torch.int64).contiguous(), B, Tn, V,
+                                 want_grad=True, ignore_id=ignore_id)
+        loss = ops.sum_finite_scale(nll, 1.0 / B)
+        ctx.save_for_backward(grad)
+        ctx.meta = (B, Tn, V, ld)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        B, Tn, V, ld = ctx.meta
+        d = ops.scale_dropout(grad, torch.float32, alpha=1.0 / B, alpha_dev=g.reshape(1).to(torch.float32).contiguous())
+        return d.view(B, Tn, ld)[..., :V], None, None, None
+
+
+def ctc_loss(logits, labels, in_lens, ignore_id=-1):
+    return CtcLossFn.apply(logits, labels, in_lens, ignore_id)
+
+
+class CeSmoothFn(torch.autograd.Function):
+    """label_smoothing_loss.py:41-63 (sum over tokens / B) + nets_utils.py:272-292 accuracy, on f32 logits
+    [B,L,V].  Returns (loss, n_hits, n_valid) as device scalars."""
+
+    @staticmethod
+    def forward(ctx, logits, target, smoothing, ignore_id, denom):
+        V = logits.shape[-1]
+        rows = logits.numel() // V
+        pit = _pitched_2d(logits, rows, V)
+        if pit is None or logits.dtype != torch.float32:
+            ld = padded_cols(V)
+            buf = torch.zeros(rows, ld, dtype=torch.float32, device=logits.device)
+            buf[:, :V].copy_(logits.reshape(rows, V))
+            pit = (buf, ld)
+        l2, ld = pit
+        tgt = target.reshape(-1).to(torch.int64).contiguous()
+        row_loss, row_hit, grad = ops.ce_smooth(l2, ld, tgt, V, smoothing, want_grad=True, ignore_id=ignore_id)
+        loss = ops.sum_scale(row_loss, 1.0 / denom)
+        hits = ops.sum_scale(row_hit, 1.0)
+        ctx.save_for_backward(grad)
+        ctx.meta = (logits.shape, ld, denom)
+        ctx.mark_non_differentiable(hits)
+        return loss.view(()), hits.view(())
+
+    @staticmethod
+    def backward(ctx, g, _gh):
+        (grad,) = ctx.saved_tensors
+        shape, ld, denom = ctx.meta
+        d = ops.scale_dropout(grad, torch.float32, alpha=1.0 / denom,
+                              alpha_dev=g.reshape(1).to(torch.float32).contiguous())
+        return d.view(shape[:-1] + (ld,))[..., : shape[-1]], None, None, None, None
+
+
+def ce_smooth(logits, target, smoothing, ignore_id, denom):
+    return CeSmoothFn.apply(logits, target, float(smoothing), int(ignore_id), float(denom))
+
+
+class AddRowsFn(torch.autograd.Function):
+    """dropout(x*scale + table[t])  for x (B, n, D), table (n, D) -- embedding.py:78-87 as a stand-alone module."""
+
+    @staticmethod
+    def forward(ctx, x, table, scale, p):
+        pp, s, sd = _drop_args(p, x)
+        ctx.meta = (scale, pp, s, sd)
+        return ops.scale_dropout(x.contiguous(), torch.float32, alpha=scale, drop_p=pp, seed=s, seed_dev=sd,
+                                 add=table, add_period=table.numel())
+
+    @staticmethod
+    def backward(ctx, dy):
+        scale, pp, s, sd = ctx.meta
+        return ops.scale_dropout(dy.contiguous(), torch.float32, alpha=scale, drop_p=pp, seed=s, seed_dev=sd), None, None, None
+
+
+def add(a, b):
+    """a + b (f32 result; inference-time glue of the incremental decoder, no autograd)."""
+    bb = _to_f32(b)
+    return ops.scale_dropout(a.contiguous(), torch.float32, add=bb, add_period=bb.numel())
+
+
+def log_softmax(logits):
+    """Row-wise log-softmax of f32 logits [..., V] (possibly a [..., :V] view of a pitch-padded buffer); inference
+    helper of ctc.py:76-83 and transformer_decoder.py:288."""
+    V = logits.shape[-1]
+    rows = logits.numel() // V
+    pit = _pitched_2d(logits, rows, V)
+    if pit is None or logits.dtype != torch.float32:
+        ld = padded_cols(V)
+        buf = torch.zeros(rows, ld, dtype=torch.float32, device=logits.device)
+        buf[:, :V].copy_(logits.reshape(rows, V))
+        pit = (buf, ld)
+    l2, ld = pit
+    out = ops.log_softmax(l2, ld, rows, V)
+    return out.view(logits.shape[:-1] + (ld,))[..., :V]

@@ -57,15 +57,15 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None):
 
 
 def gemm(layout, A, lda, B, ldb, M, N, K, C, ldc, *, precise=False, bias=None, act=0, gate=None, ldg=0,
-         gate_scale=1.0, drop_p=0.0, seed=0, alpha=1.0, resid=None, ldr=0, accumulate=False, split_k=1,
-         force_tile=0):
+         gate_scale=1.0, drop_p=0.0, seed=0, seed_dev=None, alpha=1.0, alpha_dev=None, resid=None, ldr=0,
+         accumulate=False, split_k=1, force_tile=0):
     call("avsr_gemm", layout, _ptr(A), dt(A), lda, _ptr(B), dt(B), ldb, M, N, K, int(precise), _ptr(bias), act,
-         _ptr(gate), dt(gate) if gate is not None else 0, ldg, gate_scale, drop_p, seed, alpha, _ptr(resid), ldr,
+         _ptr(gate), dt(gate) if gate is not None else 0, ldg, gate_scale, drop_p, seed, _ptr(seed_dev), alpha, _ptr(alpha_dev), _ptr(resid), ldr,
          _ptr(C), dt(C), ldc, int(accumulate), split_k, force_tile, _stream(A))
     return C
 
 
-def attention_fwd(qu, qv, k, v, pos, mask, scale, *, precise=False, drop_p=0.0, seed=0):
+def attention_fwd(qu, qv, k, v, pos, mask, scale, *, precise=False, drop_p=0.0, seed=0, seed_dev=None):
     """qu/qv/k/v: [B,T,H,64] (possibly strided views with contiguous last two dims); pos: [2T-1, H*64] or None;
     mask: uint8/bool [B,1,Tk] or [B,Tq,Tk] or None.  Returns (out [B,Tq,H*64], lse [B,H,Tq])."""
     B, Tq, H, dk = qu.shape
@@ -80,11 +80,12 @@ def attention_fwd(qu, qv, k, v, pos, mask, scale, *, precise=False, drop_p=0.0, 
     call("avsr_attention_fwd", _ptr(qu), _ptr(qv), _ptr(k), _ptr(v), _ptr(pos), dt(qu), int(precise), _ptr(mask),
          msb, msq, _ptr(out), _ptr(lse), B, H, Tq, Tk, dk, qu.stride(1), k.stride(1), v.stride(1),
          pos.stride(0) if pos is not None else 0, out.stride(1), qu.stride(0), k.stride(0), v.stride(0),
-         out.stride(0), scale, drop_p, seed, _stream(qu))
+         out.stride(0), scale, drop_p, seed, _ptr(seed_dev), _stream(qu))
     return out, lse
 
 
-def attention_bwd_dq(qu, qv, k, v, pos, mask, out, lse, dout, scale, *, precise=False, drop_p=0.0, seed=0):
+def attention_bwd_dq(qu, qv, k, v, pos, mask, out, lse, dout, scale, *, precise=False, drop_p=0.0, seed=0,
+                     seed_dev=None):
     B, Tq, H, dk = qu.shape
     Tk = k.shape[1]
     lds = (Tk + 7) // 8 * 8
@@ -101,7 +102,7 @@ def attention_bwd_dq(qu, qv, k, v, pos, mask, out, lse, dout, scale, *, precise=
     call("avsr_attention_bwd_dq", _ptr(qu), _ptr(qv), _ptr(k), _ptr(v), _ptr(pos), dt(qu), int(precise), _ptr(mask),
          msb, msq, _ptr(out), _ptr(lse), _ptr(dout), _ptr(dqu), _ptr(dqv), _ptr(pd), _ptr(ds), lds, B, H, Tq, Tk, dk,
          qu.stride(1), k.stride(1), v.stride(1), pos.stride(0) if pos is not None else 0, out.stride(1),
-         qu.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, drop_p, seed, _stream(qu))
+         qu.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, drop_p, seed, _ptr(seed_dev), _stream(qu))
     return dqu, dqv, pd, ds
 
 
@@ -112,13 +113,14 @@ def gemm_tn_batched(A, lda, sAb, sAh, Bm, ldb, sBb, sBh, C, ldc, sCb, sCh, nb, n
     return C
 
 
-def attention_bwd(qu, qv, k, v, pos, mask, out, lse, dout, scale, *, precise=False, drop_p=0.0, seed=0):
+def attention_bwd(qu, qv, k, v, pos, mask, out, lse, dout, scale, *, precise=False, drop_p=0.0, seed=0,
+                  seed_dev=None):
     """Full attention backward.  Returns dqu, dqv (or None), dk, dv, dpos (f32 [2T-1, H*64] or None)."""
     B, Tq, H, dk = qu.shape
     Tk = k.shape[1]
     D = H * dk
     dqu, dqv, pd, ds = attention_bwd_dq(qu, qv, k, v, pos, mask, out, lse, dout, scale, precise=precise,
-                                        drop_p=drop_p, seed=seed)
+                                        drop_p=drop_p, seed=seed, seed_dev=seed_dev)
     lds = pd.shape[-1]
     dkk = torch.empty(B, Tk, H, dk, dtype=qu.dtype, device=qu.device)
     dvv = torch.empty(B, Tk, H, dk, dtype=qu.dtype, device=qu.device)
@@ -137,9 +139,11 @@ def attention_bwd(qu, qv, k, v, pos, mask, out, lse, dout, scale, *, precise=Fal
     return dqu, dqv, dkk, dvv, dpos
 
 
-def scale_dropout(x, out_dtype, alpha=1.0, drop_p=0.0, seed=0):
+def scale_dropout(x, out_dtype, alpha=1.0, drop_p=0.0, seed=0, alpha_dev=None, seed_dev=None, add=None,
+                  add_period=0):
     out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
-    call("avsr_scale_dropout", _ptr(x), dt(x), _ptr(out), dt(out), x.numel(), alpha, drop_p, seed, _stream(x))
+    call("avsr_scale_dropout", _ptr(x), dt(x), _ptr(out), dt(out), x.numel(), alpha, _ptr(alpha_dev), drop_p, seed,
+         _ptr(seed_dev), _ptr(add), add_period, _stream(x))
     return out
 
 
@@ -219,11 +223,11 @@ def bn_bwd_reduce(x, dy, add, mean, invstd, gamma, beta, rows, C, act):
     return sums
 
 
-def bn_bwd_apply(x, dy, add, mean, invstd, gamma, beta, sums, inv_n, rows, C, act, want_dadd):
+def bn_bwd_apply(x, dy, add, mean, invstd, gamma, beta, sums, inv_n, rows, C, act, want_dadd, n_dev=None):
     dx = torch.empty_like(x)
     dadd = torch.empty_like(x) if want_dadd else None
     call("avsr_bn_bwd_apply", _ptr(x), _ptr(dy), _ptr(add), dt(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
-         _ptr(sums), inv_n, _ptr(dx), _ptr(dadd), rows, C, act, _stream(x))
+         _ptr(sums), inv_n, _ptr(n_dev), _ptr(dx), _ptr(dadd), rows, C, act, _stream(x))
     return dx, dadd
 
 
@@ -250,19 +254,32 @@ def ce_smooth(logits, ld, target, V, smoothing, want_grad=True, ignore_id=-1):
     return row_loss, row_hit, grad
 
 
-def sum_scale(a, scale):
+def sum_scale(a, scale, finite_only=False):
     out = torch.empty(1, dtype=torch.float32, device=a.device)
-    call("avsr_sum_scale", _ptr(a), a.numel(), scale, _ptr(out), _stream(a))
+    call("avsr_sum_scale", _ptr(a), a.numel(), scale, _ptr(out), int(finite_only), _stream(a))
     return out
 
 
-def embed_fwd(ids, table, pe, L, scale, drop_p=0.0, seed=0):
+def sum_finite_scale(a, scale):
+    return sum_scale(a, scale, finite_only=True)
+
+
+def embed_fwd(ids, table, pe, L, scale, drop_p=0.0, seed=0, seed_dev=None):
     rows, D = ids.numel(), table.shape[1]
     out = torch.empty(*ids.shape, D, dtype=torch.float32, device=table.device)
-    call("avsr_embed_fwd", _ptr(ids), _ptr(table), _ptr(pe), _ptr(out), rows, L, D, scale, drop_p, seed, _stream(table))
+    call("avsr_embed_fwd", _ptr(ids), _ptr(table), _ptr(pe), _ptr(out), rows, L, D, scale, drop_p, seed, _ptr(seed_dev),
+         _stream(table))
     return out
 
 
-def embed_bwd(ids, dout, dtable, scale, drop_p=0.0, seed=0):
+def embed_bwd(ids, dout, dtable, scale, drop_p=0.0, seed=0, seed_dev=None):
     rows, D = ids.numel(), dtable.shape[1]
-    call("avsr_embed_bwd", _ptr(ids), _ptr(dout), _ptr(dtable), rows, D, scale, drop_p, seed, _stream(dout))
+    call("avsr_embed_bwd", _ptr(ids), _ptr(dout), _ptr(dtable), rows, D, scale, drop_p, seed, _ptr(seed_dev),
+         _stream(dout))
+
+
+def log_softmax(x, ld, rows, V):
+    out = torch.zeros_like(x)
+    ws = torch.empty(rows, dtype=torch.float32, device=x.device)
+    call("avsr_log_softmax", _ptr(x), ld, _ptr(ws), _ptr(out), rows, V, _stream(x))
+    return out

@@ -47,12 +47,14 @@ int avsr_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float
  * precise=1: f32 operands split into hi+lo bf16 planes (3 MFMAs per product, ~1e-5 rel error).
  * epilogue order: +bias[n] -> act (0 none,1 relu,2 silu) -> gate (v = gate[m,n]>0 ? v*gate_scale : 0)
  *   -> dropout(drop_p, seed) -> *alpha -> +resid[m,n] -> store (c_dtype) or atomicAdd (accumulate=1, f32).
+ * seed_dev / alpha_dev (may be NULL): device-resident scalars added to seed / multiplied into alpha, so that a
+ * captured hipGraph replays with fresh dropout masks and live upstream gradients.
  * split_k>1 requires accumulate=1.  force_tile: 0 auto, 64 or 128. */
 int avsr_gemm(int layout, const void* A, int a_dtype, int lda, const void* B, int b_dtype, int ldb,
               int M, int N, int K, int precise, const float* bias, int act, const void* gate,
-              int gate_dtype, int ldg, float gate_scale, float drop_p, uint64_t seed, float alpha,
-              const float* resid, int ldr, void* C, int c_dtype, int ldc, int accumulate, int split_k,
-              int force_tile, avsr_stream_t stream);
+              int gate_dtype, int ldg, float gate_scale, float drop_p, uint64_t seed, const uint64_t* seed_dev,
+              float alpha, const float* alpha_dev, const float* resid, int ldr, void* C, int c_dtype, int ldc,
+              int accumulate, int split_k, int force_tile, avsr_stream_t stream);
 
 /* ---- fused multi-head attention (attention.py:59-104,131-193) ----------------------------- */
 /* out[b,i,h,:] = softmax_j( scale*(qu_i.k_j + [pos!=NULL] qv_i.pos[j-i+Tq-1]) , mask ) @ v ; d_k = 64.
@@ -63,7 +65,7 @@ int avsr_attention_fwd(const void* qu, const void* qv, const void* k, const void
                        int dtype, int precise, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq,
                        void* out, float* lse, int B, int H, int Tq, int Tk, int dk, int ldq, int ldk,
                        int ldv, int ldp, int ldo, int64_t sbq, int64_t sbk, int64_t sbv, int64_t sbo,
-                       float scale, float drop_p, uint64_t seed, avsr_stream_t stream);
+                       float scale, float drop_p, uint64_t seed, const uint64_t* seed_dev, avsr_stream_t stream);
 /* backward, query side: recomputes P from lse; writes dqu (and dqv), plus pd = dropout(P) and
  * ds = scale*dS as [B,H,Tq,lds] tensors from which dK, dV and dpos follow as batched TN GEMMs. */
 int avsr_attention_bwd_dq(const void* qu, const void* qv, const void* k, const void* v, const void* pos,
@@ -71,7 +73,8 @@ int avsr_attention_bwd_dq(const void* qu, const void* qv, const void* k, const v
                           const void* out, const float* lse, const void* dout, void* dqu, void* dqv,
                           void* pd, void* ds, int lds, int B, int H, int Tq, int Tk, int dk, int ldq,
                           int ldk, int ldv, int ldp, int ldo, int64_t sbq, int64_t sbk, int64_t sbv,
-                          int64_t sbo, float scale, float drop_p, uint64_t seed, avsr_stream_t stream);
+                          int64_t sbo, float scale, float drop_p, uint64_t seed, const uint64_t* seed_dev,
+                          avsr_stream_t stream);
 
 /* batched TN contraction over (b,h) for the attention backward (dV = Pd^T dO, dK = dS^T Qu, dpos = skew(dS)^T Qv):
  * C[b,h][M,N] (+)= sum_k A[b,h][k,m] * B[b,h][k,n]; operand (b,h) slices start at b*s?b + h*s?h elements.
@@ -83,9 +86,11 @@ int avsr_gemm_tn_batched(const void* A, int a_dtype, int lda, int64_t sAb, int64
                          int accumulate, int a_skew, int skew_off, int skew_lim, avsr_stream_t stream);
 
 /* ---- elementwise glue (elementwise.hip) --------------------------------------------------- */
-/* out = alpha * dropout(x)   (embedding.py:179-184; dropout branches of conformer_encoder.py:114-157, ctc.py:54) */
+/* out = dropout(alpha*x + add[i % add_period])   (add may be NULL; embedding.py:78-87,179-184; the dropout
+ * branches of conformer_encoder.py:114-157 on the backward side; ctc.py:54) */
 int avsr_scale_dropout(const void* x, int x_dtype, void* out, int out_dtype, int64_t n, float alpha,
-                       float drop_p, uint64_t seed, avsr_stream_t stream);
+                       const float* alpha_dev, float drop_p, uint64_t seed, const uint64_t* seed_dev,
+                       const float* add, int64_t add_period, avsr_stream_t stream);
 /* o1 = x + b1[col], o2 = x + b2[col]  (q + pos_bias_u / q + pos_bias_v, attention.py:176-178); o1,o2 dense */
 int avsr_head_bias_fwd(const void* x, int dtype, int64_t ldx, const float* b1, const float* b2, void* o1,
                        void* o2, int64_t rows, int cols, avsr_stream_t stream);
@@ -123,10 +128,12 @@ int avsr_bn_act_fwd(const void* x, const void* add, int dtype, const float* mean
 int avsr_bn_bwd_reduce(const void* x, const void* dy, const void* add, int dtype, const float* mean,
                        const float* invstd, const float* gamma, const float* beta, float* sums, int64_t rows,
                        int C, int act, avsr_stream_t stream);
-/* dx = gamma*invstd*(dz - sums0*inv_n - xhat*sums1*inv_n); dadd = dz (NULL skips) */
+/* dx = gamma*invstd*(dz - sums0*inv_n - xhat*sums1*inv_n); dadd = dz (NULL skips); n_dev != NULL overrides
+ * inv_n with 1 / *n_dev (device-resident global row count under cross-rank statistics) */
 int avsr_bn_bwd_apply(const void* x, const void* dy, const void* add, int dtype, const float* mean,
                       const float* invstd, const float* gamma, const float* beta, const float* sums,
-                      float inv_n, void* dx, void* dadd, int64_t rows, int C, int act, avsr_stream_t stream);
+                      float inv_n, const float* n_dev, void* dx, void* dadd, int64_t rows, int C, int act,
+                      avsr_stream_t stream);
 
 /* ---- loss heads and decoder embedding (loss.hip) ------------------------------------------- */
 int avsr_row_lse(const void* x, int dtype, int64_t ld, float* lse, int64_t rows, int V, avsr_stream_t stream);
@@ -142,12 +149,17 @@ int avsr_ctc_loss(const void* logits, int dtype, int64_t ld, const int64_t* labe
 int avsr_ce_smooth(const void* logits, int dtype, int64_t ld, const int64_t* target, int ignore_id, int V,
                    float smoothing, float* row_loss, float* row_hit, void* grad, int64_t ldg, int64_t rows,
                    avsr_stream_t stream);
-int avsr_sum_scale(const float* a, int n, float scale, float* out, avsr_stream_t stream);
+/* out[0] = scale * sum(a[0..n)); finite_only skips +-inf entries (zero_infinity of ctc.py:26-28) */
+int avsr_sum_scale(const float* a, int n, float scale, float* out, int finite_only, avsr_stream_t stream);
 /* out[r,:] = dropout(table[ids[r],:]*scale + pe[r % L,:])  (transformer_decoder.py:186-189, embedding.py:78-87) */
 int avsr_embed_fwd(const int64_t* ids, const float* table, const float* pe, float* out, int64_t rows, int L,
-                   int D, float scale, float drop_p, uint64_t seed, avsr_stream_t stream);
+                   int D, float scale, float drop_p, uint64_t seed, const uint64_t* seed_dev, avsr_stream_t stream);
 int avsr_embed_bwd(const int64_t* ids, const float* dout, float* dtable, int64_t rows, int D, float scale,
-                   float drop_p, uint64_t seed, avsr_stream_t stream);
+                   float drop_p, uint64_t seed, const uint64_t* seed_dev, avsr_stream_t stream);
+
+/* out[r,:V] = x[r,:V] - logsumexp(x[r,:V]); f32, same pitch ld for x and out; lse_ws: [rows] scratch */
+int avsr_log_softmax(const float* x, int64_t ld, float* lse_ws, float* out, int64_t rows, int V,
+                     avsr_stream_t stream);
 
 #ifdef __cplusplus
 }

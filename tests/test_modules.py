@@ -1,0 +1,106 @@
+"""Module-level parity of the HIP-backed nn.Module tree against (a) the reference-generated golden vectors and
+(b) the oracle, in precise mode (split-bf16 contractions) with dropout off.  Runs on the emulator build in the
+CPU suite and on the gfx950 build under -m gpu."""
+import os
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+from synth import synth_batch, synth_state_dict  # noqa: E402
+
+import avsr_oracle as O  # noqa: E402
+from auto_avsr_amd import functional as AF  # noqa: E402
+from auto_avsr_amd import nets  # noqa: E402
+from auto_avsr_amd.e2e import E2E  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return torch.load(os.path.join(HERE, "golden", "golden_v1.pt"), weights_only=False)
+
+
+def no_dropout(m):
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    return m
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-12)).item()
+
+
+def check_grad_norms(model, ref_norms, rtol):
+    atol = 1e-4 * max(ref_norms.values())
+    bad = []
+    for k, p in model.named_parameters():
+        got = float(p.grad.double().norm()) if p.grad is not None else 0.0
+        if abs(got - ref_norms[k]) > rtol * ref_norms[k] + atol:
+            bad.append((k, got, ref_norms[k]))
+    assert not bad, bad[:6]
+
+
+def test_encoder_small_vs_reference_golden(dev, golden):
+    c = golden["encoder_small"]
+    enc = no_dropout(nets.ConformerEncoder(attention_dim=128, attention_heads=2, linear_units=256, num_blocks=2,
+                                           cnn_module_kernel=7))
+    assert {k: tuple(v.shape) for k, v in enc.state_dict().items()} == c["shapes"], "state_dict contract"
+    enc.load_state_dict(synth_state_dict(enc.state_dict(), c["seed"]), strict=True)
+    enc.to(dev).train()
+    x = c["x"].clone().to(dev).requires_grad_()
+    mask = nets.make_non_pad_mask(c["lengths"]).unsqueeze(-2).to(dev)
+    with AF.precise():
+        out, _ = enc(x, mask)
+        assert rel(out.cpu(), c["out"]) < 1e-3
+        (out * c["w"].to(dev)).sum().backward()
+    assert rel(x.grad.cpu(), c["dx"]) < 1e-3
+    check_grad_norms(enc, c["grad_norms"], 5e-3)
+
+
+def test_decoder_small_vs_reference_golden(dev, golden):
+    c = golden["decoder_small"]
+    dec = no_dropout(nets.TransformerDecoder(odim=c["odim"], attention_dim=128, attention_heads=2, linear_units=256,
+                                             num_blocks=2))
+    assert {k: tuple(v.shape) for k, v in dec.state_dict().items()} == c["shapes"], "state_dict contract"
+    dec.load_state_dict(synth_state_dict(dec.state_dict(), c["seed"]), strict=True)
+    dec.to(dev).train()
+    mem = c["memory"].clone().to(dev).requires_grad_()
+    mmask = nets.make_non_pad_mask(c["lengths"]).unsqueeze(-2).to(dev)
+    ys_in = c["ys_in"].to(dev)
+    with AF.precise():
+        out, _ = dec(ys_in, nets.target_mask(ys_in, -1), mem, mmask)
+        assert rel(out.cpu(), c["out"]) < 1e-3
+        (out * c["w"].to(dev)).sum().backward()
+    assert rel(mem.grad.cpu(), c["dmemory"]) < 1e-3
+    check_grad_norms(dec, c["grad_norms"], 5e-3)
+
+
+@pytest.mark.parametrize("modality", ["video", "audio"])
+def test_e2e_small_vs_oracle(dev, modality):
+    torch.manual_seed(0)
+    odim = 40
+    m = no_dropout(E2E(odim, modality, adim=128, aheads=2, eunits=256, elayers=2, dunits=256, dlayers=2,
+                       cnn_module_kernel=7))
+    sd = synth_state_dict(m.state_dict(), 11)
+    m.load_state_dict(sd, strict=True)
+    m.to(dev).train()
+    x, lengths, y = synth_batch(modality, 2, 9, 4, odim, seed=5)
+    osd = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running_" not in k else v.clone())
+           for k, v in sd.items()}
+    (loss_r, ctc_r, att_r, acc_r), _ = O.e2e_forward(osd, x, lengths, y, modality=modality, heads=2)
+    loss_r.backward()
+    with AF.precise():
+        loss, loss_ctc, loss_att, acc = m(x.to(dev), lengths.to(dev), y.to(dev))
+        loss.backward()
+    assert abs(float(loss_ctc) - float(ctc_r)) < 1e-3 * abs(float(ctc_r))
+    assert abs(float(loss_att) - float(att_r)) < 1e-3 * abs(float(att_r))
+    assert abs(float(loss) - float(loss_r)) < 1e-3 * abs(float(loss_r))
+    assert acc == acc_r
+    ref_norms = {k: float(v.grad.double().norm()) for k, v in osd.items() if v.is_floating_point() and v.grad is not None}
+    check_grad_norms(m, ref_norms, 1e-2)
+    # BatchNorm running statistics of the conv module were updated like torch's (momentum 0.1, unbiased variance)
+    assert int(m.encoder.encoders[0].conv_module.norm.num_batches_tracked) == 1
