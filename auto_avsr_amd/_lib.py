@@ -9,6 +9,10 @@ import ctypes
 import os
 import re
 
+# torch wheels bundle their own libamdhip64; it must be the HIP runtime of the process, so it has to be loaded
+# before libavsr_hip.so resolves its libamdhip64.so.7 dependency (two runtimes in one process = "no device")
+import torch  # noqa: F401  (side effect: loads torch/lib/libamdhip64.so)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "avsr_hip.h")
 LIB_PATH = os.path.join(_HERE, "libavsr_hip.so")

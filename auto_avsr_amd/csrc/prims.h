@@ -7,6 +7,8 @@
 // library is always the hipcc --offload-arch=gfx950 build.
 #pragma once
 
+extern "C" void avsr_note_launch(int err);
+extern "C" int avsr_take_launch_error(void);
 #ifdef AVSR_EMU
 #include "hip_emu.h"
 #define AVSR_LAUNCH(kern, grid, block, smem, stream, ...) \
@@ -14,8 +16,14 @@
 #define AVSR_DYN_SMEM(name) char* name = emu::dyn_smem()
 #else
 #include <hip/hip_runtime.h>
-#define AVSR_LAUNCH(kern, grid, block, smem, stream, ...) \
-    hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__)
+// PyTorch shares this thread's HIP runtime and may leave benign non-sticky codes (hipErrorNotReady from
+// event queries) in the per-thread "last error" slot: clear it, launch, and record only our own result.
+#define AVSR_LAUNCH(kern, grid, block, smem, stream, ...)                          \
+    do {                                                                           \
+        (void)hipGetLastError();                                                   \
+        hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__);  \
+        avsr_note_launch((int)hipGetLastError());                                  \
+    } while (0)
 #define AVSR_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #endif
 
@@ -213,13 +221,14 @@ AVSR_DEV float dropout_scale(uint64_t seed, uint64_t idx, float p, float inv_kee
 
 // ---------------------------------------------------------------- status plumbing
 extern "C" void avsr_set_error(const char* msg);
-#define AVSR_CHECK_LAUNCH(name)                                   \
-    do {                                                          \
-        hipError_t e__ = hipGetLastError();                       \
-        if (e__ != hipSuccess) {                                  \
-            avsr_set_error(name);                                 \
-            return 2;                                             \
-        }                                                         \
+extern "C" void avsr_set_error2(const char* where, const char* what);
+#define AVSR_CHECK_LAUNCH(name)                                                   \
+    do {                                                                          \
+        int e__ = avsr_take_launch_error();                                       \
+        if (e__ != 0) {                                                           \
+            avsr_set_error2(name, hipGetErrorString((hipError_t)e__));            \
+            return 2;                                                             \
+        }                                                                         \
     } while (0)
 #define AVSR_REQUIRE(cond, msg)         \
     do {                                \

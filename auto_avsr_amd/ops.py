@@ -34,8 +34,18 @@ def _stream(*ts):
     return None
 
 
-def call(name, *args):
-    return _lib.lib().call(name, *args)
+PROFILE = None  # bench.py: list collecting (entry point, start event, end event, flops) per launch
+
+
+def call(name, *args, flops=0.0):
+    if PROFILE is None:
+        return _lib.lib().call(name, *args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = _lib.lib().call(name, *args)
+    e1.record()
+    PROFILE.append((name, e0, e1, flops))
+    return rc
 
 
 def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-12):
@@ -61,7 +71,7 @@ def gemm(layout, A, lda, B, ldb, M, N, K, C, ldc, *, precise=False, bias=None, a
          accumulate=False, split_k=1, force_tile=0):
     call("avsr_gemm", layout, _ptr(A), dt(A), lda, _ptr(B), dt(B), ldb, M, N, K, int(precise), _ptr(bias), act,
          _ptr(gate), dt(gate) if gate is not None else 0, ldg, gate_scale, drop_p, seed, _ptr(seed_dev), alpha, _ptr(alpha_dev), _ptr(resid), ldr,
-         _ptr(C), dt(C), ldc, int(accumulate), split_k, force_tile, _stream(A))
+         _ptr(C), dt(C), ldc, int(accumulate), split_k, force_tile, _stream(A), flops=2.0 * M * N * K)
     return C
 
 
@@ -238,7 +248,7 @@ def ctc_loss(logits, ld, labels, in_lens, B, T, V, want_grad=True, ignore_id=-1)
     ws_bytes = call("avsr_ctc_workspace_bytes", B, T, Lmax)
     ws = torch.empty(ws_bytes // 4 + 1, dtype=torch.float32, device=logits.device)
     nll = torch.empty(B, dtype=torch.float32, device=logits.device)
-    grad = torch.empty_like(logits) if want_grad else None
+    grad = torch.zeros(B * T, ld, dtype=logits.dtype, device=logits.device) if want_grad else None
     call("avsr_ctc_loss", _ptr(logits), dt(logits), ld, _ptr(labels), Lmax, ignore_id, _ptr(in_lens), _ptr(nll),
          _ptr(grad), ld, _ptr(ws), B, T, V, _stream(logits))
     return nll, grad
@@ -248,7 +258,7 @@ def ce_smooth(logits, ld, target, V, smoothing, want_grad=True, ignore_id=-1):
     rows = target.numel()
     row_loss = torch.empty(rows, dtype=torch.float32, device=logits.device)
     row_hit = torch.empty(rows, dtype=torch.float32, device=logits.device)
-    grad = torch.empty_like(logits) if want_grad else None
+    grad = torch.zeros(rows, ld, dtype=logits.dtype, device=logits.device) if want_grad else None
     call("avsr_ce_smooth", _ptr(logits), dt(logits), ld, _ptr(target), ignore_id, V, smoothing, _ptr(row_loss),
          _ptr(row_hit), _ptr(grad), ld, rows, _stream(logits))
     return row_loss, row_hit, grad

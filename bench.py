@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the auto_avsr training hot path (E2E forward + backward, video modality,
+12-layer Conformer / 6-layer decoder, --max-frames 1600 length-bucketed synthetic batches) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`
+(one rank per GPU, RCCL).  Rank 0 prints ONE JSON line (contract in the task description): whole-job real
+(un-padded) video frames per second, plus `roofline` (dominant kernel family, MFMA bound) and `cpu_baseline`
+(the oracle timed on the host cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--max-frames", type=int, default=1600)
+    ap.add_argument("--modality", default="video")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--precise", action="store_true", help="parity mode (split-bf16 contractions) instead of bf16")
+    return ap.parse_args()
+
+
+def cpu_baseline(modality, odim):
+    """The oracle (CPU restatement of the reference graph) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import avsr_oracle as O
+    from synth import synth_state_dict
+
+    from auto_avsr_amd.e2e import E2E
+    from auto_avsr_amd.synthetic import make_batch
+
+    cores = min(os.cpu_count() or 1, 32)  # ATen's CPU kernels stop scaling (and thrash) far below 256 threads
+    torch.set_num_threads(cores)
+    tmpl = E2E(odim, modality)
+    sd = synth_state_dict(tmpl.state_dict(), 0)
+    del tmpl
+    sd = {k: (v.requires_grad_() if v.is_floating_point() and "running_" not in k else v) for k, v in sd.items()}
+    lengths = [60, 56, 50, 44]
+    x, lens, y, frames = make_batch(lengths, [0, 1, 2, 3], modality, odim, seed=1)
+    t0 = time.time()
+    (loss, *_), _ = O.e2e_forward(sd, x, lens, y, modality=modality)
+    loss.backward()
+    dt = time.time() - t0
+    return {"value": round(frames / dt, 2), "unit": "video-frames/sec", "cores": cores, "kind": "port",
+            "sample": f"1 fwd+bwd of the fp32 oracle on {cores} threads, B=4 T=60 ({frames} real frames), {dt:.1f}s, no warm-up"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    from auto_avsr_amd import _lib, ops
+    from auto_avsr_amd import functional as AF
+    from auto_avsr_amd.e2e import E2E
+    from auto_avsr_amd.synthetic import bucket_batches, make_batch, rank_batches, utterance_lengths
+
+    assert not _lib.lib().is_emulator
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+        AF.set_bn_sync(dist.group.WORLD)
+    odim = 5049
+    torch.manual_seed(0)
+    model = E2E(odim, args.modality).to(dev).train()
+    AF.set_precise(args.precise)
+    AF.manual_seed(1234 + rank)
+    seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+    AF.set_seed_tensor(seed_dev)
+    class HotPath(torch.nn.Module):
+        """forward_tensors()[0] behind nn.Module.__call__ so that DDP's reducer hooks see the step."""
+
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, x, lens, y):
+            return self.m.forward_tensors(x, lens, y)[0]
+
+    hot = HotPath(model)
+    if world > 1:
+        # train.py:37 DDPStrategy(find_unused_parameters=False): bucketed gradient all-reduce over RCCL/xGMI
+        hot = torch.nn.parallel.DistributedDataParallel(hot, device_ids=[local_rank], find_unused_parameters=False,
+                                                        broadcast_buffers=False, gradient_as_bucket_view=True)
+
+    lengths = utterance_lengths()
+    batches = rank_batches(bucket_batches(lengths, args.max_frames, 400), rank, world, seed=0)
+    n_need = args.warmup + args.steps
+    data = [make_batch(lengths, batches[i % len(batches)], args.modality, odim, seed=i, device=dev) for i in range(n_need)]
+
+    def step(i):
+        x, lens, y, _ = data[i]
+        seed_dev.add_(1)
+        loss = hot(x, lens, y)
+        if world > 1:
+            # loss rescale of lightning.py:88-90: loss *= world / sum of batch sizes (all-gather of B)
+            bs = torch.tensor([float(x.shape[0])], device=dev)
+            allb = torch.empty(world, device=dev)
+            dist.all_gather_into_tensor(allb, bs)
+            loss = loss * (world / allb.sum())
+        loss.backward()
+        model.zero_grad(set_to_none=True)
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_need):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    frames = sum(d[3] for d in data[args.warmup:])
+    padded = sum(d[0].shape[0] * d[0].shape[1] for d in data[args.warmup:]) // (640 if args.modality == "audio" else 1)
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    ftot = torch.tensor([float(frames), float(padded)], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ftot)
+    dt = float(tmax)
+    out = {
+        "metric": "video-frames/sec/node (25fps 88x88, max-frames=1600), E2E fwd+bwd",
+        "value": round(float(ftot[0]) / dt, 2),
+        "unit": "video-frames/sec",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32 (split-bf16 MFMA)" if args.precise else "bf16",
+        "data": "synthetic",
+        "config": {"workload": "configs[1]: modality=video vsr_trlrs3_base (12-layer Conformer + 6-layer decoder, 250M), "
+                               "length-bucketed batches, max-frames=1600 (real frames), fwd+bwd"
+                               + (", DDP grad all-reduce + SyncBN over RCCL" if world > 1 else ""),
+                   "padded_frames_per_sec": round(float(ftot[1]) / dt, 2),
+                   "frontend": "ATen (interim)", "encoder_decoder_losses": "libavsr_hip.so"},
+    }
+    if rank == 0 and not args.no_roofline:
+        out["roofline"] = roofline(model, data[args.warmup], ops)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.modality, odim)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def roofline(model, batch, ops):
+    """Per-family kernel time of one training step, measured with HIP events around every C-ABI launch on the
+    launch stream; reports the dominant family (the MFMA GEMMs) against the dense bf16 MFMA peak."""
+    x, lens, y, _ = batch
+    ops.PROFILE = []
+    loss, *_ = model.forward_tensors(x, lens, y)
+    loss.backward()
+    torch.cuda.synchronize()
+    rec, ops.PROFILE = ops.PROFILE, None
+    model.zero_grad(set_to_none=True)
+    fam = {}
+    for name, e0, e1, flops in rec:
+        t = e0.elapsed_time(e1) * 1e-3
+        f = fam.setdefault(name, [0.0, 0.0, 0])
+        f[0] += t
+        f[1] += flops
+        f[2] += 1
+    tot = sum(v[0] for v in fam.values())
+    name = max(fam, key=lambda k: fam[k][0])
+    t, fl, n = fam[name]
+    peak = 2500.0
+    ach = fl / t / 1e12 if t > 0 else 0.0
+    return {"bound": "mfma", "kernel": name, "launches": n, "avg_us": round(t / n * 1e6, 2),
+            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+            "step_kernel_time_ms": round(tot * 1e3, 3),
+            "share_of_kernel_time": round(t / tot, 3),
+            "families_ms": {k: round(v[0] * 1e3, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:8]}}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,74 @@
+"""Full-size E2E (768/12 heads/3072/12+6 layers, 250M parameters) on the MI355X against the oracle and against
+the reference-generated golden numbers.  GPU only (the emulator is far too slow at this size)."""
+import os
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+from synth import synth_batch, synth_state_dict  # noqa: E402
+
+import avsr_oracle as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(modality, seed):
+    from auto_avsr_amd import _lib
+    from auto_avsr_amd.e2e import E2E
+
+    _lib._lib = None
+    assert not _lib.lib().is_emulator
+    m = E2E(5049, modality)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    sd = synth_state_dict(m.state_dict(), seed)
+    m.load_state_dict(sd)
+    return m.cuda().train(), sd
+
+
+@pytest.mark.parametrize("name", ["e2e_video", "e2e_audio"])
+def test_full_e2e_vs_reference_golden(name):
+    from auto_avsr_amd import functional as AF
+
+    c = torch.load(os.path.join(HERE, "golden", "golden_v1.pt"), weights_only=False)[name]
+    m, _ = _model(c["modality"], c["seed"])
+    assert list(m.state_dict().keys()) == c["keys"], "state_dict key order/name contract"
+    x, lengths, y = synth_batch(c["modality"], c["B"], c["T"], c["L"], 5049, c["seed"])
+    with AF.precise():
+        loss, loss_ctc, loss_att, acc = m(x.cuda(), lengths.cuda(), y.cuda())
+        loss.backward()
+    for got, key in ((loss, "loss"), (loss_ctc, "loss_ctc"), (loss_att, "loss_att")):
+        assert abs(float(got) - c[key]) < 1e-3 * abs(c[key]), (key, float(got), c[key])
+    assert acc == c["acc"]
+    atol = 1e-4 * max(c["grad_norms"].values())
+    bad = []
+    for k, p in m.named_parameters():
+        g = float(p.grad.double().norm())
+        if abs(g - c["grad_norms"][k]) > 1e-2 * c["grad_norms"][k] + atol:
+            bad.append((k, g, c["grad_norms"][k]))
+    assert not bad, bad[:8]
+
+
+def test_full_e2e_bf16_vs_oracle():
+    """bf16 bench mode on a longer batch: losses within 1e-2 of the fp32 oracle, gradient directions aligned."""
+    m, sd = _model("video", 7)
+    x, lengths, y = synth_batch("video", 3, 40, 8, 5049, seed=6, lengths=[40, 33, 21])
+    osd = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running_" not in k else v.clone())
+           for k, v in sd.items()}
+    (loss_r, ctc_r, att_r, _), _ = O.e2e_forward(osd, x, lengths, y, modality="video")
+    loss_r.backward()
+    loss, loss_ctc, loss_att, acc = m(x.cuda(), lengths.cuda(), y.cuda())
+    loss.backward()
+    assert abs(float(loss_ctc) - float(ctc_r)) < 1e-2 * abs(float(ctc_r))
+    assert abs(float(loss_att) - float(att_r)) < 1e-2 * abs(float(att_r))
+    cos = []
+    for k, p in m.named_parameters():
+        a, b = p.grad.double().flatten().cpu(), osd[k].grad.double().flatten()
+        if b.norm() > 1e-3 * max(1.0, float(osd[k].double().norm()) * 1e-3):
+            cos.append(float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)))
+    assert min(cos) > 0.9 and sum(cos) / len(cos) > 0.99, (min(cos), sum(cos) / len(cos))
