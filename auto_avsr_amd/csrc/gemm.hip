@@ -30,7 +30,7 @@ extern "C" int avsr_gemm(int layout, const void* A, int a_dtype, int lda, const 
     AVSR_REQUIRE(!(precise && (a_dtype != 0 || b_dtype != 0)), "gemm: precise mode needs f32 operands");
     if (M <= 0 || N <= 0) return 0;
     AVSR_REQUIRE(K > 0, "gemm: K must be positive");
-    avsr_gemm_impl::Params p;
+    avsr_gemm_impl::Params p{};
     p.A = A; p.B = B; p.lda = lda; p.ldb = ldb;
     p.M = M; p.N = N; p.K = K; p.k_chunk = K;
     p.bias = bias; p.act = act;

@@ -1,0 +1,204 @@
+// gemm_conv.hip -- implicit-GEMM convolutions of the front-ends on channels-last activations, built on the
+// MFMA GEMM core (gemm_core.h) with gathering operand loaders; no im2col buffer is ever materialised.
+//
+// Replaces the ATen/MIOpen convolutions of
+//   frontend/resnet.py:10-17,20-35   conv3x3 / 1x1 downsample of the ResNet-18 trunk (and resnet1d.py's k=3 / k=1
+//                                     1-D versions, run here as H = 1 images)
+//   frontend/resnet.py:204-211       the Conv3d(1, 64, (5,7,7), stride (1,2,2)) stem
+//   frontend/resnet1d.py:124-131     the Conv1d(1, 64, 80, stride 4) audio stem (KT = KH = 1)
+// and their data / weight gradients.  Weights are consumed in a [Cout][KH][KW][Cin] (forward, weight gradient)
+// or [Cin][KH][KW][Cout] (data gradient) permutation of torch's [Cout][Cin][KH][KW], produced by
+// avsr_conv_weight_permute in the activation dtype once per step.
+#include "gemm_core.h"
+#include "avsr_hip.h"
+
+namespace {
+
+using avsr_gemm_impl::Params;
+
+template <int CV, int LA, int LB>
+int conv_launch(const Params& p, int a_dtype, int b_dtype, int precise, int split_k, hipStream_t stream) {
+    using namespace avsr_gemm_impl;
+    if (precise) {
+        if (a_dtype != 0 || b_dtype != 0) return -1;
+        return launch<float, float, 2, LA, LB, CV>(p, 0, split_k, stream);
+    }
+    if (a_dtype == 1 && b_dtype == 1) return launch<bf16_t, bf16_t, 1, LA, LB, CV>(p, 0, split_k, stream);
+    if (a_dtype == 0 && b_dtype == 1) return launch<float, bf16_t, 1, LA, LB, CV>(p, 0, split_k, stream);
+    if (a_dtype == 1 && b_dtype == 0) return launch<bf16_t, float, 1, LA, LB, CV>(p, 0, split_k, stream);
+    return launch<float, float, 1, LA, LB, CV>(p, 0, split_k, stream);
+}
+
+Params base_params() {
+    Params p{};
+    p.alpha = 1.f;
+    p.gate_scale = 1.f;
+    p.nsplit = 1;
+    p.batch_h = 1;
+    p.nbatch = 1;
+    return p;
+}
+
+int pick_split(long tiles, long rows) {
+    long s = 1024 / (tiles < 1 ? 1 : tiles);
+    if (s > rows / 256) s = rows / 256;
+    if (s > 256) s = 256;
+    return (int)(s < 1 ? 1 : s);
+}
+
+// out[a][tap][b] (pitch ld_out over (tap,b)) = w[co][ci][tap]; to_dgrad: a=ci,b=co else a=co,b=ci
+template <class TO>
+__global__ __launch_bounds__(256) void weight_permute_kernel(const float* __restrict__ w, TO* __restrict__ out, int Cout,
+                                                             int Cin, int taps, int to_dgrad, long ld_out) {
+    const long total = (long)Cout * Cin * taps;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        // iterate in output order for coalesced stores
+        const int A = to_dgrad ? Cin : Cout, Bc = to_dgrad ? Cout : Cin;
+        const int b = (int)(i % Bc);
+        const int tap = (int)((i / Bc) % taps);
+        const int a = (int)(i / ((long)Bc * taps));
+        (void)A;
+        const int co = to_dgrad ? b : a, ci = to_dgrad ? a : b;
+        Elem<TO>::st(out + (long)a * ld_out + (long)tap * Bc + b, w[((long)co * Cin + ci) * taps + tap]);
+    }
+}
+// dw[co][ci][tap] = dwp[co][tap][ci]
+__global__ __launch_bounds__(256) void weight_unpermute_kernel(const float* __restrict__ dwp, float* __restrict__ dw,
+                                                               int Cout, int Cin, int taps) {
+    const long total = (long)Cout * Cin * taps;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int tap = (int)(i % taps);
+        const int ci = (int)((i / taps) % Cin);
+        const int co = (int)(i / ((long)taps * Cin));
+        dw[i] = dwp[((long)co * taps + tap) * Cin + ci];
+    }
+}
+
+}  // namespace
+
+extern "C" int avsr_conv_weight_permute(const float* w, void* out, int out_dtype, int Cout, int Cin, int taps,
+                                        int to_dgrad, int64_t ld_out, hipStream_t stream) {
+    const long total = (long)Cout * Cin * taps;
+    if (total <= 0) return 0;
+    long nb = (total + 255) / 256;
+    dim3 grid((unsigned)(nb > 2048 ? 2048 : nb)), block(256);
+    if (out_dtype == 0)
+        AVSR_LAUNCH((weight_permute_kernel<float>), grid, block, 0, stream, w, (float*)out, Cout, Cin, taps, to_dgrad, (long)ld_out);
+    else
+        AVSR_LAUNCH((weight_permute_kernel<bf16_t>), grid, block, 0, stream, w, (bf16_t*)out, Cout, Cin, taps, to_dgrad, (long)ld_out);
+    AVSR_CHECK_LAUNCH("conv_weight_permute");
+    return 0;
+}
+
+extern "C" int avsr_conv_weight_unpermute(const float* dwp, float* dw, int Cout, int Cin, int taps, hipStream_t stream) {
+    const long total = (long)Cout * Cin * taps;
+    if (total <= 0) return 0;
+    long nb = (total + 255) / 256;
+    AVSR_LAUNCH(weight_unpermute_kernel, dim3((unsigned)(nb > 2048 ? 2048 : nb)), dim3(256), 0, stream, dwp, dw, Cout, Cin, taps);
+    AVSR_CHECK_LAUNCH("conv_weight_unpermute");
+    return 0;
+}
+
+static void fill_conv(Params& p, int H, int W, int C, int OH, int OW, int KH, int KW, int stride, int ph, int pw) {
+    p.cH = H; p.cW = W; p.cC = C; p.cOH = OH; p.cOW = OW;
+    p.cKH = KH; p.cKW = KW; p.cS = stride; p.cPH = ph; p.cPW = pw;
+    p.cT = 1; p.cKT = 1; p.cPT = 0;
+}
+
+// y[N,OH,OW,Cout] = conv(x[N,H,W,Cin], wp[Cout][KH][KW][Cin])
+extern "C" int avsr_conv2d_fwd(const void* x, int dtype, const void* wp, int w_dtype, void* y, int N, int H, int W,
+                               int Cin, int Cout, int KH, int KW, int stride, int pad_h, int pad_w, int precise,
+                               hipStream_t stream) {
+    AVSR_REQUIRE(Cin % 8 == 0, "conv2d: Cin must be a multiple of 8");
+    const int OH = (H + 2 * pad_h - KH) / stride + 1, OW = (W + 2 * pad_w - KW) / stride + 1;
+    if (N <= 0) return 0;
+    Params p = base_params();
+    p.A = x; p.B = wp; p.lda = Cin; p.ldb = KH * KW * Cin;
+    p.M = N * OH * OW; p.N = Cout; p.K = KH * KW * Cin; p.k_chunk = p.K;
+    p.C = y; p.c_dtype = dtype; p.ldc = Cout;
+    fill_conv(p, H, W, Cin, OH, OW, KH, KW, stride, pad_h, pad_w);
+    AVSR_REQUIRE((conv_launch<1, 0, 0>(p, dtype, w_dtype, precise, 1, stream)) == 0, "conv2d_fwd: dtype combination");
+    AVSR_CHECK_LAUNCH("conv2d_fwd");
+    return 0;
+}
+
+// dx[N,H,W,Cin] = conv_transpose(dy[N,OH,OW,Cout], wpd[Cin][KH][KW][Cout]) (+ resid[N,H,W,Cin], same dtype)
+extern "C" int avsr_conv2d_dgrad(const void* dy, int dtype, const void* wpd, int w_dtype, const void* resid, void* dx,
+                                 int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_h, int pad_w,
+                                 int precise, hipStream_t stream) {
+    AVSR_REQUIRE(Cout % 8 == 0, "conv2d: Cout must be a multiple of 8");
+    const int OH = (H + 2 * pad_h - KH) / stride + 1, OW = (W + 2 * pad_w - KW) / stride + 1;
+    if (N <= 0) return 0;
+    Params p = base_params();
+    p.A = dy; p.B = wpd; p.lda = Cout; p.ldb = KH * KW * Cout;
+    p.M = N * H * W; p.N = Cin; p.K = KH * KW * Cout; p.k_chunk = p.K;
+    p.C = dx; p.c_dtype = dtype; p.ldc = Cin;
+    p.resid = reinterpret_cast<const float*>(resid); p.ldr = Cin; p.resid_dtype = dtype;
+    // the gathered tensor is dy (OH x OW x Cout); rows run over the input pixel grid (H x W)
+    fill_conv(p, OH, OW, Cout, H, W, KH, KW, stride, pad_h, pad_w);
+    AVSR_REQUIRE((conv_launch<2, 0, 0>(p, dtype, w_dtype, precise, 1, stream)) == 0, "conv2d_dgrad: dtype combination");
+    AVSR_CHECK_LAUNCH("conv2d_dgrad");
+    return 0;
+}
+
+// dwp[Cout][KH][KW][Cin] (f32, zero-initialised by the caller) += dy^T im2col(x)
+extern "C" int avsr_conv2d_wgrad(const void* dy, const void* x, int dtype, float* dwp, int N, int H, int W, int Cin,
+                                 int Cout, int KH, int KW, int stride, int pad_h, int pad_w, int precise,
+                                 hipStream_t stream) {
+    AVSR_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "conv2d: channels must be multiples of 8");
+    const int OH = (H + 2 * pad_h - KH) / stride + 1, OW = (W + 2 * pad_w - KW) / stride + 1;
+    if (N <= 0) return 0;
+    Params p = base_params();
+    p.A = dy; p.B = x; p.lda = Cout; p.ldb = Cin;
+    p.M = Cout; p.N = KH * KW * Cin; p.K = N * OH * OW; p.k_chunk = p.K;
+    p.C = dwp; p.c_dtype = 0; p.ldc = p.N; p.accumulate = 1;
+    fill_conv(p, H, W, Cin, OH, OW, KH, KW, stride, pad_h, pad_w);
+    const long tiles = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+    AVSR_REQUIRE((conv_launch<3, 1, 1>(p, dtype, dtype, precise, pick_split(tiles, p.K), stream)) == 0,
+                 "conv2d_wgrad: dtype combination");
+    AVSR_CHECK_LAUNCH("conv2d_wgrad");
+    return 0;
+}
+
+static void fill_stem(Params& p, int T, int H, int W, int OH, int OW, int KT, int KH, int KW, int stride, int pt, int ph,
+                      int pw) {
+    p.cH = H; p.cW = W; p.cC = 1; p.cOH = OH; p.cOW = OW;
+    p.cKH = KH; p.cKW = KW; p.cS = stride; p.cPH = ph; p.cPW = pw;
+    p.cT = T; p.cKT = KT; p.cPT = pt;
+}
+
+// y[B,T,OH,OW,Cout] = conv3d(x[B,T,H,W] (one channel, f32), wp[Cout][ldw >= KT*KH*KW]), temporal stride 1
+extern "C" int avsr_conv_stem_fwd(const float* x, const void* wp, int w_dtype, int ldw, void* y, int y_dtype, int B, int T,
+                                  int H, int W, int Cout, int KT, int KH, int KW, int stride, int pad_t, int pad_h,
+                                  int pad_w, int precise, hipStream_t stream) {
+    AVSR_REQUIRE(ldw % 8 == 0 && ldw >= KT * KH * KW, "conv_stem: weight pitch must be a multiple of 8");
+    const int OH = (H + 2 * pad_h - KH) / stride + 1, OW = (W + 2 * pad_w - KW) / stride + 1;
+    if (B <= 0 || T <= 0) return 0;
+    Params p = base_params();
+    p.A = x; p.B = wp; p.lda = 8; p.ldb = ldw;
+    p.M = B * T * OH * OW; p.N = Cout; p.K = KT * KH * KW; p.k_chunk = p.K;
+    p.C = y; p.c_dtype = y_dtype; p.ldc = Cout;
+    fill_stem(p, T, H, W, OH, OW, KT, KH, KW, stride, pad_t, pad_h, pad_w);
+    AVSR_REQUIRE((conv_launch<4, 0, 0>(p, 0, w_dtype, precise, 1, stream)) == 0, "conv_stem_fwd: dtype combination");
+    AVSR_CHECK_LAUNCH("conv_stem_fwd");
+    return 0;
+}
+
+// dw[Cout][KT*KH*KW] (f32, zero-initialised, torch layout since Cin = 1) += dy^T im2col(x)
+extern "C" int avsr_conv_stem_wgrad(const void* dy, int dy_dtype, const float* x, float* dw, int B, int T, int H, int W,
+                                    int Cout, int KT, int KH, int KW, int stride, int pad_t, int pad_h, int pad_w,
+                                    int precise, hipStream_t stream) {
+    AVSR_REQUIRE(Cout % 8 == 0, "conv_stem: Cout must be a multiple of 8");
+    const int OH = (H + 2 * pad_h - KH) / stride + 1, OW = (W + 2 * pad_w - KW) / stride + 1;
+    if (B <= 0 || T <= 0) return 0;
+    Params p = base_params();
+    p.A = dy; p.B = x; p.lda = Cout; p.ldb = 8;
+    p.M = Cout; p.N = KT * KH * KW; p.K = B * T * OH * OW; p.k_chunk = p.K;
+    p.C = dw; p.c_dtype = 0; p.ldc = p.N; p.accumulate = 1;
+    fill_stem(p, T, H, W, OH, OW, KT, KH, KW, stride, pad_t, pad_h, pad_w);
+    const long tiles = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+    AVSR_REQUIRE((conv_launch<5, 1, 1>(p, dy_dtype, 0, precise, pick_split(tiles, p.K), stream)) == 0,
+                 "conv_stem_wgrad: dtype combination");
+    AVSR_CHECK_LAUNCH("conv_stem_wgrad");
+    return 0;
+}

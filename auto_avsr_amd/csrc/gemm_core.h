@@ -53,6 +53,16 @@ struct Params {
     // This is the transpose of the reference's rel_shift (attention.py:131-151) applied to dS, so that the
     // gradient of the projected positions is an ordinary TN contraction.
     int a_skew, skew_off, skew_lim;
+    int resid_dtype;  // 0: resid is f32 (default), 1: bf16
+    // implicit-GEMM convolution on channels-last tensors (template parameter CV selects the gather):
+    //   CV 1: A[m][k] = x[n, oh*s+kh-ph, ow*s+kw-pw, ci]          m=(n,oh,ow) k=(kh,kw,ci)   forward
+    //   CV 2: A[m][k] = dy[n, (ih+ph-kh)/s, (iw+pw-kw)/s, co]     m=(n,ih,iw) k=(kh,kw,co)   data gradient
+    //   CV 3: B[k][n'] = x[...] as CV 1 with k=(n,oh,ow) n'=(kh,kw,ci)                         weight gradient
+    //   CV 4/5: CV 1/3 for a single input channel with temporal taps: k=(kt,kh,kw), clip length cT
+    int cH, cW, cC;       // spatial size / channels of the gathered tensor
+    int cOH, cOW;         // pixel grid the row index runs over
+    int cKH, cKW, cS, cPH, cPW;
+    int cT, cKT, cPT;
 };
 
 template <class T> struct Raw8;
@@ -107,7 +117,52 @@ AVSR_DEV Raw8<T> load_chunk_skew(const T* base, int ld, int r, int c, int r_lim,
     return out;
 }
 
-template <class TA, class TB, int NS, int LA, int LB, int BM, int BN, int BK>
+// 8 consecutive k (one tap, 8 channels) of pixel row m, or zeros
+template <class T, int CV>
+AVSR_DEV Raw8<T> gather_chunk(const T* base, const Params& p, int m, int k, int m_lim, int k_lim) {
+    Raw8<T> out;
+    out.zero();
+    if (m >= m_lim || k >= k_lim) return out;
+    if (CV == 1 || CV == 3) {
+        const int tap = k / p.cC, ci = k - tap * p.cC;
+        const int kh = tap / p.cKW, kw = tap - kh * p.cKW;
+        const int pix = p.cOH * p.cOW;
+        const int n = m / pix, r = m - n * pix;
+        const int oh = r / p.cOW, ow = r - oh * p.cOW;
+        const int ih = oh * p.cS + kh - p.cPH, iw = ow * p.cS + kw - p.cPW;
+        if (ih >= 0 && ih < p.cH && iw >= 0 && iw < p.cW)
+            out.load(base + (((size_t)n * p.cH + ih) * p.cW + iw) * p.cC + ci);
+    } else if (CV == 2) {
+        const int tap = k / p.cC, co = k - tap * p.cC;
+        const int kh = tap / p.cKW, kw = tap - kh * p.cKW;
+        const int pix = p.cOH * p.cOW;
+        const int n = m / pix, r = m - n * pix;
+        const int ih = r / p.cOW, iw = r - ih * p.cOW;
+        const int th = ih + p.cPH - kh, tw = iw + p.cPW - kw;
+        if (th >= 0 && tw >= 0) {
+            const int oh = th / p.cS, ow = tw / p.cS;
+            if (oh * p.cS == th && ow * p.cS == tw && oh < p.cH && ow < p.cW)
+                out.load(base + (((size_t)n * p.cH + oh) * p.cW + ow) * p.cC + co);
+        }
+    } else {  // CV 4 / 5: one input channel, taps (kt,kh,kw): per-element gather
+        const int pix = p.cOH * p.cOW;
+        const int n = m / pix, r = m - n * pix;
+        const int oh = r / p.cOW, ow = r - oh * p.cOW;
+        const int b = n / p.cT, t = n - b * p.cT;
+        for (int e = 0; e < 8; e++) {
+            const int kk = k + e;
+            if (kk >= k_lim) break;
+            const int kt = kk / (p.cKH * p.cKW), r2 = kk - kt * (p.cKH * p.cKW);
+            const int kh = r2 / p.cKW, kw = r2 - kh * p.cKW;
+            const int tt = t + kt - p.cPT, ih = oh * p.cS + kh - p.cPH, iw = ow * p.cS + kw - p.cPW;
+            if (tt >= 0 && tt < p.cT && ih >= 0 && ih < p.cH && iw >= 0 && iw < p.cW)
+                out.set(e, base + (((size_t)b * p.cT + tt) * p.cH + ih) * p.cW + iw);
+        }
+    }
+    return out;
+}
+
+template <class TA, class TB, int NS, int LA, int LB, int BM, int BN, int BK, int CV = 0>
 struct Kernel {
     static constexpr int PITCH = BK + 8;  // bf16 elements per LDS row
     static constexpr int NT = 256;
@@ -119,12 +174,15 @@ struct Kernel {
     static constexpr int A_RAW = (LA == 0) ? A_ITEMS : 2 * A_ITEMS;
     static constexpr int B_RAW = (LB == 0) ? B_ITEMS : 2 * B_ITEMS;
     static constexpr size_t LDS_BYTES = (size_t)NS * (BM + BN) * PITCH * sizeof(bf16_t);
+    static constexpr bool GA = (CV == 1 || CV == 2 || CV == 4);  // A operand gathered
+    static constexpr bool GB = (CV == 3 || CV == 5);             // B operand gathered
     static_assert(A_ITEMS >= 1 && B_ITEMS >= 1, "tile too small for 256 threads");
 
     // ---- HBM -> registers
-    template <class T, int L, int ROWS, int ITEMS, int NRAW>
+    // GATHER: this operand is read through the convolution index map of Params (CV != 0)
+    template <class T, int L, int ROWS, int ITEMS, int NRAW, bool GATHER>
     static AVSR_DEV void fetch(Raw8<T> (&raw)[NRAW], const T* base, int ld, int row0, int row_lim, int k0,
-                        int k_lim, int skew = 0, int skew_off = 0, int skew_lim = 0) {
+                        int k_lim, const Params& p, int skew = 0, int skew_off = 0, int skew_lim = 0) {
         const int tid = threadIdx.x;
         if (L == 0) {
             constexpr int CH = BK / 8;
@@ -132,7 +190,8 @@ struct Kernel {
             for (int i = 0; i < ITEMS; i++) {
                 const int id = tid + NT * i;
                 const int r = id / CH, kc = (id % CH) * 8;
-                raw[i] = load_chunk<T>(base, ld, row0 + r, k0 + kc, row_lim, k_lim);
+                if (GATHER) raw[i] = gather_chunk<T, CV>(base, p, row0 + r, k0 + kc, row_lim, k_lim);
+                else raw[i] = load_chunk<T>(base, ld, row0 + r, k0 + kc, row_lim, k_lim);
             }
         } else {
             constexpr int KP = BK / 2;
@@ -141,7 +200,11 @@ struct Kernel {
                 const int id = tid + NT * i;
                 const int kp = id % KP, mc = (id / KP) * 8;
                 // matrix is [K][rows]: "row" index of the load is k, column is the m/n index
-                if (skew) {
+                if (GATHER) {
+                    // matrix is [K = pixels][cols = taps*C]: gather_chunk(m = pixel row, k = column)
+                    raw[2 * i] = gather_chunk<T, CV>(base, p, k0 + 2 * kp, row0 + mc, k_lim, row_lim);
+                    raw[2 * i + 1] = gather_chunk<T, CV>(base, p, k0 + 2 * kp + 1, row0 + mc, k_lim, row_lim);
+                } else if (skew) {
                     raw[2 * i] = load_chunk_skew<T>(base, ld, k0 + 2 * kp, row0 + mc, k_lim, row_lim, skew_off, skew_lim);
                     raw[2 * i + 1] = load_chunk_skew<T>(base, ld, k0 + 2 * kp + 1, row0 + mc, k_lim, row_lim, skew_off, skew_lim);
                 } else {
@@ -219,8 +282,8 @@ struct Kernel {
 
         Raw8<TA> ra[A_RAW];
         Raw8<TB> rb[B_RAW];
-        fetch<TA, LA, BM, A_ITEMS, A_RAW>(ra, A, p.lda, m0, p.M, kbeg, kend, p.a_skew, p.skew_off, p.skew_lim);
-        fetch<TB, LB, BN, B_ITEMS, B_RAW>(rb, B, p.ldb, n0, p.N, kbeg, kend);
+        fetch<TA, LA, BM, A_ITEMS, A_RAW, GA>(ra, A, p.lda, m0, p.M, kbeg, kend, p, p.a_skew, p.skew_off, p.skew_lim);
+        fetch<TB, LB, BN, B_ITEMS, B_RAW, GB>(rb, B, p.ldb, n0, p.N, kbeg, kend, p);
         stash<TA, LA, BM, A_ITEMS, A_RAW>(ra, As);
         stash<TB, LB, BN, B_ITEMS, B_RAW>(rb, Bs);
         __syncthreads();
@@ -228,8 +291,8 @@ struct Kernel {
         for (int k0 = kbeg; k0 < kend; k0 += BK) {
             const bool more = (k0 + BK) < kend;
             if (more) {
-                fetch<TA, LA, BM, A_ITEMS, A_RAW>(ra, A, p.lda, m0, p.M, k0 + BK, kend, p.a_skew, p.skew_off, p.skew_lim);
-                fetch<TB, LB, BN, B_ITEMS, B_RAW>(rb, B, p.ldb, n0, p.N, k0 + BK, kend);
+                fetch<TA, LA, BM, A_ITEMS, A_RAW, GA>(ra, A, p.lda, m0, p.M, k0 + BK, kend, p, p.a_skew, p.skew_off, p.skew_lim);
+                fetch<TB, LB, BN, B_ITEMS, B_RAW, GB>(rb, B, p.ldb, n0, p.N, k0 + BK, kend, p);
             }
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ks++) {
@@ -287,7 +350,9 @@ struct Kernel {
                     if (p.drop_p > 0.f)
                         v *= dropout_scale(seed, (uint64_t)row * (uint64_t)p.N + col, p.drop_p, inv_keep);
                     v *= alpha;
-                    if (p.resid && zs == 0) v += p.resid[(size_t)row * p.ldr + col];
+                    if (p.resid && zs == 0)
+                        v += p.resid_dtype == 0 ? p.resid[(size_t)row * p.ldr + col]
+                                                : bf2f(reinterpret_cast<const bf16_t*>(p.resid)[(size_t)row * p.ldr + col]);
                     if (p.c_dtype == 0) {
                         float* c = reinterpret_cast<float*>(p.C) + c_off + (size_t)row * p.ldc + col;
                         if (p.accumulate) atomicAdd(c, v); else *c = v;
@@ -299,14 +364,14 @@ struct Kernel {
     }
 };
 
-template <class TA, class TB, int NS, int LA, int LB, int BM, int BN, int BK>
+template <class TA, class TB, int NS, int LA, int LB, int BM, int BN, int BK, int CV = 0>
 __global__ __launch_bounds__(256) void gemm_kernel(Params p) {
     AVSR_DYN_SMEM(smem);
-    Kernel<TA, TB, NS, LA, LB, BM, BN, BK>::run(p, smem);
+    Kernel<TA, TB, NS, LA, LB, BM, BN, BK, CV>::run(p, smem);
 }
 
 // host-side launch of one (layout, dtype) family: picks the tile shape
-template <class TA, class TB, int NS, int LA, int LB>
+template <class TA, class TB, int NS, int LA, int LB, int CV = 0>
 int launch(const Params& p0, int force_tile, int split_k, hipStream_t stream) {
     Params p = p0;
     constexpr int BK = 64;
@@ -323,11 +388,11 @@ int launch(const Params& p0, int force_tile, int split_k, hipStream_t stream) {
     const int nbatch = p.nbatch < 1 ? 1 : p.nbatch;
     dim3 grid((p.N + BMN - 1) / BMN, (p.M + BMN - 1) / BMN, split_k * nbatch), block(256);
     if (big) {
-        using K = Kernel<TA, TB, NS, LA, LB, 128, 128, BK>;
-        AVSR_LAUNCH((gemm_kernel<TA, TB, NS, LA, LB, 128, 128, BK>), grid, block, K::LDS_BYTES, stream, p);
+        using K = Kernel<TA, TB, NS, LA, LB, 128, 128, BK, CV>;
+        AVSR_LAUNCH((gemm_kernel<TA, TB, NS, LA, LB, 128, 128, BK, CV>), grid, block, K::LDS_BYTES, stream, p);
     } else {
-        using K = Kernel<TA, TB, NS, LA, LB, 64, 64, BK>;
-        AVSR_LAUNCH((gemm_kernel<TA, TB, NS, LA, LB, 64, 64, BK>), grid, block, K::LDS_BYTES, stream, p);
+        using K = Kernel<TA, TB, NS, LA, LB, 64, 64, BK, CV>;
+        AVSR_LAUNCH((gemm_kernel<TA, TB, NS, LA, LB, 64, 64, BK, CV>), grid, block, K::LDS_BYTES, stream, p);
     }
     return 0;
 }

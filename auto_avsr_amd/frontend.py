@@ -1,12 +1,15 @@
 """Visual (Conv3d + ResNet-18) and audio (1-D ResNet-18) front-ends with the reference's module tree and
 ``state_dict`` keys (frontend/resnet.py, frontend/resnet1d.py).
 
-STATUS ("what is native"): the convolution / BatchNorm arithmetic of the front-ends still runs
-through ATen here while the implicit-GEMM HIP kernels for them are being brought up; this file is the one place
-in the hot path that is not yet served by libavsr_hip.so."""
+The torch ``nn.Conv*`` / ``nn.BatchNorm*`` children are parameter containers only: activations are kept
+channels-last ([N, H, W, C], activation dtype) and every convolution / BatchNorm / pooling step, forward and
+backward, runs in libavsr_hip.so (implicit-GEMM MFMA convolutions, auto_avsr_amd.functional.BasicBlockFn /
+StemFn / AvgPoolFn).  The blocks therefore exchange ``(tensor, (N, H, W, C))`` pairs instead of NCHW tensors;
+``Conv3dResNet`` / ``Conv1dResNet`` keep the reference's input and output conventions."""
 import torch
-import torch.nn.functional as F
 from torch import nn
+
+from . import functional as AF
 
 
 def conv3x3(in_planes, out_planes, stride=1):
@@ -39,11 +42,11 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x):
-        out = self.relu1(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        res = x if self.downsample is None else self.downsample(x)
-        return self.relu2(out + res)
+    def forward(self, xd):
+        x, (N, H, W, C) = xd
+        out = AF.basic_block(x, (N, H, W, C), self.stride, self.training, self.conv1, self.bn1, self.conv2, self.bn2,
+                             self.downsample)
+        return out, (N, out.shape[1], out.shape[2], out.shape[3])
 
 
 def _make_layer(block, inplanes, planes, blocks, stride, relu_type, down):
@@ -70,9 +73,9 @@ class ResNet(nn.Module):
         self.inplanes = 512
         self.avgpool = nn.AdaptiveAvgPool2d(1)
 
-    def forward(self, x):
-        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
-        return self.avgpool(x).flatten(1)
+    def forward(self, xd):
+        x, (N, H, W, C) = self.layer4(self.layer3(self.layer2(self.layer1(xd))))
+        return AF.avg_pool(x, N, H * W, C)  # AdaptiveAvgPool2d(1) + flatten -> (N, 512) f32
 
 
 def threeD_to_2D_tensor(x):
@@ -96,12 +99,13 @@ class Conv3dResNet(nn.Module):
         )
 
     def forward(self, xs_pad):
-        xs = xs_pad.transpose(2, 1)
-        B = xs.size(0)
-        xs = self.frontend3D(xs)
-        Tn = xs.shape[2]
-        xs = self.trunk(threeD_to_2D_tensor(xs))
-        return xs.view(B, Tn, xs.size(1))
+        B, Tn, C1, H, W = xs_pad.shape
+        assert C1 == 1, "expects (B, T, 1, H, W) grayscale clips"
+        conv, bn = self.frontend3D[0], self.frontend3D[1]
+        geom = (B, Tn, H, W) + tuple(conv.kernel_size) + (conv.stride[1],) + tuple(conv.padding)
+        x = AF.stem(xs_pad.reshape(B, Tn, H, W).float(), conv, bn, geom, pool=True)  # (B*T, 22, 22, 64)
+        feats = self.trunk((x, (B * Tn, x.shape[1], x.shape[2], x.shape[3])))
+        return feats.view(B, Tn, feats.size(1))
 
 
 def video_resnet():
@@ -133,11 +137,19 @@ class BasicBlock1D(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x):
-        out = self.relu1(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        res = x if self.downsample is None else self.downsample(x)
-        return self.relu2(out + res)
+    def forward(self, xd):
+        x, (N, H, W, C) = xd
+        out = AF.basic_block(x, (N, H, W, C), self.stride, self.training, _As2d(self.conv1), self.bn1,
+                             _As2d(self.conv2), self.bn2,
+                             None if self.downsample is None else (_As2d(self.downsample[0]), self.downsample[1]))
+        return out, (N, out.shape[1], out.shape[2], out.shape[3])
+
+
+class _As2d:
+    """View of a Conv1d's weight as a (Cout, Cin, 1, K) 2-D kernel (the 1-D trunk runs as H = 1 images)."""
+
+    def __init__(self, conv):
+        self.weight = conv.weight.unsqueeze(2)
 
 
 class ResNet1D(nn.Module):
@@ -160,8 +172,17 @@ class ResNet1D(nn.Module):
         self.avgpool = nn.AvgPool1d(kernel_size=20 // a_upsample_ratio, stride=20 // a_upsample_ratio)
 
     def forward(self, x):
-        x = self.relu(self.bn1(self.conv1(x)))
-        return self.avgpool(self.layer4(self.layer3(self.layer2(self.layer1(x)))))
+        """x: (B, S) f32 waveform -> (B, S // 640, 512) f32."""
+        B, S = x.shape
+        k, st, pd = self.conv1.kernel_size[0], self.conv1.stride[0], self.conv1.padding[0]
+        geom = (B, 1, 1, S, 1, 1, k, st, 0, 0, pd)
+        h = AF.stem(x, self.conv1, self.bn1, geom, pool=False)  # (B, 1, S/4, 64)
+        h, (N, H, W, C) = self.layer4(self.layer3(self.layer2(self.layer1((h, (B, 1, h.shape[2], h.shape[3]))))))
+        win = self.avgpool.kernel_size[0] if isinstance(self.avgpool.kernel_size, tuple) else self.avgpool.kernel_size
+        groups = B * (W // win)
+        if W % win:
+            raise ValueError("audio length must be a multiple of 640 samples")
+        return AF.avg_pool(h, groups, win, C).view(B, W // win, C)
 
 
 class Conv1dResNet(nn.Module):
@@ -174,7 +195,7 @@ class Conv1dResNet(nn.Module):
 
     def forward(self, xs_pad):
         n = xs_pad.size(1) // 640 * 640
-        return self.trunk(xs_pad[:, :n, :].transpose(1, 2)).transpose(1, 2)
+        return self.trunk(xs_pad[:, :n, 0].float().contiguous())
 
 
 def audio_resnet():

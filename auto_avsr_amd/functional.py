@@ -803,3 +803,179 @@ def log_softmax(logits):
     l2, ld = pit
     out = ops.log_softmax(l2, ld, rows, V)
     return out.view(logits.shape[:-1] + (ld,))[..., :V]
+
+
+# ================================================================================================ front-ends
+def _bn_fwd_params(c2, rows, C, bn, training):
+    """(mean, invstd, counts) of a BatchNorm over the rows of c2; bn = (weight, bias, running_mean, running_var,
+    eps, momentum).  Training: batch statistics (cross-rank when set_bn_sync) + running-stat update."""
+    if training:
+        return _bn_train_stats(c2, rows, C, bn[4], bn[5], bn[2], bn[3])
+    mean, invstd = ops.bn_eval_params(bn[2], bn[3], bn[4])
+    return mean, invstd, None
+
+
+def _bn_bwd(c, dy, add, mean, invstd, bn, counts, rows, C, act, want_dadd, training):
+    """Backward of y = act(bn(c) + add): returns (dc, dadd, dgamma, dbeta)."""
+    sums = ops.bn_bwd_reduce(c, dy, add, mean, invstd, bn[0], bn[1], rows, C, act)
+    dgamma, dbeta = sums[1].clone(), sums[0].clone()
+    if training:
+        sums_dx, inv_n, n_dev = _bn_bwd_sums(sums, counts, rows)
+    else:
+        sums_dx, inv_n, n_dev = torch.zeros_like(sums), 0.0, None
+    dc, dadd = ops.bn_bwd_apply(c, dy, add, mean, invstd, bn[0], bn[1], sums_dx, inv_n, rows, C, act, want_dadd,
+                                n_dev=n_dev)
+    return dc, dadd, dgamma, dbeta
+
+
+def bn_tuple(m):
+    """Pack a torch BatchNorm module for the front-end functions (and count the batch in training)."""
+    if m.training and m.num_batches_tracked is not None:
+        m.num_batches_tracked.add_(1)
+    return (m.weight, m.bias, m.running_mean, m.running_var, float(m.eps), float(m.momentum if m.momentum is not None else 0.1))
+
+
+class BasicBlockFn(torch.autograd.Function):
+    """frontend/resnet.py:82-98 (and resnet1d.py:83-99 with H = 1) on a channels-last activation:
+    conv3x3(stride) -> BN -> SiLU -> conv3x3 -> BN -> (+ identity | + BN(conv1x1(stride))) -> SiLU,
+    forward and backward, every convolution an implicit MFMA GEMM, BatchNorm in batch-statistics mode."""
+
+    @staticmethod
+    def forward(ctx, x, dims, stride, training, w1, g1, b1, w2, g2, b2, wd, gd, bd, bn1, bn2, bnd):
+        N, H, W, Cin = dims
+        Cout = w1.shape[0]
+        KH, KW = w1.shape[2], w1.shape[3]
+        ph, pw = (KH - 1) // 2, (KW - 1) // 2
+        T = act_dtype()
+        pr = _state["precise"]
+        OH, OW = ops.conv_out(H, KH, stride, ph), ops.conv_out(W, KW, stride, pw)
+        rows = N * OH * OW
+        bn1 = (g1, b1) + bn1
+        bn2 = (g2, b2) + bn2
+        c1 = ops.conv2d_fwd(x, ops.conv_weight_permute(w1, T), N, H, W, Cin, Cout, KH, KW, stride, ph, pw, pr)
+        m1, i1, n1 = _bn_fwd_params(c1, rows, Cout, bn1, training)
+        a1 = ops.bn_act_fwd(c1, None, m1, i1, g1, b1, rows, Cout, 1)
+        c2 = ops.conv2d_fwd(a1, ops.conv_weight_permute(w2, T), N, OH, OW, Cout, Cout, KH, KW, 1, ph, pw, pr)
+        m2, i2, n2 = _bn_fwd_params(c2, rows, Cout, bn2, training)
+        cd = md = idd = nd = None
+        if wd is not None:
+            bnd = (gd, bd) + bnd
+            cd = ops.conv2d_fwd(x, ops.conv_weight_permute(wd, T), N, H, W, Cin, Cout, 1, 1, stride, 0, 0, pr)
+            md, idd, nd = _bn_fwd_params(cd, rows, Cout, bnd, training)
+            r = ops.bn_act_fwd(cd, None, md, idd, gd, bd, rows, Cout, 0)
+        else:
+            r = x
+        out = ops.bn_act_fwd(c2, r, m2, i2, g2, b2, rows, Cout, 1)
+        ctx.save_for_backward(x, c1, a1, c2, cd, r if wd is not None else None, w1, w2, wd, g1, b1, g2, b2, gd, bd, m1, i1,
+                              n1, m2, i2, n2, md, idd, nd)
+        ctx.meta = (dims, stride, training, (OH, OW), bn1[2:], bn2[2:], bnd[2:] if wd is not None else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x, c1, a1, c2, cd, r, w1, w2, wd, g1, b1, g2, b2, gd, bd, m1, i1, n1, m2, i2, n2, md, idd, nd) = ctx.saved_tensors
+        dims, stride, training, (OH, OW), r1, r2, rd = ctx.meta
+        N, H, W, Cin = dims
+        Cout = w1.shape[0]
+        KH, KW = w1.shape[2], w1.shape[3]
+        ph, pw = (KH - 1) // 2, (KW - 1) // 2
+        T = act_dtype()
+        pr = _state["precise"]
+        rows = N * OH * OW
+        dout = dout.contiguous()
+        if wd is None:
+            r = x
+        dc2, dr, dg2, db2 = _bn_bwd(c2, dout, r, m2, i2, (g2, b2) + r2, n2, rows, Cout, 1, True, training)
+        dw2 = ops.conv_weight_unpermute(ops.conv2d_wgrad(dc2, a1, N, OH, OW, Cout, Cout, KH, KW, 1, ph, pw, pr), w2.shape)
+        da1 = ops.conv2d_dgrad(dc2, ops.conv_weight_permute(w2, T, to_dgrad=True), None, N, OH, OW, Cout, Cout, KH, KW, 1,
+                               ph, pw, pr)
+        dc1, _, dg1, db1 = _bn_bwd(c1, da1, None, m1, i1, (g1, b1) + r1, n1, rows, Cout, 1, False, training)
+        dw1 = ops.conv_weight_unpermute(ops.conv2d_wgrad(dc1, x, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, pr), w1.shape)
+        dwd = dgd = dbd = None
+        if wd is not None:
+            dcd, _, dgd, dbd = _bn_bwd(cd, dr, None, md, idd, (gd, bd) + rd, nd, rows, Cout, 0, False, training)
+            dwd = ops.conv_weight_unpermute(ops.conv2d_wgrad(dcd, x, N, H, W, Cin, Cout, 1, 1, stride, 0, 0, pr), wd.shape)
+            skip = ops.conv2d_dgrad(dcd, ops.conv_weight_permute(wd, T, to_dgrad=True), None, N, H, W, Cin, Cout, 1, 1,
+                                    stride, 0, 0, pr)
+        else:
+            skip = dr
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv2d_dgrad(dc1, ops.conv_weight_permute(w1, T, to_dgrad=True), skip, N, H, W, Cin, Cout, KH, KW,
+                                  stride, ph, pw, pr)
+        return (dx, None, None, None, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None)
+
+
+def basic_block(x, dims, stride, training, conv1, bn1, conv2, bn2, down):
+    """x: channels-last [N,H,W,Cin] activation-dtype tensor; modules supply the parameters."""
+    t1, t2 = bn_tuple(bn1), bn_tuple(bn2)
+    if down is not None:
+        td = bn_tuple(down[1])
+        return BasicBlockFn.apply(x, dims, stride, training, conv1.weight, t1[0], t1[1], conv2.weight, t2[0], t2[1],
+                                  down[0].weight, td[0], td[1], t1[2:], t2[2:], td[2:])
+    return BasicBlockFn.apply(x, dims, stride, training, conv1.weight, t1[0], t1[1], conv2.weight, t2[0], t2[1], None, None,
+                              None, t1[2:], t2[2:], None)
+
+
+class StemFn(torch.autograd.Function):
+    """Single-input-channel stem: conv (temporal x spatial taps) -> BN -> SiLU -> optional 3x3/s2 max-pool.
+    Video: frontend/resnet.py:203-219 (Conv3d(1,64,(5,7,7),s(1,2,2)) + BatchNorm3d + SiLU + MaxPool3d).
+    Audio: frontend/resnet1d.py:124-139,190-192 (Conv1d(1,64,80,s4) + BatchNorm1d + SiLU; no pooling)."""
+
+    @staticmethod
+    def forward(ctx, x, w, g, b, bn_rest, geom, pool, training):
+        B, Tn, H, W, KT, KH, KW, stride, pt, ph, pw = geom
+        Cout = w.shape[0]
+        T = act_dtype()
+        pr = _state["precise"]
+        x = x.contiguous()
+        taps = KT * KH * KW
+        ldw = padded_cols(taps)
+        wp = ops.conv_weight_permute(w, T, ld_out=ldw)
+        c0 = ops.conv_stem_fwd(x, wp, ldw, T, B, Tn, H, W, Cout, KT, KH, KW, stride, pt, ph, pw, pr)
+        OH, OW = c0.shape[1], c0.shape[2]
+        rows = B * Tn * OH * OW
+        bn = (g, b) + bn_rest
+        m0, i0, n0 = _bn_fwd_params(c0, rows, Cout, bn, training)
+        a0 = ops.bn_act_fwd(c0, None, m0, i0, g, b, rows, Cout, 1)
+        out = ops.maxpool2d_fwd(a0, B * Tn, OH, OW, Cout, 3, 2, 1) if pool else a0
+        ctx.save_for_backward(x, c0, a0 if pool else None, g, b, m0, i0, n0)
+        ctx.meta = (geom, pool, training, bn_rest, (OH, OW), w.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, c0, a0, g, b, m0, i0, n0 = ctx.saved_tensors
+        geom, pool, training, bn_rest, (OH, OW), wshape = ctx.meta
+        B, Tn, H, W, KT, KH, KW, stride, pt, ph, pw = geom
+        Cout = wshape[0]
+        rows = B * Tn * OH * OW
+        dout = dout.contiguous()
+        da0 = ops.maxpool2d_bwd(a0, dout, B * Tn, OH, OW, Cout, 3, 2, 1) if pool else dout
+        dc0, _, dg, db = _bn_bwd(c0, da0, None, m0, i0, (g, b) + bn_rest, n0, rows, Cout, 1, False, training)
+        dw = ops.conv_stem_wgrad(dc0, x, B, Tn, H, W, Cout, KT, KH, KW, stride, pt, ph, pw, _state["precise"])
+        return None, dw.view(wshape), dg, db, None, None, None, None
+
+
+def stem(x, conv, bn, geom, pool):
+    t = bn_tuple(bn)
+    return StemFn.apply(x, conv.weight, t[0], t[1], t[2:], geom, pool, bn.training)
+
+
+class AvgPoolFn(torch.autograd.Function):
+    """Mean over groups of `win` consecutive pixels of a channels-last tensor -> f32 [groups, C]
+    (AdaptiveAvgPool2d(1), resnet.py:117,164; AvgPool1d(20), resnet1d.py:143-146)."""
+
+    @staticmethod
+    def forward(ctx, x, groups, win, C):
+        ctx.meta = (groups, win, C, x.dtype, x.shape)
+        return ops.avgpool_fwd(x.contiguous(), groups, win, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        groups, win, C, dtype, shape = ctx.meta
+        return ops.avgpool_bwd(_to_f32(dy), dtype, groups, win, C).view(shape), None, None, None
+
+
+def avg_pool(x, groups, win, C):
+    return AvgPoolFn.apply(x, groups, win, C)

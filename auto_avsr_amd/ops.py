@@ -293,3 +293,94 @@ def log_softmax(x, ld, rows, V):
     ws = torch.empty(rows, dtype=torch.float32, device=x.device)
     call("avsr_log_softmax", _ptr(x), ld, _ptr(ws), _ptr(out), rows, V, _stream(x))
     return out
+
+
+# ---------------------------------------------------------------------------------------------- convolutions
+def conv_weight_permute(w, out_dtype, to_dgrad=False, ld_out=None):
+    """torch conv weight [Cout, Cin, *taps] (f32) -> [Cout][taps][Cin] (or [Cin][taps][Cout] for the data gradient)."""
+    Cout, Cin = w.shape[0], w.shape[1]
+    taps = w[0, 0].numel()
+    a, b = (Cin, Cout) if to_dgrad else (Cout, Cin)
+    ld = ld_out or taps * b
+    alloc = torch.zeros if ld != taps * b else torch.empty
+    out = alloc(a, ld, dtype=out_dtype, device=w.device)
+    call("avsr_conv_weight_permute", _ptr(w), _ptr(out), dt(out), Cout, Cin, taps, int(to_dgrad), ld, _stream(w))
+    return out
+
+
+def conv_weight_unpermute(dwp, shape):
+    Cout, Cin = shape[0], shape[1]
+    taps = 1
+    for s in shape[2:]:
+        taps *= s
+    dw = torch.empty(shape, dtype=torch.float32, device=dwp.device)
+    call("avsr_conv_weight_unpermute", _ptr(dwp), _ptr(dw), Cout, Cin, taps, _stream(dwp))
+    return dw
+
+
+def conv_out(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
+def conv2d_fwd(x, wp, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise):
+    OH, OW = conv_out(H, KH, stride, ph), conv_out(W, KW, stride, pw)
+    y = torch.empty(N, OH, OW, Cout, dtype=x.dtype, device=x.device)
+    call("avsr_conv2d_fwd", _ptr(x), dt(x), _ptr(wp), dt(wp), _ptr(y), N, H, W, Cin, Cout, KH, KW, stride, ph, pw,
+         int(precise), _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin)
+    return y
+
+
+def conv2d_dgrad(dy, wpd, resid, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise):
+    dx = torch.empty(N, H, W, Cin, dtype=dy.dtype, device=dy.device)
+    call("avsr_conv2d_dgrad", _ptr(dy), dt(dy), _ptr(wpd), dt(wpd), _ptr(resid), _ptr(dx), N, H, W, Cin, Cout, KH, KW,
+         stride, ph, pw, int(precise), _stream(dy), flops=2.0 * N * H * W * Cin * KH * KW * Cout)
+    return dx
+
+
+def conv2d_wgrad(dy, x, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise):
+    OH, OW = conv_out(H, KH, stride, ph), conv_out(W, KW, stride, pw)
+    dwp = torch.zeros(Cout, KH * KW * Cin, dtype=torch.float32, device=x.device)
+    call("avsr_conv2d_wgrad", _ptr(dy), _ptr(x), dt(x), _ptr(dwp), N, H, W, Cin, Cout, KH, KW, stride, ph, pw,
+         int(precise), _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin)
+    return dwp
+
+
+def conv_stem_fwd(x, wp, ldw, out_dtype, B, T, H, W, Cout, KT, KH, KW, stride, pt, ph, pw, precise):
+    OH, OW = conv_out(H, KH, stride, ph), conv_out(W, KW, stride, pw)
+    y = torch.empty(B * T, OH, OW, Cout, dtype=out_dtype, device=x.device)
+    call("avsr_conv_stem_fwd", _ptr(x), _ptr(wp), dt(wp), ldw, _ptr(y), dt(y), B, T, H, W, Cout, KT, KH, KW, stride, pt,
+         ph, pw, int(precise), _stream(x), flops=2.0 * B * T * OH * OW * Cout * KT * KH * KW)
+    return y
+
+
+def conv_stem_wgrad(dy, x, B, T, H, W, Cout, KT, KH, KW, stride, pt, ph, pw, precise):
+    OH, OW = conv_out(H, KH, stride, ph), conv_out(W, KW, stride, pw)
+    dw = torch.zeros(Cout, KT * KH * KW, dtype=torch.float32, device=x.device)
+    call("avsr_conv_stem_wgrad", _ptr(dy), dt(dy), _ptr(x), _ptr(dw), B, T, H, W, Cout, KT, KH, KW, stride, pt, ph, pw,
+         int(precise), _stream(x), flops=2.0 * B * T * OH * OW * Cout * KT * KH * KW)
+    return dw
+
+
+def maxpool2d_fwd(x, N, H, W, C, K, S, P):
+    OH, OW = conv_out(H, K, S, P), conv_out(W, K, S, P)
+    y = torch.empty(N, OH, OW, C, dtype=x.dtype, device=x.device)
+    call("avsr_maxpool2d_fwd", _ptr(x), _ptr(y), dt(x), N, H, W, C, K, S, P, _stream(x))
+    return y
+
+
+def maxpool2d_bwd(x, dy, N, H, W, C, K, S, P):
+    dx = torch.empty_like(x)
+    call("avsr_maxpool2d_bwd", _ptr(x), _ptr(dy), _ptr(dx), dt(x), N, H, W, C, K, S, P, _stream(x))
+    return dx
+
+
+def avgpool_fwd(x, groups, win, C):
+    y = torch.empty(groups, C, dtype=torch.float32, device=x.device)
+    call("avsr_avgpool_fwd", _ptr(x), dt(x), _ptr(y), groups, win, C, _stream(x))
+    return y
+
+
+def avgpool_bwd(dy, out_dtype, groups, win, C):
+    dx = torch.empty(groups * win, C, dtype=out_dtype, device=dy.device)
+    call("avsr_avgpool_bwd", _ptr(dy), _ptr(dx), dt(dx), groups, win, C, _stream(dy))
+    return dx

@@ -159,7 +159,7 @@ def main():
                                "length-bucketed batches, max-frames=1600 (real frames), fwd+bwd"
                                + (", DDP grad all-reduce + SyncBN over RCCL" if world > 1 else ""),
                    "padded_frames_per_sec": round(float(ftot[1]) / dt, 2),
-                   "frontend": "ATen (interim)", "encoder_decoder_losses": "libavsr_hip.so"},
+                   "all_hot_path_compute": "libavsr_hip.so (hand-written HIP, gfx950)"},
     }
     if rank == 0 and not args.no_roofline:
         out["roofline"] = roofline(model, data[args.warmup], ops)

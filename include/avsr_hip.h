@@ -161,6 +161,42 @@ int avsr_embed_bwd(const int64_t* ids, const float* dout, float* dtable, int64_t
 int avsr_log_softmax(const float* x, int64_t ld, float* lse_ws, float* out, int64_t rows, int V,
                      avsr_stream_t stream);
 
+/* ---- implicit-GEMM convolutions on channels-last activations (gemm_conv.hip) -------------------- */
+/* torch weight [Cout][Cin][taps] (f32) -> out[a][tap][b] with row pitch ld_out, a/b = co/ci (to_dgrad=0: forward and
+ * weight-gradient layout) or ci/co (to_dgrad=1: data-gradient layout), cast to out_dtype */
+int avsr_conv_weight_permute(const float* w, void* out, int out_dtype, int Cout, int Cin, int taps, int to_dgrad,
+                             int64_t ld_out, avsr_stream_t stream);
+/* dw[Cout][Cin][taps] = dwp[Cout][taps][Cin] */
+int avsr_conv_weight_unpermute(const float* dwp, float* dw, int Cout, int Cin, int taps, avsr_stream_t stream);
+/* y[N,OH,OW,Cout] = conv(x[N,H,W,Cin], wp[Cout][KH][KW][Cin])   (frontend/resnet.py:10-17,20-35; H = 1 for 1-D) */
+int avsr_conv2d_fwd(const void* x, int dtype, const void* wp, int w_dtype, void* y, int N, int H, int W, int Cin,
+                    int Cout, int KH, int KW, int stride, int pad_h, int pad_w, int precise, avsr_stream_t stream);
+/* dx[N,H,W,Cin] = conv^T(dy[N,OH,OW,Cout], wpd[Cin][KH][KW][Cout]) (+ resid, same dtype/shape, may be NULL) */
+int avsr_conv2d_dgrad(const void* dy, int dtype, const void* wpd, int w_dtype, const void* resid, void* dx, int N,
+                      int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_h, int pad_w, int precise,
+                      avsr_stream_t stream);
+/* dwp[Cout][KH][KW][Cin] (f32, caller zeroes) += dy^T im2col(x) */
+int avsr_conv2d_wgrad(const void* dy, const void* x, int dtype, float* dwp, int N, int H, int W, int Cin, int Cout,
+                      int KH, int KW, int stride, int pad_h, int pad_w, int precise, avsr_stream_t stream);
+/* single-input-channel stem with temporal taps (resnet.py:204-211 Conv3d(1,64,(5,7,7),s(1,2,2)); resnet1d.py:124-131
+ * Conv1d(1,64,80,s4) with KT=KH=1): x f32 [B,T,H,W]; wp [Cout][ldw] */
+int avsr_conv_stem_fwd(const float* x, const void* wp, int w_dtype, int ldw, void* y, int y_dtype, int B, int T, int H,
+                       int W, int Cout, int KT, int KH, int KW, int stride, int pad_t, int pad_h, int pad_w,
+                       int precise, avsr_stream_t stream);
+/* dw[Cout][KT*KH*KW] (f32, caller zeroes) += dy^T im2col(x) */
+int avsr_conv_stem_wgrad(const void* dy, int dy_dtype, const float* x, float* dw, int B, int T, int H, int W, int Cout,
+                         int KT, int KH, int KW, int stride, int pad_t, int pad_h, int pad_w, int precise,
+                         avsr_stream_t stream);
+
+/* ---- pooling on channels-last tensors (pool.hip) ------------------------------------------------- */
+int avsr_maxpool2d_fwd(const void* x, void* y, int dtype, int64_t N, int H, int W, int C, int K, int S, int P,
+                       avsr_stream_t stream);
+int avsr_maxpool2d_bwd(const void* x, const void* dy, void* dx, int dtype, int64_t N, int H, int W, int C, int K, int S,
+                       int P, avsr_stream_t stream);
+/* y[g,:] = mean of rows g*win .. g*win+win-1 of x [groups*win, C]; y f32 */
+int avsr_avgpool_fwd(const void* x, int dtype, float* y, int64_t groups, int win, int C, avsr_stream_t stream);
+int avsr_avgpool_bwd(const float* dy, void* dx, int dtype, int64_t groups, int win, int C, avsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

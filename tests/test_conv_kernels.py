@@ -1,0 +1,106 @@
+"""Implicit-GEMM convolutions and pooling (front-ends) vs torch conv2d / conv3d / pooling autograd."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from auto_avsr_amd import ops
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, Cin, Cout, K, stride, pad
+    (3, 11, 9, 16, 24, 3, 1, 1),
+    (2, 12, 10, 64, 72, 3, 2, 1),
+    (2, 11, 11, 32, 40, 1, 2, 0),
+    (2, 1, 37, 16, 32, 3, 2, 1),   # 1-D (audio trunk) as an H = 1 image: KH = 1
+])
+@pytest.mark.parametrize("precise", [True, False])
+def test_conv2d_fwd_dgrad_wgrad(dev, cfg, precise):
+    N, H, W, Cin, Cout, K, s, p = cfg
+    torch.manual_seed(N * 7 + K)
+    KH, ph = (1, 0) if H == 1 else (K, p)
+    dtype = torch.float32 if precise else torch.bfloat16
+    x = torch.randn(N, Cin, H, W).to(dtype).float().requires_grad_()
+    w = (torch.randn(Cout, Cin, KH, K) / (Cin * KH * K) ** 0.5).requires_grad_()
+    wq = w.detach().to(dtype).float().requires_grad_()
+    y_ref = F.conv2d(x, wq, stride=s, padding=(ph, p))
+    dy = torch.randn_like(y_ref).to(dtype).float()
+    y_ref.backward(dy)
+    tol = 2e-5 if precise else 2e-2
+    xd = nhwc(x.detach()).to(dtype).to(dev)
+    wp = ops.conv_weight_permute(w.detach().to(dev), dtype)
+    y = ops.conv2d_fwd(xd, wp, N, H, W, Cin, Cout, KH, K, s, ph, p, precise)
+    assert (y.float().cpu() - nhwc(y_ref.detach())).abs().max() < tol * max(1.0, y_ref.abs().max().item())
+    dyd = nhwc(dy).to(dtype).to(dev)
+    wpd = ops.conv_weight_permute(w.detach().to(dev), dtype, to_dgrad=True)
+    dx = ops.conv2d_dgrad(dyd, wpd, None, N, H, W, Cin, Cout, KH, K, s, ph, p, precise)
+    assert (dx.float().cpu() - nhwc(x.grad)).abs().max() < tol * max(1.0, x.grad.abs().max().item())
+    res = torch.randn(N, H, W, Cin).to(dtype)
+    dx2 = ops.conv2d_dgrad(dyd, wpd, res.to(dev), N, H, W, Cin, Cout, KH, K, s, ph, p, precise)
+    assert (dx2.float().cpu() - nhwc(x.grad) - res.float()).abs().max() < 2 * tol * max(1.0, x.grad.abs().max().item())
+    dwp = ops.conv2d_wgrad(dyd, xd, N, H, W, Cin, Cout, KH, K, s, ph, p, precise)
+    dw = ops.conv_weight_unpermute(dwp, wq.shape)
+    assert (dw.cpu() - wq.grad).abs().max() < tol * max(1.0, wq.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("precise", [True, False])
+def test_conv_stem_video(dev, precise):
+    torch.manual_seed(3)
+    B, T, H, W, Cout = 2, 5, 20, 18, 16
+    x = torch.randn(B, T, H, W)
+    w = (torch.randn(Cout, 1, 5, 7, 7) / 245 ** 0.5).requires_grad_()
+    dtype = torch.float32 if precise else torch.bfloat16
+    wq = w.detach().to(dtype).float().requires_grad_()
+    xq = x.to(dtype).float() if not precise else x
+    y_ref = F.conv3d(xq.unsqueeze(1), wq, stride=(1, 2, 2), padding=(2, 3, 3))  # (B,C,T,OH,OW)
+    dy = torch.randn_like(y_ref).to(dtype).float()
+    y_ref.backward(dy)
+    tol = 3e-5 if precise else 3e-2
+    wp = ops.conv_weight_permute(w.detach().to(dev), dtype, ld_out=248)
+    y = ops.conv_stem_fwd(x.to(dev), wp, 248, dtype, B, T, H, W, Cout, 5, 7, 7, 2, 2, 3, 3, precise)
+    ref = y_ref.detach().permute(0, 2, 3, 4, 1).reshape(B * T, y_ref.shape[3], y_ref.shape[4], Cout)
+    assert (y.float().cpu() - ref).abs().max() < tol * max(1.0, ref.abs().max().item())
+    dyd = dy.permute(0, 2, 3, 4, 1).reshape(ref.shape).contiguous().to(dtype).to(dev)
+    dw = ops.conv_stem_wgrad(dyd, x.to(dev), B, T, H, W, Cout, 5, 7, 7, 2, 2, 3, 3, precise)
+    assert (dw.cpu() - wq.grad.reshape(Cout, -1)).abs().max() < tol * max(1.0, wq.grad.abs().max().item())
+
+
+def test_conv_stem_audio(dev):
+    torch.manual_seed(4)
+    B, S, Cout = 2, 640, 16
+    x = torch.randn(B, S)
+    w = (torch.randn(Cout, 1, 80) / 80 ** 0.5).requires_grad_()
+    y_ref = F.conv1d(x.unsqueeze(1), w, stride=4, padding=38)  # (B, C, S/4)
+    dy = torch.randn_like(y_ref)
+    y_ref.backward(dy)
+    wp = ops.conv_weight_permute(w.detach().to(dev), torch.float32, ld_out=80)
+    y = ops.conv_stem_fwd(x.to(dev), wp, 80, torch.float32, B, 1, 1, S, Cout, 1, 1, 80, 4, 0, 0, 38, True)
+    ref = y_ref.detach().permute(0, 2, 1).reshape(B, 1, S // 4, Cout)
+    assert (y.cpu() - ref).abs().max() < 3e-5 * max(1.0, ref.abs().max().item())
+    dyd = dy.permute(0, 2, 1).reshape(ref.shape).contiguous().to(dev)
+    dw = ops.conv_stem_wgrad(dyd, x.to(dev), B, 1, 1, S, Cout, 1, 1, 80, 4, 0, 0, 38, True)
+    assert (dw.cpu() - w.grad.reshape(Cout, -1)).abs().max() < 3e-5 * max(1.0, w.grad.abs().max().item())
+
+
+def test_pooling(dev):
+    torch.manual_seed(5)
+    N, C, H, W = 3, 16, 11, 10
+    x = torch.randn(N, C, H, W)
+    x[0, :, 2, 2] = x[0, :, 2, 3]  # ties inside a window: first maximum wins
+    x.requires_grad_()
+    y_ref = F.max_pool2d(x, 3, 2, 1)
+    dy = torch.randn_like(y_ref)
+    y_ref.backward(dy)
+    xd = nhwc(x.detach()).to(dev)
+    y = ops.maxpool2d_fwd(xd, N, H, W, C, 3, 2, 1)
+    assert (y.cpu() - nhwc(y_ref.detach())).abs().max() == 0
+    dx = ops.maxpool2d_bwd(xd, nhwc(dy).to(dev), N, H, W, C, 3, 2, 1)
+    assert (dx.cpu() - nhwc(x.grad)).abs().max() < 1e-6
+    z = torch.randn(4 * 9, 24)
+    a = ops.avgpool_fwd(z.to(dev), 4, 9, 24)
+    assert (a.cpu() - z.view(4, 9, 24).mean(1)).abs().max() < 1e-6
+    dz = ops.avgpool_bwd(a, torch.float32, 4, 9, 24)
+    assert (dz.cpu() - (a.cpu() / 9).repeat_interleave(9, 0)).abs().max() < 1e-6
