@@ -51,27 +51,40 @@ __global__ __launch_bounds__(BN_THREADS) void bn_colreduce_kernel(
             load8(gamma + cc * 8, ga);
             load8(beta + cc * 8, be);
         }
-        for (long r = r0 + rl; r < r1; r += RL) {
-            float v[8];
-            load8(x + r * C + cc * 8, v);
-            if (MODE == 0) {
+        constexpr int U = 4;  // independent rows in flight per thread (memory-level parallelism)
+        for (long rb = r0 + rl; rb < r1; rb += (long)U * RL) {
+            float v[U][8], g[U][8], ad[U][8];
 #pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const float d = v[e] - sh[e];
-                    a[e] += d;
-                    b[e] += d * d;
+            for (int u = 0; u < U; u++) {
+                const long r = rb + (long)u * RL;
+                if (r < r1) {
+                    load8(x + r * C + cc * 8, v[u]);
+                    if (MODE == 1) {
+                        load8(dy + r * C + cc * 8, g[u]);
+                        if (add) load8(add + r * C + cc * 8, ad[u]);
+                    }
                 }
-            } else {
-                float g[8], ad[8];
-                load8(dy + r * C + cc * 8, g);
-                if (add) load8(add + r * C + cc * 8, ad);
+            }
 #pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const float xh = (v[e] - mu[e]) * is[e];
-                    const float z = xh * ga[e] + be[e] + (add ? ad[e] : 0.f);
-                    const float dz = g[e] * act_grad(z, act);
-                    a[e] += dz;
-                    b[e] += dz * xh;
+            for (int u = 0; u < U; u++) {
+                const long r = rb + (long)u * RL;
+                if (r >= r1) continue;
+                if (MODE == 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const float d = v[u][e] - sh[e];
+                        a[e] += d;
+                        b[e] += d * d;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const float xh = (v[u][e] - mu[e]) * is[e];
+                        const float z = xh * ga[e] + be[e] + (add ? ad[u][e] : 0.f);
+                        const float dz = g[u][e] * act_grad(z, act);
+                        a[e] += dz;
+                        b[e] += dz * xh;
+                    }
                 }
             }
         }

@@ -69,22 +69,26 @@ __global__ __launch_bounds__(EW_THREADS) void head_bias_kernel(const T* __restri
     }
 }
 
-// dq = d1 + d2 (written with row stride ldo); db1 += colsum(d1), db2 += colsum(d2)
+// dq = d1 + d2 (written with row stride ldo); db1 += colsum(d1), db2 += colsum(d2).
+// thread = (8-column chunk, row lane): CL chunk lanes x RL row lanes per block, rows strided by RL; the RL
+// partials meet in LDS and one lane per column issues the atomics.
 template <class T>
 __global__ __launch_bounds__(EW_THREADS) void head_bias_bwd_kernel(const T* __restrict__ d1,
                                                                    const T* __restrict__ d2, T* __restrict__ dq,
                                                                    long ldo, float* __restrict__ db1,
                                                                    float* __restrict__ db2, long rows, int cols,
-                                                                   int rows_per_block) {
-    // thread handles one 8-wide column chunk over a strip of rows; cols/8 chunks per row
+                                                                   int rows_per_block, int CL) {
+    __shared__ float red[EW_THREADS * 16];
     const int cv = cols >> 3;
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL, RL = EW_THREADS / CL;
+    const int cc = blockIdx.x * CL + cl;
     const long r0 = (long)blockIdx.y * rows_per_block;
     const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    for (int cc = blockIdx.x * EW_THREADS + threadIdx.x; cc < cv; cc += gridDim.x * EW_THREADS) {
-        float s1[8], s2[8];
+    float s1[8], s2[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) s1[e] = s2[e] = 0.f;
-        for (long r = r0; r < r1; r++) {
+    for (int e = 0; e < 8; e++) s1[e] = s2[e] = 0.f;
+    if (cc < cv) {
+        for (long r = r0 + rl; r < r1; r += RL) {
             float a[8], b[8], o[8];
             load8(d1 + r * cols + cc * 8, a);
             if (d2) load8(d2 + r * cols + cc * 8, b);
@@ -97,6 +101,20 @@ __global__ __launch_bounds__(EW_THREADS) void head_bias_bwd_kernel(const T* __re
             }
             if (dq) store8(dq + r * ldo + cc * 8, o);
         }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        red[threadIdx.x * 16 + e] = s1[e];
+        red[threadIdx.x * 16 + 8 + e] = s2[e];
+    }
+    __syncthreads();
+    if (rl == 0 && cc < cv) {
+        for (int q = 1; q < RL; q++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                s1[e] += red[(q * CL + cl) * 16 + e];
+                s2[e] += red[(q * CL + cl) * 16 + 8 + e];
+            }
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             if (db1) atomicAdd(db1 + cc * 8 + e, s1[e]);
@@ -190,14 +208,16 @@ extern "C" int avsr_head_bias_bwd(const void* d1, const void* d2, int dtype, voi
                                   float* db2, int64_t rows, int cols, hipStream_t stream) {
     AVSR_REQUIRE(cols % 8 == 0 && (dq == nullptr || ldo % 8 == 0), "head_bias_bwd: cols/ldo must be multiples of 8");
     if (rows <= 0) return 0;
-    const int rpb = 32;
-    dim3 grid(((cols >> 3) + EW_THREADS - 1) / EW_THREADS, (unsigned)((rows + rpb - 1) / rpb)), block(EW_THREADS);
+    const int cv = cols >> 3;
+    const int CL = cv >= 32 ? 32 : (cv >= 16 ? 16 : 8);
+    const int rpb = 8 * (EW_THREADS / CL);  // 8 rows per thread
+    dim3 grid((cv + CL - 1) / CL, (unsigned)((rows + rpb - 1) / rpb)), block(EW_THREADS);
     if (dtype == 0)
         AVSR_LAUNCH((head_bias_bwd_kernel<float>), grid, block, 0, stream, (const float*)d1, (const float*)d2,
-                    (float*)dq, (long)ldo, db1, db2, (long)rows, cols, rpb);
+                    (float*)dq, (long)ldo, db1, db2, (long)rows, cols, rpb, CL);
     else
         AVSR_LAUNCH((head_bias_bwd_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)d1, (const bf16_t*)d2,
-                    (bf16_t*)dq, (long)ldo, db1, db2, (long)rows, cols, rpb);
+                    (bf16_t*)dq, (long)ldo, db1, db2, (long)rows, cols, rpb, CL);
     AVSR_CHECK_LAUNCH("head_bias_bwd");
     return 0;
 }

@@ -173,7 +173,8 @@ struct Kernel {
     static constexpr int B_ITEMS = (LB == 0) ? (BN * (BK / 8) / NT) : ((BK / 2) * (BN / 8) / NT);
     static constexpr int A_RAW = (LA == 0) ? A_ITEMS : 2 * A_ITEMS;
     static constexpr int B_RAW = (LB == 0) ? B_ITEMS : 2 * B_ITEMS;
-    static constexpr size_t LDS_BYTES = (size_t)NS * (BM + BN) * PITCH * sizeof(bf16_t);
+    static constexpr size_t STAGE_ELEMS = (size_t)NS * (BM + BN) * PITCH;  // one LDS stage (A then B)
+    static constexpr size_t LDS_BYTES = 2 * STAGE_ELEMS * sizeof(bf16_t);   // double buffered
     static constexpr bool GA = (CV == 1 || CV == 2 || CV == 4);  // A operand gathered
     static constexpr bool GB = (CV == 3 || CV == 5);             // B operand gathered
     static_assert(A_ITEMS >= 1 && B_ITEMS >= 1, "tile too small for 256 threads");
@@ -259,8 +260,7 @@ struct Kernel {
     }
 
     static AVSR_DEV void run(const Params& p, char* smem) {
-        bf16_t* As = reinterpret_cast<bf16_t*>(smem);
-        bf16_t* Bs = As + (size_t)NS * BM * PITCH;
+        bf16_t* stage0 = reinterpret_cast<bf16_t*>(smem);
         const int zb = blockIdx.z / p.nsplit, zs = blockIdx.z % p.nsplit;
         const int zbb = zb / p.batch_h, zbh = zb % p.batch_h;
         const TA* A = reinterpret_cast<const TA*>(p.A) + zbb * p.sAb + zbh * p.sAh;
@@ -280,16 +280,21 @@ struct Kernel {
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
+        // Software pipeline, one barrier per k-tile: while tile t is multiplied out of LDS stage (t&1), the global
+        // loads of tile t+1 are in flight and are then written to the other stage.
         Raw8<TA> ra[A_RAW];
         Raw8<TB> rb[B_RAW];
         fetch<TA, LA, BM, A_ITEMS, A_RAW, GA>(ra, A, p.lda, m0, p.M, kbeg, kend, p, p.a_skew, p.skew_off, p.skew_lim);
         fetch<TB, LB, BN, B_ITEMS, B_RAW, GB>(rb, B, p.ldb, n0, p.N, kbeg, kend, p);
-        stash<TA, LA, BM, A_ITEMS, A_RAW>(ra, As);
-        stash<TB, LB, BN, B_ITEMS, B_RAW>(rb, Bs);
+        stash<TA, LA, BM, A_ITEMS, A_RAW>(ra, stage0);
+        stash<TB, LB, BN, B_ITEMS, B_RAW>(rb, stage0 + (size_t)NS * BM * PITCH);
         __syncthreads();
 
+        int cur = 0;
         for (int k0 = kbeg; k0 < kend; k0 += BK) {
             const bool more = (k0 + BK) < kend;
+            const bf16_t* As = stage0 + (size_t)cur * STAGE_ELEMS;
+            const bf16_t* Bs = As + (size_t)NS * BM * PITCH;
             if (more) {
                 fetch<TA, LA, BM, A_ITEMS, A_RAW, GA>(ra, A, p.lda, m0, p.M, k0 + BK, kend, p, p.a_skew, p.skew_off, p.skew_lim);
                 fetch<TB, LB, BN, B_ITEMS, B_RAW, GB>(rb, B, p.ldb, n0, p.N, k0 + BK, kend, p);
@@ -315,12 +320,13 @@ struct Kernel {
 #pragma unroll
                     for (int j = 0; j < TN; j++) acc[i][j] = mma32<NS>(fa[i], fb[j], acc[i][j]);
             }
-            __syncthreads();
             if (more) {
-                stash<TA, LA, BM, A_ITEMS, A_RAW>(ra, As);
-                stash<TB, LB, BN, B_ITEMS, B_RAW>(rb, Bs);
-                __syncthreads();
+                bf16_t* An = stage0 + (size_t)(cur ^ 1) * STAGE_ELEMS;
+                stash<TA, LA, BM, A_ITEMS, A_RAW>(ra, An);
+                stash<TB, LB, BN, B_ITEMS, B_RAW>(rb, An + (size_t)NS * BM * PITCH);
             }
+            __syncthreads();
+            cur ^= 1;
         }
 
         // ---- epilogue

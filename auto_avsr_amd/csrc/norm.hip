@@ -70,89 +70,104 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(
     }
 }
 
-// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma ; optional  dx += dres.
-// dgamma/dbeta: per-lane register partials over the block's rows -> LDS -> one atomic per column.
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma ; optional  dx += dres.  One wave per row.
 template <class TDY>
-__global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(
+__global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_dx_kernel(
     const TDY* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
-    const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
-    const float* __restrict__ dres, float* __restrict__ dx, float* __restrict__ dgamma,
-    float* __restrict__ dbeta, int rows, int cols, int rows_per_block) {
+    const float* __restrict__ mean_in, const float* __restrict__ rstd_in, const float* __restrict__ dres,
+    float* __restrict__ dx, int rows, int cols) {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
+    if (row >= rows) return;
     const int nvec = cols >> 3;
-    float pg[LN_MAXV][8], pb[LN_MAXV][8];
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    const float* xr = x + (size_t)row * cols;
+    const TDY* dyr = dy + (size_t)row * cols;
+    float xh[LN_MAXV][8], g[LN_MAXV][8];
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; i++)
+    for (int i = 0; i < LN_MAXV; i++) {
+        const int c = lane + 64 * i;
+        if (c < nvec) {
+            float xv[8], dv[8], gm[8];
+            load8(xr + c * 8, xv);
+            load8(dyr + c * 8, dv);
+            load8(gamma + c * 8, gm);
 #pragma unroll
-        for (int e = 0; e < 8; e++) pg[i][e] = pb[i][e] = 0.f;
-
-    const int r0 = blockIdx.x * rows_per_block;
-    const int r1 = min(rows, r0 + rows_per_block);
-    for (int row = r0 + wave; row < r1; row += LN_WAVES) {
-        const float mean = mean_in[row], rstd = rstd_in[row];
-        const float* xr = x + (size_t)row * cols;
-        const TDY* dyr = dy + (size_t)row * cols;
-        float xh[LN_MAXV][8], g[LN_MAXV][8];
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < LN_MAXV; i++) {
-            const int c = lane + 64 * i;
-            if (c < nvec) {
-                float xv[8], dv[8], gm[8];
-                load8(xr + c * 8, xv);
-                load8(dyr + c * 8, dv);
-                load8(gamma + c * 8, gm);
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    xh[i][e] = (xv[e] - mean) * rstd;
-                    g[i][e] = dv[e] * gm[e];
-                    s1 += g[i][e];
-                    s2 += g[i][e] * xh[i][e];
-                    pg[i][e] += dv[e] * xh[i][e];
-                    pb[i][e] += dv[e];
-                }
-            }
-        }
-        s1 = wave_sum(s1) / (float)cols;
-        s2 = wave_sum(s2) / (float)cols;
-        float* dxr = dx + (size_t)row * cols;
-#pragma unroll
-        for (int i = 0; i < LN_MAXV; i++) {
-            const int c = lane + 64 * i;
-            if (c < nvec) {
-                float o[8];
-#pragma unroll
-                for (int e = 0; e < 8; e++) o[e] = rstd * (g[i][e] - s1 - xh[i][e] * s2);
-                if (dres) {
-                    float rr[8];
-                    load8(dres + (size_t)row * cols + c * 8, rr);
-#pragma unroll
-                    for (int e = 0; e < 8; e++) o[e] += rr[e];
-                }
-                store8(dxr + c * 8, o);
+            for (int e = 0; e < 8; e++) {
+                xh[i][e] = (xv[e] - mean) * rstd;
+                g[i][e] = dv[e] * gm[e];
+                s1 += g[i][e];
+                s2 += g[i][e] * xh[i][e];
             }
         }
     }
-    // cross-wave reduction of the parameter-gradient partials
-    __shared__ float red[LN_WAVES][64 * 8 + 8];
+    s1 = wave_sum(s1) / (float)cols;
+    s2 = wave_sum(s2) / (float)cols;
+    float* dxr = dx + (size_t)row * cols;
+#pragma unroll
     for (int i = 0; i < LN_MAXV; i++) {
         const int c = lane + 64 * i;
-        for (int pass = 0; pass < 2; pass++) {
-            __syncthreads();
+        if (c < nvec) {
+            float o[8];
 #pragma unroll
-            for (int e = 0; e < 8; e++) red[wave][lane * 8 + e] = pass ? pb[i][e] : pg[i][e];
-            __syncthreads();
-            if (wave == 0 && c < nvec) {
-                float* dst = pass ? dbeta : dgamma;
+            for (int e = 0; e < 8; e++) o[e] = rstd * (g[i][e] - s1 - xh[i][e] * s2);
+            if (dres) {
+                float rr[8];
+                load8(dres + (size_t)row * cols + c * 8, rr);
 #pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    float t = 0.f;
-#pragma unroll
-                    for (int w = 0; w < LN_WAVES; w++) t += red[w][lane * 8 + e];
-                    atomicAdd(dst + c * 8 + e, t);
-                }
+                for (int e = 0; e < 8; e++) o[e] += rr[e];
             }
+            store8(dxr + c * 8, o);
+        }
+    }
+}
+
+// dgamma[c] += sum_r dy[r,c]*xhat[r,c] ; dbeta[c] += sum_r dy[r,c].  thread = (8-column chunk, row lane).
+template <class TDY>
+__global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_param_kernel(
+    const TDY* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean_in,
+    const float* __restrict__ rstd_in, float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int cols,
+    int rows_per_block, int CL) {
+    __shared__ float red[LN_THREADS * 16];
+    const int cv = cols >> 3;
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL, RL = LN_THREADS / CL;
+    const int cc = blockIdx.x * CL + cl;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(rows, r0 + rows_per_block);
+    float pg[8], pb[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) pg[e] = pb[e] = 0.f;
+    if (cc < cv) {
+        for (int r = r0 + rl; r < r1; r += RL) {
+            float xv[8], dv[8];
+            load8(x + (size_t)r * cols + cc * 8, xv);
+            load8(dy + (size_t)r * cols + cc * 8, dv);
+            const float m = mean_in[r], rs = rstd_in[r];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                pg[e] += dv[e] * (xv[e] - m) * rs;
+                pb[e] += dv[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        red[threadIdx.x * 16 + e] = pg[e];
+        red[threadIdx.x * 16 + 8 + e] = pb[e];
+    }
+    __syncthreads();
+    if (rl == 0 && cc < cv) {
+        for (int q = 1; q < RL; q++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                pg[e] += red[(q * CL + cl) * 16 + e];
+                pb[e] += red[(q * CL + cl) * 16 + 8 + e];
+            }
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            atomicAdd(dgamma + cc * 8 + e, pg[e]);
+            atomicAdd(dbeta + cc * 8 + e, pb[e]);
         }
     }
 }
@@ -182,14 +197,22 @@ extern "C" int avsr_layernorm_bwd(const void* dy, int dy_dtype, const float* x, 
                                   hipStream_t stream) {
     AVSR_REQUIRE(cols % 8 == 0 && cols <= 64 * 8 * LN_MAXV, "layernorm: cols must be %8 and <= 2048");
     if (rows == 0) return 0;
-    const int rpb = 16;
-    dim3 grid((rows + rpb - 1) / rpb), block(LN_THREADS);
-    if (dy_dtype == 0)
-        AVSR_LAUNCH((layernorm_bwd_kernel<float>), grid, block, 0, stream, (const float*)dy, x, gamma,
-                    mean, rstd, dres, dx, dgamma, dbeta, rows, cols, rpb);
-    else
-        AVSR_LAUNCH((layernorm_bwd_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)dy, x,
-                    gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, cols, rpb);
+    dim3 grid((rows + LN_WAVES - 1) / LN_WAVES), block(LN_THREADS);
+    const int cv = cols >> 3;
+    const int CL = cv >= 32 ? 32 : (cv >= 16 ? 16 : 8);
+    const int rpb = 8 * (LN_THREADS / CL);
+    dim3 grid2((cv + CL - 1) / CL, (rows + rpb - 1) / rpb);
+    if (dy_dtype == 0) {
+        AVSR_LAUNCH((layernorm_bwd_dx_kernel<float>), grid, block, 0, stream, (const float*)dy, x, gamma, mean, rstd,
+                    dres, dx, rows, cols);
+        AVSR_LAUNCH((layernorm_bwd_param_kernel<float>), grid2, block, 0, stream, (const float*)dy, x, mean, rstd,
+                    dgamma, dbeta, rows, cols, rpb, CL);
+    } else {
+        AVSR_LAUNCH((layernorm_bwd_dx_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)dy, x, gamma, mean, rstd,
+                    dres, dx, rows, cols);
+        AVSR_LAUNCH((layernorm_bwd_param_kernel<bf16_t>), grid2, block, 0, stream, (const bf16_t*)dy, x, mean, rstd,
+                    dgamma, dbeta, rows, cols, rpb, CL);
+    }
     AVSR_CHECK_LAUNCH("layernorm_bwd");
     return 0;
 }

@@ -7,10 +7,12 @@
 
 namespace {
 
-// y[n,oh,ow,c] = max over the KxK window (stride S, pad P) of x[n,ih,iw,c]
+// y[n,oh,ow,c] = max over the KxK window (stride S, pad P) of x[n,ih,iw,c]; idx = kh*K+kw of the FIRST maximum in
+// scan order (the element torch routes the gradient to), one byte per output element
 template <class T>
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long N, int H, int W,
-                                                          int C, int OH, int OW, int K, int S, int P) {
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                          uint8_t* __restrict__ idx, long N, int H, int W, int C, int OH,
+                                                          int OW, int K, int S, int P) {
     const int cv = C >> 3;
     const long total = N * OH * OW * cv;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -21,8 +23,12 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
         const int oh = (int)(r % OH);
         const long n = r / OH;
         float m[8];
+        uint8_t am[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) m[e] = -INFINITY;
+        for (int e = 0; e < 8; e++) {
+            m[e] = -INFINITY;
+            am[e] = 0;
+        }
         for (int kh = 0; kh < K; kh++) {
             const int ih = oh * S + kh - P;
             if (ih < 0 || ih >= H) continue;
@@ -32,16 +38,26 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
                 float v[8];
                 load8(x + ((n * H + ih) * W + iw) * C + c, v);
 #pragma unroll
-                for (int e = 0; e < 8; e++) m[e] = fmaxf(m[e], v[e]);
+                for (int e = 0; e < 8; e++)
+                    if (v[e] > m[e]) {
+                        m[e] = v[e];
+                        am[e] = (uint8_t)(kh * K + kw);
+                    }
             }
         }
         store8(y + i * 8, m);
+        if (idx) {
+            uint64_t pk = 0;
+#pragma unroll
+            for (int e = 0; e < 8; e++) pk |= (uint64_t)am[e] << (8 * e);
+            *reinterpret_cast<uint64_t*>(idx + i * 8) = pk;
+        }
     }
 }
 
-// dx[n,ih,iw,c] = sum over the windows containing (ih,iw) whose FIRST maximum (scan order kh,kw) is (ih,iw)
+// dx[n,ih,iw,c] = sum of dy over the (at most ceil(K/S)^2) windows whose recorded arg-max is (ih,iw)
 template <class T>
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restrict__ idx, const T* __restrict__ dy,
                                                           T* __restrict__ dx, long N, int H, int W, int C, int OH, int OW,
                                                           int K, int S, int P) {
     const int cv = C >> 3;
@@ -53,38 +69,21 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
         r /= W;
         const int ih = (int)(r % H);
         const long n = r / H;
-        float me[8], acc[8];
-        load8(x + i * 8, me);
+        float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) acc[e] = 0.f;
-        // windows (oh, ow) with oh*S - P <= ih <= oh*S - P + K - 1
         const int oh_lo = max(0, (ih + P - K + 1 + S - 1) / S), oh_hi = min(OH - 1, (ih + P) / S);
         const int ow_lo = max(0, (iw + P - K + 1 + S - 1) / S), ow_hi = min(OW - 1, (iw + P) / S);
         for (int oh = oh_lo; oh <= oh_hi; oh++)
             for (int ow = ow_lo; ow <= ow_hi; ow++) {
-                bool win[8];
-#pragma unroll
-                for (int e = 0; e < 8; e++) win[e] = true;
-                for (int kh = 0; kh < K; kh++) {
-                    const int jh = oh * S + kh - P;
-                    if (jh < 0 || jh >= H) continue;
-                    for (int kw = 0; kw < K; kw++) {
-                        const int jw = ow * S + kw - P;
-                        if (jw < 0 || jw >= W) continue;
-                        if (jh == ih && jw == iw) continue;
-                        float v[8];
-                        load8(x + ((n * H + jh) * W + jw) * C + c, v);
-                        const bool before = (jh < ih) || (jh == ih && jw < iw);
-#pragma unroll
-                        for (int e = 0; e < 8; e++)
-                            if (before ? (v[e] >= me[e]) : (v[e] > me[e])) win[e] = false;
-                    }
-                }
+                const int me = (ih - (oh * S - P)) * K + (iw - (ow * S - P));
+                const long o = ((n * OH + oh) * OW + ow) * C + c;
+                const uint64_t pk = *reinterpret_cast<const uint64_t*>(idx + o);
                 float g[8];
-                load8(dy + ((n * OH + oh) * OW + ow) * C + c, g);
+                load8(dy + o, g);
 #pragma unroll
                 for (int e = 0; e < 8; e++)
-                    if (win[e]) acc[e] += g[e];
+                    if ((int)((pk >> (8 * e)) & 0xff) == me) acc[e] += g[e];
             }
         store8(dx + i * 8, acc);
     }
@@ -136,30 +135,30 @@ static inline unsigned grid_for(long n) {
 
 }  // namespace
 
-extern "C" int avsr_maxpool2d_fwd(const void* x, void* y, int dtype, int64_t N, int H, int W, int C, int K, int S, int P,
+extern "C" int avsr_maxpool2d_fwd(const void* x, void* y, uint8_t* idx, int dtype, int64_t N, int H, int W, int C, int K, int S, int P,
                                   hipStream_t stream) {
     AVSR_REQUIRE(C % 8 == 0, "maxpool: C must be a multiple of 8");
     const int OH = (H + 2 * P - K) / S + 1, OW = (W + 2 * P - K) / S + 1;
     if (N <= 0) return 0;
     const long total = (long)N * OH * OW * (C >> 3);
     if (dtype == 0)
-        AVSR_LAUNCH((maxpool_fwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, stream, (const float*)x, (float*)y, (long)N, H, W, C, OH, OW, K, S, P);
+        AVSR_LAUNCH((maxpool_fwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, stream, (const float*)x, (float*)y, idx, (long)N, H, W, C, OH, OW, K, S, P);
     else
-        AVSR_LAUNCH((maxpool_fwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, (long)N, H, W, C, OH, OW, K, S, P);
+        AVSR_LAUNCH((maxpool_fwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, idx, (long)N, H, W, C, OH, OW, K, S, P);
     AVSR_CHECK_LAUNCH("maxpool2d_fwd");
     return 0;
 }
 
-extern "C" int avsr_maxpool2d_bwd(const void* x, const void* dy, void* dx, int dtype, int64_t N, int H, int W, int C, int K,
+extern "C" int avsr_maxpool2d_bwd(const uint8_t* idx, const void* dy, void* dx, int dtype, int64_t N, int H, int W, int C, int K,
                                   int S, int P, hipStream_t stream) {
     AVSR_REQUIRE(C % 8 == 0, "maxpool: C must be a multiple of 8");
     const int OH = (H + 2 * P - K) / S + 1, OW = (W + 2 * P - K) / S + 1;
     if (N <= 0) return 0;
     const long total = (long)N * H * W * (C >> 3);
     if (dtype == 0)
-        AVSR_LAUNCH((maxpool_bwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, stream, (const float*)x, (const float*)dy, (float*)dx, (long)N, H, W, C, OH, OW, K, S, P);
+        AVSR_LAUNCH((maxpool_bwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, stream, idx, (const float*)dy, (float*)dx, (long)N, H, W, C, OH, OW, K, S, P);
     else
-        AVSR_LAUNCH((maxpool_bwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, (long)N, H, W, C, OH, OW, K, S, P);
+        AVSR_LAUNCH((maxpool_bwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, stream, idx, (const bf16_t*)dy, (bf16_t*)dx, (long)N, H, W, C, OH, OW, K, S, P);
     AVSR_CHECK_LAUNCH("maxpool2d_bwd");
     return 0;
 }

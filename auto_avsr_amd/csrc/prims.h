@@ -44,6 +44,9 @@ AVSR_DEV float bf2f(bf16_t h) {
     return __builtin_bit_cast(float, u);
 }
 AVSR_DEV bf16_t f2bf(float f) {  // round to nearest even, NaN preserved
+#ifndef AVSR_EMU
+    return __builtin_bit_cast(bf16_t, (__bf16)f);  // v_cvt_pk_bf16_f32 on gfx950
+#endif
     uint32_t u = __builtin_bit_cast(uint32_t, f);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
     u += 0x7fffu + ((u >> 16) & 1u);

@@ -938,20 +938,24 @@ class StemFn(torch.autograd.Function):
         bn = (g, b) + bn_rest
         m0, i0, n0 = _bn_fwd_params(c0, rows, Cout, bn, training)
         a0 = ops.bn_act_fwd(c0, None, m0, i0, g, b, rows, Cout, 1)
-        out = ops.maxpool2d_fwd(a0, B * Tn, OH, OW, Cout, 3, 2, 1) if pool else a0
-        ctx.save_for_backward(x, c0, a0 if pool else None, g, b, m0, i0, n0)
+        idx = None
+        if pool:
+            out, idx = ops.maxpool2d_fwd(a0, B * Tn, OH, OW, Cout, 3, 2, 1)
+        else:
+            out = a0
+        ctx.save_for_backward(x, c0, idx, g, b, m0, i0, n0)
         ctx.meta = (geom, pool, training, bn_rest, (OH, OW), w.shape)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, c0, a0, g, b, m0, i0, n0 = ctx.saved_tensors
+        x, c0, idx, g, b, m0, i0, n0 = ctx.saved_tensors
         geom, pool, training, bn_rest, (OH, OW), wshape = ctx.meta
         B, Tn, H, W, KT, KH, KW, stride, pt, ph, pw = geom
         Cout = wshape[0]
         rows = B * Tn * OH * OW
         dout = dout.contiguous()
-        da0 = ops.maxpool2d_bwd(a0, dout, B * Tn, OH, OW, Cout, 3, 2, 1) if pool else dout
+        da0 = ops.maxpool2d_bwd(idx, dout, B * Tn, OH, OW, Cout, 3, 2, 1) if pool else dout
         dc0, _, dg, db = _bn_bwd(c0, da0, None, m0, i0, (g, b) + bn_rest, n0, rows, Cout, 1, False, training)
         dw = ops.conv_stem_wgrad(dc0, x, B, Tn, H, W, Cout, KT, KH, KW, stride, pt, ph, pw, _state["precise"])
         return None, dw.view(wshape), dg, db, None, None, None, None

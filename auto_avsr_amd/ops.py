@@ -101,8 +101,9 @@ def attention_bwd_dq(qu, qv, k, v, pos, mask, out, lse, dout, scale, *, precise=
     lds = (Tk + 7) // 8 * 8
     dqu = torch.empty(B, Tq, H, dk, dtype=qu.dtype, device=qu.device)
     dqv = torch.empty_like(dqu) if pos is not None else None
-    pd = torch.zeros(B, H, Tq, lds, dtype=qu.dtype, device=qu.device)
-    ds = torch.zeros(B, H, Tq, lds, dtype=qu.dtype, device=qu.device)
+    # pad columns [Tk, lds) are never read: the TN loaders mask by the logical width
+    pd = torch.empty(B, H, Tq, lds, dtype=qu.dtype, device=qu.device)
+    ds = torch.empty(B, H, Tq, lds, dtype=qu.dtype, device=qu.device)
     msb = msq = 0
     if mask is not None:
         msb = mask.shape[1] * mask.shape[2]
@@ -364,13 +365,14 @@ def conv_stem_wgrad(dy, x, B, T, H, W, Cout, KT, KH, KW, stride, pt, ph, pw, pre
 def maxpool2d_fwd(x, N, H, W, C, K, S, P):
     OH, OW = conv_out(H, K, S, P), conv_out(W, K, S, P)
     y = torch.empty(N, OH, OW, C, dtype=x.dtype, device=x.device)
-    call("avsr_maxpool2d_fwd", _ptr(x), _ptr(y), dt(x), N, H, W, C, K, S, P, _stream(x))
-    return y
+    idx = torch.empty(N, OH, OW, C, dtype=torch.uint8, device=x.device)
+    call("avsr_maxpool2d_fwd", _ptr(x), _ptr(y), _ptr(idx), dt(x), N, H, W, C, K, S, P, _stream(x))
+    return y, idx
 
 
-def maxpool2d_bwd(x, dy, N, H, W, C, K, S, P):
-    dx = torch.empty_like(x)
-    call("avsr_maxpool2d_bwd", _ptr(x), _ptr(dy), _ptr(dx), dt(x), N, H, W, C, K, S, P, _stream(x))
+def maxpool2d_bwd(idx, dy, N, H, W, C, K, S, P):
+    dx = torch.empty(N, H, W, C, dtype=dy.dtype, device=dy.device)
+    call("avsr_maxpool2d_bwd", _ptr(idx), _ptr(dy), _ptr(dx), dt(dy), N, H, W, C, K, S, P, _stream(dy))
     return dx
 
 

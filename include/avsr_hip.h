@@ -189,9 +189,10 @@ int avsr_conv_stem_wgrad(const void* dy, int dy_dtype, const float* x, float* dw
                          avsr_stream_t stream);
 
 /* ---- pooling on channels-last tensors (pool.hip) ------------------------------------------------- */
-int avsr_maxpool2d_fwd(const void* x, void* y, int dtype, int64_t N, int H, int W, int C, int K, int S, int P,
+/* idx (may be NULL): uint8 [N,OH,OW,C], window position kh*K+kw of the first maximum (what the backward routes to) */
+int avsr_maxpool2d_fwd(const void* x, void* y, uint8_t* idx, int dtype, int64_t N, int H, int W, int C, int K, int S, int P,
                        avsr_stream_t stream);
-int avsr_maxpool2d_bwd(const void* x, const void* dy, void* dx, int dtype, int64_t N, int H, int W, int C, int K, int S,
+int avsr_maxpool2d_bwd(const uint8_t* idx, const void* dy, void* dx, int dtype, int64_t N, int H, int W, int C, int K, int S,
                        int P, avsr_stream_t stream);
 /* y[g,:] = mean of rows g*win .. g*win+win-1 of x [groups*win, C]; y f32 */
 int avsr_avgpool_fwd(const void* x, int dtype, float* y, int64_t groups, int win, int C, avsr_stream_t stream);

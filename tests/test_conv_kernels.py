@@ -95,9 +95,9 @@ def test_pooling(dev):
     dy = torch.randn_like(y_ref)
     y_ref.backward(dy)
     xd = nhwc(x.detach()).to(dev)
-    y = ops.maxpool2d_fwd(xd, N, H, W, C, 3, 2, 1)
+    y, idx = ops.maxpool2d_fwd(xd, N, H, W, C, 3, 2, 1)
     assert (y.cpu() - nhwc(y_ref.detach())).abs().max() == 0
-    dx = ops.maxpool2d_bwd(xd, nhwc(dy).to(dev), N, H, W, C, 3, 2, 1)
+    dx = ops.maxpool2d_bwd(idx, nhwc(dy).to(dev), N, H, W, C, 3, 2, 1)
     assert (dx.cpu() - nhwc(x.grad)).abs().max() < 1e-6
     z = torch.randn(4 * 9, 24)
     a = ops.avgpool_fwd(z.to(dev), 4, 9, 24)
