@@ -38,8 +38,6 @@ __global__ __launch_bounds__(BN_THREADS) void bn_colreduce_kernel(
     const int cv = C >> 3;
     const int cl = threadIdx.x % CL, rl = threadIdx.x / CL, RL = BN_THREADS / CL;
     const int cc = blockIdx.x * CL + cl;
-    const long r0 = (long)blockIdx.y * rows_per_block;
-    const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     float a[8], b[8], sh[8], mu[8], is[8], ga[8], be[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) a[e] = b[e] = sh[e] = mu[e] = is[e] = ga[e] = be[e] = 0.f;
@@ -52,6 +50,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_colreduce_kernel(
             load8(beta + cc * 8, be);
         }
         constexpr int U = 4;  // independent rows in flight per thread (memory-level parallelism)
+        for (long r0 = (long)blockIdx.y * rows_per_block; r0 < rows; r0 += (long)gridDim.y * rows_per_block) {
+        const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
         for (long rb = r0 + rl; rb < r1; rb += (long)U * RL) {
             float v[U][8], g[U][8], ad[U][8];
 #pragma unroll
@@ -88,6 +88,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_colreduce_kernel(
                 }
             }
         }
+        }
     }
 #pragma unroll
     for (int e = 0; e < 8; e++) {
@@ -102,16 +103,23 @@ __global__ __launch_bounds__(BN_THREADS) void bn_colreduce_kernel(
                 a[e] += red[(q * CL + cl) * 16 + e];
                 b[e] += red[(q * CL + cl) * 16 + 8 + e];
             }
-        const int base = MODE == 0 ? 1 : 0;
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            atomicAdd(out + (long)(base + 0) * C + cc * 8 + e, a[e]);
-            atomicAdd(out + (long)(base + 1) * C + cc * 8 + e, b[e]);
-        }
-        if (MODE == 0 && blockIdx.y == 0)
-#pragma unroll
-            for (int e = 0; e < 8; e++) out[cc * 8 + e] = sh[e];
+        // per-block partials (no atomics: thousands of blocks hitting the same two cache lines serialise in L2)
+        float* part = out + (long)blockIdx.y * 2 * C;
+        store8(part + cc * 8, a);
+        store8(part + C + cc * 8, b);
     }
+}
+
+// dst[base + j][c] = sum_p part[p][j][c], j = 0,1 ; MODE 0 also records the shift row x[0, c]
+template <class T>
+__global__ __launch_bounds__(256) void bn_partial_sum_kernel(const float* __restrict__ part, int nparts, int C,
+                                                             float* __restrict__ dst, int base, const T* __restrict__ x0) {
+    const int i = blockIdx.x * 256 + threadIdx.x;  // over 2*C
+    if (i >= 2 * C) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; p++) s += part[(long)p * 2 * C + i];
+    dst[(long)base * C + i] = s;
+    if (x0 && i < C) dst[i] = Elem<T>::ld(x0 + i);
 }
 
 // stats: [W][3][C] (shift, s1, s2), counts [W]; one thread per channel
@@ -223,21 +231,37 @@ static inline int ew_grid(long nvec) {
 
 }  // namespace
 
-// stats: [3][C] f32, must be zeroed by the caller (rows 1,2 are accumulated with atomics)
-extern "C" int avsr_bn_stats(const void* x, int dtype, float* stats, int64_t rows, int C, hipStream_t stream) {
+static inline int bn_parts(long rows, int rpb, int gx) {
+    long need = (rows + rpb - 1) / rpb;
+    long cap = 1024 / (gx < 1 ? 1 : gx);
+    if (cap < 1) cap = 1;
+    return (int)(need < cap ? need : cap);
+}
+
+extern "C" int64_t avsr_bn_workspace_floats(int C) { return (int64_t)1024 * 2 * C; }
+
+// stats: [3][C] f32 (overwritten); workspace: avsr_bn_workspace_floats(C) floats
+extern "C" int avsr_bn_stats(const void* x, int dtype, float* stats, float* workspace, int64_t rows, int C,
+                             hipStream_t stream) {
     AVSR_REQUIRE(C % 8 == 0, "batchnorm: C must be a multiple of 8");
     if (rows <= 0) return 0;
     const int cv = C >> 3, CL = pick_cl(cv);
     const int rpb = 128 * (BN_THREADS / CL) / 8;
-    dim3 grid((cv + CL - 1) / CL, (unsigned)((rows + rpb - 1) / rpb)), block(BN_THREADS);
-    if (dtype == 0)
+    const int gx = (cv + CL - 1) / CL;
+    const int parts = bn_parts(rows, rpb, gx);
+    dim3 grid(gx, parts), block(BN_THREADS);
+    dim3 g2((2 * C + 255) / 256);
+    if (dtype == 0) {
         AVSR_LAUNCH((bn_colreduce_kernel<float, 0>), grid, block, 0, stream, (const float*)x, (const float*)nullptr,
                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                    (const float*)nullptr, stats, (long)rows, C, CL, rpb, 0);
-    else
+                    (const float*)nullptr, workspace, (long)rows, C, CL, rpb, 0);
+        AVSR_LAUNCH((bn_partial_sum_kernel<float>), g2, dim3(256), 0, stream, (const float*)workspace, parts, C, stats, 1, (const float*)x);
+    } else {
         AVSR_LAUNCH((bn_colreduce_kernel<bf16_t, 0>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)nullptr,
                     (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                    (const float*)nullptr, stats, (long)rows, C, CL, rpb, 0);
+                    (const float*)nullptr, workspace, (long)rows, C, CL, rpb, 0);
+        AVSR_LAUNCH((bn_partial_sum_kernel<bf16_t>), g2, dim3(256), 0, stream, (const float*)workspace, parts, C, stats, 1, (const bf16_t*)x);
+    }
     AVSR_CHECK_LAUNCH("bn_stats");
     return 0;
 }
@@ -276,21 +300,25 @@ extern "C" int avsr_bn_act_fwd(const void* x, const void* add, int dtype, const 
     return 0;
 }
 
-// sums: [2][C] f32 zeroed by the caller
+// sums: [2][C] f32 (overwritten); workspace: avsr_bn_workspace_floats(C) floats
 extern "C" int avsr_bn_bwd_reduce(const void* x, const void* dy, const void* add, int dtype, const float* mean,
                                   const float* invstd, const float* gamma, const float* beta, float* sums,
-                                  int64_t rows, int C, int act, hipStream_t stream) {
+                                  float* workspace, int64_t rows, int C, int act, hipStream_t stream) {
     AVSR_REQUIRE(C % 8 == 0, "batchnorm: C must be a multiple of 8");
     if (rows <= 0) return 0;
     const int cv = C >> 3, CL = pick_cl(cv);
     const int rpb = 128 * (BN_THREADS / CL) / 8;
-    dim3 grid((cv + CL - 1) / CL, (unsigned)((rows + rpb - 1) / rpb)), block(BN_THREADS);
+    const int gx = (cv + CL - 1) / CL;
+    const int parts = bn_parts(rows, rpb, gx);
+    dim3 grid(gx, parts), block(BN_THREADS);
+    dim3 g2((2 * C + 255) / 256);
     if (dtype == 0)
         AVSR_LAUNCH((bn_colreduce_kernel<float, 1>), grid, block, 0, stream, (const float*)x, (const float*)dy,
-                    (const float*)add, mean, invstd, gamma, beta, sums, (long)rows, C, CL, rpb, act);
+                    (const float*)add, mean, invstd, gamma, beta, workspace, (long)rows, C, CL, rpb, act);
     else
         AVSR_LAUNCH((bn_colreduce_kernel<bf16_t, 1>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dy,
-                    (const bf16_t*)add, mean, invstd, gamma, beta, sums, (long)rows, C, CL, rpb, act);
+                    (const bf16_t*)add, mean, invstd, gamma, beta, workspace, (long)rows, C, CL, rpb, act);
+    AVSR_LAUNCH((bn_partial_sum_kernel<float>), g2, dim3(256), 0, stream, (const float*)workspace, parts, C, sums, 0, (const float*)nullptr);
     AVSR_CHECK_LAUNCH("bn_bwd_reduce");
     return 0;
 }

@@ -117,6 +117,49 @@ AVSR_DEV Raw8<T> load_chunk_skew(const T* base, int ld, int r, int c, int r_lim,
     return out;
 }
 
+// Shared epilogue of the MFMA GEMM kernels: acc[i][j] is the 32x32 accumulator whose top-left element is
+// (row0 + 32 i, col0 + 32 j); order: +bias -> act -> gate -> dropout -> *alpha -> +resid -> store / atomicAdd.
+template <int TM, int TN>
+AVSR_DEV void epilogue(f32x16 (&acc)[TM][TN], const Params& p, int row0, int col0, int lane, int zs, long c_off) {
+    const float inv_keep = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+    const float alpha = p.alpha * (p.alpha_dev ? *p.alpha_dev : 1.f);
+    const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int col = col0 + j * 32 + (lane & 31);
+            if (col >= p.N) continue;
+            const float bias = (p.bias && zs == 0) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] + bias;
+                if (p.act == 1) v = fmaxf(v, 0.f);
+                else if (p.act == 2) v = avsr_silu(v);
+                if (p.gate) {
+                    const float g = p.gate_dtype == 0
+                                        ? reinterpret_cast<const float*>(p.gate)[(size_t)row * p.ldg + col]
+                                        : bf2f(reinterpret_cast<const bf16_t*>(p.gate)[(size_t)row * p.ldg + col]);
+                    v = g > 0.f ? v * p.gate_scale : 0.f;
+                }
+                if (p.drop_p > 0.f)
+                    v *= dropout_scale(seed, (uint64_t)row * (uint64_t)p.N + col, p.drop_p, inv_keep);
+                v *= alpha;
+                if (p.resid && zs == 0)
+                    v += p.resid_dtype == 0 ? p.resid[(size_t)row * p.ldr + col]
+                                            : bf2f(reinterpret_cast<const bf16_t*>(p.resid)[(size_t)row * p.ldr + col]);
+                if (p.c_dtype == 0) {
+                    float* c = reinterpret_cast<float*>(p.C) + c_off + (size_t)row * p.ldc + col;
+                    if (p.accumulate) atomicAdd(c, v); else *c = v;
+                } else {
+                    reinterpret_cast<bf16_t*>(p.C)[c_off + (size_t)row * p.ldc + col] = f2bf(v);
+                }
+            }
+        }
+}
+
 // 8 consecutive k (one tap, 8 channels) of pixel row m, or zeros
 template <class T, int CV>
 AVSR_DEV Raw8<T> gather_chunk(const T* base, const Params& p, int m, int k, int m_lim, int k_lim) {
@@ -329,44 +372,7 @@ struct Kernel {
             cur ^= 1;
         }
 
-        // ---- epilogue
-        const float inv_keep = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
-        const float alpha = p.alpha * (p.alpha_dev ? *p.alpha_dev : 1.f);
-        const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int j = 0; j < TN; j++) {
-                const int col = n0 + wn * WN + j * 32 + (lane & 31);
-                if (col >= p.N) continue;
-                const float bias = (p.bias && zs == 0) ? p.bias[col] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (row >= p.M) continue;
-                    float v = acc[i][j][r] + bias;
-                    if (p.act == 1) v = fmaxf(v, 0.f);
-                    else if (p.act == 2) v = avsr_silu(v);
-                    if (p.gate) {
-                        const float g = p.gate_dtype == 0
-                                            ? reinterpret_cast<const float*>(p.gate)[(size_t)row * p.ldg + col]
-                                            : bf2f(reinterpret_cast<const bf16_t*>(p.gate)[(size_t)row * p.ldg + col]);
-                        v = g > 0.f ? v * p.gate_scale : 0.f;
-                    }
-                    if (p.drop_p > 0.f)
-                        v *= dropout_scale(seed, (uint64_t)row * (uint64_t)p.N + col, p.drop_p, inv_keep);
-                    v *= alpha;
-                    if (p.resid && zs == 0)
-                        v += p.resid_dtype == 0 ? p.resid[(size_t)row * p.ldr + col]
-                                                : bf2f(reinterpret_cast<const bf16_t*>(p.resid)[(size_t)row * p.ldr + col]);
-                    if (p.c_dtype == 0) {
-                        float* c = reinterpret_cast<float*>(p.C) + c_off + (size_t)row * p.ldc + col;
-                        if (p.accumulate) atomicAdd(c, v); else *c = v;
-                    } else {
-                        reinterpret_cast<bf16_t*>(p.C)[c_off + (size_t)row * p.ldc + col] = f2bf(v);
-                    }
-                }
-            }
+        epilogue<TM, TN>(acc, p, m0 + wm * WM, n0 + wn * WN, lane, zs, c_off);
     }
 };
 

@@ -1,0 +1,195 @@
+// gemm_fast.hip -- the tuned path of the GEMM family: C[M,N] = epi(A[M,K] . B[N,K]^T) with both operands bf16
+// and k-contiguous (K a multiple of 64).  Every dense contraction of the bf16 hot path is brought into this
+// form: Linear forward (B = bf16 weight copy), data gradient (B = transposed weight copy), weight gradient
+// (A = dY^T, B = x^T transposed activation copies with the token dimension zero-padded to 64).
+//
+// CDNA4 structure:
+//  * operands go HBM -> LDS directly by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction) into a
+//    STAGES-deep ring; no VGPR staging, no ds_write pass; loads of tile t+STAGES-1 are issued before tile t is
+//    multiplied, and are waited for with a COUNTED s_waitcnt vmcnt (never 0 in the steady state) in front of a raw
+//    s_barrier, so DMA stays in flight across barriers;
+//  * LDS image per operand stage: [rows][64] bf16 = 128-byte rows, lane-linear (what the DMA writes), with the
+//    16-byte chunk index XOR-swizzled by (row>>1)&7 -- applied to the per-lane SOURCE address on the way in and to
+//    the ds_read_b128 address on the way out -- conflict-free for the 32x32x16 MFMA fragment reads;
+//  * 256 threads = 2x2 waves, each wave a (BM/2)x(BN/2) grid of v_mfma_f32_32x32x16_bf16 accumulators;
+//  * rows beyond M / N are clamped on load (never stored); split-K over blockIdx.z with f32 atomics.
+#include "gemm_core.h"
+#include "avsr_hip.h"
+
+namespace {
+
+using avsr_gemm_impl::Params;
+
+template <int BM, int BN, int STAGES>
+struct FastKernel {
+    static constexpr int BK = 64;
+    static constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+    static constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;  // wave-instructions per wave per stage
+    static constexpr int LPT = A_LOADS + B_LOADS;               // LDS-DMA ops per thread per tile
+    static constexpr size_t LDS_BYTES = (size_t)STAGES * STAGE_BYTES;
+
+    static AVSR_DEV void issue(const bf16_t* A, const bf16_t* B, int lda, int ldb, int m0, int n0, int M, int N, int k0,
+                               char* stage, int wave, int lane) {
+        const int rsub = lane >> 3, pc = lane & 7;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; i++) {
+            const int r = (wave * A_LOADS + i) * 8 + rsub;  // row inside the tile
+            const int c = pc ^ ((r >> 1) & 7);              // source chunk that lands in physical chunk pc
+            const int gr = min(m0 + r, M - 1);
+            glds16(A + (size_t)gr * lda + k0 + c * 8, stage + (wave * A_LOADS + i) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; i++) {
+            const int r = (wave * B_LOADS + i) * 8 + rsub;
+            const int c = pc ^ ((r >> 1) & 7);
+            const int gr = min(n0 + r, N - 1);
+            glds16(B + (size_t)gr * ldb + k0 + c * 8, stage + A_BYTES + (wave * B_LOADS + i) * 1024);
+        }
+    }
+
+    static AVSR_DEV bf16x8 frag(const char* base, int r, int chunk) {
+        return *reinterpret_cast<const bf16x8*>(base + r * 128 + ((chunk ^ ((r >> 1) & 7)) << 4));
+    }
+
+    static AVSR_DEV void run(const Params& p, char* smem) {
+        const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+        const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int wm = wave >> 1, wn = wave & 1;
+        const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+        const int zs = blockIdx.z;
+        const int kbeg = zs * p.k_chunk;
+        const int kend = min(p.K, kbeg + p.k_chunk);
+        const int nt = (kend - kbeg) / BK;
+
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+        // prologue: tiles 0 .. STAGES-2 in flight
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; s++)
+            if (s < nt) issue(A, B, p.lda, p.ldb, m0, n0, p.M, p.N, kbeg + s * BK, smem + s * STAGE_BYTES, wave, lane);
+
+        for (int t = 0; t < nt; t++) {
+            // retire tile t: loads of at most STAGES-2 later tiles may stay in flight
+            const int later = min(STAGES - 2, nt - 1 - t);
+            if (later >= 2) wait_vmcnt<2 * LPT>();
+            else if (later == 1) wait_vmcnt<LPT>();
+            else wait_vmcnt<0>();
+            block_barrier_raw();  // tile t is in LDS for every wave; everyone is done reading tile t-1's buffer
+            if (t + STAGES - 1 < nt)
+                issue(A, B, p.lda, p.ldb, m0, n0, p.M, p.N, kbeg + (t + STAGES - 1) * BK,
+                      smem + ((t + STAGES - 1) % STAGES) * STAGE_BYTES, wave, lane);
+            const char* As = smem + (t % STAGES) * STAGE_BYTES;
+            const char* Bs = As + A_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ks++) {
+                const int chunk = ks * 2 + (lane >> 5);
+                bf16x8 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; i++) fa[i] = frag(As, wm * WM + i * 32 + (lane & 31), chunk);
+#pragma unroll
+                for (int j = 0; j < TN; j++) fb[j] = frag(Bs, wn * WN + j * 32 + (lane & 31), chunk);
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) acc[i][j] = mfma32(fa[i], fb[j], acc[i][j]);
+            }
+        }
+        avsr_gemm_impl::epilogue<TM, TN>(acc, p, m0 + wm * WM, n0 + wn * WN, lane, zs, 0);
+    }
+};
+
+template <int BM, int BN, int STAGES>
+__global__ __launch_bounds__(256) void gemm_fast_kernel(Params p) {
+    AVSR_DYN_SMEM(smem);
+    FastKernel<BM, BN, STAGES>::run(p, smem);
+}
+
+template <int BM, int BN, int STAGES>
+void launch_fast(Params& p, int split_k, hipStream_t stream) {
+    int kc = (p.K + split_k - 1) / split_k;
+    kc = ((kc + 63) / 64) * 64;
+    split_k = (p.K + kc - 1) / kc;
+    p.k_chunk = kc;
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, split_k), block(256);
+    AVSR_LAUNCH((gemm_fast_kernel<BM, BN, STAGES>), grid, block, (FastKernel<BM, BN, STAGES>::LDS_BYTES), stream, p);
+}
+
+}  // namespace
+
+// tile: 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128
+extern "C" int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
+                                 int act, const void* gate, int gate_dtype, int ldg, float gate_scale, float drop_p,
+                                 uint64_t seed, const uint64_t* seed_dev, float alpha, const float* alpha_dev,
+                                 const void* resid, int resid_dtype, int ldr, void* C, int c_dtype, int ldc, int accumulate,
+                                 int split_k, int tile, hipStream_t stream) {
+    AVSR_REQUIRE(K > 0 && K % 64 == 0, "gemm_bf16_nt: K must be a positive multiple of 64");
+    AVSR_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "gemm_bf16_nt: lda/ldb must be multiples of 8 elements");
+    AVSR_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "gemm_bf16_nt: operands must be 16-byte aligned");
+    AVSR_REQUIRE(!(accumulate && c_dtype != 0), "gemm_bf16_nt: accumulate needs an f32 output");
+    AVSR_REQUIRE(!(split_k > 1 && !accumulate), "gemm_bf16_nt: split-K needs accumulate=1");
+    if (M <= 0 || N <= 0) return 0;
+    Params p{};
+    p.A = A; p.B = B; p.lda = lda; p.ldb = ldb;
+    p.M = M; p.N = N; p.K = K;
+    p.bias = bias; p.act = act;
+    p.gate = gate; p.gate_dtype = gate_dtype; p.ldg = ldg; p.gate_scale = gate_scale;
+    p.drop_p = drop_p; p.seed = seed; p.seed_dev = seed_dev;
+    p.alpha = alpha; p.alpha_dev = alpha_dev;
+    p.resid = reinterpret_cast<const float*>(resid); p.resid_dtype = resid_dtype; p.ldr = ldr;
+    p.C = C; p.c_dtype = c_dtype; p.ldc = ldc; p.accumulate = accumulate;
+    p.nsplit = 1; p.batch_h = 1; p.nbatch = 1;
+    if (split_k < 1) split_k = 1;
+    if (tile == 0) {
+        const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+        const long t12864 = (long)((M + 127) / 128) * ((N + 63) / 64);
+        tile = t128 >= 224 ? 3 : (t12864 >= 200 ? 2 : 1);
+    }
+    if (tile == 3) launch_fast<128, 128, 3>(p, split_k, stream);
+    else if (tile == 2) launch_fast<128, 64, 3>(p, split_k, stream);
+    else launch_fast<64, 64, 4>(p, split_k, stream);
+    AVSR_CHECK_LAUNCH("gemm_bf16_nt");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dst[c][r] = src[r][c] as bf16, dst row pitch ldd >= R (columns [R, ldd) zero-filled): the k-contiguous copies
+// (W^T for the data gradient, dY^T / x^T for the weight gradient) that bring every contraction into NT form.
+namespace {
+template <class T>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const T* __restrict__ src, long lds_, bf16_t* __restrict__ dst,
+                                                             long ldd, int R, int Ccols) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < Ccols) ? Elem<T>::ld(src + (long)r * lds_ + c) : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;  // dst row c, dst col r
+        if (c < Ccols && r < ldd) dst[(long)c * ldd + r] = f2bf(tile[tx][i]);
+    }
+}
+}  // namespace
+
+extern "C" int avsr_transpose_cast(const void* src, int src_dtype, int64_t ld_src, void* dst, int64_t ld_dst, int R, int C,
+                                   hipStream_t stream) {
+    AVSR_REQUIRE(ld_dst >= R, "transpose_cast: destination pitch must cover the source rows");
+    if (R <= 0 || C <= 0) return 0;
+    dim3 grid((C + 63) / 64, (unsigned)((ld_dst + 63) / 64)), block(256);
+    if (src_dtype == 0)
+        AVSR_LAUNCH((transpose_cast_kernel<float>), grid, block, 0, stream, (const float*)src, (long)ld_src, (bf16_t*)dst, (long)ld_dst, R, C);
+    else
+        AVSR_LAUNCH((transpose_cast_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)src, (long)ld_src, (bf16_t*)dst, (long)ld_dst, R, C);
+    AVSR_CHECK_LAUNCH("transpose_cast");
+    return 0;
+}

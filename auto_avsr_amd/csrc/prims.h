@@ -97,6 +97,30 @@ AVSR_DEV void store8(float* p, const float* v) {
     *reinterpret_cast<f32x4*>(p + 4) = b;
 }
 
+// ---------------------------------------------------------------- async global -> LDS (LDS-DMA)
+// global_load_lds_dwordx4: lane l copies 16 bytes from its own global address to (wave-uniform LDS base + 16*l).
+// The transfer is tracked by vmcnt; ordering against ds_read is the caller's job (counted s_waitcnt + barrier).
+AVSR_DEV void glds16(const void* gptr, void* lds_wave_base) {
+#ifdef AVSR_EMU
+    memcpy(reinterpret_cast<char*>(lds_wave_base) + 16 * emu::lane_id(), gptr, 16);
+#else
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+AVSR_DEV void block_barrier_raw() {  // s_barrier without the vmcnt(0) drain that __syncthreads() implies
+#ifdef AVSR_EMU
+    emu::sync_threads();
+#else
+    __builtin_amdgcn_s_barrier();
+#endif
+}
+template <int N> AVSR_DEV void wait_vmcnt() {
+#ifndef AVSR_EMU
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+
 // ---------------------------------------------------------------- math
 AVSR_DEV float avsr_exp(float x) {
 #ifdef AVSR_EMU

@@ -77,20 +77,74 @@ def _rows(x):
     return x.numel() // x.shape[-1]
 
 
+# ---- bf16 weight copies for the tuned NT kernel ---------------------------------------------------------------
+# In bench (bf16) mode every contraction runs as C = A . B^T with both operands bf16 and k-contiguous
+# (csrc/gemm_fast.hip).  Weights therefore need a bf16 copy ([out][in], Linear forward) and a transposed bf16 copy
+# ([in][out_padded_to_64], data gradient).  Copies are cached per parameter version: an optimizer step bumps
+# `_version`, so they are rebuilt exactly once per training step (bench.py invalidates explicitly).
+_wcache = {}
+
+
+def invalidate_weight_cache():
+    _wcache.clear()
+
+
+def _w_bf16(w2d, transposed):
+    key = (w2d.data_ptr(), transposed, tuple(w2d.shape))
+    ver = w2d._version
+    ent = _wcache.get(key)
+    if ent is not None and ent[0] == ver:
+        return ent[1]
+    if transposed:
+        t = ops.transpose_cast(w2d, w2d.shape[0], w2d.shape[1])  # [in][out -> 64-padded], zero tail
+    else:
+        t = ops.scale_dropout(w2d.contiguous(), torch.bfloat16)
+    _wcache[key] = (ver, t)
+    return t
+
+
+def _fast_ok(a, K, lda):
+    return (not _state["precise"]) and a.dtype == torch.bfloat16 and K % 64 == 0 and (lda or K) % 8 == 0
+
+
+def _pick_tile(M, N):
+    return 2 if ((M + 63) // 64) * ((N + 63) // 64) > 1500 else 1
+
+
 def _gemm_nt(a, w, M, N, K, out, *, lda=None, ldc=None, **kw):
     """out[M,N] = epi(a[M,K] @ w[N,K]^T)."""
+    if _fast_ok(a, K, lda) and w.dim() == 2 and w.dtype == torch.float32 and w.is_contiguous():
+        return ops.gemm_bf16_nt(a, lda or K, _w_bf16(w, False), K, M, N, K, out, ldc or N, tile=_pick_tile(M, N), **kw)
     return ops.gemm(NT, a, lda or K, w, K, M, N, K, out, ldc or N, precise=_state["precise"], **kw)
 
 
 def _gemm_nn(a, w, M, N, K, out, *, lda=None, ldb=None, ldc=None, **kw):
     """out[M,N] = epi(a[M,K] @ w[K,N])  (data gradient: w is the [out=K, in=N] weight)."""
+    Kp = (K + 63) // 64 * 64
+    if (not _state["precise"]) and a.dtype == torch.bfloat16 and w.dim() == 2 and w.dtype == torch.float32 \
+            and w.is_contiguous() and (ldb or N) == N and (lda or K) >= Kp and (lda or K) % 8 == 0:
+        # a's row pitch covers the 64-padded K (its pad columns are zero or multiply the zero tail of w^T)
+        wt = _w_bf16(w, True)  # [N][Kp]
+        return ops.gemm_bf16_nt(a, lda or K, wt, wt.shape[1], M, N, Kp, out, ldc or N, tile=_pick_tile(M, N), **kw)
     return ops.gemm(NN, a, lda or K, w, ldb or N, M, N, K, out, ldc or N, precise=_state["precise"], **kw)
 
 
-def _wgrad(dy, x, rows, n_out, n_in, lda=None, ldb=None):
+def _wgrad(dy, x, rows, n_out, n_in, lda=None, ldb=None, xT=None):
     """dW[n_out, n_in] = dy[rows, n_out]^T x[rows, n_in] (f32).  Small outputs are split along the token
     dimension so that the launch still fills the 256 CUs."""
     tiles = ((n_out + 63) // 64) * ((n_in + 63) // 64)
+    if (not _state["precise"]) and dy.dtype == torch.bfloat16 and (xT is not None or x.dtype == torch.bfloat16):
+        dyT = ops.transpose_cast(dy, rows, n_out, ld_src=lda or n_out)  # [n_out][rows -> 64-padded]
+        if xT is None:
+            xT = ops.transpose_cast(x, rows, n_in, ld_src=ldb or n_in)
+        Kp = dyT.shape[1]
+        split = 1
+        if tiles < 256 and Kp >= 512:
+            split = max(1, min(4, 512 // max(tiles, 1), Kp // 256))
+        dw = (torch.zeros if split > 1 else torch.empty)(n_out, n_in, dtype=torch.float32, device=dy.device)
+        ops.gemm_bf16_nt(dyT, Kp, xT, Kp, n_out, n_in, Kp, dw, n_in, accumulate=split > 1, split_k=split,
+                         tile=_pick_tile(n_out, n_in))
+        return dw
     split = 1
     if tiles < 192 and rows >= 512:
         split = max(1, min(8, 256 // max(tiles, 1), rows // 256))
@@ -101,6 +155,13 @@ def _wgrad(dy, x, rows, n_out, n_in, lda=None, ldb=None):
     ops.gemm(TN, dy, lda or n_out, x, ldb or n_in, n_out, n_in, rows, dw, n_in, precise=_state["precise"],
              accumulate=split > 1, split_k=split)
     return dw
+
+
+def _xT(x, rows, n):
+    """Transposed bf16 copy of an activation shared by several weight gradients (None in precise mode)."""
+    if _state["precise"] or x.dtype != torch.bfloat16:
+        return None
+    return ops.transpose_cast(x, rows, n)
 
 
 def _bgrad(dy, rows, n):
@@ -494,9 +555,11 @@ class MhaSublayerFn(torch.autograd.Function):
         else:
             dq = dqu.view(B * Tq, D)
         dk2, dv2 = dk_.view(B * Tk, D), dv_.view(B * Tk, D)
-        dwq, dbq = _wgrad(dq, h, B * Tq, D, D), _bgrad(dq, B * Tq, D)
-        dwk, dbk = _wgrad(dk2, ka, B * Tk, D, D), _bgrad(dk2, B * Tk, D)
-        dwv, dbv = _wgrad(dv2, ka, B * Tk, D, D), _bgrad(dv2, B * Tk, D)
+        hT = _xT(h, B * Tq, D)
+        kaT = hT if not cross else _xT(ka, B * Tk, D)
+        dwq, dbq = _wgrad(dq, h, B * Tq, D, D, xT=hT), _bgrad(dq, B * Tq, D)
+        dwk, dbk = _wgrad(dk2, ka, B * Tk, D, D, xT=kaT), _bgrad(dk2, B * Tk, D)
+        dwv, dbv = _wgrad(dv2, ka, B * Tk, D, D, xT=kaT), _bgrad(dv2, B * Tk, D)
         dmem = None
         if cross:
             dh = torch.empty(B * Tq, D, dtype=T, device=x.device)

@@ -198,8 +198,9 @@ def dwconv_wgrad(x, dy, dw, db, B, T, C, K):
 
 
 def bn_stats(x, rows, C):
-    stats = torch.zeros(3, C, dtype=torch.float32, device=x.device)
-    call("avsr_bn_stats", _ptr(x), dt(x), _ptr(stats), rows, C, _stream(x))
+    stats = torch.empty(3, C, dtype=torch.float32, device=x.device)
+    ws = torch.empty(1024 * 2 * C, dtype=torch.float32, device=x.device)
+    call("avsr_bn_stats", _ptr(x), dt(x), _ptr(stats), _ptr(ws), rows, C, _stream(x))
     return stats
 
 
@@ -228,9 +229,10 @@ def bn_act_fwd(x, add, mean, invstd, gamma, beta, rows, C, act):
 
 
 def bn_bwd_reduce(x, dy, add, mean, invstd, gamma, beta, rows, C, act):
-    sums = torch.zeros(2, C, dtype=torch.float32, device=x.device)
+    sums = torch.empty(2, C, dtype=torch.float32, device=x.device)
+    ws = torch.empty(1024 * 2 * C, dtype=torch.float32, device=x.device)
     call("avsr_bn_bwd_reduce", _ptr(x), _ptr(dy), _ptr(add), dt(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
-         _ptr(sums), rows, C, act, _stream(x))
+         _ptr(sums), _ptr(ws), rows, C, act, _stream(x))
     return sums
 
 
@@ -386,3 +388,21 @@ def avgpool_bwd(dy, out_dtype, groups, win, C):
     dx = torch.empty(groups * win, C, dtype=out_dtype, device=dy.device)
     call("avsr_avgpool_bwd", _ptr(dy), _ptr(dx), dt(dx), groups, win, C, _stream(dy))
     return dx
+
+
+def gemm_bf16_nt(A, lda, B, ldb, M, N, K, C, ldc, *, bias=None, act=0, gate=None, ldg=0, gate_scale=1.0, drop_p=0.0,
+                 seed=0, seed_dev=None, alpha=1.0, alpha_dev=None, resid=None, ldr=0, accumulate=False, split_k=1,
+                 tile=0):
+    call("avsr_gemm_bf16_nt", _ptr(A), lda, _ptr(B), ldb, M, N, K, _ptr(bias), act, _ptr(gate),
+         dt(gate) if gate is not None else 0, ldg, gate_scale, drop_p, seed, _ptr(seed_dev), alpha, _ptr(alpha_dev),
+         _ptr(resid), dt(resid) if resid is not None else 0, ldr, _ptr(C), dt(C), ldc, int(accumulate), split_k, tile,
+         _stream(A), flops=2.0 * M * N * K)
+    return C
+
+
+def transpose_cast(src, R, Ccols, ld_src=None, pad_to=64):
+    """bf16 [Ccols, ldd] = src[R, Ccols]^T with ldd = R rounded up to `pad_to` (zero tail)."""
+    ldd = (R + pad_to - 1) // pad_to * pad_to
+    dst = torch.empty(Ccols, ldd, dtype=torch.bfloat16, device=src.device)
+    call("avsr_transpose_cast", _ptr(src), dt(src), ld_src or Ccols, _ptr(dst), ldd, R, Ccols, _stream(src))
+    return dst

@@ -111,6 +111,7 @@ def main():
     def step(i):
         x, lens, y, _ = data[i]
         seed_dev.add_(1)
+        AF.invalidate_weight_cache()  # an optimizer step would change the weights: pay the bf16 re-casts every step
         loss = hot(x, lens, y)
         if world > 1:
             # loss rescale of lightning.py:88-90: loss *= world / sum of batch sizes (all-gather of B)

@@ -111,8 +111,10 @@ int avsr_dwconv_wgrad(const void* x, const void* dy, int dtype, float* dw, float
                       int K, avsr_stream_t stream);
 
 /* ---- training-mode BatchNorm (+SiLU, + residual add) on channels-last [rows, C] ------------------- */
-/* stats [3][C] (shift, sum(x-shift), sum((x-shift)^2)); caller zeroes it */
-int avsr_bn_stats(const void* x, int dtype, float* stats, int64_t rows, int C, avsr_stream_t stream);
+int64_t avsr_bn_workspace_floats(int C);
+/* stats [3][C] (shift, sum(x-shift), sum((x-shift)^2)), overwritten; workspace: avsr_bn_workspace_floats(C) */
+int avsr_bn_stats(const void* x, int dtype, float* stats, float* workspace, int64_t rows, int C,
+                  avsr_stream_t stream);
 /* merge `world` per-rank partials [world][3][C] + counts[world] -> mean, invstd; momentum update of the
  * running stats (unbiased variance) when running_mean != NULL */
 int avsr_bn_finalize(const float* stats, const float* counts, int world, int C, float eps, float momentum,
@@ -124,10 +126,10 @@ int avsr_bn_eval_params(const float* running_mean, const float* running_var, flo
 int avsr_bn_act_fwd(const void* x, const void* add, int dtype, const float* mean, const float* invstd,
                     const float* gamma, const float* beta, void* y, int64_t rows, int C, int act,
                     avsr_stream_t stream);
-/* sums [2][C] += (sum dz, sum dz*xhat), dz = dy*act'(z) */
+/* sums [2][C] = (sum dz, sum dz*xhat), dz = dy*act'(z); workspace as above */
 int avsr_bn_bwd_reduce(const void* x, const void* dy, const void* add, int dtype, const float* mean,
-                       const float* invstd, const float* gamma, const float* beta, float* sums, int64_t rows,
-                       int C, int act, avsr_stream_t stream);
+                       const float* invstd, const float* gamma, const float* beta, float* sums, float* workspace,
+                       int64_t rows, int C, int act, avsr_stream_t stream);
 /* dx = gamma*invstd*(dz - sums0*inv_n - xhat*sums1*inv_n); dadd = dz (NULL skips); n_dev != NULL overrides
  * inv_n with 1 / *n_dev (device-resident global row count under cross-rank statistics) */
 int avsr_bn_bwd_apply(const void* x, const void* dy, const void* add, int dtype, const float* mean,
@@ -197,6 +199,18 @@ int avsr_maxpool2d_bwd(const uint8_t* idx, const void* dy, void* dx, int dtype, 
 /* y[g,:] = mean of rows g*win .. g*win+win-1 of x [groups*win, C]; y f32 */
 int avsr_avgpool_fwd(const void* x, int dtype, float* y, int64_t groups, int win, int C, avsr_stream_t stream);
 int avsr_avgpool_bwd(const float* dy, void* dx, int dtype, int64_t groups, int win, int C, avsr_stream_t stream);
+
+/* ---- tuned bf16 NT GEMM (gemm_fast.hip): LDS-DMA operand ring, swizzled LDS, counted vmcnt ------------------ */
+/* C[M,N] = epi(A[M,K] . B[N,K]^T), A and B bf16 k-contiguous, K % 64 == 0; epilogue as avsr_gemm (resid may be
+ * f32 or bf16); tile: 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128 */
+int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias, int act,
+                      const void* gate, int gate_dtype, int ldg, float gate_scale, float drop_p, uint64_t seed,
+                      const uint64_t* seed_dev, float alpha, const float* alpha_dev, const void* resid, int resid_dtype,
+                      int ldr, void* C, int c_dtype, int ldc, int accumulate, int split_k, int tile,
+                      avsr_stream_t stream);
+/* dst[c][r] = bf16(src[r][c]); dst row pitch ld_dst >= R, columns [R, ld_dst) zero-filled */
+int avsr_transpose_cast(const void* src, int src_dtype, int64_t ld_src, void* dst, int64_t ld_dst, int R, int C,
+                        avsr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -80,3 +80,39 @@ def test_gemm_epilogue_split_ragged(dev):
     assert _run_gemm(dev, 2, 96, 80, 700, 1, 1, 0, 64, split=4) < 2e-6
     assert _run_gemm(dev, 1, 64, 64, 203, 1, 1, 0, 64) < 2e-6
     assert _run_gemm(dev, 0, 1, 5, 8, 1, 1, 0, 0) < 2e-6
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("shape", [(150, 70, 192), (200, 130, 64), (257, 300, 448)])
+def test_gemm_fast_nt(dev, tile, shape):
+    """LDS-DMA / swizzled-LDS / counted-vmcnt NT kernel: exact products of bf16 operands, all tiles, ragged M/N,
+    pipeline depths shorter and longer than the ring."""
+    M, N, K = shape
+    torch.manual_seed(M + tile)
+    A, B = torch.randn(M, K).bfloat16(), torch.randn(N, K).bfloat16()
+    ref = A.double() @ B.double().t()
+    C = torch.zeros(M, N + 3, device=dev)
+    ops.gemm_bf16_nt(A.to(dev), K, B.to(dev), K, M, N, K, C, N + 3, tile=tile)
+    assert ((C.cpu()[:, :N].double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    assert C.cpu()[:, N:].abs().max() == 0
+    # split-K + epilogue (bias, relu, alpha, bf16 residual) + bf16 output
+    bias, resid = torch.randn(N), torch.randn(M, N).bfloat16()
+    C2 = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+    ops.gemm_bf16_nt(A.to(dev), K, B.to(dev), K, M, N, K, C2, N, bias=bias.to(dev), act=1, alpha=0.5,
+                     resid=resid.to(dev), ldr=N, tile=tile)
+    ref2 = torch.relu(ref + bias.double()) * 0.5 + resid.double()
+    assert ((C2.cpu().double() - ref2).abs().max() / ref2.abs().max()) < 1e-2
+    C3 = torch.zeros(M, N, device=dev)
+    ops.gemm_bf16_nt(A.to(dev), K, B.to(dev), K, M, N, K, C3, N, accumulate=True, split_k=3, tile=tile)
+    assert ((C3.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-6
+
+
+def test_transpose_cast(dev):
+    torch.manual_seed(9)
+    x = torch.randn(150, 70)
+    t = ops.transpose_cast(x.to(dev), 150, 70)
+    assert t.shape == (70, 192)
+    assert (t.cpu()[:, :150].float() - x.t().bfloat16().float()).abs().max() == 0 and t.cpu()[:, 150:].abs().max() == 0
+    xb = torch.randn(33, 136).bfloat16()
+    t2 = ops.transpose_cast(xb.to(dev), 33, 136)
+    assert (t2.cpu()[:, :33] == xb.t()).all()

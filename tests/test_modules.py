@@ -104,3 +104,32 @@ def test_e2e_small_vs_oracle(dev, modality):
     check_grad_norms(m, ref_norms, 1e-2)
     # BatchNorm running statistics of the conv module were updated like torch's (momentum 0.1, unbiased variance)
     assert int(m.encoder.encoders[0].conv_module.norm.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("modality", ["video"])
+def test_e2e_small_bf16_mode(dev, modality):
+    """bf16 bench mode (LDS-DMA NT kernel, bf16 weight / transposed activation copies): losses within 2e-2 of the
+    fp32 oracle and gradients aligned with it."""
+    torch.manual_seed(0)
+    odim = 72
+    m = no_dropout(E2E(odim, modality, adim=128, aheads=2, eunits=256, elayers=2, dunits=256, dlayers=2,
+                       cnn_module_kernel=7))
+    sd = synth_state_dict(m.state_dict(), 13)
+    m.load_state_dict(sd, strict=True)
+    m.to(dev).train()
+    x, lengths, y = synth_batch(modality, 2, 9, 4, odim, seed=8)
+    osd = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running_" not in k else v.clone())
+           for k, v in sd.items()}
+    (loss_r, ctc_r, att_r, _), _ = O.e2e_forward(osd, x, lengths, y, modality=modality, heads=2)
+    loss_r.backward()
+    AF.invalidate_weight_cache()
+    loss, loss_ctc, loss_att, acc = m(x.to(dev), lengths.to(dev), y.to(dev))
+    loss.backward()
+    assert abs(float(loss_ctc) - float(ctc_r)) < 2e-2 * abs(float(ctc_r))
+    assert abs(float(loss_att) - float(att_r)) < 2e-2 * abs(float(att_r))
+    cos = []
+    for k, p in m.named_parameters():
+        a, b = p.grad.double().flatten().cpu(), osd[k].grad.double().flatten()
+        if b.norm() > 1e-4 * max(1.0, float(osd[k].double().norm())):
+            cos.append((float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)), k))
+    assert min(cos)[0] > 0.9, sorted(cos)[:5]
