@@ -110,16 +110,23 @@ __global__ __launch_bounds__(BN_THREADS) void bn_colreduce_kernel(
     }
 }
 
-// dst[base + j][c] = sum_p part[p][j][c], j = 0,1 ; MODE 0 also records the shift row x[0, c]
+// dst[base + j][c] = sum_p part[p][j][c], j = 0,1 ; MODE 0 also records the shift row x[0, c].
+// block = 64 consecutive columns x 4 partial lanes; partials strided over the lanes, combined in LDS.
 template <class T>
 __global__ __launch_bounds__(256) void bn_partial_sum_kernel(const float* __restrict__ part, int nparts, int C,
                                                              float* __restrict__ dst, int base, const T* __restrict__ x0) {
-    const int i = blockIdx.x * 256 + threadIdx.x;  // over 2*C
-    if (i >= 2 * C) return;
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tx;  // over 2*C
     float s = 0.f;
-    for (int p = 0; p < nparts; p++) s += part[(long)p * 2 * C + i];
-    dst[(long)base * C + i] = s;
-    if (x0 && i < C) dst[i] = Elem<T>::ld(x0 + i);
+    if (i < 2 * C)
+        for (int p = ty; p < nparts; p += 4) s += part[(long)p * 2 * C + i];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && i < 2 * C) {
+        dst[(long)base * C + i] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+        if (x0 && i < C) dst[i] = Elem<T>::ld(x0 + i);
+    }
 }
 
 // stats: [W][3][C] (shift, s1, s2), counts [W]; one thread per channel
@@ -233,7 +240,7 @@ static inline int ew_grid(long nvec) {
 
 static inline int bn_parts(long rows, int rpb, int gx) {
     long need = (rows + rpb - 1) / rpb;
-    long cap = 1024 / (gx < 1 ? 1 : gx);
+    long cap = 512 / (gx < 1 ? 1 : gx);
     if (cap < 1) cap = 1;
     return (int)(need < cap ? need : cap);
 }
@@ -250,7 +257,7 @@ extern "C" int avsr_bn_stats(const void* x, int dtype, float* stats, float* work
     const int gx = (cv + CL - 1) / CL;
     const int parts = bn_parts(rows, rpb, gx);
     dim3 grid(gx, parts), block(BN_THREADS);
-    dim3 g2((2 * C + 255) / 256);
+    dim3 g2((2 * C + 63) / 64);
     if (dtype == 0) {
         AVSR_LAUNCH((bn_colreduce_kernel<float, 0>), grid, block, 0, stream, (const float*)x, (const float*)nullptr,
                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
@@ -311,7 +318,7 @@ extern "C" int avsr_bn_bwd_reduce(const void* x, const void* dy, const void* add
     const int gx = (cv + CL - 1) / CL;
     const int parts = bn_parts(rows, rpb, gx);
     dim3 grid(gx, parts), block(BN_THREADS);
-    dim3 g2((2 * C + 255) / 256);
+    dim3 g2((2 * C + 63) / 64);
     if (dtype == 0)
         AVSR_LAUNCH((bn_colreduce_kernel<float, 1>), grid, block, 0, stream, (const float*)x, (const float*)dy,
                     (const float*)add, mean, invstd, gamma, beta, workspace, (long)rows, C, CL, rpb, act);

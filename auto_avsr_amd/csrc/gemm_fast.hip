@@ -163,27 +163,41 @@ extern "C" int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
 // dst[c][r] = src[r][c] as bf16, dst row pitch ldd >= R (columns [R, ldd) zero-filled): the k-contiguous copies
 // (W^T for the data gradient, dY^T / x^T for the weight gradient) that bring every contraction into NT form.
 namespace {
+// 64x64 tile: each thread loads 2 x 8 consecutive source columns (16/32-byte loads), parks them transposed in a bf16
+// LDS tile (pitch 72: conflict-free for the column-wise 16-byte reads), and writes 2 x 8 consecutive destination
+// elements (16-byte stores).
 template <class T>
 __global__ __launch_bounds__(256) void transpose_cast_kernel(const T* __restrict__ src, long lds_, bf16_t* __restrict__ dst,
                                                              long ldd, int R, int Ccols) {
-    __shared__ float tile[64][65];
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64 * 72];  // tile[c][r]
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int i = ty; i < 64; i += 4) {
-        const int r = r0 + i, c = c0 + tx;
-        tile[i][tx] = (r < R && c < Ccols) ? Elem<T>::ld(src + (long)r * lds_ + c) : 0.f;
+    const bool vec_ok = (lds_ % 8 == 0) && (Ccols % 8 == 0);
+    for (int id = threadIdx.x; id < 64 * 8; id += 256) {
+        const int r = id >> 3, cc = (id & 7) * 8;
+        float v[8];
+        const int gr = r0 + r, gc = c0 + cc;
+        if (gr < R && vec_ok && gc + 8 <= Ccols) {
+            load8(src + (long)gr * lds_ + gc, v);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = (gr < R && gc + e < Ccols) ? Elem<T>::ld(src + (long)gr * lds_ + gc + e) : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) tile[(cc + e) * 72 + r] = f2bf(v[e]);
     }
     __syncthreads();
-    for (int i = ty; i < 64; i += 4) {
-        const int c = c0 + i, r = r0 + tx;  // dst row c, dst col r
-        if (c < Ccols && r < ldd) dst[(long)c * ldd + r] = f2bf(tile[tx][i]);
+    for (int id = threadIdx.x; id < 64 * 8; id += 256) {
+        const int c = id >> 3, rr = (id & 7) * 8;
+        const int gc = c0 + c, gr = r0 + rr;  // dst row gc, dst cols gr..gr+7 (ldd % 8 == 0, gr % 8 == 0)
+        if (gc < Ccols && gr < ldd)
+            *reinterpret_cast<bf16x8*>(dst + (long)gc * ldd + gr) = *reinterpret_cast<const bf16x8*>(tile + c * 72 + rr);
     }
 }
 }  // namespace
 
 extern "C" int avsr_transpose_cast(const void* src, int src_dtype, int64_t ld_src, void* dst, int64_t ld_dst, int R, int C,
                                    hipStream_t stream) {
-    AVSR_REQUIRE(ld_dst >= R, "transpose_cast: destination pitch must cover the source rows");
+    AVSR_REQUIRE(ld_dst >= R && ld_dst % 8 == 0, "transpose_cast: destination pitch must cover the source rows and be a multiple of 8");
     if (R <= 0 || C <= 0) return 0;
     dim3 grid((C + 63) / 64, (unsigned)((ld_dst + 63) / 64)), block(256);
     if (src_dtype == 0)

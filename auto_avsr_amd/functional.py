@@ -598,7 +598,7 @@ def _bn_train_stats(c2, rows, C, eps, momentum, running_mean, running_var):
         import torch.distributed as dist
 
         W = dist.get_world_size(group)
-        mine = torch.cat([stats.reshape(-1), torch.tensor([float(rows)], device=c2.device)])
+        mine = torch.cat([stats.reshape(-1), torch.full((1,), float(rows), dtype=torch.float32, device=c2.device)])
         allv = torch.empty(W, mine.numel(), dtype=torch.float32, device=c2.device)
         dist.all_gather_into_tensor(allv, mine, group=group)
         counts = allv[:, -1].contiguous()
@@ -606,7 +606,7 @@ def _bn_train_stats(c2, rows, C, eps, momentum, running_mean, running_var):
         mean, invstd = ops.bn_finalize(stats_all, counts, W, C, eps, momentum, running_mean, running_var)
         n_total = None  # read on device below
         return mean, invstd, counts
-    counts = torch.tensor([float(rows)], device=c2.device)
+    counts = torch.full((1,), float(rows), dtype=torch.float32, device=c2.device)  # fill kernel: graph-capturable
     mean, invstd = ops.bn_finalize(stats.unsqueeze(0), counts, 1, C, eps, momentum, running_mean, running_var)
     return mean, invstd, counts
 

@@ -559,9 +559,9 @@ def add_sos_eos_static(ys_pad, sos, eos, ignore_id):
     comp = torch.gather(y, 1, order)
     ar = torch.arange(L + 1, device=y.device).unsqueeze(0)
     body = torch.cat([comp, comp.new_full((B, 1), eos)], 1)
-    ys_out = torch.where(ar < n, body, torch.where(ar == n, body.new_tensor(eos), body.new_tensor(ignore_id)))
+    ys_out = torch.where(ar < n, body, torch.where(ar == n, eos, ignore_id))  # python scalars: no H2D copies
     shifted = torch.cat([comp.new_full((B, 1), sos), comp], 1)
-    ys_in = torch.where(ar <= n, shifted, shifted.new_tensor(eos))
+    ys_in = torch.where(ar <= n, shifted, eos)
     return ys_in, ys_out
 
 

@@ -31,6 +31,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--precise", action="store_true", help="parity mode (split-bf16 contractions) instead of bf16")
+    ap.add_argument("--shapes", type=int, default=4, help="distinct length-bucketed batch shapes cycled through")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (N=1)")
     return ap.parse_args()
 
 
@@ -106,10 +108,42 @@ def main():
     lengths = utterance_lengths()
     batches = rank_batches(bucket_batches(lengths, args.max_frames, 400), rank, world, seed=0)
     n_need = args.warmup + args.steps
-    data = [make_batch(lengths, batches[i % len(batches)], args.modality, odim, seed=i, device=dev) for i in range(n_need)]
+    # `--shapes` batches spread over the bucket list (short/wide ... long/narrow) are kept resident and cycled, the
+    # way a bucketed sampler revisits its (B, T, L) shapes; every step still runs a full fwd+bwd on its batch.
+    nshape = max(1, min(args.shapes, len(batches)))
+    picks = [batches[(2 * j + 1) * len(batches) // (2 * nshape)] for j in range(nshape)]
+    pool = [make_batch(lengths, b, args.modality, odim, seed=j, device=dev) for j, b in enumerate(picks)]
+    data = [pool[i % nshape] for i in range(n_need)]
+    use_graph = world == 1 and not args.no_graph
+    graphs = {}
+
+    def eager_step(x, lens, y):
+        seed_dev.add_(1)
+        AF.invalidate_weight_cache()  # an optimizer step would change the weights: pay the bf16 re-casts every step
+        loss = hot(x, lens, y)
+        loss.backward()
+        return loss
 
     def step(i):
         x, lens, y, _ = data[i]
+        if use_graph:
+            # one hipGraph per batch shape: the ~3000 kernel launches of a step are replayed by the GPU front-end
+            # instead of being issued one by one from Python (HIP graphs, not a tracing compiler)
+            key = i % nshape
+            if key not in graphs:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    eager_step(x, lens, y)
+                    model.zero_grad(set_to_none=True)
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    eager_step(x, lens, y)
+                graphs[key] = g
+                AF.invalidate_weight_cache()
+            graphs[key].replay()
+            return None
         seed_dev.add_(1)
         AF.invalidate_weight_cache()  # an optimizer step would change the weights: pay the bf16 re-casts every step
         loss = hot(x, lens, y)
@@ -123,6 +157,9 @@ def main():
         model.zero_grad(set_to_none=True)
         return loss
 
+    if use_graph:  # captures are set-up, not steps
+        for j in range(nshape):
+            step(j)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -158,7 +195,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": "configs[1]: modality=video vsr_trlrs3_base (12-layer Conformer + 6-layer decoder, 250M), "
                                "length-bucketed batches, max-frames=1600 (real frames), fwd+bwd"
-                               + (", DDP grad all-reduce + SyncBN over RCCL" if world > 1 else ""),
+                               + (", DDP grad all-reduce + SyncBN over RCCL" if world > 1 else "")
+                               + (f", hipGraph replay, {nshape} batch shapes cycled" if use_graph else f", eager launches, {nshape} batch shapes cycled"),
                    "padded_frames_per_sec": round(float(ftot[1]) / dt, 2),
                    "all_hot_path_compute": "libavsr_hip.so (hand-written HIP, gfx950)"},
     }
