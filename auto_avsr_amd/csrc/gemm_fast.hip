@@ -20,7 +20,10 @@ namespace {
 
 using avsr_gemm_impl::Params;
 
-template <int BM, int BN, int STAGES>
+// CV = 0: plain A[M][K].  CV = 1 / 2: A is the im2col view of a channels-last image tensor (forward / data gradient,
+// see gemm_core.h Params); channels are a multiple of 64, so a 64-wide k-tile lies inside one filter tap and the
+// tap decode is wave-uniform; out-of-image taps read a caller-provided page of zeros.
+template <int BM, int BN, int STAGES, int CV = 0>
 struct FastKernel {
     static constexpr int BK = 64;
     static constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -29,15 +32,63 @@ struct FastKernel {
     static constexpr int LPT = A_LOADS + B_LOADS;               // LDS-DMA ops per thread per tile
     static constexpr size_t LDS_BYTES = (size_t)STAGES * STAGE_BYTES;
 
+    // per-lane decode of the A rows this lane stages (fixed for the whole k loop)
+    struct RowInfo {
+        long base[A_LOADS];          // element offset of pixel (n, 0, 0, 0) of the gathered tensor
+        int y0[A_LOADS], x0[A_LOADS];  // CV1: oh*s-ph, ow*s-pw ; CV2: ih+ph, iw+pw
+    };
+    static AVSR_DEV RowInfo decode_rows(const Params& p, int m0, int wave, int lane) {
+        RowInfo ri;
+        const int rsub = lane >> 3;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; i++) {
+            const int m = min(m0 + (wave * A_LOADS + i) * 8 + rsub, p.M - 1);
+            const int pix = p.cOH * p.cOW;
+            const int n = m / pix, r = m - n * pix;
+            const int y = r / p.cOW, x = r - y * p.cOW;
+            ri.base[i] = (long)n * p.cH * p.cW * p.cC;
+            if (CV == 1) {
+                ri.y0[i] = y * p.cS - p.cPH;
+                ri.x0[i] = x * p.cS - p.cPW;
+            } else {
+                ri.y0[i] = y + p.cPH;
+                ri.x0[i] = x + p.cPW;
+            }
+        }
+        return ri;
+    }
+
     static AVSR_DEV void issue(const bf16_t* A, const bf16_t* B, int lda, int ldb, int m0, int n0, int M, int N, int k0,
-                               char* stage, int wave, int lane) {
+                               char* stage, int wave, int lane, const Params& p, const RowInfo& ri) {
         const int rsub = lane >> 3, pc = lane & 7;
+        int kh = 0, kw = 0, cbase = 0;
+        if (CV != 0) {  // wave-uniform tap decode of this k-tile
+            const int tap = k0 / p.cC;
+            cbase = k0 - tap * p.cC;
+            kh = tap / p.cKW;
+            kw = tap - kh * p.cKW;
+        }
 #pragma unroll
         for (int i = 0; i < A_LOADS; i++) {
             const int r = (wave * A_LOADS + i) * 8 + rsub;  // row inside the tile
             const int c = pc ^ ((r >> 1) & 7);              // source chunk that lands in physical chunk pc
-            const int gr = min(m0 + r, M - 1);
-            glds16(A + (size_t)gr * lda + k0 + c * 8, stage + (wave * A_LOADS + i) * 1024);
+            const bf16_t* src;
+            if (CV == 0) {
+                const int gr = min(m0 + r, M - 1);
+                src = A + (size_t)gr * lda + k0 + c * 8;
+            } else if (CV == 1) {
+                const int ih = ri.y0[i] + kh, iw = ri.x0[i] + kw;
+                const bool ok = ih >= 0 && ih < p.cH && iw >= 0 && iw < p.cW;
+                src = ok ? A + ri.base[i] + ((long)ih * p.cW + iw) * p.cC + cbase + c * 8
+                         : reinterpret_cast<const bf16_t*>(p.gate);  // zero page
+            } else {
+                const int th = ri.y0[i] - kh, tw = ri.x0[i] - kw;
+                const int oh = th / p.cS, ow = tw / p.cS;
+                const bool ok = th >= 0 && tw >= 0 && oh * p.cS == th && ow * p.cS == tw && oh < p.cH && ow < p.cW;
+                src = ok ? A + ri.base[i] + ((long)oh * p.cW + ow) * p.cC + cbase + c * 8
+                         : reinterpret_cast<const bf16_t*>(p.gate);
+            }
+            glds16(src, stage + (wave * A_LOADS + i) * 1024);
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; i++) {
@@ -71,10 +122,12 @@ struct FastKernel {
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
+        RowInfo ri;
+        if (CV != 0) ri = decode_rows(p, m0, wave, lane);
         // prologue: tiles 0 .. STAGES-2 in flight
 #pragma unroll
         for (int s = 0; s < STAGES - 1; s++)
-            if (s < nt) issue(A, B, p.lda, p.ldb, m0, n0, p.M, p.N, kbeg + s * BK, smem + s * STAGE_BYTES, wave, lane);
+            if (s < nt) issue(A, B, p.lda, p.ldb, m0, n0, p.M, p.N, kbeg + s * BK, smem + s * STAGE_BYTES, wave, lane, p, ri);
 
         for (int t = 0; t < nt; t++) {
             // retire tile t: loads of at most STAGES-2 later tiles may stay in flight
@@ -85,7 +138,7 @@ struct FastKernel {
             block_barrier_raw();  // tile t is in LDS for every wave; everyone is done reading tile t-1's buffer
             if (t + STAGES - 1 < nt)
                 issue(A, B, p.lda, p.ldb, m0, n0, p.M, p.N, kbeg + (t + STAGES - 1) * BK,
-                      smem + ((t + STAGES - 1) % STAGES) * STAGE_BYTES, wave, lane);
+                      smem + ((t + STAGES - 1) % STAGES) * STAGE_BYTES, wave, lane, p, ri);
             const char* As = smem + (t % STAGES) * STAGE_BYTES;
             const char* Bs = As + A_BYTES;
 #pragma unroll
@@ -102,24 +155,30 @@ struct FastKernel {
                     for (int j = 0; j < TN; j++) acc[i][j] = mfma32(fa[i], fb[j], acc[i][j]);
             }
         }
-        avsr_gemm_impl::epilogue<TM, TN>(acc, p, m0 + wm * WM, n0 + wn * WN, lane, zs, 0);
+        if (CV != 0) {
+            Params q = p;
+            q.gate = nullptr;  // in conv mode the field carries the zero page, not an activation gate
+            avsr_gemm_impl::epilogue<TM, TN>(acc, q, m0 + wm * WM, n0 + wn * WN, lane, zs, 0);
+        } else {
+            avsr_gemm_impl::epilogue<TM, TN>(acc, p, m0 + wm * WM, n0 + wn * WN, lane, zs, 0);
+        }
     }
 };
 
-template <int BM, int BN, int STAGES>
+template <int BM, int BN, int STAGES, int CV = 0>
 __global__ __launch_bounds__(256) void gemm_fast_kernel(Params p) {
     AVSR_DYN_SMEM(smem);
-    FastKernel<BM, BN, STAGES>::run(p, smem);
+    FastKernel<BM, BN, STAGES, CV>::run(p, smem);
 }
 
-template <int BM, int BN, int STAGES>
+template <int BM, int BN, int STAGES, int CV = 0>
 void launch_fast(Params& p, int split_k, hipStream_t stream) {
     int kc = (p.K + split_k - 1) / split_k;
     kc = ((kc + 63) / 64) * 64;
     split_k = (p.K + kc - 1) / kc;
     p.k_chunk = kc;
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, split_k), block(256);
-    AVSR_LAUNCH((gemm_fast_kernel<BM, BN, STAGES>), grid, block, (FastKernel<BM, BN, STAGES>::LDS_BYTES), stream, p);
+    AVSR_LAUNCH((gemm_fast_kernel<BM, BN, STAGES, CV>), grid, block, (FastKernel<BM, BN, STAGES, CV>::LDS_BYTES), stream, p);
 }
 
 }  // namespace
@@ -156,6 +215,43 @@ extern "C" int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
     else if (tile == 2) launch_fast<128, 64, 3>(p, split_k, stream);
     else launch_fast<64, 64, 4>(p, split_k, stream);
     AVSR_CHECK_LAUNCH("gemm_bf16_nt");
+    return 0;
+}
+
+// bf16 implicit-GEMM convolution on the tuned kernel: forward (dgrad = 0: x[N,H,W,Cin] * wp[Cout][KH][KW][Cin] ->
+// y[N,OH,OW,Cout]) or data gradient (dgrad = 1: dy[N,OH,OW,Cout] * wpd[Cin][KH][KW][Cout] (+resid) -> dx[N,H,W,Cin]).
+// The gathered tensor's channel count must be a multiple of 64; zero_page: >= 16 zero bytes in device memory.
+extern "C" int avsr_conv2d_bf16(int dgrad, const void* src, const void* wp, const void* resid, void* out, const void* zero_page,
+                                int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_h, int pad_w,
+                                hipStream_t stream) {
+    const int OH = (H + 2 * pad_h - KH) / stride + 1, OW = (W + 2 * pad_w - KW) / stride + 1;
+    const int Cg = dgrad ? Cout : Cin;  // channels of the gathered tensor
+    AVSR_REQUIRE(Cg % 64 == 0, "conv2d_bf16: gathered channel count must be a multiple of 64");
+    AVSR_REQUIRE(zero_page != nullptr, "conv2d_bf16: zero page required");
+    if (N <= 0) return 0;
+    Params p{};
+    p.A = src; p.B = wp;
+    p.K = KH * KW * Cg; p.lda = Cg; p.ldb = p.K;
+    p.alpha = 1.f; p.gate_scale = 1.f;
+    p.nsplit = 1; p.batch_h = 1; p.nbatch = 1;
+    p.gate = zero_page;
+    p.c_dtype = 1; p.C = out;
+    p.cKH = KH; p.cKW = KW; p.cS = stride; p.cPH = pad_h; p.cPW = pad_w; p.cC = Cg; p.cT = 1; p.cKT = 1;
+    if (!dgrad) {
+        p.M = N * OH * OW; p.N = Cout; p.ldc = Cout;
+        p.cH = H; p.cW = W; p.cOH = OH; p.cOW = OW;
+    } else {
+        p.M = N * H * W; p.N = Cin; p.ldc = Cin;
+        p.cH = OH; p.cW = OW; p.cOH = H; p.cOW = W;
+        p.resid = reinterpret_cast<const float*>(resid); p.resid_dtype = 1; p.ldr = Cin;
+    }
+    const bool wide = p.N >= 128;
+    if (!dgrad) {
+        if (wide) launch_fast<128, 128, 3, 1>(p, 1, stream); else launch_fast<128, 64, 3, 1>(p, 1, stream);
+    } else {
+        if (wide) launch_fast<128, 128, 3, 2>(p, 1, stream); else launch_fast<128, 64, 3, 2>(p, 1, stream);
+    }
+    AVSR_CHECK_LAUNCH("conv2d_bf16");
     return 0;
 }
 

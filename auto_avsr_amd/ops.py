@@ -325,9 +325,23 @@ def conv_out(n, k, s, p):
     return (n + 2 * p - k) // s + 1
 
 
+_zero_pages = {}
+
+
+def zero_page(device):
+    z = _zero_pages.get(device)
+    if z is None:
+        z = _zero_pages[device] = torch.zeros(64, dtype=torch.float32, device=device)
+    return z
+
+
 def conv2d_fwd(x, wp, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise):
     OH, OW = conv_out(H, KH, stride, ph), conv_out(W, KW, stride, pw)
     y = torch.empty(N, OH, OW, Cout, dtype=x.dtype, device=x.device)
+    if not precise and x.dtype == torch.bfloat16 and wp.dtype == torch.bfloat16 and Cin % 64 == 0:
+        call("avsr_conv2d_bf16", 0, _ptr(x), _ptr(wp), None, _ptr(y), _ptr(zero_page(x.device)), N, H, W, Cin, Cout, KH,
+             KW, stride, ph, pw, _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin)
+        return y
     call("avsr_conv2d_fwd", _ptr(x), dt(x), _ptr(wp), dt(wp), _ptr(y), N, H, W, Cin, Cout, KH, KW, stride, ph, pw,
          int(precise), _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin)
     return y
@@ -335,6 +349,10 @@ def conv2d_fwd(x, wp, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise):
 
 def conv2d_dgrad(dy, wpd, resid, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise):
     dx = torch.empty(N, H, W, Cin, dtype=dy.dtype, device=dy.device)
+    if not precise and dy.dtype == torch.bfloat16 and wpd.dtype == torch.bfloat16 and Cout % 64 == 0:
+        call("avsr_conv2d_bf16", 1, _ptr(dy), _ptr(wpd), _ptr(resid), _ptr(dx), _ptr(zero_page(dy.device)), N, H, W, Cin,
+             Cout, KH, KW, stride, ph, pw, _stream(dy), flops=2.0 * N * H * W * Cin * KH * KW * Cout)
+        return dx
     call("avsr_conv2d_dgrad", _ptr(dy), dt(dy), _ptr(wpd), dt(wpd), _ptr(resid), _ptr(dx), N, H, W, Cin, Cout, KH, KW,
          stride, ph, pw, int(precise), _stream(dy), flops=2.0 * N * H * W * Cin * KH * KW * Cout)
     return dx

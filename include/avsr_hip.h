@@ -208,6 +208,12 @@ int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int
                       const uint64_t* seed_dev, float alpha, const float* alpha_dev, const void* resid, int resid_dtype,
                       int ldr, void* C, int c_dtype, int ldc, int accumulate, int split_k, int tile,
                       avsr_stream_t stream);
+/* bf16 implicit-GEMM convolution on the tuned LDS-DMA kernel: dgrad = 0 forward, 1 data gradient (see
+ * avsr_conv2d_fwd / avsr_conv2d_dgrad for the tensor conventions); gathered channel count % 64 == 0;
+ * zero_page: >= 16 zero bytes of device memory (source of the padding taps) */
+int avsr_conv2d_bf16(int dgrad, const void* src, const void* wp, const void* resid, void* out, const void* zero_page,
+                     int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_h, int pad_w,
+                     avsr_stream_t stream);
 /* dst[c][r] = bf16(src[r][c]); dst row pitch ld_dst >= R, columns [R, ld_dst) zero-filled */
 int avsr_transpose_cast(const void* src, int src_dtype, int64_t ld_src, void* dst, int64_t ld_dst, int R, int C,
                         avsr_stream_t stream);

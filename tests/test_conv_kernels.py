@@ -16,6 +16,9 @@ def nhwc(t):
     (2, 12, 10, 64, 72, 3, 2, 1),
     (2, 11, 11, 32, 40, 1, 2, 0),
     (2, 1, 37, 16, 32, 3, 2, 1),   # 1-D (audio trunk) as an H = 1 image: KH = 1
+    (2, 9, 10, 64, 128, 3, 1, 1),  # channel counts that take the LDS-DMA bf16 kernel in bf16 mode
+    (2, 10, 9, 128, 64, 3, 2, 1),
+    (3, 7, 7, 64, 128, 1, 2, 0),
 ])
 @pytest.mark.parametrize("precise", [True, False])
 def test_conv2d_fwd_dgrad_wgrad(dev, cfg, precise):
