@@ -599,8 +599,9 @@ def _bn_train_stats(c2, rows, C, eps, momentum, running_mean, running_var):
 
         W = dist.get_world_size(group)
         mine = torch.cat([stats.reshape(-1), torch.full((1,), float(rows), dtype=torch.float32, device=c2.device)])
-        allv = torch.empty(W, mine.numel(), dtype=torch.float32, device=c2.device)
-        dist.all_gather_into_tensor(allv, mine, group=group)
+        flat = torch.empty(W * mine.numel(), dtype=torch.float32, device=c2.device)
+        dist.all_gather_into_tensor(flat, mine, group=group)
+        allv = flat.view(W, mine.numel())
         counts = allv[:, -1].contiguous()
         stats_all = allv[:, :-1].contiguous().view(W, 3, C)
         mean, invstd = ops.bn_finalize(stats_all, counts, W, C, eps, momentum, running_mean, running_var)
