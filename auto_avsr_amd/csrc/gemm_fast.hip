@@ -259,17 +259,30 @@ extern "C" int avsr_conv2d_bf16(int dgrad, const void* src, const void* wp, cons
 // dst[c][r] = src[r][c] as bf16, dst row pitch ldd >= R (columns [R, ldd) zero-filled): the k-contiguous copies
 // (W^T for the data gradient, dY^T / x^T for the weight gradient) that bring every contraction into NT form.
 namespace {
-// 64x64 tile: each thread loads 2 x 8 consecutive source columns (16/32-byte loads), parks them transposed in a bf16
-// LDS tile (pitch 72: conflict-free for the column-wise 16-byte reads), and writes 2 x 8 consecutive destination
-// elements (16-byte stores).
+// 64x64 tile: each thread loads 2 x 8 consecutive source columns (16/32-byte loads), applies v = alpha*dropout(src),
+// optionally writes the bf16 copy (dst), parks the values transposed in a bf16 LDS tile (pitch 72) from which 2 x 8
+// consecutive destination elements are written with 16-byte stores (dstT), and optionally adds the tile's column
+// sums into colsum (bias gradients) -- the whole "backward prologue" of a Linear layer in one pass over dY.
 template <class T>
 __global__ __launch_bounds__(256) void transpose_cast_kernel(const T* __restrict__ src, long lds_, bf16_t* __restrict__ dst,
-                                                             long ldd, int R, int Ccols) {
+                                                             bf16_t* __restrict__ dstT, long ldd, float* __restrict__ colsum,
+                                                             int R, int Ccols, float alpha0, const float* alpha_dev,
+                                                             float drop_p, uint64_t seed0, const uint64_t* seed_dev) {
     __shared__ __attribute__((aligned(16))) bf16_t tile[64 * 72];  // tile[c][r]
+    __shared__ float csum[4][64];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const bool vec_ok = (lds_ % 8 == 0) && (Ccols % 8 == 0);
-    for (int id = threadIdx.x; id < 64 * 8; id += 256) {
-        const int r = id >> 3, cc = (id & 7) * 8;
+    const float alpha = alpha0 * (alpha_dev ? *alpha_dev : 1.f);
+    const uint64_t seed = seed0 + (seed_dev ? *seed_dev : 0ull);
+    const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    float part[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) part[e] = 0.f;
+    // thread (rsub = id>>3 in 0..31, chunk = id&7) handles rows rsub and rsub+32 of the tile, columns chunk*8..+8
+    const int cc = (threadIdx.x & 7) * 8;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int r = (threadIdx.x >> 3) + 32 * half;
         float v[8];
         const int gr = r0 + r, gc = c0 + cc;
         if (gr < R && vec_ok && gc + 8 <= Ccols) {
@@ -279,14 +292,46 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const T* __restrict
             for (int e = 0; e < 8; e++) v[e] = (gr < R && gc + e < Ccols) ? Elem<T>::ld(src + (long)gr * lds_ + gc + e) : 0.f;
         }
 #pragma unroll
-        for (int e = 0; e < 8; e++) tile[(cc + e) * 72 + r] = f2bf(v[e]);
+        for (int e = 0; e < 8; e++) {
+            v[e] *= alpha * dropout_scale(seed, (uint64_t)gr * (uint64_t)Ccols + gc + e, drop_p, inv_keep);
+            const bf16_t q = f2bf(v[e]);
+            tile[(cc + e) * 72 + r] = q;
+            part[e] += bf2f(q);
+        }
+        if (dst && gr < R) {
+            if (vec_ok && gc + 8 <= Ccols) store8(dst + (long)gr * Ccols + gc, v);
+            else
+                for (int e = 0; e < 8; e++)
+                    if (gc + e < Ccols) dst[(long)gr * Ccols + gc + e] = f2bf(v[e]);
+        }
+    }
+    if (colsum) {
+        // reduce the 32 row-lanes sharing a column chunk: lanes l, l+8, ... within a wave, then across the 4 waves
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            float t = part[e];
+            t += __shfl_xor(t, 8);
+            t += __shfl_xor(t, 16);
+            t += __shfl_xor(t, 32);
+            part[e] = t;
+        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane < 8)
+#pragma unroll
+            for (int e = 0; e < 8; e++) csum[wave][lane * 8 + e] = part[e];
     }
     __syncthreads();
-    for (int id = threadIdx.x; id < 64 * 8; id += 256) {
-        const int c = id >> 3, rr = (id & 7) * 8;
-        const int gc = c0 + c, gr = r0 + rr;  // dst row gc, dst cols gr..gr+7 (ldd % 8 == 0, gr % 8 == 0)
-        if (gc < Ccols && gr < ldd)
-            *reinterpret_cast<bf16x8*>(dst + (long)gc * ldd + gr) = *reinterpret_cast<const bf16x8*>(tile + c * 72 + rr);
+    if (colsum && threadIdx.x < 64) {
+        const int gc = c0 + threadIdx.x;
+        if (gc < Ccols) atomicAdd(colsum + gc, csum[0][threadIdx.x] + csum[1][threadIdx.x] + csum[2][threadIdx.x] + csum[3][threadIdx.x]);
+    }
+    if (dstT) {
+        for (int id = threadIdx.x; id < 64 * 8; id += 256) {
+            const int c = id >> 3, rr = (id & 7) * 8;
+            const int gc = c0 + c, gr = r0 + rr;  // dst row gc, dst cols gr..gr+7 (ldd % 8 == 0, gr % 8 == 0)
+            if (gc < Ccols && gr < ldd)
+                *reinterpret_cast<bf16x8*>(dstT + (long)gc * ldd + gr) = *reinterpret_cast<const bf16x8*>(tile + c * 72 + rr);
+        }
     }
 }
 }  // namespace
@@ -297,9 +342,32 @@ extern "C" int avsr_transpose_cast(const void* src, int src_dtype, int64_t ld_sr
     if (R <= 0 || C <= 0) return 0;
     dim3 grid((C + 63) / 64, (unsigned)((ld_dst + 63) / 64)), block(256);
     if (src_dtype == 0)
-        AVSR_LAUNCH((transpose_cast_kernel<float>), grid, block, 0, stream, (const float*)src, (long)ld_src, (bf16_t*)dst, (long)ld_dst, R, C);
+        AVSR_LAUNCH((transpose_cast_kernel<float>), grid, block, 0, stream, (const float*)src, (long)ld_src, (bf16_t*)nullptr, (bf16_t*)dst,
+                    (long)ld_dst, (float*)nullptr, R, C, 1.f, (const float*)nullptr, 0.f, 0ull, (const uint64_t*)nullptr);
     else
-        AVSR_LAUNCH((transpose_cast_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)src, (long)ld_src, (bf16_t*)dst, (long)ld_dst, R, C);
+        AVSR_LAUNCH((transpose_cast_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)src, (long)ld_src, (bf16_t*)nullptr, (bf16_t*)dst,
+                    (long)ld_dst, (float*)nullptr, R, C, 1.f, (const float*)nullptr, 0.f, 0ull, (const uint64_t*)nullptr);
     AVSR_CHECK_LAUNCH("transpose_cast");
+    return 0;
+}
+
+// One pass over a [R][C] matrix (f32 or bf16, row pitch ld_src): v = alpha * dropout(src);
+//   dst  (bf16 [R][C], may be NULL)          = v
+//   dstT (bf16 [C][ld_dstT], may be NULL)    = v^T, columns [R, ld_dstT) zero
+//   colsum (f32 [C], may be NULL)           += column sums of the bf16-rounded v   (bias gradient)
+extern "C" int avsr_cast_transpose_colsum(const void* src, int src_dtype, int64_t ld_src, void* dst, void* dstT,
+                                          int64_t ld_dstT, float* colsum, int R, int C, float alpha, const float* alpha_dev,
+                                          float drop_p, uint64_t seed, const uint64_t* seed_dev, hipStream_t stream) {
+    AVSR_REQUIRE(dstT == nullptr || (ld_dstT >= R && ld_dstT % 8 == 0), "cast_transpose_colsum: bad transposed pitch");
+    if (R <= 0 || C <= 0) return 0;
+    const long rows_cover = dstT ? ld_dstT : R;
+    dim3 grid((C + 63) / 64, (unsigned)((rows_cover + 63) / 64)), block(256);
+    if (src_dtype == 0)
+        AVSR_LAUNCH((transpose_cast_kernel<float>), grid, block, 0, stream, (const float*)src, (long)ld_src, (bf16_t*)dst, (bf16_t*)dstT,
+                    (long)ld_dstT, colsum, R, C, alpha, alpha_dev, drop_p, seed, seed_dev);
+    else
+        AVSR_LAUNCH((transpose_cast_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)src, (long)ld_src, (bf16_t*)dst, (bf16_t*)dstT,
+                    (long)ld_dstT, colsum, R, C, alpha, alpha_dev, drop_p, seed, seed_dev);
+    AVSR_CHECK_LAUNCH("cast_transpose_colsum");
     return 0;
 }

@@ -129,19 +129,77 @@ def _gemm_nn(a, w, M, N, K, out, *, lda=None, ldb=None, ldc=None, **kw):
     return ops.gemm(NN, a, lda or K, w, ldb or N, M, N, K, out, ldc or N, precise=_state["precise"], **kw)
 
 
-def _wgrad(dy, x, rows, n_out, n_in, lda=None, ldb=None, xT=None):
+class _ZeroArena:
+    """Hands out zero-initialised f32 scratch (bias / LayerNorm / split-K accumulators) as slices of large chunks
+    that are zero-filled once: one fill kernel per ~64 MiB instead of one per tensor.  A slice is never handed out
+    twice; chunks are freed by the allocator when their last view dies."""
+
+    CHUNK = 16 * 1024 * 1024  # floats
+
+    def __init__(self):
+        self.buf = {}
+
+    def take(self, n, device):
+        n_al = (n + 63) // 64 * 64
+        if n_al > self.CHUNK // 4:
+            return torch.zeros(n, dtype=torch.float32, device=device)
+        ent = self.buf.get(device)
+        if ent is None or ent[1] + n_al > ent[0].numel():
+            ent = self.buf[device] = [torch.zeros(self.CHUNK, dtype=torch.float32, device=device), 0]
+        out = ent[0][ent[1]: ent[1] + n]
+        ent[1] += n_al
+        return out
+
+
+_arena = _ZeroArena()
+
+
+def _zeros(shape, device):
+    n = 1
+    for s_ in (shape if isinstance(shape, (tuple, list)) else (shape,)):
+        n *= s_
+    return _arena.take(n, device).view(shape)
+
+
+def _fast_mode(t):
+    return (not _state["precise"]) and t.dtype in (torch.bfloat16, torch.float32)
+
+
+def _prologue(src, rows, n, *, alpha=1.0, drop=(0.0, 0, None), want_dst=True, want_bias=True, ld_src=None):
+    """Backward prologue of a Linear layer on its output gradient `src` [rows, n] (f32 or activation dtype):
+    g = act_dtype(alpha * dropout(src)), g^T (bf16 fast path only, else None) and the bias gradient colsum(g).
+    Returns (g or src when no copy was needed, gT, db)."""
+    p, sd, sdev = drop
+    db = _zeros(n, src.device) if want_bias else None
+    if not _state["precise"]:
+        need_dst = want_dst and (src.dtype != torch.bfloat16 or alpha != 1.0 or p > 0 or (ld_src or n) != n)
+        g, gT = ops.cast_transpose_colsum(src, rows, n, ld_src=ld_src, want_dst=need_dst, want_T=True, colsum=db,
+                                          alpha=alpha, drop_p=p, seed=sd, seed_dev=sdev)
+        return (g if need_dst else src), gT, db
+    if src.dtype != act_dtype() or alpha != 1.0 or p > 0:
+        g = ops.scale_dropout(src, act_dtype(), alpha=alpha, drop_p=p, seed=sd, seed_dev=sdev)
+    else:
+        g = src
+    if want_bias:
+        ops.colsum_into(g, db, rows, n)
+    return g, None, db
+
+
+def _wgrad(dy, x, rows, n_out, n_in, lda=None, ldb=None, xT=None, dyT=None):
     """dW[n_out, n_in] = dy[rows, n_out]^T x[rows, n_in] (f32).  Small outputs are split along the token
     dimension so that the launch still fills the 256 CUs."""
     tiles = ((n_out + 63) // 64) * ((n_in + 63) // 64)
-    if (not _state["precise"]) and dy.dtype == torch.bfloat16 and (xT is not None or x.dtype == torch.bfloat16):
-        dyT = ops.transpose_cast(dy, rows, n_out, ld_src=lda or n_out)  # [n_out][rows -> 64-padded]
+    if (not _state["precise"]) and (dyT is not None or dy.dtype == torch.bfloat16) and \
+            (xT is not None or x.dtype == torch.bfloat16):
+        if dyT is None:
+            dyT = ops.transpose_cast(dy, rows, n_out, ld_src=lda or n_out)  # [n_out][rows -> 64-padded]
         if xT is None:
             xT = ops.transpose_cast(x, rows, n_in, ld_src=ldb or n_in)
         Kp = dyT.shape[1]
         split = 1
-        if tiles < 256 and Kp >= 512:
-            split = max(1, min(4, 512 // max(tiles, 1), Kp // 256))
-        dw = (torch.zeros if split > 1 else torch.empty)(n_out, n_in, dtype=torch.float32, device=dy.device)
+        if tiles < 100 and Kp >= 512:
+            split = max(1, min(4, 256 // max(tiles, 1), Kp // 256))
+        dw = _zeros((n_out, n_in), dy.device) if split > 1 else torch.empty(n_out, n_in, dtype=torch.float32, device=dy.device)
         ops.gemm_bf16_nt(dyT, Kp, xT, Kp, n_out, n_in, Kp, dw, n_in, accumulate=split > 1, split_k=split,
                          tile=_pick_tile(n_out, n_in))
         return dw
@@ -149,7 +207,7 @@ def _wgrad(dy, x, rows, n_out, n_in, lda=None, ldb=None, xT=None):
     if tiles < 192 and rows >= 512:
         split = max(1, min(8, 256 // max(tiles, 1), rows // 256))
     if split > 1:
-        dw = torch.zeros(n_out, n_in, dtype=torch.float32, device=dy.device)
+        dw = _zeros((n_out, n_in), dy.device)
     else:
         dw = torch.empty(n_out, n_in, dtype=torch.float32, device=dy.device)
     ops.gemm(TN, dy, lda or n_out, x, ldb or n_in, n_out, n_in, rows, dw, n_in, precise=_state["precise"],
@@ -165,7 +223,7 @@ def _xT(x, rows, n):
 
 
 def _bgrad(dy, rows, n):
-    db = torch.zeros(n, dtype=torch.float32, device=dy.device)
+    db = _zeros(n, dy.device)
     ops.colsum_into(dy, db, rows, n)
     return db
 
@@ -234,8 +292,8 @@ class LayerNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, gamma, mean, rstd = ctx.saved_tensors
         D = x.shape[-1]
-        dg = torch.zeros(D, dtype=torch.float32, device=x.device)
-        db = torch.zeros(D, dtype=torch.float32, device=x.device)
+        dg = _zeros(D, x.device)
+        db = _zeros(D, x.device)
         dx = ops.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dg, db)
         return dx, dg, db, None, None
 
@@ -325,18 +383,17 @@ class FfnSublayerFn(torch.autograd.Function):
         rows, D = _rows(x), x.shape[-1]
         Fh = w1.shape[0]
         T = act_dtype()
-        g = ops.scale_dropout(dy, T, alpha=scale, drop_p=p2, seed=s2, seed_dev=sd2)  # grad of the W2 output
-        db2 = _bgrad(g, rows, D)
-        dw2 = _wgrad(g, u, rows, D, Fh)
+        g, gT, db2 = _prologue(dy, rows, D, alpha=scale, drop=(p2, s2, sd2))  # grad of the W2 output (+ g^T, bias grad)
+        dw2 = _wgrad(g, u, rows, D, Fh, dyT=gT, xT=_xT(u, rows, Fh))
         du = torch.empty(rows, Fh, dtype=T, device=x.device)
         # relu' and the hidden dropout mask are both "u > 0" on the saved post-dropout activation
         _gemm_nn(g, w2, rows, Fh, D, du, gate=u, ldg=Fh, gate_scale=1.0 / (1.0 - p1) if p1 > 0 else 1.0)
-        db1 = _bgrad(du, rows, Fh)
-        dw1 = _wgrad(du, h, rows, Fh, D)
+        _, duT, db1 = _prologue(du, rows, Fh, want_dst=False)
+        dw1 = _wgrad(du, h, rows, Fh, D, dyT=duT, xT=_xT(h, rows, D))
         dh = torch.empty(rows, D, dtype=T, device=x.device)
         _gemm_nn(du, w1, rows, D, Fh, dh)
-        dg = torch.zeros(D, dtype=torch.float32, device=x.device)
-        dbt = torch.zeros(D, dtype=torch.float32, device=x.device)
+        dg = _zeros(D, x.device)
+        dbt = _zeros(D, x.device)
         dx = ops.layernorm_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dres=dy)
         return dx, dg, dbt, dw1, db1, dw2, db2, None, None, None
 
@@ -535,9 +592,8 @@ class MhaSublayerFn(torch.autograd.Function):
         Tk = ka.shape[1]
         dk = D // H
         T = act_dtype()
-        g = ops.scale_dropout(dy, T, drop_p=po, seed=so, seed_dev=sdo)
-        dbo = _bgrad(g, B * Tq, D)
-        dwo = _wgrad(g, ctxv, B * Tq, D, D)
+        g, gT, dbo = _prologue(dy, B * Tq, D, drop=(po, so, sdo))
+        dwo = _wgrad(g, ctxv, B * Tq, D, D, dyT=gT, xT=_xT(ctxv.view(B * Tq, D), B * Tq, D))
         dctx = torch.empty(B, Tq, D, dtype=T, device=x.device)
         _gemm_nn(g, wo, B * Tq, D, D, dctx)
         dqu, dqv, dk_, dv_, dpos = ops.attention_bwd(
@@ -547,19 +603,22 @@ class MhaSublayerFn(torch.autograd.Function):
         du = dv_bias = dwpos = None
         if relpos:
             dq = torch.empty(B * Tq, D, dtype=T, device=x.device)
-            du = torch.zeros(D, dtype=torch.float32, device=x.device)
-            dv_bias = torch.zeros(D, dtype=torch.float32, device=x.device)
+            du = _zeros(D, x.device)
+            dv_bias = _zeros(D, x.device)
             ops.head_bias_bwd(dqu, dqv, dq, D, du, dv_bias, B * Tq, D)
             du, dv_bias = du.view(H, dk), dv_bias.view(H, dk)
             dwpos = _wgrad(dpos, pe, pe.shape[0], D, D)
         else:
             dq = dqu.view(B * Tq, D)
         dk2, dv2 = dk_.view(B * Tk, D), dv_.view(B * Tk, D)
-        hT = _xT(h, B * Tq, D)
-        kaT = hT if not cross else _xT(ka, B * Tk, D)
-        dwq, dbq = _wgrad(dq, h, B * Tq, D, D, xT=hT), _bgrad(dq, B * Tq, D)
-        dwk, dbk = _wgrad(dk2, ka, B * Tk, D, D, xT=kaT), _bgrad(dk2, B * Tk, D)
-        dwv, dbv = _wgrad(dv2, ka, B * Tk, D, D, xT=kaT), _bgrad(dv2, B * Tk, D)
+        hT = _xT(h.view(B * Tq, D), B * Tq, D)
+        kaT = hT if not cross else _xT(ka.view(B * Tk, D), B * Tk, D)
+        _, dqT, dbq = _prologue(dq, B * Tq, D, want_dst=False)
+        _, dkT, dbk = _prologue(dk2, B * Tk, D, want_dst=False)
+        _, dvT, dbv = _prologue(dv2, B * Tk, D, want_dst=False)
+        dwq = _wgrad(dq, h, B * Tq, D, D, xT=hT, dyT=dqT)
+        dwk = _wgrad(dk2, ka, B * Tk, D, D, xT=kaT, dyT=dkT)
+        dwv = _wgrad(dv2, ka, B * Tk, D, D, xT=kaT, dyT=dvT)
         dmem = None
         if cross:
             dh = torch.empty(B * Tq, D, dtype=T, device=x.device)
@@ -576,8 +635,8 @@ class MhaSublayerFn(torch.autograd.Function):
             _gemm_nn(dk2, wk, B * Tq, D, D, t2, resid=t1, ldr=D)
             dh = torch.empty_like(t1)
             _gemm_nn(dv2, wv, B * Tq, D, D, dh, resid=t2, ldr=D)
-        dg = torch.zeros(D, dtype=torch.float32, device=x.device)
-        dbt = torch.zeros(D, dtype=torch.float32, device=x.device)
+        dg = _zeros(D, x.device)
+        dbt = _zeros(D, x.device)
         dx = ops.layernorm_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dres=dy)
         return (dx, dmem, None, None, dg, dbt, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dwpos, du, dv_bias, None, None,
                 None, None)
@@ -668,30 +727,29 @@ class ConvSublayerFn(torch.autograd.Function):
         B, Tn, D = x.shape
         rows = B * Tn
         T = act_dtype()
-        g = ops.scale_dropout(dy, T, drop_p=po, seed=so, seed_dev=sdo)
-        db2 = _bgrad(g, rows, D)
-        dw2 = _wgrad(g, s, rows, D, D).view(D, D, 1)
+        g, gT, db2 = _prologue(dy, rows, D, drop=(po, so, sdo))
+        dw2 = _wgrad(g, s, rows, D, D, dyT=gT, xT=_xT(s, rows, D)).view(D, D, 1)
         ds = torch.empty(rows, D, dtype=T, device=x.device)
         _gemm_nn(g, w_pw2.view(D, D), rows, D, D, ds)
         sums = ops.bn_bwd_reduce(c, ds, None, bmean, binv, bn_w, bn_b, rows, D, 1)
-        dbn_w, dbn_b = sums[1].clone(), sums[0].clone()
+        dbn_w, dbn_b = sums[1], sums[0]
         if training:
             sums_dx, inv_n, n_dev = _bn_bwd_sums(sums, counts, rows)
         else:
             sums_dx, inv_n, n_dev = torch.zeros_like(sums), 0.0, None
         dc, _ = ops.bn_bwd_apply(c, ds, None, bmean, binv, bn_w, bn_b, sums_dx, inv_n, rows, D, 1, False, n_dev=n_dev)
-        dwdw = torch.zeros(D, K, dtype=torch.float32, device=x.device)
-        dbdw = torch.zeros(D, dtype=torch.float32, device=x.device)
+        dwdw = _zeros((D, K), x.device)
+        dbdw = _zeros(D, x.device)
         ops.dwconv_wgrad(gl, dc, dwdw, dbdw, B, Tn, D, K)
         dgl = ops.dwconv(dc, wdw, None, B, Tn, D, K, flip=True)
         da = ops.glu_bwd(a, dgl, rows, D)
-        db1 = _bgrad(da, rows, 2 * D)
-        dw1 = _wgrad(da, h, rows, 2 * D, D).view(2 * D, D, 1)
+        _, daT, db1 = _prologue(da, rows, 2 * D, want_dst=False)
+        dw1 = _wgrad(da, h, rows, 2 * D, D, dyT=daT, xT=_xT(h.view(rows, D), rows, D)).view(2 * D, D, 1)
         if fused:
             dh = torch.empty(rows, D, dtype=T, device=x.device)
             _gemm_nn(da, w_pw1.view(2 * D, D), rows, D, 2 * D, dh)
-            dg = torch.zeros(D, dtype=torch.float32, device=x.device)
-            dbt = torch.zeros(D, dtype=torch.float32, device=x.device)
+            dg = _zeros(D, x.device)
+            dbt = _zeros(D, x.device)
             dx = ops.layernorm_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dres=dy)
         else:
             dg = dbt = None
@@ -882,7 +940,7 @@ def _bn_fwd_params(c2, rows, C, bn, training):
 def _bn_bwd(c, dy, add, mean, invstd, bn, counts, rows, C, act, want_dadd, training):
     """Backward of y = act(bn(c) + add): returns (dc, dadd, dgamma, dbeta)."""
     sums = ops.bn_bwd_reduce(c, dy, add, mean, invstd, bn[0], bn[1], rows, C, act)
-    dgamma, dbeta = sums[1].clone(), sums[0].clone()
+    dgamma, dbeta = sums[1], sums[0]  # views of a fresh tensor
     if training:
         sums_dx, inv_n, n_dev = _bn_bwd_sums(sums, counts, rows)
     else:

@@ -424,3 +424,15 @@ def transpose_cast(src, R, Ccols, ld_src=None, pad_to=64):
     dst = torch.empty(Ccols, ldd, dtype=torch.bfloat16, device=src.device)
     call("avsr_transpose_cast", _ptr(src), dt(src), ld_src or Ccols, _ptr(dst), ldd, R, Ccols, _stream(src))
     return dst
+
+
+def cast_transpose_colsum(src, R, Ccols, *, ld_src=None, want_dst=False, want_T=True, colsum=None, alpha=1.0,
+                          alpha_dev=None, drop_p=0.0, seed=0, seed_dev=None):
+    """One pass over src [R, Ccols]: returns (dst bf16 [R, Ccols] or None, dstT bf16 [Ccols, R->64-padded] or None);
+    colsum (f32 [Ccols], accumulated into) optional."""
+    dst = torch.empty(R, Ccols, dtype=torch.bfloat16, device=src.device) if want_dst else None
+    ldd = (R + 63) // 64 * 64
+    dstT = torch.empty(Ccols, ldd, dtype=torch.bfloat16, device=src.device) if want_T else None
+    call("avsr_cast_transpose_colsum", _ptr(src), dt(src), ld_src or Ccols, _ptr(dst), _ptr(dstT), ldd, _ptr(colsum), R,
+         Ccols, alpha, _ptr(alpha_dev), drop_p, seed, _ptr(seed_dev), _stream(src))
+    return dst, dstT

@@ -218,6 +218,12 @@ int avsr_conv2d_bf16(int dgrad, const void* src, const void* wp, const void* res
 int avsr_transpose_cast(const void* src, int src_dtype, int64_t ld_src, void* dst, int64_t ld_dst, int R, int C,
                         avsr_stream_t stream);
 
+/* backward prologue of a Linear layer in one pass: v = alpha*dropout(src[R][C]); dst = bf16(v) (NULL skips);
+ * dstT = bf16(v)^T with row pitch ld_dstT >= R, zero tail (NULL skips); colsum[C] += column sums (NULL skips) */
+int avsr_cast_transpose_colsum(const void* src, int src_dtype, int64_t ld_src, void* dst, void* dstT, int64_t ld_dstT,
+                               float* colsum, int R, int C, float alpha, const float* alpha_dev, float drop_p,
+                               uint64_t seed, const uint64_t* seed_dev, avsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

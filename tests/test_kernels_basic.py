@@ -116,3 +116,19 @@ def test_transpose_cast(dev):
     xb = torch.randn(33, 136).bfloat16()
     t2 = ops.transpose_cast(xb.to(dev), 33, 136)
     assert (t2.cpu()[:, :33] == xb.t()).all()
+
+
+def test_cast_transpose_colsum(dev):
+    torch.manual_seed(10)
+    R, C = 150, 136
+    x = torch.randn(R, C)
+    cs = torch.zeros(C, device=dev)
+    dst, dstT = ops.cast_transpose_colsum(x.to(dev), R, C, want_dst=True, colsum=cs, alpha=0.5)
+    ref = (0.5 * x).bfloat16()
+    assert (dst.cpu() == ref).all()
+    assert (dstT.cpu()[:, :R] == ref.t()).all() and dstT.cpu()[:, R:].abs().max() == 0
+    assert (cs.cpu() - ref.float().sum(0)).abs().max() < 1e-3
+    # dropout: same mask as scale_dropout with the same (seed, index)
+    d2, _ = ops.cast_transpose_colsum(x.to(dev), R, C, want_dst=True, want_T=False, drop_p=0.3, seed=99)
+    ref2 = ops.scale_dropout(x.to(dev), torch.bfloat16, drop_p=0.3, seed=99)
+    assert (d2.cpu() == ref2.cpu()).all()
