@@ -213,7 +213,7 @@ extern "C" int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
     }
     if (tile == 3) launch_fast<128, 128, 3>(p, split_k, stream);
     else if (tile == 2) launch_fast<128, 64, 3>(p, split_k, stream);
-    else launch_fast<64, 64, 4>(p, split_k, stream);
+    else launch_fast<64, 64, 3>(p, split_k, stream);  // 3 stages = 48 KiB: 3 blocks/CU (measured > 4 stages, 2 blocks/CU)
     AVSR_CHECK_LAUNCH("gemm_bf16_nt");
     return 0;
 }

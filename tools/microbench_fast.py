@@ -16,8 +16,7 @@ def timeit(fn, iters=100, warm=10):
     return s.elapsed_time(e) / iters * 1e3
 
 rows = []
-shapes = [(1600, 3072, 768), (1600, 768, 3072), (1600, 2304, 768), (1600, 768, 768), (768, 768, 1600), (3072, 768, 1600),
-          (1600, 5056, 768), (4096, 4096, 4096), (774400, 64, 576), (193600, 128, 1152)]
+shapes = [(1600, 3072, 768), (1600, 768, 3072), (1600, 1536, 768), (1600, 768, 768), (768, 768, 1600), (3072, 768, 1600), (260, 768, 768), (260, 3072, 768)]
 for (M, N, K) in shapes:
     A = torch.randn(M, K, device=dev).bfloat16()
     B = torch.randn(N, K, device=dev).bfloat16()
@@ -25,7 +24,7 @@ for (M, N, K) in shapes:
     if M * N <= 4096 * 4096:
         ref = A.float() @ B.float().t()
     for tile in (1, 2, 3):
-        for split in (1, 2, 4):
+        for split in (1,):
             if split > 1 and (K // 64) < 2 * split:
                 continue
             if split > 1 and M * N > 1600 * 3072:
