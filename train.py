@@ -1,0 +1,76 @@
+"""Training entry point with the reference's command line (train.py:52-190).  With pytorch_lightning present the
+run goes through Lightning's Trainer exactly as the reference configures it (train.py:17-42: SyncBatchNorm, DDP,
+gradient clip 10, top-10 + last checkpoints); otherwise -- as in this image -- it is handed to the native
+one-process-per-GPU driver ``auto_avsr_amd.train_native`` (torch.distributed over RCCL)."""
+import os
+from argparse import ArgumentParser
+
+
+def parse_args(argv=None):
+    p = ArgumentParser()
+    p.add_argument("--exp-dir", default="./exp", type=str, help="directory for checkpoints and logs")
+    p.add_argument("--exp-name", default="run", type=str)
+    p.add_argument("--group-name", default=None, type=str)
+    p.add_argument("--modality", default="video", type=str, choices=["audio", "video"])
+    p.add_argument("--root-dir", default=None, type=str)
+    p.add_argument("--train-file", default=None, type=str)
+    p.add_argument("--val-file", default="lrs3_test_transcript_lengths_seg16s.csv", type=str)
+    p.add_argument("--test-file", default="lrs3_test_transcript_lengths_seg16s.csv", type=str)
+    p.add_argument("--num-nodes", default=4, type=int)
+    p.add_argument("--gpus", default=8, type=int)
+    p.add_argument("--pretrained-model-path", default=None, type=str)
+    p.add_argument("--transfer-frontend", action="store_true")
+    p.add_argument("--transfer-encoder", action="store_true")
+    p.add_argument("--warmup-epochs", default=5, type=int)
+    p.add_argument("--max-epochs", default=75, type=int)
+    p.add_argument("--max-frames", default=1600, type=int)
+    p.add_argument("--lr", default=1e-3, type=float)
+    p.add_argument("--weight-decay", default=0.03, type=float)
+    p.add_argument("--ctc-weight", default=0.1, type=float)
+    p.add_argument("--train-num-buckets", default=400, type=int)
+    p.add_argument("--ckpt-path", default=None, type=str)
+    p.add_argument("--slurm-job-id", default=0, type=float)
+    p.add_argument("--debug", action="store_true")
+    # native-driver extras (not in the reference)
+    p.add_argument("--synthetic", action="store_true", help="train on the synthetic LRS3-shaped workload")
+    p.add_argument("--steps", default=None, type=int, help="stop after this many optimizer steps")
+    return p.parse_args(argv)
+
+
+def get_trainer(args):
+    from pytorch_lightning import Trainer, seed_everything
+    from pytorch_lightning.callbacks import LearningRateMonitor, ModelCheckpoint
+    from pytorch_lightning.strategies import DDPStrategy
+
+    seed_everything(42, workers=True)
+    ckpt = ModelCheckpoint(dirpath=os.path.join(args.exp_dir, args.exp_name) if args.exp_dir else None,
+                           monitor="monitoring_step", mode="max", save_last=True, filename="{epoch}", save_top_k=10)
+    return Trainer(sync_batchnorm=True, default_root_dir=args.exp_dir, max_epochs=args.max_epochs,
+                   num_nodes=args.num_nodes, devices=args.gpus, accelerator="gpu",
+                   strategy=DDPStrategy(find_unused_parameters=False),
+                   callbacks=[ckpt, LearningRateMonitor(logging_interval="step")],
+                   reload_dataloaders_every_n_epochs=1, gradient_clip_val=10.0)
+
+
+def cli_main(argv=None):
+    args = parse_args(argv)
+    args.slurm_job_id = os.environ.get("SLURM_JOB_ID", args.slurm_job_id)  # optional here (reference: required)
+    from lightning import HAVE_LIGHTNING, ModelModule
+
+    if HAVE_LIGHTNING and not args.synthetic:
+        from average_checkpoints import ensemble
+        from datamodule.data_module import DataModule  # needs the reference's data stack
+
+        module = ModelModule(args)
+        trainer = get_trainer(args)
+        trainer.fit(model=module, datamodule=DataModule(args, train_num_buckets=args.train_num_buckets),
+                    ckpt_path=args.ckpt_path)
+        ensemble(args)
+        return
+    from auto_avsr_amd.train_native import run
+
+    run(args)
+
+
+if __name__ == "__main__":
+    cli_main()
