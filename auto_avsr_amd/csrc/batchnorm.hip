@@ -111,20 +111,23 @@ __global__ __launch_bounds__(BN_THREADS) void bn_colreduce_kernel(
 }
 
 // dst[base + j][c] = sum_p part[p][j][c], j = 0,1 ; MODE 0 also records the shift row x[0, c].
-// block = 64 consecutive columns x 4 partial lanes; partials strided over the lanes, combined in LDS.
+// block = 16 consecutive columns x 16 partial lanes (short dependent chains), combined in LDS.
 template <class T>
 __global__ __launch_bounds__(256) void bn_partial_sum_kernel(const float* __restrict__ part, int nparts, int C,
                                                              float* __restrict__ dst, int base, const T* __restrict__ x0) {
-    __shared__ float red[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + tx;  // over 2*C
+    __shared__ float red[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + tx;  // over 2*C
     float s = 0.f;
     if (i < 2 * C)
-        for (int p = ty; p < nparts; p += 4) s += part[(long)p * 2 * C + i];
+        for (int p = ty; p < nparts; p += 16) s += part[(long)p * 2 * C + i];
     red[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && i < 2 * C) {
-        dst[(long)base * C + i] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; q++) t += red[q][tx];
+        dst[(long)base * C + i] = t;
         if (x0 && i < C) dst[i] = Elem<T>::ld(x0 + i);
     }
 }
@@ -257,7 +260,7 @@ extern "C" int avsr_bn_stats(const void* x, int dtype, float* stats, float* work
     const int gx = (cv + CL - 1) / CL;
     const int parts = bn_parts(rows, rpb, gx);
     dim3 grid(gx, parts), block(BN_THREADS);
-    dim3 g2((2 * C + 63) / 64);
+    dim3 g2((2 * C + 15) / 16);
     if (dtype == 0) {
         AVSR_LAUNCH((bn_colreduce_kernel<float, 0>), grid, block, 0, stream, (const float*)x, (const float*)nullptr,
                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
@@ -318,7 +321,7 @@ extern "C" int avsr_bn_bwd_reduce(const void* x, const void* dy, const void* add
     const int gx = (cv + CL - 1) / CL;
     const int parts = bn_parts(rows, rpb, gx);
     dim3 grid(gx, parts), block(BN_THREADS);
-    dim3 g2((2 * C + 63) / 64);
+    dim3 g2((2 * C + 15) / 16);
     if (dtype == 0)
         AVSR_LAUNCH((bn_colreduce_kernel<float, 1>), grid, block, 0, stream, (const float*)x, (const float*)dy,
                     (const float*)add, mean, invstd, gamma, beta, workspace, (long)rows, C, CL, rpb, act);

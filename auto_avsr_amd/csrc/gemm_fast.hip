@@ -132,9 +132,14 @@ struct FastKernel {
         for (int t = 0; t < nt; t++) {
             // retire tile t: loads of at most STAGES-2 later tiles may stay in flight
             const int later = min(STAGES - 2, nt - 1 - t);
-            if (later >= 2) wait_vmcnt<2 * LPT>();
-            else if (later == 1) wait_vmcnt<LPT>();
-            else wait_vmcnt<0>();
+            switch (later) {  // wave-uniform; counts are immediates
+                case 0: wait_vmcnt<0>(); break;
+                case 1: wait_vmcnt<LPT>(); break;
+                case 2: wait_vmcnt<2 * LPT>(); break;
+                case 3: wait_vmcnt<3 * LPT>(); break;
+                case 4: wait_vmcnt<4 * LPT>(); break;
+                default: wait_vmcnt<5 * LPT>(); break;
+            }
             block_barrier_raw();  // tile t is in LDS for every wave; everyone is done reading tile t-1's buffer
             if (t + STAGES - 1 < nt)
                 issue(A, B, p.lda, p.ldb, m0, n0, p.M, p.N, kbeg + (t + STAGES - 1) * BK,
@@ -213,7 +218,9 @@ extern "C" int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
     }
     if (tile == 3) launch_fast<128, 128, 3>(p, split_k, stream);
     else if (tile == 2) launch_fast<128, 64, 3>(p, split_k, stream);
-    else launch_fast<64, 64, 3>(p, split_k, stream);  // 3 stages = 48 KiB: 3 blocks/CU (measured > 4 stages, 2 blocks/CU)
+    // 3 stages = 48 KiB -> 3 blocks/CU.  Measured: deeper rings (4-6 stages) are slower -- the LDS-DMA path wants more
+    // co-resident waves issuing, not more bytes in flight per wave.
+    else launch_fast<64, 64, 3>(p, split_k, stream);
     AVSR_CHECK_LAUNCH("gemm_bf16_nt");
     return 0;
 }
@@ -369,5 +376,72 @@ extern "C" int avsr_cast_transpose_colsum(const void* src, int src_dtype, int64_
         AVSR_LAUNCH((transpose_cast_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)src, (long)ld_src, (bf16_t*)dst, (bf16_t*)dstT,
                     (long)ld_dstT, colsum, R, C, alpha, alpha_dev, drop_p, seed, seed_dev);
     AVSR_CHECK_LAUNCH("cast_transpose_colsum");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Multi-tensor weight preparation: ONE launch casts every registered f32 weight [R][C] to its bf16 copy ([R][C]) and/or
+// its transposed bf16 copy ([C][ldT], zero tail) -- what the optimizer step would otherwise trigger as ~300 tiny
+// launches per training step.  The table lives in device memory (addresses of parameters are stable).
+struct AvsrCastEntry {
+    const float* src;
+    bf16_t* dst;   // may be null
+    bf16_t* dstT;  // may be null
+    int R, C, ldT, blk0, tiles_c, pad0, pad1, pad2;
+};
+
+namespace {
+__global__ __launch_bounds__(256) void multi_cast_transpose_kernel(const AvsrCastEntry* __restrict__ table, int n) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64 * 72];
+    // binary search: last entry with blk0 <= blockIdx.x
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const AvsrCastEntry e = table[lo];
+    const int local = blockIdx.x - e.blk0;
+    const int r0 = (local / e.tiles_c) * 64, c0 = (local % e.tiles_c) * 64;
+    const bool vec_ok = (e.C % 8 == 0);
+    const int cc = (threadIdx.x & 7) * 8;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int r = (threadIdx.x >> 3) + 32 * half;
+        const int gr = r0 + r, gc = c0 + cc;
+        float v[8];
+        if (gr < e.R && vec_ok && gc + 8 <= e.C) {
+            load8(e.src + (long)gr * e.C + gc, v);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = (gr < e.R && gc + k < e.C) ? e.src[(long)gr * e.C + gc + k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) tile[(cc + k) * 72 + r] = f2bf(v[k]);
+        if (e.dst && gr < e.R) {
+            if (vec_ok && gc + 8 <= e.C) store8(e.dst + (long)gr * e.C + gc, v);
+            else
+                for (int k = 0; k < 8; k++)
+                    if (gc + k < e.C) e.dst[(long)gr * e.C + gc + k] = f2bf(v[k]);
+        }
+    }
+    __syncthreads();
+    if (e.dstT) {
+        for (int id = threadIdx.x; id < 64 * 8; id += 256) {
+            const int c = id >> 3, rr = (id & 7) * 8;
+            const int gc = c0 + c, gr = r0 + rr;
+            if (gc < e.C && gr < e.ldT)
+                *reinterpret_cast<bf16x8*>(e.dstT + (long)gc * e.ldT + gr) = *reinterpret_cast<const bf16x8*>(tile + c * 72 + rr);
+        }
+    }
+}
+}  // namespace
+
+// table: n entries of 64 bytes {src, dst, dstT, R, C, ldT, blk0, tiles_c, 0, 0, 0}; blk0 = running sum of
+// ceil(max(R, ldT)/64) * ceil(C/64); total_blocks = the final sum
+extern "C" int avsr_multi_cast_transpose(const void* table, int n, int total_blocks, hipStream_t stream) {
+    if (n <= 0 || total_blocks <= 0) return 0;
+    AVSR_LAUNCH(multi_cast_transpose_kernel, dim3(total_blocks), dim3(256), 0, stream,
+                reinterpret_cast<const AvsrCastEntry*>(table), n);
+    AVSR_CHECK_LAUNCH("multi_cast_transpose");
     return 0;
 }

@@ -82,11 +82,42 @@ def _rows(x):
 # (csrc/gemm_fast.hip).  Weights therefore need a bf16 copy ([out][in], Linear forward) and a transposed bf16 copy
 # ([in][out_padded_to_64], data gradient).  Copies are cached per parameter version: an optimizer step bumps
 # `_version`, so they are rebuilt exactly once per training step (bench.py invalidates explicitly).
-_wcache = {}
+_wcache = {}   # (data_ptr, transposed, shape) -> [version, bf16 copy, source weight]
+_wtable = {"n": 0, "dev": None, "blocks": 0, "built_for": -1}
 
 
 def invalidate_weight_cache():
     _wcache.clear()
+    _wtable.update(n=0, dev=None, blocks=0, built_for=-1)
+
+
+def refresh_weight_cache():
+    """Rebuild every registered bf16 weight copy in place with ONE multi-tensor launch (what a training step needs
+    after the optimizer changed the weights).  Falls back to lazy per-weight casts until weights are registered."""
+    if not _wcache:
+        return
+    if _wtable["built_for"] != len(_wcache):
+        import struct
+
+        groups = {}
+        for (ptr, transposed, shape), ent in _wcache.items():
+            g = groups.setdefault((ptr, shape), [ent[2], None, None])
+            g[2 if transposed else 1] = ent[1]
+        blob, blk = b"", 0
+        for (ptr, shape), (w, dst, dstT) in groups.items():
+            R, C = shape
+            ldT = dstT.shape[1] if dstT is not None else 0
+            tiles_c = (C + 63) // 64
+            tiles_r = (max(R, ldT) + 63) // 64
+            blob += struct.pack("<QQQiiiiiiii", w.data_ptr(), dst.data_ptr() if dst is not None else 0,
+                                dstT.data_ptr() if dstT is not None else 0, R, C, ldT, blk, tiles_c, 0, 0, 0)
+            blk += tiles_r * tiles_c
+        dev = next(iter(groups.values()))[0].device
+        host = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+        _wtable.update(n=len(groups), dev=host.to(dev), blocks=blk, built_for=len(_wcache))
+    ops.multi_cast_transpose(_wtable["dev"], _wtable["n"], _wtable["blocks"])
+    for ent in _wcache.values():
+        ent[0] = ent[2]._version
 
 
 def _w_bf16(w2d, transposed):
@@ -95,11 +126,18 @@ def _w_bf16(w2d, transposed):
     ent = _wcache.get(key)
     if ent is not None and ent[0] == ver:
         return ent[1]
+    if ent is not None:  # stale copy: refresh in place (keeps addresses stable for captured graphs)
+        if transposed:
+            ops.transpose_cast_into(w2d, ent[1])
+        else:
+            ops.cast_into(w2d, ent[1])
+        ent[0] = ver
+        return ent[1]
     if transposed:
         t = ops.transpose_cast(w2d, w2d.shape[0], w2d.shape[1])  # [in][out -> 64-padded], zero tail
     else:
         t = ops.scale_dropout(w2d.contiguous(), torch.bfloat16)
-    _wcache[key] = (ver, t)
+    _wcache[key] = [ver, t, w2d]
     return t
 
 

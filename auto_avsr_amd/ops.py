@@ -436,3 +436,17 @@ def cast_transpose_colsum(src, R, Ccols, *, ld_src=None, want_dst=False, want_T=
     call("avsr_cast_transpose_colsum", _ptr(src), dt(src), ld_src or Ccols, _ptr(dst), _ptr(dstT), ldd, _ptr(colsum), R,
          Ccols, alpha, _ptr(alpha_dev), drop_p, seed, _ptr(seed_dev), _stream(src))
     return dst, dstT
+
+
+def transpose_cast_into(src, dst):
+    R, Ccols = src.shape
+    call("avsr_transpose_cast", _ptr(src), dt(src), Ccols, _ptr(dst), dst.shape[1], R, Ccols, _stream(src))
+
+
+def cast_into(src, dst):
+    call("avsr_scale_dropout", _ptr(src), dt(src), _ptr(dst), dt(dst), src.numel(), 1.0, None, 0.0, 0, None, None, 0,
+         _stream(src))
+
+
+def multi_cast_transpose(table_dev, n, blocks):
+    call("avsr_multi_cast_transpose", _ptr(table_dev), n, blocks, _stream(table_dev))

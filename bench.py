@@ -119,7 +119,7 @@ def main():
 
     def eager_step(x, lens, y):
         seed_dev.add_(1)
-        AF.invalidate_weight_cache()  # an optimizer step would change the weights: pay the bf16 re-casts every step
+        AF.refresh_weight_cache()  # an optimizer step would change the weights: pay the bf16 re-casts every step
         loss = hot(x, lens, y)
         loss.backward()
         return loss
@@ -141,11 +141,10 @@ def main():
                 with torch.cuda.graph(g):
                     eager_step(x, lens, y)
                 graphs[key] = g
-                AF.invalidate_weight_cache()
             graphs[key].replay()
             return None
         seed_dev.add_(1)
-        AF.invalidate_weight_cache()  # an optimizer step would change the weights: pay the bf16 re-casts every step
+        AF.refresh_weight_cache()  # an optimizer step would change the weights: pay the bf16 re-casts every step
         loss = hot(x, lens, y)
         if world > 1:
             # loss rescale of lightning.py:88-90: loss *= world / sum of batch sizes (all-gather of B)

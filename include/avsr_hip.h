@@ -224,6 +224,10 @@ int avsr_cast_transpose_colsum(const void* src, int src_dtype, int64_t ld_src, v
                                float* colsum, int R, int C, float alpha, const float* alpha_dev, float drop_p,
                                uint64_t seed, const uint64_t* seed_dev, avsr_stream_t stream);
 
+/* one launch: for each of n table entries (64 bytes: {const float* src; bf16* dst; bf16* dstT; int R, C, ldT, blk0,
+ * tiles_c, 0, 0, 0}) write the bf16 copy dst[R][C] and/or the transposed copy dstT[C][ldT] (zero tail) of src */
+int avsr_multi_cast_transpose(const void* table, int n, int total_blocks, avsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -133,3 +133,31 @@ def test_e2e_small_bf16_mode(dev, modality):
         if b.norm() > 1e-4 * max(1.0, float(osd[k].double().norm())):
             cos.append((float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)), k))
     assert min(cos)[0] > 0.9, sorted(cos)[:5]
+
+
+def test_weight_cache_refresh(dev):
+    """bf16 weight copies: lazy build, in-place refresh after an optimizer-style update, multi-tensor refresh."""
+    torch.manual_seed(3)
+    AF.invalidate_weight_cache()
+    lin1, lin2 = torch.nn.Linear(64, 72).to(dev), torch.nn.Linear(128, 200).to(dev)
+    x1, x2 = torch.randn(5, 64, device=dev).bfloat16(), torch.randn(7, 128, device=dev).bfloat16()
+
+    def run():
+        y1 = AF.linear(x1, lin1.weight, lin1.bias, out_dtype=torch.float32)
+        y2 = AF.linear(x2.requires_grad_(), lin2.weight, lin2.bias, out_dtype=torch.float32)
+        y2.sum().backward()  # registers the transposed copy of lin2.weight (data gradient)
+        return y1, y2
+
+    y1, y2 = run()
+    with torch.no_grad():
+        lin1.weight.mul_(2.0)
+        lin2.weight.add_(1.0)
+    AF.refresh_weight_cache()  # one launch for all registered copies
+    x2.grad = None
+    z1, z2 = run()
+    ref1 = x1.float().cpu() @ lin1.weight.detach().cpu().bfloat16().float().t() + lin1.bias.detach().cpu()
+    ref2 = x2.detach().float().cpu() @ lin2.weight.detach().cpu().bfloat16().float().t() + lin2.bias.detach().cpu()
+    assert (z1.cpu() - ref1).abs().max() < 1e-3 and (z2.detach().cpu() - ref2).abs().max() < 1e-3
+    gx = lin2.weight.detach().cpu().bfloat16().float().sum(0)
+    assert (x2.grad.float().cpu() - gx).abs().max() < 0.02 * gx.abs().max()
+    AF.invalidate_weight_cache()
