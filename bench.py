@@ -137,6 +137,8 @@ def main():
                     eager_step(x, lens, y)
                     model.zero_grad(set_to_none=True)
                 torch.cuda.current_stream().wait_stream(side)
+                AF.refresh_weight_cache()  # builds the multi-tensor cast table (H2D copy) outside the capture
+                torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     eager_step(x, lens, y)
