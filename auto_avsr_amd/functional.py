@@ -1091,8 +1091,13 @@ class StemFn(torch.autograd.Function):
         x = x.contiguous()
         taps = KT * KH * KW
         ldw = padded_cols(taps)
-        wp = ops.conv_weight_permute(w, T, ld_out=ldw)
-        c0 = ops.conv_stem_fwd(x, wp, ldw, T, B, Tn, H, W, Cout, KT, KH, KW, stride, pt, ph, pw, pr)
+        dedicated = (not pr) and (KT, KH, KW, stride, pt, ph, pw, Cout) == (5, 7, 7, 2, 2, 3, 3, 64) \
+            and W % 4 == 0 and W <= 96 and (W - 1) // 2 + 1 <= 64
+        if dedicated:  # csrc/stem.hip: input rows staged once in LDS
+            c0 = ops.stem357_fwd(x, w, B, Tn, H, W)
+        else:
+            wp = ops.conv_weight_permute(w, T, ld_out=ldw)
+            c0 = ops.conv_stem_fwd(x, wp, ldw, T, B, Tn, H, W, Cout, KT, KH, KW, stride, pt, ph, pw, pr)
         OH, OW = c0.shape[1], c0.shape[2]
         rows = B * Tn * OH * OW
         bn = (g, b) + bn_rest
@@ -1104,20 +1109,23 @@ class StemFn(torch.autograd.Function):
         else:
             out = a0
         ctx.save_for_backward(x, c0, idx, g, b, m0, i0, n0)
-        ctx.meta = (geom, pool, training, bn_rest, (OH, OW), w.shape)
+        ctx.meta = (geom, pool, training, bn_rest, (OH, OW), w.shape, dedicated)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, c0, idx, g, b, m0, i0, n0 = ctx.saved_tensors
-        geom, pool, training, bn_rest, (OH, OW), wshape = ctx.meta
+        geom, pool, training, bn_rest, (OH, OW), wshape, dedicated = ctx.meta
         B, Tn, H, W, KT, KH, KW, stride, pt, ph, pw = geom
         Cout = wshape[0]
         rows = B * Tn * OH * OW
         dout = dout.contiguous()
         da0 = ops.maxpool2d_bwd(idx, dout, B * Tn, OH, OW, Cout, 3, 2, 1) if pool else dout
         dc0, _, dg, db = _bn_bwd(c0, da0, None, m0, i0, (g, b) + bn_rest, n0, rows, Cout, 1, False, training)
-        dw = ops.conv_stem_wgrad(dc0, x, B, Tn, H, W, Cout, KT, KH, KW, stride, pt, ph, pw, _state["precise"])
+        if dedicated:
+            dw = ops.stem357_wgrad(dc0, x, B, Tn, H, W)
+        else:
+            dw = ops.conv_stem_wgrad(dc0, x, B, Tn, H, W, Cout, KT, KH, KW, stride, pt, ph, pw, _state["precise"])
         return None, dw.view(wshape), dg, db, None, None, None, None
 
 

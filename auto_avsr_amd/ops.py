@@ -450,3 +450,21 @@ def cast_into(src, dst):
 
 def multi_cast_transpose(table_dev, n, blocks):
     call("avsr_multi_cast_transpose", _ptr(table_dev), n, blocks, _stream(table_dev))
+
+
+def stem357_fwd(x, w, B, T, H, W):
+    OH, OW = conv_out(H, 7, 2, 3), conv_out(W, 7, 2, 3)
+    y = torch.empty(B * T, OH, OW, 64, dtype=torch.bfloat16, device=x.device)
+    ws = torch.empty(call("avsr_stem357_workspace_bytes") // 4 + 16, dtype=torch.float32, device=x.device)
+    call("avsr_stem357_fwd", _ptr(x), _ptr(w), _ptr(y), _ptr(ws), B, T, H, W, _stream(x),
+         flops=2.0 * B * T * OH * OW * 64 * 245)
+    return y
+
+
+def stem357_wgrad(dy, x, B, T, H, W):
+    dw = torch.zeros(64, 1, 5, 7, 7, dtype=torch.float32, device=x.device)
+    ws = torch.empty(call("avsr_stem357_workspace_bytes") // 4 + 16, dtype=torch.float32, device=x.device)
+    OH, OW = conv_out(H, 7, 2, 3), conv_out(W, 7, 2, 3)
+    call("avsr_stem357_wgrad", _ptr(dy), _ptr(x), _ptr(dw), _ptr(ws), B, T, H, W, _stream(x),
+         flops=2.0 * B * T * OH * OW * 64 * 245)
+    return dw

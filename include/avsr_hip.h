@@ -228,6 +228,14 @@ int avsr_cast_transpose_colsum(const void* src, int src_dtype, int64_t ld_src, v
  * tiles_c, 0, 0, 0}) write the bf16 copy dst[R][C] and/or the transposed copy dstT[C][ldT] (zero tail) of src */
 int avsr_multi_cast_transpose(const void* table, int n, int total_blocks, avsr_stream_t stream);
 
+/* dedicated bf16 kernels for the Conv3d(1,64,(5,7,7),s(1,2,2),p(2,3,3)) visual stem (resnet.py:204-211): the 35
+ * (kt,kh) input rows of an output row are staged once in LDS.  workspace: avsr_stem357_workspace_bytes() bytes */
+int64_t avsr_stem357_workspace_bytes(void);
+int avsr_stem357_fwd(const float* x, const float* w, void* y, void* workspace, int B, int T, int H, int W,
+                     avsr_stream_t stream);
+int avsr_stem357_wgrad(const void* dy, const float* x, float* dw, void* workspace, int B, int T, int H, int W,
+                       avsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,3 +107,21 @@ def test_pooling(dev):
     assert (a.cpu() - z.view(4, 9, 24).mean(1)).abs().max() < 1e-6
     dz = ops.avgpool_bwd(a, torch.float32, 4, 9, 24)
     assert (dz.cpu() - (a.cpu() / 9).repeat_interleave(9, 0)).abs().max() < 1e-6
+
+
+def test_stem357_dedicated(dev):
+    """Dedicated bf16 stem kernels (LDS-staged input rows) vs torch conv3d on bf16-rounded operands."""
+    torch.manual_seed(6)
+    B, T, H, W = 2, 4, 20, 24
+    x = torch.randn(B, T, H, W)
+    w = (torch.randn(64, 1, 5, 7, 7) / 245 ** 0.5)
+    xq, wq = x.bfloat16().float(), w.bfloat16().float().requires_grad_()
+    y_ref = F.conv3d(xq.unsqueeze(1), wq, stride=(1, 2, 2), padding=(2, 3, 3))
+    dy = torch.randn_like(y_ref).bfloat16().float()
+    y_ref.backward(dy)
+    y = ops.stem357_fwd(x.to(dev), w.to(dev), B, T, H, W)
+    ref = y_ref.detach().permute(0, 2, 3, 4, 1).reshape(B * T, y_ref.shape[3], y_ref.shape[4], 64)
+    assert (y.float().cpu() - ref).abs().max() < 2e-2 * max(1.0, ref.abs().max().item())
+    dyd = dy.permute(0, 2, 3, 4, 1).reshape(ref.shape).contiguous().bfloat16().to(dev)
+    dw = ops.stem357_wgrad(dyd, x.to(dev), B, T, H, W)
+    assert (dw.cpu() - wq.grad).abs().max() < 2e-2 * max(1.0, wq.grad.abs().max().item())
