@@ -1,0 +1,163 @@
+// gemm_tn_fast.hip -- bf16 weight-gradient contractions without transposed copies:
+//     C[M][N] (+)= sum_k A[k][m] * B[k][n]        A: [K][lda], B: [K][ldb], both bf16, m / n contiguous
+// (dW = dY^T x for every Linear / pointwise conv, and -- with B gathered through the im2col index map -- the
+// convolution weight gradients).  The contraction index is the SLOW dimension of both operands, so tiles are staged
+// k-major in LDS exactly as they lie in HBM (LDS-DMA, 128-byte rows, 3-stage ring, counted vmcnt as in
+// gemm_fast.hip) and the MFMA fragments are fetched with the CDNA4 LDS transpose read ds_read_b64_tr_b16.
+// Rows k >= K and columns beyond M / N are redirected to a caller-provided page of zeros; split-K over blockIdx.z
+// with f32 atomics.
+#include "gemm_core.h"
+#include "avsr_hip.h"
+
+namespace {
+
+using avsr_gemm_impl::Params;
+
+template <int STAGES, int CV>
+struct TnKernel {
+    static constexpr int BM = 64, BN = 64, BK = 64;
+    static constexpr int OP_BYTES = BK * 128;          // one operand stage: 64 k-rows x 64 columns bf16
+    static constexpr int STAGE_BYTES = 2 * OP_BYTES;
+    static constexpr int LPT = 4;                      // LDS-DMA ops per thread per tile (2 for A, 2 for B)
+    static constexpr size_t LDS_BYTES = (size_t)STAGES * STAGE_BYTES;
+
+    static AVSR_DEV void issue(const Params& p, const bf16_t* A, const bf16_t* B, int m0, int n0, int k0, int kend,
+                               char* stage, int wave, int lane) {
+        const int ksub = lane >> 3, chunk = (lane & 7) * 8;
+        const bf16_t* zero = reinterpret_cast<const bf16_t*>(p.gate);
+        int kh = 0, kw = 0, cbase = 0;
+        if (CV == 3) {  // the 64-column tile lies inside one filter tap (Cin % 64 == 0): wave-uniform decode
+            const int tap = n0 / p.cC;
+            cbase = n0 - tap * p.cC;
+            kh = tap / p.cKW;
+            kw = tap - kh * p.cKW;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int kr = (wave * 2 + i) * 8 + ksub;  // k-row inside the tile
+            const int k = k0 + kr;
+            const bool kin = k < kend;
+            const bf16_t* sa = (kin && m0 + chunk < p.M) ? A + (size_t)k * p.lda + m0 + chunk : zero;
+            glds16(sa, stage + (wave * 2 + i) * 1024);
+            const bf16_t* sb = zero;
+            if (CV == 0) {
+                if (kin && n0 + chunk < p.N) sb = B + (size_t)k * p.ldb + n0 + chunk;
+            } else if (kin) {
+                const int pix = p.cOH * p.cOW;
+                const int n = k / pix, r = k - n * pix;
+                const int oh = r / p.cOW, ow = r - oh * p.cOW;
+                const int ih = oh * p.cS + kh - p.cPH, iw = ow * p.cS + kw - p.cPW;
+                if (ih >= 0 && ih < p.cH && iw >= 0 && iw < p.cW)
+                    sb = B + (((size_t)n * p.cH + ih) * p.cW + iw) * p.cC + cbase + chunk;
+            }
+            glds16(sb, stage + OP_BYTES + (wave * 2 + i) * 1024);
+        }
+    }
+
+    // 32 (m or n) x 16 (k) MFMA fragment of the k-major tile at `base`: columns c0..c0+31, k-step ks
+    static AVSR_DEV bf16x8 frag(const char* base, int c0, int ks, int lane) {
+        const int g = lane >> 4, i = lane & 15;
+        const bf16_t* t = reinterpret_cast<const bf16_t*>(base);
+        const int row = ks * 16 + 8 * (g >> 1) + (i >> 2);
+        const int col = c0 + 16 * (g & 1) + 4 * (i & 3);
+        const bf16x4 lo = lds_tr16(t + row * 64 + col);
+        const bf16x4 hi = lds_tr16(t + (row + 4) * 64 + col);
+        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+
+    static AVSR_DEV void run(const Params& p, char* smem) {
+        const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+        const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int wm = wave >> 1, wn = wave & 1;
+        const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+        const int zs = blockIdx.z;
+        const int kbeg = zs * p.k_chunk;
+        const int kend = min(p.K, kbeg + p.k_chunk);
+        const int nt = (kend - kbeg + BK - 1) / BK;
+        f32x16 acc[1][1];
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[0][0][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; s++)
+            if (s < nt) issue(p, A, B, m0, n0, kbeg + s * BK, kend, smem + s * STAGE_BYTES, wave, lane);
+        for (int t = 0; t < nt; t++) {
+            const int later = min(STAGES - 2, nt - 1 - t);
+            if (later >= 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+            block_barrier_raw();
+            if (t + STAGES - 1 < nt)
+                issue(p, A, B, m0, n0, kbeg + (t + STAGES - 1) * BK, kend, smem + ((t + STAGES - 1) % STAGES) * STAGE_BYTES,
+                      wave, lane);
+            const char* As = smem + (t % STAGES) * STAGE_BYTES;
+            const char* Bs = As + OP_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ks++)
+                acc[0][0] = mfma32(frag(As, wm * 32, ks, lane), frag(Bs, wn * 32, ks, lane), acc[0][0]);
+        }
+        Params q = p;
+        q.gate = nullptr;  // the field carries the zero page
+        avsr_gemm_impl::epilogue<1, 1>(acc, q, m0 + wm * 32, n0 + wn * 32, lane, zs, 0);
+    }
+};
+
+template <int STAGES, int CV>
+__global__ __launch_bounds__(256) void gemm_tn_fast_kernel(Params p) {
+    AVSR_DYN_SMEM(smem);
+    TnKernel<STAGES, CV>::run(p, smem);
+}
+
+template <int CV>
+void launch_tn(Params& p, int split_k, hipStream_t stream) {
+    if (split_k < 1) split_k = 1;
+    int kc = (p.K + split_k - 1) / split_k;
+    kc = ((kc + 63) / 64) * 64;
+    split_k = (p.K + kc - 1) / kc;
+    p.k_chunk = kc;
+    dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, split_k), block(256);
+    AVSR_LAUNCH((gemm_tn_fast_kernel<3, CV>), grid, block, (TnKernel<3, CV>::LDS_BYTES), stream, p);
+}
+
+}  // namespace
+
+// C[M][N] (f32; accumulate: atomicAdd into, else overwrite -- split_k > 1 needs accumulate) = sum_k A[k][m] B[k][n]
+extern "C" int avsr_gemm_bf16_tn(const void* A, int lda, const void* B, int ldb, int M, int N, int K, float* C, int ldc,
+                                 int accumulate, int split_k, const void* zero_page, hipStream_t stream) {
+    AVSR_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && M % 8 == 0 && N % 8 == 0, "gemm_bf16_tn: M, N, lda, ldb must be multiples of 8");
+    AVSR_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "gemm_bf16_tn: operands must be 16-byte aligned");
+    AVSR_REQUIRE(zero_page != nullptr, "gemm_bf16_tn: zero page required");
+    AVSR_REQUIRE(!(split_k > 1 && !accumulate), "gemm_bf16_tn: split-K needs accumulate=1");
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    Params p{};
+    p.A = A; p.B = B; p.lda = lda; p.ldb = ldb; p.M = M; p.N = N; p.K = K;
+    p.alpha = 1.f; p.gate_scale = 1.f; p.gate = zero_page;
+    p.C = C; p.c_dtype = 0; p.ldc = ldc; p.accumulate = accumulate;
+    p.nsplit = 1; p.batch_h = 1; p.nbatch = 1;
+    launch_tn<0>(p, split_k, stream);
+    AVSR_CHECK_LAUNCH("gemm_bf16_tn");
+    return 0;
+}
+
+// dwp[Cout][KH][KW][Cin] (f32, caller zeroes) += dy[N,OH,OW,Cout]^T im2col(x[N,H,W,Cin]); bf16, Cin % 64 == 0
+extern "C" int avsr_conv2d_wgrad_bf16(const void* dy, const void* x, float* dwp, const void* zero_page, int N, int H, int W,
+                                      int Cin, int Cout, int KH, int KW, int stride, int pad_h, int pad_w,
+                                      hipStream_t stream) {
+    AVSR_REQUIRE(Cin % 64 == 0 && Cout % 8 == 0, "conv2d_wgrad_bf16: Cin must be a multiple of 64, Cout of 8");
+    AVSR_REQUIRE(zero_page != nullptr, "conv2d_wgrad_bf16: zero page required");
+    const int OH = (H + 2 * pad_h - KH) / stride + 1, OW = (W + 2 * pad_w - KW) / stride + 1;
+    if (N <= 0) return 0;
+    Params p{};
+    p.A = dy; p.B = x; p.lda = Cout; p.ldb = Cin;
+    p.M = Cout; p.N = KH * KW * Cin; p.K = N * OH * OW;
+    p.alpha = 1.f; p.gate_scale = 1.f; p.gate = zero_page;
+    p.C = dwp; p.c_dtype = 0; p.ldc = p.N; p.accumulate = 1;
+    p.nsplit = 1; p.batch_h = 1; p.nbatch = 1;
+    p.cH = H; p.cW = W; p.cC = Cin; p.cOH = OH; p.cOW = OW; p.cKH = KH; p.cKW = KW; p.cS = stride; p.cPH = pad_h; p.cPW = pad_w;
+    p.cT = 1; p.cKT = 1;
+    const long tiles = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+    long split = 1024 / (tiles < 1 ? 1 : tiles);
+    if (split > p.K / 512) split = p.K / 512;
+    if (split < 1) split = 1;
+    launch_tn<3>(p, (int)split, stream);
+    AVSR_CHECK_LAUNCH("conv2d_wgrad_bf16");
+    return 0;
+}

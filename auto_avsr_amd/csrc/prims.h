@@ -121,6 +121,28 @@ template <int N> AVSR_DEV void wait_vmcnt() {
 #endif
 }
 
+// ds_read_b64_tr_b16: LDS transpose read.  Inside each 16-lane group, lane i supplies the address of 4 consecutive
+// bf16 = the piece (row i/4, columns 4*(i%4)..+3) of a 4x16 block; it receives column i of that block (rows 0..3).
+// Verified on gfx950 (tools/probes/tr_probe.hip).  Lets an MFMA fragment (8 consecutive k for one m) be read from a
+// [k][m]-major LDS tile, i.e. from operands stored with the contraction index as the SLOW dimension.
+AVSR_DEV bf16x4 lds_tr16(const bf16_t* p) {
+#ifdef AVSR_EMU
+    bf16x4 mine = *reinterpret_cast<const bf16x4*>(p);
+    size_t stride;
+    const unsigned char* all = emu::wave_gather(&mine, sizeof(mine), &stride);
+    const int l = emu::lane_id(), i = l & 15, g = l >> 4;
+    bf16x4 out;
+    for (int j = 0; j < 4; j++) {
+        bf16x4 src;
+        memcpy(&src, all + (size_t)(16 * g + 4 * j + (i >> 2)) * stride, sizeof(src));
+        out[j] = src[i & 3];
+    }
+    return out;
+#else
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)p);
+#endif
+}
+
 // ---------------------------------------------------------------- math
 AVSR_DEV float avsr_exp(float x) {
 #ifdef AVSR_EMU

@@ -211,9 +211,12 @@ def _prologue(src, rows, n, *, alpha=1.0, drop=(0.0, 0, None), want_dst=True, wa
     db = _zeros(n, src.device) if want_bias else None
     if not _state["precise"]:
         need_dst = want_dst and (src.dtype != torch.bfloat16 or alpha != 1.0 or p > 0 or (ld_src or n) != n)
-        g, gT = ops.cast_transpose_colsum(src, rows, n, ld_src=ld_src, want_dst=need_dst, want_T=True, colsum=db,
-                                          alpha=alpha, drop_p=p, seed=sd, seed_dev=sdev)
-        return (g if need_dst else src), gT, db
+        if need_dst or want_bias:
+            g, _ = ops.cast_transpose_colsum(src, rows, n, ld_src=ld_src, want_dst=need_dst, want_T=False, colsum=db,
+                                             alpha=alpha, drop_p=p, seed=sd, seed_dev=sdev)
+        else:
+            g = None
+        return (g if need_dst else src), None, db
     if src.dtype != act_dtype() or alpha != 1.0 or p > 0:
         g = ops.scale_dropout(src, act_dtype(), alpha=alpha, drop_p=p, seed=sd, seed_dev=sdev)
     else:
@@ -227,20 +230,19 @@ def _wgrad(dy, x, rows, n_out, n_in, lda=None, ldb=None, xT=None, dyT=None):
     """dW[n_out, n_in] = dy[rows, n_out]^T x[rows, n_in] (f32).  Small outputs are split along the token
     dimension so that the launch still fills the 256 CUs."""
     tiles = ((n_out + 63) // 64) * ((n_in + 63) // 64)
-    if (not _state["precise"]) and (dyT is not None or dy.dtype == torch.bfloat16) and \
-            (xT is not None or x.dtype == torch.bfloat16):
-        if dyT is None:
-            dyT = ops.transpose_cast(dy, rows, n_out, ld_src=lda or n_out)  # [n_out][rows -> 64-padded]
-        if xT is None:
-            xT = ops.transpose_cast(x, rows, n_in, ld_src=ldb or n_in)
-        Kp = dyT.shape[1]
-        split = 1
-        if tiles < 100 and Kp >= 512:
-            split = max(1, min(4, 256 // max(tiles, 1), Kp // 256))
-        dw = _zeros((n_out, n_in), dy.device) if split > 1 else torch.empty(n_out, n_in, dtype=torch.float32, device=dy.device)
-        ops.gemm_bf16_nt(dyT, Kp, xT, Kp, n_out, n_in, Kp, dw, n_in, accumulate=split > 1, split_k=split,
-                         tile=_pick_tile(n_out, n_in))
-        return dw
+    if (not _state["precise"]) and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and n_in % 8 == 0 \
+            and (lda or n_out) % 8 == 0 and (ldb or n_in) % 8 == 0:
+        # csrc/gemm_tn_fast.hip: k-major LDS tiles + ds_read_b64_tr_b16 -- no transposed copies of dY / x
+        m_pad = (n_out + 7) // 8 * 8
+        if m_pad != n_out and (lda or n_out) < m_pad:
+            m_pad = None
+        if m_pad is not None:
+            split = 2 if (tiles < 300 and rows >= 512) else 1
+            alloc = _zeros if split > 1 else (lambda shp, dev: torch.empty(shp, dtype=torch.float32, device=dev))
+            dw = alloc((m_pad, n_in), dy.device)
+            ops.gemm_bf16_tn(dy, lda or n_out, x, ldb or n_in, m_pad, n_in, rows, dw, n_in, accumulate=split > 1,
+                             split_k=split)
+            return dw if m_pad == n_out else dw[:n_out]
     split = 1
     if tiles < 192 and rows >= 512:
         split = max(1, min(8, 256 // max(tiles, 1), rows // 256))
@@ -254,10 +256,9 @@ def _wgrad(dy, x, rows, n_out, n_in, lda=None, ldb=None, xT=None, dyT=None):
 
 
 def _xT(x, rows, n):
-    """Transposed bf16 copy of an activation shared by several weight gradients (None in precise mode)."""
-    if _state["precise"] or x.dtype != torch.bfloat16:
-        return None
-    return ops.transpose_cast(x, rows, n)
+    """(historical) transposed activation copies are no longer needed: the weight-gradient kernel reads the
+    k-major operands directly through LDS transpose reads."""
+    return None
 
 
 def _bgrad(dy, rows, n):

@@ -361,6 +361,10 @@ def conv2d_dgrad(dy, wpd, resid, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, pre
 def conv2d_wgrad(dy, x, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise):
     OH, OW = conv_out(H, KH, stride, ph), conv_out(W, KW, stride, pw)
     dwp = torch.zeros(Cout, KH * KW * Cin, dtype=torch.float32, device=x.device)
+    if not precise and x.dtype == torch.bfloat16 and Cin % 64 == 0 and Cout % 8 == 0:
+        call("avsr_conv2d_wgrad_bf16", _ptr(dy), _ptr(x), _ptr(dwp), _ptr(zero_page(x.device)), N, H, W, Cin, Cout, KH,
+             KW, stride, ph, pw, _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin)
+        return dwp
     call("avsr_conv2d_wgrad", _ptr(dy), _ptr(x), dt(x), _ptr(dwp), N, H, W, Cin, Cout, KH, KW, stride, ph, pw,
          int(precise), _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin)
     return dwp
@@ -468,3 +472,10 @@ def stem357_wgrad(dy, x, B, T, H, W):
     call("avsr_stem357_wgrad", _ptr(dy), _ptr(x), _ptr(dw), _ptr(ws), B, T, H, W, _stream(x),
          flops=2.0 * B * T * OH * OW * 64 * 245)
     return dw
+
+
+def gemm_bf16_tn(A, lda, B, ldb, M, N, K, C, ldc, *, accumulate=False, split_k=1):
+    """C[M,N] (f32) (+)= A[K,M]^T B[K,N], bf16 operands with the contraction index as the slow dimension."""
+    call("avsr_gemm_bf16_tn", _ptr(A), lda, _ptr(B), ldb, M, N, K, _ptr(C), ldc, int(accumulate), split_k,
+         _ptr(zero_page(A.device)), _stream(A), flops=2.0 * M * N * K)
+    return C

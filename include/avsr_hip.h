@@ -236,6 +236,15 @@ int avsr_stem357_fwd(const float* x, const float* w, void* y, void* workspace, i
 int avsr_stem357_wgrad(const void* dy, const float* x, float* dw, void* workspace, int B, int T, int H, int W,
                        avsr_stream_t stream);
 
+/* bf16 weight-gradient contraction without transposed copies (gemm_tn_fast.hip: LDS-DMA k-major tiles +
+ * ds_read_b64_tr_b16): C[M][N] (f32, ldc) (+)= sum_k A[k][m] B[k][n]; A [K][lda], B [K][ldb] bf16 */
+int avsr_gemm_bf16_tn(const void* A, int lda, const void* B, int ldb, int M, int N, int K, float* C, int ldc,
+                      int accumulate, int split_k, const void* zero_page, avsr_stream_t stream);
+/* convolution weight gradient on the same kernel (B = im2col gather); dwp [Cout][KH][KW][Cin] f32, caller zeroes */
+int avsr_conv2d_wgrad_bf16(const void* dy, const void* x, float* dwp, const void* zero_page, int N, int H, int W,
+                           int Cin, int Cout, int KH, int KW, int stride, int pad_h, int pad_w,
+                           avsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

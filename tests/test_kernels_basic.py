@@ -132,3 +132,19 @@ def test_cast_transpose_colsum(dev):
     d2, _ = ops.cast_transpose_colsum(x.to(dev), R, C, want_dst=True, want_T=False, drop_p=0.3, seed=99)
     ref2 = ops.scale_dropout(x.to(dev), torch.bfloat16, drop_p=0.3, seed=99)
     assert (d2.cpu() == ref2.cpu()).all()
+
+
+@pytest.mark.parametrize("shape", [(72, 136, 150), (64, 64, 64), (200, 72, 1000)])
+def test_gemm_bf16_tn_transpose_read(dev, shape):
+    """Weight-gradient kernel: k-major LDS tiles + ds_read_b64_tr_b16 fragments, ragged K / M / N, split-K."""
+    M, N, K = shape
+    torch.manual_seed(M + K)
+    A, B = torch.randn(K, M).bfloat16(), torch.randn(K, N).bfloat16()
+    ref = A.double().t() @ B.double()
+    C = torch.zeros(M, N + 5, device=dev)
+    ops.gemm_bf16_tn(A.to(dev), M, B.to(dev), N, M, N, K, C, N + 5)
+    assert ((C.cpu()[:, :N].double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    assert C.cpu()[:, N:].abs().max() == 0
+    C2 = torch.zeros(M, N, device=dev)
+    ops.gemm_bf16_tn(A.to(dev), M, B.to(dev), N, M, N, K, C2, N, accumulate=True, split_k=3)
+    assert ((C2.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-6
