@@ -31,6 +31,7 @@ struct FastKernel {
     static constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;  // wave-instructions per wave per stage
     static constexpr int LPT = A_LOADS + B_LOADS;               // LDS-DMA ops per thread per tile
     static constexpr size_t LDS_BYTES = (size_t)STAGES * STAGE_BYTES;
+    static_assert(LDS_BYTES >= (size_t)BM * (BN + 4) * 4, "operand ring must be able to hold the epilogue tile");
 
     // per-lane decode of the A rows this lane stages (fixed for the whole k loop)
     struct RowInfo {
@@ -163,9 +164,9 @@ struct FastKernel {
         if (CV != 0) {
             Params q = p;
             q.gate = nullptr;  // in conv mode the field carries the zero page, not an activation gate
-            avsr_gemm_impl::epilogue<TM, TN>(acc, q, m0 + wm * WM, n0 + wn * WN, lane, zs, 0);
+            avsr_gemm_impl::epilogue_lds<BM, BN, TM, TN>(acc, q, m0, n0, wm * WM, wn * WN, zs, 0, smem);
         } else {
-            avsr_gemm_impl::epilogue<TM, TN>(acc, p, m0 + wm * WM, n0 + wn * WN, lane, zs, 0);
+            avsr_gemm_impl::epilogue_lds<BM, BN, TM, TN>(acc, p, m0, n0, wm * WM, wn * WN, zs, 0, smem);
         }
     }
 };

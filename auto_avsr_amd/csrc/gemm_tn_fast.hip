@@ -96,7 +96,7 @@ struct TnKernel {
         }
         Params q = p;
         q.gate = nullptr;  // the field carries the zero page
-        avsr_gemm_impl::epilogue<1, 1>(acc, q, m0 + wm * 32, n0 + wn * 32, lane, zs, 0);
+        avsr_gemm_impl::epilogue_lds<64, 64, 1, 1>(acc, q, m0, n0, wm * 32, wn * 32, zs, 0, smem);
     }
 };
 
