@@ -63,6 +63,11 @@ struct Params {
     int cOH, cOW;         // pixel grid the row index runs over
     int cKH, cKW, cS, cPH, cPW;
     int cT, cKT, cPT;
+    // tuned bf16 kernel (gemm_fast.hip) only: image count, tile order, and the residue classes a strided data
+    // gradient is split into (row grid cls_h x cls_w starting at pixel (cls_y0, cls_x0) with step cS; taps
+    // kh = cls_py + cS*i, kw = cls_px + cS*j; m-tiles [cls_tile0[c], cls_tile0[c+1]))
+    int cN, xcd_order, ncls;
+    int cls_tile0[5], cls_py[4], cls_px[4], cls_y0[4], cls_x0[4], cls_h[4], cls_w[4], cls_nkh[4], cls_nkw[4];
 };
 
 template <class T> struct Raw8;
@@ -165,9 +170,10 @@ AVSR_DEV void epilogue(f32x16 (&acc)[TM][TN], const Params& p, int row0, int col
 // a time -- vector loads of bias / gate / residual, one 16-byte (bf16) or two 16-byte (f32) coalesced stores.
 // Measured on the short-K problems of this model (K = 576..768), the per-element epilogue above was ~40 % of the
 // kernel time; `smem` is the (now idle) operand staging area and must hold BM*(BN+4) floats.
-template <int BM, int BN, int TM, int TN>
+// rowmap (LDS, may be null): output row of every tile row, -1 = none; default is row m0 + r.
+template <int BM, int BN, int TM, int TN, int NTHR = 256>
 AVSR_DEV void epilogue_lds(f32x16 (&acc)[TM][TN], const Params& p, int m0, int n0, int wrow, int wcol, int zs, long c_off,
-                           char* smem) {
+                           char* smem, const int* rowmap = nullptr) {
     constexpr int PITCH = BN + 4;
     float* tile = reinterpret_cast<float*>(smem);
     const int lane = threadIdx.x & 63;
@@ -187,10 +193,10 @@ AVSR_DEV void epilogue_lds(f32x16 (&acc)[TM][TN], const Params& p, int m0, int n
     if (p.accumulate) {
         // split-K / "+=" outputs: one f32 atomic per element with CONSECUTIVE LANES ON CONSECUTIVE COLUMNS, so that a
         // wave's atomic instruction covers whole cache lines (8 columns per lane would scatter it over 16 lines)
-        for (int idx = threadIdx.x; idx < BM * BN; idx += 256) {
+        for (int idx = threadIdx.x; idx < BM * BN; idx += NTHR) {
             const int r = idx / BN, c = idx - r * BN;
-            const int row = m0 + r, col = n0 + c;
-            if (row >= p.M || col >= p.N) continue;
+            const int row = rowmap ? rowmap[r] : m0 + r, col = n0 + c;
+            if (row < 0 || row >= p.M || col >= p.N) continue;
             float v = tile[r * PITCH + c];
             if (p.bias && lead) v += p.bias[col];
             v *= alpha;
@@ -199,10 +205,10 @@ AVSR_DEV void epilogue_lds(f32x16 (&acc)[TM][TN], const Params& p, int m0, int n
         return;
     }
     constexpr int CPR = BN / 8;  // chunks per row
-    for (int id = threadIdx.x; id < BM * CPR; id += 256) {
+    for (int id = threadIdx.x; id < BM * CPR; id += NTHR) {
         const int r = id / CPR, c = (id % CPR) * 8;
-        const int row = m0 + r, col = n0 + c;
-        if (row >= p.M || col >= p.N) continue;
+        const int row = rowmap ? rowmap[r] : m0 + r, col = n0 + c;
+        if (row < 0 || row >= p.M || col >= p.N) continue;
         float v[8];
         {
             const f32x4 a = *reinterpret_cast<const f32x4*>(tile + r * PITCH + c);

@@ -13,6 +13,7 @@
 //    the ds_read_b128 address on the way out -- conflict-free for the 32x32x16 MFMA fragment reads;
 //  * 256 threads = 2x2 waves, each wave a (BM/2)x(BN/2) grid of v_mfma_f32_32x32x16_bf16 accumulators;
 //  * rows beyond M / N are clamped on load (never stored); split-K over blockIdx.z with f32 atomics.
+#include <type_traits>
 #include "gemm_core.h"
 #include "avsr_hip.h"
 
@@ -20,84 +21,128 @@ namespace {
 
 using avsr_gemm_impl::Params;
 
+// run-time tuning knobs (avsr_tune): 0 = conv tile override, 1 = XCD-aware tile order, 2 = ablation (benchmarks only)
+int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
 // CV = 0: plain A[M][K].  CV = 1 / 2: A is the im2col view of a channels-last image tensor (forward / data gradient,
 // see gemm_core.h Params); channels are a multiple of 64, so a 64-wide k-tile lies inside one filter tap and the
-// tap decode is wave-uniform; out-of-image taps read a caller-provided page of zeros.
-template <int BM, int BN, int STAGES, int CV = 0>
+// tap decode is wave-uniform (scalar); out-of-image taps read a caller-provided page of zeros.
+//
+// Gather addressing.  Every A row a lane stages is decoded ONCE per block into (pointer to tap (0,0) of that row,
+// bit mask of the taps that fall inside the image); inside the k loop a load costs one 64-bit add of a scalar tap
+// offset and a select against the zero page.  The data gradient of a strided convolution is split into the s*s
+// residue classes of (ih+ph, iw+pw) mod s: a class only ever touches the taps kh = py (mod s), kw = px (mod s), so
+// each class is a dense implicit GEMM over its own (shorter) tap list and no MFMA is spent on structural zeros.
+//
+// WGM x WGN waves per block (64*WGM*WGN threads), each wave a (BM/WGM) x (BN/WGN) grid of 32x32x16 accumulators.
+// ABL (benchmarks only): 1 = no LDS reads / MFMA, 2 = no operand loads in the steady state.
+template <int BM, int BN, int STAGES, int CV = 0, int WGM = 2, int WGN = 2, int ABL = 0>
 struct FastKernel {
-    static constexpr int BK = 64;
-    static constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    static constexpr int BK = 64, NW = WGM * WGN, NTHR = 64 * NW;
+    static constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
-    static constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;  // wave-instructions per wave per stage
-    static constexpr int LPT = A_LOADS + B_LOADS;               // LDS-DMA ops per thread per tile
-    static constexpr size_t LDS_BYTES = (size_t)STAGES * STAGE_BYTES;
-    static_assert(LDS_BYTES >= (size_t)BM * (BN + 4) * 4, "operand ring must be able to hold the epilogue tile");
+    static constexpr int A_LOADS = BM / (8 * NW), B_LOADS = BN / (8 * NW);  // wave-instructions per wave per stage
+    static constexpr int LPT = A_LOADS + B_LOADS;                           // LDS-DMA ops per thread per tile
+    static constexpr size_t RING_BYTES = (size_t)STAGES * STAGE_BYTES, EPI_BYTES = (size_t)BM * (BN + 4) * 4;
+    static constexpr size_t MAP_OFF = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
+    static constexpr size_t LDS_BYTES = MAP_OFF + (CV == 2 ? BM * 4 : 0);
+    static_assert(A_LOADS >= 1 && B_LOADS >= 1 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile / wave-count mismatch");
+    static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
 
-    // per-lane decode of the A rows this lane stages (fixed for the whole k loop)
-    struct RowInfo {
-        long base[A_LOADS];          // element offset of pixel (n, 0, 0, 0) of the gathered tensor
-        int y0[A_LOADS], x0[A_LOADS];  // CV1: oh*s-ph, ow*s-pw ; CV2: ih+ph, iw+pw
+    struct Rows {
+        const bf16_t* a[A_LOADS];  // CV 0: &A[row][8c] ; CV 1/2: &src[pixel of tap (0,0)][8c] (may lie outside the tensor)
+        uint32_t mask[A_LOADS];    // CV 1/2: bit t set <=> tap t of the block's tap list reads inside the image
+        const bf16_t* b[B_LOADS];  // &B[row][8c]
     };
-    static AVSR_DEV RowInfo decode_rows(const Params& p, int m0, int wave, int lane) {
-        RowInfo ri;
-        const int rsub = lane >> 3;
-#pragma unroll
-        for (int i = 0; i < A_LOADS; i++) {
-            const int m = min(m0 + (wave * A_LOADS + i) * 8 + rsub, p.M - 1);
-            const int pix = p.cOH * p.cOW;
-            const int n = m / pix, r = m - n * pix;
-            const int y = r / p.cOW, x = r - y * p.cOW;
-            ri.base[i] = (long)n * p.cH * p.cW * p.cC;
-            if (CV == 1) {
-                ri.y0[i] = y * p.cS - p.cPH;
-                ri.x0[i] = x * p.cS - p.cPW;
-            } else {
-                ri.y0[i] = y + p.cPH;
-                ri.x0[i] = x + p.cPW;
-            }
-        }
-        return ri;
+    // wave-uniform description of the tap list this block walks
+    struct Taps {
+        int nkw, ntaps, cpt;  // taps per filter row, tap count, 64-wide k-tiles per tap
+        int py, px;           // CV 2: residue class
+    };
+
+    // tile row r (of this block) -> (image n, grid coordinates a, b) ; false when the row is beyond the class
+    static AVSR_DEV bool row_coords(const Params& p, int cls, int mloc, int& n, int& a, int& b) {
+        const int hc = p.cls_h[cls], wc = p.cls_w[cls];
+        const long mc = (long)p.cN * hc * wc;
+        const bool ok = mloc < mc;
+        const int m = ok ? mloc : (int)(mc - 1);
+        const int pix = hc * wc;
+        n = m / pix;
+        const int r = m - n * pix;
+        a = r / wc;
+        b = r - a * wc;
+        return ok;
     }
 
-    static AVSR_DEV void issue(const bf16_t* A, const bf16_t* B, int lda, int ldb, int m0, int n0, int M, int N, int k0,
-                               char* stage, int wave, int lane, const Params& p, const RowInfo& ri) {
+    static AVSR_DEV Rows decode_rows(const Params& p, const bf16_t* A, const bf16_t* B, int m0, int n0, int cls,
+                                     const Taps& tp, int wave, int lane) {
+        Rows ri;
         const int rsub = lane >> 3, pc = lane & 7;
-        int kh = 0, kw = 0, cbase = 0;
-        if (CV != 0) {  // wave-uniform tap decode of this k-tile
-            const int tap = k0 / p.cC;
-            cbase = k0 - tap * p.cC;
-            kh = tap / p.cKW;
-            kw = tap - kh * p.cKW;
-        }
 #pragma unroll
         for (int i = 0; i < A_LOADS; i++) {
             const int r = (wave * A_LOADS + i) * 8 + rsub;  // row inside the tile
             const int c = pc ^ ((r >> 1) & 7);              // source chunk that lands in physical chunk pc
-            const bf16_t* src;
             if (CV == 0) {
-                const int gr = min(m0 + r, M - 1);
-                src = A + (size_t)gr * lda + k0 + c * 8;
-            } else if (CV == 1) {
-                const int ih = ri.y0[i] + kh, iw = ri.x0[i] + kw;
-                const bool ok = ih >= 0 && ih < p.cH && iw >= 0 && iw < p.cW;
-                src = ok ? A + ri.base[i] + ((long)ih * p.cW + iw) * p.cC + cbase + c * 8
-                         : reinterpret_cast<const bf16_t*>(p.gate);  // zero page
+                const int gr = min(m0 + r, p.M - 1);
+                ri.a[i] = A + (size_t)gr * p.lda + c * 8;
+                ri.mask[i] = 0;
             } else {
-                const int th = ri.y0[i] - kh, tw = ri.x0[i] - kw;
-                const int oh = th / p.cS, ow = tw / p.cS;
-                const bool ok = th >= 0 && tw >= 0 && oh * p.cS == th && ow * p.cS == tw && oh < p.cH && ow < p.cW;
-                src = ok ? A + ri.base[i] + ((long)oh * p.cW + ow) * p.cC + cbase + c * 8
-                         : reinterpret_cast<const bf16_t*>(p.gate);
+                int n, a, b;
+                row_coords(p, cls, m0 + r, n, a, b);
+                int ya, xa;
+                if (CV == 1) {
+                    ya = a * p.cS - p.cPH;
+                    xa = b * p.cS - p.cPW;
+                } else {
+                    ya = (p.cls_y0[cls] + a * p.cS + p.cPH) / p.cS;
+                    xa = (p.cls_x0[cls] + b * p.cS + p.cPW) / p.cS;
+                }
+                ri.a[i] = A + ((long)n * p.cH * p.cW + (long)ya * p.cW + xa) * p.cC + c * 8;
+                uint32_t mk = 0;
+                for (int t = 0; t < tp.ntaps; t++) {
+                    const int ta = t / tp.nkw, tb = t - ta * tp.nkw;
+                    const int y = CV == 1 ? ya + ta : ya - ta, x = CV == 1 ? xa + tb : xa - tb;
+                    if (y >= 0 && y < p.cH && x >= 0 && x < p.cW) mk |= 1u << t;
+                }
+                ri.mask[i] = mk;
             }
-            glds16(src, stage + (wave * A_LOADS + i) * 1024);
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; i++) {
             const int r = (wave * B_LOADS + i) * 8 + rsub;
             const int c = pc ^ ((r >> 1) & 7);
-            const int gr = min(n0 + r, N - 1);
-            glds16(B + (size_t)gr * ldb + k0 + c * 8, stage + A_BYTES + (wave * B_LOADS + i) * 1024);
+            const int gr = min(n0 + r, p.N - 1);
+            ri.b[i] = B + (size_t)gr * p.ldb + c * 8;
         }
+        return ri;
+    }
+
+    // stage k-tile t of this block
+    static AVSR_DEV void issue(const Params& p, const Rows& ri, const Taps& tp, int kbeg, int t, char* stage, int wave) {
+        long da, db;
+        int tap = 0;
+        if (CV == 0) {
+            da = db = kbeg + t * BK;
+        } else {
+            tap = t / tp.cpt;
+            const int cb = (t - tap * tp.cpt) * BK;
+            const int ta = tap / tp.nkw, tb = tap - ta * tp.nkw;
+            if (CV == 1) {
+                da = (long)(ta * p.cW + tb) * p.cC + cb;
+                db = (long)tap * p.cC + cb;
+            } else {
+                da = -(long)(ta * p.cW + tb) * p.cC + cb;
+                db = (long)((tp.py + ta * p.cS) * p.cKW + tp.px + tb * p.cS) * p.cC + cb;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < A_LOADS; i++) {
+            const bf16_t* src = ri.a[i] + da;
+            if (CV != 0) src = ((ri.mask[i] >> tap) & 1u) ? src : reinterpret_cast<const bf16_t*>(p.gate);  // zero page
+            glds16(src, stage + (wave * A_LOADS + i) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; i++) glds16(ri.b[i] + db, stage + A_BYTES + (wave * B_LOADS + i) * 1024);
     }
 
     static AVSR_DEV bf16x8 frag(const char* base, int r, int chunk) {
@@ -108,12 +153,46 @@ struct FastKernel {
         const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
         const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int wm = wave >> 1, wn = wave & 1;
-        const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+        const int wm = wave / WGN, wn = wave % WGN;
+        int bx = blockIdx.x, by = blockIdx.y;
+        if (p.xcd_order && gridDim.z == 1) {
+            // block b runs on XCD b % 8 (observed): hand every XCD one contiguous run of tiles so that tiles sharing
+            // A rows (the n-tiles of an m-tile, the halo rows of neighbouring m-tiles) meet in the same L2
+            const int gx = gridDim.x, total = gx * gridDim.y;
+            const int id = by * gx + bx;
+            const int xcd = id & 7, slot = id >> 3, q = total >> 3, r = total & 7;
+            const int nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+            by = nid / gx;
+            bx = nid - by * gx;
+        }
+        const int n0 = bx * BN;
         const int zs = blockIdx.z;
-        const int kbeg = zs * p.k_chunk;
-        const int kend = min(p.K, kbeg + p.k_chunk);
-        const int nt = (kend - kbeg) / BK;
+
+        // which tap list / row range does this block work on
+        int cls = 0, m0 = by * BM, nt, kbeg = 0;
+        Taps tp{1, 1, 1, 0, 0};
+        if (CV == 0) {
+            kbeg = zs * p.k_chunk;
+            nt = (min(p.K, kbeg + p.k_chunk) - kbeg) / BK;
+        } else {
+            while (cls + 1 < p.ncls && by >= p.cls_tile0[cls + 1]) cls++;
+            m0 = (by - p.cls_tile0[cls]) * BM;
+            tp.nkw = p.cls_nkw[cls];
+            tp.ntaps = p.cls_nkh[cls] * tp.nkw;
+            tp.cpt = p.cC / BK;
+            tp.py = p.cls_py[cls];
+            tp.px = p.cls_px[cls];
+            nt = tp.ntaps * tp.cpt;
+        }
+        int* rowmap = nullptr;
+        if (CV == 2) {  // output pixel of every tile row (classes interleave in memory)
+            rowmap = reinterpret_cast<int*>(smem + MAP_OFF);
+            for (int r = threadIdx.x; r < BM; r += NTHR) {
+                int n, a, b;
+                const bool ok = row_coords(p, cls, m0 + r, n, a, b);
+                rowmap[r] = ok ? (n * p.cOH + p.cls_y0[cls] + a * p.cS) * p.cOW + p.cls_x0[cls] + b * p.cS : -1;
+            }
+        }
 
         f32x16 acc[TM][TN];
 #pragma unroll
@@ -123,73 +202,135 @@ struct FastKernel {
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-        RowInfo ri;
-        if (CV != 0) ri = decode_rows(p, m0, wave, lane);
+        const Rows ri = decode_rows(p, A, B, m0, n0, cls, tp, wave, lane);
         // prologue: tiles 0 .. STAGES-2 in flight
 #pragma unroll
         for (int s = 0; s < STAGES - 1; s++)
-            if (s < nt) issue(A, B, p.lda, p.ldb, m0, n0, p.M, p.N, kbeg + s * BK, smem + s * STAGE_BYTES, wave, lane, p, ri);
+            if (s < nt) issue(p, ri, tp, kbeg, s, smem + s * STAGE_BYTES, wave);
 
-        for (int t = 0; t < nt; t++) {
-            // retire tile t: loads of at most STAGES-2 later tiles may stay in flight
-            const int later = min(STAGES - 2, nt - 1 - t);
-            switch (later) {  // wave-uniform; counts are immediates
-                case 0: wait_vmcnt<0>(); break;
-                case 1: wait_vmcnt<LPT>(); break;
-                case 2: wait_vmcnt<2 * LPT>(); break;
-                case 3: wait_vmcnt<3 * LPT>(); break;
-                case 4: wait_vmcnt<4 * LPT>(); break;
-                default: wait_vmcnt<5 * LPT>(); break;
+        // One k-tile: retire its loads, barrier, first fragments, (optionally) stage tile t+STAGES-1, multiply.
+        // ISSUE is a compile-time flag -- the steady state (every iteration stages a tile) and the drain (none does)
+        // are separate loops, so neither carries a branch between the fragment reads and the MFMAs that use them.
+        auto step = [&](int t, auto issue_flag) {
+            constexpr bool ISSUE = decltype(issue_flag)::value;
+            // loads of at most STAGES-2 later tiles may stay in flight
+            if (ISSUE) {
+                wait_vmcnt<(STAGES - 2) * LPT>();
+            } else {
+                switch (nt - 1 - t) {  // wave-uniform; counts are immediates
+                    case 0: wait_vmcnt<0>(); break;
+                    default: wait_vmcnt<(STAGES > 2 ? LPT : 0)>(); break;
+                }
             }
             block_barrier_raw();  // tile t is in LDS for every wave; everyone is done reading tile t-1's buffer
-            if (t + STAGES - 1 < nt)
-                issue(A, B, p.lda, p.ldb, m0, n0, p.M, p.N, kbeg + (t + STAGES - 1) * BK,
-                      smem + ((t + STAGES - 1) % STAGES) * STAGE_BYTES, wave, lane, p, ri);
             const char* As = smem + (t % STAGES) * STAGE_BYTES;
             const char* Bs = As + A_BYTES;
+            // Two fragment register sets.  The fragments of k-steps 0 and 1 are requested right after the barrier, ahead
+            // of the address arithmetic of the next operand loads (which hides their LDS latency); k-step ks+2 is
+            // requested as soon as the MFMAs of k-step ks have been issued.  The scheduling fences keep that order.
+            // (The compiler makes the first LDS wait after an LDS-DMA instruction a full one; placed here it is free.)
+            bf16x8 fa[2][TM], fb[2][TN];
+            const int arow = wm * WM + (lane & 31), brow = wn * WN + (lane & 31);
+            auto load_frags = [&](int set, int ks) {
+                const int chunk = ks * 2 + (lane >> 5);
+#pragma unroll
+                for (int i = 0; i < TM; i++) fa[set][i] = frag(As, arow + i * 32, chunk);
+#pragma unroll
+                for (int j = 0; j < TN; j++) fb[set][j] = frag(Bs, brow + j * 32, chunk);
+            };
+            if (ABL != 1) {
+                load_frags(0, 0);
+                load_frags(1, 1);
+            }
+            sched_fence();
+            if (ISSUE && ABL != 2)
+                issue(p, ri, tp, kbeg, t + STAGES - 1, smem + ((t + STAGES - 1) % STAGES) * STAGE_BYTES, wave);
+            sched_fence();
+            if (ABL == 1) return;
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ks++) {
-                const int chunk = ks * 2 + (lane >> 5);
-                bf16x8 fa[TM], fb[TN];
-#pragma unroll
-                for (int i = 0; i < TM; i++) fa[i] = frag(As, wm * WM + i * 32 + (lane & 31), chunk);
-#pragma unroll
-                for (int j = 0; j < TN; j++) fb[j] = frag(Bs, wn * WN + j * 32 + (lane & 31), chunk);
 #pragma unroll
                 for (int i = 0; i < TM; i++)
 #pragma unroll
-                    for (int j = 0; j < TN; j++) acc[i][j] = mfma32(fa[i], fb[j], acc[i][j]);
+                    for (int j = 0; j < TN; j++) acc[i][j] = mfma32(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
+                if (ks + 2 < BK / 16) load_frags(ks & 1, ks + 2);
+                sched_fence();
             }
-        }
+        };
+        int t = 0;
+        for (; t + STAGES - 1 < nt; t++) step(t, std::true_type{});
+        for (; t < nt; t++) step(t, std::false_type{});
         if (CV != 0) {
             Params q = p;
             q.gate = nullptr;  // in conv mode the field carries the zero page, not an activation gate
-            avsr_gemm_impl::epilogue_lds<BM, BN, TM, TN>(acc, q, m0, n0, wm * WM, wn * WN, zs, 0, smem);
+            avsr_gemm_impl::epilogue_lds<BM, BN, TM, TN, NTHR>(acc, q, m0, n0, wm * WM, wn * WN, zs, 0, smem, rowmap);
         } else {
-            avsr_gemm_impl::epilogue_lds<BM, BN, TM, TN>(acc, p, m0, n0, wm * WM, wn * WN, zs, 0, smem);
+            avsr_gemm_impl::epilogue_lds<BM, BN, TM, TN, NTHR>(acc, p, m0, n0, wm * WM, wn * WN, zs, 0, smem, nullptr);
         }
     }
 };
 
-template <int BM, int BN, int STAGES, int CV = 0>
-__global__ __launch_bounds__(256) void gemm_fast_kernel(Params p) {
+template <int BM, int BN, int STAGES, int CV, int WGM, int WGN, int ABL>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_fast_kernel(Params p) {
     AVSR_DYN_SMEM(smem);
-    FastKernel<BM, BN, STAGES, CV>::run(p, smem);
+    FastKernel<BM, BN, STAGES, CV, WGM, WGN, ABL>::run(p, smem);
 }
 
-template <int BM, int BN, int STAGES, int CV = 0>
+template <int BM, int BN, int STAGES, int CV = 0, int WGM = 2, int WGN = 2, int ABL = 0>
 void launch_fast(Params& p, int split_k, hipStream_t stream) {
-    int kc = (p.K + split_k - 1) / split_k;
-    kc = ((kc + 63) / 64) * 64;
-    split_k = (p.K + kc - 1) / kc;
-    p.k_chunk = kc;
-    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, split_k), block(256);
-    AVSR_LAUNCH((gemm_fast_kernel<BM, BN, STAGES, CV>), grid, block, (FastKernel<BM, BN, STAGES, CV>::LDS_BYTES), stream, p);
+    using K = FastKernel<BM, BN, STAGES, CV, WGM, WGN, ABL>;
+    p.xcd_order = g_tune[1];
+    int gy;
+    if (CV == 0) {
+        int kc = (p.K + split_k - 1) / split_k;
+        kc = ((kc + 63) / 64) * 64;
+        split_k = (p.K + kc - 1) / kc;
+        p.k_chunk = kc;
+        gy = (p.M + BM - 1) / BM;
+    } else {
+        split_k = 1;
+        int t0 = 0;
+        for (int c = 0; c < p.ncls; c++) {
+            p.cls_tile0[c] = t0;
+            t0 += (int)(((long)p.cN * p.cls_h[c] * p.cls_w[c] + BM - 1) / BM);
+        }
+        p.cls_tile0[p.ncls] = t0;
+        gy = t0;
+    }
+    dim3 grid((p.N + BN - 1) / BN, gy, split_k), block(K::NTHR);
+    AVSR_LAUNCH((gemm_fast_kernel<BM, BN, STAGES, CV, WGM, WGN, ABL>), grid, block, K::LDS_BYTES, stream, p);
+}
+
+// tile codes shared by the GEMM and convolution entry points
+//   1 = 64x64 (3 stages, 4 waves)   2 = 128x64   3 = 128x128   4 = 128x128 with 2 stages (2 blocks per CU)
+//   5 = 256x128, 8 waves of 64x64   6 = 256x128, 4 waves of 128x64   7 = 128x64 with 2 stages   8 = 256x64, 8 waves
+template <int CV>
+bool launch_tile(int tile, Params& p, int split_k, hipStream_t stream) {
+    switch (tile) {
+        case 1: if (CV == 0) { launch_fast<64, 64, 3, 0>(p, split_k, stream); return true; } return false;
+        case 2: launch_fast<128, 64, 3, CV>(p, split_k, stream); return true;
+        case 3:
+            if (CV == 1 && g_tune[2] == 1) launch_fast<128, 128, 3, 1, 2, 2, 1>(p, split_k, stream);
+            else if (CV == 1 && g_tune[2] == 2) launch_fast<128, 128, 3, 1, 2, 2, 2>(p, split_k, stream);
+            else launch_fast<128, 128, 3, CV>(p, split_k, stream);
+            return true;
+        case 4: launch_fast<128, 128, 2, CV>(p, split_k, stream); return true;
+        case 5: launch_fast<256, 128, 3, CV, 4, 2>(p, split_k, stream); return true;
+        case 6: launch_fast<256, 128, 3, CV, 2, 2>(p, split_k, stream); return true;
+        case 7: launch_fast<128, 64, 2, CV>(p, split_k, stream); return true;
+        case 8: launch_fast<256, 64, 3, CV, 4, 2>(p, split_k, stream); return true;
+        default: return false;
+    }
 }
 
 }  // namespace
 
-// tile: 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128
+extern "C" int avsr_tune(int knob, int value) {
+    AVSR_REQUIRE(knob >= 0 && knob < 8, "tune: unknown knob");
+    g_tune[knob] = value;
+    return 0;
+}
+
 extern "C" int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
                                  int act, const void* gate, int gate_dtype, int ldg, float gate_scale, float drop_p,
                                  uint64_t seed, const uint64_t* seed_dev, float alpha, const float* alpha_dev,
@@ -215,13 +356,12 @@ extern "C" int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
     if (tile == 0) {
         const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
         const long t12864 = (long)((M + 127) / 128) * ((N + 63) / 64);
-        tile = t128 >= 224 ? 3 : (t12864 >= 200 ? 2 : 1);
+        // measured on MI355X (tools/microbench_tiles.py): two or three co-resident blocks per CU beat one block with a
+        // deeper ring at every size -- 128x128 / 128x64 with a 2-stage ring (2 / 3 blocks per CU) once the grid fills the
+        // chip, 64x64 with 3 stages (3 blocks per CU) for the skinny M = B*T GEMMs of the transformer layers
+        tile = t128 >= 512 ? 4 : (t12864 >= 400 ? 7 : 1);
     }
-    if (tile == 3) launch_fast<128, 128, 3>(p, split_k, stream);
-    else if (tile == 2) launch_fast<128, 64, 3>(p, split_k, stream);
-    // 3 stages = 48 KiB -> 3 blocks/CU.  Measured: deeper rings (4-6 stages) are slower -- the LDS-DMA path wants more
-    // co-resident waves issuing, not more bytes in flight per wave.
-    else launch_fast<64, 64, 3>(p, split_k, stream);
+    AVSR_REQUIRE(launch_tile<0>(tile, p, split_k, stream), "gemm_bf16_nt: unknown tile code");
     AVSR_CHECK_LAUNCH("gemm_bf16_nt");
     return 0;
 }
@@ -236,6 +376,9 @@ extern "C" int avsr_conv2d_bf16(int dgrad, const void* src, const void* wp, cons
     const int Cg = dgrad ? Cout : Cin;  // channels of the gathered tensor
     AVSR_REQUIRE(Cg % 64 == 0, "conv2d_bf16: gathered channel count must be a multiple of 64");
     AVSR_REQUIRE(zero_page != nullptr, "conv2d_bf16: zero page required");
+    AVSR_REQUIRE(KH * KW <= 32, "conv2d_bf16: at most 32 filter taps");
+    AVSR_REQUIRE(stride == 1 || (stride == 2 && KH <= 8 && KW <= 8), "conv2d_bf16: stride must be 1 or 2");
+    AVSR_REQUIRE((long)N * H * W < (1l << 31) && (long)N * OH * OW < (1l << 31), "conv2d_bf16: pixel count exceeds int32");
     if (N <= 0) return 0;
     Params p{};
     p.A = src; p.B = wp;
@@ -244,21 +387,46 @@ extern "C" int avsr_conv2d_bf16(int dgrad, const void* src, const void* wp, cons
     p.nsplit = 1; p.batch_h = 1; p.nbatch = 1;
     p.gate = zero_page;
     p.c_dtype = 1; p.C = out;
+    p.cN = N;
     p.cKH = KH; p.cKW = KW; p.cS = stride; p.cPH = pad_h; p.cPW = pad_w; p.cC = Cg; p.cT = 1; p.cKT = 1;
     if (!dgrad) {
         p.M = N * OH * OW; p.N = Cout; p.ldc = Cout;
         p.cH = H; p.cW = W; p.cOH = OH; p.cOW = OW;
+        p.ncls = 1;
+        p.cls_h[0] = OH; p.cls_w[0] = OW; p.cls_nkh[0] = KH; p.cls_nkw[0] = KW;
     } else {
         p.M = N * H * W; p.N = Cin; p.ldc = Cin;
         p.cH = OH; p.cW = OW; p.cOH = H; p.cOW = W;
         p.resid = reinterpret_cast<const float*>(resid); p.resid_dtype = 1; p.ldr = Cin;
+        // residue classes of (ih + ph, iw + pw) mod stride, heaviest tap list first
+        struct Cls { int py, px, y0, x0, h, w, nkh, nkw; } cl[4];
+        int nc = 0;
+        for (int py = 0; py < stride; py++)
+            for (int px = 0; px < stride; px++) {
+                Cls c;
+                c.py = py; c.px = px;
+                c.y0 = ((py - pad_h) % stride + stride) % stride;
+                c.x0 = ((px - pad_w) % stride + stride) % stride;
+                c.h = c.y0 < H ? (H - c.y0 + stride - 1) / stride : 0;
+                c.w = c.x0 < W ? (W - c.x0 + stride - 1) / stride : 0;
+                c.nkh = py < KH ? (KH - py + stride - 1) / stride : 0;
+                c.nkw = px < KW ? (KW - px + stride - 1) / stride : 0;
+                if (c.nkh == 0 || c.nkw == 0) c.nkh = c.nkw = 0;
+                if (c.h > 0 && c.w > 0) cl[nc++] = c;
+            }
+        for (int i = 0; i < nc; i++)
+            for (int j = i + 1; j < nc; j++)
+                if (cl[j].nkh * cl[j].nkw > cl[i].nkh * cl[i].nkw) { Cls t = cl[i]; cl[i] = cl[j]; cl[j] = t; }
+        p.ncls = nc;
+        for (int i = 0; i < nc; i++) {
+            p.cls_py[i] = cl[i].py; p.cls_px[i] = cl[i].px; p.cls_y0[i] = cl[i].y0; p.cls_x0[i] = cl[i].x0;
+            p.cls_h[i] = cl[i].h; p.cls_w[i] = cl[i].w; p.cls_nkh[i] = cl[i].nkh; p.cls_nkw[i] = cl[i].nkw;
+        }
     }
-    const bool wide = p.N >= 128;
-    if (!dgrad) {
-        if (wide) launch_fast<128, 128, 3, 1>(p, 1, stream); else launch_fast<128, 64, 3, 1>(p, 1, stream);
-    } else {
-        if (wide) launch_fast<128, 128, 3, 2>(p, 1, stream); else launch_fast<128, 64, 3, 2>(p, 1, stream);
-    }
+    int tile = g_tune[0];
+    if (tile == 0) tile = p.N >= 128 ? 4 : 7;  // 2-stage rings: 2 / 3 co-resident blocks per CU (measured best)
+    const bool ok = dgrad ? launch_tile<2>(tile, p, 1, stream) : launch_tile<1>(tile, p, 1, stream);
+    AVSR_REQUIRE(ok, "conv2d_bf16: unknown tile code");
     AVSR_CHECK_LAUNCH("conv2d_bf16");
     return 0;
 }

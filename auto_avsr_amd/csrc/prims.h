@@ -115,6 +115,12 @@ AVSR_DEV void block_barrier_raw() {  // s_barrier without the vmcnt(0) drain tha
     __builtin_amdgcn_s_barrier();
 #endif
 }
+// compiler scheduling fence: no instruction is moved across it (keeps a hand-placed prefetch ahead of the MFMAs)
+AVSR_DEV void sched_fence() {
+#ifndef AVSR_EMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
 template <int N> AVSR_DEV void wait_vmcnt() {
 #ifndef AVSR_EMU
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

@@ -335,10 +335,15 @@ def zero_page(device):
     return z
 
 
+def tune(knob, value):
+    """Process-wide tuning knob of the tuned kernels (benchmarks): see avsr_tune in include/avsr_hip.h."""
+    call("avsr_tune", int(knob), int(value))
+
+
 def conv2d_fwd(x, wp, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise):
     OH, OW = conv_out(H, KH, stride, ph), conv_out(W, KW, stride, pw)
     y = torch.empty(N, OH, OW, Cout, dtype=x.dtype, device=x.device)
-    if not precise and x.dtype == torch.bfloat16 and wp.dtype == torch.bfloat16 and Cin % 64 == 0:
+    if not precise and x.dtype == torch.bfloat16 and wp.dtype == torch.bfloat16 and Cin % 64 == 0 and stride <= 2:
         call("avsr_conv2d_bf16", 0, _ptr(x), _ptr(wp), None, _ptr(y), _ptr(zero_page(x.device)), N, H, W, Cin, Cout, KH,
              KW, stride, ph, pw, _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin)
         return y
@@ -349,7 +354,7 @@ def conv2d_fwd(x, wp, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise):
 
 def conv2d_dgrad(dy, wpd, resid, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise):
     dx = torch.empty(N, H, W, Cin, dtype=dy.dtype, device=dy.device)
-    if not precise and dy.dtype == torch.bfloat16 and wpd.dtype == torch.bfloat16 and Cout % 64 == 0:
+    if not precise and dy.dtype == torch.bfloat16 and wpd.dtype == torch.bfloat16 and Cout % 64 == 0 and stride <= 2:
         call("avsr_conv2d_bf16", 1, _ptr(dy), _ptr(wpd), _ptr(resid), _ptr(dx), _ptr(zero_page(dy.device)), N, H, W, Cin,
              Cout, KH, KW, stride, ph, pw, _stream(dy), flops=2.0 * N * H * W * Cin * KH * KW * Cout)
         return dx

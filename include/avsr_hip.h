@@ -202,14 +202,20 @@ int avsr_avgpool_bwd(const float* dy, void* dx, int dtype, int64_t groups, int w
 
 /* ---- tuned bf16 NT GEMM (gemm_fast.hip): LDS-DMA operand ring, swizzled LDS, counted vmcnt ------------------ */
 /* C[M,N] = epi(A[M,K] . B[N,K]^T), A and B bf16 k-contiguous, K % 64 == 0; epilogue as avsr_gemm (resid may be
- * f32 or bf16); tile: 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128 */
+ * f32 or bf16); tile: 0 auto, 1 = 64x64, 2 = 128x64, 3 = 128x128 (3-stage ring, 4 waves), 4 = 128x128 with a 2-stage
+ * ring, 5 = 256x128 with 8 waves, 6 = 256x128 with 4 waves, 7 = 128x64 with a 2-stage ring, 8 = 256x64 with 8 waves */
 int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias, int act,
                       const void* gate, int gate_dtype, int ldg, float gate_scale, float drop_p, uint64_t seed,
                       const uint64_t* seed_dev, float alpha, const float* alpha_dev, const void* resid, int resid_dtype,
                       int ldr, void* C, int c_dtype, int ldc, int accumulate, int split_k, int tile,
                       avsr_stream_t stream);
+/* Tuning knobs of the tuned kernels (process-wide; meant for benchmarks, defaults are the measured best):
+ * knob 0 = tile code forced on avsr_conv2d_bf16 (0 = auto), 1 = XCD-aware tile order (default 0: measured neutral to slower),
+ * 2 = ablation mode of the 128x128 forward convolution kernel (1 = no MFMA, 2 = no operand loads; wrong results). */
+int avsr_tune(int knob, int value);
 /* bf16 implicit-GEMM convolution on the tuned LDS-DMA kernel: dgrad = 0 forward, 1 data gradient (see
- * avsr_conv2d_fwd / avsr_conv2d_dgrad for the tensor conventions); gathered channel count % 64 == 0;
+ * avsr_conv2d_fwd / avsr_conv2d_dgrad for the tensor conventions); gathered channel count % 64 == 0; stride 1 or 2
+ * (a strided data gradient runs as stride^2 dense sub-problems, one per residue class of the input pixel);
  * zero_page: >= 16 zero bytes of device memory (source of the padding taps) */
 int avsr_conv2d_bf16(int dgrad, const void* src, const void* wp, const void* resid, void* out, const void* zero_page,
                      int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_h, int pad_w,

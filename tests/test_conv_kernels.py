@@ -19,6 +19,7 @@ def nhwc(t):
     (2, 9, 10, 64, 128, 3, 1, 1),  # channel counts that take the LDS-DMA bf16 kernel in bf16 mode
     (2, 10, 9, 128, 64, 3, 2, 1),
     (3, 7, 7, 64, 128, 1, 2, 0),
+    (2, 11, 7, 64, 64, 3, 2, 1),   # odd extents: the residue classes of the strided data gradient differ in size
 ])
 @pytest.mark.parametrize("precise", [True, False])
 def test_conv2d_fwd_dgrad_wgrad(dev, cfg, precise):
@@ -47,6 +48,32 @@ def test_conv2d_fwd_dgrad_wgrad(dev, cfg, precise):
     dwp = ops.conv2d_wgrad(dyd, xd, N, H, W, Cin, Cout, KH, K, s, ph, p, precise)
     dw = ops.conv_weight_unpermute(dwp, wq.shape)
     assert (dw.cpu() - wq.grad).abs().max() < tol * max(1.0, wq.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("tile", [2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("cfg", [(5, 9, 10, 64, 128, 3, 1, 1), (4, 11, 12, 128, 64, 3, 2, 1), (9, 7, 7, 64, 192, 1, 2, 0)])
+def test_conv2d_bf16_tiles(dev, cfg, tile):
+    """Every tile / wave-count variant of the tuned bf16 convolution kernel gives the same forward and data gradient."""
+    N, H, W, Cin, Cout, K, s, p = cfg
+    torch.manual_seed(tile)
+    x = torch.randn(N, Cin, H, W).bfloat16().float()
+    w = (torch.randn(Cout, Cin, K, K) / (Cin * K * K) ** 0.5)
+    wq = w.bfloat16().float()
+    x.requires_grad_()
+    y_ref = F.conv2d(x, wq, stride=s, padding=p)
+    dy = torch.randn_like(y_ref).bfloat16().float()
+    y_ref.backward(dy)
+    ops.tune(0, tile)
+    try:
+        xd = nhwc(x.detach()).bfloat16().to(dev)
+        y = ops.conv2d_fwd(xd, ops.conv_weight_permute(w.to(dev), torch.bfloat16), N, H, W, Cin, Cout, K, K, s, p, p, False)
+        res = torch.randn(N, H, W, Cin).bfloat16()
+        dx = ops.conv2d_dgrad(nhwc(dy).bfloat16().to(dev), ops.conv_weight_permute(w.to(dev), torch.bfloat16, to_dgrad=True),
+                              res.to(dev), N, H, W, Cin, Cout, K, K, s, p, p, False)
+    finally:
+        ops.tune(0, 0)
+    assert (y.float().cpu() - nhwc(y_ref.detach())).abs().max() < 2e-2 * max(1.0, y_ref.abs().max().item())
+    assert (dx.float().cpu() - nhwc(x.grad) - res.float()).abs().max() < 4e-2 * max(1.0, x.grad.abs().max().item())
 
 
 @pytest.mark.parametrize("precise", [True, False])

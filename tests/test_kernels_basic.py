@@ -82,7 +82,7 @@ def test_gemm_epilogue_split_ragged(dev):
     assert _run_gemm(dev, 0, 1, 5, 8, 1, 1, 0, 0) < 2e-6
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("shape", [(150, 70, 192), (200, 130, 64), (257, 300, 448)])
 def test_gemm_fast_nt(dev, tile, shape):
     """LDS-DMA / swizzled-LDS / counted-vmcnt NT kernel: exact products of bf16 operands, all tiles, ragged M/N,
