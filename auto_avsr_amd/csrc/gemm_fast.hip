@@ -152,7 +152,7 @@ struct FastKernel {
     static AVSR_DEV void run(const Params& p, char* smem) {
         const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
         const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int lane = threadIdx.x & 63, wave = wave_id();
         const int wm = wave / WGN, wn = wave % WGN;
         int bx = blockIdx.x, by = blockIdx.y;
         if (p.xcd_order && gridDim.z == 1) {
@@ -359,7 +359,7 @@ extern "C" int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
         // measured on MI355X (tools/microbench_tiles.py): two or three co-resident blocks per CU beat one block with a
         // deeper ring at every size -- 128x128 / 128x64 with a 2-stage ring (2 / 3 blocks per CU) once the grid fills the
         // chip, 64x64 with 3 stages (3 blocks per CU) for the skinny M = B*T GEMMs of the transformer layers
-        tile = t128 >= 512 ? 4 : (t12864 >= 400 ? 7 : 1);
+        tile = t128 >= 1024 ? 4 : (t12864 >= 400 ? 7 : 1);
     }
     AVSR_REQUIRE(launch_tile<0>(tile, p, split_k, stream), "gemm_bf16_nt: unknown tile code");
     AVSR_CHECK_LAUNCH("gemm_bf16_nt");

@@ -54,21 +54,22 @@ struct TnKernel {
         }
     }
 
-    // 32 (m or n) x 16 (k) MFMA fragment of the k-major tile at `base`: columns c0..c0+31, k-step ks
-    static AVSR_DEV bf16x8 frag(const char* base, int c0, int ks, int lane) {
+    // 32 (m or n) x 16 (k) MFMA fragment of the k-major tile at `base`: columns c0..c0+31, k-step ks, as two
+    // transpose reads.  Issued in the asm form (prims.h lds_tr16_async): the compiler would otherwise park every
+    // transpose read behind a vmcnt(0) -- i.e. behind the LDS-DMA of the NEXT tiles -- and serialise the ring.
+    static AVSR_DEV void frag_async(const char* base, int c0, int ks, int lane, bf16x4& lo, bf16x4& hi) {
         const int g = lane >> 4, i = lane & 15;
         const bf16_t* t = reinterpret_cast<const bf16_t*>(base);
         const int row = ks * 16 + 8 * (g >> 1) + (i >> 2);
         const int col = c0 + 16 * (g & 1) + 4 * (i & 3);
-        const bf16x4 lo = lds_tr16(t + row * 64 + col);
-        const bf16x4 hi = lds_tr16(t + (row + 4) * 64 + col);
-        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        lo = lds_tr16_async(t + row * 64 + col);
+        hi = lds_tr16_async(t + (row + 4) * 64 + col);
     }
 
     static AVSR_DEV void run(const Params& p, char* smem) {
         const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
         const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int lane = threadIdx.x & 63, wave = wave_id();
         const int wm = wave >> 1, wn = wave & 1;
         const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
         const int zs = blockIdx.z;
@@ -90,9 +91,26 @@ struct TnKernel {
                       wave, lane);
             const char* As = smem + (t % STAGES) * STAGE_BYTES;
             const char* Bs = As + OP_BYTES;
+            bf16x4 f[2][4];  // two register sets: k-step ks+1 is requested before the MFMA of k-step ks
+            frag_async(As, wm * 32, 0, lane, f[0][0], f[0][1]);
+            frag_async(Bs, wn * 32, 0, lane, f[0][2], f[0][3]);
 #pragma unroll
-            for (int ks = 0; ks < BK / 16; ks++)
-                acc[0][0] = mfma32(frag(As, wm * 32, ks, lane), frag(Bs, wn * 32, ks, lane), acc[0][0]);
+            for (int ks = 0; ks < BK / 16; ks++) {
+                const int c = ks & 1;
+                if (ks + 1 < BK / 16) {
+                    frag_async(As, wm * 32, ks + 1, lane, f[c ^ 1][0], f[c ^ 1][1]);
+                    frag_async(Bs, wn * 32, ks + 1, lane, f[c ^ 1][2], f[c ^ 1][3]);
+                    lds_wait<4>();  // the four reads just issued may stay in flight
+                } else {
+                    lds_wait<0>();
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) lds_tie(f[c][q]);
+                const bf16x8 a{f[c][0][0], f[c][0][1], f[c][0][2], f[c][0][3], f[c][1][0], f[c][1][1], f[c][1][2], f[c][1][3]};
+                const bf16x8 b{f[c][2][0], f[c][2][1], f[c][2][2], f[c][2][3], f[c][3][0], f[c][3][1], f[c][3][2], f[c][3][3]};
+                acc[0][0] = mfma32(a, b, acc[0][0]);
+                sched_fence();
+            }
         }
         Params q = p;
         q.gate = nullptr;  // the field carries the zero page

@@ -115,6 +115,15 @@ AVSR_DEV void block_barrier_raw() {  // s_barrier without the vmcnt(0) drain tha
     __builtin_amdgcn_s_barrier();
 #endif
 }
+// wave index inside the block as a SCALAR (the compiler cannot see that threadIdx.x >> 6 is wave-uniform; with the
+// scalar form per-wave guards become scalar branches and LDS-DMA bases need no v_readfirstlane)
+AVSR_DEV int wave_id() {
+#ifdef AVSR_EMU
+    return (int)(threadIdx.x >> 6);
+#else
+    return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#endif
+}
 // compiler scheduling fence: no instruction is moved across it (keeps a hand-placed prefetch ahead of the MFMAs)
 AVSR_DEV void sched_fence() {
 #ifndef AVSR_EMU
@@ -146,6 +155,33 @@ AVSR_DEV bf16x4 lds_tr16(const bf16_t* p) {
     return out;
 #else
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)p);
+#endif
+}
+
+// The same read issued WITHOUT the compiler knowing it is an LDS access.  hipcc orders every LDS-address-space load
+// behind all pending LDS-DMA writes (it inserts s_waitcnt vmcnt(0) in front of the builtin above whenever a
+// global_load_lds is in flight -- even one that targets another ring slot), which serialises an operand ring.  The
+// asm form keeps the DMA in flight; in exchange the CALLER orders the read: lds_wait<N>() (s_waitcnt lgkmcnt(N),
+// N = number of later LDS operations that may still be outstanding) followed by lds_tie() on every register that
+// must not be consumed before the wait.  Reads are asm volatile, so they issue in program order.
+AVSR_DEV bf16x4 lds_tr16_async(const bf16_t* p) {
+#ifdef AVSR_EMU
+    return lds_tr16(p);
+#else
+    const uint32_t addr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) bf16_t*)p;
+    bf16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+#endif
+}
+template <int N> AVSR_DEV void lds_wait() {
+#ifndef AVSR_EMU
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
+#endif
+}
+template <class T> AVSR_DEV void lds_tie(T& v) {  // makes every later use of v depend on the preceding lds_wait
+#ifndef AVSR_EMU
+    asm volatile("" : "+v"(v));
 #endif
 }
 

@@ -366,7 +366,13 @@ def conv2d_dgrad(dy, wpd, resid, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, pre
 def conv2d_wgrad(dy, x, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise):
     OH, OW = conv_out(H, KH, stride, ph), conv_out(W, KW, stride, pw)
     dwp = torch.zeros(Cout, KH * KW * Cin, dtype=torch.float32, device=x.device)
-    if not precise and x.dtype == torch.bfloat16 and Cin % 64 == 0 and Cout % 8 == 0:
+    bf = not precise and x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
+    if bf and KH == 3 and KW == 3 and ph == 1 and pw == 1 and stride <= 2 and Cin % 64 == 0 and Cout % 64 == 0 \
+            and (OW - 1) * stride + 3 <= 64:
+        call("avsr_conv3x3_wgrad_bf16", _ptr(dy), _ptr(x), _ptr(dwp), _ptr(zero_page(x.device)), N, H, W, Cin, Cout, stride,
+             _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin)
+        return dwp
+    if bf and Cin % 64 == 0 and Cout % 8 == 0:
         call("avsr_conv2d_wgrad_bf16", _ptr(dy), _ptr(x), _ptr(dwp), _ptr(zero_page(x.device)), N, H, W, Cin, Cout, KH,
              KW, stride, ph, pw, _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin)
         return dwp

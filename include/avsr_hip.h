@@ -250,6 +250,11 @@ int avsr_gemm_bf16_tn(const void* A, int lda, const void* B, int ldb, int M, int
 int avsr_conv2d_wgrad_bf16(const void* dy, const void* x, float* dwp, const void* zero_page, int N, int H, int W,
                            int Cin, int Cout, int KH, int KW, int stride, int pad_h, int pad_w,
                            avsr_stream_t stream);
+/* weight gradient of a 3x3 / pad 1 convolution, stride 1 or 2 (conv_wgrad.hip; reference resnet.py:10-35 under
+ * autograd): one zero-padded x patch per pixel tile serves all nine taps as shifted LDS views; Cin, Cout % 64 == 0;
+ * dwp [Cout][3][3][Cin] f32, caller zeroes */
+int avsr_conv3x3_wgrad_bf16(const void* dy, const void* x, float* dwp, const void* zero_page, int N, int H, int W,
+                            int Cin, int Cout, int stride, avsr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -76,6 +76,30 @@ def test_conv2d_bf16_tiles(dev, cfg, tile):
     assert (dx.float().cpu() - nhwc(x.grad) - res.float()).abs().max() < 4e-2 * max(1.0, x.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, Cin, Cout, stride -- trunk geometries in miniature: row bands (tall images), several whole images per
+    # tile (small images), ragged last band / last image group, stride 2 with odd and even extents
+    (3, 22, 22, 64, 64, 1), (5, 11, 11, 128, 64, 1), (7, 6, 6, 64, 128, 1), (17, 3, 3, 64, 64, 1),
+    (3, 22, 22, 64, 128, 2), (4, 11, 11, 64, 64, 2), (5, 6, 6, 128, 64, 2), (2, 9, 13, 64, 64, 1), (2, 7, 10, 64, 64, 2),
+])
+def test_conv3x3_wgrad_direct(dev, cfg):
+    """Dedicated 3x3 weight-gradient kernel (shifted LDS views of one padded patch) vs torch autograd."""
+    N, H, W, Cin, Cout, s = cfg
+    torch.manual_seed(H * 31 + N)
+    x = torch.randn(N, Cin, H, W).bfloat16().float()
+    w = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    y = F.conv2d(x, w, stride=s, padding=1)
+    dy = torch.randn_like(y).bfloat16().float()
+    y.backward(dy)
+    OH, OW = y.shape[2], y.shape[3]
+    dwp = torch.zeros(Cout, 9 * Cin, dtype=torch.float32, device=dev)
+    dyd, xd = nhwc(dy).bfloat16().to(dev), nhwc(x).bfloat16().to(dev)
+    ops.call("avsr_conv3x3_wgrad_bf16", ops._ptr(dyd), ops._ptr(xd), ops._ptr(dwp), ops._ptr(ops.zero_page(dev)), N, H, W, Cin,
+             Cout, s, ops._stream(dwp))
+    dw = ops.conv_weight_unpermute(dwp, w.shape)
+    assert (dw.cpu() - w.grad).abs().max() < 2e-3 * max(1.0, w.grad.abs().max().item())
+
+
 @pytest.mark.parametrize("precise", [True, False])
 def test_conv_stem_video(dev, precise):
     torch.manual_seed(3)
