@@ -24,6 +24,16 @@ extern "C" int avsr_take_launch_error(void) {
 }
 extern "C" const char* avsr_last_error(void) { return g_err; }
 extern "C" int avsr_abi_version(void) { return 1; }
+// process-wide tuning knobs (benchmarks; see avsr_tune in avsr_hip.h)
+int avsr_tune_knobs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+extern "C" int avsr_tune(int knob, int value) {
+    if (knob < 0 || knob >= 8) {
+        avsr_set_error("tune: unknown knob");
+        return 1;
+    }
+    avsr_tune_knobs[knob] = value;
+    return 0;
+}
 // 1 when this library is the host-side emulator build used by the CPU tests, 0 for the gfx950 build.
 extern "C" int avsr_is_emulator(void) {
 #ifdef AVSR_EMU

@@ -21,8 +21,9 @@ namespace {
 
 using avsr_gemm_impl::Params;
 
-// run-time tuning knobs (avsr_tune): 0 = conv tile override, 1 = XCD-aware tile order, 2 = ablation (benchmarks only)
-int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+// run-time tuning knobs (avsr_tune, common.hip): 0 = conv tile override, 1 = XCD-aware tile order, 2 = ablation
+// (benchmarks only)
+#define g_tune avsr_tune_knobs
 
 // CV = 0: plain A[M][K].  CV = 1 / 2: A is the im2col view of a channels-last image tensor (forward / data gradient,
 // see gemm_core.h Params); channels are a multiple of 64, so a 64-wide k-tile lies inside one filter tap and the
@@ -325,12 +326,6 @@ bool launch_tile(int tile, Params& p, int split_k, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int avsr_tune(int knob, int value) {
-    AVSR_REQUIRE(knob >= 0 && knob < 8, "tune: unknown knob");
-    g_tune[knob] = value;
-    return 0;
-}
-
 extern "C" int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
                                  int act, const void* gate, int gate_dtype, int ldg, float gate_scale, float drop_p,
                                  uint64_t seed, const uint64_t* seed_dev, float alpha, const float* alpha_dev,
@@ -556,7 +551,7 @@ struct AvsrCastEntry {
     const float* src;
     bf16_t* dst;   // may be null
     bf16_t* dstT;  // may be null
-    int R, C, ldT, blk0, tiles_c, pad0, pad1, pad2;
+    int R, C, ldT, blk0, tiles_c, limT, pad1, pad2;  // limT (0 = ldT): rows of dstT that are written (zero tail included)
 };
 
 namespace {
@@ -598,15 +593,16 @@ __global__ __launch_bounds__(256) void multi_cast_transpose_kernel(const AvsrCas
         for (int id = threadIdx.x; id < 64 * 8; id += 256) {
             const int c = id >> 3, rr = (id & 7) * 8;
             const int gc = c0 + c, gr = r0 + rr;
-            if (gc < e.C && gr < e.ldT)
+            if (gc < e.C && gr < (e.limT ? e.limT : e.ldT))
                 *reinterpret_cast<bf16x8*>(e.dstT + (long)gc * e.ldT + gr) = *reinterpret_cast<const bf16x8*>(tile + c * 72 + rr);
         }
     }
 }
 }  // namespace
 
-// table: n entries of 64 bytes {src, dst, dstT, R, C, ldT, blk0, tiles_c, 0, 0, 0}; blk0 = running sum of
-// ceil(max(R, ldT)/64) * ceil(C/64); total_blocks = the final sum
+// table: n entries of 64 bytes {src, dst, dstT, R, C, ldT, blk0, tiles_c, limT, 0, 0}; blk0 = running sum of
+// ceil(max(R, limT ? limT : ldT)/64) * ceil(C/64); total_blocks = the final sum.  limT < ldT lets several transposed
+// copies share one [C][ldT] buffer side by side (concatenated projection weights).
 extern "C" int avsr_multi_cast_transpose(const void* table, int n, int total_blocks, hipStream_t stream) {
     if (n <= 0 || total_blocks <= 0) return 0;
     AVSR_LAUNCH(multi_cast_transpose_kernel, dim3(total_blocks), dim3(256), 0, stream,

@@ -10,6 +10,7 @@ one pre-LN residual branch each, ``x + scale * dropout(f(LN(x)))``, forward and 
 add, the dropout masks, bias / activation and the LayerNorm gradient are all fused into kernel epilogues.
 """
 import contextlib
+import os
 import math
 
 import torch
@@ -82,12 +83,15 @@ def _rows(x):
 # (csrc/gemm_fast.hip).  Weights therefore need a bf16 copy ([out][in], Linear forward) and a transposed bf16 copy
 # ([in][out_padded_to_64], data gradient).  Copies are cached per parameter version: an optimizer step bumps
 # `_version`, so they are rebuilt exactly once per training step (bench.py invalidates explicitly).
-_wcache = {}   # (data_ptr, transposed, shape) -> [version, bf16 copy, source weight]
+_FUSE_QKV = os.environ.get("AVSR_FUSE_QKV", "1") != "0"  # A/B switch for the fused self-attention projections
+_wcache = {}   # (data_ptr, transposed, shape) -> [version, bf16 copy, source weight, is a slice of a concatenation]
+_wcat = {}     # (data_ptrs..., transposed) -> concatenated bf16 buffer whose slices are registered in _wcache
 _wtable = {"n": 0, "dev": None, "blocks": 0, "built_for": -1}
 
 
 def invalidate_weight_cache():
     _wcache.clear()
+    _wcat.clear()
     _wtable.update(n=0, dev=None, blocks=0, built_for=-1)
 
 
@@ -106,11 +110,12 @@ def refresh_weight_cache():
         blob, blk = b"", 0
         for (ptr, shape), (w, dst, dstT) in groups.items():
             R, C = shape
-            ldT = dstT.shape[1] if dstT is not None else 0
+            ldT = dstT.stride(0) if dstT is not None else 0   # a slice of a concatenation has pitch > its own width
+            limT = dstT.shape[1] if dstT is not None else 0
             tiles_c = (C + 63) // 64
-            tiles_r = (max(R, ldT) + 63) // 64
+            tiles_r = (max(R, limT) + 63) // 64
             blob += struct.pack("<QQQiiiiiiii", w.data_ptr(), dst.data_ptr() if dst is not None else 0,
-                                dstT.data_ptr() if dstT is not None else 0, R, C, ldT, blk, tiles_c, 0, 0, 0)
+                                dstT.data_ptr() if dstT is not None else 0, R, C, ldT, blk, tiles_c, limT, 0, 0)
             blk += tiles_r * tiles_c
         dev = next(iter(groups.values()))[0].device
         host = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
@@ -127,6 +132,9 @@ def _w_bf16(w2d, transposed):
     if ent is not None and ent[0] == ver:
         return ent[1]
     if ent is not None:  # stale copy: refresh in place (keeps addresses stable for captured graphs)
+        if len(ent) > 3 and ent[3]:  # slice of a concatenated buffer: only the multi-tensor kernel knows its pitch
+            refresh_weight_cache()
+            return ent[1]
         if transposed:
             ops.transpose_cast_into(w2d, ent[1])
         else:
@@ -139,6 +147,31 @@ def _w_bf16(w2d, transposed):
         t = ops.scale_dropout(w2d.contiguous(), torch.bfloat16)
     _wcache[key] = [ver, t, w2d]
     return t
+
+
+def _w_bf16_cat(ws, transposed):
+    """bf16 copy of the row-concatenation of several [out_i, K] weights (out_i % 64 == 0): [sum out_i, K], or its
+    transpose [K, sum out_i].  The slices are registered in the weight cache, so refresh_weight_cache() keeps the
+    concatenation current with the same single launch -- fused Q/K/V projections need no extra copies."""
+    key = tuple(w.data_ptr() for w in ws) + (transposed,)
+    buf = _wcat.get(key)
+    if buf is None:
+        K = ws[0].shape[1]
+        total = sum(w.shape[0] for w in ws)
+        assert all(w.shape[1] == K and w.shape[0] % 64 == 0 and w.dtype == torch.float32 and w.is_contiguous() for w in ws)
+        buf = torch.empty((K, total) if transposed else (total, K), dtype=torch.bfloat16, device=ws[0].device)
+        off = 0
+        for w in ws:
+            sl = buf[:, off:off + w.shape[0]] if transposed else buf[off:off + w.shape[0]]
+            _wcache[(w.data_ptr(), transposed, tuple(w.shape))] = [-1, sl, w, True]
+            off += w.shape[0]
+        _wcat[key] = buf
+        _wtable["built_for"] = -1
+        refresh_weight_cache()
+    else:
+        for w in ws:
+            _w_bf16(w, transposed)  # refreshes everything if one slice is stale
+    return buf
 
 
 def _fast_ok(a, K, lda):
@@ -169,27 +202,51 @@ def _gemm_nn(a, w, M, N, K, out, *, lda=None, ldb=None, ldc=None, **kw):
 
 class _ZeroArena:
     """Hands out zero-initialised f32 scratch (bias / LayerNorm / split-K accumulators) as slices of large chunks
-    that are zero-filled once: one fill kernel per ~64 MiB instead of one per tensor.  A slice is never handed out
-    twice; chunks are freed by the allocator when their last view dies."""
+    that are zero-filled once: one fill kernel per 64 MiB instead of one per tensor.  A slice is never handed out
+    twice; chunks are freed by the allocator when their last view dies.
+
+    hipGraph capture: a captured step must not bake in slices of a chunk that was filled OUTSIDE the capture (it
+    would be neither re-zeroed on replay nor guaranteed to stay mapped), so new_step() drops the current chunk when
+    called under capture, and chunks allocated under capture are kept alive for the life of the process -- their
+    fill node is part of the graph, every replay starts from zeros."""
 
     CHUNK = 16 * 1024 * 1024  # floats
 
     def __init__(self):
         self.buf = {}
+        self.keep = []
+
+    @staticmethod
+    def _capturing(device):
+        return device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+
+    def new_step(self):
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            self.buf.clear()
 
     def take(self, n, device):
         n_al = (n + 63) // 64 * 64
+        cap = self._capturing(device)
         if n_al > self.CHUNK // 4:
-            return torch.zeros(n, dtype=torch.float32, device=device)
+            t = torch.zeros(n, dtype=torch.float32, device=device)
+            return t
         ent = self.buf.get(device)
-        if ent is None or ent[1] + n_al > ent[0].numel():
-            ent = self.buf[device] = [torch.zeros(self.CHUNK, dtype=torch.float32, device=device), 0]
+        if ent is None or ent[1] + n_al > ent[0].numel() or (cap and not ent[2]):
+            ent = self.buf[device] = [torch.zeros(self.CHUNK, dtype=torch.float32, device=device), 0, cap]
+            if cap:
+                self.keep.append(ent[0])
         out = ent[0][ent[1]: ent[1] + n]
         ent[1] += n_al
         return out
 
 
 _arena = _ZeroArena()
+
+
+def new_step():
+    """Call at the start of every training step that may be captured into a hipGraph (bench.py, train_native.py):
+    makes the zero-scratch arena start the step on a chunk whose fill belongs to the capture."""
+    _arena.new_step()
 
 
 def _zeros(shape, device):
@@ -595,35 +652,48 @@ class MhaSublayerFn(torch.autograd.Function):
         cross = memory is not None
         ka = _to_act(memory) if cross else h
         Tk = ka.shape[1]
-        q = _proj(h, wq, bq, B * Tq, D)
-        k = _proj(ka, wk, bk, B * Tk, D)
-        v = _proj(ka, wv, bv, B * Tk, D)
+        # self attention in bf16: ONE projection GEMM onto the concatenated [Wq; Wk; Wv] (N = 3D fills the chip where
+        # three N = D launches do not); q / k / v are column thirds of its output, read in place by the attention kernel
+        fused = _FUSE_QKV and (not cross) and (not _state["precise"]) and D % 64 == 0 and T == torch.bfloat16 \
+            and all(w.dtype == torch.float32 and w.is_contiguous() for w in (wq, wk, wv))
         relpos = pos_emb is not None
+        if fused:
+            qkv = torch.empty(B * Tq, 3 * D, dtype=T, device=x.device)
+            ops.gemm_bf16_nt(h, D, _w_bf16_cat((wq, wk, wv), False), D, B * Tq, 3 * D, D, qkv, 3 * D,
+                             bias=torch.cat([bq, bk, bv]))
+            q5 = qkv.view(B, Tq, 3, H, dk)
+            q, k4, v4 = qkv, q5[:, :, 1], q5[:, :, 2]
+            ldq = 3 * D
+        else:
+            q = _proj(h, wq, bq, B * Tq, D)
+            k4 = _proj(ka, wk, bk, B * Tk, D).view(B, Tk, H, dk)
+            v4 = _proj(ka, wv, bv, B * Tk, D).view(B, Tk, H, dk)
+            ldq = D
         pe = pproj = qv = None
         if relpos:
             pe = _to_act(pos_emb.reshape(-1, D))
             pproj = torch.empty(pe.shape[0], D, dtype=T, device=x.device)
             _gemm_nt(pe, wpos, pe.shape[0], D, D, pproj)
-            qu, qv = ops.head_bias_fwd(q, D, B * Tq, D, bias_u.reshape(-1), bias_v.reshape(-1))
+            qu, qv = ops.head_bias_fwd(q, ldq, B * Tq, D, bias_u.reshape(-1), bias_v.reshape(-1))
+            qu, qv = qu.view(B, Tq, H, dk), qv.view(B, Tq, H, dk)
         else:
-            qu = q
+            qu = q5[:, :, 0] if fused else q.view(B, Tq, H, dk)
         pa, sa, sda = _drop_args(p_attn, x)
         m = _mask_arg(mask)
-        ctxv, lse = ops.attention_fwd(qu.view(B, Tq, H, dk), qv.view(B, Tq, H, dk) if relpos else None,
-                                      k.view(B, Tk, H, dk), v.view(B, Tk, H, dk), pproj, m, 1.0 / math.sqrt(dk),
+        ctxv, lse = ops.attention_fwd(qu, qv, k4, v4, pproj, m, 1.0 / math.sqrt(dk),
                                       precise=_state["precise"], drop_p=pa, seed=sa, seed_dev=sda)
         po, so, sdo = _drop_args(p_out, x)
         y = torch.empty_like(x)
         _gemm_nt(ctxv, wo, B * Tq, D, D, y, bias=bo, drop_p=po, seed=so, seed_dev=sdo, resid=x, ldr=D)
-        ctx.save_for_backward(x, ln_w, mean, rstd, h, ka if cross else None, pe, m, wq, wk, wv, wo, wpos, qu, qv, k, v,
+        ctx.save_for_backward(x, ln_w, mean, rstd, h, ka if cross else None, pe, m, wq, wk, wv, wo, wpos, qu, qv, k4, v4,
                               pproj, ctxv, lse)
-        ctx.meta = (H, pa, sa, sda, po, so, sdo, cross, relpos)
+        ctx.meta = (H, pa, sa, sda, po, so, sdo, cross, relpos, fused)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x, ln_w, mean, rstd, h, ka, pe, m, wq, wk, wv, wo, wpos, qu, qv, k, v, pproj, ctxv, lse) = ctx.saved_tensors
-        H, pa, sa, sda, po, so, sdo, cross, relpos = ctx.meta
+        (x, ln_w, mean, rstd, h, ka, pe, m, wq, wk, wv, wo, wpos, qu, qv, k4, v4, pproj, ctxv, lse) = ctx.saved_tensors
+        H, pa, sa, sda, po, so, sdo, cross, relpos, fused = ctx.meta
         dy = dy.contiguous()
         B, Tq, D = x.shape
         if not cross:
@@ -635,45 +705,59 @@ class MhaSublayerFn(torch.autograd.Function):
         dwo = _wgrad(g, ctxv, B * Tq, D, D, dyT=gT, xT=_xT(ctxv.view(B * Tq, D), B * Tq, D))
         dctx = torch.empty(B, Tq, D, dtype=T, device=x.device)
         _gemm_nn(g, wo, B * Tq, D, D, dctx)
+        outs = {}
+        if fused:  # dq | dk | dv land side by side: one bias-gradient pass, one weight-gradient GEMM, one data-gradient GEMM
+            dqkv = torch.empty(B * Tq, 3 * D, dtype=T, device=x.device)
+            d5 = dqkv.view(B, Tq, 3, H, dk)
+            outs = dict(dk_out=d5[:, :, 1], dv_out=d5[:, :, 2])
+            if not relpos:
+                outs["dqu_out"] = d5[:, :, 0]
         dqu, dqv, dk_, dv_, dpos = ops.attention_bwd(
-            qu.view(B, Tq, H, dk), qv.view(B, Tq, H, dk) if relpos else None, k.view(B, Tk, H, dk),
-            v.view(B, Tk, H, dk), pproj, m, ctxv, lse, dctx, 1.0 / math.sqrt(dk), precise=_state["precise"],
-            drop_p=pa, seed=sa, seed_dev=sda)
+            qu, qv, k4, v4, pproj, m, ctxv, lse, dctx, 1.0 / math.sqrt(dk), precise=_state["precise"],
+            drop_p=pa, seed=sa, seed_dev=sda, **outs)
         du = dv_bias = dwpos = None
         if relpos:
-            dq = torch.empty(B * Tq, D, dtype=T, device=x.device)
+            dq = dqkv if fused else torch.empty(B * Tq, D, dtype=T, device=x.device)
             du = _zeros(D, x.device)
             dv_bias = _zeros(D, x.device)
-            ops.head_bias_bwd(dqu, dqv, dq, D, du, dv_bias, B * Tq, D)
+            ops.head_bias_bwd(dqu, dqv, dq, 3 * D if fused else D, du, dv_bias, B * Tq, D)
             du, dv_bias = du.view(H, dk), dv_bias.view(H, dk)
             dwpos = _wgrad(dpos, pe, pe.shape[0], D, D)
-        else:
+        elif not fused:
             dq = dqu.view(B * Tq, D)
-        dk2, dv2 = dk_.view(B * Tk, D), dv_.view(B * Tk, D)
-        hT = _xT(h.view(B * Tq, D), B * Tq, D)
-        kaT = hT if not cross else _xT(ka.view(B * Tk, D), B * Tk, D)
-        _, dqT, dbq = _prologue(dq, B * Tq, D, want_dst=False)
-        _, dkT, dbk = _prologue(dk2, B * Tk, D, want_dst=False)
-        _, dvT, dbv = _prologue(dv2, B * Tk, D, want_dst=False)
-        dwq = _wgrad(dq, h, B * Tq, D, D, xT=hT, dyT=dqT)
-        dwk = _wgrad(dk2, ka, B * Tk, D, D, xT=kaT, dyT=dkT)
-        dwv = _wgrad(dv2, ka, B * Tk, D, D, xT=kaT, dyT=dvT)
         dmem = None
-        if cross:
-            dh = torch.empty(B * Tq, D, dtype=T, device=x.device)
-            _gemm_nn(dq, wq, B * Tq, D, D, dh)
-            if ctx.needs_input_grad[1]:
-                t2 = torch.empty(B * Tk, D, dtype=torch.float32, device=x.device)
-                _gemm_nn(dk2, wk, B * Tk, D, D, t2)
-                dmem = torch.empty(B, Tk, D, dtype=torch.float32, device=x.device)
-                _gemm_nn(dv2, wv, B * Tk, D, D, dmem, resid=t2, ldr=D)
+        if fused:
+            _, _, dbc = _prologue(dqkv, B * Tq, 3 * D, want_dst=False)
+            dwc = _wgrad(dqkv, h, B * Tq, 3 * D, D)
+            dwq, dwk, dwv = dwc[:D], dwc[D:2 * D], dwc[2 * D:]
+            dbq, dbk, dbv = dbc[:D], dbc[D:2 * D], dbc[2 * D:]
+            dh = torch.empty(B * Tq, D, dtype=torch.float32, device=x.device)
+            ops.gemm_bf16_nt(dqkv, 3 * D, _w_bf16_cat((wq, wk, wv), True), 3 * D, B * Tq, D, 3 * D, dh, D)
         else:
-            t1 = torch.empty(B * Tq, D, dtype=torch.float32, device=x.device)
-            _gemm_nn(dq, wq, B * Tq, D, D, t1)
-            t2 = torch.empty_like(t1)
-            _gemm_nn(dk2, wk, B * Tq, D, D, t2, resid=t1, ldr=D)
-            dh = torch.empty_like(t1)
-            _gemm_nn(dv2, wv, B * Tq, D, D, dh, resid=t2, ldr=D)
+            dk2, dv2 = dk_.view(B * Tk, D), dv_.view(B * Tk, D)
+            hT = _xT(h.view(B * Tq, D), B * Tq, D)
+            kaT = hT if not cross else _xT(ka.view(B * Tk, D), B * Tk, D)
+            _, dqT, dbq = _prologue(dq, B * Tq, D, want_dst=False)
+            _, dkT, dbk = _prologue(dk2, B * Tk, D, want_dst=False)
+            _, dvT, dbv = _prologue(dv2, B * Tk, D, want_dst=False)
+            dwq = _wgrad(dq, h, B * Tq, D, D, xT=hT, dyT=dqT)
+            dwk = _wgrad(dk2, ka, B * Tk, D, D, xT=kaT, dyT=dkT)
+            dwv = _wgrad(dv2, ka, B * Tk, D, D, xT=kaT, dyT=dvT)
+            if cross:
+                dh = torch.empty(B * Tq, D, dtype=T, device=x.device)
+                _gemm_nn(dq, wq, B * Tq, D, D, dh)
+                if ctx.needs_input_grad[1]:
+                    t2 = torch.empty(B * Tk, D, dtype=torch.float32, device=x.device)
+                    _gemm_nn(dk2, wk, B * Tk, D, D, t2)
+                    dmem = torch.empty(B, Tk, D, dtype=torch.float32, device=x.device)
+                    _gemm_nn(dv2, wv, B * Tk, D, D, dmem, resid=t2, ldr=D)
+            else:
+                t1 = torch.empty(B * Tq, D, dtype=torch.float32, device=x.device)
+                _gemm_nn(dq, wq, B * Tq, D, D, t1)
+                t2 = torch.empty_like(t1)
+                _gemm_nn(dk2, wk, B * Tq, D, D, t2, resid=t1, ldr=D)
+                dh = torch.empty_like(t1)
+                _gemm_nn(dv2, wv, B * Tq, D, D, dh, resid=t2, ldr=D)
         dg = _zeros(D, x.device)
         dbt = _zeros(D, x.device)
         dx = ops.layernorm_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dres=dy)

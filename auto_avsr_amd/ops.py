@@ -95,12 +95,14 @@ def attention_fwd(qu, qv, k, v, pos, mask, scale, *, precise=False, drop_p=0.0, 
 
 
 def attention_bwd_dq(qu, qv, k, v, pos, mask, out, lse, dout, scale, *, precise=False, drop_p=0.0, seed=0,
-                     seed_dev=None):
+                     seed_dev=None, dqu_out=None):
     B, Tq, H, dk = qu.shape
     Tk = k.shape[1]
     lds = (Tk + 7) // 8 * 8
-    dqu = torch.empty(B, Tq, H, dk, dtype=qu.dtype, device=qu.device)
-    dqv = torch.empty_like(dqu) if pos is not None else None
+    # the kernel addresses dqu / dqv with qu's strides: dqu_out (a [B,Tq,H,64] view, e.g. the q third of a fused
+    # d(qkv) buffer) must be laid out like qu
+    dqu = dqu_out if dqu_out is not None else torch.empty(B, Tq, H, dk, dtype=qu.dtype, device=qu.device)
+    dqv = torch.empty(B, Tq, H, dk, dtype=qu.dtype, device=qu.device) if pos is not None else None
     # pad columns [Tk, lds) are never read: the TN loaders mask by the logical width
     pd = torch.empty(B, H, Tq, lds, dtype=qu.dtype, device=qu.device)
     ds = torch.empty(B, H, Tq, lds, dtype=qu.dtype, device=qu.device)
@@ -108,8 +110,8 @@ def attention_bwd_dq(qu, qv, k, v, pos, mask, out, lse, dout, scale, *, precise=
     if mask is not None:
         msb = mask.shape[1] * mask.shape[2]
         msq = mask.shape[2] if mask.shape[1] > 1 else 0
-    # dqu/dqv are laid out like a contiguous [B,Tq,H,64]; the kernel uses qu's strides for them, so require equality
-    assert qu.stride(1) == H * dk and qu.stride(0) == Tq * H * dk, "bwd expects contiguous qu/qv"
+    assert dqu.stride() == qu.stride() and (dqv is None or (dqv.stride() == qu.stride() and qv.stride() == qu.stride())), \
+        "bwd writes dqu/dqv with qu's strides"
     call("avsr_attention_bwd_dq", _ptr(qu), _ptr(qv), _ptr(k), _ptr(v), _ptr(pos), dt(qu), int(precise), _ptr(mask),
          msb, msq, _ptr(out), _ptr(lse), _ptr(dout), _ptr(dqu), _ptr(dqv), _ptr(pd), _ptr(ds), lds, B, H, Tq, Tk, dk,
          qu.stride(1), k.stride(1), v.stride(1), pos.stride(0) if pos is not None else 0, out.stride(1),
@@ -125,22 +127,23 @@ def gemm_tn_batched(A, lda, sAb, sAh, Bm, ldb, sBb, sBh, C, ldc, sCb, sCh, nb, n
 
 
 def attention_bwd(qu, qv, k, v, pos, mask, out, lse, dout, scale, *, precise=False, drop_p=0.0, seed=0,
-                  seed_dev=None):
-    """Full attention backward.  Returns dqu, dqv (or None), dk, dv, dpos (f32 [2T-1, H*64] or None)."""
+                  seed_dev=None, dqu_out=None, dk_out=None, dv_out=None):
+    """Full attention backward.  Returns dqu, dqv (or None), dk, dv, dpos (f32 [2T-1, H*64] or None).
+    dqu_out / dk_out / dv_out: optional [B,T,H,64] destination views (slices of a fused d(qkv) buffer)."""
     B, Tq, H, dk = qu.shape
     Tk = k.shape[1]
     D = H * dk
     dqu, dqv, pd, ds = attention_bwd_dq(qu, qv, k, v, pos, mask, out, lse, dout, scale, precise=precise,
-                                        drop_p=drop_p, seed=seed, seed_dev=seed_dev)
+                                        drop_p=drop_p, seed=seed, seed_dev=seed_dev, dqu_out=dqu_out)
     lds = pd.shape[-1]
-    dkk = torch.empty(B, Tk, H, dk, dtype=qu.dtype, device=qu.device)
-    dvv = torch.empty(B, Tk, H, dk, dtype=qu.dtype, device=qu.device)
+    dkk = dk_out if dk_out is not None else torch.empty(B, Tk, H, dk, dtype=qu.dtype, device=qu.device)
+    dvv = dv_out if dv_out is not None else torch.empty(B, Tk, H, dk, dtype=qu.dtype, device=qu.device)
     do4 = dout.view(B, Tq, H, dk)
     # dV[b,h] = Pd[b,h]^T dO[b,h] ; dK[b,h] = dS[b,h]^T Qu[b,h]
-    gemm_tn_batched(pd, lds, H * Tq * lds, Tq * lds, do4, do4.stride(1), do4.stride(0), dk, dvv, D, Tk * D, dk,
-                    B, H, Tk, dk, Tq, precise=precise)
-    gemm_tn_batched(ds, lds, H * Tq * lds, Tq * lds, qu, qu.stride(1), qu.stride(0), dk, dkk, D, Tk * D, dk,
-                    B, H, Tk, dk, Tq, precise=precise)
+    gemm_tn_batched(pd, lds, H * Tq * lds, Tq * lds, do4, do4.stride(1), do4.stride(0), dk, dvv, dvv.stride(1),
+                    dvv.stride(0), dk, B, H, Tk, dk, Tq, precise=precise)
+    gemm_tn_batched(ds, lds, H * Tq * lds, Tq * lds, qu, qu.stride(1), qu.stride(0), dk, dkk, dkk.stride(1),
+                    dkk.stride(0), dk, B, H, Tk, dk, Tq, precise=precise)
     dpos = None
     if pos is not None:
         dpos = torch.zeros(2 * Tq - 1, D, dtype=torch.float32, device=qu.device)
@@ -365,13 +368,16 @@ def conv2d_dgrad(dy, wpd, resid, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, pre
 
 def conv2d_wgrad(dy, x, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise):
     OH, OW = conv_out(H, KH, stride, ph), conv_out(W, KW, stride, pw)
-    dwp = torch.zeros(Cout, KH * KW * Cin, dtype=torch.float32, device=x.device)
     bf = not precise and x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
     if bf and KH == 3 and KW == 3 and ph == 1 and pw == 1 and stride <= 2 and Cin % 64 == 0 and Cout % 64 == 0 \
             and (OW - 1) * stride + 3 <= 64:
-        call("avsr_conv3x3_wgrad_bf16", _ptr(dy), _ptr(x), _ptr(dwp), _ptr(zero_page(x.device)), N, H, W, Cin, Cout, stride,
-             _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin)
+        dwp = torch.empty(Cout, KH * KW * Cin, dtype=torch.float32, device=x.device)
+        nws = call("avsr_conv3x3_wgrad_workspace_bytes", N, H, W, Cin, Cout, stride)
+        ws = torch.empty(nws // 4, dtype=torch.float32, device=x.device)
+        call("avsr_conv3x3_wgrad_bf16", _ptr(dy), _ptr(x), _ptr(dwp), _ptr(zero_page(x.device)), _ptr(ws), nws, N, H, W, Cin,
+             Cout, stride, _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin)
         return dwp
+    dwp = torch.zeros(Cout, KH * KW * Cin, dtype=torch.float32, device=x.device)
     if bf and Cin % 64 == 0 and Cout % 8 == 0:
         call("avsr_conv2d_wgrad_bf16", _ptr(dy), _ptr(x), _ptr(dwp), _ptr(zero_page(x.device)), N, H, W, Cin, Cout, KH,
              KW, stride, ph, pw, _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin)

@@ -118,6 +118,7 @@ def main():
     graphs = {}
 
     def eager_step(x, lens, y):
+        AF.new_step()
         seed_dev.add_(1)
         AF.refresh_weight_cache()  # an optimizer step would change the weights: pay the bf16 re-casts every step
         loss = hot(x, lens, y)

@@ -211,7 +211,9 @@ int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int
                       avsr_stream_t stream);
 /* Tuning knobs of the tuned kernels (process-wide; meant for benchmarks, defaults are the measured best):
  * knob 0 = tile code forced on avsr_conv2d_bf16 (0 = auto), 1 = XCD-aware tile order (default 0: measured neutral to slower),
- * 2 = ablation mode of the 128x128 forward convolution kernel (1 = no MFMA, 2 = no operand loads; wrong results). */
+ * 2 = ablation mode of the 128x128 forward convolution kernel (1 = no MFMA, 2 = no operand loads; wrong results),
+ * 3 = avsr_conv3x3_wgrad_bf16 output stage (0 = as the workspace argument says, 1 = always atomics, 2 = none),
+ * 4 = 1 disables the XCD-aware work order of avsr_conv3x3_wgrad_bf16. */
 int avsr_tune(int knob, int value);
 /* bf16 implicit-GEMM convolution on the tuned LDS-DMA kernel: dgrad = 0 forward, 1 data gradient (see
  * avsr_conv2d_fwd / avsr_conv2d_dgrad for the tensor conventions); gathered channel count % 64 == 0; stride 1 or 2
@@ -252,9 +254,13 @@ int avsr_conv2d_wgrad_bf16(const void* dy, const void* x, float* dwp, const void
                            avsr_stream_t stream);
 /* weight gradient of a 3x3 / pad 1 convolution, stride 1 or 2 (conv_wgrad.hip; reference resnet.py:10-35 under
  * autograd): one zero-padded x patch per pixel tile serves all nine taps as shifted LDS views; Cin, Cout % 64 == 0;
- * dwp [Cout][3][3][Cin] f32, caller zeroes */
-int avsr_conv3x3_wgrad_bf16(const void* dy, const void* x, float* dwp, const void* zero_page, int N, int H, int W,
-                            int Cin, int Cout, int stride, avsr_stream_t stream);
+ * dwp [Cout][3][3][Cin] f32.  With a workspace of avsr_conv3x3_wgrad_workspace_bytes() dwp is overwritten with the
+ * ordered (deterministic) sum of per-block partial gradients; with workspace = NULL the blocks atomicAdd into dwp,
+ * which the caller must have zeroed. */
+int64_t avsr_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int stride);
+int avsr_conv3x3_wgrad_bf16(const void* dy, const void* x, float* dwp, const void* zero_page, void* workspace,
+                            int64_t workspace_bytes, int N, int H, int W, int Cin, int Cout, int stride,
+                            avsr_stream_t stream);
 
 #ifdef __cplusplus
 }

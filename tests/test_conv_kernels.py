@@ -82,7 +82,8 @@ def test_conv2d_bf16_tiles(dev, cfg, tile):
     (3, 22, 22, 64, 64, 1), (5, 11, 11, 128, 64, 1), (7, 6, 6, 64, 128, 1), (17, 3, 3, 64, 64, 1),
     (3, 22, 22, 64, 128, 2), (4, 11, 11, 64, 64, 2), (5, 6, 6, 128, 64, 2), (2, 9, 13, 64, 64, 1), (2, 7, 10, 64, 64, 2),
 ])
-def test_conv3x3_wgrad_direct(dev, cfg):
+@pytest.mark.parametrize("partial", [True, False])
+def test_conv3x3_wgrad_direct(dev, cfg, partial):
     """Dedicated 3x3 weight-gradient kernel (shifted LDS views of one padded patch) vs torch autograd."""
     N, H, W, Cin, Cout, s = cfg
     torch.manual_seed(H * 31 + N)
@@ -94,8 +95,13 @@ def test_conv3x3_wgrad_direct(dev, cfg):
     OH, OW = y.shape[2], y.shape[3]
     dwp = torch.zeros(Cout, 9 * Cin, dtype=torch.float32, device=dev)
     dyd, xd = nhwc(dy).bfloat16().to(dev), nhwc(x).bfloat16().to(dev)
-    ops.call("avsr_conv3x3_wgrad_bf16", ops._ptr(dyd), ops._ptr(xd), ops._ptr(dwp), ops._ptr(ops.zero_page(dev)), N, H, W, Cin,
-             Cout, s, ops._stream(dwp))
+    nws = ops.call("avsr_conv3x3_wgrad_workspace_bytes", N, H, W, Cin, Cout, s)
+    assert nws > 0 and nws % (Cout * 9 * Cin * 4) == 0
+    ws = torch.full((nws // 4,), float("nan"), device=dev) if partial else None  # every partial slot must be written
+    if partial:
+        dwp.fill_(float("nan"))  # partial mode overwrites
+    ops.call("avsr_conv3x3_wgrad_bf16", ops._ptr(dyd), ops._ptr(xd), ops._ptr(dwp), ops._ptr(ops.zero_page(dev)),
+             ops._ptr(ws), nws if partial else 0, N, H, W, Cin, Cout, s, ops._stream(dwp))
     dw = ops.conv_weight_unpermute(dwp, w.shape)
     assert (dw.cpu() - w.grad).abs().max() < 2e-3 * max(1.0, w.grad.abs().max().item())
 

@@ -161,3 +161,54 @@ def test_weight_cache_refresh(dev):
     gx = lin2.weight.detach().cpu().bfloat16().float().sum(0)
     assert (x2.grad.float().cpu() - gx).abs().max() < 0.02 * gx.abs().max()
     AF.invalidate_weight_cache()
+
+
+@pytest.mark.parametrize("relpos", [True, False])
+def test_fused_qkv_projection(dev, relpos):
+    """bf16 self attention runs ONE projection GEMM onto [Wq; Wk; Wv] (and one weight- / data-gradient GEMM in the
+    backward).  Must agree with the three-GEMM path (forced through precise mode's f32 reference within bf16
+    tolerance), keep agreeing after an optimizer-style weight update + refresh_weight_cache(), and hand back
+    per-parameter gradients."""
+    torch.manual_seed(11)
+    AF.invalidate_weight_cache()
+    B, T, D, H = 2, 9, 128, 2
+    from auto_avsr_amd import nets
+    att = (nets.RelPositionMultiHeadedAttention(H, D, 0.0) if relpos else nets.MultiHeadedAttention(H, D, 0.0)).to(dev)
+    ln = torch.nn.LayerNorm(D).to(dev)
+    x = torch.randn(B, T, D, device=dev)
+    pos = torch.randn(1, 2 * T - 1, D, device=dev) if relpos else None
+    mask = torch.ones(B, 1, T, dtype=torch.bool, device=dev)
+    mask[1, 0, 6:] = False
+    params = [att.linear_q, att.linear_k, att.linear_v, att.linear_out]
+
+    def run(precise):
+        AF.set_precise(precise)
+        for p in att.parameters():
+            p.grad = None
+        xx = x.clone().requires_grad_()
+        extra = (att.linear_pos.weight, att.pos_bias_u, att.pos_bias_v) if relpos else (None, None, None)
+        y = AF.mha_sublayer(xx, None, pos, mask, ln.weight, ln.bias, att.linear_q.weight, att.linear_q.bias,
+                            att.linear_k.weight, att.linear_k.bias, att.linear_v.weight, att.linear_v.bias,
+                            att.linear_out.weight, att.linear_out.bias, *extra, H, 0.0, 0.0)
+        (y * torch.linspace(-1, 1, D, device=dev)).sum().backward()
+        return y.detach().float().cpu(), xx.grad.float().cpu(), [l.weight.grad.float().cpu().clone() for l in params], \
+            [l.bias.grad.float().cpu().clone() for l in params]
+
+    try:
+        for round_ in range(2):
+            ref = run(True)
+            got = run(False)
+            assert (got[0] - ref[0]).abs().max() < 0.05 * ref[0].abs().max()
+            assert (got[1] - ref[1]).abs().max() < 0.05 * ref[1].abs().max()
+            for grp in (2, 3):  # weights, biases; dL/d(bias_k) is analytically zero (softmax shift invariance), so
+                floor = max(b.abs().max().item() for b in ref[grp])  # tolerances are relative to the group's scale
+                for a, b in zip(got[grp], ref[grp]):
+                    assert a.shape == b.shape and (a - b).abs().max() < 0.05 * max(b.abs().max().item(), 0.2 * floor)
+            with torch.no_grad():  # optimizer step: every cached bf16 copy (concatenated or not) is stale now
+                for l in params:
+                    l.weight.mul_(0.5)
+                    l.weight.add_(0.01)
+            AF.refresh_weight_cache()
+    finally:
+        AF.set_precise(False)
+        AF.invalidate_weight_cache()

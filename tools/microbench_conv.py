@@ -36,6 +36,15 @@ for name, H, W, Cin, Cout, K, s, p in layers:
                   ("wgrad", lambda: ops.conv2d_wgrad(dy, x, N, H, W, Cin, Cout, K, K, s, p, p, False))):
         us = timeit(f)
         rows.append(dict(layer=name, op=op, us=round(us, 1), tflops=round(fl / us / 1e6, 1)))
+        if op == "wgrad":  # output stage of the dedicated 3x3 kernel: partial sums + reduce (default) / atomics / none
+            for mode, tag in ((1, "atomics_us"), (2, "no_output_us")):
+                ops.tune(3, mode)
+                rows[-1][tag] = round(timeit(f), 1)
+            ops.tune(3, 0)
+            ops.tune(3, 2)
+            for abl in (0, 1, 2, 3, 4, 8, 15):
+                ops.tune(5, abl); rows[-1][f"abl{abl}"] = round(timeit(f), 1)
+            ops.tune(5, 0); ops.tune(3, 0)
         print(rows[-1], flush=True)
 if which in ("all", "stem"):
     B, T = 4, 400

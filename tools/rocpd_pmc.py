@@ -16,6 +16,6 @@ cols = [r[1] for r in cur.execute(f"pragma table_info({kd})")]
 evcol = "event_id" if "event_id" in cols else "id"
 ev_of = dict(cur.execute(f"select id, {evcol} from {kd}"))
 for did, name, st, en, grid in rows:
-    if "gemm" not in name: continue
+    if "gemm" not in name and "wgrad" not in name: continue
     v = vals.get(ev_of[did], {})
     print(re.sub(r"\(.*", "", name)[:60], f"{(en-st)/1e3:.1f}us", {k: int(x) for k, x in sorted(v.items())})
