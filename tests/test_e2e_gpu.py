@@ -72,3 +72,61 @@ def test_full_e2e_bf16_vs_oracle():
         if b.norm() > 1e-3 * max(1.0, float(osd[k].double().norm()) * 1e-3):
             cos.append(float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)))
     assert min(cos) > 0.9 and sum(cos) / len(cos) > 0.99, (min(cos), sum(cos) / len(cos))
+
+
+def test_hipgraph_replay_matches_eager():
+    """The bench path: a training step captured into a hipGraph (per batch shape) must reproduce the eager
+    gradients on EVERY replay -- zero-initialised accumulators re-zeroed, fresh cast of the weights, no buffer of the
+    capture freed or reused afterwards (two shapes are captured before either graph is replayed)."""
+    from auto_avsr_amd import functional as AF
+
+    m, _ = _model("video", 9)
+    AF.invalidate_weight_cache()
+    batches = [synth_batch("video", 2, 24, 6, 5049, seed=3, lengths=[24, 17]),
+               synth_batch("video", 3, 16, 5, 5049, seed=4, lengths=[16, 16, 9])]
+    batches = [tuple(t.cuda() for t in b) for b in batches]
+
+    def step(b):
+        AF.new_step()
+        AF.refresh_weight_cache()
+        loss, *_ = m.forward_tensors(*b)
+        loss.backward()
+
+    eager = []
+    # never touch the legacy default stream: gradient-accumulation nodes remember the stream they were created on, and
+    # a node bound to the default stream would make the capture below synchronise with it (illegal under capture)
+    work = torch.cuda.Stream()
+    work.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(work):
+        for b in batches:
+            m.zero_grad(set_to_none=True)
+            step(b)
+            eager.append({k: p.grad.float().clone() for k, p in m.named_parameters()})
+    torch.cuda.current_stream().wait_stream(work)
+    torch.cuda.synchronize()
+    graphs, grads = [], []
+    for b in batches:
+        m.zero_grad(set_to_none=True)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step(b)
+            m.zero_grad(set_to_none=True)
+        torch.cuda.current_stream().wait_stream(side)
+        AF.refresh_weight_cache()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step(b)
+        graphs.append(g)
+        grads.append({k: p.grad for k, p in m.named_parameters()})  # static buffers of this capture
+    for rep in range(3):
+        for gi in (1, 0):
+            graphs[gi].replay()
+            torch.cuda.synchronize()
+            for k, ref in eager[gi].items():
+                got = grads[gi][k].float()
+                assert torch.isfinite(got).all(), k
+                tol = 2e-2 * max(float(ref.abs().max()), 1e-6) + 1e-6
+                assert float((got - ref).abs().max()) <= tol, (rep, gi, k, float((got - ref).abs().max()), tol)
+    AF.invalidate_weight_cache()
