@@ -39,43 +39,58 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c0 = blockIdx.x * DW_CH, t0 = blockIdx.y * DW_TT, b = blockIdx.z;
     const int pad = (K - 1) / 2;
-    stage_time_tile<T>(xs, x, b, t0 - pad, DW_TT + K - 1, Tlen, C, c0);
-    for (int k = ty; k < K; k += 4) ws[k * DW_CH + tx] = (c0 + tx < C) ? w[(long)(c0 + tx) * K + (flip ? K - 1 - k : k)] : 0.f;
+    // all DW_MAXK taps are always multiplied (weights beyond K are zero, their x rows staged as real data or zeros):
+    // a fixed trip count lets the LDS reads of the taps issue back to back
+    stage_time_tile<T>(xs, x, b, t0 - pad, DW_TT + DW_MAXK - 1, Tlen, C, c0);
+    for (int k = ty; k < DW_MAXK; k += 4)
+        ws[k * DW_CH + tx] = (k < K && c0 + tx < C) ? w[(long)(c0 + tx) * K + (flip ? K - 1 - k : k)] : 0.f;
     __syncthreads();
     const float bv = (bias && c0 + tx < C) ? bias[c0 + tx] : 0.f;
 #pragma unroll
     for (int o = 0; o < DW_TT / 4; o++) {
         const int t = ty * (DW_TT / 4) + o;
         float acc = bv;
-        for (int k = 0; k < K; k++) acc += ws[k * DW_CH + tx] * xs[(t + k) * DW_CH + tx];
+#pragma unroll
+        for (int k = 0; k < DW_MAXK; k++) acc += ws[k * DW_CH + tx] * xs[(t + k) * DW_CH + tx];
         if (t0 + t < Tlen && c0 + tx < C) Elem<T>::st(y + ((long)b * Tlen + t0 + t) * C + c0 + tx, acc);
     }
 }
 
 // dw[c,k] += sum_{b,t} dy[b,t,c] x[b,t+k-pad,c] ;  db[c] += sum dy
+// A block owns 64 channels and walks every gridDim.y-th (batch element, 64-step time tile) pair with its sums in
+// registers; one round of atomics per block at the end.  (One block per tile put B*T/64 colliding atomics on every
+// 128-byte line of dw -- one line per channel -- and the serialised atomics, not the arithmetic, set the kernel time.)
 template <class T>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                           float* __restrict__ dw, float* __restrict__ db, int Tlen,
+                                                           float* __restrict__ dw, float* __restrict__ db, int B, int Tlen,
                                                            int C, int K) {
     __shared__ float xs[(DW_TW + DW_MAXK - 1) * DW_CH];
     __shared__ float ds[DW_TW * DW_CH];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c0 = blockIdx.x * DW_CH, t0 = blockIdx.y * DW_TW, b = blockIdx.z;
+    const int c0 = blockIdx.x * DW_CH;
     const int pad = (K - 1) / 2;
-    stage_time_tile<T>(xs, x, b, t0 - pad, DW_TW + K - 1, Tlen, C, c0);
-    stage_time_tile<T>(ds, dy, b, t0, DW_TW, Tlen, C, c0);
-    __syncthreads();
+    const int tiles_t = (Tlen + DW_TW - 1) / DW_TW, items = B * tiles_t;
     float acc[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) acc[i] = 0.f;
     float sb = 0.f;
-    for (int t = 0; t < DW_TW; t++) {
-        const float g = ds[t * DW_CH + tx];
-        sb += g;
+    for (int it = blockIdx.y; it < items; it += gridDim.y) {
+        const int b = it / tiles_t, t0 = (it - b * tiles_t) * DW_TW;
+        __syncthreads();  // the previous item's tiles are no longer read
+        stage_time_tile<T>(xs, x, b, t0 - pad, DW_TW + K - 1, Tlen, C, c0);
+        stage_time_tile<T>(ds, dy, b, t0, DW_TW, Tlen, C, c0);
+        __syncthreads();
+        // branch-free inner loop: taps beyond K read a clamped (valid) row and are simply never written back, so the
+        // eight LDS reads of a time step issue together instead of one latency-exposed round trip per tap
+#pragma unroll 2
+        for (int t = 0; t < DW_TW; t++) {
+            const float g = ds[t * DW_CH + tx];
+            sb += g;
+            float xv[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int k = ty + 4 * i;
-            if (k < K) acc[i] += g * xs[(t + k) * DW_CH + tx];
+            for (int i = 0; i < 8; i++) xv[i] = xs[(t + min(ty + 4 * i, K - 1)) * DW_CH + tx];
+#pragma unroll
+            for (int i = 0; i < 8; i++) acc[i] += g * xv[i];
         }
     }
     if (c0 + tx < C) {
@@ -109,11 +124,15 @@ extern "C" int avsr_dwconv_wgrad(const void* x, const void* dy, int dtype, float
     AVSR_REQUIRE(K >= 1 && K <= DW_MAXK && (K & 1), "dwconv: K must be odd and <= 31");
     AVSR_REQUIRE(C % 8 == 0, "dwconv: C must be a multiple of 8");
     if (B <= 0 || T <= 0) return 0;
-    dim3 grid((C + DW_CH - 1) / DW_CH, (T + DW_TW - 1) / DW_TW, B), block(256);
+    const int items = B * ((T + DW_TW - 1) / DW_TW), cblocks = (C + DW_CH - 1) / DW_CH;
+    int chunks = (512 + cblocks - 1) / cblocks;  // about two blocks per CU, a few items each
+    if (chunks > items) chunks = items;
+    if (chunks > 16) chunks = 16;
+    dim3 grid(cblocks, chunks), block(256);
     if (dtype == 0)
-        AVSR_LAUNCH((dwconv_wgrad_kernel<float>), grid, block, 0, stream, (const float*)x, (const float*)dy, dw, db, T, C, K);
+        AVSR_LAUNCH((dwconv_wgrad_kernel<float>), grid, block, 0, stream, (const float*)x, (const float*)dy, dw, db, B, T, C, K);
     else
-        AVSR_LAUNCH((dwconv_wgrad_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dy, dw, db, T, C, K);
+        AVSR_LAUNCH((dwconv_wgrad_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dy, dw, db, B, T, C, K);
     AVSR_CHECK_LAUNCH("dwconv_wgrad");
     return 0;
 }
