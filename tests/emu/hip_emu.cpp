@@ -169,6 +169,9 @@ static void run_block(Worker& w, dim3 grid, dim3 block, dim3 bidx, size_t dyn_sm
     w.bar_gen = 0;
     w.body = &body;
     if (w.smem.size() < dyn_smem_bytes + 64) w.smem.assign(dyn_smem_bytes + 64, 0);
+    // LDS is not zeroed by the hardware: poison the dynamic segment (0xFF bytes = NaN in f32 and bf16) so that a kernel
+    // relying on uninitialised shared memory fails on the emulator too
+    std::memset(w.smem.data(), 0xFF, w.smem.size());
     blockIdx = bidx;
     blockDim = block;
     gridDim = grid;

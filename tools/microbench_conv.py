@@ -57,5 +57,9 @@ if which in ("all", "stem"):
     rows.append(dict(layer="stem", op="fwd", us=round(us, 1), tflops=round(fl / us / 1e6, 1))); print(rows[-1], flush=True)
     us = timeit(lambda: ops.conv_stem_wgrad(dy0, xs, B, T, 88, 88, 64, 5, 7, 7, 2, 2, 3, 3, False))
     rows.append(dict(layer="stem", op="wgrad", us=round(us, 1), tflops=round(fl / us / 1e6, 1))); print(rows[-1], flush=True)
+    us = timeit(lambda: ops.stem357_fwd(xs, w0, B, T, 88, 88))
+    rows.append(dict(layer="stem357", op="fwd", us=round(us, 1), tflops=round(fl / us / 1e6, 1))); print(rows[-1], flush=True)
+    us = timeit(lambda: ops.stem357_wgrad(dy0, xs, B, T, 88, 88))
+    rows.append(dict(layer="stem357", op="wgrad", us=round(us, 1), tflops=round(fl / us / 1e6, 1))); print(rows[-1], flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(rows, open("gpurun_out/microbench_conv.json", "w"), indent=1)
