@@ -245,7 +245,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgParams p) {
 // dwp[i] = sum_z ws[z][i]: the blocks' partial gradients are combined in a fixed order (deterministic, no atomics).
 // 1024 threads = 64 float4 columns x 16 z-lanes; a z-lane sums every 16th partial with independent loads in flight,
 // then the 16 lane sums are combined through LDS in a fixed order.
-__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n4, int split) {
+// torch_layout: dw is [Cout][Cin][3][3] (what autograd hands to the optimizer) instead of [Cout][3][3][Cin]
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n4, int split,
+                                                            int Cin, int torch_layout) {
     __shared__ f32x4 part[16][64];
     const int tx = threadIdx.x & 63, tz = threadIdx.x >> 6;
     const long i = (long)blockIdx.x * 64 + tx;
@@ -272,7 +274,17 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
         for (int q = 1; q < 16; q++)
 #pragma unroll
             for (int e = 0; e < 4; e++) s[e] += part[q][tx][e];
-        reinterpret_cast<f32x4*>(dw)[i] = s;
+        if (!torch_layout) {
+            reinterpret_cast<f32x4*>(dw)[i] = s;
+        } else {
+            const long e0 = i * 4;  // = (co * 9 + tap) * Cin + ci
+            const int ci = (int)(e0 % Cin);
+            const long ct = e0 / Cin;
+            const int tap = (int)(ct % 9);
+            const long co = ct / 9;
+#pragma unroll
+            for (int e = 0; e < 4; e++) dw[(co * Cin + ci + e) * 9 + tap] = s[e];
+        }
     }
 }
 
@@ -328,7 +340,8 @@ extern "C" int64_t avsr_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int C
 // without one (workspace = NULL) the blocks atomicAdd into dwp, which the caller must have zeroed.
 extern "C" int avsr_conv3x3_wgrad_bf16(const void* dy, const void* x, float* dwp, const void* zero_page, void* workspace,
                                        int64_t workspace_bytes, int N, int H, int W, int Cin, int Cout, int stride,
-                                       hipStream_t stream) {
+                                       int torch_layout, hipStream_t stream) {
+    AVSR_REQUIRE(!torch_layout || workspace != nullptr, "conv3x3_wgrad_bf16: the torch layout needs the workspace mode");
     AVSR_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, "conv3x3_wgrad_bf16: channel counts must be multiples of 64");
     AVSR_REQUIRE(stride == 1 || stride == 2, "conv3x3_wgrad_bf16: stride must be 1 or 2");
     AVSR_REQUIRE(zero_page != nullptr, "conv3x3_wgrad_bf16: zero page required");
@@ -340,7 +353,7 @@ extern "C" int avsr_conv3x3_wgrad_bf16(const void* dy, const void* x, float* dwp
     p.dy = reinterpret_cast<const bf16_t*>(dy); p.x = reinterpret_cast<const bf16_t*>(x);
     p.zero = reinterpret_cast<const bf16_t*>(zero_page);
     const int64_t need = (int64_t)pl.split * Cout * 9 * Cin * 4;
-    const bool partial = workspace != nullptr && avsr_tune_knobs[3] != 1;
+    const bool partial = workspace != nullptr && (avsr_tune_knobs[3] != 1 || torch_layout);
     AVSR_REQUIRE(!partial || workspace_bytes >= need, "conv3x3_wgrad_bf16: workspace too small");
     p.dw = partial ? reinterpret_cast<float*>(workspace) : dwp;
     p.partial = avsr_tune_knobs[3] == 2 ? 2 : (partial ? 1 : 0);
@@ -351,7 +364,7 @@ extern "C" int avsr_conv3x3_wgrad_bf16(const void* dy, const void* x, float* dwp
     if (partial) {
         const long n4 = (long)Cout * 9 * Cin / 4;
         AVSR_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(1024), 0, stream,
-                    reinterpret_cast<const float*>(workspace), dwp, n4, pl.split);
+                    reinterpret_cast<const float*>(workspace), dwp, n4, pl.split, Cin, torch_layout);
     }
     AVSR_CHECK_LAUNCH("conv3x3_wgrad_bf16");
     return 0;

@@ -62,6 +62,34 @@ __global__ __launch_bounds__(256) void weight_permute_kernel(const float* __rest
         Elem<TO>::st(out + (long)a * ld_out + (long)tap * Bc + b, w[((long)co * Cin + ci) * taps + tap]);
     }
 }
+// every conv weight of the model in ONE launch (the per-step refresh of the bf16 [Cout][taps][Cin] / [Cin][taps][Cout]
+// copies): table entries {w, out, Cout, Cin, taps, to_dgrad, blk0}, 2048 output elements per block
+struct AvsrPermEntry {
+    const float* w;
+    bf16_t* out;
+    int Cout, Cin, taps, to_dgrad, blk0, pad0, pad1, pad2;
+};
+__global__ __launch_bounds__(256) void multi_weight_permute_kernel(const AvsrPermEntry* __restrict__ table, int n) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {  // last entry with blk0 <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const AvsrPermEntry e = table[lo];
+    const long total = (long)e.Cout * e.Cin * e.taps;
+    const int Bc = e.to_dgrad ? e.Cout : e.Cin;
+    const long base = (long)(blockIdx.x - e.blk0) * 2048;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const long i = base + threadIdx.x + 256 * j;  // output order: [a][tap][b]
+        if (i >= total) break;
+        const int b = (int)(i % Bc);
+        const int tap = (int)((i / Bc) % e.taps);
+        const int a = (int)(i / ((long)Bc * e.taps));
+        const int co = e.to_dgrad ? b : a, ci = e.to_dgrad ? a : b;
+        e.out[i] = f2bf(e.w[((long)co * e.Cin + ci) * e.taps + tap]);
+    }
+}
 // dw[co][ci][tap] = dwp[co][tap][ci]
 __global__ __launch_bounds__(256) void weight_unpermute_kernel(const float* __restrict__ dwp, float* __restrict__ dw,
                                                                int Cout, int Cin, int taps) {
@@ -87,6 +115,16 @@ extern "C" int avsr_conv_weight_permute(const float* w, void* out, int out_dtype
     else
         AVSR_LAUNCH((weight_permute_kernel<bf16_t>), grid, block, 0, stream, w, (bf16_t*)out, Cout, Cin, taps, to_dgrad, (long)ld_out);
     AVSR_CHECK_LAUNCH("conv_weight_permute");
+    return 0;
+}
+
+// table: n entries of 48 bytes {w, out, Cout, Cin, taps, to_dgrad, blk0, 0, 0, 0}; blk0 = running sum of
+// ceil(Cout*Cin*taps / 2048); total_blocks = the final sum.  Outputs are dense bf16 [a][taps][b].
+extern "C" int avsr_multi_weight_permute(const void* table, int n, int total_blocks, hipStream_t stream) {
+    if (n <= 0 || total_blocks <= 0) return 0;
+    AVSR_LAUNCH(multi_weight_permute_kernel, dim3(total_blocks), dim3(256), 0, stream,
+                reinterpret_cast<const AvsrPermEntry*>(table), n);
+    AVSR_CHECK_LAUNCH("multi_weight_permute");
     return 0;
 }
 

@@ -89,15 +89,62 @@ _wcat = {}     # (data_ptrs..., transposed) -> concatenated bf16 buffer whose sl
 _wtable = {"n": 0, "dev": None, "blocks": 0, "built_for": -1}
 
 
+_wconv = {}    # (data_ptr, to_dgrad, shape) -> [version, bf16 permuted copy, conv weight]
+_wconv_table = {"n": 0, "dev": None, "blocks": 0, "built_for": -1}
+
+
 def invalidate_weight_cache():
     _wcache.clear()
     _wcat.clear()
+    _wconv.clear()
     _wtable.update(n=0, dev=None, blocks=0, built_for=-1)
+    _wconv_table.update(n=0, dev=None, blocks=0, built_for=-1)
+
+
+def _refresh_conv_weights():
+    if not _wconv:
+        return
+    if _wconv_table["built_for"] != len(_wconv):
+        import struct
+
+        blob, blk = b"", 0
+        for (ptr, to_dgrad, shape), ent in _wconv.items():
+            Cout, Cin = shape[0], shape[1]
+            taps = ent[2][0, 0].numel()
+            blob += struct.pack("<QQiiiiiiii", ent[2].data_ptr(), ent[1].data_ptr(), Cout, Cin, taps, int(to_dgrad), blk, 0, 0, 0)
+            blk += (Cout * Cin * taps + 2047) // 2048
+        dev = next(iter(_wconv.values()))[2].device
+        host = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+        _wconv_table.update(n=len(_wconv), dev=host.to(dev), blocks=blk, built_for=len(_wconv))
+    ops.multi_weight_permute(_wconv_table["dev"], _wconv_table["n"], _wconv_table["blocks"])
+    for ent in _wconv.values():
+        ent[0] = ent[2]._version
+
+
+def _w_conv(w, to_dgrad):
+    """bf16 [Cout][taps][Cin] (forward) / [Cin][taps][Cout] (data gradient) copy of a conv weight, cached like the
+    Linear copies and refreshed by refresh_weight_cache() in one multi-tensor launch."""
+    if _state["precise"] or w.dtype != torch.float32 or not w.is_contiguous():
+        return ops.conv_weight_permute(w, act_dtype(), to_dgrad=to_dgrad)
+    key = (w.data_ptr(), to_dgrad, tuple(w.shape))
+    ent = _wconv.get(key)
+    if ent is not None and ent[0] == w._version:
+        return ent[1]
+    if ent is None:
+        ent = _wconv[key] = [-1, ops.conv_weight_permute(w, torch.bfloat16, to_dgrad=to_dgrad), w]
+    else:  # stale: refresh in place (addresses stay stable for captured graphs)
+        Cout, Cin = w.shape[0], w.shape[1]
+        taps = w[0, 0].numel()
+        ops.call("avsr_conv_weight_permute", w.data_ptr(), ent[1].data_ptr(), 1, Cout, Cin, taps, int(to_dgrad),
+                 taps * (Cout if to_dgrad else Cin), ops._stream(w))
+    ent[0] = w._version
+    return ent[1]
 
 
 def refresh_weight_cache():
     """Rebuild every registered bf16 weight copy in place with ONE multi-tensor launch (what a training step needs
     after the optimizer changed the weights).  Falls back to lazy per-weight casts until weights are registered."""
+    _refresh_conv_weights()
     if not _wcache:
         return
     if _wtable["built_for"] != len(_wcache):
@@ -1097,15 +1144,15 @@ class BasicBlockFn(torch.autograd.Function):
         rows = N * OH * OW
         bn1 = (g1, b1) + bn1
         bn2 = (g2, b2) + bn2
-        c1 = ops.conv2d_fwd(x, ops.conv_weight_permute(w1, T), N, H, W, Cin, Cout, KH, KW, stride, ph, pw, pr)
+        c1 = ops.conv2d_fwd(x, _w_conv(w1, False), N, H, W, Cin, Cout, KH, KW, stride, ph, pw, pr)
         m1, i1, n1 = _bn_fwd_params(c1, rows, Cout, bn1, training)
         a1 = ops.bn_act_fwd(c1, None, m1, i1, g1, b1, rows, Cout, 1)
-        c2 = ops.conv2d_fwd(a1, ops.conv_weight_permute(w2, T), N, OH, OW, Cout, Cout, KH, KW, 1, ph, pw, pr)
+        c2 = ops.conv2d_fwd(a1, _w_conv(w2, False), N, OH, OW, Cout, Cout, KH, KW, 1, ph, pw, pr)
         m2, i2, n2 = _bn_fwd_params(c2, rows, Cout, bn2, training)
         cd = md = idd = nd = None
         if wd is not None:
             bnd = (gd, bd) + bnd
-            cd = ops.conv2d_fwd(x, ops.conv_weight_permute(wd, T), N, H, W, Cin, Cout, 1, 1, stride, 0, 0, pr)
+            cd = ops.conv2d_fwd(x, _w_conv(wd, False), N, H, W, Cin, Cout, 1, 1, stride, 0, 0, pr)
             md, idd, nd = _bn_fwd_params(cd, rows, Cout, bnd, training)
             r = ops.bn_act_fwd(cd, None, md, idd, gd, bd, rows, Cout, 0)
         else:
@@ -1131,22 +1178,22 @@ class BasicBlockFn(torch.autograd.Function):
         if wd is None:
             r = x
         dc2, dr, dg2, db2 = _bn_bwd(c2, dout, r, m2, i2, (g2, b2) + r2, n2, rows, Cout, 1, True, training)
-        dw2 = ops.conv_weight_unpermute(ops.conv2d_wgrad(dc2, a1, N, OH, OW, Cout, Cout, KH, KW, 1, ph, pw, pr), w2.shape)
-        da1 = ops.conv2d_dgrad(dc2, ops.conv_weight_permute(w2, T, to_dgrad=True), None, N, OH, OW, Cout, Cout, KH, KW, 1,
+        dw2 = ops.conv2d_wgrad(dc2, a1, N, OH, OW, Cout, Cout, KH, KW, 1, ph, pw, pr, torch_layout=True)
+        da1 = ops.conv2d_dgrad(dc2, _w_conv(w2, True), None, N, OH, OW, Cout, Cout, KH, KW, 1,
                                ph, pw, pr)
         dc1, _, dg1, db1 = _bn_bwd(c1, da1, None, m1, i1, (g1, b1) + r1, n1, rows, Cout, 1, False, training)
-        dw1 = ops.conv_weight_unpermute(ops.conv2d_wgrad(dc1, x, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, pr), w1.shape)
+        dw1 = ops.conv2d_wgrad(dc1, x, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, pr, torch_layout=True)
         dwd = dgd = dbd = None
         if wd is not None:
             dcd, _, dgd, dbd = _bn_bwd(cd, dr, None, md, idd, (gd, bd) + rd, nd, rows, Cout, 0, False, training)
-            dwd = ops.conv_weight_unpermute(ops.conv2d_wgrad(dcd, x, N, H, W, Cin, Cout, 1, 1, stride, 0, 0, pr), wd.shape)
-            skip = ops.conv2d_dgrad(dcd, ops.conv_weight_permute(wd, T, to_dgrad=True), None, N, H, W, Cin, Cout, 1, 1,
+            dwd = ops.conv2d_wgrad(dcd, x, N, H, W, Cin, Cout, 1, 1, stride, 0, 0, pr, torch_layout=True)
+            skip = ops.conv2d_dgrad(dcd, _w_conv(wd, True), None, N, H, W, Cin, Cout, 1, 1,
                                     stride, 0, 0, pr)
         else:
             skip = dr
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.conv2d_dgrad(dc1, ops.conv_weight_permute(w1, T, to_dgrad=True), skip, N, H, W, Cin, Cout, KH, KW,
+            dx = ops.conv2d_dgrad(dc1, _w_conv(w1, True), skip, N, H, W, Cin, Cout, KH, KW,
                                   stride, ph, pw, pr)
         return (dx, None, None, None, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None)
 

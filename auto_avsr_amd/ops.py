@@ -366,17 +366,21 @@ def conv2d_dgrad(dy, wpd, resid, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, pre
     return dx
 
 
-def conv2d_wgrad(dy, x, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise):
+def conv2d_wgrad(dy, x, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise, torch_layout=False):
+    """Weight gradient.  Returns [Cout, KH*KW*Cin] (permuted, [Cout][KH][KW][Cin]) -- or, with torch_layout=True, the
+    gradient already in the parameter's own [Cout, Cin, KH, KW] layout."""
     OH, OW = conv_out(H, KH, stride, ph), conv_out(W, KW, stride, pw)
     bf = not precise and x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
     if bf and KH == 3 and KW == 3 and ph == 1 and pw == 1 and stride <= 2 and Cin % 64 == 0 and Cout % 64 == 0 \
             and (OW - 1) * stride + 3 <= 64:
-        dwp = torch.empty(Cout, KH * KW * Cin, dtype=torch.float32, device=x.device)
+        dwp = torch.empty((Cout, Cin, KH, KW) if torch_layout else (Cout, KH * KW * Cin), dtype=torch.float32, device=x.device)
         nws = call("avsr_conv3x3_wgrad_workspace_bytes", N, H, W, Cin, Cout, stride)
         ws = torch.empty(nws // 4, dtype=torch.float32, device=x.device)
         call("avsr_conv3x3_wgrad_bf16", _ptr(dy), _ptr(x), _ptr(dwp), _ptr(zero_page(x.device)), _ptr(ws), nws, N, H, W, Cin,
-             Cout, stride, _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin)
+             Cout, stride, int(torch_layout), _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin)
         return dwp
+    if torch_layout:
+        return conv_weight_unpermute(conv2d_wgrad(dy, x, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise), (Cout, Cin, KH, KW))
     dwp = torch.zeros(Cout, KH * KW * Cin, dtype=torch.float32, device=x.device)
     if bf and Cin % 64 == 0 and Cout % 8 == 0:
         call("avsr_conv2d_wgrad_bf16", _ptr(dy), _ptr(x), _ptr(dwp), _ptr(zero_page(x.device)), N, H, W, Cin, Cout, KH,
@@ -467,6 +471,10 @@ def transpose_cast_into(src, dst):
 def cast_into(src, dst):
     call("avsr_scale_dropout", _ptr(src), dt(src), _ptr(dst), dt(dst), src.numel(), 1.0, None, 0.0, 0, None, None, 0,
          _stream(src))
+
+
+def multi_weight_permute(table_dev, n, blocks):
+    call("avsr_multi_weight_permute", _ptr(table_dev), n, blocks, _stream(table_dev))
 
 
 def multi_cast_transpose(table_dev, n, blocks):

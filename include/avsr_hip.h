@@ -169,6 +169,9 @@ int avsr_log_softmax(const float* x, int64_t ld, float* lse_ws, float* out, int6
 int avsr_conv_weight_permute(const float* w, void* out, int out_dtype, int Cout, int Cin, int taps, int to_dgrad,
                              int64_t ld_out, avsr_stream_t stream);
 /* dw[Cout][Cin][taps] = dwp[Cout][taps][Cin] */
+/* all conv weights of a model in one launch: table of 48-byte entries {const float* w, bf16* out, int Cout, Cin, taps,
+ * to_dgrad, blk0, 0, 0, 0} in device memory, blk0 = running sum of ceil(Cout*Cin*taps / 2048) */
+int avsr_multi_weight_permute(const void* table, int n, int total_blocks, avsr_stream_t stream);
 int avsr_conv_weight_unpermute(const float* dwp, float* dw, int Cout, int Cin, int taps, avsr_stream_t stream);
 /* y[N,OH,OW,Cout] = conv(x[N,H,W,Cin], wp[Cout][KH][KW][Cin])   (frontend/resnet.py:10-17,20-35; H = 1 for 1-D) */
 int avsr_conv2d_fwd(const void* x, int dtype, const void* wp, int w_dtype, void* y, int N, int H, int W, int Cin,
@@ -260,6 +263,7 @@ int avsr_conv2d_wgrad_bf16(const void* dy, const void* x, float* dwp, const void
 int64_t avsr_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int stride);
 int avsr_conv3x3_wgrad_bf16(const void* dy, const void* x, float* dwp, const void* zero_page, void* workspace,
                             int64_t workspace_bytes, int N, int H, int W, int Cin, int Cout, int stride,
+                            int torch_layout /* 1: write [Cout][Cin][3][3] (workspace mode only) */,
                             avsr_stream_t stream);
 
 #ifdef __cplusplus

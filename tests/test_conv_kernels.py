@@ -101,8 +101,13 @@ def test_conv3x3_wgrad_direct(dev, cfg, partial):
     if partial:
         dwp.fill_(float("nan"))  # partial mode overwrites
     ops.call("avsr_conv3x3_wgrad_bf16", ops._ptr(dyd), ops._ptr(xd), ops._ptr(dwp), ops._ptr(ops.zero_page(dev)),
-             ops._ptr(ws), nws if partial else 0, N, H, W, Cin, Cout, s, ops._stream(dwp))
+             ops._ptr(ws), nws if partial else 0, N, H, W, Cin, Cout, s, 0, ops._stream(dwp))
     dw = ops.conv_weight_unpermute(dwp, w.shape)
+    if partial:  # same gradient written directly in the parameter's [Cout][Cin][3][3] layout
+        dwt = torch.full((Cout, Cin, 3, 3), float("nan"), device=dev)
+        ops.call("avsr_conv3x3_wgrad_bf16", ops._ptr(dyd), ops._ptr(xd), ops._ptr(dwt), ops._ptr(ops.zero_page(dev)),
+                 ops._ptr(ws), nws, N, H, W, Cin, Cout, s, 1, ops._stream(dwt))
+        assert torch.equal(dwt.cpu(), dw.cpu())
     assert (dw.cpu() - w.grad).abs().max() < 2e-3 * max(1.0, w.grad.abs().max().item())
 
 
