@@ -20,6 +20,7 @@
 // the next tile's global loads in flight while the current one is multiplied.
 // NS = 2 keeps a hi and a lo bf16 plane per operand (f32-class accuracy).
 #pragma once
+#include <algorithm>
 #include "prims.h"
 
 namespace avsr_gemm_impl {
@@ -437,16 +438,20 @@ struct Kernel {
         }
     }
 
-    static AVSR_DEV void run(const Params& p, char* smem) {
+    static AVSR_DEV void run(const Params& p, char* smem) { run_at(p, smem, blockIdx.y, blockIdx.z); }
+
+    // by, bz: the block's m-tile and (batch, k-split) index -- blockIdx.y / blockIdx.z for a single problem, remapped
+    // when several problems share one launch (gemm_multi_kernel)
+    static AVSR_DEV void run_at(const Params& p, char* smem, int by, int bz) {
         bf16_t* stage0 = reinterpret_cast<bf16_t*>(smem);
-        const int zb = blockIdx.z / p.nsplit, zs = blockIdx.z % p.nsplit;
+        const int zb = bz / p.nsplit, zs = bz % p.nsplit;
         const int zbb = zb / p.batch_h, zbh = zb % p.batch_h;
         const TA* A = reinterpret_cast<const TA*>(p.A) + zbb * p.sAb + zbh * p.sAh;
         const TB* B = reinterpret_cast<const TB*>(p.B) + zbb * p.sBb + zbh * p.sBh;
         const long c_off = zbb * p.sCb + zbh * p.sCh;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int wm = wave >> 1, wn = wave & 1;
-        const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+        const int m0 = by * BM, n0 = blockIdx.x * BN;
         const int kbeg = zs * p.k_chunk;
         const int kend = min(p.K, kbeg + p.k_chunk);
 
@@ -515,6 +520,48 @@ template <class TA, class TB, int NS, int LA, int LB, int BM, int BN, int BK, in
 __global__ __launch_bounds__(256) void gemm_kernel(Params p) {
     AVSR_DYN_SMEM(smem);
     Kernel<TA, TB, NS, LA, LB, BM, BN, BK, CV>::run(p, smem);
+}
+
+// Up to three independent problems of one (layout, dtype) family in ONE launch: blockIdx.z enumerates the problems'
+// (batch, k-split) indices back to back, blockIdx.y covers the tallest problem (shorter ones exit).  Used where a
+// few small batched contractions have no dependence on each other (attention backward: dV, dK, dpos) and each alone
+// would leave most of the chip idle and pay its own launch boundary.
+struct MultiParams {
+    Params p[3];
+    int zend[3];  // running end of each problem's blockIdx.z range
+    int n;
+};
+template <class TA, class TB, int NS, int LA, int LB, int BM, int BN, int BK>
+__global__ __launch_bounds__(256) void gemm_multi_kernel(MultiParams mp) {
+    AVSR_DYN_SMEM(smem);
+    int q = 0;
+    while (q + 1 < mp.n && (int)blockIdx.z >= mp.zend[q]) q++;
+    const Params& p = mp.p[q];
+    if ((int)blockIdx.y * BM >= p.M || (int)blockIdx.x * BN >= p.N) return;
+    Kernel<TA, TB, NS, LA, LB, BM, BN, BK, 0>::run_at(p, smem, blockIdx.y, blockIdx.z - (q ? mp.zend[q - 1] : 0));
+}
+
+template <class TA, class TB, int NS, int LA, int LB>
+int launch_multi(const Params* ps, int n, hipStream_t stream) {
+    constexpr int BK = 64, BMN = 64;
+    MultiParams mp{};
+    mp.n = n;
+    int gx = 0, gy = 0, gz = 0;
+    for (int q = 0; q < n; q++) {
+        Params p = ps[q];
+        p.k_chunk = ((p.K + BK - 1) / BK) * BK;
+        p.nsplit = 1;
+        if (p.batch_h < 1) p.batch_h = 1;
+        const int nbatch = p.nbatch < 1 ? 1 : p.nbatch;
+        gx = std::max(gx, (p.N + BMN - 1) / BMN);
+        gy = std::max(gy, (p.M + BMN - 1) / BMN);
+        gz += nbatch;
+        mp.zend[q] = gz;
+        mp.p[q] = p;
+    }
+    using K = Kernel<TA, TB, NS, LA, LB, BMN, BMN, BK, 0>;
+    AVSR_LAUNCH((gemm_multi_kernel<TA, TB, NS, LA, LB, BMN, BMN, BK>), dim3(gx, gy, gz), dim3(256), K::LDS_BYTES, stream, mp);
+    return 0;
 }
 
 // host-side launch of one (layout, dtype) family: picks the tile shape

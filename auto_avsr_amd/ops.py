@@ -139,17 +139,13 @@ def attention_bwd(qu, qv, k, v, pos, mask, out, lse, dout, scale, *, precise=Fal
     dkk = dk_out if dk_out is not None else torch.empty(B, Tk, H, dk, dtype=qu.dtype, device=qu.device)
     dvv = dv_out if dv_out is not None else torch.empty(B, Tk, H, dk, dtype=qu.dtype, device=qu.device)
     do4 = dout.view(B, Tq, H, dk)
-    # dV[b,h] = Pd[b,h]^T dO[b,h] ; dK[b,h] = dS[b,h]^T Qu[b,h]
-    gemm_tn_batched(pd, lds, H * Tq * lds, Tq * lds, do4, do4.stride(1), do4.stride(0), dk, dvv, dvv.stride(1),
-                    dvv.stride(0), dk, B, H, Tk, dk, Tq, precise=precise)
-    gemm_tn_batched(ds, lds, H * Tq * lds, Tq * lds, qu, qu.stride(1), qu.stride(0), dk, dkk, dkk.stride(1),
-                    dkk.stride(0), dk, B, H, Tk, dk, Tq, precise=precise)
-    dpos = None
-    if pos is not None:
-        dpos = torch.zeros(2 * Tq - 1, D, dtype=torch.float32, device=qu.device)
-        gemm_tn_batched(ds, lds, H * Tq * lds, Tq * lds, qv, qv.stride(1), qv.stride(0), dk, dpos, D, 0, dk,
-                        B, H, 2 * Tq - 1, dk, Tq, precise=precise, accumulate=True, a_skew=True,
-                        skew_off=Tq - 1, skew_lim=Tk)
+    # dV[b,h] = Pd[b,h]^T dO[b,h] ; dK[b,h] = dS[b,h]^T Qu[b,h] ; dpos += skew(dS[b,h])^T Qv[b,h] -- one launch
+    dpos = torch.zeros(2 * Tq - 1, D, dtype=torch.float32, device=qu.device) if pos is not None else None
+    assert qv is None or qv.stride() == qu.stride()
+    assert dkk.stride(2) == dk and dvv.stride(2) == dk and do4.stride(2) == dk and qu.stride(2) == dk
+    call("avsr_attention_bwd_kv", _ptr(pd), _ptr(ds), lds, _ptr(do4), do4.stride(1), do4.stride(0), _ptr(qu),
+         _ptr(qv) if pos is not None else None, qu.stride(1), qu.stride(0), _ptr(dkk), dkk.stride(1), dkk.stride(0),
+         _ptr(dvv), dvv.stride(1), dvv.stride(0), _ptr(dpos), dt(qu), int(precise), B, H, Tq, Tk, dk, _stream(qu))
     return dqu, dqv, dkk, dvv, dpos
 
 
