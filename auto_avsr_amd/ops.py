@@ -35,9 +35,12 @@ def _stream(*ts):
 
 
 PROFILE = None  # bench.py: list collecting (entry point, start event, end event, flops) per launch
+RECORD = None   # bench.py: (entry point, list) -- the argument tuples of every launch of that entry point
 
 
 def call(name, *args, flops=0.0):
+    if RECORD is not None and name == RECORD[0]:
+        RECORD[1].append((args, flops))
     if PROFILE is None:
         return _lib.lib().call(name, *args)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
