@@ -65,37 +65,14 @@ def _worker(rank, world, port, emu_path, out_dir):
     dist.destroy_process_group()
 
 
-def test_ddp_syncbn_matches_global_batch(emu_lib_path, tmp_path):
-    sys.path.insert(0, os.path.join(HERE, "golden"))
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from synth import synth_batch, synth_state_dict
-
-    import avsr_oracle as O
-    from auto_avsr_amd.e2e import E2E
-
+def test_ddp_ragged_shards_run(emu_lib_path, tmp_path):
+    """Two ranks with DIFFERENT local batch shapes (2 x 8 frames and 1 x 5 frames): the DDP all-reduce, the cross-rank
+    BatchNorm statistics (set_bn_sync) and the W / sum(B) loss rescale run to completion and give finite, non-zero
+    gradients.  Exact equivalence with the oracle on the global batch needs shards without rank-local padding
+    (BatchNorm statistics include padded frames) and is asserted in test_ddp_equal_shards below."""
     port = 29500 + os.getpid() % 2000
     mp.spawn(_worker, args=(2, port, emu_lib_path, str(tmp_path)), nprocs=2, join=True)
     grads = torch.load(os.path.join(tmp_path, "grads.pt"))
-    # oracle: the three utterances as ONE batch.  Padding differs (rank 1 padded to T=5, the global batch to T=8),
-    # and BatchNorm statistics include padded frames, so build the union of what the ranks saw:
-    # rank 0: 2 x 8 frames, rank 1: 1 x 5 frames -> statistics over 21 frames.  Emulate by running the oracle per
-    # rank shard with shared (merged) BatchNorm statistics is not expressible; instead compare against the oracle
-    # on a batch where no rank-local padding exists.
-    odim = 40
-    tmpl = E2E(odim, "video", adim=128, aheads=2, eunits=256, elayers=1, dunits=256, dlayers=1, cnn_module_kernel=7)
-    sd = synth_state_dict(tmpl.state_dict(), 31)
-    osd = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running_" not in k else v.clone())
-           for k, v in sd.items()}
-    x, lengths, y = synth_batch("video", 3, 8, 3, odim, seed=12, lengths=[8, 6, 5])
-    total = 0
-    for xs, ls, ys in ((x[:2], lengths[:2], y[:2]), (x[2:, :5], lengths[2:], y[2:])):
-        # per-shard oracle losses (sum / local B) recombined as sum / global B need shared BN statistics, which the
-        # functional oracle cannot do across calls -> use eval-mode-free check below instead
-        total += xs.shape[0]
-    assert total == 3
-    # Consistency check that does not need cross-call statistics: gradients are finite, non-zero, and identical on
-    # reruns (determinism of the merged statistics); exact global-batch equivalence is asserted for a batch whose
-    # shards have equal length in test_ddp_equal_shards below.
     assert all(torch.isfinite(g).all() for g in grads.values())
     assert sum(float(g.abs().sum()) for g in grads.values()) > 0
 
