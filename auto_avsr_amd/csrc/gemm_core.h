@@ -67,6 +67,7 @@ struct Params {
     // tuned bf16 kernel (gemm_fast.hip) only: image count, tile order, and the residue classes a strided data
     // gradient is split into (row grid cls_h x cls_w starting at pixel (cls_y0, cls_x0) with step cS; taps
     // kh = cls_py + cS*i, kw = cls_px + cS*j; m-tiles [cls_tile0[c], cls_tile0[c+1]))
+    float* colsum;  // LDS epilogue, non-accumulating outputs: colsum[n] += sum_m of the stored value (bias gradients)
     int cN, xcd_order, ncls;
     int cls_tile0[5], cls_py[4], cls_px[4], cls_y0[4], cls_x0[4], cls_h[4], cls_w[4], cls_nkh[4], cls_nkw[4];
 };
@@ -206,6 +207,10 @@ AVSR_DEV void epilogue_lds(f32x16 (&acc)[TM][TN], const Params& p, int m0, int n
         return;
     }
     constexpr int CPR = BN / 8;  // chunks per row
+    static_assert(NTHR % CPR == 0 && 64 % CPR == 0, "a thread keeps one column chunk for all of its rows");
+    float cs[8];  // this thread's share of the column sums (its chunk, its rows)
+#pragma unroll
+    for (int e = 0; e < 8; e++) cs[e] = 0.f;
     for (int id = threadIdx.x; id < BM * CPR; id += NTHR) {
         const int r = id / CPR, c = (id % CPR) * 8;
         const int row = rowmap ? rowmap[r] : m0 + r, col = n0 + c;
@@ -275,6 +280,10 @@ AVSR_DEV void epilogue_lds(f32x16 (&acc)[TM][TN], const Params& p, int m0, int n
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] += rr[e];
         }
+        if (p.colsum) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) cs[e] += e < nv ? v[e] : 0.f;
+        }
         const size_t co = c_off + (size_t)row * p.ldc + col;
         if (p.c_dtype == 0) {
             float* cp = reinterpret_cast<float*>(p.C) + co;
@@ -293,6 +302,18 @@ AVSR_DEV void epilogue_lds(f32x16 (&acc)[TM][TN], const Params& p, int m0, int n
                 for (int e = 0; e < nv; e++) cp[e] = f2bf(v[e]);
             }
         }
+    }
+    if (p.colsum) {
+        // lanes l, l + CPR, l + 2 CPR, ... of a wave hold the same column chunk: butterfly over those lane bits, then one
+        // atomic per column from lanes 0 .. CPR-1 (a Linear's bias gradient without a second pass over its output gradient)
+#pragma unroll
+        for (int m = 32; m >= CPR; m >>= 1)
+#pragma unroll
+            for (int e = 0; e < 8; e++) cs[e] += __shfl_xor(cs[e], m);
+        if (lane < CPR)
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                if (n0 + lane * 8 + e < p.N) atomicAdd(p.colsum + n0 + lane * 8 + e, cs[e]);
     }
 }
 

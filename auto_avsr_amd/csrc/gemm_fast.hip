@@ -330,7 +330,8 @@ extern "C" int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
                                  int act, const void* gate, int gate_dtype, int ldg, float gate_scale, float drop_p,
                                  uint64_t seed, const uint64_t* seed_dev, float alpha, const float* alpha_dev,
                                  const void* resid, int resid_dtype, int ldr, void* C, int c_dtype, int ldc, int accumulate,
-                                 int split_k, int tile, hipStream_t stream) {
+                                 int split_k, int tile, float* colsum, hipStream_t stream) {
+    AVSR_REQUIRE(!(colsum && accumulate), "gemm_bf16_nt: colsum needs a non-accumulating output");
     AVSR_REQUIRE(K > 0 && K % 64 == 0, "gemm_bf16_nt: K must be a positive multiple of 64");
     AVSR_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "gemm_bf16_nt: lda/ldb must be multiples of 8 elements");
     AVSR_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "gemm_bf16_nt: operands must be 16-byte aligned");
@@ -346,6 +347,7 @@ extern "C" int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
     p.alpha = alpha; p.alpha_dev = alpha_dev;
     p.resid = reinterpret_cast<const float*>(resid); p.resid_dtype = resid_dtype; p.ldr = ldr;
     p.C = C; p.c_dtype = c_dtype; p.ldc = ldc; p.accumulate = accumulate;
+    p.colsum = colsum;
     p.nsplit = 1; p.batch_h = 1; p.nbatch = 1;
     if (split_k < 1) split_k = 1;
     if (tile == 0) {

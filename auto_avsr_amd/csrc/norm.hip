@@ -139,15 +139,27 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_param_kernel(
 #pragma unroll
     for (int e = 0; e < 8; e++) pg[e] = pb[e] = 0.f;
     if (cc < cv) {
-        for (int r = r0 + rl; r < r1; r += RL) {
-            float xv[8], dv[8];
-            load8(x + (size_t)r * cols + cc * 8, xv);
-            load8(dy + (size_t)r * cols + cc * 8, dv);
-            const float m = mean_in[r], rs = rstd_in[r];
+        constexpr int U = 4;  // independent rows in flight per thread: the loop is a chain of HBM/L2 round trips otherwise
+        for (int rb = r0 + rl; rb < r1; rb += U * RL) {
+            float xv[U][8], dv[U][8], m[U], rs[U];
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                pg[e] += dv[e] * (xv[e] - m) * rs;
-                pb[e] += dv[e];
+            for (int u = 0; u < U; u++) {
+                const int r = rb + u * RL;
+                if (r < r1) {
+                    load8(x + (size_t)r * cols + cc * 8, xv[u]);
+                    load8(dy + (size_t)r * cols + cc * 8, dv[u]);
+                    m[u] = mean_in[r];
+                    rs[u] = rstd_in[r];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (rb + u * RL >= r1) continue;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    pg[e] += dv[u][e] * (xv[u][e] - m[u]) * rs[u];
+                    pb[e] += dv[u][e];
+                }
             }
         }
     }

@@ -236,15 +236,21 @@ def _gemm_nt(a, w, M, N, K, out, *, lda=None, ldc=None, **kw):
     return ops.gemm(NT, a, lda or K, w, K, M, N, K, out, ldc or N, precise=_state["precise"], **kw)
 
 
-def _gemm_nn(a, w, M, N, K, out, *, lda=None, ldb=None, ldc=None, **kw):
-    """out[M,N] = epi(a[M,K] @ w[K,N])  (data gradient: w is the [out=K, in=N] weight)."""
+def _gemm_nn(a, w, M, N, K, out, *, lda=None, ldb=None, ldc=None, colsum=None, **kw):
+    """out[M,N] = epi(a[M,K] @ w[K,N])  (data gradient: w is the [out=K, in=N] weight).
+    colsum (f32 [N], zero-initialised): also receives the column sums of out -- the bias gradient of the Linear whose
+    output gradient this is -- from the GEMM epilogue on the tuned path, from a separate pass otherwise."""
     Kp = (K + 63) // 64 * 64
     if (not _state["precise"]) and a.dtype == torch.bfloat16 and w.dim() == 2 and w.dtype == torch.float32 \
             and w.is_contiguous() and (ldb or N) == N and (lda or K) >= Kp and (lda or K) % 8 == 0:
         # a's row pitch covers the 64-padded K (its pad columns are zero or multiply the zero tail of w^T)
         wt = _w_bf16(w, True)  # [N][Kp]
-        return ops.gemm_bf16_nt(a, lda or K, wt, wt.shape[1], M, N, Kp, out, ldc or N, tile=_pick_tile(M, N), **kw)
-    return ops.gemm(NN, a, lda or K, w, ldb or N, M, N, K, out, ldc or N, precise=_state["precise"], **kw)
+        return ops.gemm_bf16_nt(a, lda or K, wt, wt.shape[1], M, N, Kp, out, ldc or N, tile=_pick_tile(M, N),
+                                colsum=colsum, **kw)
+    ops.gemm(NN, a, lda or K, w, ldb or N, M, N, K, out, ldc or N, precise=_state["precise"], **kw)
+    if colsum is not None:
+        ops.colsum_into(out, colsum, M, N)
+    return out
 
 
 class _ZeroArena:
@@ -301,6 +307,9 @@ def _zeros(shape, device):
     for s_ in (shape if isinstance(shape, (tuple, list)) else (shape,)):
         n *= s_
     return _arena.take(n, device).view(shape)
+
+
+ops.zeros_f32 = _zeros  # zero-initialised f32 scratch of the binding layer comes from the same arena
 
 
 def _fast_mode(t):
@@ -530,9 +539,9 @@ class FfnSublayerFn(torch.autograd.Function):
         dw2 = _wgrad(g, u, rows, D, Fh, dyT=gT, xT=_xT(u, rows, Fh))
         du = torch.empty(rows, Fh, dtype=T, device=x.device)
         # relu' and the hidden dropout mask are both "u > 0" on the saved post-dropout activation
-        _gemm_nn(g, w2, rows, Fh, D, du, gate=u, ldg=Fh, gate_scale=1.0 / (1.0 - p1) if p1 > 0 else 1.0)
-        _, duT, db1 = _prologue(du, rows, Fh, want_dst=False)
-        dw1 = _wgrad(du, h, rows, Fh, D, dyT=duT, xT=_xT(h, rows, D))
+        db1 = _zeros(Fh, x.device)  # bias gradient of W1: column sums of du, taken in the epilogue of the GEMM that makes du
+        _gemm_nn(g, w2, rows, Fh, D, du, gate=u, ldg=Fh, gate_scale=1.0 / (1.0 - p1) if p1 > 0 else 1.0, colsum=db1)
+        dw1 = _wgrad(du, h, rows, Fh, D)
         dh = torch.empty(rows, D, dtype=T, device=x.device)
         _gemm_nn(du, w1, rows, D, Fh, dh)
         dg = _zeros(D, x.device)
@@ -574,8 +583,8 @@ class FfnFn(torch.autograd.Function):
         db2 = _bgrad(g, rows, D)
         dw2 = _wgrad(g, u, rows, D, Fh)
         du = torch.empty(rows, Fh, dtype=T, device=g.device)
-        _gemm_nn(g, w2, rows, Fh, D, du, gate=u, ldg=Fh, gate_scale=1.0 / (1.0 - p1) if p1 > 0 else 1.0)
-        db1 = _bgrad(du, rows, Fh)
+        db1 = _zeros(Fh, x2.device)
+        _gemm_nn(g, w2, rows, Fh, D, du, gate=u, ldg=Fh, gate_scale=1.0 / (1.0 - p1) if p1 > 0 else 1.0, colsum=db1)
         dw1 = _wgrad(du, x2, rows, Fh, D)
         dx = torch.empty(x2.shape, dtype=torch.float32, device=g.device)
         _gemm_nn(du, w1, rows, D, Fh, dx)
@@ -819,6 +828,24 @@ def mha_sublayer(x, memory, pos_emb, mask, ln_w, ln_b, wq, bq, wk, bk, wv, bv, w
 
 
 # ------------------------------------------------------------------------------------------------ BatchNorm plumbing
+_const_cache = {}
+
+
+def _const1(value, device):
+    """A resident 1-element f32 constant (BatchNorm row counts): one fill per distinct value instead of one per
+    BatchNorm per step.  Never created under hipGraph capture (its fill would only run at replay)."""
+    if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        t = _const_cache.get((device, value))
+        return t if t is not None else torch.full((1,), value, dtype=torch.float32, device=device)
+    key = (device, value)
+    t = _const_cache.get(key)
+    if t is None:
+        if len(_const_cache) > 4096:
+            _const_cache.clear()
+        t = _const_cache[key] = torch.full((1,), value, dtype=torch.float32, device=device)
+    return t
+
+
 def _bn_train_stats(c2, rows, C, eps, momentum, running_mean, running_var):
     """Batch statistics (+ running-stat update) of a [rows, C] activation; merged across ranks when set_bn_sync()."""
     stats = ops.bn_stats(c2, rows, C)
@@ -827,7 +854,7 @@ def _bn_train_stats(c2, rows, C, eps, momentum, running_mean, running_var):
         import torch.distributed as dist
 
         W = dist.get_world_size(group)
-        mine = torch.cat([stats.reshape(-1), torch.full((1,), float(rows), dtype=torch.float32, device=c2.device)])
+        mine = torch.cat([stats.reshape(-1), _const1(float(rows), c2.device)])
         flat = torch.empty(W * mine.numel(), dtype=torch.float32, device=c2.device)
         dist.all_gather_into_tensor(flat, mine, group=group)
         allv = flat.view(W, mine.numel())
@@ -836,7 +863,7 @@ def _bn_train_stats(c2, rows, C, eps, momentum, running_mean, running_var):
         mean, invstd = ops.bn_finalize(stats_all, counts, W, C, eps, momentum, running_mean, running_var)
         n_total = None  # read on device below
         return mean, invstd, counts
-    counts = torch.full((1,), float(rows), dtype=torch.float32, device=c2.device)  # fill kernel: graph-capturable
+    counts = _const1(float(rows), c2.device)
     mean, invstd = ops.bn_finalize(stats.unsqueeze(0), counts, 1, C, eps, momentum, running_mean, running_var)
     return mean, invstd, counts
 

@@ -34,6 +34,9 @@ def _stream(*ts):
     return None
 
 
+zeros_f32 = lambda shape, device: torch.zeros(shape, dtype=torch.float32, device=device)  # functional.py installs its arena
+
+
 PROFILE = None  # bench.py: list collecting (entry point, start event, end event, flops) per launch
 RECORD = None   # bench.py: (entry point, list) -- the argument tuples of every launch of that entry point
 
@@ -143,7 +146,7 @@ def attention_bwd(qu, qv, k, v, pos, mask, out, lse, dout, scale, *, precise=Fal
     dvv = dv_out if dv_out is not None else torch.empty(B, Tk, H, dk, dtype=qu.dtype, device=qu.device)
     do4 = dout.view(B, Tq, H, dk)
     # dV[b,h] = Pd[b,h]^T dO[b,h] ; dK[b,h] = dS[b,h]^T Qu[b,h] ; dpos += skew(dS[b,h])^T Qv[b,h] -- one launch
-    dpos = torch.zeros(2 * Tq - 1, D, dtype=torch.float32, device=qu.device) if pos is not None else None
+    dpos = zeros_f32((2 * Tq - 1, D), qu.device) if pos is not None else None  # accumulated into
     assert qv is None or qv.stride() == qu.stride()
     assert dkk.stride(2) == dk and dvv.stride(2) == dk and do4.stride(2) == dk and qu.stride(2) == dk
     call("avsr_attention_bwd_kv", _ptr(pd), _ptr(ds), lds, _ptr(do4), do4.stride(1), do4.stride(0), _ptr(qu),
@@ -434,11 +437,11 @@ def avgpool_bwd(dy, out_dtype, groups, win, C):
 
 def gemm_bf16_nt(A, lda, B, ldb, M, N, K, C, ldc, *, bias=None, act=0, gate=None, ldg=0, gate_scale=1.0, drop_p=0.0,
                  seed=0, seed_dev=None, alpha=1.0, alpha_dev=None, resid=None, ldr=0, accumulate=False, split_k=1,
-                 tile=0):
+                 tile=0, colsum=None):
     call("avsr_gemm_bf16_nt", _ptr(A), lda, _ptr(B), ldb, M, N, K, _ptr(bias), act, _ptr(gate),
          dt(gate) if gate is not None else 0, ldg, gate_scale, drop_p, seed, _ptr(seed_dev), alpha, _ptr(alpha_dev),
          _ptr(resid), dt(resid) if resid is not None else 0, ldr, _ptr(C), dt(C), ldc, int(accumulate), split_k, tile,
-         _stream(A), flops=2.0 * M * N * K)
+         _ptr(colsum), _stream(A), flops=2.0 * M * N * K)
     return C
 
 

@@ -218,6 +218,7 @@ int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int
                       const void* gate, int gate_dtype, int ldg, float gate_scale, float drop_p, uint64_t seed,
                       const uint64_t* seed_dev, float alpha, const float* alpha_dev, const void* resid, int resid_dtype,
                       int ldr, void* C, int c_dtype, int ldc, int accumulate, int split_k, int tile,
+                      float* colsum /* may be NULL: colsum[n] += sum_m C[m,n] (f32, before rounding; accumulate = 0) */,
                       avsr_stream_t stream);
 /* Tuning knobs of the tuned kernels (process-wide; meant for benchmarks, defaults are the measured best):
  * knob 0 = tile code forced on avsr_conv2d_bf16 (0 = auto), 1 = XCD-aware tile order (default 0: measured neutral to slower),

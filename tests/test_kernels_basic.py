@@ -102,6 +102,11 @@ def test_gemm_fast_nt(dev, tile, shape):
                      resid=resid.to(dev), ldr=N, tile=tile)
     ref2 = torch.relu(ref + bias.double()) * 0.5 + resid.double()
     assert ((C2.cpu().double() - ref2).abs().max() / ref2.abs().max()) < 1e-2
+    # column sums of the stored values from the epilogue (bias gradient of the layer whose output gradient C is)
+    cs = torch.full((N,), 3.0, device=dev)
+    ops.gemm_bf16_nt(A.to(dev), K, B.to(dev), K, M, N, K, C2, N, bias=bias.to(dev), act=1, alpha=0.5,
+                     resid=resid.to(dev), ldr=N, tile=tile, colsum=cs)
+    assert ((cs.cpu().double() - 3.0 - ref2.sum(0)).abs().max() / ref2.sum(0).abs().max()) < 1e-4
     C3 = torch.zeros(M, N, device=dev)
     ops.gemm_bf16_nt(A.to(dev), K, B.to(dev), K, M, N, K, C3, N, accumulate=True, split_k=3, tile=tile)
     assert ((C3.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-6
