@@ -47,13 +47,20 @@ def run(args):
                                                         broadcast_buffers=False, gradient_as_bucket_view=True)
     lengths = utterance_lengths()
     batches = rank_batches(bucket_batches(lengths, args.max_frames, args.train_num_buckets), rank, world, seed=0)
-    opt, sched = module.make_optimizer(len(batches))
+    # lightning.py:48-52 + train.py:41 + cosine.py as one fused multi-tensor step (optim.py): AdamW(.9/.98), clip 10,
+    # per-step warm-up cosine; step count / lr / gradient norm stay on the device
+    from .optim import FusedAdamW
+
+    opt = FusedAdamW(model.parameters(), lr=args.lr, betas=(0.9, 0.98), weight_decay=args.weight_decay, max_grad_norm=10.0,
+                     warmup_steps=args.warmup_epochs * len(batches), total_steps=args.max_epochs * len(batches))
     total = args.steps or args.max_epochs * len(batches)
     t0 = time.time()
     for step in range(total):
         x, lens, y, frames = make_batch(lengths, batches[step % len(batches)], args.modality, model.odim, seed=step,
                                         device=dev)
         seed_dev.add_(1)
+        AF.new_step()
+        AF.refresh_weight_cache()  # the optimizer moved the f32 master weights: one launch re-casts every bf16 copy
         loss, loss_ctc, loss_att, hits, ntok = hot(x, lens, y)
         if world > 1:
             bs = torch.tensor([float(x.shape[0])], device=dev)
@@ -61,13 +68,11 @@ def run(args):
             dist.all_gather_into_tensor(allb, bs)
             loss = loss * (world / allb.sum())
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
         opt.step()
-        sched.step()
         opt.zero_grad(set_to_none=True)
         if rank == 0 and (step % 10 == 0 or step == total - 1):
             print(f"step {step} loss {float(loss):.4f} ctc {float(loss_ctc):.4f} att {float(loss_att):.4f} "
-                  f"acc {float(hits) / max(float(ntok), 1):.4f} lr {sched.get_last_lr()[0]:.2e} "
+                  f"acc {float(hits) / max(float(ntok), 1):.4f} lr {opt.last_lr:.2e} gnorm {opt.last_grad_norm:.2f} "
                   f"({time.time() - t0:.1f}s)", flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -273,6 +273,16 @@ int avsr_conv3x3_wgrad_bf16(const void* dy, const void* x, float* dwp, const voi
                             int64_t workspace_bytes, int N, int H, int W, int Cin, int Cout, int stride,
                             int torch_layout /* 1: write [Cout][Cin][3][3] (workspace mode only) */,
                             avsr_stream_t stream);
+/* ---- optimizer step (optim.hip): global-norm clip + AdamW + warm-up cosine schedule, all parameters in 3 launches ---
+ * Replaces torch.nn.utils.clip_grad_norm_(params, max_grad_norm) + torch.optim.AdamW(...).step() +
+ * WarmupCosineScheduler.step() (reference lightning.py:48-52, train.py:41, cosine.py:6-25).
+ * table: n entries of 48 bytes {float* p, const float* g, float* m, float* v, int64 numel, int blk0, int 0} in device
+ * memory, blk0 = running sum of ceil(numel / 4096), total_blocks = the final sum; partial: total_blocks floats of
+ * scratch; state: 4 device floats {step, lr, grad_norm, clip_coef} -- step starts at 0 and is incremented by the call,
+ * lr = base_lr * warm-up-cosine(step) (total_steps <= 0: constant).  max_grad_norm <= 0 disables clipping. */
+int avsr_adamw_step(const void* table, int n, int total_blocks, float* partial, float* state, float base_lr, float beta1,
+                    float beta2, float eps, float weight_decay, float max_grad_norm, int64_t warmup_steps,
+                    int64_t total_steps, avsr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,103 @@
+"""Fused clip + AdamW + warm-up cosine step (csrc/optim.hip) vs the reference's torch.optim.AdamW(betas=(0.9, 0.98)) +
+clip_grad_norm_(10) + WarmupCosineScheduler (lightning.py:48-52, train.py:41, cosine.py:6-25)."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cosine import WarmupCosineScheduler  # noqa: E402
+
+from auto_avsr_amd.optim import FusedAdamW  # noqa: E402
+
+
+@pytest.mark.parametrize("clip", [10.0, 0.5, 0.0])
+def test_fused_adamw_matches_torch(dev, clip):
+    torch.manual_seed(0)
+    shapes = [(7,), (33, 5), (4097,), (64, 65), (3, 1, 5, 7, 7), (1,)]
+    ref_p = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    our_p = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in ref_p]
+    lr, wd, warm, total = 1e-2, 0.03, 3, 10
+    ref = torch.optim.AdamW(ref_p, lr=lr, betas=(0.9, 0.98), weight_decay=wd)
+    sched = WarmupCosineScheduler(ref, warm, total, 1)
+    ours = FusedAdamW(our_p, lr=lr, betas=(0.9, 0.98), eps=1e-8, weight_decay=wd, max_grad_norm=clip, warmup_steps=warm,
+                      total_steps=total)
+    for it in range(6):
+        gs = [torch.randn(s) * (3.0 if it % 2 else 0.3) for s in shapes]
+        for p, q, g in zip(ref_p, our_p, gs):
+            p.grad = g.clone()
+            q.grad = g.clone().to(dev)  # fresh tensors every step, as after a backward
+        lr_used = sched.get_last_lr()[0]  # torch applies the schedule of the previous scheduler.step()
+        norm = torch.nn.utils.clip_grad_norm_(ref_p, clip) if clip > 0 else torch.linalg.vector_norm(torch.cat([g.flatten() for g in gs]))
+        ref.step()
+        sched.step()
+        ours.step()
+        assert abs(ours.last_grad_norm - float(norm)) < 1e-4 * max(1.0, float(norm))
+        assert ours.step_count == it + 1
+        # schedule: the reference scheduler is constructed with step count 1 (factor 1/warm), then stepped after each
+        # optimizer step; the fused step uses factor(step) with step = 1, 2, ...
+        assert abs(ours.last_lr - lr_used) < 1e-9 + 1e-6 * lr_used, (it, ours.last_lr, lr_used)
+        for p, q in zip(ref_p, our_p):
+            assert (p.detach() - q.detach().cpu()).abs().max() < 2e-6 * max(1.0, float(p.detach().abs().max()))
+
+
+@pytest.mark.gpu
+def test_fused_adamw_under_hipgraph():
+    """The whole training step (forward, backward, fused optimizer, bf16 weight re-cast) captured once and replayed:
+    parameters after three replays equal three eager steps (the step count, learning rate and clip coefficient live on
+    the device, the gradient pointer table is re-sent from its pinned buffer by a captured copy node)."""
+    from auto_avsr_amd import functional as AF
+
+    dev = torch.device("cuda:0")
+
+    def make():
+        torch.manual_seed(3)
+        l1, l2 = torch.nn.Linear(64, 128).to(dev), torch.nn.Linear(128, 64).to(dev)
+        return l1, l2, FusedAdamW(list(l1.parameters()) + list(l2.parameters()), lr=1e-2, weight_decay=0.03, max_grad_norm=1.0,
+                                 warmup_steps=2, total_steps=8)
+
+    x = torch.randn(32, 64, device=dev).bfloat16()
+
+    def step(l1, l2, opt):
+        AF.new_step()
+        AF.refresh_weight_cache()
+        h = AF.linear(x, l1.weight, l1.bias)
+        y = AF.linear(h, l2.weight, l2.bias, out_dtype=torch.float32)
+        (y * y).mean().backward()
+        opt.step()
+
+    AF.invalidate_weight_cache()
+    work = torch.cuda.Stream()
+    work.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(work):
+        e1, e2, eo = make()
+        for _ in range(3):
+            step(e1, e2, eo)
+            eo.zero_grad()
+        AF.invalidate_weight_cache()
+        g1, g2, go = make()
+        step(g1, g2, go)  # warm-up (registers the weight copies), then rewind parameters and optimizer state
+        go.zero_grad()
+        torch.manual_seed(3)
+        r1, r2 = torch.nn.Linear(64, 128).to(dev), torch.nn.Linear(128, 64).to(dev)
+        with torch.no_grad():
+            for p, q in zip(list(g1.parameters()) + list(g2.parameters()), list(r1.parameters()) + list(r2.parameters())):
+                p.copy_(q)
+            for t in go.exp_avg + go.exp_avg_sq:
+                t.zero_()
+            go.state.zero_()
+        AF.refresh_weight_cache()  # builds the cast table (H2D copy) outside the capture
+    torch.cuda.current_stream().wait_stream(work)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step(g1, g2, go)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert go.step_count == 3 and abs(go.last_lr - eo.last_lr) < 1e-9
+    for p, q in zip(list(e1.parameters()) + list(e2.parameters()), list(g1.parameters()) + list(g2.parameters())):
+        assert (p.detach() - q.detach()).abs().max() < 1e-5 * max(1.0, float(p.detach().abs().max()))
+    AF.invalidate_weight_cache()
