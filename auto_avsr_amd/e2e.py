@@ -36,9 +36,10 @@ class E2E(nn.Module):
         self.criterion = nets.LabelSmoothingLoss(self.odim, self.ignore_id, 0.1, False)
 
     def scorers(self):
-        """e2e_asr_conformer.py:60-61.  The CTC prefix scorer belongs to the beam-search stack, which is the
-        section-8(f) 'next' item; the decoder scorer API (TransformerDecoder.score / batch_score) exists."""
-        raise NotImplementedError("CTCPrefixScorer / beam search are outside this round's hot-path scope")
+        """e2e_asr_conformer.py:60-61: the scorers of hybrid CTC / attention beam search."""
+        from .decoding import CTCPrefixScorer
+
+        return dict(decoder=self.decoder, ctc=CTCPrefixScorer(self.ctc, self.eos))
 
     def forward_tensors(self, x, lengths, label):
         """The training hot path with no host synchronisation: returns device scalars

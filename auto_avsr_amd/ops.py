@@ -91,7 +91,7 @@ def attention_fwd(qu, qv, k, v, pos, mask, scale, *, precise=False, drop_p=0.0, 
     msb = msq = 0
     if mask is not None:
         assert mask.dtype in (torch.uint8, torch.bool) and mask.is_contiguous() and mask.dim() == 3
-        msb = mask.shape[1] * mask.shape[2]
+        msb = mask.shape[1] * mask.shape[2] if mask.shape[0] > 1 else 0  # a batch-1 mask is shared by every sequence
         msq = mask.shape[2] if mask.shape[1] > 1 else 0
     call("avsr_attention_fwd", _ptr(qu), _ptr(qv), _ptr(k), _ptr(v), _ptr(pos), dt(qu), int(precise), _ptr(mask),
          msb, msq, _ptr(out), _ptr(lse), B, H, Tq, Tk, dk, qu.stride(1), k.stride(1), v.stride(1),
@@ -114,7 +114,7 @@ def attention_bwd_dq(qu, qv, k, v, pos, mask, out, lse, dout, scale, *, precise=
     ds = torch.empty(B, H, Tq, lds, dtype=qu.dtype, device=qu.device)
     msb = msq = 0
     if mask is not None:
-        msb = mask.shape[1] * mask.shape[2]
+        msb = mask.shape[1] * mask.shape[2] if mask.shape[0] > 1 else 0  # a batch-1 mask is shared by every sequence
         msq = mask.shape[2] if mask.shape[1] > 1 else 0
     assert dqu.stride() == qu.stride() and (dqv is None or (dqv.stride() == qu.stride() and qv.stride() == qu.stride())), \
         "bwd writes dqu/dqv with qu's strides"
@@ -297,7 +297,7 @@ def embed_bwd(ids, dout, dtable, scale, drop_p=0.0, seed=0, seed_dev=None):
 
 
 def log_softmax(x, ld, rows, V):
-    out = torch.zeros_like(x)
+    out = torch.zeros(rows, ld, dtype=torch.float32, device=x.device)  # x may be a [rows, V] view of a pitched buffer
     ws = torch.empty(rows, dtype=torch.float32, device=x.device)
     call("avsr_log_softmax", _ptr(x), ld, _ptr(ws), _ptr(out), rows, V, _stream(x))
     return out

@@ -1,7 +1,8 @@
-"""Evaluation entry point with the reference's command line (eval.py:25-64).  Decoding needs the beam-search
-stack (espnet.nets.batch_beam_search + scorers), which is the section-8(f) 'next' item of SURVEY.md; until it
-lands this entry point loads the checkpoint, runs the encoder on the requested input and reports CTC greedy
-token ids, and says so."""
+"""Evaluation entry point with the reference's command line (eval.py:25-64): loads a checkpoint into ModelModule and
+decodes with the hybrid CTC / attention beam search (auto_avsr_amd/decoding.py).  The reference iterates an LRS3 test
+set through Lightning's Trainer.test; datasets and pytorch_lightning are not part of this image, so without them this
+entry point decodes `--demo-frames` synthetic frames (plumbing check, BASELINE.json configs[0]) and prints the
+hypothesis; with a DataModule available the WER loop is ModelModule.on_test_epoch_start / test_step / on_test_epoch_end."""
 from argparse import ArgumentParser
 
 
@@ -13,13 +14,27 @@ def parse_args(argv=None):
     p.add_argument("--pretrained-model-path", type=str, default=None)
     p.add_argument("--decode-snr-target", type=float, default=999999)
     p.add_argument("--debug", action="store_true")
+    p.add_argument("--demo-frames", type=int, default=50, help="synthetic clip length when no dataset is given")
     return p.parse_args(argv)
 
 
 def cli_main(argv=None):
+    import torch
+
+    from lightning import ModelModule
+
     args = parse_args(argv)
-    raise SystemExit("eval.py: beam-search decoding is not part of this round's hot-path scope "
-                     "(SURVEY.md section 8f, item 2); train.py / bench.py exercise the implemented path.")
+    if not torch.cuda.is_available():
+        raise SystemExit("eval.py needs an MI355X: the model runs on libavsr_hip.so only (no CPU path)")
+    module = ModelModule(args).cuda().eval()
+    if args.root_dir is not None:
+        raise SystemExit("eval.py: dataset iteration needs the reference DataModule (torchaudio / torchvision / "
+                         "pytorch_lightning), which this image does not have; ModelModule.test_step implements the WER loop")
+    T = args.demo_frames
+    sample = torch.randn(T, 1, 88, 88, device="cuda") if args.modality == "video" else torch.randn(T * 640, 1, device="cuda")
+    with torch.no_grad():
+        text = module(sample)
+    print(f"hypothesis ({T} synthetic frames, random weights unless --pretrained-model-path): {text!r}")
 
 
 if __name__ == "__main__":

@@ -273,6 +273,14 @@ int avsr_conv3x3_wgrad_bf16(const void* dy, const void* x, float* dwp, const voi
                             int64_t workspace_bytes, int N, int H, int W, int Cin, int Cout, int stride,
                             int torch_layout /* 1: write [Cout][Cin][3][3] (workspace mode only) */,
                             avsr_stream_t stream);
+/* ---- beam-search support (ctc_prefix.hip): CTC prefix scores of every (running hypothesis, candidate token) pair in
+ * one launch -- the python loop over frames of espnet/nets/ctc_prefix_score.py:71-187 (CTCPrefixScoreTH.__call__).
+ * logp [T][ldv] f32 log-softmax of one utterance; r_prev [T][2][NH]; last [NH]; cand [NH][S]; out_len = len(prefix)-1;
+ * r_new [T][2][NH][S]; psi [NH][S]; psi_eos [NH] */
+int avsr_ctc_prefix_score(const float* logp, int T, int V, int ldv, const float* r_prev, const int64_t* last,
+                          const int64_t* cand, int NH, int S, int out_len, int blank, float* r_new, float* psi,
+                          float* psi_eos, avsr_stream_t stream);
+
 /* ---- optimizer step (optim.hip): global-norm clip + AdamW + warm-up cosine schedule, all parameters in 3 launches ---
  * Replaces torch.nn.utils.clip_grad_norm_(params, max_grad_norm) + torch.optim.AdamW(...).step() +
  * WarmupCosineScheduler.step() (reference lightning.py:48-52, train.py:41, cosine.py:6-25).

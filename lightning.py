@@ -95,13 +95,53 @@ class ModelModule(_Base):
         return self._step(batch, batch_idx, "val")
 
     # ---- evaluation (lightning.py:54-84,116-123): beam search over the encoder output
-    def forward(self, sample):
-        raise NotImplementedError("beam-search decoding (espnet.nets.batch_beam_search) is the section-8(f) 'next' "
-                                  "item; the training hot path is E2E.forward")
+    def _decode(self, sample):
+        """Front-end -> encoder (no mask, B = 1) -> hybrid CTC/attention beam search -> text (lightning.py:54-64)."""
+        x = self.model.frontend(sample.unsqueeze(0))
+        x = self.model.proj_encoder(x)
+        enc_feat, _ = self.model.encoder(x, None)
+        enc_feat = enc_feat.squeeze(0)
+        nbest_hyps = self.beam_search(enc_feat)
+        nbest_hyps = [h.asdict() for h in nbest_hyps[: min(len(nbest_hyps), 1)]]
+        predicted_token_id = torch.tensor(list(map(int, nbest_hyps[0]["yseq"][1:])))
+        return self.text_transform.post_process(predicted_token_id).replace("<eos>", "")
 
-    test_step = forward
+    def forward(self, sample):
+        self.beam_search = get_beam_search_decoder(self.model, self.token_list)
+        return self._decode(sample)
+
+    def on_test_epoch_start(self):
+        self.total_length = 0
+        self.total_edit_distance = 0
+        self.text_transform = TextTransform()
+        self.beam_search = get_beam_search_decoder(self.model, self.token_list)
+
+    def test_step(self, sample, sample_idx):
+        predicted = self._decode(sample["input"])
+        actual = self.text_transform.post_process(sample["target"])
+        self.total_edit_distance += compute_word_level_distance(actual, predicted)
+        self.total_length += len(actual.split())
+
+    def on_test_epoch_end(self):
+        wer = self.total_edit_distance / max(self.total_length, 1)
+        if HAVE_LIGHTNING:
+            self.log("wer", wer)
+        return wer
 
 
 def get_beam_search_decoder(model, token_list, rnnlm=None, rnnlm_conf=None, penalty=0, ctc_weight=0.1, lm_weight=0.0,
                             beam_size=40):
-    raise NotImplementedError("beam search is outside this round's hot-path scope (SURVEY.md section 8f item 2)")
+    """lightning.py:126-158: decoder (1 - ctc_weight) + CTC prefix scorer (ctc_weight) + length bonus (penalty), beam 40,
+    pre-beam on the decoder scores.  No language model is shipped with the reference (`scorers["lm"] = None`)."""
+    from espnet.nets.batch_beam_search import BatchBeamSearch
+    from espnet.nets.scorers.length_bonus import LengthBonus
+
+    if rnnlm is not None or lm_weight != 0.0:
+        raise NotImplementedError("language-model fusion is not part of the reference's released configuration")
+    sos = eos = model.odim - 1
+    scorers = model.scorers()
+    scorers["lm"] = None
+    scorers["length_bonus"] = LengthBonus(len(token_list))
+    weights = {"decoder": 1.0 - ctc_weight, "ctc": ctc_weight, "lm": lm_weight, "length_bonus": penalty}
+    return BatchBeamSearch(beam_size=beam_size, vocab_size=len(token_list), weights=weights, scorers=scorers, sos=sos, eos=eos,
+                           token_list=token_list, pre_beam_score_key=None if ctc_weight == 1.0 else "decoder")

@@ -1,0 +1,105 @@
+"""Evaluation path: CTC prefix-score kernel and the batched hybrid CTC/attention beam
+search against golden vectors produced by the reference's CTCPrefixScoreTH / BatchBeamSearch
+(tests/golden/make_golden_decode.py)."""
+import os
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from synth import synth_state_dict  # noqa: E402
+
+from auto_avsr_amd import functional as AF  # noqa: E402
+from auto_avsr_amd import nets  # noqa: E402
+from auto_avsr_amd.decoding import LOGZERO, BatchBeamSearch, CTCPrefixScorer, LengthBonus, end_detect  # noqa: E402
+
+GOLD = torch.load(os.path.join(HERE, "golden", "golden_decode_v1.pt"), weights_only=False)
+
+
+class _FixedCtc(torch.nn.Module):
+    """CTC head stand-in that returns a given log-softmax (the kernel is tested on the golden posteriors themselves)."""
+
+    def __init__(self, logp):
+        super().__init__()
+        self.logp = logp
+        self.ctc_lo = torch.nn.Linear(1, logp.shape[-1])
+
+    def log_softmax(self, x):
+        return self.logp.unsqueeze(0)
+
+
+@pytest.mark.parametrize("case", GOLD["prefix"], ids=lambda c: f"seed{c['seed']}")
+def test_ctc_prefix_scores_vs_reference(dev, case):
+    T, V, NH, S = case["T"], case["V"], case["NH"], case["S"]
+    sc = CTCPrefixScorer(_FixedCtc(case["logp"].to(dev)), eos=V - 1)
+    st = sc.batch_init_state(torch.zeros(T, 1, device=dev))
+    y0 = torch.tensor([[V - 1]], device=dev)
+    s0, full0 = sc.batch_score_partial(y0, case["ids0"].to(dev), st)
+    ref0 = case["sc0"]
+    assert (s0.cpu() - ref0).abs().max() < 1e-3 * max(1.0, float(ref0[ref0 > LOGZERO / 2].abs().max()))
+    toks = case["toks"].to(dev)
+    st1 = sc.select_states(full0, torch.zeros(NH, dtype=torch.int64, device=dev), toks)
+    y1 = torch.cat([torch.full((NH, 1), V - 1, device=dev), toks.unsqueeze(1)], 1)
+    s1, full1 = sc.batch_score_partial(y1, case["ids1"].to(dev), st1)
+    ref1 = case["sc1"]
+    assert (s1.cpu() - ref1).abs().max() < 1e-3 * max(1.0, float(ref1[ref1 > LOGZERO / 2].abs().max()))
+    r1 = full1[0].cpu()
+    live = case["r1"] > LOGZERO / 2
+    assert ((r1 - case["r1"]).abs()[live]).max() < 1e-3 * float(case["r1"][live].abs().max())
+    assert bool((r1[~live] < LOGZERO / 2).all())
+
+
+@pytest.mark.parametrize("case", GOLD["beam"], ids=lambda c: f"seed{c['seed']}")
+def test_beam_search_vs_reference(dev, case):
+    """Same weights, same encoder output: the n-best token sequences equal the reference's, scores within 1e-3."""
+    odim, T, D = case["odim"], case["T"], case["D"]
+    AF.set_precise(True)
+    try:
+        torch.manual_seed(0)
+        dec = nets.TransformerDecoder(odim, attention_dim=D, attention_heads=2, linear_units=256, num_blocks=2).eval()
+        ctc = nets.CTC(odim, D, 0.1, reduce=True).eval()
+        dec.load_state_dict(synth_state_dict(dec.state_dict(), case["seed"]))
+        ctc.load_state_dict(synth_state_dict(ctc.state_dict(), case["seed"] + 1))
+        dec, ctc = dec.to(dev), ctc.to(dev)
+        g = torch.Generator().manual_seed(500 + case["seed"])
+        enc = (torch.randn(T, D, generator=g) * 1.5).to(dev)
+        scorers = {"decoder": dec, "ctc": CTCPrefixScorer(ctc, odim - 1), "lm": None, "length_bonus": LengthBonus(odim)}
+        weights = {"decoder": 1.0 - case["ctc_weight"], "ctc": case["ctc_weight"], "lm": 0.0, "length_bonus": case["penalty"]}
+        bs = BatchBeamSearch(beam_size=case["beam"], vocab_size=odim, weights=weights, scorers=scorers, sos=odim - 1,
+                             eos=odim - 1, token_list=[str(i) for i in range(odim)], pre_beam_score_key="decoder")
+        nbest = bs(enc)
+    finally:
+        AF.set_precise(False)
+    assert len(nbest) == case["n_ended"]
+    for got, ref in zip(nbest, case["hyps"]):
+        d = got.asdict()
+        assert d["yseq"] == ref["yseq"]
+        assert abs(d["score"] - ref["score"]) < 1e-3 * max(1.0, abs(ref["score"]))
+        for k, v in ref["scores"].items():
+            assert abs(d["scores"][k] - v) < 2e-3 * max(1.0, abs(v)), k
+
+
+def test_end_detect_rule():
+    ended = [dict(yseq=[0] * 5, score=-1.0), dict(yseq=[0] * 6, score=-20.0), dict(yseq=[0] * 7, score=-20.0),
+             dict(yseq=[0] * 8, score=-20.0)]
+    assert end_detect(ended, 8) and not end_detect(ended, 7) and not end_detect([], 3)
+
+
+def test_e2e_scorers_and_decoder_factory(dev):
+    """E2E.scorers() + lightning.get_beam_search_decoder produce a working search on a small instance."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import lightning
+    from auto_avsr_amd.e2e import E2E
+
+    m = E2E(40, "video", adim=128, aheads=2, eunits=256, elayers=1, dunits=256, dlayers=1, cnn_module_kernel=7).to(dev).eval()
+    sc = m.scorers()
+    assert set(sc) == {"decoder", "ctc"}
+    bs = lightning.get_beam_search_decoder(m, [str(i) for i in range(40)], beam_size=3)
+    x = torch.randn(6, 1, 88, 88, device=dev)
+    with torch.no_grad():
+        feats = m.proj_encoder(m.frontend(x.unsqueeze(0)))
+        enc, _ = m.encoder(feats, None)
+        nbest = bs(enc.squeeze(0))
+    assert len(nbest) >= 1 and nbest[0].asdict()["yseq"][0] == 39 and nbest[0].asdict()["yseq"][-1] == 39

@@ -130,3 +130,30 @@ def test_hipgraph_replay_matches_eager():
                 tol = 2e-2 * max(float(ref.abs().max()), 1e-6) + 1e-6
                 assert float((got - ref).abs().max()) <= tol, (rep, gi, k, float((got - ref).abs().max()), tol)
     AF.invalidate_weight_cache()
+
+
+def test_full_e2e_beam_search_vs_reference():
+    """Evaluation path at full size (eval mode, precise contractions): front-end -> encoder -> hybrid CTC/attention beam
+    search as lightning.ModelModule.forward wires it; hypotheses equal the reference's (tests/golden/make_golden_decode.py)."""
+    import lightning
+    from auto_avsr_amd import functional as AF
+
+    c = torch.load(os.path.join(HERE, "golden", "golden_decode_v1.pt"), weights_only=False)["e2e"][0]
+    m, _ = _model("video", c["seed"])
+    m.eval()
+    x, _, _ = synth_batch("video", 1, c["T"], 3, 5049, seed=c["seed"], lengths=[c["T"]])
+    bs = lightning.get_beam_search_decoder(m, [str(i) for i in range(5049)], beam_size=c["beam"])
+    AF.set_precise(True)
+    try:
+        with torch.no_grad():
+            feats = m.proj_encoder(m.frontend(x.cuda()))
+            enc, _ = m.encoder(feats, None)
+            assert (enc[0, :, :8].float().cpu() - c["enc_sample"]).abs().max() < 1e-3 * float(c["enc_sample"].abs().max())
+            nbest = bs(enc.squeeze(0).float())
+    finally:
+        AF.set_precise(False)
+    assert len(nbest) == c["n_ended"]
+    for got, ref in zip(nbest, c["hyps"]):
+        d = got.asdict()
+        assert d["yseq"] == ref["yseq"]
+        assert abs(d["score"] - ref["score"]) < 1e-3 * max(1.0, abs(ref["score"]))
