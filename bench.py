@@ -158,8 +158,9 @@ def main():
                 graphs[key] = g
             graphs[key].replay()
             return None
+        AF.new_step()
         seed_dev.add_(1)
-        AF.refresh_weight_cache()  # an optimizer step would change the weights: pay the bf16 re-casts every step
+        AF.refresh_weight_cache()  # the optimizer step changed the weights: one launch re-casts every bf16 copy
         loss = hot(x, lens, y)
         if world > 1:
             # loss rescale of lightning.py:88-90: loss *= world / sum of batch sizes (all-gather of B)
