@@ -95,35 +95,6 @@ AVSR_DEV void stage_rows(bf16_t* lds, const T* src, long ld, int row0, int row_l
             *reinterpret_cast<bf16x8*>(lds + (size_t)p * ROWS * PITCH + r * PITCH + c) = pl[p];
     }
 }
-// ---- transposed staging of a [64 keys][64 d] tile into [NS][64 d][KT+8]: (key pairs packed per dword)
-template <class T, int NS>
-AVSR_DEV void stage_rows_T(bf16_t* lds, const T* src, long ld, int row0, int row_lim) {
-    constexpr int TP = KT + 8;
-    for (int id = threadIdx.x; id < (KT / 2) * 8; id += 256) {
-        const int kp = id & 31, c = (id >> 5) * 8;  // key pair, d chunk
-        float v0[8], v1[8];
-        const int g0 = row0 + 2 * kp, g1 = g0 + 1;
-        if (g0 < row_lim) load8(src + (long)g0 * ld + c, v0);
-        else
-#pragma unroll
-            for (int e = 0; e < 8; e++) v0[e] = 0.f;
-        if (g1 < row_lim) load8(src + (long)g1 * ld + c, v1);
-        else
-#pragma unroll
-            for (int e = 0; e < 8; e++) v1[e] = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            bf16_t s0[NS], s1[NS];
-            split_bf16<NS>(v0[e], s0);
-            split_bf16<NS>(v1[e], s1);
-#pragma unroll
-            for (int p = 0; p < NS; p++)
-                *reinterpret_cast<uint32_t*>(lds + (size_t)p * DK * TP + (c + e) * TP + 2 * kp) =
-                    (uint32_t)s0[p] | ((uint32_t)s1[p] << 16);
-        }
-    }
-}
-
 template <int NS>
 AVSR_DEV Frag<NS> ldfrag(const bf16_t* lds, int plane_elems, int pitch, int row, int koff) {
     Frag<NS> f;
@@ -132,14 +103,18 @@ AVSR_DEV Frag<NS> ldfrag(const bf16_t* lds, int plane_elems, int pitch, int row,
         f.p[p] = *reinterpret_cast<const bf16x8*>(lds + (size_t)p * plane_elems + row * pitch + koff);
     return f;
 }
-// fragment whose 8 k-values are strided by `pitch` (element [k0+e][col])
+// B fragment [n][k] of a tile stored k-major ([k][pitch], n contiguous): columns n0 + lc, k = k0 + 8*quad .. +7, as
+// two ds_read_b64_tr_b16 (each 16-lane group transposes a 4x16 block; see prims.h lds_tr16)
 template <int NS>
-AVSR_DEV Frag<NS> ldfrag_strided(const bf16_t* lds, int plane_elems, int pitch, int k0, int col) {
+AVSR_DEV Frag<NS> ldfrag_tr(const bf16_t* lds, int plane_elems, int pitch, int k0, int n0) {
+    const int lane = threadIdx.x & 63, quad = lane >> 4, lc = lane & 15;
     Frag<NS> f;
 #pragma unroll
-    for (int p = 0; p < NS; p++)
-#pragma unroll
-        for (int e = 0; e < 8; e++) f.p[p][e] = (short)lds[(size_t)p * plane_elems + (k0 + e) * pitch + col];
+    for (int p = 0; p < NS; p++) {
+        const bf16_t* p0 = lds + (size_t)p * plane_elems + (k0 + 8 * quad + (lc >> 2)) * pitch + n0 + 4 * (lc & 3);
+        const bf16x4 lo = lds_tr16(p0), hi = lds_tr16(p0 + 4 * pitch);
+        f.p[p] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
     return f;
 }
 // A fragment straight from HBM: 8 consecutive elements of one row
@@ -176,10 +151,12 @@ template <class T, int NS, bool RELPOS, bool BWD>
 struct Attn {
     // LDS carve (bf16 elements unless noted)
     static constexpr int KS_E = NS * KT * PITCH;               // K tile  [key][d]
-    static constexpr int VS_E = NS * KT * PITCH;               // fwd: V^T [d][key]; bwd: V [key][d]
+    static constexpr int VS_E = NS * KT * PITCH;               // V tile  [key][d]
     static constexpr int PB_E = RELPOS ? NS * PB_ROWS * PITCH : 0;
     static constexpr int PS_E = 4 * NS * 16 * PITCH;           // per wave P (fwd) / dS (bwd) as A operand
-    static constexpr int DG_E = (RELPOS && BWD) ? 4 * NS * 16 * DG_PITCH : 0;
+    // skewed dS (bwd): one bf16 plane fits in the wave's G scratch once the scores are formed, two planes do not
+    static constexpr int DG_E = (RELPOS && BWD && NS > 1) ? 4 * NS * 16 * DG_PITCH : 0;
+    static_assert(16 * DG_PITCH * 2 <= 16 * G_PITCH * 4, "dS skew scratch must fit the G scratch");
     static constexpr int G_F = RELPOS ? 4 * 16 * G_PITCH : 0;  // f32
     static constexpr size_t LDS_BYTES = (size_t)(KS_E + VS_E + PB_E + PS_E + DG_E) * 2 + (size_t)G_F * 4;
 
@@ -252,14 +229,16 @@ struct Attn {
         }
 
         const int ntiles = (Tk + KT - 1) / KT;
+        const bool wave_active = i0 + 16 * w < Tq;
+        const bool row_mask = p.mask && p.mask_sq != 0;  // false: one mask row per batch item (padding mask)
         for (int kt = 0; kt < ntiles; kt++) {
             const int j0 = kt * KT;
             __syncthreads();
             stage_rows<T, NS, KT>(Ks, kk, p.ldk, j0, Tk);
-            if (BWD) stage_rows<T, NS, KT>(Vs, vv, p.ldv, j0, Tk);
-            else stage_rows_T<T, NS>(Vs, vv, p.ldv, j0, Tk);
+            stage_rows<T, NS, KT>(Vs, vv, p.ldv, j0, Tk);
             if (RELPOS) stage_rows<T, NS, PB_ROWS>(Pb, pos, p.ldp, j0 - i0 + Tq - 1 - 63, 2 * Tq - 1);
             __syncthreads();
+            if (!wave_active) continue;  // wave-uniform: this wave's 16 query rows are all past Tq
 
             // ---- scores: (q+u).k
             f32x4 s[4];
@@ -294,18 +273,24 @@ struct Attn {
                     }
             }
             // ---- mask + softmax pieces
-            bool valid[4][4];
+            bool valid[4][4], colok[4];
             float pr[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int jg = j0 + j * 16 + lc;
+                colok[j] = jg < Tk;
+                if (colok[j] && p.mask && !row_mask) colok[j] = p.mask[(long)b * p.mask_sb + jg] != 0;
+            }
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int ig = i0 + 16 * w + 4 * quad + r;
-                const long mrow = p.mask ? (long)b * p.mask_sb + (long)(ig < Tq ? ig : 0) * p.mask_sq : 0;
+                const long mrow = row_mask ? (long)b * p.mask_sb + (long)(ig < Tq ? ig : 0) * p.mask_sq : 0;
                 float mx = NEG_BIG;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int jg = j0 + j * 16 + lc;
-                    bool ok = jg < Tk;
-                    if (ok && p.mask) ok = p.mask[mrow + jg] != 0;
+                    bool ok = colok[j];
+                    if (ok && row_mask) ok = p.mask[mrow + jg] != 0;
                     valid[j][r] = ok;
                     s[j][r] = ok ? s[j][r] * p.scale : NEG_BIG;
                     mx = fmaxf(mx, s[j][r]);
@@ -361,7 +346,7 @@ struct Attn {
                     const Frag<NS> fa = ldfrag<NS>(Pw, PS_PLANE, PITCH, lc, ks * 32 + 8 * quad);
 #pragma unroll
                     for (int n = 0; n < 4; n++)
-                        acc0[n] = mma16<NS>(fa, ldfrag<NS>(Vs, DK * (KT + 8), KT + 8, n * 16 + lc, ks * 32 + 8 * quad), acc0[n]);
+                        acc0[n] = mma16<NS>(fa, ldfrag_tr<NS>(Vs, KT * PITCH, PITCH, ks * 32, n * 16), acc0[n]);
                 }
             } else {
                 // ---- dP = dO V^T ; dS = P * (keep*dP - delta) * scale
@@ -375,8 +360,30 @@ struct Attn {
                 }
                 T* pd_g = reinterpret_cast<T*>(p.pd) + (((long)b * p.H + h) * Tq) * p.lds;
                 T* ds_g = reinterpret_cast<T*>(p.ds) + (((long)b * p.H + h) * Tq) * p.lds;
-                bf16_t* DGw = DG + (size_t)w * 16 * DG_PITCH;
-                constexpr int DG_PLANE = 4 * 16 * DG_PITCH;
+                bf16_t* DGw = NS == 1 ? reinterpret_cast<bf16_t*>(Gw) : DG + (size_t)w * 16 * DG_PITCH;
+                constexpr int DG_PLANE = 4 * 16 * DG_PITCH;  // only used when NS > 1
+                // 2-byte outputs leave through the wave's LDS tile as 16-byte row chunks (rows are lds-pitched, lds % 8
+                // == 0; columns in [Tk, lds) receive zeros); 4-byte outputs (test paths) are stored per element
+                constexpr bool CHUNKED = sizeof(T) == 2 && NS == 1;
+                auto store_tile = [&](T* dst) {
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        const int id = lane + 64 * c, rr = id >> 3, ch = id & 7;
+                        const int ig = i0 + 16 * w + rr, jg = j0 + 8 * ch;
+                        const bf16x8 v8 = *reinterpret_cast<const bf16x8*>(Pw + rr * PITCH + 8 * ch);
+                        if (ig < Tq && jg < p.lds) *reinterpret_cast<bf16x8*>(dst + (long)ig * p.lds + jg) = v8;
+                    }
+                };
+                if (CHUNKED) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            Pw[(4 * quad + r) * PITCH + j * 16 + lc] = f2bf(pr[j][r] * keep[j][r]);
+                    wave_sync();
+                    store_tile(pd_g);
+                }
+                wave_sync();  // the G scratch has been consumed (scores) and the P tile has been read back
                 if (RELPOS) {  // zero the skew scratch (16 x 104 per plane per wave)
                     for (int q = 0; q < NS; q++)
                         for (int id = lane; id < 16 * DG_PITCH / 8; id += 64)
@@ -390,7 +397,7 @@ struct Attn {
                         const int rr = 4 * quad + r, jj = j * 16 + lc;
                         const int ig = i0 + 16 * w + rr, jg = j0 + jj;
                         const float dsv = pr[j][r] * (keep[j][r] * dp[j][r] - delta[r]) * p.scale;
-                        if (ig < Tq && jg < Tk) {
+                        if (!CHUNKED && ig < Tq && jg < Tk) {
                             Elem<T>::st(pd_g + (long)ig * p.lds + jg, pr[j][r] * keep[j][r]);
                             Elem<T>::st(ds_g + (long)ig * p.lds + jg, dsv);
                         }
@@ -403,13 +410,14 @@ struct Attn {
                         }
                     }
                 wave_sync();
+                if (CHUNKED) store_tile(ds_g);
                 // dQu += dS K   (contraction over keys: K fragments are key-strided in LDS)
 #pragma unroll
                 for (int ks = 0; ks < 2; ks++) {
                     const Frag<NS> fa = ldfrag<NS>(Pw, PS_PLANE, PITCH, lc, ks * 32 + 8 * quad);
 #pragma unroll
                     for (int n = 0; n < 4; n++)
-                        acc0[n] = mma16<NS>(fa, ldfrag_strided<NS>(Ks, KT * PITCH, PITCH, ks * 32 + 8 * quad, n * 16 + lc), acc0[n]);
+                        acc0[n] = mma16<NS>(fa, ldfrag_tr<NS>(Ks, KT * PITCH, PITCH, ks * 32, n * 16), acc0[n]);
                 }
                 if (RELPOS) {  // dQv += dG Pband
 #pragma unroll
@@ -417,7 +425,7 @@ struct Attn {
                         const Frag<NS> fa = ldfrag<NS>(DGw, DG_PLANE, DG_PITCH, lc, ks * 32 + 8 * quad);
 #pragma unroll
                         for (int n = 0; n < 4; n++)
-                            acc1[n] = mma16<NS>(fa, ldfrag_strided<NS>(Pb, PB_ROWS * PITCH, PITCH, sb + ks * 32 + 8 * quad, n * 16 + lc), acc1[n]);
+                            acc1[n] = mma16<NS>(fa, ldfrag_tr<NS>(Pb, PB_ROWS * PITCH, PITCH, sb + ks * 32, n * 16), acc1[n]);
                     }
                 }
             }
@@ -507,7 +515,7 @@ extern "C" int avsr_attention_bwd_dq(const void* qu, const void* qv, const void*
     AVSR_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && (pos == nullptr || ldp % 8 == 0),
                  "attention: row strides must be multiples of 8");
     AVSR_REQUIRE(pos == nullptr || Tq == Tk, "attention: relative-position form needs Tq == Tk");
-    AVSR_REQUIRE(lds >= Tk, "attention: lds must cover Tk");
+    AVSR_REQUIRE(lds >= Tk && lds % 8 == 0, "attention: lds must cover Tk and be a multiple of 8");
     if (B == 0 || Tq == 0) return 0;
     AttnParams p{};
     p.qu = qu; p.qv = qv; p.k = k; p.v = v; p.pos = pos;

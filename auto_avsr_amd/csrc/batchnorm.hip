@@ -136,9 +136,10 @@ __global__ __launch_bounds__(256) void bn_partial_sum_kernel(const float* __rest
 __global__ void bn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ counts, int W, int C,
                                    float eps, float momentum, float* __restrict__ mean_out,
                                    float* __restrict__ invstd_out, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var) {
+                                   float* __restrict__ running_var, int64_t* __restrict__ num_batches_tracked) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;  // nn.BatchNorm's batch counter, kept on the device
     double n_tot = 0.0, mean = 0.0;
     for (int w = 0; w < W; w++) {
         const double n = counts[w];
@@ -278,10 +279,10 @@ extern "C" int avsr_bn_stats(const void* x, int dtype, float* stats, float* work
 
 extern "C" int avsr_bn_finalize(const float* stats, const float* counts, int world, int C, float eps, float momentum,
                                 float* mean, float* invstd, float* running_mean, float* running_var,
-                                hipStream_t stream) {
+                                int64_t* num_batches_tracked, hipStream_t stream) {
     dim3 grid((C + 127) / 128), block(128);
     AVSR_LAUNCH(bn_finalize_kernel, grid, block, 0, stream, stats, counts, world, C, eps, momentum, mean, invstd,
-                running_mean, running_var);
+                running_mean, running_var, num_batches_tracked);
     AVSR_CHECK_LAUNCH("bn_finalize");
     return 0;
 }

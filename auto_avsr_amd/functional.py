@@ -846,8 +846,9 @@ def _const1(value, device):
     return t
 
 
-def _bn_train_stats(c2, rows, C, eps, momentum, running_mean, running_var):
-    """Batch statistics (+ running-stat update) of a [rows, C] activation; merged across ranks when set_bn_sync()."""
+def _bn_train_stats(c2, rows, C, eps, momentum, running_mean, running_var, nbt=None):
+    """Batch statistics (+ running-stat update, + num_batches_tracked count) of a [rows, C] activation; merged across
+    ranks when set_bn_sync()."""
     stats = ops.bn_stats(c2, rows, C)
     group = _state["bn_sync"]
     if group is not None:
@@ -860,11 +861,11 @@ def _bn_train_stats(c2, rows, C, eps, momentum, running_mean, running_var):
         allv = flat.view(W, mine.numel())
         counts = allv[:, -1].contiguous()
         stats_all = allv[:, :-1].contiguous().view(W, 3, C)
-        mean, invstd = ops.bn_finalize(stats_all, counts, W, C, eps, momentum, running_mean, running_var)
+        mean, invstd = ops.bn_finalize(stats_all, counts, W, C, eps, momentum, running_mean, running_var, nbt)
         n_total = None  # read on device below
         return mean, invstd, counts
     counts = _const1(float(rows), c2.device)
-    mean, invstd = ops.bn_finalize(stats.unsqueeze(0), counts, 1, C, eps, momentum, running_mean, running_var)
+    mean, invstd = ops.bn_finalize(stats.unsqueeze(0), counts, 1, C, eps, momentum, running_mean, running_var, nbt)
     return mean, invstd, counts
 
 
@@ -885,7 +886,7 @@ class ConvSublayerFn(torch.autograd.Function):
     pointwise(D->2D) -> GLU -> depthwise(K) -> BatchNorm1d (batch stats over every frame) -> SiLU -> pointwise."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, w_pw1, b_pw1, w_dw, b_dw, bn_w, bn_b, bn_rm, bn_rv, w_pw2, b_pw2, training,
+    def forward(ctx, x, ln_w, ln_b, w_pw1, b_pw1, w_dw, b_dw, bn_w, bn_b, bn_rm, bn_rv, bn_nbt, w_pw2, b_pw2, training,
                 momentum, bn_eps, p_out, eps):
         x = x.contiguous()
         B, Tn, D = x.shape
@@ -903,7 +904,7 @@ class ConvSublayerFn(torch.autograd.Function):
         wdw = w_dw.view(D, K)
         c = ops.dwconv(gl, wdw, b_dw, B, Tn, D, K)
         if training:
-            bmean, binv, counts = _bn_train_stats(c, rows, D, bn_eps, momentum, bn_rm, bn_rv)
+            bmean, binv, counts = _bn_train_stats(c, rows, D, bn_eps, momentum, bn_rm, bn_rv, bn_nbt)
         else:
             bmean, binv = ops.bn_eval_params(bn_rm, bn_rv, bn_eps)
             counts = None
@@ -952,20 +953,19 @@ class ConvSublayerFn(torch.autograd.Function):
             dg = dbt = None
             dx = torch.empty(B, Tn, D, dtype=torch.float32, device=x.device)
             _gemm_nn(da, w_pw1.view(2 * D, D), rows, D, 2 * D, dx)
-        return (dx, dg, dbt, dw1, db1, dwdw.view(D, 1, K), dbdw, dbn_w, dbn_b, None, None, dw2, db2, None, None, None,
-                None, None)
+        return (dx, dg, dbt, dw1, db1, dwdw.view(D, 1, K), dbdw, dbn_w, dbn_b, None, None, None, dw2, db2, None, None,
+                None, None, None)
 
 
 def conv_sublayer(x, ln_w, ln_b, w_pw1, b_pw1, w_dw, b_dw, bn, w_pw2, b_pw2, p_out, eps=1e-12):
     """bn: the torch.nn.BatchNorm1d module holding weight / bias / running stats (updated in place in training).
     ln_w = ln_b = None gives the bare module (no LayerNorm, no residual, no output dropout)."""
     training = bn.training
-    if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
     momentum = bn.momentum if bn.momentum is not None else 0.1
+    # the batch counter of the BatchNorm is incremented by its statistics kernel (bn_finalize)
     return ConvSublayerFn.apply(_to_f32(x), ln_w, ln_b, w_pw1, b_pw1, w_dw, b_dw, bn.weight, bn.bias, bn.running_mean,
-                                bn.running_var, w_pw2, b_pw2, training, float(momentum), float(bn.eps), float(p_out),
-                                eps)
+                                bn.running_var, bn.num_batches_tracked if training else None, w_pw2, b_pw2, training,
+                                float(momentum), float(bn.eps), float(p_out), eps)
 
 
 # ------------------------------------------------------------------------------------------------ misc
@@ -1129,7 +1129,7 @@ def _bn_fwd_params(c2, rows, C, bn, training):
     """(mean, invstd, counts) of a BatchNorm over the rows of c2; bn = (weight, bias, running_mean, running_var,
     eps, momentum).  Training: batch statistics (cross-rank when set_bn_sync) + running-stat update."""
     if training:
-        return _bn_train_stats(c2, rows, C, bn[4], bn[5], bn[2], bn[3])
+        return _bn_train_stats(c2, rows, C, bn[4], bn[5], bn[2], bn[3], bn[6] if len(bn) > 6 else None)
     mean, invstd = ops.bn_eval_params(bn[2], bn[3], bn[4])
     return mean, invstd, None
 
@@ -1148,10 +1148,10 @@ def _bn_bwd(c, dy, add, mean, invstd, bn, counts, rows, C, act, want_dadd, train
 
 
 def bn_tuple(m):
-    """Pack a torch BatchNorm module for the front-end functions (and count the batch in training)."""
-    if m.training and m.num_batches_tracked is not None:
-        m.num_batches_tracked.add_(1)
-    return (m.weight, m.bias, m.running_mean, m.running_var, float(m.eps), float(m.momentum if m.momentum is not None else 0.1))
+    """Pack a torch BatchNorm module for the front-end functions.  In training the batch counter is incremented by
+    the statistics kernel (bn_finalize) -- one launch less per BatchNorm than `num_batches_tracked.add_(1)`."""
+    return (m.weight, m.bias, m.running_mean, m.running_var, float(m.eps), float(m.momentum if m.momentum is not None else 0.1),
+            m.num_batches_tracked if m.training else None)
 
 
 class BasicBlockFn(torch.autograd.Function):

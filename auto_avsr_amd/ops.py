@@ -209,11 +209,11 @@ def bn_stats(x, rows, C):
     return stats
 
 
-def bn_finalize(stats, counts, world, C, eps, momentum, running_mean, running_var):
+def bn_finalize(stats, counts, world, C, eps, momentum, running_mean, running_var, num_batches_tracked=None):
     mean = torch.empty(C, dtype=torch.float32, device=stats.device)
     invstd = torch.empty(C, dtype=torch.float32, device=stats.device)
     call("avsr_bn_finalize", _ptr(stats), _ptr(counts), world, C, eps, momentum, _ptr(mean), _ptr(invstd),
-         _ptr(running_mean), _ptr(running_var), _stream(stats))
+         _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _stream(stats))
     return mean, invstd
 
 

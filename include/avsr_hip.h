@@ -123,10 +123,10 @@ int64_t avsr_bn_workspace_floats(int C);
 int avsr_bn_stats(const void* x, int dtype, float* stats, float* workspace, int64_t rows, int C,
                   avsr_stream_t stream);
 /* merge `world` per-rank partials [world][3][C] + counts[world] -> mean, invstd; momentum update of the
- * running stats (unbiased variance) when running_mean != NULL */
+ * running stats (unbiased variance) when running_mean != NULL; *num_batches_tracked += 1 when != NULL */
 int avsr_bn_finalize(const float* stats, const float* counts, int world, int C, float eps, float momentum,
                      float* mean, float* invstd, float* running_mean, float* running_var,
-                     avsr_stream_t stream);
+                     int64_t* num_batches_tracked, avsr_stream_t stream);
 int avsr_bn_eval_params(const float* running_mean, const float* running_var, float eps, int C, float* mean,
                         float* invstd, avsr_stream_t stream);
 /* y = act(gamma*(x-mean)*invstd + beta (+ add)); act 0 none, 1 SiLU */

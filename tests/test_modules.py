@@ -104,6 +104,9 @@ def test_e2e_small_vs_oracle(dev, modality):
     check_grad_norms(m, ref_norms, 1e-2)
     # BatchNorm running statistics of the conv module were updated like torch's (momentum 0.1, unbiased variance)
     assert int(m.encoder.encoders[0].conv_module.norm.num_batches_tracked) == 1
+    # ... and so was every batch counter (incremented on the device by the statistics kernel)
+    bns = [mod for mod in m.modules() if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm)]
+    assert len(bns) > 3 and all(int(b.num_batches_tracked) == 1 for b in bns)
 
 
 @pytest.mark.parametrize("modality", ["video"])
