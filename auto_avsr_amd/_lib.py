@@ -76,10 +76,13 @@ class _Lib:
             fn.restype = restype
             fn.argtypes = argtypes
         self.is_emulator = bool(self.cdll.avsr_is_emulator())
+        self._fns = {name: (getattr(self.cdll, name), restype is ctypes.c_int)
+                     for name, (restype, _, _) in self.protos.items()}
 
     def call(self, name, *args):
-        rc = getattr(self.cdll, name)(*args)
-        if self.protos[name][0] is not ctypes.c_int:
+        fn, status = self._fns[name]
+        rc = fn(*args)
+        if not status:
             return rc
         if rc != 0:
             raise AvsrLibraryError(f"{name} failed ({rc}): {self.cdll.avsr_last_error().decode()}")

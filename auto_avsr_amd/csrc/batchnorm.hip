@@ -114,8 +114,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_colreduce_kernel(
 // block = 16 consecutive columns x 16 partial lanes (short dependent chains), combined in LDS.
 template <class T>
 __global__ __launch_bounds__(256) void bn_partial_sum_kernel(const float* __restrict__ part, int nparts, int C,
-                                                             float* __restrict__ dst, int base, const T* __restrict__ x0) {
+                                                             float* __restrict__ dst, int base, const T* __restrict__ x0,
+                                                             float* __restrict__ count_out, float count) {
     __shared__ float red[16][17];
+    if (count_out && blockIdx.x == 0 && threadIdx.x == 0) *count_out = count;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int i = blockIdx.x * 16 + tx;  // over 2*C
     float s = 0.f;
@@ -132,29 +134,31 @@ __global__ __launch_bounds__(256) void bn_partial_sum_kernel(const float* __rest
     }
 }
 
-// stats: [W][3][C] (shift, s1, s2), counts [W]; one thread per channel
+// stats: rank w at stats + w*ss: [3][C] (shift, s1, s2); count of rank w at counts[w*cs]; one thread per channel
 __global__ void bn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ counts, int W, int C,
-                                   float eps, float momentum, float* __restrict__ mean_out,
+                                   long ss, long cs, float eps, float momentum, float* __restrict__ mean_out,
                                    float* __restrict__ invstd_out, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, int64_t* __restrict__ num_batches_tracked) {
+                                   float* __restrict__ running_var, int64_t* __restrict__ num_batches_tracked,
+                                   float* __restrict__ n_total_out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;  // nn.BatchNorm's batch counter, kept on the device
     double n_tot = 0.0, mean = 0.0;
     for (int w = 0; w < W; w++) {
-        const double n = counts[w];
+        const double n = counts[w * cs];
         if (n <= 0.0) continue;
-        const double mw = (double)stats[((long)w * 3 + 0) * C + c] + (double)stats[((long)w * 3 + 1) * C + c] / n;
+        const double mw = (double)stats[w * ss + c] + (double)stats[w * ss + C + c] / n;
         mean += n * mw;
         n_tot += n;
     }
     mean /= n_tot;
+    if (c == 0 && n_total_out) *n_total_out = (float)n_tot;
     double m2 = 0.0;
     for (int w = 0; w < W; w++) {
-        const double n = counts[w];
+        const double n = counts[w * cs];
         if (n <= 0.0) continue;
-        const double s1 = stats[((long)w * 3 + 1) * C + c], s2 = stats[((long)w * 3 + 2) * C + c];
-        const double mw = (double)stats[((long)w * 3 + 0) * C + c] + s1 / n;
+        const double s1 = stats[w * ss + C + c], s2 = stats[w * ss + 2 * C + c];
+        const double mw = (double)stats[w * ss + c] + s1 / n;
         m2 += (s2 - s1 * s1 / n) + n * (mw - mean) * (mw - mean);
     }
     const double var = m2 / n_tot;
@@ -251,9 +255,9 @@ static inline int bn_parts(long rows, int rpb, int gx) {
 
 extern "C" int64_t avsr_bn_workspace_floats(int C) { return (int64_t)1024 * 2 * C; }
 
-// stats: [3][C] f32 (overwritten); workspace: avsr_bn_workspace_floats(C) floats
+// stats: [3][C] f32 (overwritten); workspace: avsr_bn_workspace_floats(C) floats; *count_out = rows when != NULL
 extern "C" int avsr_bn_stats(const void* x, int dtype, float* stats, float* workspace, int64_t rows, int C,
-                             hipStream_t stream) {
+                             float* count_out, hipStream_t stream) {
     AVSR_REQUIRE(C % 8 == 0, "batchnorm: C must be a multiple of 8");
     if (rows <= 0) return 0;
     const int cv = C >> 3, CL = pick_cl(cv);
@@ -266,23 +270,27 @@ extern "C" int avsr_bn_stats(const void* x, int dtype, float* stats, float* work
         AVSR_LAUNCH((bn_colreduce_kernel<float, 0>), grid, block, 0, stream, (const float*)x, (const float*)nullptr,
                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                     (const float*)nullptr, workspace, (long)rows, C, CL, rpb, 0);
-        AVSR_LAUNCH((bn_partial_sum_kernel<float>), g2, dim3(256), 0, stream, (const float*)workspace, parts, C, stats, 1, (const float*)x);
+        AVSR_LAUNCH((bn_partial_sum_kernel<float>), g2, dim3(256), 0, stream, (const float*)workspace, parts, C, stats, 1, (const float*)x,
+                    count_out, (float)rows);
     } else {
         AVSR_LAUNCH((bn_colreduce_kernel<bf16_t, 0>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)nullptr,
                     (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                     (const float*)nullptr, workspace, (long)rows, C, CL, rpb, 0);
-        AVSR_LAUNCH((bn_partial_sum_kernel<bf16_t>), g2, dim3(256), 0, stream, (const float*)workspace, parts, C, stats, 1, (const bf16_t*)x);
+        AVSR_LAUNCH((bn_partial_sum_kernel<bf16_t>), g2, dim3(256), 0, stream, (const float*)workspace, parts, C, stats, 1, (const bf16_t*)x,
+                    count_out, (float)rows);
     }
     AVSR_CHECK_LAUNCH("bn_stats");
     return 0;
 }
 
-extern "C" int avsr_bn_finalize(const float* stats, const float* counts, int world, int C, float eps, float momentum,
-                                float* mean, float* invstd, float* running_mean, float* running_var,
-                                int64_t* num_batches_tracked, hipStream_t stream) {
+extern "C" int avsr_bn_finalize(const float* stats, const float* counts, int world, int C, int64_t stats_stride,
+                                int64_t counts_stride, float eps, float momentum, float* mean, float* invstd,
+                                float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                float* n_total, hipStream_t stream) {
     dim3 grid((C + 127) / 128), block(128);
-    AVSR_LAUNCH(bn_finalize_kernel, grid, block, 0, stream, stats, counts, world, C, eps, momentum, mean, invstd,
-                running_mean, running_var, num_batches_tracked);
+    const long ss = stats_stride > 0 ? (long)stats_stride : 3L * C, cs = counts_stride > 0 ? (long)counts_stride : 1L;
+    AVSR_LAUNCH(bn_finalize_kernel, grid, block, 0, stream, stats, counts, world, C, ss, cs, eps, momentum, mean, invstd,
+                running_mean, running_var, num_batches_tracked, n_total);
     AVSR_CHECK_LAUNCH("bn_finalize");
     return 0;
 }
@@ -329,7 +337,8 @@ extern "C" int avsr_bn_bwd_reduce(const void* x, const void* dy, const void* add
     else
         AVSR_LAUNCH((bn_colreduce_kernel<bf16_t, 1>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dy,
                     (const bf16_t*)add, mean, invstd, gamma, beta, workspace, (long)rows, C, CL, rpb, act);
-    AVSR_LAUNCH((bn_partial_sum_kernel<float>), g2, dim3(256), 0, stream, (const float*)workspace, parts, C, sums, 0, (const float*)nullptr);
+    AVSR_LAUNCH((bn_partial_sum_kernel<float>), g2, dim3(256), 0, stream, (const float*)workspace, parts, C, sums, 0, (const float*)nullptr,
+                (float*)nullptr, 0.f);
     AVSR_CHECK_LAUNCH("bn_bwd_reduce");
     return 0;
 }

@@ -849,28 +849,30 @@ def _const1(value, device):
 def _bn_train_stats(c2, rows, C, eps, momentum, running_mean, running_var, nbt=None):
     """Batch statistics (+ running-stat update, + num_batches_tracked count) of a [rows, C] activation; merged across
     ranks when set_bn_sync()."""
-    stats = ops.bn_stats(c2, rows, C)
     group = _state["bn_sync"]
     if group is not None:
         import torch.distributed as dist
 
+        # one all-gather of {shifted statistics, row count} per BatchNorm (ranks hold different row counts); the
+        # payload is written by the statistics kernel and read in place (strided) by the merge kernel, which also
+        # leaves the global row count on the device for the backward pass -- no glue launches around the collective
         W = dist.get_world_size(group)
-        mine = torch.cat([stats.reshape(-1), _const1(float(rows), c2.device)])
+        mine = ops.bn_stats(c2, rows, C, with_count=True)
         flat = torch.empty(W * mine.numel(), dtype=torch.float32, device=c2.device)
         dist.all_gather_into_tensor(flat, mine, group=group)
-        allv = flat.view(W, mine.numel())
-        counts = allv[:, -1].contiguous()
-        stats_all = allv[:, :-1].contiguous().view(W, 3, C)
-        mean, invstd = ops.bn_finalize(stats_all, counts, W, C, eps, momentum, running_mean, running_var, nbt)
-        n_total = None  # read on device below
-        return mean, invstd, counts
+        n_total = torch.empty(1, dtype=torch.float32, device=c2.device)
+        mean, invstd = ops.bn_finalize(flat, flat.data_ptr() + 12 * C, W, C, eps, momentum, running_mean, running_var,
+                                       nbt, stats_stride=3 * C + 1, counts_stride=3 * C + 1, n_total=n_total)
+        return mean, invstd, n_total
+    stats = ops.bn_stats(c2, rows, C)
     counts = _const1(float(rows), c2.device)
-    mean, invstd = ops.bn_finalize(stats.unsqueeze(0), counts, 1, C, eps, momentum, running_mean, running_var, nbt)
+    mean, invstd = ops.bn_finalize(stats, counts, 1, C, eps, momentum, running_mean, running_var, nbt)
     return mean, invstd, counts
 
 
 def _bn_bwd_sums(sums, counts, rows):
-    """All-reduce the backward sums across the sync group; returns (sums_for_dx, inv_n, n_dev)."""
+    """All-reduce the backward sums across the sync group; returns (sums_for_dx, inv_n, n_dev).  `counts` is what
+    _bn_train_stats returned: under synchronisation the global row count, resident on the device."""
     group = _state["bn_sync"]
     if group is None:
         return sums, 1.0 / rows, None
@@ -878,7 +880,7 @@ def _bn_bwd_sums(sums, counts, rows):
 
     tot = sums.clone()
     dist.all_reduce(tot, group=group)
-    return tot, 0.0, ops.sum_scale(counts, 1.0)  # global row count stays on the device (no host sync)
+    return tot, 0.0, counts  # global row count stays on the device (no host sync)
 
 
 class ConvSublayerFn(torch.autograd.Function):

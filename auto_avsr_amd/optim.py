@@ -3,8 +3,7 @@ cosine learning-rate schedule of the reference (lightning.py:48-52: AdamW(lr, be
 train.py:41: gradient_clip_val=10.0; cosine.py:6-25) as THREE kernel launches over all parameters
 (csrc/optim.hip: avsr_adamw_step), with the step count, learning rate, gradient norm and clip coefficient resident on the
 device -- no host synchronisation, capturable in a hipGraph."""
-import struct
-
+import numpy as np
 import torch
 
 from . import ops
@@ -28,6 +27,18 @@ class FusedAdamW:
         # pinned staging buffers are allocated HERE: hipHostMalloc is not allowed while a stream is capturing, and the
         # pointer table of a captured step can only be built during the capture (that is when its gradients exist)
         self._table_bytes = 48 * len(self.params)
+        # table rows {p, g, m, v, numel, blk0 | 0 << 32} as six u64 (csrc/optim.hip OptEntry): only column 1 (the gradient
+        # address) changes between steps
+        n = len(self.params)
+        self._rows = np.zeros((n, 6), dtype=np.uint64)
+        self._rows[:, 0] = [p.data_ptr() for p in self.params]
+        self._rows[:, 2] = [m.data_ptr() for m in self.exp_avg]
+        self._rows[:, 3] = [v.data_ptr() for v in self.exp_avg_sq]
+        numel = np.array([p.numel() for p in self.params], dtype=np.int64)
+        blocks = (numel + _CHUNK - 1) // _CHUNK
+        self._rows[:, 4] = numel.astype(np.uint64)
+        self._rows[:, 5] = (np.cumsum(blocks) - blocks).astype(np.uint64)
+        self._blocks = int(blocks.sum())
         self._free_host = [self._new_host() for _ in range(8)]
 
     def _new_host(self):
@@ -35,16 +46,15 @@ class FusedAdamW:
         return t.pin_memory() if self.device.type == "cuda" else t
 
     # -- gradient pointer table: gradients are fresh tensors after every backward, so their addresses may move
-    def _table(self):
-        key = tuple(p.grad.data_ptr() for p in self.params)
+    def _table(self, grads):
+        key = tuple([g.data_ptr() for g in grads])
         ent = self._tables.get(key)
         if ent is None:
-            blob, blk = b"", 0
-            for p, m, v in zip(self.params, self.exp_avg, self.exp_avg_sq):
-                g = p.grad
-                assert g.dtype == torch.float32 and g.is_contiguous() and g.numel() == p.numel()
-                blob += struct.pack("<QQQQqii", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), blk, 0)
-                blk += (p.numel() + _CHUNK - 1) // _CHUNK
+            assert all(g.dtype == torch.float32 and g.is_contiguous() and g.numel() == p.numel()
+                       for g, p in zip(grads, self.params)), "gradients must be dense f32 of the parameter's size"
+            rows = self._rows.copy()
+            rows[:, 1] = key
+            blk = self._blocks
             capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
             if not capturing and len(self._tables) >= 16:  # eager address churn: recycle the oldest eager tables
                 for k in [k for k, e in self._tables.items() if not e[5]][:8]:
@@ -54,7 +64,7 @@ class FusedAdamW:
                     raise RuntimeError("FusedAdamW: out of pre-pinned table buffers under hipGraph capture")
                 self._free_host.append(self._new_host())
             host = self._free_host.pop()
-            host.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))  # plain host memcpy
+            host.numpy()[:] = rows.reshape(-1).view(np.uint8)  # plain host memcpy into the pinned buffer
             dev = torch.empty(host.numel(), dtype=torch.uint8, device=self.device)
             ent = self._tables[key] = (host, dev, len(self.params), blk,
                                        torch.empty(blk, dtype=torch.float32, device=self.device), capturing)
@@ -65,9 +75,10 @@ class FusedAdamW:
 
     @torch.no_grad()
     def step(self):
-        if any(p.grad is None for p in self.params):
+        grads = [p.grad for p in self.params]
+        if any(g is None for g in grads):
             raise RuntimeError("FusedAdamW.step(): every trainable parameter needs a gradient")
-        table, n, blk, partial = self._table()
+        table, n, blk, partial = self._table(grads)
         ops.call("avsr_adamw_step", ops._ptr(table), n, blk, ops._ptr(partial), ops._ptr(self.state), self.lr,
                  self.betas[0], self.betas[1], self.eps, self.weight_decay, self.max_grad_norm, self.warmup_steps,
                  self.total_steps, ops._stream(table))

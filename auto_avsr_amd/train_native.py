@@ -44,7 +44,7 @@ def run(args):
     hot = Hot(model)
     if world > 1:
         hot = torch.nn.parallel.DistributedDataParallel(hot, device_ids=[local], find_unused_parameters=False,
-                                                        broadcast_buffers=False, gradient_as_bucket_view=True)
+                                                        broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=64)
     lengths = utterance_lengths()
     batches = rank_batches(bucket_batches(lengths, args.max_frames, args.train_num_buckets), rank, world, seed=0)
     # lightning.py:48-52 + train.py:41 + cosine.py as one fused multi-tensor step (optim.py): AdamW(.9/.98), clip 10,

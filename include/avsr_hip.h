@@ -119,14 +119,17 @@ int avsr_dwconv_wgrad(const void* x, const void* dy, int dtype, float* dw, float
 
 /* ---- training-mode BatchNorm (+SiLU, + residual add) on channels-last [rows, C] ------------------- */
 int64_t avsr_bn_workspace_floats(int C);
-/* stats [3][C] (shift, sum(x-shift), sum((x-shift)^2)), overwritten; workspace: avsr_bn_workspace_floats(C) */
+/* stats [3][C] (shift, sum(x-shift), sum((x-shift)^2)), overwritten; workspace: avsr_bn_workspace_floats(C);
+ * *count_out = (float)rows when != NULL (lets [stats | count] travel as one all-gather payload) */
 int avsr_bn_stats(const void* x, int dtype, float* stats, float* workspace, int64_t rows, int C,
-                  avsr_stream_t stream);
-/* merge `world` per-rank partials [world][3][C] + counts[world] -> mean, invstd; momentum update of the
- * running stats (unbiased variance) when running_mean != NULL; *num_batches_tracked += 1 when != NULL */
-int avsr_bn_finalize(const float* stats, const float* counts, int world, int C, float eps, float momentum,
-                     float* mean, float* invstd, float* running_mean, float* running_var,
-                     int64_t* num_batches_tracked, avsr_stream_t stream);
+                  float* count_out, avsr_stream_t stream);
+/* merge `world` per-rank partials (rank w: stats + w*stats_stride as [3][C], count counts[w*counts_stride]; strides in
+ * floats, 0 = dense [world][3][C] / [world]) -> mean, invstd; momentum update of the running stats (unbiased
+ * variance) when running_mean != NULL; *num_batches_tracked += 1 and *n_total = sum of counts when != NULL */
+int avsr_bn_finalize(const float* stats, const float* counts, int world, int C, int64_t stats_stride,
+                     int64_t counts_stride, float eps, float momentum, float* mean, float* invstd,
+                     float* running_mean, float* running_var, int64_t* num_batches_tracked, float* n_total,
+                     avsr_stream_t stream);
 int avsr_bn_eval_params(const float* running_mean, const float* running_var, float eps, int C, float* mean,
                         float* invstd, avsr_stream_t stream);
 /* y = act(gamma*(x-mean)*invstd + beta (+ add)); act 0 none, 1 SiLU */

@@ -114,3 +114,14 @@ def test_batchnorm_two_rank_merge(dev):
     allx = torch.cat([xa, xb]).double()
     assert (mean.cpu() - allx.mean(0)).abs().max() < 1e-5
     assert (invstd.cpu() - 1 / torch.sqrt(allx.var(0, unbiased=False) + 1e-5)).abs().max() < 1e-5
+    # the all-gather payload form: rank w at flat[w * (3C+1)] = {stats[3][C], row count}, merged in place (strided), with
+    # the global row count left on the device
+    pa, pb = ops.bn_stats(xa.to(dev), 300, C, with_count=True), ops.bn_stats(xb.to(dev), 500, C, with_count=True)
+    assert pa.numel() == 3 * C + 1 and float(pa[-1]) == 300.0 and float(pb[-1]) == 500.0
+    flat = torch.cat([pa, pb])
+    n_total = torch.zeros(1, device=dev)
+    nbt = torch.zeros((), dtype=torch.int64, device=dev)
+    mean2, invstd2 = ops.bn_finalize(flat, flat.data_ptr() + 12 * C, 2, C, 1e-5, 0.1, None, None, nbt,
+                                     stats_stride=3 * C + 1, counts_stride=3 * C + 1, n_total=n_total)
+    assert torch.equal(mean2, mean) and torch.equal(invstd2, invstd)
+    assert float(n_total) == 800.0 and int(nbt) == 1
