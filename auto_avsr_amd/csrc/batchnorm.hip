@@ -134,6 +134,46 @@ __global__ __launch_bounds__(256) void bn_partial_sum_kernel(const float* __rest
     }
 }
 
+// Single-rank statistics in one step: sums the MODE 0 partials [nparts][2][C] (as bn_partial_sum_kernel) and finishes
+// the channel (as bn_finalize_kernel with one rank) -- one launch and one dependent round trip less per BatchNorm.
+template <class T>
+__global__ __launch_bounds__(256) void bn_partial_finalize_kernel(
+    const float* __restrict__ part, int nparts, int C, const T* __restrict__ x0, float n, float eps, float momentum,
+    float* __restrict__ mean_out, float* __restrict__ invstd_out, float* __restrict__ running_mean,
+    float* __restrict__ running_var, int64_t* __restrict__ num_batches_tracked) {
+    __shared__ float red1[16][17], red2[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + tx;
+    float a = 0.f, b = 0.f;
+    if (c < C)
+        for (int p = ty; p < nparts; p += 16) {
+            a += part[(long)p * 2 * C + c];
+            b += part[(long)p * 2 * C + C + c];
+        }
+    red1[ty][tx] = a;
+    red2[ty][tx] = b;
+    __syncthreads();
+    if (ty != 0 || c >= C) return;
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        s1 += (double)red1[q][tx];
+        s2 += (double)red2[q][tx];
+    }
+    const double nn = (double)n;
+    const double mean = (double)Elem<T>::ld(x0 + c) + s1 / nn;
+    const double m2 = s2 - s1 * s1 / nn;
+    const double var = m2 / nn;
+    mean_out[c] = (float)mean;
+    invstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = nn > 1.0 ? m2 / (nn - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+}
+
 // stats: rank w at stats + w*ss: [3][C] (shift, s1, s2); count of rank w at counts[w*cs]; one thread per channel
 __global__ void bn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ counts, int W, int C,
                                    long ss, long cs, float eps, float momentum, float* __restrict__ mean_out,
@@ -280,6 +320,37 @@ extern "C" int avsr_bn_stats(const void* x, int dtype, float* stats, float* work
                     count_out, (float)rows);
     }
     AVSR_CHECK_LAUNCH("bn_stats");
+    return 0;
+}
+
+// avsr_bn_stats + avsr_bn_finalize for one rank (world == 1) in two launches instead of three
+extern "C" int avsr_bn_stats_finalize(const void* x, int dtype, float* workspace, int64_t rows, int C, float eps,
+                                      float momentum, float* mean, float* invstd, float* running_mean,
+                                      float* running_var, int64_t* num_batches_tracked, hipStream_t stream) {
+    AVSR_REQUIRE(C % 8 == 0, "batchnorm: C must be a multiple of 8");
+    AVSR_REQUIRE(rows > 0, "batchnorm: no rows");
+    const int cv = C >> 3, CL = pick_cl(cv);
+    const int rpb = 128 * (BN_THREADS / CL) / 8;
+    const int gx = (cv + CL - 1) / CL;
+    const int parts = bn_parts(rows, rpb, gx);
+    dim3 grid(gx, parts), block(BN_THREADS);
+    dim3 g2((C + 15) / 16);
+    if (dtype == 0) {
+        AVSR_LAUNCH((bn_colreduce_kernel<float, 0>), grid, block, 0, stream, (const float*)x, (const float*)nullptr,
+                    (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                    (const float*)nullptr, workspace, (long)rows, C, CL, rpb, 0);
+        AVSR_LAUNCH((bn_partial_finalize_kernel<float>), g2, dim3(256), 0, stream, (const float*)workspace, parts, C,
+                    (const float*)x, (float)rows, eps, momentum, mean, invstd, running_mean, running_var,
+                    num_batches_tracked);
+    } else {
+        AVSR_LAUNCH((bn_colreduce_kernel<bf16_t, 0>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)nullptr,
+                    (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                    (const float*)nullptr, workspace, (long)rows, C, CL, rpb, 0);
+        AVSR_LAUNCH((bn_partial_finalize_kernel<bf16_t>), g2, dim3(256), 0, stream, (const float*)workspace, parts, C,
+                    (const bf16_t*)x, (float)rows, eps, momentum, mean, invstd, running_mean, running_var,
+                    num_batches_tracked);
+    }
+    AVSR_CHECK_LAUNCH("bn_stats_finalize");
     return 0;
 }
 

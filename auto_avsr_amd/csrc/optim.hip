@@ -36,6 +36,25 @@ AVSR_DEV const OptEntry& find_entry(const OptEntry* table, int n, int blk) {
     return table[lo];
 }
 
+// per-step scalars of the AdamW update, derived from the device-resident state
+struct AdamScalars {
+    float coef, decay, step_size, inv_sqrt_bc2;
+};
+AVSR_DEV AdamScalars adam_scalars(const float* state, float beta1, float beta2, float weight_decay) {
+    const float step = state[0], lr = state[1];
+    const float bc1 = 1.f - powf(beta1, step), bc2 = 1.f - powf(beta2, step);
+    return AdamScalars{state[3], 1.f - lr * weight_decay, lr / bc1, 1.f / sqrtf(bc2)};
+}
+// torch.optim.AdamW (decoupled weight decay, no amsgrad) on one element, g := coef * grad
+AVSR_DEV void adam_update(float& p, float g, float& m, float& v, const AdamScalars& s, float beta1, float beta2, float eps) {
+    const float gk = g * s.coef;
+    p *= s.decay;
+    m = beta1 * m + (1.f - beta1) * gk;
+    v = beta2 * v + (1.f - beta2) * gk * gk;
+    const float denom = sqrtf(v) * s.inv_sqrt_bc2 + eps;
+    p -= s.step_size * (m / denom);
+}
+
 // partial[block] = sum of squares of the block's chunk of gradients
 __global__ __launch_bounds__(256) void multi_sumsq_kernel(const OptEntry* __restrict__ table, int n, float* __restrict__ partial) {
     __shared__ float red[4];
@@ -93,10 +112,11 @@ __global__ __launch_bounds__(256) void multi_adamw_kernel(const OptEntry* __rest
                                                           float eps, float weight_decay) {
     const OptEntry e = find_entry(table, n, blockIdx.x);
     const long base = (long)(blockIdx.x - e.blk0) * OPT_CHUNK;
-    const float step = state[0], lr = state[1], coef = state[3];
-    const float bc1 = 1.f - powf(beta1, step), bc2 = 1.f - powf(beta2, step);
-    const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2), decay = 1.f - lr * weight_decay;
-    const bool aligned = ((((uintptr_t)e.p) | ((uintptr_t)e.g) | ((uintptr_t)e.m) | ((uintptr_t)e.v)) & 15) == 0;
+    const AdamScalars sc = adam_scalars(state, beta1, beta2, weight_decay);
+    // p, m, v are allocations of their own; the gradient may be a view at any dword offset (DDP gradient buckets pack
+    // parameters back to back, and e.g. a 5049-element bias shifts everything behind it by 4 bytes)
+    const bool aligned = ((((uintptr_t)e.p) | ((uintptr_t)e.m) | ((uintptr_t)e.v)) & 15) == 0;
+    const bool g_aligned = (((uintptr_t)e.g) & 15) == 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const long i = base + (threadIdx.x + 256 * j) * 4;
@@ -105,8 +125,11 @@ __global__ __launch_bounds__(256) void multi_adamw_kernel(const OptEntry* __rest
         const bool vec = aligned && i + 3 < e.numel;
         const int cnt = vec ? 4 : (int)((e.numel - i) < 4 ? (e.numel - i) : 4);
         if (vec) {
-            const f32x4 pp = *reinterpret_cast<const f32x4*>(e.p + i), gg = *reinterpret_cast<const f32x4*>(e.g + i);
+            const f32x4 pp = *reinterpret_cast<const f32x4*>(e.p + i);
             const f32x4 mm = *reinterpret_cast<const f32x4*>(e.m + i), vv = *reinterpret_cast<const f32x4*>(e.v + i);
+            f32x4 gg;
+            if (g_aligned) gg = *reinterpret_cast<const f32x4*>(e.g + i);
+            else gg = f32x4{e.g[i], e.g[i + 1], e.g[i + 2], e.g[i + 3]};
 #pragma unroll
             for (int k = 0; k < 4; k++) { p[k] = pp[k]; g[k] = gg[k]; m[k] = mm[k]; v[k] = vv[k]; }
         } else {
@@ -115,12 +138,7 @@ __global__ __launch_bounds__(256) void multi_adamw_kernel(const OptEntry* __rest
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (k >= cnt) break;
-            const float gk = g[k] * coef;
-            p[k] *= decay;
-            m[k] = beta1 * m[k] + (1.f - beta1) * gk;
-            v[k] = beta2 * v[k] + (1.f - beta2) * gk * gk;
-            const float denom = sqrtf(v[k]) * inv_sqrt_bc2 + eps;
-            p[k] -= step_size * (m[k] / denom);
+            adam_update(p[k], g[k], m[k], v[k], sc, beta1, beta2, eps);
         }
         if (vec) {
             *reinterpret_cast<f32x4*>(e.p + i) = f32x4{p[0], p[1], p[2], p[3]};
@@ -128,6 +146,93 @@ __global__ __launch_bounds__(256) void multi_adamw_kernel(const OptEntry* __rest
             *reinterpret_cast<f32x4*>(e.v + i) = f32x4{v[0], v[1], v[2], v[3]};
         } else {
             for (int k = 0; k < cnt; k++) { e.p[i + k] = p[k]; e.m[i + k] = m[k]; e.v[i + k] = v[k]; }
+        }
+    }
+}
+
+// AdamW on 2-D weights whose bf16 operand copies the GEMMs read (gemm_fast.hip: AvsrCastEntry) are refreshed in the same
+// pass: block = one 64x64 tile; the updated tile leaves as f32 (p, m, v), as bf16 [R][C] (dst) and, through LDS, as the
+// transposed bf16 [C][ldT] (dstT, rows [R, limT) zero).  Saves the separate re-cast launch -- a second read of every
+// f32 weight -- that an optimizer step otherwise forces before the next forward pass.
+struct OptTileEntry {  // 80 bytes
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    bf16_t* dst;   // may be null
+    bf16_t* dstT;  // may be null
+    int R, C, ldT, blk0, tiles_c, limT;
+    int pad0, pad1;
+};
+
+__global__ __launch_bounds__(256) void multi_adamw_cast_kernel(const OptTileEntry* __restrict__ table, int n,
+                                                               const float* __restrict__ state, float beta1, float beta2,
+                                                               float eps, float weight_decay) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64 * 72];
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {  // last entry with blk0 <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const OptTileEntry e = table[lo];
+    const AdamScalars sc = adam_scalars(state, beta1, beta2, weight_decay);
+    const int local = blockIdx.x - e.blk0;
+    const int r0 = (local / e.tiles_c) * 64, c0 = (local % e.tiles_c) * 64;
+    const bool vec_ok = (e.C % 8 == 0) && ((((uintptr_t)e.p) | ((uintptr_t)e.m) | ((uintptr_t)e.v)) & 15) == 0;
+    const bool g_aligned = (((uintptr_t)e.g) & 15) == 0;  // the gradient may be a dword-aligned bucket view
+    const int cc = (threadIdx.x & 7) * 8;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int r = (threadIdx.x >> 3) + 32 * half;
+        const int gr = r0 + r, gc = c0 + cc;
+        const long off = (long)gr * e.C + gc;
+        float p[8], g[8], m[8], v[8];
+        const bool vec = gr < e.R && vec_ok && gc + 8 <= e.C;
+        const int cnt = gr < e.R ? (vec ? 8 : (e.C - gc < 8 ? (e.C - gc > 0 ? e.C - gc : 0) : 8)) : 0;
+        if (vec) {
+            load8(e.p + off, p);
+            if (g_aligned) load8(e.g + off, g);
+            else
+#pragma unroll
+                for (int k = 0; k < 8; k++) g[k] = e.g[off + k];
+            load8(e.m + off, m);
+            load8(e.v + off, v);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const bool ok = k < cnt;
+                p[k] = ok ? e.p[off + k] : 0.f;
+                g[k] = ok ? e.g[off + k] : 0.f;
+                m[k] = ok ? e.m[off + k] : 0.f;
+                v[k] = ok ? e.v[off + k] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < cnt) adam_update(p[k], g[k], m[k], v[k], sc, beta1, beta2, eps);
+        if (vec) {
+            store8(e.p + off, p);
+            store8(e.m + off, m);
+            store8(e.v + off, v);
+            if (e.dst) store8(e.dst + off, p);
+        } else {
+            for (int k = 0; k < cnt; k++) {
+                e.p[off + k] = p[k];
+                e.m[off + k] = m[k];
+                e.v[off + k] = v[k];
+                if (e.dst) e.dst[off + k] = f2bf(p[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) tile[(cc + k) * 72 + r] = f2bf(p[k]);  // rows/columns past the matrix are zero
+    }
+    __syncthreads();
+    if (e.dstT) {
+        for (int id = threadIdx.x; id < 64 * 8; id += 256) {
+            const int c = id >> 3, rr = (id & 7) * 8;
+            const int gc = c0 + c, gr = r0 + rr;
+            if (gc < e.C && gr < (e.limT ? e.limT : e.ldT))
+                *reinterpret_cast<bf16x8*>(e.dstT + (long)gc * e.ldT + gr) = *reinterpret_cast<const bf16x8*>(tile + c * 72 + rr);
         }
     }
 }
@@ -150,5 +255,34 @@ extern "C" int avsr_adamw_step(const void* table, int n, int total_blocks, float
     AVSR_LAUNCH(multi_adamw_kernel, dim3(total_blocks), dim3(256), 0, stream, t, n, (const float*)state, beta1, beta2, eps,
                 weight_decay);
     AVSR_CHECK_LAUNCH("adamw_step");
+    return 0;
+}
+
+// The same step with the bf16 operand copies of the 2-D weights refreshed in the update pass:
+//   table / n / total_blocks   every parameter (48-byte entries as above): gradient norm
+//   lin_table / lin_n / lin_blocks   the parameters updated by the linear kernel (same entry format, own blk0 numbering)
+//   tile_table / tile_n / tile_blocks   80-byte entries {p, g, m, v, dst, dstT (bf16, may be 0), int R, C, ldT, blk0,
+//       tiles_c, limT, 0, 0}: weights [R][C] updated tile-wise, blk0 = running sum of
+//       ceil(max(R, limT ? limT : ldT) / 64) * ceil(C / 64) as in avsr_multi_cast_transpose
+// Every parameter must be in exactly one of lin_table / tile_table.
+extern "C" int avsr_adamw_cast_step(const void* table, int n, int total_blocks, const void* lin_table, int lin_n,
+                                    int lin_blocks, const void* tile_table, int tile_n, int tile_blocks, float* partial,
+                                    float* state, float base_lr, float beta1, float beta2, float eps, float weight_decay,
+                                    float max_grad_norm, int64_t warmup_steps, int64_t total_steps, hipStream_t stream) {
+    if (n <= 0 || total_blocks <= 0) return 0;
+    AVSR_REQUIRE(table && partial && state, "adamw_cast_step: null argument");
+    AVSR_REQUIRE((lin_n <= 0 || lin_table) && (tile_n <= 0 || tile_table), "adamw_cast_step: null table");
+    const OptEntry* t = reinterpret_cast<const OptEntry*>(table);
+    AVSR_LAUNCH(multi_sumsq_kernel, dim3(total_blocks), dim3(256), 0, stream, t, n, partial);
+    AVSR_LAUNCH(clip_coef_kernel, dim3(1), dim3(256), 0, stream, (const float*)partial, total_blocks, max_grad_norm, base_lr,
+                (float)warmup_steps, (float)total_steps, state);
+    if (tile_n > 0 && tile_blocks > 0)
+        AVSR_LAUNCH(multi_adamw_cast_kernel, dim3(tile_blocks), dim3(256), 0, stream,
+                    reinterpret_cast<const OptTileEntry*>(tile_table), tile_n, (const float*)state, beta1, beta2, eps,
+                    weight_decay);
+    if (lin_n > 0 && lin_blocks > 0)
+        AVSR_LAUNCH(multi_adamw_kernel, dim3(lin_blocks), dim3(256), 0, stream, reinterpret_cast<const OptEntry*>(lin_table),
+                    lin_n, (const float*)state, beta1, beta2, eps, weight_decay);
+    AVSR_CHECK_LAUNCH("adamw_cast_step");
     return 0;
 }

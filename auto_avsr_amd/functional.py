@@ -93,10 +93,45 @@ _wconv = {}    # (data_ptr, to_dgrad, shape) -> [version, bf16 permuted copy, co
 _wconv_table = {"n": 0, "dev": None, "blocks": 0, "built_for": -1}
 
 
+_wgen = {"cleared": 0, "owner": None, "owner_gen": None}
+
+
+def _cast_generation():
+    return (_wgen["cleared"], len(_wcache))
+
+
+def weight_cast_groups():
+    """(generation, [(weight, bf16 copy or None, transposed bf16 copy or None, R, C, ldT, limT)]) of every registered
+    Linear-type weight -- what refresh_weight_cache() re-casts.  An optimizer that rewrites these copies itself
+    (optim.FusedAdamW(cast_weights=True)) reads the list here and claims it with claim_weight_casts()."""
+    groups = {}
+    for (ptr, transposed, shape), ent in _wcache.items():
+        g = groups.setdefault((ptr, shape), [ent[2], None, None])
+        g[2 if transposed else 1] = ent[1]
+    out = []
+    for (ptr, shape), (w, dst, dstT) in groups.items():
+        R, C = shape
+        ldT = dstT.stride(0) if dstT is not None else 0   # a slice of a concatenation has pitch > its own width
+        limT = dstT.shape[1] if dstT is not None else 0
+        out.append((w, dst, dstT, R, C, ldT, limT))
+    return _cast_generation(), out
+
+
+def claim_weight_casts(owner, generation):
+    """`owner` (held weakly) has just rewritten every copy listed by weight_cast_groups() at `generation` and will do so
+    after each of its steps: refresh_weight_cache() skips the Linear re-cast while that stays true."""
+    import weakref
+
+    _wgen["owner"] = weakref.ref(owner) if owner is not None else None
+    _wgen["owner_gen"] = generation
+
+
 def invalidate_weight_cache():
     _wcache.clear()
     _wcat.clear()
     _wconv.clear()
+    _wgen["cleared"] += 1
+    _wgen["owner"] = None
     _wtable.update(n=0, dev=None, blocks=0, built_for=-1)
     _wconv_table.update(n=0, dev=None, blocks=0, built_for=-1)
 
@@ -147,24 +182,21 @@ def refresh_weight_cache():
     _refresh_conv_weights()
     if not _wcache:
         return
+    owner = _wgen["owner"]() if _wgen["owner"] is not None else None
+    if owner is not None and _wgen["owner_gen"] == _cast_generation():
+        return  # the optimizer step rewrote every copy together with the weights (optim.FusedAdamW cast_weights=True)
     if _wtable["built_for"] != len(_wcache):
         import struct
 
-        groups = {}
-        for (ptr, transposed, shape), ent in _wcache.items():
-            g = groups.setdefault((ptr, shape), [ent[2], None, None])
-            g[2 if transposed else 1] = ent[1]
         blob, blk = b"", 0
-        for (ptr, shape), (w, dst, dstT) in groups.items():
-            R, C = shape
-            ldT = dstT.stride(0) if dstT is not None else 0   # a slice of a concatenation has pitch > its own width
-            limT = dstT.shape[1] if dstT is not None else 0
+        groups = weight_cast_groups()[1]
+        for (w, dst, dstT, R, C, ldT, limT) in groups:
             tiles_c = (C + 63) // 64
             tiles_r = (max(R, limT) + 63) // 64
             blob += struct.pack("<QQQiiiiiiii", w.data_ptr(), dst.data_ptr() if dst is not None else 0,
                                 dstT.data_ptr() if dstT is not None else 0, R, C, ldT, blk, tiles_c, limT, 0, 0)
             blk += tiles_r * tiles_c
-        dev = next(iter(groups.values()))[0].device
+        dev = groups[0][0].device
         host = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
         _wtable.update(n=len(groups), dev=host.to(dev), blocks=blk, built_for=len(_wcache))
     ops.multi_cast_transpose(_wtable["dev"], _wtable["n"], _wtable["blocks"])
@@ -864,10 +896,8 @@ def _bn_train_stats(c2, rows, C, eps, momentum, running_mean, running_var, nbt=N
         mean, invstd = ops.bn_finalize(flat, flat.data_ptr() + 12 * C, W, C, eps, momentum, running_mean, running_var,
                                        nbt, stats_stride=3 * C + 1, counts_stride=3 * C + 1, n_total=n_total)
         return mean, invstd, n_total
-    stats = ops.bn_stats(c2, rows, C)
-    counts = _const1(float(rows), c2.device)
-    mean, invstd = ops.bn_finalize(stats, counts, 1, C, eps, momentum, running_mean, running_var, nbt)
-    return mean, invstd, counts
+    mean, invstd = ops.bn_stats_finalize(c2, rows, C, eps, momentum, running_mean, running_var, nbt)
+    return mean, invstd, None
 
 
 def _bn_bwd_sums(sums, counts, rows):

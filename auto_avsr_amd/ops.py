@@ -219,6 +219,16 @@ def bn_stats(x, rows, C, with_count=False):
     return flat if with_count else flat.view(3, C)
 
 
+def bn_stats_finalize(x, rows, C, eps, momentum, running_mean, running_var, num_batches_tracked=None):
+    """(mean, invstd) of the rows of x + running-stat update, single rank."""
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = torch.empty(1024 * 2 * C, dtype=torch.float32, device=x.device)
+    call("avsr_bn_stats_finalize", _ptr(x), dt(x), _ptr(ws), rows, C, eps, momentum, _ptr(mean), _ptr(invstd),
+         _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _stream(x))
+    return mean, invstd
+
+
 def bn_finalize(stats, counts, world, C, eps, momentum, running_mean, running_var, num_batches_tracked=None,
                 stats_stride=0, counts_stride=0, n_total=None):
     """counts: tensor or raw device address of the first count."""

@@ -2,7 +2,11 @@
 cosine learning-rate schedule of the reference (lightning.py:48-52: AdamW(lr, betas=(0.9, 0.98), weight_decay);
 train.py:41: gradient_clip_val=10.0; cosine.py:6-25) as THREE kernel launches over all parameters
 (csrc/optim.hip: avsr_adamw_step), with the step count, learning rate, gradient norm and clip coefficient resident on the
-device -- no host synchronisation, capturable in a hipGraph."""
+device -- no host synchronisation, capturable in a hipGraph.
+
+cast_weights=True additionally rewrites the bf16 operand copies of the Linear weights (functional.py weight cache) inside
+the update pass (avsr_adamw_cast_step): the step then leaves the model ready for the next forward pass, and the separate
+re-cast launch -- a second read of every f32 weight -- disappears from the training step."""
 import numpy as np
 import torch
 
@@ -13,7 +17,7 @@ _CHUNK = 4096
 
 class FusedAdamW:
     def __init__(self, params, lr, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0, max_grad_norm=0.0, warmup_steps=0,
-                 total_steps=0):
+                 total_steps=0, cast_weights=False):
         self.params = [p for p in params if p.requires_grad]
         assert self.params, "no trainable parameters"
         assert all(p.dtype == torch.float32 and p.is_contiguous() for p in self.params), "f32 contiguous master weights"
@@ -26,7 +30,9 @@ class FusedAdamW:
         self._tables = {}  # gradient addresses -> (pinned host table, device table, n, blocks, scratch, made under capture)
         # pinned staging buffers are allocated HERE: hipHostMalloc is not allowed while a stream is capturing, and the
         # pointer table of a captured step can only be built during the capture (that is when its gradients exist)
-        self._table_bytes = 48 * len(self.params)
+        self.cast_weights = bool(cast_weights)
+        self._cast_plan = None  # (generation, covered parameter mask, linear rows, linear blocks, tile rows, tile blocks)
+        self._table_bytes = (48 + 48 + 80) * len(self.params)  # full + linear + tile tables share one buffer
         # table rows {p, g, m, v, numel, blk0 | 0 << 32} as six u64 (csrc/optim.hip OptEntry): only column 1 (the gradient
         # address) changes between steps
         n = len(self.params)
@@ -46,15 +52,59 @@ class FusedAdamW:
         return t.pin_memory() if self.device.type == "cuda" else t
 
     # -- gradient pointer table: gradients are fresh tensors after every backward, so their addresses may move
-    def _table(self, grads):
+    def _plan(self):
+        """Split of the parameters into tile-updated Linear weights (with their bf16 copies) and the rest, for the
+        current content of the functional weight cache.  None: nothing registered (yet) -- plain step."""
+        from . import functional as AF
+
+        gen, groups = AF.weight_cast_groups()
+        if self._cast_plan is not None and self._cast_plan[0] == gen:
+            return self._cast_plan
+        index = {p.data_ptr(): i for i, p in enumerate(self.params)}
+        covered = np.zeros(len(self.params), dtype=bool)
+        tiles, blk = [], 0
+        for (w, dst, dstT, R, C, ldT, limT) in groups:
+            i = index.get(w.data_ptr())
+            if i is None or covered[i] or self.params[i].numel() != R * C:
+                continue  # not ours (frozen) -- or an alias we cannot express: the ordinary re-cast must stay
+            covered[i] = True
+            tiles_c = (C + 63) // 64
+            tiles.append((i, dst.data_ptr() if dst is not None else 0, dstT.data_ptr() if dstT is not None else 0,
+                          R, C, ldT, blk, tiles_c, limT))
+            blk += ((max(R, limT) + 63) // 64) * tiles_c
+        ours = sum(1 for g in groups if g[0].data_ptr() in index)
+        if not tiles or len(tiles) != ours:
+            self._cast_plan = (gen, None)
+            return self._cast_plan
+        trow = np.zeros(len(tiles), dtype=np.dtype([("ptr", "<u8", 6), ("i", "<i4", 8)]))
+        for k, (i, d, dT, R, C, ldT, b0, tc, limT) in enumerate(tiles):
+            trow["ptr"][k] = (self._rows[i, 0], 0, self._rows[i, 2], self._rows[i, 3], d, dT)
+            trow["i"][k] = (R, C, ldT, b0, tc, limT, 0, 0)
+        lin = self._rows[~covered].copy()
+        nb = (lin[:, 4].astype(np.int64) + _CHUNK - 1) // _CHUNK
+        lin[:, 5] = (np.cumsum(nb) - nb).astype(np.uint64)
+        self._cast_plan = (gen, covered, lin, int(nb.sum()), trow, blk, np.array([t[0] for t in tiles]))
+        return self._cast_plan
+
+    def _table(self, grads, plan=None):
         key = tuple([g.data_ptr() for g in grads])
+        if plan is not None:
+            key = key + plan[0]  # cache generation: (invalidations, registered copies)
         ent = self._tables.get(key)
         if ent is None:
             assert all(g.dtype == torch.float32 and g.is_contiguous() and g.numel() == p.numel()
                        for g, p in zip(grads, self.params)), "gradients must be dense f32 of the parameter's size"
             rows = self._rows.copy()
-            rows[:, 1] = key
+            rows[:, 1] = key[:len(grads)]
             blk = self._blocks
+            blob = rows.reshape(-1).view(np.uint8)
+            if plan is not None:
+                _, covered, lin, lin_blk, trow, tile_blk, tidx = plan
+                lin = lin.copy()
+                lin[:, 1] = rows[~covered, 1]
+                trow = trow.copy()
+                trow["ptr"][:, 1] = rows[tidx, 1]
+                blob = np.concatenate([blob, lin.reshape(-1).view(np.uint8), trow.view(np.uint8).reshape(-1)])
             capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
             if not capturing and len(self._tables) >= 16:  # eager address churn: recycle the oldest eager tables
                 for k in [k for k, e in self._tables.items() if not e[5]][:8]:
@@ -64,7 +114,7 @@ class FusedAdamW:
                     raise RuntimeError("FusedAdamW: out of pre-pinned table buffers under hipGraph capture")
                 self._free_host.append(self._new_host())
             host = self._free_host.pop()
-            host.numpy()[:] = rows.reshape(-1).view(np.uint8)  # plain host memcpy into the pinned buffer
+            host.numpy()[:blob.size] = blob  # plain host memcpy into the pinned buffer
             dev = torch.empty(host.numel(), dtype=torch.uint8, device=self.device)
             ent = self._tables[key] = (host, dev, len(self.params), blk,
                                        torch.empty(blk, dtype=torch.float32, device=self.device), capturing)
@@ -78,10 +128,24 @@ class FusedAdamW:
         grads = [p.grad for p in self.params]
         if any(g is None for g in grads):
             raise RuntimeError("FusedAdamW.step(): every trainable parameter needs a gradient")
-        table, n, blk, partial = self._table(grads)
-        ops.call("avsr_adamw_step", ops._ptr(table), n, blk, ops._ptr(partial), ops._ptr(self.state), self.lr,
-                 self.betas[0], self.betas[1], self.eps, self.weight_decay, self.max_grad_norm, self.warmup_steps,
-                 self.total_steps, ops._stream(table))
+        plan = self._plan() if self.cast_weights else None
+        if plan is not None and plan[1] is None:
+            plan = None
+        table, n, blk, partial = self._table(grads, plan)
+        if plan is None:
+            ops.call("avsr_adamw_step", ops._ptr(table), n, blk, ops._ptr(partial), ops._ptr(self.state), self.lr,
+                     self.betas[0], self.betas[1], self.eps, self.weight_decay, self.max_grad_norm, self.warmup_steps,
+                     self.total_steps, ops._stream(table))
+            return
+        from . import functional as AF
+
+        gen, _, lin, lin_blk, trow, tile_blk, _ = plan
+        base = table.data_ptr()
+        lin_ptr, tile_ptr = base + 48 * n, base + 48 * n + 48 * len(lin)
+        ops.call("avsr_adamw_cast_step", base, n, blk, lin_ptr, len(lin), lin_blk, tile_ptr, len(trow), tile_blk,
+                 ops._ptr(partial), ops._ptr(self.state), self.lr, self.betas[0], self.betas[1], self.eps,
+                 self.weight_decay, self.max_grad_norm, self.warmup_steps, self.total_steps, ops._stream(table))
+        AF.claim_weight_casts(self, gen)  # refresh_weight_cache() now has nothing to do for the Linear copies
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:

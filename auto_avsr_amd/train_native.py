@@ -52,7 +52,8 @@ def run(args):
     from .optim import FusedAdamW
 
     opt = FusedAdamW(model.parameters(), lr=args.lr, betas=(0.9, 0.98), weight_decay=args.weight_decay, max_grad_norm=10.0,
-                     warmup_steps=args.warmup_epochs * len(batches), total_steps=args.max_epochs * len(batches))
+                     warmup_steps=args.warmup_epochs * len(batches), total_steps=args.max_epochs * len(batches),
+                     cast_weights=True)
     total = args.steps or args.max_epochs * len(batches)
     t0 = time.time()
     for step in range(total):

@@ -105,11 +105,12 @@ def main():
     opt = None
     if not args.no_optimizer:
         # the reference's optimisation (lightning.py:48-52, train.py:41): AdamW(1e-3, (0.9, 0.98), wd 0.03), global-norm
-        # clip 10, per-step warm-up cosine -- one fused multi-tensor step (auto_avsr_amd/optim.py)
+        # clip 10, per-step warm-up cosine -- one fused multi-tensor step (auto_avsr_amd/optim.py) that also rewrites the
+        # bf16 operand copies of the Linear weights, so the next forward pass needs no separate re-cast of 250M weights
         from auto_avsr_amd.optim import FusedAdamW
 
         opt = FusedAdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.98), weight_decay=0.03, max_grad_norm=10.0,
-                         warmup_steps=5 * 1000, total_steps=75 * 1000)
+                         warmup_steps=5 * 1000, total_steps=75 * 1000, cast_weights=True)
     if world > 1:
         # train.py:37 DDPStrategy(find_unused_parameters=False): bucketed gradient all-reduce over RCCL/xGMI
         # 64 MB buckets: ring all-reduce over point-to-point xGMI links is per-link bound and wants large messages;

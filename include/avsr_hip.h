@@ -130,6 +130,10 @@ int avsr_bn_finalize(const float* stats, const float* counts, int world, int C, 
                      int64_t counts_stride, float eps, float momentum, float* mean, float* invstd,
                      float* running_mean, float* running_var, int64_t* num_batches_tracked, float* n_total,
                      avsr_stream_t stream);
+/* single-rank training statistics: avsr_bn_stats + avsr_bn_finalize(world = 1) fused (two launches, not three) */
+int avsr_bn_stats_finalize(const void* x, int dtype, float* workspace, int64_t rows, int C, float eps,
+                           float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
+                           int64_t* num_batches_tracked, avsr_stream_t stream);
 int avsr_bn_eval_params(const float* running_mean, const float* running_var, float eps, int C, float* mean,
                         float* invstd, avsr_stream_t stream);
 /* y = act(gamma*(x-mean)*invstd + beta (+ add)); act 0 none, 1 SiLU */
@@ -294,6 +298,19 @@ int avsr_ctc_prefix_score(const float* logp, int T, int V, int ldv, const float*
 int avsr_adamw_step(const void* table, int n, int total_blocks, float* partial, float* state, float base_lr, float beta1,
                     float beta2, float eps, float weight_decay, float max_grad_norm, int64_t warmup_steps,
                     int64_t total_steps, avsr_stream_t stream);
+/* The same step with the bf16 operand copies of 2-D weights (see avsr_multi_cast_transpose) rewritten in the update pass,
+ * so that no separate re-cast launch re-reads the f32 weights before the next forward pass:
+ *   table / n / total_blocks          every parameter (48-byte entries as above) -- gradient norm only
+ *   lin_table / lin_n / lin_blocks    parameters updated by the linear kernel (same format, own blk0 numbering)
+ *   tile_table / tile_n / tile_blocks 80-byte entries {float* p, const float* g, float* m, float* v, bf16* dst,
+ *       bf16* dstT (either may be 0), int R, C, ldT, blk0, tiles_c, limT, 0, 0}: weight [R][C] updated in 64x64 tiles,
+ *       dst = bf16 [R][C], dstT = bf16 [C][ldT] (rows [R, limT) zero; limT 0 = ldT), blk0 = running sum of
+ *       ceil(max(R, limT ? limT : ldT)/64) * ceil(C/64)
+ * Every parameter must appear in exactly one of lin_table / tile_table. */
+int avsr_adamw_cast_step(const void* table, int n, int total_blocks, const void* lin_table, int lin_n, int lin_blocks,
+                         const void* tile_table, int tile_n, int tile_blocks, float* partial, float* state,
+                         float base_lr, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
+                         int64_t warmup_steps, int64_t total_steps, avsr_stream_t stream);
 
 #ifdef __cplusplus
 }

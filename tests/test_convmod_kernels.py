@@ -91,6 +91,11 @@ def test_batchnorm_train(dev, C, with_add, act):
     rmd, rvd = rm.to(dev), rv.to(dev)
     mean, invstd = ops.bn_finalize(stats.unsqueeze(0), counts, 1, C, bn.eps, bn.momentum, rmd, rvd)
     assert (rmd.cpu() - bn.running_mean).abs().max() < 1e-4 and (rvd.cpu() - bn.running_var).abs().max() < 1e-3
+    # the single-rank fused form (statistics + finalize in two launches) gives the same numbers
+    rm2, rv2, nbt = rm.to(dev), rv.to(dev), torch.zeros((), dtype=torch.int64, device=dev)
+    mean2, invstd2 = ops.bn_stats_finalize(xd, rows, C, bn.eps, bn.momentum, rm2, rv2, nbt)
+    assert (mean2 - mean).abs().max() < 1e-6 and ((invstd2 - invstd).abs() / invstd).max() < 1e-6
+    assert (rm2 - rmd).abs().max() < 1e-6 and (rv2 - rvd).abs().max() < 1e-5 and int(nbt) == 1
     g, b = bn.weight.detach().to(dev), bn.bias.detach().to(dev)
     y = ops.bn_act_fwd(xd, addd, mean, invstd, g, b, rows, C, act)
     assert (y.cpu() - y_ref).abs().max() < 1e-4

@@ -43,8 +43,70 @@ def test_fused_adamw_matches_torch(dev, clip):
             assert (p.detach() - q.detach().cpu()).abs().max() < 2e-6 * max(1.0, float(p.detach().abs().max()))
 
 
+def test_fused_adamw_cast_weights(dev):
+    """cast_weights=True: same parameters / moments as the plain fused step, and the bf16
+    operand copies of the registered Linear weights (plain, transposed, slices of a Q/K/V concatenation) equal a fresh
+    re-cast of the updated weights -- with refresh_weight_cache() turned into a no-op for them."""
+    from auto_avsr_amd import functional as AF
+
+    torch.manual_seed(5)
+    shapes = [(128, 64), (64, 128), (64, 64), (64, 64), (64, 64), (72, 40), (64,), (5049,), (3, 1, 5, 7, 7)]
+
+    def make(cast):
+        torch.manual_seed(11)
+        ps = [torch.nn.Parameter(torch.randn(s).to(dev)) for s in shapes]
+        return ps, FusedAdamW(ps, lr=1e-2, weight_decay=0.03, max_grad_norm=1.0, warmup_steps=2, total_steps=8,
+                              cast_weights=cast)
+
+    AF.invalidate_weight_cache()
+    pa, oa = make(False)
+    pb, ob = make(True)
+    # register copies of pb's 2-D weights the way the modules do: forward copy, data-gradient (transposed) copy, fused QKV
+    copies = [(pb[0], False), (pb[0], True), (pb[1], True), (pb[5], False), (pb[5], True)]
+    got = [AF._w_bf16(w, t) for w, t in copies]
+    cat = AF._w_bf16_cat([pb[2], pb[3], pb[4]], False)
+    catT = AF._w_bf16_cat([pb[2], pb[3], pb[4]], True)
+    for it in range(3):
+        gs = [torch.randn(s) * (3.0 if it % 2 else 0.3) for s in shapes]
+        for p, q, g in zip(pa, pb, gs):
+            p.grad, q.grad = g.clone().to(dev), g.clone().to(dev)
+        oa.step()
+        ob.step()
+        for p, q, ma, mb, va, vb in zip(pa, pb, oa.exp_avg, ob.exp_avg, oa.exp_avg_sq, ob.exp_avg_sq):
+            # same arithmetic in two kernels: equal up to the compiler's choice of fused multiply-adds
+            for a, b in ((p.detach(), q.detach()), (ma, mb), (va, vb)):
+                assert (a - b).abs().max() <= 1e-6 * max(1.0, float(a.abs().max()))
+        assert AF._wgen["owner"] is not None and AF._wgen["owner"]() is ob
+        launches = []
+        orig = AF.ops.multi_cast_transpose
+        AF.ops.multi_cast_transpose = lambda *a, **k: launches.append(a)
+        try:
+            AF.refresh_weight_cache()  # nothing left to do
+        finally:
+            AF.ops.multi_cast_transpose = orig
+        assert not launches
+        for (w, t), c in zip(copies, got):
+            ref = w.detach().cpu().to(torch.bfloat16)
+            if t:
+                assert torch.equal(c.cpu()[:, :w.shape[0]], ref.t()) and not c.cpu()[:, w.shape[0]:].any()
+            else:
+                assert torch.equal(c.cpu(), ref)
+        full = torch.cat([pb[2], pb[3], pb[4]]).detach().cpu().to(torch.bfloat16)
+        assert torch.equal(cat.cpu(), full) and torch.equal(catT.cpu(), full.t())
+    # a weight registered later changes the cache generation: the claim lapses until the next optimizer step
+    AF._w_bf16(pb[1], False)
+    assert AF._wgen["owner_gen"] != AF._cast_generation()
+    for q in pb:
+        q.grad = torch.ones_like(q)
+    ob.step()
+    assert AF._wgen["owner_gen"] == AF._cast_generation()
+    assert torch.equal(AF._w_bf16(pb[1], False).cpu(), pb[1].detach().cpu().to(torch.bfloat16))
+    AF.invalidate_weight_cache()
+
+
 @pytest.mark.gpu
-def test_fused_adamw_under_hipgraph():
+@pytest.mark.parametrize("cast", [False, True], ids=["plain", "cast_weights"])
+def test_fused_adamw_under_hipgraph(cast):
     """The whole training step (forward, backward, fused optimizer, bf16 weight re-cast) captured once and replayed:
     parameters after three replays equal three eager steps (the step count, learning rate and clip coefficient live on
     the device, the gradient pointer table is re-sent from its pinned buffer by a captured copy node)."""
@@ -56,7 +118,7 @@ def test_fused_adamw_under_hipgraph():
         torch.manual_seed(3)
         l1, l2 = torch.nn.Linear(64, 128).to(dev), torch.nn.Linear(128, 64).to(dev)
         return l1, l2, FusedAdamW(list(l1.parameters()) + list(l2.parameters()), lr=1e-2, weight_decay=0.03, max_grad_norm=1.0,
-                                 warmup_steps=2, total_steps=8)
+                                 warmup_steps=2, total_steps=8, cast_weights=cast)
 
     x = torch.randn(32, 64, device=dev).bfloat16()
 
@@ -88,6 +150,7 @@ def test_fused_adamw_under_hipgraph():
             for t in go.exp_avg + go.exp_avg_sq:
                 t.zero_()
             go.state.zero_()
+        AF.claim_weight_casts(None, None)  # the parameters were rewound behind the optimizer's back
         AF.refresh_weight_cache()  # builds the cast table (H2D copy) outside the capture
     torch.cuda.current_stream().wait_stream(work)
     torch.cuda.synchronize()
