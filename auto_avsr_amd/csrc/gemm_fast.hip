@@ -13,8 +13,8 @@
 //    the ds_read_b128 address on the way out -- conflict-free for the 32x32x16 MFMA fragment reads;
 //  * 256 threads = 2x2 waves, each wave a (BM/2)x(BN/2) grid of v_mfma_f32_32x32x16_bf16 accumulators;
 //  * rows beyond M / N are clamped on load (never stored); split-K over blockIdx.z with f32 atomics.
-#include <type_traits>
-#include "gemm_core.h"
+#include "gemm_fast_kernel.h"
+#include "gemm_pair.h"
 #include "avsr_hip.h"
 
 namespace {
@@ -25,251 +25,7 @@ using avsr_gemm_impl::Params;
 // (benchmarks only)
 #define g_tune avsr_tune_knobs
 
-// CV = 0: plain A[M][K].  CV = 1 / 2: A is the im2col view of a channels-last image tensor (forward / data gradient,
-// see gemm_core.h Params); channels are a multiple of 64, so a 64-wide k-tile lies inside one filter tap and the
-// tap decode is wave-uniform (scalar); out-of-image taps read a caller-provided page of zeros.
-//
-// Gather addressing.  Every A row a lane stages is decoded ONCE per block into (pointer to tap (0,0) of that row,
-// bit mask of the taps that fall inside the image); inside the k loop a load costs one 64-bit add of a scalar tap
-// offset and a select against the zero page.  The data gradient of a strided convolution is split into the s*s
-// residue classes of (ih+ph, iw+pw) mod s: a class only ever touches the taps kh = py (mod s), kw = px (mod s), so
-// each class is a dense implicit GEMM over its own (shorter) tap list and no MFMA is spent on structural zeros.
-//
-// WGM x WGN waves per block (64*WGM*WGN threads), each wave a (BM/WGM) x (BN/WGN) grid of 32x32x16 accumulators.
-// ABL (benchmarks only): 1 = no LDS reads / MFMA, 2 = no operand loads in the steady state.
-template <int BM, int BN, int STAGES, int CV = 0, int WGM = 2, int WGN = 2, int ABL = 0>
-struct FastKernel {
-    static constexpr int BK = 64, NW = WGM * WGN, NTHR = 64 * NW;
-    static constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
-    static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
-    static constexpr int A_LOADS = BM / (8 * NW), B_LOADS = BN / (8 * NW);  // wave-instructions per wave per stage
-    static constexpr int LPT = A_LOADS + B_LOADS;                           // LDS-DMA ops per thread per tile
-    static constexpr size_t RING_BYTES = (size_t)STAGES * STAGE_BYTES, EPI_BYTES = (size_t)BM * (BN + 4) * 4;
-    static constexpr size_t MAP_OFF = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
-    static constexpr size_t LDS_BYTES = MAP_OFF + (CV == 2 ? BM * 4 : 0);
-    static_assert(A_LOADS >= 1 && B_LOADS >= 1 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile / wave-count mismatch");
-    static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
-
-    struct Rows {
-        const bf16_t* a[A_LOADS];  // CV 0: &A[row][8c] ; CV 1/2: &src[pixel of tap (0,0)][8c] (may lie outside the tensor)
-        uint32_t mask[A_LOADS];    // CV 1/2: bit t set <=> tap t of the block's tap list reads inside the image
-        const bf16_t* b[B_LOADS];  // &B[row][8c]
-    };
-    // wave-uniform description of the tap list this block walks
-    struct Taps {
-        int nkw, ntaps, cpt;  // taps per filter row, tap count, 64-wide k-tiles per tap
-        int py, px;           // CV 2: residue class
-    };
-
-    // tile row r (of this block) -> (image n, grid coordinates a, b) ; false when the row is beyond the class
-    static AVSR_DEV bool row_coords(const Params& p, int cls, int mloc, int& n, int& a, int& b) {
-        const int hc = p.cls_h[cls], wc = p.cls_w[cls];
-        const long mc = (long)p.cN * hc * wc;
-        const bool ok = mloc < mc;
-        const int m = ok ? mloc : (int)(mc - 1);
-        const int pix = hc * wc;
-        n = m / pix;
-        const int r = m - n * pix;
-        a = r / wc;
-        b = r - a * wc;
-        return ok;
-    }
-
-    static AVSR_DEV Rows decode_rows(const Params& p, const bf16_t* A, const bf16_t* B, int m0, int n0, int cls,
-                                     const Taps& tp, int wave, int lane) {
-        Rows ri;
-        const int rsub = lane >> 3, pc = lane & 7;
-#pragma unroll
-        for (int i = 0; i < A_LOADS; i++) {
-            const int r = (wave * A_LOADS + i) * 8 + rsub;  // row inside the tile
-            const int c = pc ^ ((r >> 1) & 7);              // source chunk that lands in physical chunk pc
-            if (CV == 0) {
-                const int gr = min(m0 + r, p.M - 1);
-                ri.a[i] = A + (size_t)gr * p.lda + c * 8;
-                ri.mask[i] = 0;
-            } else {
-                int n, a, b;
-                row_coords(p, cls, m0 + r, n, a, b);
-                int ya, xa;
-                if (CV == 1) {
-                    ya = a * p.cS - p.cPH;
-                    xa = b * p.cS - p.cPW;
-                } else {
-                    ya = (p.cls_y0[cls] + a * p.cS + p.cPH) / p.cS;
-                    xa = (p.cls_x0[cls] + b * p.cS + p.cPW) / p.cS;
-                }
-                ri.a[i] = A + ((long)n * p.cH * p.cW + (long)ya * p.cW + xa) * p.cC + c * 8;
-                uint32_t mk = 0;
-                for (int t = 0; t < tp.ntaps; t++) {
-                    const int ta = t / tp.nkw, tb = t - ta * tp.nkw;
-                    const int y = CV == 1 ? ya + ta : ya - ta, x = CV == 1 ? xa + tb : xa - tb;
-                    if (y >= 0 && y < p.cH && x >= 0 && x < p.cW) mk |= 1u << t;
-                }
-                ri.mask[i] = mk;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B_LOADS; i++) {
-            const int r = (wave * B_LOADS + i) * 8 + rsub;
-            const int c = pc ^ ((r >> 1) & 7);
-            const int gr = min(n0 + r, p.N - 1);
-            ri.b[i] = B + (size_t)gr * p.ldb + c * 8;
-        }
-        return ri;
-    }
-
-    // stage k-tile t of this block
-    static AVSR_DEV void issue(const Params& p, const Rows& ri, const Taps& tp, int kbeg, int t, char* stage, int wave) {
-        long da, db;
-        int tap = 0;
-        if (CV == 0) {
-            da = db = kbeg + t * BK;
-        } else {
-            tap = t / tp.cpt;
-            const int cb = (t - tap * tp.cpt) * BK;
-            const int ta = tap / tp.nkw, tb = tap - ta * tp.nkw;
-            if (CV == 1) {
-                da = (long)(ta * p.cW + tb) * p.cC + cb;
-                db = (long)tap * p.cC + cb;
-            } else {
-                da = -(long)(ta * p.cW + tb) * p.cC + cb;
-                db = (long)((tp.py + ta * p.cS) * p.cKW + tp.px + tb * p.cS) * p.cC + cb;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < A_LOADS; i++) {
-            const bf16_t* src = ri.a[i] + da;
-            if (CV != 0) src = ((ri.mask[i] >> tap) & 1u) ? src : reinterpret_cast<const bf16_t*>(p.gate);  // zero page
-            glds16(src, stage + (wave * A_LOADS + i) * 1024);
-        }
-#pragma unroll
-        for (int i = 0; i < B_LOADS; i++) glds16(ri.b[i] + db, stage + A_BYTES + (wave * B_LOADS + i) * 1024);
-    }
-
-    static AVSR_DEV bf16x8 frag(const char* base, int r, int chunk) {
-        return *reinterpret_cast<const bf16x8*>(base + r * 128 + ((chunk ^ ((r >> 1) & 7)) << 4));
-    }
-
-    static AVSR_DEV void run(const Params& p, char* smem) {
-        const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
-        const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
-        const int lane = threadIdx.x & 63, wave = wave_id();
-        const int wm = wave / WGN, wn = wave % WGN;
-        int bx = blockIdx.x, by = blockIdx.y;
-        if (p.xcd_order && gridDim.z == 1) {
-            // block b runs on XCD b % 8 (observed): hand every XCD one contiguous run of tiles so that tiles sharing
-            // A rows (the n-tiles of an m-tile, the halo rows of neighbouring m-tiles) meet in the same L2
-            const int gx = gridDim.x, total = gx * gridDim.y;
-            const int id = by * gx + bx;
-            const int xcd = id & 7, slot = id >> 3, q = total >> 3, r = total & 7;
-            const int nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-            by = nid / gx;
-            bx = nid - by * gx;
-        }
-        const int n0 = bx * BN;
-        const int zs = blockIdx.z;
-
-        // which tap list / row range does this block work on
-        int cls = 0, m0 = by * BM, nt, kbeg = 0;
-        Taps tp{1, 1, 1, 0, 0};
-        if (CV == 0) {
-            kbeg = zs * p.k_chunk;
-            nt = (min(p.K, kbeg + p.k_chunk) - kbeg) / BK;
-        } else {
-            while (cls + 1 < p.ncls && by >= p.cls_tile0[cls + 1]) cls++;
-            m0 = (by - p.cls_tile0[cls]) * BM;
-            tp.nkw = p.cls_nkw[cls];
-            tp.ntaps = p.cls_nkh[cls] * tp.nkw;
-            tp.cpt = p.cC / BK;
-            tp.py = p.cls_py[cls];
-            tp.px = p.cls_px[cls];
-            nt = tp.ntaps * tp.cpt;
-        }
-        int* rowmap = nullptr;
-        if (CV == 2) {  // output pixel of every tile row (classes interleave in memory)
-            rowmap = reinterpret_cast<int*>(smem + MAP_OFF);
-            for (int r = threadIdx.x; r < BM; r += NTHR) {
-                int n, a, b;
-                const bool ok = row_coords(p, cls, m0 + r, n, a, b);
-                rowmap[r] = ok ? (n * p.cOH + p.cls_y0[cls] + a * p.cS) * p.cOW + p.cls_x0[cls] + b * p.cS : -1;
-            }
-        }
-
-        f32x16 acc[TM][TN];
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int j = 0; j < TN; j++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-        const Rows ri = decode_rows(p, A, B, m0, n0, cls, tp, wave, lane);
-        // prologue: tiles 0 .. STAGES-2 in flight
-#pragma unroll
-        for (int s = 0; s < STAGES - 1; s++)
-            if (s < nt) issue(p, ri, tp, kbeg, s, smem + s * STAGE_BYTES, wave);
-
-        // One k-tile: retire its loads, barrier, first fragments, (optionally) stage tile t+STAGES-1, multiply.
-        // ISSUE is a compile-time flag -- the steady state (every iteration stages a tile) and the drain (none does)
-        // are separate loops, so neither carries a branch between the fragment reads and the MFMAs that use them.
-        auto step = [&](int t, auto issue_flag) {
-            constexpr bool ISSUE = decltype(issue_flag)::value;
-            // loads of at most STAGES-2 later tiles may stay in flight
-            if (ISSUE) {
-                wait_vmcnt<(STAGES - 2) * LPT>();
-            } else {
-                switch (nt - 1 - t) {  // wave-uniform; counts are immediates
-                    case 0: wait_vmcnt<0>(); break;
-                    default: wait_vmcnt<(STAGES > 2 ? LPT : 0)>(); break;
-                }
-            }
-            block_barrier_raw();  // tile t is in LDS for every wave; everyone is done reading tile t-1's buffer
-            const char* As = smem + (t % STAGES) * STAGE_BYTES;
-            const char* Bs = As + A_BYTES;
-            // Two fragment register sets.  The fragments of k-steps 0 and 1 are requested right after the barrier, ahead
-            // of the address arithmetic of the next operand loads (which hides their LDS latency); k-step ks+2 is
-            // requested as soon as the MFMAs of k-step ks have been issued.  The scheduling fences keep that order.
-            // (The compiler makes the first LDS wait after an LDS-DMA instruction a full one; placed here it is free.)
-            bf16x8 fa[2][TM], fb[2][TN];
-            const int arow = wm * WM + (lane & 31), brow = wn * WN + (lane & 31);
-            auto load_frags = [&](int set, int ks) {
-                const int chunk = ks * 2 + (lane >> 5);
-#pragma unroll
-                for (int i = 0; i < TM; i++) fa[set][i] = frag(As, arow + i * 32, chunk);
-#pragma unroll
-                for (int j = 0; j < TN; j++) fb[set][j] = frag(Bs, brow + j * 32, chunk);
-            };
-            if (ABL != 1) {
-                load_frags(0, 0);
-                load_frags(1, 1);
-            }
-            sched_fence();
-            if (ISSUE && ABL != 2)
-                issue(p, ri, tp, kbeg, t + STAGES - 1, smem + ((t + STAGES - 1) % STAGES) * STAGE_BYTES, wave);
-            sched_fence();
-            if (ABL == 1) return;
-#pragma unroll
-            for (int ks = 0; ks < BK / 16; ks++) {
-#pragma unroll
-                for (int i = 0; i < TM; i++)
-#pragma unroll
-                    for (int j = 0; j < TN; j++) acc[i][j] = mfma32(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
-                if (ks + 2 < BK / 16) load_frags(ks & 1, ks + 2);
-                sched_fence();
-            }
-        };
-        int t = 0;
-        for (; t + STAGES - 1 < nt; t++) step(t, std::true_type{});
-        for (; t < nt; t++) step(t, std::false_type{});
-        if (CV != 0) {
-            Params q = p;
-            q.gate = nullptr;  // in conv mode the field carries the zero page, not an activation gate
-            avsr_gemm_impl::epilogue_lds<BM, BN, TM, TN, NTHR>(acc, q, m0, n0, wm * WM, wn * WN, zs, 0, smem, rowmap);
-        } else {
-            avsr_gemm_impl::epilogue_lds<BM, BN, TM, TN, NTHR>(acc, p, m0, n0, wm * WM, wn * WN, zs, 0, smem, nullptr);
-        }
-    }
-};
+using avsr_fast::FastKernel;
 
 template <int BM, int BN, int STAGES, int CV, int WGM, int WGN, int ABL>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_fast_kernel(Params p) {
@@ -358,6 +114,7 @@ extern "C" int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
         // chip, 64x64 with 3 stages (3 blocks per CU) for the skinny M = B*T GEMMs of the transformer layers
         tile = t128 >= 1024 ? 4 : (t12864 >= 400 ? 7 : 1);
     }
+    if (avsr_pair::stash_nt(p, tile, split_k, stream)) return 0;  // launched by avsr_gemm_pair_end (gemm_pair.hip)
     AVSR_REQUIRE(launch_tile<0>(tile, p, split_k, stream), "gemm_bf16_nt: unknown tile code");
     AVSR_CHECK_LAUNCH("gemm_bf16_nt");
     return 0;

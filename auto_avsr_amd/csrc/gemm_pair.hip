@@ -1,0 +1,115 @@
+// gemm_pair.hip -- the two GEMMs of a Linear layer's backward pass in ONE launch.
+//
+// Given the output gradient dY of y = x W^T, the data gradient dX = dY W (an NT GEMM against the transposed bf16 weight
+// copy, gemm_fast.hip) and the weight gradient dW = dY^T x (a TN GEMM, gemm_tn_fast.hip) are independent.  At the
+// reference's batch geometry (M = B*T <= 1600 rows) either one is ~300 tiles of 64x64 -- barely more than one block per
+// CU on a 256-CU part, so each launch is a latency-bound tail of a few k-steps (measured: 22 us each, 44.5 us back to
+// back, 29.8 us when the two run concurrently on two streams).  Here the blocks of both problems share one grid:
+// blocks [0, n_nt) run the NT tile kernel, the rest the TN tile kernel, so every CU holds 2-3 blocks of mixed work
+// and no stream fork / join or extra launch boundary is paid.
+//
+// Interface: avsr_gemm_pair_begin() opens a pair on the calling thread; the next avsr_gemm_bf16_nt and
+// avsr_gemm_bf16_tn calls on that thread are recorded instead of launched (only the tile shapes the pair kernel is
+// built for; anything else launches immediately as usual); avsr_gemm_pair_end() launches what was recorded.  The two
+// problems must be independent (neither reads the other's output).
+#include "gemm_fast_kernel.h"
+#include "gemm_tn_kernel.h"
+#include "gemm_pair.h"
+#include "avsr_hip.h"
+
+namespace {
+
+using avsr_gemm_impl::Params;
+using avsr_fast::FastKernel;
+using Tn = avsr_tn::TnKernel<3, 0>;
+
+struct PairState {
+    bool active = false, have_nt = false, have_tn = false;
+    Params nt, tn;
+    int nt_tile = 0;
+    int gxa = 0, gya = 0;            // NT grid
+    int gxb = 0, gyb = 0, gzb = 0;   // TN grid (z = k-split)
+    hipStream_t stream = nullptr;
+};
+thread_local PairState g_pair;
+
+template <class KA>
+__global__ __launch_bounds__(256) void gemm_pair_kernel(Params pa, Params pb, int na, int gxa, int gya, int gxb, int gyb) {
+    AVSR_DYN_SMEM(smem);
+    int b = blockIdx.x;
+    if (b < na) {
+        const int by = b / gxa;
+        KA::run_at(pa, smem, b - by * gxa, by, 0, gxa, gya, 1);
+    } else {
+        b -= na;
+        const int r = b / gxb;
+        Tn::run_at(pb, smem, b - r * gxb, r % gyb, r / gyb);
+    }
+}
+
+template <class KA>
+void launch_pair(const PairState& s) {
+    const int na = s.have_nt ? s.gxa * s.gya : 0;
+    const int nb = s.have_tn ? s.gxb * s.gyb * s.gzb : 0;
+    const size_t lds = KA::LDS_BYTES > Tn::LDS_BYTES ? KA::LDS_BYTES : Tn::LDS_BYTES;
+    AVSR_LAUNCH((gemm_pair_kernel<KA>), dim3(na + nb), dim3(256), lds, s.stream, s.nt, s.tn, na, s.gxa > 0 ? s.gxa : 1,
+                s.gya > 0 ? s.gya : 1, s.gxb > 0 ? s.gxb : 1, s.gyb > 0 ? s.gyb : 1);
+}
+
+}  // namespace
+
+namespace avsr_pair {
+
+bool stash_nt(const Params& p, int tile, int split_k, hipStream_t stream) {
+    PairState& s = g_pair;
+    if (!s.active || s.have_nt || split_k > 1 || p.accumulate || (tile != 1 && tile != 7)) return false;
+    if (s.have_tn && s.stream != stream) return false;
+    s.nt = p;
+    s.nt.xcd_order = 0;
+    s.nt.k_chunk = ((p.K + 63) / 64) * 64;
+    s.nt_tile = tile;
+    const int BM = tile == 1 ? 64 : 128;
+    s.gxa = (p.N + 63) / 64;
+    s.gya = (p.M + BM - 1) / BM;
+    s.stream = stream;
+    s.have_nt = true;
+    return true;
+}
+
+bool stash_tn(const Params& p, int split_k, hipStream_t stream) {
+    PairState& s = g_pair;
+    if (!s.active || s.have_tn) return false;
+    if (s.have_nt && s.stream != stream) return false;
+    if (split_k < 1) split_k = 1;
+    int kc = (p.K + split_k - 1) / split_k;
+    kc = ((kc + 63) / 64) * 64;
+    split_k = (p.K + kc - 1) / kc;
+    s.tn = p;
+    s.tn.k_chunk = kc;
+    s.gxb = (p.N + 63) / 64;
+    s.gyb = (p.M + 63) / 64;
+    s.gzb = split_k;
+    s.stream = stream;
+    s.have_tn = true;
+    return true;
+}
+
+}  // namespace avsr_pair
+
+extern "C" int avsr_gemm_pair_begin(void) {
+    AVSR_REQUIRE(!g_pair.active, "gemm_pair_begin: a pair is already open on this thread");
+    g_pair = PairState{};
+    g_pair.active = true;
+    return 0;
+}
+
+extern "C" int avsr_gemm_pair_end(void) {
+    PairState s = g_pair;
+    g_pair = PairState{};
+    AVSR_REQUIRE(s.active, "gemm_pair_end: no open pair on this thread");
+    if (!s.have_nt && !s.have_tn) return 0;
+    if (s.have_nt && s.nt_tile == 7) launch_pair<FastKernel<128, 64, 2, 0>>(s);
+    else launch_pair<FastKernel<64, 64, 3, 0>>(s);
+    AVSR_CHECK_LAUNCH("gemm_pair");
+    return 0;
+}

@@ -519,10 +519,11 @@ class LinearFn(torch.autograd.Function):
             pit = (buf, ld)
         d2, ldy = pit
         dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty(xshape, dtype=torch.float32 if x2.dtype == torch.float32 else act_dtype(), device=dy.device)
-            _gemm_nn(d2, w, rows, K, N, dx, lda=ldy, ldb=K)
-        dw = _wgrad(d2, x2, rows, N, K, lda=ldy, ldb=K)
+        with ops.paired():  # data gradient + weight gradient: one launch
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty(xshape, dtype=torch.float32 if x2.dtype == torch.float32 else act_dtype(), device=dy.device)
+                _gemm_nn(d2, w, rows, K, N, dx, lda=ldy, ldb=K)
+            dw = _wgrad(d2, x2, rows, N, K, lda=ldy, ldb=K)
         db = None
         if has_b:
             if ldy == N:
@@ -568,14 +569,16 @@ class FfnSublayerFn(torch.autograd.Function):
         Fh = w1.shape[0]
         T = act_dtype()
         g, gT, db2 = _prologue(dy, rows, D, alpha=scale, drop=(p2, s2, sd2))  # grad of the W2 output (+ g^T, bias grad)
-        dw2 = _wgrad(g, u, rows, D, Fh, dyT=gT, xT=_xT(u, rows, Fh))
         du = torch.empty(rows, Fh, dtype=T, device=x.device)
         # relu' and the hidden dropout mask are both "u > 0" on the saved post-dropout activation
         db1 = _zeros(Fh, x.device)  # bias gradient of W1: column sums of du, taken in the epilogue of the GEMM that makes du
-        _gemm_nn(g, w2, rows, Fh, D, du, gate=u, ldg=Fh, gate_scale=1.0 / (1.0 - p1) if p1 > 0 else 1.0, colsum=db1)
-        dw1 = _wgrad(du, h, rows, Fh, D)
+        with ops.paired():  # every (weight gradient, data gradient) pair of a Linear leaves as one launch
+            dw2 = _wgrad(g, u, rows, D, Fh, dyT=gT, xT=_xT(u, rows, Fh))
+            _gemm_nn(g, w2, rows, Fh, D, du, gate=u, ldg=Fh, gate_scale=1.0 / (1.0 - p1) if p1 > 0 else 1.0, colsum=db1)
         dh = torch.empty(rows, D, dtype=T, device=x.device)
-        _gemm_nn(du, w1, rows, D, Fh, dh)
+        with ops.paired():
+            dw1 = _wgrad(du, h, rows, Fh, D)
+            _gemm_nn(du, w1, rows, D, Fh, dh)
         dg = _zeros(D, x.device)
         dbt = _zeros(D, x.device)
         dx = ops.layernorm_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dres=dy)
@@ -613,13 +616,15 @@ class FfnFn(torch.autograd.Function):
         T = act_dtype()
         g = _to_act(dy)
         db2 = _bgrad(g, rows, D)
-        dw2 = _wgrad(g, u, rows, D, Fh)
         du = torch.empty(rows, Fh, dtype=T, device=g.device)
         db1 = _zeros(Fh, x2.device)
-        _gemm_nn(g, w2, rows, Fh, D, du, gate=u, ldg=Fh, gate_scale=1.0 / (1.0 - p1) if p1 > 0 else 1.0, colsum=db1)
-        dw1 = _wgrad(du, x2, rows, Fh, D)
+        with ops.paired():
+            dw2 = _wgrad(g, u, rows, D, Fh)
+            _gemm_nn(g, w2, rows, Fh, D, du, gate=u, ldg=Fh, gate_scale=1.0 / (1.0 - p1) if p1 > 0 else 1.0, colsum=db1)
         dx = torch.empty(x2.shape, dtype=torch.float32, device=g.device)
-        _gemm_nn(du, w1, rows, D, Fh, dx)
+        with ops.paired():
+            dw1 = _wgrad(du, x2, rows, Fh, D)
+            _gemm_nn(du, w1, rows, D, Fh, dx)
         return dx, dw1, db1, dw2, db2, None
 
 
@@ -676,9 +681,10 @@ class AttentionCoreFn(torch.autograd.Function):
         T = act_dtype()
         g = _to_act(dy)
         dbo = _bgrad(g, B * Tq, D)
-        dwo = _wgrad(g, ctxv, B * Tq, D, D)
         dctx = torch.empty(B, Tq, D, dtype=T, device=g.device)
-        _gemm_nn(g, wo, B * Tq, D, D, dctx)
+        with ops.paired():
+            dwo = _wgrad(g, ctxv, B * Tq, D, D)
+            _gemm_nn(g, wo, B * Tq, D, D, dctx)
         dqu, dqv, dk_, dv_, dpos = ops.attention_bwd(
             qu.view(B, Tq, H, dk), qv.view(B, Tq, H, dk) if relpos else None, k.view(B, Tk, H, dk),
             v.view(B, Tk, H, dk), pproj, m, ctxv, lse, dctx, 1.0 / math.sqrt(dk), precise=_state["precise"],
@@ -694,27 +700,41 @@ class AttentionCoreFn(torch.autograd.Function):
         else:
             dq = dqu.view(B * Tq, D)
         dk2, dv2 = dk_.view(B * Tk, D), dv_.view(B * Tk, D)
-        dwq, dwk, dwv = _wgrad(dq, qa, B * Tq, D, D), _wgrad(dk2, ka, B * Tk, D, D), _wgrad(dv2, ka, B * Tk, D, D)
         dbq = dbk = dbv = None
         if has_b:
             dbq, dbk, dbv = _bgrad(dq, B * Tq, D), _bgrad(dk2, B * Tk, D), _bgrad(dv2, B * Tk, D)
         dq_in = dkv_in = None
+        # each projection: weight gradient + data gradient as one launch (the data gradients chain through `resid`)
         if same_kv:
             t1 = torch.empty(B * Tq, D, dtype=torch.float32, device=g.device)
-            _gemm_nn(dq, wq, B * Tq, D, D, t1)
+            with ops.paired():
+                dwq = _wgrad(dq, qa, B * Tq, D, D)
+                _gemm_nn(dq, wq, B * Tq, D, D, t1)
             t2 = torch.empty_like(t1)
-            _gemm_nn(dk2, wk, B * Tk, D, D, t2, resid=t1, ldr=D)
+            with ops.paired():
+                dwk = _wgrad(dk2, ka, B * Tk, D, D)
+                _gemm_nn(dk2, wk, B * Tk, D, D, t2, resid=t1, ldr=D)
             dq_in = torch.empty(B, Tq, D, dtype=torch.float32, device=g.device)
-            _gemm_nn(dv2, wv, B * Tk, D, D, dq_in, resid=t2, ldr=D)
+            with ops.paired():
+                dwv = _wgrad(dv2, ka, B * Tk, D, D)
+                _gemm_nn(dv2, wv, B * Tk, D, D, dq_in, resid=t2, ldr=D)
         else:
-            if ctx.needs_input_grad[0]:
-                dq_in = torch.empty(B, Tq, D, dtype=torch.float32, device=g.device)
-                _gemm_nn(dq, wq, B * Tq, D, D, dq_in)
-            if ctx.needs_input_grad[1]:
-                t2 = torch.empty(B * Tk, D, dtype=torch.float32, device=g.device)
-                _gemm_nn(dk2, wk, B * Tk, D, D, t2)
-                dkv_in = torch.empty(B, Tk, D, dtype=torch.float32, device=g.device)
-                _gemm_nn(dv2, wv, B * Tk, D, D, dkv_in, resid=t2, ldr=D)
+            with ops.paired():
+                dwq = _wgrad(dq, qa, B * Tq, D, D)
+                if ctx.needs_input_grad[0]:
+                    dq_in = torch.empty(B, Tq, D, dtype=torch.float32, device=g.device)
+                    _gemm_nn(dq, wq, B * Tq, D, D, dq_in)
+            need_kv = ctx.needs_input_grad[1]
+            t2 = torch.empty(B * Tk, D, dtype=torch.float32, device=g.device) if need_kv else None
+            with ops.paired():
+                dwk = _wgrad(dk2, ka, B * Tk, D, D)
+                if need_kv:
+                    _gemm_nn(dk2, wk, B * Tk, D, D, t2)
+            with ops.paired():
+                dwv = _wgrad(dv2, ka, B * Tk, D, D)
+                if need_kv:
+                    dkv_in = torch.empty(B, Tk, D, dtype=torch.float32, device=g.device)
+                    _gemm_nn(dv2, wv, B * Tk, D, D, dkv_in, resid=t2, ldr=D)
         return (dq_in, dkv_in, None, None, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dwpos, du, dv_bias, None, None,
                 None)
 
@@ -790,9 +810,10 @@ class MhaSublayerFn(torch.autograd.Function):
         dk = D // H
         T = act_dtype()
         g, gT, dbo = _prologue(dy, B * Tq, D, drop=(po, so, sdo))
-        dwo = _wgrad(g, ctxv, B * Tq, D, D, dyT=gT, xT=_xT(ctxv.view(B * Tq, D), B * Tq, D))
         dctx = torch.empty(B, Tq, D, dtype=T, device=x.device)
-        _gemm_nn(g, wo, B * Tq, D, D, dctx)
+        with ops.paired():
+            dwo = _wgrad(g, ctxv, B * Tq, D, D, dyT=gT, xT=_xT(ctxv.view(B * Tq, D), B * Tq, D))
+            _gemm_nn(g, wo, B * Tq, D, D, dctx)
         outs = {}
         if fused:  # dq | dk | dv land side by side: one bias-gradient pass, one weight-gradient GEMM, one data-gradient GEMM
             dqkv = torch.empty(B * Tq, 3 * D, dtype=T, device=x.device)
@@ -816,11 +837,13 @@ class MhaSublayerFn(torch.autograd.Function):
         dmem = None
         if fused:
             _, _, dbc = _prologue(dqkv, B * Tq, 3 * D, want_dst=False)
-            dwc = _wgrad(dqkv, h, B * Tq, 3 * D, D)
+            dh = torch.empty(B * Tq, D, dtype=torch.float32, device=x.device)
+            wcT = _w_bf16_cat((wq, wk, wv), True)
+            with ops.paired():
+                dwc = _wgrad(dqkv, h, B * Tq, 3 * D, D)
+                ops.gemm_bf16_nt(dqkv, 3 * D, wcT, 3 * D, B * Tq, D, 3 * D, dh, D)
             dwq, dwk, dwv = dwc[:D], dwc[D:2 * D], dwc[2 * D:]
             dbq, dbk, dbv = dbc[:D], dbc[D:2 * D], dbc[2 * D:]
-            dh = torch.empty(B * Tq, D, dtype=torch.float32, device=x.device)
-            ops.gemm_bf16_nt(dqkv, 3 * D, _w_bf16_cat((wq, wk, wv), True), 3 * D, B * Tq, D, 3 * D, dh, D)
         else:
             dk2, dv2 = dk_.view(B * Tk, D), dv_.view(B * Tk, D)
             hT = _xT(h.view(B * Tq, D), B * Tq, D)
@@ -828,24 +851,36 @@ class MhaSublayerFn(torch.autograd.Function):
             _, dqT, dbq = _prologue(dq, B * Tq, D, want_dst=False)
             _, dkT, dbk = _prologue(dk2, B * Tk, D, want_dst=False)
             _, dvT, dbv = _prologue(dv2, B * Tk, D, want_dst=False)
-            dwq = _wgrad(dq, h, B * Tq, D, D, xT=hT, dyT=dqT)
-            dwk = _wgrad(dk2, ka, B * Tk, D, D, xT=kaT, dyT=dkT)
-            dwv = _wgrad(dv2, ka, B * Tk, D, D, xT=kaT, dyT=dvT)
+            # each projection: weight gradient + data gradient as one launch (data gradients chain through `resid`)
             if cross:
                 dh = torch.empty(B * Tq, D, dtype=T, device=x.device)
-                _gemm_nn(dq, wq, B * Tq, D, D, dh)
-                if ctx.needs_input_grad[1]:
-                    t2 = torch.empty(B * Tk, D, dtype=torch.float32, device=x.device)
-                    _gemm_nn(dk2, wk, B * Tk, D, D, t2)
-                    dmem = torch.empty(B, Tk, D, dtype=torch.float32, device=x.device)
-                    _gemm_nn(dv2, wv, B * Tk, D, D, dmem, resid=t2, ldr=D)
+                with ops.paired():
+                    dwq = _wgrad(dq, h, B * Tq, D, D, xT=hT, dyT=dqT)
+                    _gemm_nn(dq, wq, B * Tq, D, D, dh)
+                need_mem = ctx.needs_input_grad[1]
+                t2 = torch.empty(B * Tk, D, dtype=torch.float32, device=x.device) if need_mem else None
+                with ops.paired():
+                    dwk = _wgrad(dk2, ka, B * Tk, D, D, xT=kaT, dyT=dkT)
+                    if need_mem:
+                        _gemm_nn(dk2, wk, B * Tk, D, D, t2)
+                with ops.paired():
+                    dwv = _wgrad(dv2, ka, B * Tk, D, D, xT=kaT, dyT=dvT)
+                    if need_mem:
+                        dmem = torch.empty(B, Tk, D, dtype=torch.float32, device=x.device)
+                        _gemm_nn(dv2, wv, B * Tk, D, D, dmem, resid=t2, ldr=D)
             else:
                 t1 = torch.empty(B * Tq, D, dtype=torch.float32, device=x.device)
-                _gemm_nn(dq, wq, B * Tq, D, D, t1)
+                with ops.paired():
+                    dwq = _wgrad(dq, h, B * Tq, D, D, xT=hT, dyT=dqT)
+                    _gemm_nn(dq, wq, B * Tq, D, D, t1)
                 t2 = torch.empty_like(t1)
-                _gemm_nn(dk2, wk, B * Tq, D, D, t2, resid=t1, ldr=D)
+                with ops.paired():
+                    dwk = _wgrad(dk2, ka, B * Tk, D, D, xT=kaT, dyT=dkT)
+                    _gemm_nn(dk2, wk, B * Tq, D, D, t2, resid=t1, ldr=D)
                 dh = torch.empty_like(t1)
-                _gemm_nn(dv2, wv, B * Tq, D, D, dh, resid=t2, ldr=D)
+                with ops.paired():
+                    dwv = _wgrad(dv2, ka, B * Tk, D, D, xT=kaT, dyT=dvT)
+                    _gemm_nn(dv2, wv, B * Tq, D, D, dh, resid=t2, ldr=D)
         dg = _zeros(D, x.device)
         dbt = _zeros(D, x.device)
         dx = ops.layernorm_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dres=dy)
@@ -958,9 +993,10 @@ class ConvSublayerFn(torch.autograd.Function):
         rows = B * Tn
         T = act_dtype()
         g, gT, db2 = _prologue(dy, rows, D, drop=(po, so, sdo))
-        dw2 = _wgrad(g, s, rows, D, D, dyT=gT, xT=_xT(s, rows, D)).view(D, D, 1)
         ds = torch.empty(rows, D, dtype=T, device=x.device)
-        _gemm_nn(g, w_pw2.view(D, D), rows, D, D, ds)
+        with ops.paired():
+            dw2 = _wgrad(g, s, rows, D, D, dyT=gT, xT=_xT(s, rows, D)).view(D, D, 1)
+            _gemm_nn(g, w_pw2.view(D, D), rows, D, D, ds)
         sums = ops.bn_bwd_reduce(c, ds, None, bmean, binv, bn_w, bn_b, rows, D, 1)
         dbn_w, dbn_b = sums[1], sums[0]
         if training:
@@ -974,17 +1010,20 @@ class ConvSublayerFn(torch.autograd.Function):
         dgl = ops.dwconv(dc, wdw, None, B, Tn, D, K, flip=True)
         da = ops.glu_bwd(a, dgl, rows, D)
         _, daT, db1 = _prologue(da, rows, 2 * D, want_dst=False)
-        dw1 = _wgrad(da, h, rows, 2 * D, D, dyT=daT, xT=_xT(h.view(rows, D), rows, D)).view(2 * D, D, 1)
         if fused:
             dh = torch.empty(rows, D, dtype=T, device=x.device)
-            _gemm_nn(da, w_pw1.view(2 * D, D), rows, D, 2 * D, dh)
+            with ops.paired():
+                dw1 = _wgrad(da, h, rows, 2 * D, D, dyT=daT, xT=_xT(h.view(rows, D), rows, D)).view(2 * D, D, 1)
+                _gemm_nn(da, w_pw1.view(2 * D, D), rows, D, 2 * D, dh)
             dg = _zeros(D, x.device)
             dbt = _zeros(D, x.device)
             dx = ops.layernorm_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dres=dy)
         else:
             dg = dbt = None
             dx = torch.empty(B, Tn, D, dtype=torch.float32, device=x.device)
-            _gemm_nn(da, w_pw1.view(2 * D, D), rows, D, 2 * D, dx)
+            with ops.paired():
+                dw1 = _wgrad(da, h, rows, 2 * D, D, dyT=daT, xT=_xT(h.view(rows, D), rows, D)).view(2 * D, D, 1)
+                _gemm_nn(da, w_pw1.view(2 * D, D), rows, D, 2 * D, dx)
         return (dx, dg, dbt, dw1, db1, dwdw.view(D, 1, K), dbdw, dbn_w, dbn_b, None, None, None, dw2, db2, None, None,
                 None, None, None)
 

@@ -1,5 +1,8 @@
 """Thin Python wrappers over the C ABI (include/avsr_hip.h): one function per entry point,
 taking torch tensors as device-memory handles.  No compute happens in Python or ATen here."""
+import contextlib
+import os
+
 import torch
 
 from . import _lib
@@ -60,6 +63,25 @@ def call(name, *args, flops=0.0):
     e1.record()
     PROFILE.append((name, e0, e1, flops))
     return rc
+
+
+PAIR_GEMMS = os.environ.get("AVSR_PAIR_GEMMS", "1") != "0"  # A/B switch for the paired backward GEMMs
+
+
+@contextlib.contextmanager
+def paired():
+    """The data-gradient (NT) and weight-gradient (TN) GEMM issued inside the block leave as ONE launch whose grid holds
+    the tiles of both (csrc/gemm_pair.hip) -- at M = B*T <= 1600 either one alone cannot fill the 256 CUs.  The two must
+    be independent.  Switched off while bench.py's per-launch profiling hooks are installed."""
+    if not PAIR_GEMMS or PROFILE is not None or RECORD is not None:
+        yield
+        return
+    L = _lib.lib()
+    L.call("avsr_gemm_pair_begin")
+    try:
+        yield
+    finally:
+        L.call("avsr_gemm_pair_end")
 
 
 def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-12):

@@ -266,6 +266,12 @@ int avsr_stem357_wgrad(const void* dy, const float* x, float* dw, void* workspac
  * ds_read_b64_tr_b16): C[M][N] (f32, ldc) (+)= sum_k A[k][m] B[k][n]; A [K][lda], B [K][ldb] bf16 */
 int avsr_gemm_bf16_tn(const void* A, int lda, const void* B, int ldb, int M, int N, int K, float* C, int ldc,
                       int accumulate, int split_k, const void* zero_page, avsr_stream_t stream);
+/* Paired launch of the two GEMMs of a Linear backward pass (gemm_pair.hip): between begin and end, the first
+ * avsr_gemm_bf16_nt call (split_k 1, non-accumulating, 64x64 / 128x64 tile shapes) and the first avsr_gemm_bf16_tn call
+ * of the calling thread are recorded and then launched together by avsr_gemm_pair_end as ONE grid (NT tiles first, TN
+ * tiles after) -- the two problems must be independent.  Calls the pair cannot hold launch immediately, as usual. */
+int avsr_gemm_pair_begin(void);
+int avsr_gemm_pair_end(void);
 /* convolution weight gradient on the same kernel (B = im2col gather); dwp [Cout][KH][KW][Cin] f32, caller zeroes */
 int avsr_conv2d_wgrad_bf16(const void* dy, const void* x, float* dwp, const void* zero_page, int N, int H, int W,
                            int Cin, int Cout, int KH, int KW, int stride, int pad_h, int pad_w,

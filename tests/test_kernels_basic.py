@@ -153,3 +153,51 @@ def test_gemm_bf16_tn_transpose_read(dev, shape):
     C2 = torch.zeros(M, N, device=dev)
     ops.gemm_bf16_tn(A.to(dev), M, B.to(dev), N, M, N, K, C2, N, accumulate=True, split_k=3)
     assert ((C2.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("tile", [1, 7])
+@pytest.mark.parametrize("split", [1, 2])
+def test_gemm_pair_nt_tn(dev, tile, split):
+    """Data-gradient (NT) + weight-gradient (TN) GEMM of a Linear backward as ONE launch (csrc/gemm_pair.hip): the grid
+    holds the tiles of both problems; results equal the two separate launches bit for bit (same tile kernels)."""
+    torch.manual_seed(tile * 10 + split)
+    rows, n_out, n_in = 200, 136, 192  # dX[rows, n_in] = dY[rows, n_out(64-padded K)] W ; dW[n_out, n_in] = dY^T X
+    Kp = 192
+    dy = torch.zeros(rows, Kp)
+    dy[:, :n_out] = torch.randn(rows, n_out)
+    dy = dy.bfloat16().to(dev)
+    wT = torch.zeros(n_in, Kp)
+    wT[:, :n_out] = torch.randn(n_in, n_out)
+    wT = wT.bfloat16().to(dev)
+    x = torch.randn(rows, n_in).bfloat16().to(dev)
+    bias = torch.randn(n_in, device=dev)
+
+    def nt(out, cs):
+        ops.gemm_bf16_nt(dy, Kp, wT, Kp, rows, n_in, Kp, out, n_in, bias=bias, act=1, tile=tile, colsum=cs)
+
+    def tn(out):
+        ops.gemm_bf16_tn(dy, Kp, x, n_in, n_out, n_in, rows, out, n_in, accumulate=split > 1, split_k=split)
+
+    dx0, cs0, dw0 = torch.zeros(rows, n_in, device=dev, dtype=torch.bfloat16), torch.zeros(n_in, device=dev), torch.zeros(n_out, n_in, device=dev)
+    nt(dx0, cs0)
+    tn(dw0)
+    ref_dw = dy.cpu().double()[:, :n_out].t() @ x.cpu().double()
+    assert ((dw0.cpu().double() - ref_dw).abs().max() / ref_dw.abs().max()) < 2e-6
+    dx1, cs1, dw1 = torch.zeros_like(dx0), torch.zeros_like(cs0), torch.zeros_like(dw0)
+    with ops.paired():
+        tn(dw1)
+        nt(dx1, cs1)
+    assert torch.equal(dx1, dx0) and torch.equal(dw1, dw0)
+    assert (cs1 - cs0).abs().max() <= 1e-4 * cs0.abs().max()  # atomics: summation order differs
+    # a pair holding only one of the two, and calls the pair cannot hold (second NT, split-K NT) launch as usual
+    dx2, dw2, dx3 = torch.zeros_like(dx0), torch.zeros_like(dw0), torch.zeros(rows, n_in, device=dev)
+    with ops.paired():
+        nt(dx2, None)
+        ops.gemm_bf16_nt(dy, Kp, wT, Kp, rows, n_in, Kp, dx3, n_in, accumulate=True, split_k=3, tile=tile)
+    with ops.paired():
+        tn(dw2)
+    with ops.paired():
+        pass
+    assert torch.equal(dx2, dx0) and torch.equal(dw2, dw0)
+    ref_dx = dy.cpu().double() @ wT.cpu().double().t()
+    assert ((dx3.cpu().double() - ref_dx).abs().max() / ref_dx.abs().max()) < 2e-6
