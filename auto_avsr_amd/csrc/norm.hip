@@ -72,12 +72,12 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(
 
 // dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma ; optional  dx += dres.  One wave per row.
 template <class TDY>
-__global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_dx_kernel(
+AVSR_DEV void layernorm_bwd_dx_block(
     const TDY* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in, const float* __restrict__ dres,
-    float* __restrict__ dx, int rows, int cols) {
+    float* __restrict__ dx, int rows, int cols, int blk) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
+    const int row = blk * LN_WAVES + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nvec = cols >> 3;
     const float mean = mean_in[row], rstd = rstd_in[row];
@@ -125,15 +125,14 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_dx_kernel(
 
 // dgamma[c] += sum_r dy[r,c]*xhat[r,c] ; dbeta[c] += sum_r dy[r,c].  thread = (8-column chunk, row lane).
 template <class TDY>
-__global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_param_kernel(
+AVSR_DEV void layernorm_bwd_param_block(
     const TDY* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean_in,
     const float* __restrict__ rstd_in, float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int cols,
-    int rows_per_block, int CL) {
-    __shared__ float red[LN_THREADS * 16];
+    int rows_per_block, int CL, int bx, int by, float* red) {
     const int cv = cols >> 3;
     const int cl = threadIdx.x % CL, rl = threadIdx.x / CL, RL = LN_THREADS / CL;
-    const int cc = blockIdx.x * CL + cl;
-    const int r0 = blockIdx.y * rows_per_block;
+    const int cc = bx * CL + cl;
+    const int r0 = by * rows_per_block;
     const int r1 = min(rows, r0 + rows_per_block);
     float pg[8], pb[8];
 #pragma unroll
@@ -184,6 +183,24 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_param_kernel(
     }
 }
 
+// Both halves of the backward pass in one grid: blocks [0, npx*npy) reduce the parameter gradients (the long pole: few
+// blocks, each walking 64 rows), the rest compute dx one wave per row.  The two are independent, and one of them alone
+// does not fill the chip at B*T <= 1600 rows -- together they overlap and one launch boundary disappears.
+template <class TDY>
+__global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(
+    const TDY* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ mean_in, const float* __restrict__ rstd_in, const float* __restrict__ dres,
+    float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int cols,
+    int rows_per_block, int CL, int npx, int npy) {
+    __shared__ float red[LN_THREADS * 16];
+    const int b = blockIdx.x;
+    if (b < npx * npy)
+        layernorm_bwd_param_block<TDY>(dy, x, mean_in, rstd_in, dgamma, dbeta, rows, cols, rows_per_block, CL, b % npx,
+                                       b / npx, red);
+    else
+        layernorm_bwd_dx_block<TDY>(dy, x, gamma, mean_in, rstd_in, dres, dx, rows, cols, b - npx * npy);
+}
+
 }  // namespace
 
 extern "C" int avsr_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y,
@@ -209,22 +226,18 @@ extern "C" int avsr_layernorm_bwd(const void* dy, int dy_dtype, const float* x, 
                                   hipStream_t stream) {
     AVSR_REQUIRE(cols % 8 == 0 && cols <= 64 * 8 * LN_MAXV, "layernorm: cols must be %8 and <= 2048");
     if (rows == 0) return 0;
-    dim3 grid((rows + LN_WAVES - 1) / LN_WAVES), block(LN_THREADS);
+    const int ndx = (rows + LN_WAVES - 1) / LN_WAVES;
     const int cv = cols >> 3;
     const int CL = cv >= 32 ? 32 : (cv >= 16 ? 16 : 8);
     const int rpb = 8 * (LN_THREADS / CL);  // 64 rows per block; 32 was measured slower (more colliding atomics per column)
-    dim3 grid2((cv + CL - 1) / CL, (rows + rpb - 1) / rpb);
-    if (dy_dtype == 0) {
-        AVSR_LAUNCH((layernorm_bwd_dx_kernel<float>), grid, block, 0, stream, (const float*)dy, x, gamma, mean, rstd,
-                    dres, dx, rows, cols);
-        AVSR_LAUNCH((layernorm_bwd_param_kernel<float>), grid2, block, 0, stream, (const float*)dy, x, mean, rstd,
-                    dgamma, dbeta, rows, cols, rpb, CL);
-    } else {
-        AVSR_LAUNCH((layernorm_bwd_dx_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)dy, x, gamma, mean, rstd,
-                    dres, dx, rows, cols);
-        AVSR_LAUNCH((layernorm_bwd_param_kernel<bf16_t>), grid2, block, 0, stream, (const bf16_t*)dy, x, mean, rstd,
-                    dgamma, dbeta, rows, cols, rpb, CL);
-    }
+    const int npx = (cv + CL - 1) / CL, npy = (rows + rpb - 1) / rpb;
+    dim3 grid(npx * npy + ndx), block(LN_THREADS);
+    if (dy_dtype == 0)
+        AVSR_LAUNCH((layernorm_bwd_kernel<float>), grid, block, 0, stream, (const float*)dy, x, gamma, mean, rstd, dres, dx,
+                    dgamma, dbeta, rows, cols, rpb, CL, npx, npy);
+    else
+        AVSR_LAUNCH((layernorm_bwd_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)dy, x, gamma, mean, rstd, dres,
+                    dx, dgamma, dbeta, rows, cols, rpb, CL, npx, npy);
     AVSR_CHECK_LAUNCH("layernorm_bwd");
     return 0;
 }
