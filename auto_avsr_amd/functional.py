@@ -518,14 +518,21 @@ class LinearFn(torch.autograd.Function):
             buf[:, :N].copy_(dy.reshape(rows, N))  # re-pitch (data movement only)
             pit = (buf, ld)
         d2, ldy = pit
-        dx = None
+        dx = db = None
+        if (not _state["precise"]) and d2.dtype == torch.float32 and x2.dtype == torch.bfloat16 and ldy % 8 == 0 and K % 8 == 0:
+            # f32 output gradient (loss heads, the f32 residual stream) in the bf16 mode: ONE pass makes the bf16 copy of
+            # the whole pitched buffer (its pad columns are zeros) and the bias gradient, and both GEMMs below then run
+            # on the tuned bf16 kernels as one paired launch instead of on the generic f32 kernel
+            full = d2 if ldy == N else d2.as_strided((rows, ldy), (ldy, 1))
+            d2, _, dbf = _prologue(full, rows, ldy, want_dst=True, want_bias=has_b)
+            if has_b:
+                db = dbf[:N]
         with ops.paired():  # data gradient + weight gradient: one launch
             if ctx.needs_input_grad[0]:
                 dx = torch.empty(xshape, dtype=torch.float32 if x2.dtype == torch.float32 else act_dtype(), device=dy.device)
                 _gemm_nn(d2, w, rows, K, N, dx, lda=ldy, ldb=K)
             dw = _wgrad(d2, x2, rows, N, K, lda=ldy, ldb=K)
-        db = None
-        if has_b:
+        if has_b and db is None:
             if ldy == N:
                 db = _bgrad(d2, rows, N)
             else:  # padded columns hold zeros: summing the whole pitch is exact

@@ -156,3 +156,89 @@ def test_ddp_equal_shards(emu_lib_path, tmp_path):
         if d > 1e-2 * float(ref[k].double().norm()) + atol:
             bad.append((k, d, float(ref[k].double().norm())))
     assert not bad, bad[:6]
+
+
+def _worker_bench_like(rank, world, port, emu_path, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from synth import synth_batch, synth_state_dict
+
+    from auto_avsr_amd import _lib
+    from auto_avsr_amd import functional as AF
+    from auto_avsr_amd.e2e import E2E
+    from auto_avsr_amd.optim import FusedAdamW
+
+    _lib._install_for_tests(emu_path)
+    AF.set_precise(False)  # the bf16 bench mode: LDS-DMA GEMMs, paired backward GEMMs, cached bf16 weight copies
+    AF.invalidate_weight_cache()
+    AF.set_bn_sync(dist.group.WORLD)
+    odim = 41  # odd-sized biases: every gradient behind them in a DDP bucket sits at a 4-byte (not 16-byte) offset
+    m = E2E(odim, "video", adim=128, aheads=2, eunits=256, elayers=1, dunits=256, dlayers=1, cnn_module_kernel=7)
+    m.load_state_dict(synth_state_dict(m.state_dict(), 31))
+    m.train()
+    AF.manual_seed(100 + rank)
+
+    class Hot(torch.nn.Module):
+        def __init__(self, mm):
+            super().__init__()
+            self.m = mm
+
+        def forward(self, x, lens, y):
+            return self.m.forward_tensors(x, lens, y)[0]
+
+    # exactly bench.py's N > 1 configuration
+    ddp = torch.nn.parallel.DistributedDataParallel(Hot(m), find_unused_parameters=False, broadcast_buffers=False,
+                                                    gradient_as_bucket_view=True, bucket_cap_mb=64)
+    opt = FusedAdamW(m.parameters(), lr=1e-3, betas=(0.9, 0.98), weight_decay=0.03, max_grad_norm=10.0, warmup_steps=2,
+                     total_steps=10, cast_weights=True)
+    x, lengths, y = synth_batch("video", 3, 8, 3, odim, seed=12, lengths=[8, 6, 5])
+    xs, ls, ys = (x[:2], lengths[:2], y[:2]) if rank == 0 else (x[2:, :5], lengths[2:], y[2:])
+    params = list(m.parameters())
+    before = [p.detach().clone() for p in params]
+    misaligned = 0
+    for it in range(2):
+        AF.new_step()
+        AF.refresh_weight_cache()
+        loss = ddp(xs, ls, ys)
+        bs = torch.tensor([float(xs.shape[0])])
+        allb = [torch.zeros(1) for _ in range(world)]
+        dist.all_gather(allb, bs)
+        (loss * (world / torch.stack(allb).sum())).backward()
+        misaligned += sum(1 for p in params if p.grad.data_ptr() % 16)
+        opt.step()
+        for p in params:
+            p.grad = None
+    assert misaligned > 0, "the test is meant to exercise gradient views at odd offsets"
+    assert all(torch.isfinite(p).all() for p in params)
+    assert sum(float((p.detach() - b).abs().sum()) for p, b in zip(params, before)) > 0
+    # the optimizer kept every bf16 operand copy current
+    gen, groups = AF.weight_cast_groups()
+    assert groups and AF._wgen["owner_gen"] == gen
+    for (w, dst, dstT, R, C, ldT, limT) in groups:
+        ref = w.detach().reshape(R, C).to(torch.bfloat16)
+        assert dst is None or torch.equal(dst, ref)
+        assert dstT is None or torch.equal(dstT[:, :R], ref.t())
+    # replicas stay bit-identical (same averaged gradients, same update)
+    flat = torch.cat([p.detach().flatten() for p in params])
+    other = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(other, flat)
+    assert torch.equal(other[0], other[1])
+    if rank == 0:
+        torch.save({"ok": True, "step": opt.step_count}, os.path.join(out_dir, "bench_like.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_bench_configuration(emu_lib_path, tmp_path):
+    """bench.py's N > 1 step on two gloo ranks in the bf16 mode: DDP with gradient_as_bucket_view and 64 MB buckets,
+    cross-rank BatchNorm, ragged per-rank batches, W / sum(B) loss rescale, FusedAdamW(cast_weights=True) reading
+    gradients that are dword-aligned views into the buckets.  Two steps; replicas must stay identical and the bf16 weight
+    copies must follow the weights."""
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_worker_bench_like, args=(2, port, emu_lib_path, str(tmp_path)), nprocs=2, join=True)
+    res = torch.load(os.path.join(tmp_path, "bench_like.pt"))
+    assert res["ok"] and res["step"] == 2

@@ -215,3 +215,35 @@ def test_fused_qkv_projection(dev, relpos):
     finally:
         AF.set_precise(False)
         AF.invalidate_weight_cache()
+
+
+def test_linear_padded_head_f32_grad_bf16_mode(dev):
+    """Vocabulary-style head in the bf16 mode: y = x W^T + b with an odd width (121 -> row pitch 128), f32 output, f32
+    output gradient.  The backward casts the pitched gradient once (bias gradient in the same pass) and runs the data
+    and weight gradients on the bf16 kernels as one paired launch; compared with torch on the bf16-rounded operands."""
+    torch.manual_seed(21)
+    rows, K, N = 96, 64, 121
+    AF.set_precise(False)
+    AF.invalidate_weight_cache()
+    try:
+        x = (torch.randn(2, rows // 2, K) * 0.5).bfloat16()
+        w = torch.nn.Parameter(torch.randn(N, K) * 0.2)
+        b = torch.nn.Parameter(torch.randn(N) * 0.1)
+        xd = x.clone().to(dev).requires_grad_()
+        wd, bd = torch.nn.Parameter(w.detach().to(dev)), torch.nn.Parameter(b.detach().to(dev))
+        y = AF.linear(xd, wd, bd, out_dtype=torch.float32, pad_out=True)
+        assert y.shape == (2, rows // 2, N) and y.stride(-2) == 128
+        gy = torch.randn(2, rows // 2, N)
+        (y * gy.to(dev)).sum().backward()
+        xr = x.float().requires_grad_()
+        wr = w.detach().bfloat16().float().requires_grad_()
+        yr = xr @ wr.t() + b
+        (yr * gy).sum().backward()
+        assert rel(y.detach().cpu(), yr.detach()) < 1e-5
+        gyb = gy.bfloat16().float()  # the backward rounds the output gradient to bf16
+        assert rel(wd.grad.cpu(), gyb.reshape(rows, N).t() @ x.float().reshape(rows, K)) < 1e-5
+        assert rel(bd.grad.cpu(), gyb.reshape(rows, N).sum(0)) < 1e-5
+        assert rel(xd.grad.float().cpu(), (gyb.reshape(rows, N) @ wr.detach()).reshape(2, rows // 2, K)) < 1e-2
+    finally:
+        AF.invalidate_weight_cache()
+        AF.set_precise(True)
