@@ -223,6 +223,7 @@ def test_linear_padded_head_f32_grad_bf16_mode(dev):
     and weight gradients on the bf16 kernels as one paired launch; compared with torch on the bf16-rounded operands."""
     torch.manual_seed(21)
     rows, K, N = 96, 64, 121
+    was_precise = AF._state["precise"]
     AF.set_precise(False)
     AF.invalidate_weight_cache()
     try:
@@ -246,4 +247,4 @@ def test_linear_padded_head_f32_grad_bf16_mode(dev):
         assert rel(xd.grad.float().cpu(), (gyb.reshape(rows, N) @ wr.detach()).reshape(2, rows // 2, K)) < 1e-2
     finally:
         AF.invalidate_weight_cache()
-        AF.set_precise(True)
+        AF.set_precise(was_precise)
