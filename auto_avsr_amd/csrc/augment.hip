@@ -1,0 +1,193 @@
+// augment.hip -- the reference's per-sample augmentation / normalisation transforms and its padding collation as two
+// batch-level kernels that run where the data is consumed (input pipeline on the device).
+//
+// Replaces, for a whole batch at once (the reference runs these per sample in DataLoader workers on the CPU):
+//   VideoTransform           datamodule/transforms.py:89-110   x/255 -> Random/CenterCrop(88) -> Grayscale ->
+//                                                               AdaptiveTimeMask(10, 25) -> Normalize(0.421, 0.165)
+//   AudioTransform           datamodule/transforms.py:113-136  AdaptiveTimeMask(6400, 16000) -> AddNoise -> layer_norm
+//   AdaptiveTimeMask.forward datamodule/transforms.py:50-64    (the intervals are drawn on the host with the reference's
+//                                                               own RNG call sequence; the kernels apply them)
+//   AddNoise.forward         datamodule/transforms.py:81-88    torchaudio.functional.add_noise (absent dependency,
+//                                                               restated: scale noise to the requested SNR, add)
+//   pad / collate_pad        datamodule/data_module.py:10-41   zero padding of every sample to the longest of the batch
+//
+// Both kernels are HBM-bound streaming passes: video reads 3 B and writes 4 B (or 2 B) per output pixel straight from
+// the decoder's THWC uint8 frames into the padded [B, Tmax, 1, 88, 88] batch tensor the stem kernel consumes; nothing
+// is materialised in between (the reference materialises five intermediate tensors per clip).  The f32 arithmetic of
+// the video path is issued with explicitly rounded, non-contractable operations in the reference's order, so the result
+// is bit-identical to torch's CPU ops.
+#include <math.h>
+#include "prims.h"
+#include "avsr_hip.h"
+
+namespace {
+
+// ---- exactly rounded f32 operations (no fused multiply-add contraction), host emulator included
+AVSR_DEV float mul_rn(float a, float b) {
+#ifdef AVSR_EMU
+    volatile float r = a * b;
+    return r;
+#else
+    return __fmul_rn(a, b);
+#endif
+}
+AVSR_DEV float add_rn(float a, float b) {
+#ifdef AVSR_EMU
+    volatile float r = a + b;
+    return r;
+#else
+    return __fadd_rn(a, b);
+#endif
+}
+AVSR_DEV float div_rn(float a, float b) {
+#ifdef AVSR_EMU
+    volatile float r = a / b;
+    return r;
+#else
+    return __fdiv_rn(a, b);
+#endif
+}
+
+// is frame / sample t inside one of the n masking intervals [iv[2i], iv[2i+1]) ?
+AVSR_DEV bool masked_at(const int* __restrict__ iv, int n, long t) {
+    bool m = false;
+    for (int i = 0; i < n; i++) m = m || (t >= iv[2 * i] && t < iv[2 * i + 1]);
+    return m;
+}
+
+// grid (ceil(crop*crop/8 / 256), Tmax, B); thread = 8 consecutive pixels of one output row (crop % 8 == 0)
+template <class T>
+__global__ __launch_bounds__(256) void video_transform_kernel(
+    const int64_t* __restrict__ src_ptr, const int32_t* __restrict__ lens,
+    const int32_t* __restrict__ crop_y, const int32_t* __restrict__ crop_x, const int32_t* __restrict__ iv,
+    const int32_t* __restrict__ niv, int max_iv, T* __restrict__ out, int Tmax, int H, int W, int crop, float mean,
+    float std) {
+    const int b = blockIdx.z, t = blockIdx.y;
+    const int per_row = crop >> 3;
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= crop * per_row) return;
+    const int y = id / per_row, x0 = (id - y * per_row) * 8;
+    T* o = out + (((long)b * Tmax + t) * crop + y) * crop + x0;
+    float v[8];
+    if (t >= lens[b]) {  // collate_pad: frames past the clip are zeros
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = 0.f;
+        store8(o, v);
+        return;
+    }
+    const bool masked = iv != nullptr && masked_at(iv + (long)b * max_iv * 2, niv[b], t);
+    if (masked) {  // AdaptiveTimeMask zeroes the grey frame BEFORE Normalize
+        const float z = div_rn(add_rn(0.f, -mean), std);
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = z;
+        store8(o, v);
+        return;
+    }
+    const uint8_t* p = reinterpret_cast<const uint8_t*>(src_ptr[b]) + (((long)t * H + crop_y[b] + y) * (long)W + crop_x[b] + x0) * 3;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        // x / 255.0 per channel, then torchvision's rgb_to_grayscale: 0.2989 r + 0.587 g + 0.114 b, then (v - mean) / std
+        const float r = div_rn((float)p[3 * k], 255.0f), g = div_rn((float)p[3 * k + 1], 255.0f),
+                    bl = div_rn((float)p[3 * k + 2], 255.0f);
+        const float grey = add_rn(add_rn(mul_rn(0.2989f, r), mul_rn(0.587f, g)), mul_rn(0.114f, bl));
+        v[k] = div_rn(add_rn(grey, -mean), std);
+    }
+    store8(o, v);
+}
+
+constexpr int AUD_THREADS = 512;
+
+AVSR_DEV double block_sum_d(double v, double* red) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    __syncthreads();  // red may still be read from the previous reduction
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < AUD_THREADS / 64; w++) s += red[w];
+    return s;
+}
+
+// one block per utterance: mask -> add noise at the requested SNR -> layer_norm over the whole utterance -> padded batch
+__global__ __launch_bounds__(AUD_THREADS) void audio_transform_kernel(
+    const int64_t* __restrict__ wav_ptr, const int32_t* __restrict__ lens,
+    const int32_t* __restrict__ iv, const int32_t* __restrict__ niv, int max_iv, const float* __restrict__ noise,
+    const int64_t* __restrict__ noise_start, const float* __restrict__ snr_db, float eps, float* __restrict__ out,
+    long Lmax) {
+    __shared__ double red[AUD_THREADS / 64];
+    const int b = blockIdx.x;
+    const long n = lens[b];
+    const float* s = reinterpret_cast<const float*>(wav_ptr[b]);
+    const int* ivb = iv ? iv + (long)b * max_iv * 2 : nullptr;
+    const int nm = iv ? niv[b] : 0;
+    const bool noisy = noise != nullptr && noise_start[b] >= 0;
+    const float* nz = noisy ? noise + noise_start[b] : nullptr;
+    float* o = out + (long)b * Lmax;
+    auto speech = [&](long i) { return masked_at(ivb, nm, i) ? 0.f : s[i]; };
+    float scale = 0.f;
+    if (noisy) {
+        // torchaudio.functional.add_noise: scale = 10^((10 (log10 E_s - log10 E_n) - snr) / 20)
+        double es = 0.0, en = 0.0;
+        for (long i = threadIdx.x; i < n; i += AUD_THREADS) {
+            const float a = speech(i), c = nz[i];
+            es += (double)a * a;
+            en += (double)c * c;
+        }
+        es = block_sum_d(es, red);
+        en = block_sum_d(en, red);
+        const float orig = 10.f * (log10f((float)es) - log10f((float)en));
+        scale = powf(10.f, (orig - snr_db[b]) / 20.f);
+    }
+    auto noisy_at = [&](long i) { return noisy ? speech(i) + scale * nz[i] : speech(i); };
+    double sum = 0.0;
+    for (long i = threadIdx.x; i < n; i += AUD_THREADS) sum += (double)noisy_at(i);
+    const double mean = n > 0 ? block_sum_d(sum, red) / (double)n : 0.0;
+    double sq = 0.0;
+    for (long i = threadIdx.x; i < n; i += AUD_THREADS) {
+        const double d = (double)noisy_at(i) - mean;
+        sq += d * d;
+    }
+    const double var = n > 0 ? block_sum_d(sq, red) / (double)n : 0.0;  // biased, as layer_norm
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps)), mu = (float)mean;
+    for (long i = threadIdx.x; i < Lmax; i += AUD_THREADS) o[i] = i < n ? (noisy_at(i) - mu) * rstd : 0.f;
+}
+
+}  // namespace
+
+// src_ptr[b]: device address of clip b, decoder-layout frames uint8 [lens[b]][H][W][3].
+// out: [B][Tmax][1][crop][crop] (f32 or bf16), frames t >= lens[b] zero.  crop_y / crop_x[b]: crop origin (drawn on the
+// host: RandomCrop for training, (H-crop)/2 for evaluation).  iv: int32 [B][max_iv][2] masking intervals in frames,
+// niv[b] of them used (NULL: no time masking).  value = ((0.2989 r + 0.587 g + 0.114 b) / 255 - mean) / std, 0 -> masked.
+extern "C" int avsr_video_transform(const int64_t* src_ptr, const int32_t* lens, const int32_t* crop_y,
+                                    const int32_t* crop_x, const int32_t* iv, const int32_t* niv, int max_iv, void* out,
+                                    int out_dtype, int B, int Tmax, int H, int W, int crop, float mean, float std,
+                                    hipStream_t stream) {
+    AVSR_REQUIRE(crop > 0 && crop % 8 == 0 && crop <= H && crop <= W, "video_transform: crop must be a multiple of 8 within the frame");
+    AVSR_REQUIRE(std != 0.f, "video_transform: std must be non-zero");
+    AVSR_REQUIRE(iv == nullptr || (niv != nullptr && max_iv > 0), "video_transform: interval list without counts");
+    if (B <= 0 || Tmax <= 0) return 0;
+    dim3 grid((crop * (crop >> 3) + 255) / 256, Tmax, B), block(256);
+    if (out_dtype == 0)
+        AVSR_LAUNCH((video_transform_kernel<float>), grid, block, 0, stream, src_ptr, lens, crop_y, crop_x, iv, niv, max_iv,
+                    (float*)out, Tmax, H, W, crop, mean, std);
+    else
+        AVSR_LAUNCH((video_transform_kernel<bf16_t>), grid, block, 0, stream, src_ptr, lens, crop_y, crop_x, iv, niv, max_iv,
+                    (bf16_t*)out, Tmax, H, W, crop, mean, std);
+    AVSR_CHECK_LAUNCH("video_transform");
+    return 0;
+}
+
+// wav_ptr[b]: device address of utterance b (f32 [lens[b]]); out: f32 [B][Lmax][1], samples >= lens[b] zero.
+// iv / niv / max_iv: masking intervals in samples (NULL: none).  noise (NULL: none): f32 noise recording; utterance b
+// adds noise[noise_start[b] + i] scaled to snr_db[b] (noise_start[b] < 0: clean).  eps: layer_norm epsilon (1e-8).
+extern "C" int avsr_audio_transform(const int64_t* wav_ptr, const int32_t* lens, const int32_t* iv,
+                                    const int32_t* niv, int max_iv, const float* noise, const int64_t* noise_start,
+                                    const float* snr_db, float eps, float* out, int B, int64_t Lmax, hipStream_t stream) {
+    AVSR_REQUIRE(iv == nullptr || (niv != nullptr && max_iv > 0), "audio_transform: interval list without counts");
+    AVSR_REQUIRE(noise == nullptr || (noise_start != nullptr && snr_db != nullptr), "audio_transform: noise without start / SNR");
+    if (B <= 0 || Lmax <= 0) return 0;
+    AVSR_LAUNCH(audio_transform_kernel, dim3(B), dim3(AUD_THREADS), 0, stream, wav_ptr, lens, iv, niv, max_iv, noise,
+                noise_start, snr_db, eps, out, (long)Lmax);
+    AVSR_CHECK_LAUNCH("audio_transform");
+    return 0;
+}

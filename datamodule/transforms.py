@@ -1,9 +1,15 @@
-"""Token <-> text mapping of the reference (datamodule/transforms.py:142-171).  The audio / video augmentation
-transforms of the reference run in DataLoader workers on the CPU and need torchaudio / torchvision (absent here);
-they are out of the hot-path scope and not re-implemented."""
+"""The reference's datamodule/transforms.py import path.
+* TextTransform: token <-> text mapping (transforms.py:142-171).
+* VideoTransform / AudioTransform / AdaptiveTimeMask / AddNoise: the reference runs these per sample in DataLoader
+  workers on the CPU (torchvision / torchaudio); here the same names resolve to the device-side pipeline of
+  auto_avsr_amd/transforms.py (csrc/augment.hip), which also offers the batch-level video_batch / audio_batch that fuse
+  the transform with collate_pad."""
 import os
 
 import torch
+
+from auto_avsr_amd.transforms import (AdaptiveTimeMask, AddNoise, AudioTransform, VideoTransform,  # noqa: F401
+                                      audio_batch, pad_targets, video_batch)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SP_MODEL_PATH = os.path.join(os.path.dirname(_HERE), "spm", "unigram", "unigram5000.model")

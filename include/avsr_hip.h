@@ -318,6 +318,25 @@ int avsr_adamw_cast_step(const void* table, int n, int total_blocks, const void*
                          float base_lr, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
                          int64_t warmup_steps, int64_t total_steps, avsr_stream_t stream);
 
+/* ---- input pipeline on the device (augment.hip): the per-sample transforms of the reference's DataLoader workers and its
+ * padding collation, one launch per batch.
+ * Replaces VideoTransform (datamodule/transforms.py:89-110: x/255, Random/CenterCrop(88), Grayscale,
+ * AdaptiveTimeMask(10,25), Normalize(0.421,0.165)), AudioTransform (:113-136: AdaptiveTimeMask(6400,16000), AddNoise
+ * (:67-88, torchaudio.functional.add_noise), layer_norm eps 1e-8) and pad / collate_pad (datamodule/data_module.py:10-41).
+ * Random decisions (crop origin, masking intervals, noise offset, SNR) are drawn on the host and passed in.
+ * avsr_video_transform: src_ptr[b] = device address of clip b, uint8 [lens[b]][H][W][3] (decoder layout);
+ *   out [B][Tmax][1][crop][crop] (out_dtype 0 f32 / 1 bf16), frames >= lens[b] zero; iv int32 [B][max_iv][2] frame
+ *   intervals [start, end) to mask, niv[b] used, NULL = none.  f32 results are bit-identical to the torch CPU ops.
+ * avsr_audio_transform: wav_ptr[b] = device address of utterance b, f32 [lens[b]]; out f32 [B][Lmax][1], zero tail; iv in
+ *   samples; noise (NULL = none) f32 recording, utterance b uses noise[noise_start[b] + i] at snr_db[b] (start < 0: clean). */
+int avsr_video_transform(const int64_t* src_ptr, const int32_t* lens, const int32_t* crop_y,
+                         const int32_t* crop_x, const int32_t* iv, const int32_t* niv, int max_iv, void* out,
+                         int out_dtype, int B, int Tmax, int H, int W, int crop, float mean, float std,
+                         avsr_stream_t stream);
+int avsr_audio_transform(const int64_t* wav_ptr, const int32_t* lens, const int32_t* iv,
+                         const int32_t* niv, int max_iv, const float* noise, const int64_t* noise_start,
+                         const float* snr_db, float eps, float* out, int B, int64_t Lmax, avsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
