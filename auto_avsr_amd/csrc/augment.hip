@@ -20,32 +20,27 @@
 #include "prims.h"
 #include "avsr_hip.h"
 
+// Every f32 operation in this file is individually rounded: no fused multiply-add contraction (the build's default is
+// -ffp-contract=fast, and HIP's __fmul_rn / __fadd_rn are plain operators that the contraction pass still fuses), and
+// division is hipcc's default correctly rounded one.  That is what makes the video path bit-identical to torch's CPU ops.
+#ifndef AVSR_EMU
+#pragma clang fp contract(off)
+#endif
+
 namespace {
 
-// ---- exactly rounded f32 operations (no fused multiply-add contraction), host emulator included
+// ---- individually rounded f32 operations; the host emulator build keeps them apart with volatile temporaries
 AVSR_DEV float mul_rn(float a, float b) {
-#ifdef AVSR_EMU
     volatile float r = a * b;
     return r;
-#else
-    return __fmul_rn(a, b);
-#endif
 }
 AVSR_DEV float add_rn(float a, float b) {
-#ifdef AVSR_EMU
     volatile float r = a + b;
     return r;
-#else
-    return __fadd_rn(a, b);
-#endif
 }
 AVSR_DEV float div_rn(float a, float b) {
-#ifdef AVSR_EMU
     volatile float r = a / b;
     return r;
-#else
-    return __fdiv_rn(a, b);
-#endif
 }
 
 // is frame / sample t inside one of the n masking intervals [iv[2i], iv[2i+1]) ?

@@ -88,7 +88,8 @@ def _table(device, ptrs, lens, extra_i32=(), intervals=None):
         parts.append(niv.view(np.uint8))
         iv_off = niv_off + niv.nbytes
         parts.append(ivs.reshape(-1).view(np.uint8))
-    blob = torch.from_numpy(np.concatenate(parts)).to(device, non_blocking=True)
+    # blocking copy: the source is a temporary pageable buffer (an asynchronous copy could read it after it is gone)
+    blob = torch.from_numpy(np.concatenate(parts)).to(device)
     return blob, offs, niv_off, iv_off, max_iv
 
 
@@ -160,8 +161,8 @@ def audio_batch(wavs, subset, add_noise=None, eps=1e-8):
         if add_noise.noise.device != dev:
             add_noise.noise = add_noise.noise.to(dev)
         noise = add_noise.noise
-        start_t = torch.tensor(starts, dtype=torch.int64).to(dev, non_blocking=True)
-        snr_t = torch.tensor(snrs, dtype=torch.float32).to(dev, non_blocking=True)
+        start_t = torch.tensor(starts, dtype=torch.int64).to(dev)
+        snr_t = torch.tensor(snrs, dtype=torch.float32).to(dev)
     ops.call("avsr_audio_transform", base + offs[0], base + offs[1], base + iv_off, base + niv_off, max_iv, ops._ptr(noise),
              ops._ptr(start_t), ops._ptr(snr_t), eps, ops._ptr(out), B, Lmax, ops._stream(out))
     _keep_alive(out, wavs, blob, start_t, snr_t)

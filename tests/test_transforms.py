@@ -47,7 +47,8 @@ def test_oracle_matches_reference_golden(golden):
         seed_all(c["seed"])
         out, _, _ = TO.video_transform(make_clip(c["frames"], c["seed"]).permute(0, 3, 1, 2), c["subset"])
         assert tuple(out.shape) == c["shape"] and torch.equal(out[::12], c["sample_frames"])
-        assert float(out.double().sum()) == c["sum"] and float(out.double().abs().sum()) == c["abssum"]
+        # whole-tensor checksums (f64 sums: the reduction order depends on the host's thread count, hence the tolerance)
+        assert abs(float(out.double().sum()) - c["sum"]) < 1e-7 and abs(float(out.double().abs().sum()) - c["abssum"]) < 1e-7
     for m in golden["masks"]:
         seed_all(m["seed"])
         ivs = TO.adaptive_time_mask_intervals(m["length"], m["window"], m["stride"])
@@ -78,7 +79,8 @@ def test_video_transform_matches_reference_golden(dev, golden):
         clip = make_clip(c["frames"], c["seed"]).to(dev)
         out = TR.VideoTransform(c["subset"])(clip.permute(0, 3, 1, 2)).cpu()  # load_video's [T, 3, H, W] view
         assert tuple(out.shape) == c["shape"] and torch.equal(out[::12], c["sample_frames"])
-        assert float(out.double().sum()) == c["sum"] and float(out.double().abs().sum()) == c["abssum"]
+        # whole-tensor checksums (f64 sums: the reduction order depends on the host's thread count, hence the tolerance)
+        assert abs(float(out.double().sum()) - c["sum"]) < 1e-7 and abs(float(out.double().abs().sum()) - c["abssum"]) < 1e-7
 
 
 def test_adaptive_time_mask_protocol(golden):
