@@ -90,7 +90,8 @@ __global__ __launch_bounds__(256) void video_transform_kernel(
     store8(o, v);
 }
 
-constexpr int AUD_THREADS = 512;
+constexpr int AUD_THREADS = 256;
+constexpr int AUD_CHUNK = 8192;  // samples per block
 
 AVSR_DEV double block_sum_d(double v, double* red) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
@@ -103,48 +104,81 @@ AVSR_DEV double block_sum_d(double v, double* red) {
     return s;
 }
 
-// one block per utterance: mask -> add noise at the requested SNR -> layer_norm over the whole utterance -> padded batch
-__global__ __launch_bounds__(AUD_THREADS) void audio_transform_kernel(
-    const int64_t* __restrict__ wav_ptr, const int32_t* __restrict__ lens,
-    const int32_t* __restrict__ iv, const int32_t* __restrict__ niv, int max_iv, const float* __restrict__ noise,
+// mask -> add noise at the requested SNR -> layer_norm over the whole utterance -> padded batch, as four grid-wide
+// phases (an utterance is up to 256 000 samples: one block per utterance would leave 250 CUs idle for milliseconds).
+// Block (chunk, utterance); the per-utterance statistics travel through per-chunk partial sums in `part`
+// ([3 phases][B][nch][2] doubles, summed in chunk order by every block that needs them -- deterministic).
+//   PHASE 0: E_speech, E_noise            PHASE 1: sum(y)            PHASE 2: sum((y - mean)^2)            PHASE 3: write
+template <int PHASE>
+__global__ __launch_bounds__(AUD_THREADS) void audio_phase_kernel(
+    const int64_t* __restrict__ wav_ptr, const int32_t* __restrict__ lens, const int32_t* __restrict__ iv,
+    const int32_t* __restrict__ niv, int max_iv, const float* __restrict__ noise,
     const int64_t* __restrict__ noise_start, const float* __restrict__ snr_db, float eps, float* __restrict__ out,
-    long Lmax) {
+    long Lmax, double* __restrict__ part, int nch) {
     __shared__ double red[AUD_THREADS / 64];
-    const int b = blockIdx.x;
+    const int b = blockIdx.y, ch = blockIdx.x, B = gridDim.y;
     const long n = lens[b];
+    const long i0 = (long)ch * AUD_CHUNK, i1 = i0 + AUD_CHUNK;
     const float* s = reinterpret_cast<const float*>(wav_ptr[b]);
     const int* ivb = iv ? iv + (long)b * max_iv * 2 : nullptr;
     const int nm = iv ? niv[b] : 0;
     const bool noisy = noise != nullptr && noise_start[b] >= 0;
     const float* nz = noisy ? noise + noise_start[b] : nullptr;
-    float* o = out + (long)b * Lmax;
     auto speech = [&](long i) { return masked_at(ivb, nm, i) ? 0.f : s[i]; };
+    auto total = [&](int phase, int k) {  // sum of the partials of an earlier phase, in chunk order
+        const double* p = part + (((long)phase * B + b) * nch) * 2 + k;
+        double t = 0.0;
+        for (int c = 0; c < nch; c++) t += p[2 * c];
+        return t;
+    };
+    double* mine = part + (((long)PHASE * B + b) * nch + ch) * 2;
+    const long hi = i1 < n ? i1 : n;
+    if (PHASE == 0) {
+        double es = 0.0, en = 0.0;
+        if (noisy)
+            for (long i = i0 + threadIdx.x; i < hi; i += AUD_THREADS) {
+                const float a = speech(i), c = nz[i];
+                es += (double)a * a;
+                en += (double)c * c;
+            }
+        es = block_sum_d(es, red);
+        en = block_sum_d(en, red);
+        if (threadIdx.x == 0) {
+            mine[0] = es;
+            mine[1] = en;
+        }
+        return;
+    }
     float scale = 0.f;
     if (noisy) {
         // torchaudio.functional.add_noise: scale = 10^((10 (log10 E_s - log10 E_n) - snr) / 20)
-        double es = 0.0, en = 0.0;
-        for (long i = threadIdx.x; i < n; i += AUD_THREADS) {
-            const float a = speech(i), c = nz[i];
-            es += (double)a * a;
-            en += (double)c * c;
-        }
-        es = block_sum_d(es, red);
-        en = block_sum_d(en, red);
-        const float orig = 10.f * (log10f((float)es) - log10f((float)en));
+        const float orig = 10.f * (log10f((float)total(0, 0)) - log10f((float)total(0, 1)));
         scale = powf(10.f, (orig - snr_db[b]) / 20.f);
     }
     auto noisy_at = [&](long i) { return noisy ? speech(i) + scale * nz[i] : speech(i); };
-    double sum = 0.0;
-    for (long i = threadIdx.x; i < n; i += AUD_THREADS) sum += (double)noisy_at(i);
-    const double mean = n > 0 ? block_sum_d(sum, red) / (double)n : 0.0;
-    double sq = 0.0;
-    for (long i = threadIdx.x; i < n; i += AUD_THREADS) {
-        const double d = (double)noisy_at(i) - mean;
-        sq += d * d;
+    if (PHASE == 1) {
+        double sum = 0.0;
+        for (long i = i0 + threadIdx.x; i < hi; i += AUD_THREADS) sum += (double)noisy_at(i);
+        sum = block_sum_d(sum, red);
+        if (threadIdx.x == 0) mine[0] = sum, mine[1] = 0.0;
+        return;
     }
-    const double var = n > 0 ? block_sum_d(sq, red) / (double)n : 0.0;  // biased, as layer_norm
+    const double mean = n > 0 ? total(1, 0) / (double)n : 0.0;
+    if (PHASE == 2) {
+        double sq = 0.0;
+        for (long i = i0 + threadIdx.x; i < hi; i += AUD_THREADS) {
+            const double d = (double)noisy_at(i) - mean;
+            sq += d * d;
+        }
+        sq = block_sum_d(sq, red);
+        if (threadIdx.x == 0) mine[0] = sq, mine[1] = 0.0;
+        return;
+    }
+    const double var = n > 0 ? total(2, 0) / (double)n : 0.0;  // biased, as layer_norm
     const float rstd = (float)(1.0 / sqrt(var + (double)eps)), mu = (float)mean;
-    for (long i = threadIdx.x; i < Lmax; i += AUD_THREADS) o[i] = i < n ? (noisy_at(i) - mu) * rstd : 0.f;
+    float* o = out + (long)b * Lmax;
+    const long top = i1 < Lmax ? i1 : Lmax;
+    for (long i = i0 + threadIdx.x; i < top; i += AUD_THREADS) o[i] = i < n ? (noisy_at(i) - mu) * rstd : 0.f;
 }
 
 }  // namespace
@@ -175,14 +209,31 @@ extern "C" int avsr_video_transform(const int64_t* src_ptr, const int32_t* lens,
 // wav_ptr[b]: device address of utterance b (f32 [lens[b]]); out: f32 [B][Lmax][1], samples >= lens[b] zero.
 // iv / niv / max_iv: masking intervals in samples (NULL: none).  noise (NULL: none): f32 noise recording; utterance b
 // adds noise[noise_start[b] + i] scaled to snr_db[b] (noise_start[b] < 0: clean).  eps: layer_norm epsilon (1e-8).
+// workspace: avsr_audio_transform_workspace_bytes(B, Lmax) bytes of device scratch (per-chunk partial sums).
+extern "C" int64_t avsr_audio_transform_workspace_bytes(int B, int64_t Lmax) {
+    const int64_t nch = (Lmax + AUD_CHUNK - 1) / AUD_CHUNK;
+    return (int64_t)3 * B * nch * 2 * (int64_t)sizeof(double);
+}
+
 extern "C" int avsr_audio_transform(const int64_t* wav_ptr, const int32_t* lens, const int32_t* iv,
                                     const int32_t* niv, int max_iv, const float* noise, const int64_t* noise_start,
-                                    const float* snr_db, float eps, float* out, int B, int64_t Lmax, hipStream_t stream) {
+                                    const float* snr_db, float eps, float* out, int B, int64_t Lmax, void* workspace,
+                                    hipStream_t stream) {
     AVSR_REQUIRE(iv == nullptr || (niv != nullptr && max_iv > 0), "audio_transform: interval list without counts");
     AVSR_REQUIRE(noise == nullptr || (noise_start != nullptr && snr_db != nullptr), "audio_transform: noise without start / SNR");
     if (B <= 0 || Lmax <= 0) return 0;
-    AVSR_LAUNCH(audio_transform_kernel, dim3(B), dim3(AUD_THREADS), 0, stream, wav_ptr, lens, iv, niv, max_iv, noise,
-                noise_start, snr_db, eps, out, (long)Lmax);
+    AVSR_REQUIRE(workspace != nullptr, "audio_transform: workspace of avsr_audio_transform_workspace_bytes(B, Lmax) needed");
+    const int nch = (int)((Lmax + AUD_CHUNK - 1) / AUD_CHUNK);
+    double* part = reinterpret_cast<double*>(workspace);
+    dim3 grid(nch, B), block(AUD_THREADS);
+#define AVSR_AUD_PHASE(P)                                                                                              \
+    AVSR_LAUNCH((audio_phase_kernel<P>), grid, block, 0, stream, wav_ptr, lens, iv, niv, max_iv, noise, noise_start,    \
+                snr_db, eps, out, (long)Lmax, part, nch)
+    AVSR_AUD_PHASE(0);
+    AVSR_AUD_PHASE(1);
+    AVSR_AUD_PHASE(2);
+    AVSR_AUD_PHASE(3);
+#undef AVSR_AUD_PHASE
     AVSR_CHECK_LAUNCH("audio_transform");
     return 0;
 }

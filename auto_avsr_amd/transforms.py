@@ -163,9 +163,10 @@ def audio_batch(wavs, subset, add_noise=None, eps=1e-8):
         noise = add_noise.noise
         start_t = torch.tensor(starts, dtype=torch.int64).to(dev)
         snr_t = torch.tensor(snrs, dtype=torch.float32).to(dev)
+    ws = torch.empty(ops.call("avsr_audio_transform_workspace_bytes", B, Lmax), dtype=torch.uint8, device=dev)
     ops.call("avsr_audio_transform", base + offs[0], base + offs[1], base + iv_off, base + niv_off, max_iv, ops._ptr(noise),
-             ops._ptr(start_t), ops._ptr(snr_t), eps, ops._ptr(out), B, Lmax, ops._stream(out))
-    _keep_alive(out, wavs, blob, start_t, snr_t)
+             ops._ptr(start_t), ops._ptr(snr_t), eps, ops._ptr(out), B, Lmax, ops._ptr(ws), ops._stream(out))
+    _keep_alive(out, wavs, blob, start_t, snr_t, ws)
     return out, lens
 
 

@@ -328,14 +328,17 @@ int avsr_adamw_cast_step(const void* table, int n, int total_blocks, const void*
  *   out [B][Tmax][1][crop][crop] (out_dtype 0 f32 / 1 bf16), frames >= lens[b] zero; iv int32 [B][max_iv][2] frame
  *   intervals [start, end) to mask, niv[b] used, NULL = none.  f32 results are bit-identical to the torch CPU ops.
  * avsr_audio_transform: wav_ptr[b] = device address of utterance b, f32 [lens[b]]; out f32 [B][Lmax][1], zero tail; iv in
- *   samples; noise (NULL = none) f32 recording, utterance b uses noise[noise_start[b] + i] at snr_db[b] (start < 0: clean). */
+ *   samples; noise (NULL = none) f32 recording, utterance b uses noise[noise_start[b] + i] at snr_db[b] (start < 0: clean);
+ *   workspace: avsr_audio_transform_workspace_bytes(B, Lmax) bytes of device scratch. */
 int avsr_video_transform(const int64_t* src_ptr, const int32_t* lens, const int32_t* crop_y,
                          const int32_t* crop_x, const int32_t* iv, const int32_t* niv, int max_iv, void* out,
                          int out_dtype, int B, int Tmax, int H, int W, int crop, float mean, float std,
                          avsr_stream_t stream);
+int64_t avsr_audio_transform_workspace_bytes(int B, int64_t Lmax);
 int avsr_audio_transform(const int64_t* wav_ptr, const int32_t* lens, const int32_t* iv,
                          const int32_t* niv, int max_iv, const float* noise, const int64_t* noise_start,
-                         const float* snr_db, float eps, float* out, int B, int64_t Lmax, avsr_stream_t stream);
+                         const float* snr_db, float eps, float* out, int B, int64_t Lmax, void* workspace,
+                         avsr_stream_t stream);
 
 #ifdef __cplusplus
 }
