@@ -39,6 +39,16 @@ def _run(cmd):
     return r
 
 
+def _file_flags(src):
+    """Per-file compiler flags: a source may carry a line `// AVSR_CXXFLAGS: <flags>` (e.g. augment.hip turns FMA
+    contraction off for bit-exact f32 arithmetic; the flag is part of the source digest, so a change rebuilds)."""
+    with open(src) as f:
+        for line in f:
+            if "AVSR_CXXFLAGS:" in line:
+                return line.split("AVSR_CXXFLAGS:", 1)[1].split()
+    return []
+
+
 def _build(objdir, out, compile_cmd, link_cmd, extra_inputs, force):
     os.makedirs(objdir, exist_ok=True)
     srcs = _sources()
@@ -59,7 +69,7 @@ def _build(objdir, out, compile_cmd, link_cmd, extra_inputs, force):
 
     def one(j):
         s, o, stamp, dig = j
-        _run(compile_cmd + ["-c", s, "-o", o])
+        _run(compile_cmd + _file_flags(s) + ["-c", s, "-o", o])
         with open(stamp, "w") as f:
             f.write(dig)
 

@@ -20,26 +20,33 @@
 #include "prims.h"
 #include "avsr_hip.h"
 
-// Every f32 operation in this file is individually rounded: no fused multiply-add contraction (the build's default is
-// -ffp-contract=fast, and HIP's __fmul_rn / __fadd_rn are plain operators that the contraction pass still fuses), and
-// division is hipcc's default correctly rounded one.  That is what makes the video path bit-identical to torch's CPU ops.
-#ifndef AVSR_EMU
-#pragma clang fp contract(off)
-#endif
+// Every f32 operation in this file is individually rounded: the file is compiled with FMA contraction off
+// AVSR_CXXFLAGS: -ffp-contract=off
+// (build.py appends the flags of the line above to this file's compile command; the build's default is
+// -ffp-contract=fast, under which the backend fuses mul + add pairs regardless of `#pragma clang fp contract(off)`, and
+// HIP's __fmul_rn / __fadd_rn are plain operators that get fused too), and division is hipcc's default correctly rounded
+// one.  That is what makes the video path bit-identical to torch's CPU ops.
 
 namespace {
 
-// ---- individually rounded f32 operations; the host emulator build keeps them apart with volatile temporaries
+// ---- individually rounded f32 operations.  Device: plain operators under -ffp-contract=off (a `volatile` temporary
+// would be a scratch-memory round trip per operation -- measured 8x slower).  Host emulator: volatile
+// temporaries keep the host compiler from fusing them.
+#ifdef AVSR_EMU
+#define AVSR_RN_TMP volatile float
+#else
+#define AVSR_RN_TMP float
+#endif
 AVSR_DEV float mul_rn(float a, float b) {
-    volatile float r = a * b;
+    AVSR_RN_TMP r = a * b;
     return r;
 }
 AVSR_DEV float add_rn(float a, float b) {
-    volatile float r = a + b;
+    AVSR_RN_TMP r = a + b;
     return r;
 }
 AVSR_DEV float div_rn(float a, float b) {
-    volatile float r = a / b;
+    AVSR_RN_TMP r = a / b;
     return r;
 }
 
@@ -120,8 +127,16 @@ __global__ __launch_bounds__(AUD_THREADS) void audio_phase_kernel(
     const long n = lens[b];
     const long i0 = (long)ch * AUD_CHUNK, i1 = i0 + AUD_CHUNK;
     const float* s = reinterpret_cast<const float*>(wav_ptr[b]);
-    const int* ivb = iv ? iv + (long)b * max_iv * 2 : nullptr;
+    // the masking runs of this utterance, staged in LDS once per block: every sample is tested against all of them
+    constexpr int IV_LDS = 64;
+    __shared__ int siv[2 * IV_LDS];
     const int nm = iv ? niv[b] : 0;
+    const int* ivb = iv ? iv + (long)b * max_iv * 2 : nullptr;
+    if (nm <= IV_LDS) {
+        for (int i = threadIdx.x; i < 2 * nm; i += AUD_THREADS) siv[i] = ivb[i];
+        __syncthreads();
+        ivb = siv;
+    }
     const bool noisy = noise != nullptr && noise_start[b] >= 0;
     const float* nz = noisy ? noise + noise_start[b] : nullptr;
     auto speech = [&](long i) { return masked_at(ivb, nm, i) ? 0.f : s[i]; };
