@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) void video_transform_kernel(
 }
 
 constexpr int AUD_THREADS = 256;
-constexpr int AUD_CHUNK = 8192;  // samples per block
+constexpr int AUD_CHUNK = 2048;  // samples per block: 8 per thread, all loads of a thread in flight together
+constexpr int AUD_PER = AUD_CHUNK / AUD_THREADS;
 
 AVSR_DEV double block_sum_d(double v, double* red) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
@@ -115,7 +116,10 @@ AVSR_DEV double block_sum_d(double v, double* red) {
 // phases (an utterance is up to 256 000 samples: one block per utterance would leave 250 CUs idle for milliseconds).
 // Block (chunk, utterance); the per-utterance statistics travel through per-chunk partial sums in `part`
 // ([3 phases][B][nch][2] doubles, summed in chunk order by every block that needs them -- deterministic).
-//   PHASE 0: E_speech, E_noise            PHASE 1: sum(y)            PHASE 2: sum((y - mean)^2)            PHASE 3: write
+//   PHASE 0: E_speech, E_noise over the masked speech / the noise segment
+//   PHASE 1: y = speech + scale * noise  -> written to `out` (un-normalised), sum(y)
+//   PHASE 2: sum((y - mean)^2) from `out`
+//   PHASE 3: out = (y - mean) * rstd, zero tail
 template <int PHASE>
 __global__ __launch_bounds__(AUD_THREADS) void audio_phase_kernel(
     const int64_t* __restrict__ wav_ptr, const int32_t* __restrict__ lens, const int32_t* __restrict__ iv,
@@ -125,65 +129,84 @@ __global__ __launch_bounds__(AUD_THREADS) void audio_phase_kernel(
     __shared__ double red[AUD_THREADS / 64];
     const int b = blockIdx.y, ch = blockIdx.x, B = gridDim.y;
     const long n = lens[b];
-    const long i0 = (long)ch * AUD_CHUNK, i1 = i0 + AUD_CHUNK;
-    const float* s = reinterpret_cast<const float*>(wav_ptr[b]);
-    // the masking runs of this utterance, staged in LDS once per block: every sample is tested against all of them
-    constexpr int IV_LDS = 64;
-    __shared__ int siv[2 * IV_LDS];
-    const int nm = iv ? niv[b] : 0;
-    const int* ivb = iv ? iv + (long)b * max_iv * 2 : nullptr;
-    if (nm <= IV_LDS) {
-        for (int i = threadIdx.x; i < 2 * nm; i += AUD_THREADS) siv[i] = ivb[i];
-        __syncthreads();
-        ivb = siv;
-    }
-    const bool noisy = noise != nullptr && noise_start[b] >= 0;
-    const float* nz = noisy ? noise + noise_start[b] : nullptr;
-    auto speech = [&](long i) { return masked_at(ivb, nm, i) ? 0.f : s[i]; };
+    const long i0 = (long)ch * AUD_CHUNK + threadIdx.x;
+    float* o = out + (long)b * Lmax;
+    double* mine = part + (((long)PHASE * B + b) * nch + ch) * 2;
     auto total = [&](int phase, int k) {  // sum of the partials of an earlier phase, in chunk order
         const double* p = part + (((long)phase * B + b) * nch) * 2 + k;
         double t = 0.0;
         for (int c = 0; c < nch; c++) t += p[2 * c];
         return t;
     };
-    double* mine = part + (((long)PHASE * B + b) * nch + ch) * 2;
-    const long hi = i1 < n ? i1 : n;
-    if (PHASE == 0) {
-        double es = 0.0, en = 0.0;
-        if (noisy)
-            for (long i = i0 + threadIdx.x; i < hi; i += AUD_THREADS) {
-                const float a = speech(i), c = nz[i];
-                es += (double)a * a;
-                en += (double)c * c;
-            }
-        es = block_sum_d(es, red);
-        en = block_sum_d(en, red);
-        if (threadIdx.x == 0) {
-            mine[0] = es;
-            mine[1] = en;
+    const bool noisy = noise != nullptr && noise_start[b] >= 0;
+    if (PHASE <= 1) {
+        // the masking runs of this utterance, staged in LDS once per block: every sample is tested against all of them
+        constexpr int IV_LDS = 64;
+        __shared__ int siv[2 * IV_LDS];
+        const int nm = iv ? niv[b] : 0;
+        const int* ivb = iv ? iv + (long)b * max_iv * 2 : nullptr;
+        if (nm <= IV_LDS) {
+            for (int i = threadIdx.x; i < 2 * nm; i += AUD_THREADS) siv[i] = ivb[i];
+            __syncthreads();
+            ivb = siv;
         }
-        return;
-    }
-    float scale = 0.f;
-    if (noisy) {
-        // torchaudio.functional.add_noise: scale = 10^((10 (log10 E_s - log10 E_n) - snr) / 20)
-        const float orig = 10.f * (log10f((float)total(0, 0)) - log10f((float)total(0, 1)));
-        scale = powf(10.f, (orig - snr_db[b]) / 20.f);
-    }
-    auto noisy_at = [&](long i) { return noisy ? speech(i) + scale * nz[i] : speech(i); };
-    if (PHASE == 1) {
+        const float* s = reinterpret_cast<const float*>(wav_ptr[b]);
+        const float* nz = noisy ? noise + noise_start[b] : nullptr;
+        float sp[AUD_PER], nv[AUD_PER];
+#pragma unroll
+        for (int j = 0; j < AUD_PER; j++) {  // all loads first
+            const long i = i0 + (long)j * AUD_THREADS;
+            sp[j] = i < n ? s[i] : 0.f;
+            nv[j] = (noisy && i < n) ? nz[i] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < AUD_PER; j++)
+            if (masked_at(ivb, nm, i0 + (long)j * AUD_THREADS)) sp[j] = 0.f;
+        if (PHASE == 0) {
+            double es = 0.0, en = 0.0;
+#pragma unroll
+            for (int j = 0; j < AUD_PER; j++) {
+                es += (double)sp[j] * sp[j];
+                en += (double)nv[j] * nv[j];
+            }
+            es = block_sum_d(es, red);
+            en = block_sum_d(en, red);
+            if (threadIdx.x == 0) mine[0] = es, mine[1] = en;
+            return;
+        }
+        float scale = 0.f;
+        if (noisy) {
+            // torchaudio.functional.add_noise: scale = 10^((10 (log10 E_s - log10 E_n) - snr) / 20)
+            const float orig = 10.f * (log10f((float)total(0, 0)) - log10f((float)total(0, 1)));
+            scale = powf(10.f, (orig - snr_db[b]) / 20.f);
+        }
         double sum = 0.0;
-        for (long i = i0 + threadIdx.x; i < hi; i += AUD_THREADS) sum += (double)noisy_at(i);
+#pragma unroll
+        for (int j = 0; j < AUD_PER; j++) {
+            const long i = i0 + (long)j * AUD_THREADS;
+            const float y = noisy ? sp[j] + scale * nv[j] : sp[j];
+            if (i < n) {
+                o[i] = y;
+                sum += (double)y;
+            }
+        }
         sum = block_sum_d(sum, red);
         if (threadIdx.x == 0) mine[0] = sum, mine[1] = 0.0;
         return;
     }
     const double mean = n > 0 ? total(1, 0) / (double)n : 0.0;
+    float y[AUD_PER];
+#pragma unroll
+    for (int j = 0; j < AUD_PER; j++) {
+        const long i = i0 + (long)j * AUD_THREADS;
+        y[j] = i < n ? o[i] : 0.f;
+    }
     if (PHASE == 2) {
         double sq = 0.0;
-        for (long i = i0 + threadIdx.x; i < hi; i += AUD_THREADS) {
-            const double d = (double)noisy_at(i) - mean;
-            sq += d * d;
+#pragma unroll
+        for (int j = 0; j < AUD_PER; j++) {
+            const double d = (double)y[j] - mean;
+            if (i0 + (long)j * AUD_THREADS < n) sq += d * d;
         }
         sq = block_sum_d(sq, red);
         if (threadIdx.x == 0) mine[0] = sq, mine[1] = 0.0;
@@ -191,9 +214,11 @@ __global__ __launch_bounds__(AUD_THREADS) void audio_phase_kernel(
     }
     const double var = n > 0 ? total(2, 0) / (double)n : 0.0;  // biased, as layer_norm
     const float rstd = (float)(1.0 / sqrt(var + (double)eps)), mu = (float)mean;
-    float* o = out + (long)b * Lmax;
-    const long top = i1 < Lmax ? i1 : Lmax;
-    for (long i = i0 + threadIdx.x; i < top; i += AUD_THREADS) o[i] = i < n ? (noisy_at(i) - mu) * rstd : 0.f;
+#pragma unroll
+    for (int j = 0; j < AUD_PER; j++) {
+        const long i = i0 + (long)j * AUD_THREADS;
+        if (i < Lmax) o[i] = i < n ? (y[j] - mu) * rstd : 0.f;
+    }
 }
 
 }  // namespace
