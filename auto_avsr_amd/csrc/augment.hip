@@ -115,7 +115,7 @@ AVSR_DEV double block_sum_d(double v, double* red) {
 // mask -> add noise at the requested SNR -> layer_norm over the whole utterance -> padded batch, as four grid-wide
 // phases (an utterance is up to 256 000 samples: one block per utterance would leave 250 CUs idle for milliseconds).
 // Block (chunk, utterance); the per-utterance statistics travel through per-chunk partial sums in `part`
-// ([3 phases][B][nch][2] doubles, summed in chunk order by every block that needs them -- deterministic).
+// ([3 phases][B][nch][2] doubles, reduced in one fixed order by every block that needs them -- deterministic).
 //   PHASE 0: E_speech, E_noise over the masked speech / the noise segment
 //   PHASE 1: y = speech + scale * noise  -> written to `out` (un-normalised), sum(y)
 //   PHASE 2: sum((y - mean)^2) from `out`
@@ -132,11 +132,15 @@ __global__ __launch_bounds__(AUD_THREADS) void audio_phase_kernel(
     const long i0 = (long)ch * AUD_CHUNK + threadIdx.x;
     float* o = out + (long)b * Lmax;
     double* mine = part + (((long)PHASE * B + b) * nch + ch) * 2;
-    auto total = [&](int phase, int k) {  // sum of the partials of an earlier phase, in chunk order
+    // Sum of the per-chunk partials of an earlier phase.  The partials were written by blocks on other XCDs, so every
+    // load is an HBM / Infinity-Cache round trip: the block fetches them in parallel (one chunk per thread) and reduces,
+    // instead of one thread walking them (125 serialised round trips for a 256 000-sample utterance).  Every block of
+    // an utterance reduces in the same order, so all of them see bit-identical statistics.
+    auto total = [&](int phase, int k) {
         const double* p = part + (((long)phase * B + b) * nch) * 2 + k;
         double t = 0.0;
-        for (int c = 0; c < nch; c++) t += p[2 * c];
-        return t;
+        for (int c = threadIdx.x; c < nch; c += AUD_THREADS) t += p[2 * c];
+        return block_sum_d(t, red);
     };
     const bool noisy = noise != nullptr && noise_start[b] >= 0;
     if (PHASE <= 1) {
