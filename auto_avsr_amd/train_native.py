@@ -61,7 +61,7 @@ def run(args):
                                         device=dev)
         seed_dev.add_(1)
         AF.new_step()
-        AF.refresh_weight_cache()  # the optimizer moved the f32 master weights: one launch re-casts every bf16 copy
+        AF.refresh_weight_cache()  # conv-weight permutes; the Linear copies were rewritten by the optimizer step itself
         loss, loss_ctc, loss_att, hits, ntok = hot(x, lens, y)
         if world > 1:
             bs = torch.tensor([float(x.shape[0])], device=dev)
