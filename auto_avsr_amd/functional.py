@@ -635,6 +635,45 @@ class FfnFn(torch.autograd.Function):
         return dx, dw1, db1, dw2, db2, None
 
 
+class MlpFn(torch.autograd.Function):
+    """Two-layer perceptron with its own input / hidden / output widths: W2 relu(W1 x + b1) + b2  (f32 out).
+    The fusion head of the audio-visual model (e2e_av.py); same kernels and backward structure as FfnFn."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        x2 = _to_act(x)
+        rows, Din = _rows(x2), x2.shape[-1]
+        Fh, Dout = w1.shape[0], w2.shape[0]
+        u = torch.empty(rows, Fh, dtype=act_dtype(), device=x.device)
+        _gemm_nt(x2, w1, rows, Fh, Din, u, bias=b1, act=1)
+        y = torch.empty(x.shape[:-1] + (Dout,), dtype=torch.float32, device=x.device)
+        _gemm_nt(u, w2, rows, Dout, Fh, y, bias=b2)
+        ctx.save_for_backward(x2, u, w1, w2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, u, w1, w2 = ctx.saved_tensors
+        rows, Din = _rows(x2), x2.shape[-1]
+        Fh, Dout = w1.shape[0], w2.shape[0]
+        g = _to_act(dy)
+        db2 = _bgrad(g, rows, Dout)
+        du = torch.empty(rows, Fh, dtype=act_dtype(), device=g.device)
+        db1 = _zeros(Fh, x2.device)
+        with ops.paired():
+            dw2 = _wgrad(g, u, rows, Dout, Fh)
+            _gemm_nn(g, w2, rows, Fh, Dout, du, gate=u, ldg=Fh, gate_scale=1.0, colsum=db1)  # relu' = (u > 0)
+        dx = torch.empty(x2.shape, dtype=torch.float32, device=g.device)
+        with ops.paired():
+            dw1 = _wgrad(du, x2, rows, Fh, Din)
+            _gemm_nn(du, w1, rows, Din, Fh, dx)
+        return dx, dw1, db1, dw2, db2
+
+
+def mlp(x, w1, b1, w2, b2):
+    return MlpFn.apply(x, w1, b1, w2, b2)
+
+
 # ------------------------------------------------------------------------------------------------ attention cores
 def _proj(h, w, b, rows, D):
     out = torch.empty(rows, w.shape[0], dtype=act_dtype(), device=h.device)

@@ -288,3 +288,28 @@ def e2e_forward(sd, x, lengths, label, modality="video", heads=12, ctc_weight=0.
     loss = ctc_weight * loss_ctc + (1 - ctc_weight) * loss_att
     acc = token_accuracy(pred, ys_out)
     return (loss, loss_ctc, loss_att, acc), dict(feats=feats, enc=enc, pred=pred, ys_in=ys_in, ys_out=ys_out)
+
+
+def e2e_av_forward(sd, video, audio, lengths, label, heads=12, ctc_weight=0.1, train_bn=True):
+    """Audio-visual composition (no counterpart in the reference snapshot): the two pinned stacks
+    (`frontend` / `proj_encoder` / `encoder` on video, `aux_*` on audio), frame-wise concatenation, the fusion MLP
+    fc2(relu(fc1(.))) -- this build's choice --, then the pinned heads exactly as in e2e_forward."""
+    odim = sd["ctc.ctc_lo.weight"].shape[0]
+    sos = eos = odim - 1
+    vf = video_frontend(sd, "frontend.", video, train_bn)
+    af = audio_frontend(sd, "aux_frontend.", audio, train_bn)
+    T = min(vf.shape[1], af.shape[1])
+    vf, af = vf[:, :T], af[:, :T]
+    pad_mask = (torch.arange(T).unsqueeze(0) < lengths.unsqueeze(1)).unsqueeze(-2)
+    v = conformer_encoder(sd, "encoder.", linear(sd, "proj_encoder.", vf), pad_mask, heads, train_bn)
+    a = conformer_encoder(sd, "aux_encoder.", linear(sd, "aux_proj_encoder.", af), pad_mask, heads, train_bn)
+    mem = linear(sd, "fusion.fc2.", torch.relu(linear(sd, "fusion.fc1.", torch.cat([v, a], dim=-1))))
+    loss_ctc = ctc_loss(sd, "ctc.", mem, lengths, label)
+    ys_in, ys_out = add_sos_eos(label, sos, eos)
+    L = ys_in.shape[1]
+    ys_mask = (ys_in != -1).unsqueeze(-2) & torch.tril(torch.ones(L, L, dtype=torch.bool)).unsqueeze(0)
+    pred = transformer_decoder(sd, "decoder.", ys_in, ys_mask, mem, pad_mask, heads)
+    loss_att = label_smoothing_loss(pred, ys_out)
+    loss = ctc_weight * loss_ctc + (1 - ctc_weight) * loss_att
+    return (loss, loss_ctc, loss_att, token_accuracy(pred, ys_out)), dict(mem=mem, pred=pred)
+
