@@ -176,14 +176,16 @@ def _w_conv(w, to_dgrad):
     return ent[1]
 
 
-def refresh_weight_cache():
+def refresh_weight_cache(force=False):
     """Rebuild every registered bf16 weight copy in place with ONE multi-tensor launch (what a training step needs
-    after the optimizer changed the weights).  Falls back to lazy per-weight casts until weights are registered."""
+    after the optimizer changed the weights).  Falls back to lazy per-weight casts until weights are registered.
+    force: re-cast even when an optimizer has claimed the copies (a weight was changed behind its back, e.g. by
+    load_state_dict -- detected through the tensor version in _w_bf16)."""
     _refresh_conv_weights()
     if not _wcache:
         return
     owner = _wgen["owner"]() if _wgen["owner"] is not None else None
-    if owner is not None and _wgen["owner_gen"] == _cast_generation():
+    if not force and owner is not None and _wgen["owner_gen"] == _cast_generation():
         return  # the optimizer step rewrote every copy together with the weights (optim.FusedAdamW cast_weights=True)
     if _wtable["built_for"] != len(_wcache):
         import struct
@@ -212,7 +214,7 @@ def _w_bf16(w2d, transposed):
         return ent[1]
     if ent is not None:  # stale copy: refresh in place (keeps addresses stable for captured graphs)
         if len(ent) > 3 and ent[3]:  # slice of a concatenated buffer: only the multi-tensor kernel knows its pitch
-            refresh_weight_cache()
+            refresh_weight_cache(force=True)
             return ent[1]
         if transposed:
             ops.transpose_cast_into(w2d, ent[1])

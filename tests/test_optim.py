@@ -93,6 +93,15 @@ def test_fused_adamw_cast_weights(dev):
                 assert torch.equal(c.cpu(), ref)
         full = torch.cat([pb[2], pb[3], pb[4]]).detach().cpu().to(torch.bfloat16)
         assert torch.equal(cat.cpu(), full) and torch.equal(catT.cpu(), full.t())
+    # a weight changed behind the optimizer's back (load_state_dict, manual edits: the tensor version moves) is re-cast
+    # on its next use even while the claim stands -- also when it is a slice of a concatenation
+    with torch.no_grad():
+        pb[3].mul_(0.5)
+        pb[0].add_(1.0)
+    assert AF._wgen["owner_gen"] == AF._cast_generation()
+    cat2 = AF._w_bf16_cat([pb[2], pb[3], pb[4]], False)
+    assert cat2 is cat and torch.equal(cat.cpu(), torch.cat([pb[2], pb[3], pb[4]]).detach().cpu().to(torch.bfloat16))
+    assert torch.equal(AF._w_bf16(pb[0], False).cpu(), pb[0].detach().cpu().to(torch.bfloat16))
     # a weight registered later changes the cache generation: the claim lapses until the next optimizer step
     AF._w_bf16(pb[1], False)
     assert AF._wgen["owner_gen"] != AF._cast_generation()
