@@ -45,7 +45,7 @@ class FusedAdamW:
         self._rows[:, 4] = numel.astype(np.uint64)
         self._rows[:, 5] = (np.cumsum(blocks) - blocks).astype(np.uint64)
         self._blocks = int(blocks.sum())
-        self._free_host = [self._new_host() for _ in range(8)]
+        self._free_host = [self._new_host() for _ in range(24)]  # every captured step shape holds one for good
 
     def _new_host(self):
         t = torch.empty(self._table_bytes, dtype=torch.uint8)
