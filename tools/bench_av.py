@@ -1,0 +1,62 @@
+"""Throughput of the audio-visual composition (auto_avsr_amd/e2e_av.py) at BASELINE config 5 (max-frames 3200):
+full training step (fwd + bwd + fused clip / AdamW), eager launches, one batch shape.  Not part of bench.py's contract
+(the reference snapshot has no AV model to compare with).  GPU box:  python tools/bench_av.py [--frames 3200] [--steps 8]"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.getcwd())
+import torch
+
+from auto_avsr_amd import functional as AF
+from auto_avsr_amd.e2e_av import E2EAV
+from auto_avsr_amd.optim import FusedAdamW
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=3200)
+    ap.add_argument("--T", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    odim = 5049
+    model = E2EAV(odim).to(dev).train()
+    AF.set_precise(False)
+    AF.manual_seed(1)
+    seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+    AF.set_seed_tensor(seed_dev)
+    opt = FusedAdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.98), weight_decay=0.03, max_grad_norm=10.0,
+                     warmup_steps=5000, total_steps=75000, cast_weights=True)
+    B, T = args.frames // args.T, args.T
+    video = torch.randn(B, T, 1, 88, 88, device=dev)
+    audio = torch.randn(B, T * 640, 1, device=dev)
+    lengths = torch.full((B,), T, dtype=torch.int64, device=dev)
+    label = torch.randint(1, odim - 1, (B, 1, max(1, round(T / 6.5))), device=dev)
+
+    def step():
+        AF.new_step()
+        seed_dev.add_(1)
+        AF.refresh_weight_cache()
+        loss = model.forward_tensors(video, audio, lengths, label)[0]
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    n = sum(p.numel() for p in model.parameters())
+    print(f"E2EAV {n / 1e6:.1f} M parameters, batch {B} x {T} frames: {dt * 1e3:.2f} ms / step = {B * T / dt:,.0f} frames/s")
+
+
+if __name__ == "__main__":
+    main()
