@@ -243,6 +243,62 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(const T* __restr
     }
 }
 
+// y[n,oh,ow,c] = max over the KxK / stride S / pad P window of act(bn(x[n,ih,iw,c])), idx = kh*K+kw of the first maximum:
+// bn_act_fwd + maxpool_fwd (pool.hip) without the full-resolution activation between them -- the video stem's BN + SiLU
+// output is 396 MB per 1600-frame batch, written once and read once only to be pooled 4:1.  Each activated value is
+// rounded to the storage type before the comparison, exactly as if it had been stored and re-loaded.
+template <class T>
+__global__ __launch_bounds__(BN_THREADS) void bn_act_pool_fwd_kernel(
+    const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y, uint8_t* __restrict__ idx, long N,
+    int H, int W, int C, int OH, int OW, int K, int S, int P, int act) {
+    const int cv = C >> 3;
+    const long total = N * OH * OW * cv;
+    for (long i = (long)blockIdx.x * BN_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * BN_THREADS) {
+        const int c = (int)(i % cv) * 8;
+        long r = i / cv;
+        const int ow = (int)(r % OW);
+        r /= OW;
+        const int oh = (int)(r % OH);
+        const long n = r / OH;
+        float mu[8], is[8], ga[8], be[8], m[8];
+        uint8_t am[8];
+        load8(mean + c, mu);
+        load8(invstd + c, is);
+        load8(gamma + c, ga);
+        load8(beta + c, be);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            m[e] = -INFINITY;
+            am[e] = 0;
+        }
+        for (int kh = 0; kh < K; kh++) {
+            const int ih = oh * S + kh - P;
+            if (ih < 0 || ih >= H) continue;
+            for (int kw = 0; kw < K; kw++) {
+                const int iw = ow * S + kw - P;
+                if (iw < 0 || iw >= W) continue;
+                float v[8];
+                load8(x + ((n * H + ih) * W + iw) * C + c, v);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    float a = act_fwd((v[e] - mu[e]) * is[e] * ga[e] + be[e], act);
+                    if (sizeof(T) == 2) a = bf2f(f2bf(a));  // the value the unfused path would have stored
+                    if (a > m[e]) {
+                        m[e] = a;
+                        am[e] = (uint8_t)(kh * K + kw);
+                    }
+                }
+            }
+        }
+        store8(y + i * 8, m);
+        uint64_t pk = 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) pk |= (uint64_t)am[e] << (8 * e);
+        *reinterpret_cast<uint64_t*>(idx + i * 8) = pk;
+    }
+}
+
 // sums: [2][C] all-reduced (sum dz, sum dz*xhat); n = global row count
 template <class T>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
@@ -387,6 +443,25 @@ extern "C" int avsr_bn_act_fwd(const void* x, const void* add, int dtype, const 
         AVSR_LAUNCH((bn_act_fwd_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)add, mean,
                     invstd, gamma, beta, (bf16_t*)y, (long)rows, C, act);
     AVSR_CHECK_LAUNCH("bn_act_fwd");
+    return 0;
+}
+
+// y [N][OH][OW][C], idx uint8 [N][OH][OW][C] = maxpool(act(bn(x [N][H][W][C]))) with OH = (H + 2P - K)/S + 1
+extern "C" int avsr_bn_act_pool_fwd(const void* x, int dtype, const float* mean, const float* invstd, const float* gamma,
+                                    const float* beta, void* y, uint8_t* idx, int64_t N, int H, int W, int C, int K, int S,
+                                    int P, int act, hipStream_t stream) {
+    AVSR_REQUIRE(C % 8 == 0, "batchnorm: C must be a multiple of 8");
+    AVSR_REQUIRE(idx != nullptr, "bn_act_pool_fwd: idx required");
+    const int OH = (H + 2 * P - K) / S + 1, OW = (W + 2 * P - K) / S + 1;
+    if (N <= 0) return 0;
+    dim3 grid(ew_grid((long)N * OH * OW * (C >> 3))), block(BN_THREADS);
+    if (dtype == 0)
+        AVSR_LAUNCH((bn_act_pool_fwd_kernel<float>), grid, block, 0, stream, (const float*)x, mean, invstd, gamma, beta,
+                    (float*)y, idx, (long)N, H, W, C, OH, OW, K, S, P, act);
+    else
+        AVSR_LAUNCH((bn_act_pool_fwd_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, mean, invstd, gamma, beta,
+                    (bf16_t*)y, idx, (long)N, H, W, C, OH, OW, K, S, P, act);
+    AVSR_CHECK_LAUNCH("bn_act_pool_fwd");
     return 0;
 }
 

@@ -84,6 +84,9 @@ def _rows(x):
 # ([in][out_padded_to_64], data gradient).  Copies are cached per parameter version: an optimizer step bumps
 # `_version`, so they are rebuilt exactly once per training step (bench.py invalidates explicitly).
 _FUSE_QKV = os.environ.get("AVSR_FUSE_QKV", "1") != "0"  # A/B switch for the fused self-attention projections
+# fused BN + SiLU + max-pool of the video stem: validated on the emulator, not yet on the MI355X (the round's GPU budget
+# was spent) -- off until it has been run and timed there
+_FUSE_STEM_POOL = os.environ.get("AVSR_FUSE_STEM_POOL", "0") == "1"
 _wcache = {}   # (data_ptr, transposed, shape) -> [version, bf16 copy, source weight, is a slice of a concatenation]
 _wcat = {}     # (data_ptrs..., transposed) -> concatenated bf16 buffer whose slices are registered in _wcache
 _wtable = {"n": 0, "dev": None, "blocks": 0, "built_for": -1}
@@ -1380,12 +1383,16 @@ class StemFn(torch.autograd.Function):
         rows = B * Tn * OH * OW
         bn = (g, b) + bn_rest
         m0, i0, n0 = _bn_fwd_params(c0, rows, Cout, bn, training)
-        a0 = ops.bn_act_fwd(c0, None, m0, i0, g, b, rows, Cout, 1)
         idx = None
-        if pool:
+        if pool and _FUSE_STEM_POOL:
+            # BN + SiLU + max-pool in one pass: the full-resolution activation (396 MB per 1600 video frames) is never
+            # written (the backward pass recomputes it from c0 anyway)
+            out, idx = ops.bn_act_pool_fwd(c0, m0, i0, g, b, B * Tn, OH, OW, Cout, 3, 2, 1, 1)
+        elif pool:
+            a0 = ops.bn_act_fwd(c0, None, m0, i0, g, b, rows, Cout, 1)
             out, idx = ops.maxpool2d_fwd(a0, B * Tn, OH, OW, Cout, 3, 2, 1)
         else:
-            out = a0
+            out = ops.bn_act_fwd(c0, None, m0, i0, g, b, rows, Cout, 1)
         ctx.save_for_backward(x, c0, idx, g, b, m0, i0, n0)
         ctx.meta = (geom, pool, training, bn_rest, (OH, OW), w.shape, dedicated)
         return out

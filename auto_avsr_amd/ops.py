@@ -278,6 +278,16 @@ def bn_act_fwd(x, add, mean, invstd, gamma, beta, rows, C, act):
     return y
 
 
+def bn_act_pool_fwd(x, mean, invstd, gamma, beta, N, H, W, C, K, S, P, act):
+    """maxpool(act(bn(x))) without the full-resolution activation; returns (y, idx) like maxpool2d_fwd."""
+    OH, OW = conv_out(H, K, S, P), conv_out(W, K, S, P)
+    y = torch.empty(N, OH, OW, C, dtype=x.dtype, device=x.device)
+    idx = torch.empty(N, OH, OW, C, dtype=torch.uint8, device=x.device)
+    call("avsr_bn_act_pool_fwd", _ptr(x), dt(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(idx),
+         N, H, W, C, K, S, P, act, _stream(x))
+    return y, idx
+
+
 def bn_bwd_reduce(x, dy, add, mean, invstd, gamma, beta, rows, C, act):
     sums = torch.empty(2, C, dtype=torch.float32, device=x.device)
     ws = torch.empty(1024 * 2 * C, dtype=torch.float32, device=x.device)

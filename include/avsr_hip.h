@@ -140,6 +140,12 @@ int avsr_bn_eval_params(const float* running_mean, const float* running_var, flo
 int avsr_bn_act_fwd(const void* x, const void* add, int dtype, const float* mean, const float* invstd,
                     const float* gamma, const float* beta, void* y, int64_t rows, int C, int act,
                     avsr_stream_t stream);
+/* maxpool(act(bn(x))) in one pass: y [N][OH][OW][C] + argmax idx (uint8, kh*K+kw of the first maximum) from
+ * x [N][H][W][C]; replaces BatchNorm3d + SiLU + MaxPool3d((1,3,3),(1,2,2),(0,1,1)) of the video stem
+ * (frontend/resnet.py:212-218) without materialising the full-resolution activation */
+int avsr_bn_act_pool_fwd(const void* x, int dtype, const float* mean, const float* invstd, const float* gamma,
+                         const float* beta, void* y, uint8_t* idx, int64_t N, int H, int W, int C, int K, int S, int P,
+                         int act, avsr_stream_t stream);
 /* sums [2][C] = (sum dz, sum dz*xhat), dz = dy*act'(z); workspace as above */
 int avsr_bn_bwd_reduce(const void* x, const void* dy, const void* add, int dtype, const float* mean,
                        const float* invstd, const float* gamma, const float* beta, float* sums, float* workspace,

@@ -130,3 +130,33 @@ def test_batchnorm_two_rank_merge(dev):
                                      stats_stride=3 * C + 1, counts_stride=3 * C + 1, n_total=n_total)
     assert torch.equal(mean2, mean) and torch.equal(invstd2, invstd)
     assert float(n_total) == 800.0 and int(nbt) == 1
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+def test_bn_act_pool_fused_matches_two_pass(dev, dtype):
+    """maxpool(SiLU(bn(x))) in one pass (video stem) vs bn_act_fwd followed by maxpool2d_fwd: same pooled values (to one
+    rounding of the storage type -- the two kernels may contract the affine map differently) and an argmax that points
+    at a maximal element of its window."""
+    torch.manual_seed(9)
+    N, H, W, C = 3, 11, 14, 64
+    x = (torch.randn(N, H, W, C) * 2).to(dtype).to(dev)
+    mean, invstd = torch.randn(C, device=dev) * 0.3, torch.rand(C, device=dev) + 0.5
+    gamma, beta = torch.randn(C, device=dev), torch.randn(C, device=dev) * 0.2
+    a = ops.bn_act_fwd(x.view(-1, C), None, mean, invstd, gamma, beta, N * H * W, C, 1).view(N, H, W, C)
+    want, want_idx = ops.maxpool2d_fwd(a, N, H, W, C, 3, 2, 1)
+    got, got_idx = ops.bn_act_pool_fwd(x, mean, invstd, gamma, beta, N, H, W, C, 3, 2, 1, 1)
+    assert got.shape == want.shape and got_idx.shape == want_idx.shape
+    tol = 2.0 ** -7 if dtype == torch.bfloat16 else 1e-5
+    assert ((got.float() - want.float()).abs() <= tol * want.float().abs().clamp_min(1.0)).all()
+    # the recorded argmax addresses an element that attains the pooled value
+    ap = torch.nn.functional.pad(a.float().cpu(), (0, 0, 1, 1, 1, 1), value=float("-inf"))  # pad W and H by 1
+    OH, OW = got.shape[1], got.shape[2]
+    gi = got_idx.cpu().long()
+    kh, kw = gi // 3, gi % 3
+    oh = torch.arange(OH).view(1, OH, 1, 1) * 2
+    ow = torch.arange(OW).view(1, 1, OW, 1) * 2
+    n = torch.arange(N).view(N, 1, 1, 1).expand_as(gi)
+    c = torch.arange(C).view(1, 1, 1, C).expand_as(gi)
+    picked = ap[n, oh + kh, ow + kw, c]
+    assert ((picked - want.float().cpu()).abs() <= tol * want.float().cpu().abs().clamp_min(1.0)).all()
+    assert (got_idx == want_idx).float().mean() > 0.99

@@ -248,3 +248,35 @@ def test_linear_padded_head_f32_grad_bf16_mode(dev):
     finally:
         AF.invalidate_weight_cache()
         AF.set_precise(was_precise)
+
+
+def test_stem_fused_pool_switch_equivalence(emu_lib_path):
+    """AVSR_FUSE_STEM_POOL (BN + SiLU + max-pool of the video stem in one pass; off by default until it has been run on
+    the MI355X): same losses and gradients as the two-pass path, bf16 mode, emulator build."""
+    from auto_avsr_amd import _lib
+
+    _lib._install_for_tests(emu_lib_path)
+    was_precise, was_fused = AF._state["precise"], AF._FUSE_STEM_POOL
+    odim = 40
+    res = []
+    try:
+        AF.set_precise(False)
+        for fused in (False, True):
+            AF._FUSE_STEM_POOL = fused
+            AF.invalidate_weight_cache()
+            torch.manual_seed(0)
+            m = no_dropout(E2E(odim, "video", adim=64, aheads=1, eunits=64, elayers=1, dunits=64, dlayers=1, cnn_module_kernel=7))
+            m.load_state_dict(synth_state_dict(m.state_dict(), 3), strict=True)
+            m.train()
+            x, lengths, y = synth_batch("video", 2, 7, 3, odim, seed=2)
+            loss, loss_ctc, loss_att, _ = m(x, lengths, y)
+            loss.backward()
+            res.append((float(loss_ctc), float(loss_att), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    finally:
+        AF._FUSE_STEM_POOL = was_fused
+        AF.set_precise(was_precise)
+        AF.invalidate_weight_cache()
+    (c0, a0, g0), (c1, a1, g1) = res
+    assert abs(c0 - c1) < 1e-4 * abs(c0) and abs(a0 - a1) < 1e-4 * abs(a0)
+    for k in g0:
+        assert rel(g1[k], g0[k]) < 1e-3 or float(g0[k].abs().max()) < 1e-7, k
