@@ -334,6 +334,122 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
     }
 }
 
+// ---- backward of maxpool(act(bn(x))) without the full-resolution gradient tensor: the gradient of the activation at
+// (n, ih, iw) is gathered from the pooled gradient -- sum over the (at most 4 for K=3, S=2) windows that contain the pixel
+// and whose recorded argmax is that pixel -- wherever the two BatchNorm backward passes need it (pool.hip maxpool_bwd
+// would write it to HBM once, 396 MB for the video stem, and both passes would read it back).
+template <class T>
+AVSR_DEV void pool_grad8(const uint8_t* __restrict__ idx, const T* __restrict__ dpool, long n, int ih, int iw, int c, int C,
+                         int OH, int OW, int K, int S, int P, float* g) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) g[e] = 0.f;
+    const int oh_lo = max(0, (ih + P - K + 1 + S - 1) / S), oh_hi = min(OH - 1, (ih + P) / S);
+    const int ow_lo = max(0, (iw + P - K + 1 + S - 1) / S), ow_hi = min(OW - 1, (iw + P) / S);
+    for (int oh = oh_lo; oh <= oh_hi; oh++)
+        for (int ow = ow_lo; ow <= ow_hi; ow++) {
+            const int me = (ih - (oh * S - P)) * K + (iw - (ow * S - P));
+            const long o = ((n * OH + oh) * OW + ow) * C + c;
+            const uint64_t pk = *reinterpret_cast<const uint64_t*>(idx + o);
+            float d[8];
+            load8(dpool + o, d);
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                if ((int)((pk >> (8 * e)) & 0xff) == me) g[e] += d[e];
+        }
+}
+
+// partial sums (sum dz, sum dz * xhat) per block, as bn_colreduce_kernel<T, 1>; rows are the N*H*W pixels
+template <class T>
+__global__ __launch_bounds__(BN_THREADS) void bn_pool_bwd_reduce_kernel(
+    const T* __restrict__ x, const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ out, long rows, int H, int W, int C, int OH, int OW, int K, int S, int P, int CL,
+    int rows_per_block, int act) {
+    __shared__ float red[BN_THREADS * 16];
+    const int cv = C >> 3;
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL, RL = BN_THREADS / CL;
+    const int cc = blockIdx.x * CL + cl;
+    float a[8], b[8], mu[8], is[8], ga[8], be[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) a[e] = b[e] = mu[e] = is[e] = ga[e] = be[e] = 0.f;
+    if (cc < cv) {
+        load8(mean + cc * 8, mu);
+        load8(invstd + cc * 8, is);
+        load8(gamma + cc * 8, ga);
+        load8(beta + cc * 8, be);
+        for (long r0 = (long)blockIdx.y * rows_per_block; r0 < rows; r0 += (long)gridDim.y * rows_per_block) {
+            const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+            for (long r = r0 + rl; r < r1; r += RL) {
+                const int iw = (int)(r % W);
+                const long q = r / W;
+                const int ih = (int)(q % H);
+                float v[8], g[8];
+                load8(x + r * C + cc * 8, v);
+                pool_grad8<T>(idx, dpool, q / H, ih, iw, cc * 8, C, OH, OW, K, S, P, g);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const float xh = (v[e] - mu[e]) * is[e];
+                    const float dz = g[e] * act_grad(xh * ga[e] + be[e], act);
+                    a[e] += dz;
+                    b[e] += dz * xh;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        red[threadIdx.x * 16 + e] = a[e];
+        red[threadIdx.x * 16 + 8 + e] = b[e];
+    }
+    __syncthreads();
+    if (rl == 0 && cc < cv) {
+        for (int q = 1; q < RL; q++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                a[e] += red[(q * CL + cl) * 16 + e];
+                b[e] += red[(q * CL + cl) * 16 + 8 + e];
+            }
+        float* part = out + (long)blockIdx.y * 2 * C;
+        store8(part + cc * 8, a);
+        store8(part + C + cc * 8, b);
+    }
+}
+
+// dx = gamma * invstd * (dz - sum_dz / n - xhat * sum_dz_xhat / n), dz from the pooled gradient, as bn_bwd_apply_kernel
+template <class T>
+__global__ __launch_bounds__(BN_THREADS) void bn_pool_bwd_apply_kernel(
+    const T* __restrict__ x, const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ sums, float inv_n0, const float* __restrict__ n_dev, T* __restrict__ dx, long rows, int H,
+    int W, int C, int OH, int OW, int K, int S, int P, int act) {
+    const float inv_n = n_dev ? 1.0f / *n_dev : inv_n0;
+    const int cv = C >> 3;
+    const long nvec = rows * cv;
+    for (long i = (long)blockIdx.x * BN_THREADS + threadIdx.x; i < nvec; i += (long)gridDim.x * BN_THREADS) {
+        const int c = (int)(i % cv) * 8;
+        const long r = i / cv;
+        const int iw = (int)(r % W);
+        const long q = r / W;
+        const int ih = (int)(q % H);
+        float v[8], g[8], mu[8], is[8], ga[8], be[8], s1[8], s2[8], o[8];
+        load8(x + i * 8, v);
+        pool_grad8<T>(idx, dpool, q / H, ih, iw, c, C, OH, OW, K, S, P, g);
+        load8(mean + c, mu);
+        load8(invstd + c, is);
+        load8(gamma + c, ga);
+        load8(beta + c, be);
+        load8(sums + c, s1);
+        load8(sums + C + c, s2);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float xh = (v[e] - mu[e]) * is[e];
+            const float dz = g[e] * act_grad(xh * ga[e] + be[e], act);
+            o[e] = ga[e] * is[e] * (dz - s1[e] * inv_n - xh * s2[e] * inv_n);
+        }
+        store8(dx + i * 8, o);
+    }
+}
+
 static inline int pick_cl(int cv) { return cv >= 32 ? 32 : (cv >= 16 ? 16 : 8); }
 static inline int ew_grid(long nvec) {
     long b = (nvec + BN_THREADS - 1) / BN_THREADS;
@@ -462,6 +578,54 @@ extern "C" int avsr_bn_act_pool_fwd(const void* x, int dtype, const float* mean,
         AVSR_LAUNCH((bn_act_pool_fwd_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, mean, invstd, gamma, beta,
                     (bf16_t*)y, idx, (long)N, H, W, C, OH, OW, K, S, P, act);
     AVSR_CHECK_LAUNCH("bn_act_pool_fwd");
+    return 0;
+}
+
+// backward of avsr_bn_act_pool_fwd, first pass: sums [2][C] = (sum dz, sum dz * xhat) over the N*H*W pixels, the gradient
+// gathered from dpool [N][OH][OW][C] through idx; workspace: avsr_bn_workspace_floats(C) floats
+extern "C" int avsr_bn_pool_bwd_reduce(const void* x, const void* dpool, const uint8_t* idx, int dtype, const float* mean,
+                                       const float* invstd, const float* gamma, const float* beta, float* sums,
+                                       float* workspace, int64_t N, int H, int W, int C, int K, int S, int P, int act,
+                                       hipStream_t stream) {
+    AVSR_REQUIRE(C % 8 == 0, "batchnorm: C must be a multiple of 8");
+    const int OH = (H + 2 * P - K) / S + 1, OW = (W + 2 * P - K) / S + 1;
+    const long rows = (long)N * H * W;
+    if (rows <= 0) return 0;
+    const int cv = C >> 3, CL = pick_cl(cv);
+    const int rpb = 128 * (BN_THREADS / CL) / 8;
+    const int gx = (cv + CL - 1) / CL;
+    const int parts = bn_parts(rows, rpb, gx);
+    dim3 grid(gx, parts), block(BN_THREADS);
+    dim3 g2((2 * C + 15) / 16);
+    if (dtype == 0)
+        AVSR_LAUNCH((bn_pool_bwd_reduce_kernel<float>), grid, block, 0, stream, (const float*)x, (const float*)dpool, idx, mean,
+                    invstd, gamma, beta, workspace, rows, H, W, C, OH, OW, K, S, P, CL, rpb, act);
+    else
+        AVSR_LAUNCH((bn_pool_bwd_reduce_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dpool, idx,
+                    mean, invstd, gamma, beta, workspace, rows, H, W, C, OH, OW, K, S, P, CL, rpb, act);
+    AVSR_LAUNCH((bn_partial_sum_kernel<float>), g2, dim3(256), 0, stream, (const float*)workspace, parts, C, sums, 0,
+                (const float*)nullptr, (float*)nullptr, 0.f);
+    AVSR_CHECK_LAUNCH("bn_pool_bwd_reduce");
+    return 0;
+}
+
+// second pass: dx [N][H][W][C] from the (all-reduced) sums; inv_n / n_dev as avsr_bn_bwd_apply
+extern "C" int avsr_bn_pool_bwd_apply(const void* x, const void* dpool, const uint8_t* idx, int dtype, const float* mean,
+                                      const float* invstd, const float* gamma, const float* beta, const float* sums,
+                                      float inv_n, const float* n_dev, void* dx, int64_t N, int H, int W, int C, int K,
+                                      int S, int P, int act, hipStream_t stream) {
+    AVSR_REQUIRE(C % 8 == 0, "batchnorm: C must be a multiple of 8");
+    const int OH = (H + 2 * P - K) / S + 1, OW = (W + 2 * P - K) / S + 1;
+    const long rows = (long)N * H * W;
+    if (rows <= 0) return 0;
+    dim3 grid(ew_grid(rows * (C >> 3))), block(BN_THREADS);
+    if (dtype == 0)
+        AVSR_LAUNCH((bn_pool_bwd_apply_kernel<float>), grid, block, 0, stream, (const float*)x, (const float*)dpool, idx, mean,
+                    invstd, gamma, beta, sums, inv_n, n_dev, (float*)dx, rows, H, W, C, OH, OW, K, S, P, act);
+    else
+        AVSR_LAUNCH((bn_pool_bwd_apply_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dpool, idx,
+                    mean, invstd, gamma, beta, sums, inv_n, n_dev, (bf16_t*)dx, rows, H, W, C, OH, OW, K, S, P, act);
+    AVSR_CHECK_LAUNCH("bn_pool_bwd_apply");
     return 0;
 }
 

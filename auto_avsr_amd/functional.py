@@ -1405,8 +1405,21 @@ class StemFn(torch.autograd.Function):
         Cout = wshape[0]
         rows = B * Tn * OH * OW
         dout = dout.contiguous()
-        da0 = ops.maxpool2d_bwd(idx, dout, B * Tn, OH, OW, Cout, 3, 2, 1) if pool else dout
-        dc0, _, dg, db = _bn_bwd(c0, da0, None, m0, i0, (g, b) + bn_rest, n0, rows, Cout, 1, False, training)
+        if pool and _FUSE_STEM_POOL:
+            # the activation gradient is gathered from the pooled gradient inside both BatchNorm backward passes: the
+            # full-resolution gradient (396 MB per 1600 video frames) is neither written nor read back
+            dp = _to_act(dout)
+            sums = ops.bn_pool_bwd_reduce(c0, dp, idx, m0, i0, g, b, B * Tn, OH, OW, Cout, 3, 2, 1, 1)
+            dg, db = sums[1], sums[0]
+            if training:
+                sums_dx, inv_n, n_dev = _bn_bwd_sums(sums, n0, rows)
+            else:
+                sums_dx, inv_n, n_dev = torch.zeros_like(sums), 0.0, None
+            dc0 = ops.bn_pool_bwd_apply(c0, dp, idx, m0, i0, g, b, sums_dx, inv_n, B * Tn, OH, OW, Cout, 3, 2, 1, 1,
+                                        n_dev=n_dev)
+        else:
+            da0 = ops.maxpool2d_bwd(idx, dout, B * Tn, OH, OW, Cout, 3, 2, 1) if pool else dout
+            dc0, _, dg, db = _bn_bwd(c0, da0, None, m0, i0, (g, b) + bn_rest, n0, rows, Cout, 1, False, training)
         if dedicated:
             dw = ops.stem357_wgrad(dc0, x, B, Tn, H, W)
         else:

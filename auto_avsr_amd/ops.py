@@ -288,6 +288,21 @@ def bn_act_pool_fwd(x, mean, invstd, gamma, beta, N, H, W, C, K, S, P, act):
     return y, idx
 
 
+def bn_pool_bwd_reduce(x, dpool, idx, mean, invstd, gamma, beta, N, H, W, C, K, S, P, act):
+    sums = torch.empty(2, C, dtype=torch.float32, device=x.device)
+    ws = torch.empty(1024 * 2 * C, dtype=torch.float32, device=x.device)
+    call("avsr_bn_pool_bwd_reduce", _ptr(x), _ptr(dpool), _ptr(idx), dt(x), _ptr(mean), _ptr(invstd), _ptr(gamma),
+         _ptr(beta), _ptr(sums), _ptr(ws), N, H, W, C, K, S, P, act, _stream(x))
+    return sums
+
+
+def bn_pool_bwd_apply(x, dpool, idx, mean, invstd, gamma, beta, sums, inv_n, N, H, W, C, K, S, P, act, n_dev=None):
+    dx = torch.empty_like(x)
+    call("avsr_bn_pool_bwd_apply", _ptr(x), _ptr(dpool), _ptr(idx), dt(x), _ptr(mean), _ptr(invstd), _ptr(gamma),
+         _ptr(beta), _ptr(sums), inv_n, _ptr(n_dev), _ptr(dx), N, H, W, C, K, S, P, act, _stream(x))
+    return dx
+
+
 def bn_bwd_reduce(x, dy, add, mean, invstd, gamma, beta, rows, C, act):
     sums = torch.empty(2, C, dtype=torch.float32, device=x.device)
     ws = torch.empty(1024 * 2 * C, dtype=torch.float32, device=x.device)

@@ -146,6 +146,16 @@ int avsr_bn_act_fwd(const void* x, const void* add, int dtype, const float* mean
 int avsr_bn_act_pool_fwd(const void* x, int dtype, const float* mean, const float* invstd, const float* gamma,
                          const float* beta, void* y, uint8_t* idx, int64_t N, int H, int W, int C, int K, int S, int P,
                          int act, avsr_stream_t stream);
+/* backward of avsr_bn_act_pool_fwd in the two BatchNorm backward passes, the activation gradient gathered from the pooled
+ * gradient dpool [N][OH][OW][C] through idx (no full-resolution gradient tensor): sums [2][C] = (sum dz, sum dz*xhat),
+ * then dx [N][H][W][C] from the (all-reduced) sums; workspace / inv_n / n_dev as avsr_bn_bwd_reduce / _apply */
+int avsr_bn_pool_bwd_reduce(const void* x, const void* dpool, const uint8_t* idx, int dtype, const float* mean,
+                            const float* invstd, const float* gamma, const float* beta, float* sums, float* workspace,
+                            int64_t N, int H, int W, int C, int K, int S, int P, int act, avsr_stream_t stream);
+int avsr_bn_pool_bwd_apply(const void* x, const void* dpool, const uint8_t* idx, int dtype, const float* mean,
+                           const float* invstd, const float* gamma, const float* beta, const float* sums, float inv_n,
+                           const float* n_dev, void* dx, int64_t N, int H, int W, int C, int K, int S, int P, int act,
+                           avsr_stream_t stream);
 /* sums [2][C] = (sum dz, sum dz*xhat), dz = dy*act'(z); workspace as above */
 int avsr_bn_bwd_reduce(const void* x, const void* dy, const void* add, int dtype, const float* mean,
                        const float* invstd, const float* gamma, const float* beta, float* sums, float* workspace,

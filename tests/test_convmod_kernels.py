@@ -165,3 +165,36 @@ def test_bn_act_pool_fused_matches_two_pass(emu_lib_path, dtype):
     picked = ap[n, oh + kh, ow + kw, c]
     assert ((picked - want.float().cpu()).abs() <= tol * want.float().cpu().abs().clamp_min(1.0)).all()
     assert (got_idx == want_idx).float().mean() > 0.99
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+def test_bn_pool_bwd_fused_matches_three_pass(emu_lib_path, dtype):
+    """Backward of maxpool(SiLU(bn(x))) with the activation gradient gathered from the pooled gradient inside the two
+    BatchNorm backward passes vs maxpool2d_bwd -> bn_bwd_reduce -> bn_bwd_apply.  Emulator build only (the path is
+    switched off in the product until it has been run on the MI355X)."""
+    from auto_avsr_amd import _lib
+
+    _lib._install_for_tests(emu_lib_path)
+    torch.manual_seed(10)
+    N, H, W, C = 2, 9, 12, 64
+    x = (torch.randn(N, H, W, C) * 2).to(dtype)
+    mean, invstd = torch.randn(C) * 0.3, torch.rand(C) + 0.5
+    gamma, beta = torch.randn(C), torch.randn(C) * 0.2
+    a = ops.bn_act_fwd(x.view(-1, C), None, mean, invstd, gamma, beta, N * H * W, C, 1).view(N, H, W, C)
+    y, idx = ops.maxpool2d_fwd(a, N, H, W, C, 3, 2, 1)
+    dpool = torch.randn(y.shape).to(dtype)
+    rows = N * H * W
+    da = ops.maxpool2d_bwd(idx, dpool, N, H, W, C, 3, 2, 1)
+    sums0 = ops.bn_bwd_reduce(x.view(-1, C), da.view(-1, C), None, mean, invstd, gamma, beta, rows, C, 1)
+    dx0, _ = ops.bn_bwd_apply(x.view(-1, C), da.view(-1, C), None, mean, invstd, gamma, beta, sums0, 1.0 / rows, rows, C, 1, False)
+    sums1 = ops.bn_pool_bwd_reduce(x, dpool, idx, mean, invstd, gamma, beta, N, H, W, C, 3, 2, 1, 1)
+    dx1 = ops.bn_pool_bwd_apply(x, dpool, idx, mean, invstd, gamma, beta, sums1, 1.0 / rows, N, H, W, C, 3, 2, 1, 1)
+    # the three-pass path rounds the gathered gradient to the storage type before the BatchNorm passes; the fused one does not
+    tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
+
+    def relerr(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm())
+
+    assert relerr(sums1, sums0) < tol and relerr(dx1.float().view(-1, C), dx0.float()) < tol
+    if dtype == torch.float32:  # no intermediate rounding in either path: element-wise agreement
+        assert ((dx1.view(-1, C) - dx0).abs() <= 1e-4 * dx0.abs().clamp_min(1.0)).all()

@@ -279,4 +279,5 @@ def test_stem_fused_pool_switch_equivalence(emu_lib_path):
     (c0, a0, g0), (c1, a1, g1) = res
     assert abs(c0 - c1) < 1e-4 * abs(c0) and abs(a0 - a1) < 1e-4 * abs(a0)
     for k in g0:
-        assert rel(g1[k], g0[k]) < 1e-3 or float(g0[k].abs().max()) < 1e-7, k
+        # bf16 mode: the fused path skips one bf16 rounding of the stem's activation gradient
+        assert rel(g1[k], g0[k]) < 1e-2 or float(g0[k].abs().max()) < 1e-7, k
