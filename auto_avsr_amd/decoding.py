@@ -18,6 +18,8 @@ from typing import Any, Dict, List, NamedTuple, Optional
 import torch
 
 from . import ops
+from .ctc_prefix_score import CTCPrefixScore, CTCPrefixScoreTH
+from .scorer_interface import BatchPartialScorerInterface, BatchScorerInterface
 
 LOGZERO = -10000000000.0
 
@@ -49,7 +51,7 @@ def end_detect(ended_hyps, i, M=3, D_end=math.log(1 * math.exp(-10))):
     return count == M
 
 
-class LengthBonus:
+class LengthBonus(BatchScorerInterface):
     """scorers/length_bonus.py:10-59: a constant 1 per emitted token."""
 
     def __init__(self, n_vocab: int):
@@ -65,22 +67,61 @@ class LengthBonus:
         return torch.ones(1, dtype=x.dtype, device=x.device).expand(self.n), None
 
 
-class CTCPrefixScorer:
-    """scorers/ctc.py:10-157 in its batch form (batch_init_state / batch_score_partial / select_state) over
-    ctc_prefix_score.py:10-219, for one utterance.  State of a beam of n hypotheses: (r [T, 2, n], s [n]) = forward
-    variables of each prefix (ending in non-blank / blank) and its log prefix probability."""
+class CTCPrefixScorer(BatchPartialScorerInterface):
+    """scorers/ctc.py:10-157 over ctc_prefix_score.py, for one utterance.  Two state contracts are served:
+
+    * the tensor contract this build's BatchBeamSearch drives (batch_init_state returns the state of the empty
+      prefix; batch_score_partial takes / returns whole-beam tensors; select_states gathers the new beam) -- state of
+      a beam of n hypotheses: (r [T, 2, n], s [n]) = forward variables of each prefix (ending in non-blank / blank)
+      and its log prefix probability;
+    * the reference's own contract, for callers written against it (the reference's BeamSearch / BatchBeamSearch):
+      init_state / score_partial / select_state on the host form `CTCPrefixScore` (scorers/ctc.py:26-85) and
+      batch_score_partial on a LIST of per-hypothesis states through `self.impl` = `CTCPrefixScoreTH`
+      (scorers/ctc.py:87-126), selected by the type of `state`."""
 
     def __init__(self, ctc: torch.nn.Module, eos: int):
         self.ctc = ctc
         self.eos = eos
         self.blank = 0
         self.logp = None
+        self.impl = None
+
+    # -- reference contract, single hypothesis (scorers/ctc.py:26-85)
+    def init_state(self, x: torch.Tensor):
+        logp = self.ctc.log_softmax(x.unsqueeze(0)).detach().squeeze(0).float().cpu().numpy()
+        self.impl = CTCPrefixScore(logp, 0, self.eos)
+        return 0, self.impl.initial_state()
+
+    def select_state(self, state, i, new_id=None):
+        if type(state) == tuple:
+            if len(state) == 2:  # CTCPrefixScore: (scores, states) indexed by candidate
+                sc, st = state
+                return sc[i], st[i]
+            r, log_psi, f_min, f_max, scoring_idmap = state  # CTCPrefixScoreTH
+            s = log_psi[i, new_id].expand(log_psi.size(1))
+            col = scoring_idmap[i, new_id] if scoring_idmap is not None else new_id
+            return r[:, :, i, col], s, f_min, f_max
+        return None if state is None else state[i]
+
+    def score_partial(self, y, ids, state, x):
+        prev_score, st = state
+        presub, new_st = self.impl(y.cpu(), ids.cpu(), st)
+        return torch.as_tensor(presub - prev_score, device=x.device, dtype=x.dtype), (presub, new_st)
+
+    def extend_prob(self, x: torch.Tensor):
+        self.impl.extend_prob(self.ctc.log_softmax(x.unsqueeze(0)))
+
+    def extend_state(self, state):
+        return [self.impl.extend_state(s) for s in state]
 
     def batch_init_state(self, x: torch.Tensor):
         logp = self.ctc.log_softmax(x.unsqueeze(0)).detach().squeeze(0)  # (T, V[, pad])
         self.logp = logp.float().contiguous()
         self.T = logp.shape[0]
         self.odim = self.ctc.ctc_lo.out_features
+        # the reference's batch implementation object (scorers/ctc.py:96-98), for callers that use its list-of-states
+        # contract; shares nothing mutable with the tensor contract below
+        self.impl = CTCPrefixScoreTH(self.logp[:, : self.odim].unsqueeze(0), torch.tensor([self.T]), 0, self.eos)
         r0 = torch.full((self.T, 2, 1), LOGZERO, dtype=torch.float32, device=x.device)
         r0[:, 1, 0] = torch.cumsum(self.logp[:, self.blank], 0)  # only blanks so far
         return r0, torch.zeros(1, dtype=torch.float32, device=x.device)
@@ -89,6 +130,10 @@ class CTCPrefixScorer:
         """yseq [n, L] (sos first), ids [n, S] candidate tokens.  Returns (scores [n, V]: log psi(prefix + v) - log
         psi(prefix), LOGZERO outside the candidates / for blank, the complete-sequence probability for eos) and the
         state of every (hypothesis, candidate): (r_new [T, 2, n, S], log_psi [n, V], ids)."""
+        if state is None or isinstance(state, list):  # the reference's contract (scorers/ctc.py:101-126)
+            batch_state = None if (state is None or state[0] is None) else (
+                torch.stack([st[0] for st in state], dim=2), torch.stack([st[1] for st in state]), state[0][2], state[0][3])
+            return self.impl(yseq, batch_state, ids)
         r_prev, s_prev = state
         n, S = ids.shape
         dev = ids.device

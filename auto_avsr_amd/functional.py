@@ -96,7 +96,15 @@ _wconv = {}    # (data_ptr, to_dgrad, shape) -> [version, bf16 permuted copy, co
 _wconv_table = {"n": 0, "dev": None, "blocks": 0, "built_for": -1}
 
 
-_wgen = {"cleared": 0, "owner": None, "owner_gen": None}
+_wgen = {"cleared": 0, "owner": None, "owner_gen": None, "dirty": 0}
+
+
+def note_optimizer_step(linear_copies_rewritten: bool):
+    """Called by an optimizer that updates parameters through raw pointers (optim.FusedAdamW: `_version` is not bumped):
+    every cached bf16 copy it did not rewrite itself is stale from now on.  The next refresh_weight_cache() -- the explicit
+    one at the start of a training step, or the implicit one on the first weight access of a forward pass (eval / decoding
+    after native training) -- brings them up to date."""
+    _wgen["dirty"] = max(_wgen["dirty"], 1 if linear_copies_rewritten else 2)
 
 
 def _cast_generation():
@@ -135,6 +143,7 @@ def invalidate_weight_cache():
     _wconv.clear()
     _wgen["cleared"] += 1
     _wgen["owner"] = None
+    _wgen["dirty"] = 0
     _wtable.update(n=0, dev=None, blocks=0, built_for=-1)
     _wconv_table.update(n=0, dev=None, blocks=0, built_for=-1)
 
@@ -165,6 +174,8 @@ def _w_conv(w, to_dgrad):
     if _state["precise"] or w.dtype != torch.float32 or not w.is_contiguous():
         return ops.conv_weight_permute(w, act_dtype(), to_dgrad=to_dgrad)
     key = (w.data_ptr(), to_dgrad, tuple(w.shape))
+    if _wgen["dirty"]:
+        refresh_weight_cache()
     ent = _wconv.get(key)
     if ent is not None and ent[0] == w._version:
         return ent[1]
@@ -184,11 +195,12 @@ def refresh_weight_cache(force=False):
     after the optimizer changed the weights).  Falls back to lazy per-weight casts until weights are registered.
     force: re-cast even when an optimizer has claimed the copies (a weight was changed behind its back, e.g. by
     load_state_dict -- detected through the tensor version in _w_bf16)."""
+    dirty, _wgen["dirty"] = _wgen["dirty"], 0
     _refresh_conv_weights()
     if not _wcache:
         return
     owner = _wgen["owner"]() if _wgen["owner"] is not None else None
-    if not force and owner is not None and _wgen["owner_gen"] == _cast_generation():
+    if not force and dirty < 2 and owner is not None and _wgen["owner_gen"] == _cast_generation():
         return  # the optimizer step rewrote every copy together with the weights (optim.FusedAdamW cast_weights=True)
     if _wtable["built_for"] != len(_wcache):
         import struct
@@ -211,6 +223,8 @@ def refresh_weight_cache(force=False):
 
 def _w_bf16(w2d, transposed):
     key = (w2d.data_ptr(), transposed, tuple(w2d.shape))
+    if _wgen["dirty"]:
+        refresh_weight_cache()
     ver = w2d._version
     ent = _wcache.get(key)
     if ent is not None and ent[0] == ver:

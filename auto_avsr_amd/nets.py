@@ -14,6 +14,7 @@ import torch
 from torch import nn
 
 from . import functional as AF
+from .scorer_interface import BatchScorerInterface
 
 
 # ================================================================================================ building blocks
@@ -379,8 +380,8 @@ def _decoder_legacy_keys(state_dict, prefix, *_):
     _rename(state_dict, prefix + "output_norm.", prefix + "after_norm.")
 
 
-class TransformerDecoder(nn.Module):
-    """decoder/transformer_decoder.py:144-334.  Teacher-forced ``forward`` is the training hot path; the
+class TransformerDecoder(BatchScorerInterface, nn.Module):
+    """decoder/transformer_decoder.py:144-334 (a BatchScorerInterface like the reference's, :144).  Teacher-forced ``forward`` is the training hot path; the
     incremental scorer API (``forward_one_step`` / ``score`` / ``batch_score``) serves beam search."""
 
     def __init__(self, odim, attention_dim=256, attention_heads=4, linear_units=2048, num_blocks=6, dropout_rate=0.1,

@@ -128,6 +128,8 @@ class FusedAdamW:
         grads = [p.grad for p in self.params]
         if any(g is None for g in grads):
             raise RuntimeError("FusedAdamW.step(): every trainable parameter needs a gradient")
+        from . import functional as AF
+
         plan = self._plan() if self.cast_weights else None
         if plan is not None and plan[1] is None:
             plan = None
@@ -136,8 +138,8 @@ class FusedAdamW:
             ops.call("avsr_adamw_step", ops._ptr(table), n, blk, ops._ptr(partial), ops._ptr(self.state), self.lr,
                      self.betas[0], self.betas[1], self.eps, self.weight_decay, self.max_grad_norm, self.warmup_steps,
                      self.total_steps, ops._stream(table))
+            AF.note_optimizer_step(False)  # parameters changed behind `_version`: every cached bf16 copy is stale
             return
-        from . import functional as AF
 
         gen, _, lin, lin_blk, trow, tile_blk, _ = plan
         base = table.data_ptr()
@@ -146,6 +148,7 @@ class FusedAdamW:
                  ops._ptr(partial), ops._ptr(self.state), self.lr, self.betas[0], self.betas[1], self.eps,
                  self.weight_decay, self.max_grad_norm, self.warmup_steps, self.total_steps, ops._stream(table))
         AF.claim_weight_casts(self, gen)  # refresh_weight_cache() now has nothing to do for the Linear copies
+        AF.note_optimizer_step(True)      # ... but the conv-weight permutes are stale until it runs
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:

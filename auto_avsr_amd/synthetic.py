@@ -61,7 +61,11 @@ def make_batch(lengths, idxs, modality="video", odim=5049, seed=0, device="cpu")
 
 
 def rank_batches(batches, rank, world, seed=0):
-    """DistributedSampler-style assignment: seeded shuffle of the batch list, round-robin over ranks."""
+    """DistributedSampler-style assignment: seeded shuffle of the batch list, padded with its own head to a multiple of
+    `world` (so that EVERY rank gets the same number of batches -- a rank that ran out early would leave the others
+    waiting in the gradient all-reduce), round-robin over ranks."""
     g = torch.Generator().manual_seed(seed)
     perm = torch.randperm(len(batches), generator=g).tolist()
+    pad = (-len(perm)) % world
+    perm = perm + perm[:pad]
     return [batches[i] for i in perm[rank::world]]

@@ -1,9 +1,12 @@
 """Native training driver: one process per GPU (torchrun), torch.distributed over RCCL, no Lightning.
 
 Implements what the reference gets from `Trainer(sync_batchnorm=True, DDPStrategy(find_unused_parameters=False),
-gradient_clip_val=10.0)` + `ModelModule.training_step` + `configure_optimizers` (train.py:30-42,
-lightning.py:48-52,86-94): DDP gradient averaging, cross-rank BatchNorm statistics, the W / sum(B) loss rescale,
-global-norm clipping at 10, AdamW(0.9, 0.98) and the per-step warm-up cosine schedule, on the synthetic
+gradient_clip_val=10.0, callbacks=[ModelCheckpoint(save_top_k=10, save_last=True)])` + `ModelModule.training_step /
+validation_step / configure_optimizers` + `ensemble(args)` (train.py:17-50, lightning.py:48-52,86-114,
+average_checkpoints.py): DDP gradient averaging, cross-rank BatchNorm statistics, the W / sum(B) loss rescale, global-norm
+clipping at 10, AdamW(0.9, 0.98) with the per-step warm-up cosine schedule, a validation pass and an `epoch=N.ckpt`
+(Lightning layout: state_dict keys prefixed `model.`) per epoch with the ten newest kept, `last.ckpt` carrying the
+optimizer state for `--ckpt-path` resume, and the 10-checkpoint average `model_avg_10.pth` at the end -- on the synthetic
 LRS3-shaped workload (no dataset on the box)."""
 import os
 import time
@@ -12,11 +15,155 @@ import torch
 import torch.distributed as dist
 
 
+class _Hot(torch.nn.Module):
+    """forward_tensors() behind nn.Module.__call__ so that DDP's reducer hooks see the step."""
+
+    def __init__(self, m):
+        super().__init__()
+        self.m = m
+
+    def forward(self, x, lens, y):
+        return self.m.forward_tensors(x, lens, y)
+
+
+def save_checkpoint(folder, epoch, model, opt, global_step, keep=10):
+    """rank 0: `epoch=N.ckpt` in the layout average_checkpoints.py / lightning.py:44 read ({"state_dict": {"model.<key>"}}),
+    the `keep` newest kept (ModelCheckpoint(monitor="monitoring_step", mode="max", save_top_k=10): the monitored value
+    is the global step, so "top 10" = the ten latest), plus last.ckpt with the optimizer state."""
+    os.makedirs(folder, exist_ok=True)
+    sd = {"model." + k: v.detach().cpu() for k, v in model.state_dict().items()}
+    meta = {"epoch": epoch, "global_step": global_step}
+    torch.save({"state_dict": sd, **meta}, os.path.join(folder, f"epoch={epoch}.ckpt"))
+    torch.save({"state_dict": sd, "optimizer": opt.state_dict(), **meta}, os.path.join(folder, "last.ckpt"))
+    old = os.path.join(folder, f"epoch={epoch - keep}.ckpt")
+    if os.path.exists(old):
+        os.remove(old)
+
+
+def load_checkpoint(path, model, opt):
+    """--ckpt-path resume (train.py:49 `trainer.fit(..., ckpt_path=...)`): weights, optimizer state, position."""
+    from . import functional as AF
+
+    ck = torch.load(path, map_location="cpu")
+    model.load_state_dict({k[len("model."):]: v for k, v in ck["state_dict"].items() if k.startswith("model.")})
+    if "optimizer" in ck:
+        opt.load_state_dict(ck["optimizer"])
+    AF.invalidate_weight_cache()  # every cached bf16 copy belongs to the old weights
+    return int(ck.get("epoch", -1)) + 1, int(ck.get("global_step", 0))
+
+
+@torch.no_grad()
+def validate(model, batches, world):
+    """ModelModule.validation_step over the val batches (lightning.py:95-96,104-113): eval-mode forward, metrics averaged
+    over batches and ranks."""
+    was_training = model.training
+    model.eval()
+    tot = torch.zeros(5, device=batches[0][0].device) if batches else None
+    for x, lens, y, _ in batches:
+        loss, loss_ctc, loss_att, hits, ntok = model.forward_tensors(x, lens, y)
+        tot += torch.stack([loss, loss_ctc, loss_att, hits / ntok.clamp_min(1), torch.ones_like(loss)])
+    model.train(was_training)
+    if tot is None:
+        return None
+    if world > 1:
+        dist.all_reduce(tot)
+    n = float(tot[4])
+    return {"loss_val": float(tot[0]) / n, "loss_ctc_val": float(tot[1]) / n, "loss_att_val": float(tot[2]) / n,
+            "decoder_acc_val": float(tot[3]) / n}
+
+
+def fit(model, args, dev, rank=0, world=1, backend="nccl", log=print):
+    """The training loop proper, on an already constructed `E2E`-like model (tests run it on a small instance over
+    gloo + the emulator).  Returns the list of per-step losses of this rank."""
+    from . import functional as AF
+    from .optim import FusedAdamW
+    from .synthetic import bucket_batches, make_batch, rank_batches, utterance_lengths
+
+    AF.manual_seed(42 + rank)
+    seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+    AF.set_seed_tensor(seed_dev)
+    hot = _Hot(model)
+    if world > 1:
+        AF.set_bn_sync(dist.group.WORLD)
+        hot = torch.nn.parallel.DistributedDataParallel(
+            hot, device_ids=[dev.index] if dev.type == "cuda" else None, find_unused_parameters=False,
+            broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=64)
+    lengths = utterance_lengths(getattr(args, "synthetic_utterances", 0) or 20000)
+    all_batches = bucket_batches(lengths, args.max_frames, args.train_num_buckets)
+    # every rank sees the same number of batches per epoch (DistributedSampler pads): the schedule lengths below and the
+    # number of collectives per epoch are identical on all ranks
+    steps_per_epoch = (len(all_batches) + world - 1) // world
+    # lightning.py:48-52 + train.py:41 + cosine.py as one fused multi-tensor step (optim.py): AdamW(.9/.98), clip 10,
+    # per-step warm-up cosine; step count / lr / gradient norm stay on the device
+    opt = FusedAdamW(model.parameters(), lr=args.lr, betas=(0.9, 0.98), weight_decay=args.weight_decay, max_grad_norm=10.0,
+                     warmup_steps=args.warmup_epochs * steps_per_epoch, total_steps=args.max_epochs * steps_per_epoch,
+                     cast_weights=dev.type == "cuda")
+    folder = os.path.join(args.exp_dir, args.exp_name) if getattr(args, "exp_dir", None) else None
+    start_epoch, global_step = 0, 0
+    if getattr(args, "ckpt_path", None):
+        start_epoch, global_step = load_checkpoint(args.ckpt_path, model, opt)
+        seed_dev.add_(global_step)  # dropout masks are a function of (rank, global step, site): a resumed run continues them
+    n_val = getattr(args, "val_batches", 0) or 0
+    val_lengths = utterance_lengths(2000, seed=43)
+    val_all = bucket_batches(val_lengths, 1000, 1)  # val_dataloader: max_frames 1000, one bucket (data_module.py:156-158)
+    val = [make_batch(val_lengths, b, args.modality, model.odim, seed=10_000 + i, device=dev)
+           for i, b in enumerate(rank_batches(val_all, rank, world, seed=1)[:n_val])]
+    max_steps = getattr(args, "steps", None)
+    losses = []
+    t0 = time.time()
+    done = False
+    for epoch in range(start_epoch, args.max_epochs):
+        # reload_dataloaders_every_n_epochs=1 + shuffle=True (train.py:39, data_module.py:140): a new order every epoch
+        batches = rank_batches(all_batches, rank, world, seed=epoch)
+        assert len(batches) == steps_per_epoch
+        for bi, idxs in enumerate(batches):
+            x, lens, y, frames = make_batch(lengths, idxs, args.modality, model.odim, seed=global_step, device=dev)
+            seed_dev.add_(1)
+            AF.manual_seed(42 + rank)  # restart the per-site counter: mask = f(rank, site index, seed_dev = global step)
+            AF.new_step()
+            AF.refresh_weight_cache()  # conv-weight permutes; the Linear copies were rewritten by the optimizer step itself
+            loss, loss_ctc, loss_att, hits, ntok = hot(x, lens, y)
+            if world > 1:
+                bs = torch.tensor([float(x.shape[0])], device=dev)
+                allb = torch.empty(world, device=dev)
+                dist.all_gather_into_tensor(allb, bs)
+                loss = loss * (world / allb.sum())  # lightning.py:88-90
+            loss.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            global_step += 1
+            every = getattr(args, "log_every", 10)
+            if every and ((global_step - 1) % every == 0 or global_step == max_steps):
+                losses.append(float(loss.detach()))
+                if rank == 0:
+                    log(f"epoch {epoch} step {global_step} loss {losses[-1]:.4f} ctc {float(loss_ctc.detach()):.4f} att "
+                        f"{float(loss_att.detach()):.4f} acc {float(hits) / max(float(ntok), 1):.4f} lr {opt.last_lr:.2e} gnorm "
+                        f"{opt.last_grad_norm:.2f} ({time.time() - t0:.1f}s)")
+            if max_steps and global_step >= max_steps:
+                done = True
+                break
+        if done and bi + 1 < len(batches):
+            break  # stopped inside an epoch (--steps): no end-of-epoch work
+        metrics = validate(model, val, world)
+        if rank == 0 and metrics:
+            log(f"epoch {epoch} validation: " + " ".join(f"{k} {v:.4f}" for k, v in metrics.items()))
+        if rank == 0 and folder:
+            save_checkpoint(folder, epoch, model, opt, global_step)
+        if world > 1:
+            dist.barrier()
+        if done:
+            break
+    else:
+        if rank == 0 and folder and args.max_epochs >= 10:
+            from average_checkpoints import ensemble
+
+            log(f"averaged checkpoint: {ensemble(args)}")
+    AF.set_bn_sync(None)
+    return losses
+
+
 def run(args):
     from lightning import ModelModule
-
-    from . import functional as AF
-    from .synthetic import bucket_batches, make_batch, rank_batches, utterance_lengths
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -25,55 +172,8 @@ def run(args):
     dev = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
-        AF.set_bn_sync(dist.group.WORLD)
     torch.manual_seed(42)
     module = ModelModule(args).to(dev).train()
-    model = module.model
-    AF.manual_seed(42 + rank)
-    seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
-    AF.set_seed_tensor(seed_dev)
-
-    class Hot(torch.nn.Module):
-        def __init__(self, m):
-            super().__init__()
-            self.m = m
-
-        def forward(self, x, lens, y):
-            return self.m.forward_tensors(x, lens, y)
-
-    hot = Hot(model)
-    if world > 1:
-        hot = torch.nn.parallel.DistributedDataParallel(hot, device_ids=[local], find_unused_parameters=False,
-                                                        broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=64)
-    lengths = utterance_lengths()
-    batches = rank_batches(bucket_batches(lengths, args.max_frames, args.train_num_buckets), rank, world, seed=0)
-    # lightning.py:48-52 + train.py:41 + cosine.py as one fused multi-tensor step (optim.py): AdamW(.9/.98), clip 10,
-    # per-step warm-up cosine; step count / lr / gradient norm stay on the device
-    from .optim import FusedAdamW
-
-    opt = FusedAdamW(model.parameters(), lr=args.lr, betas=(0.9, 0.98), weight_decay=args.weight_decay, max_grad_norm=10.0,
-                     warmup_steps=args.warmup_epochs * len(batches), total_steps=args.max_epochs * len(batches),
-                     cast_weights=True)
-    total = args.steps or args.max_epochs * len(batches)
-    t0 = time.time()
-    for step in range(total):
-        x, lens, y, frames = make_batch(lengths, batches[step % len(batches)], args.modality, model.odim, seed=step,
-                                        device=dev)
-        seed_dev.add_(1)
-        AF.new_step()
-        AF.refresh_weight_cache()  # conv-weight permutes; the Linear copies were rewritten by the optimizer step itself
-        loss, loss_ctc, loss_att, hits, ntok = hot(x, lens, y)
-        if world > 1:
-            bs = torch.tensor([float(x.shape[0])], device=dev)
-            allb = torch.empty(world, device=dev)
-            dist.all_gather_into_tensor(allb, bs)
-            loss = loss * (world / allb.sum())
-        loss.backward()
-        opt.step()
-        opt.zero_grad(set_to_none=True)
-        if rank == 0 and (step % 10 == 0 or step == total - 1):
-            print(f"step {step} loss {float(loss):.4f} ctc {float(loss_ctc):.4f} att {float(loss_att):.4f} "
-                  f"acc {float(hits) / max(float(ntok), 1):.4f} lr {opt.last_lr:.2e} gnorm {opt.last_grad_norm:.2f} "
-                  f"({time.time() - t0:.1f}s)", flush=True)
+    fit(module.model, args, dev, rank, world)
     if world > 1:
         dist.destroy_process_group()

@@ -16,9 +16,11 @@ decoder's layout (uint8 [T, H, W, 3]; the reference's load_video returns the [T,
 and are uploaded as bytes: 3 B per pixel cross PCIe instead of the 4 B per pixel of a CPU-transformed f32 tensor.
 There is no CPU implementation here: without libavsr_hip.so the calls raise (tests use the emulator build of the same
 kernels)."""
+import os
 import random
 
 import numpy as np
+
 import torch
 
 from . import ops
@@ -197,14 +199,39 @@ class VideoTransform:
         return out[0]
 
 
+NOISE_FILENAME = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "datamodule", "babble_noise.wav")
+
+
+def load_default_noise():
+    """The reference's babble recording (datamodule/transforms.py:21-24: `babble_noise.wav` next to the module), read
+    with the standard library: [1, n] f32 in [-1, 1).  The file is data, not code -- it is not part of this repository."""
+    import wave
+
+    import numpy as np
+
+    if not os.path.exists(NOISE_FILENAME):
+        raise FileNotFoundError(
+            f"{NOISE_FILENAME} not found: AudioTransform needs the reference's babble noise recording for training-time / "
+            "SNR-targeted augmentation -- copy it there, pass noise=<[1, n] tensor>, or pass noise=False to train without "
+            "additive noise (NOT the reference's recipe)")
+    with wave.open(NOISE_FILENAME, "rb") as f:
+        assert f.getframerate() == 16000 and f.getsampwidth() == 2
+        pcm = np.frombuffer(f.readframes(f.getnframes()), dtype="<i2").reshape(-1, f.getnchannels())
+    return torch.from_numpy(pcm[:, 0].astype(np.float32) / 32768.0).unsqueeze(0)
+
+
 class AudioTransform:
-    """transforms.py:113-136 on one waveform: [T, 1] f32 (load_audio) -> [T, 1] f32."""
+    """transforms.py:113-136 on one waveform: [T, 1] f32 (load_audio) -> [T, 1] f32.
+    noise: [1, n] babble recording; None = load the reference's default file (raises if it is absent -- the reference
+    always adds noise in training, transforms.py:116-118); False = explicitly no additive noise."""
 
     def __init__(self, subset, snr_target=None, noise=None):
         assert subset in ("train", "val", "test")
         self.subset = subset
         self.add_noise = None
-        if noise is not None and (subset == "train" or snr_target is not None):
+        if noise is not False and (subset == "train" or snr_target is not None):
+            if noise is None:
+                noise = load_default_noise()
             self.add_noise = AddNoise(noise=noise, snr_target=None if subset == "train" else snr_target)
 
     def __call__(self, sample):

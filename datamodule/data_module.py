@@ -1,10 +1,18 @@
-"""Batch formation of the reference (datamodule/data_module.py:10-106) without its file I/O: ``pad`` /
-``collate_pad`` and the length-bucketed, frame-budgeted batching.  The LightningDataModule wrapper and the
-mp4 / wav readers need pytorch_lightning, torchvision and torchaudio and are out of the hot-path scope; the
-synthetic generator used for measurement lives in auto_avsr_amd/synthetic.py."""
+"""Batch formation of the reference (datamodule/data_module.py:10-182): ``pad`` / ``collate_pad``, the length-bucketed,
+frame-budgeted ``CustomBucketDataset`` and the ``DataModule`` that hands train / val / test loaders to the trainer.
+With pytorch_lightning installed ``DataModule`` is a LightningDataModule (what train.py / eval.py pass to the Trainer);
+without it the same class is a plain object with the same three loader methods (auto_avsr_amd.train_native / eval.py call
+them directly).  File decoding lives in datamodule/av_dataset.py; the synthetic generator in auto_avsr_amd/synthetic.py."""
+import os
+
 import torch
 
 from auto_avsr_amd.synthetic import bucket_batches
+
+try:  # optional third-party harness (absent in the build image)
+    from pytorch_lightning import LightningDataModule as _DMBase
+except ImportError:  # pragma: no cover - exercised in this image
+    _DMBase = object
 
 
 def pad(samples, pad_val=0.0):
@@ -44,3 +52,50 @@ class CustomBucketDataset(torch.utils.data.Dataset):
 
     def __len__(self):
         return len(self.batches)
+
+
+class DataModule(_DMBase):
+    """data_module.py:109-182: train / val loaders yield pre-formed, padded batches (`batch_size=None`: one dataset item
+    IS a batch), the test loader yields single utterances.  `args.synthetic_utterances = n` (an extra of this build)
+    replaces the file-backed AVDataset by n synthetic utterances."""
+
+    def __init__(self, args=None, batch_size=None, train_num_buckets=50, train_shuffle=True, num_workers=10):
+        super().__init__()
+        self.args = args
+        self.batch_size = batch_size
+        self.train_num_buckets = train_num_buckets
+        self.train_shuffle = train_shuffle
+        self.num_workers = num_workers
+
+    def _dataset(self, subset, label_file):
+        from .av_dataset import AVDataset, SyntheticAVDataset
+        from .transforms import AudioTransform, VideoTransform
+
+        n_syn = getattr(self.args, "synthetic_utterances", 0)
+        if n_syn:
+            return SyntheticAVDataset(n_syn, self.args.modality, seed={"train": 0, "val": 1, "test": 2}[subset])
+        if subset == "test":
+            at = AudioTransform("test", snr_target=getattr(self.args, "decode_snr_target", 999999))
+        else:
+            at = AudioTransform(subset)
+        return AVDataset(root_dir=self.args.root_dir, label_path=os.path.join(self.args.root_dir, "labels", label_file),
+                         subset=subset, modality=self.args.modality, audio_transform=at,
+                         video_transform=VideoTransform(subset))
+
+    def _workers(self):
+        return 0 if getattr(self.args, "synthetic_utterances", 0) else self.num_workers
+
+    def train_dataloader(self):
+        ds = self._dataset("train", self.args.train_file)
+        ds = CustomBucketDataset(ds, ds.input_lengths, self.args.max_frames, self.train_num_buckets,
+                                 batch_size=self.batch_size)
+        return torch.utils.data.DataLoader(ds, num_workers=self._workers(), batch_size=None, shuffle=self.train_shuffle,
+                                           collate_fn=collate_pad)
+
+    def val_dataloader(self):
+        ds = self._dataset("val", self.args.val_file)
+        ds = CustomBucketDataset(ds, ds.input_lengths, 1000, 1, batch_size=self.batch_size)
+        return torch.utils.data.DataLoader(ds, batch_size=None, num_workers=self._workers(), collate_fn=collate_pad)
+
+    def test_dataloader(self):
+        return torch.utils.data.DataLoader(self._dataset("test", self.args.test_file), batch_size=None)

@@ -1,8 +1,13 @@
-"""Evaluation entry point with the reference's command line (eval.py:25-64): loads a checkpoint into ModelModule and
-decodes with the hybrid CTC / attention beam search (auto_avsr_amd/decoding.py).  The reference iterates an LRS3 test
-set through Lightning's Trainer.test; datasets and pytorch_lightning are not part of this image, so without them this
-entry point decodes `--demo-frames` synthetic frames (plumbing check, BASELINE.json configs[0]) and prints the
-hypothesis; with a DataModule available the WER loop is ModelModule.on_test_epoch_start / test_step / on_test_epoch_end."""
+"""Evaluation entry point with the reference's command line (eval.py:25-79): loads a checkpoint into ModelModule and
+runs the WER loop -- hybrid CTC / attention beam search per utterance (auto_avsr_amd/decoding.py), word-level edit
+distance against the reference transcript, WER = total distance / total words (lightning.py:69-84,116-123).
+
+With pytorch_lightning installed the loop is driven by `Trainer.test(model, datamodule)` exactly as in the reference.
+Without it (this image) the same three hooks -- on_test_epoch_start / test_step / on_test_epoch_end -- are called
+directly over `DataModule.test_dataloader()`.  `--root-dir` selects the reference's on-disk test set; without it the
+loader yields `--synthetic-utterances` LRS3-shaped synthetic utterances (plumbing check: random targets, so the WER of an
+untrained model is ~1; BASELINE.json configs[0])."""
+import logging
 from argparse import ArgumentParser
 
 
@@ -14,27 +19,61 @@ def parse_args(argv=None):
     p.add_argument("--pretrained-model-path", type=str, default=None)
     p.add_argument("--decode-snr-target", type=float, default=999999)
     p.add_argument("--debug", action="store_true")
-    p.add_argument("--demo-frames", type=int, default=50, help="synthetic clip length when no dataset is given")
+    # extras of this build (not in the reference)
+    p.add_argument("--synthetic-utterances", type=int, default=0,
+                   help="decode this many synthetic utterances instead of a dataset (default when --root-dir is absent: 4)")
+    p.add_argument("--max-test-frames", type=int, default=100, help="length cap of the synthetic utterances")
     return p.parse_args(argv)
+
+
+def run_test_loop(module, loader, device, log=None):
+    """Trainer.test without Lightning: the module's own hooks over the loader (lightning.py:69-84,116-123)."""
+    import torch
+
+    module.on_test_epoch_start()
+    with torch.no_grad():
+        for i, sample in enumerate(loader):
+            sample = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in sample.items()}
+            module.test_step(sample, i)
+            if log is not None:
+                log(i, module.total_edit_distance, module.total_length)
+    return module.on_test_epoch_end()
 
 
 def cli_main(argv=None):
     import torch
 
-    from lightning import ModelModule
+    from datamodule.data_module import DataModule
+    from lightning import HAVE_LIGHTNING, ModelModule
 
     args = parse_args(argv)
+    logging.basicConfig(format="%(asctime)s %(message)s" if args.debug else "%(message)s",
+                        level=logging.DEBUG if args.debug else logging.INFO, datefmt="%Y-%m-%d %H:%M:%S")
     if not torch.cuda.is_available():
         raise SystemExit("eval.py needs an MI355X: the model runs on libavsr_hip.so only (no CPU path)")
-    module = ModelModule(args).cuda().eval()
-    if args.root_dir is not None:
-        raise SystemExit("eval.py: dataset iteration needs the reference DataModule (torchaudio / torchvision / "
-                         "pytorch_lightning), which this image does not have; ModelModule.test_step implements the WER loop")
-    T = args.demo_frames
-    sample = torch.randn(T, 1, 88, 88, device="cuda") if args.modality == "video" else torch.randn(T * 640, 1, device="cuda")
-    with torch.no_grad():
-        text = module(sample)
-    print(f"hypothesis ({T} synthetic frames, random weights unless --pretrained-model-path): {text!r}")
+    if args.root_dir is None and not args.synthetic_utterances:
+        args.synthetic_utterances = 4
+    module = ModelModule(args)
+    datamodule = DataModule(args)
+    if HAVE_LIGHTNING and not args.synthetic_utterances:
+        from pytorch_lightning import Trainer
+
+        Trainer(num_nodes=1, devices=1, accelerator="gpu").test(model=module, datamodule=datamodule)
+        return
+    module = module.cuda().eval()
+    if args.synthetic_utterances:
+        from auto_avsr_amd.synthetic import utterance_lengths
+        from datamodule.av_dataset import SyntheticAVDataset
+
+        lens = [min(int(t), args.max_test_frames) for t in utterance_lengths(args.synthetic_utterances, seed=7)]
+        loader = torch.utils.data.DataLoader(
+            SyntheticAVDataset(len(lens), args.modality, odim=module.model.odim, seed=2, lengths=lens), batch_size=None)
+    else:
+        loader = datamodule.test_dataloader()
+    wer = run_test_loop(module, loader, torch.device("cuda"),
+                        log=lambda i, d, n: logging.info(f"utt {i}: running WER {d / max(n, 1):.4f} ({d}/{n} words)"))
+    print(f"WER {wer:.4f} over {module.total_length} reference words")
+    return wer
 
 
 if __name__ == "__main__":

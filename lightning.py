@@ -57,6 +57,24 @@ class ModelModule(_Base):
         self.model = E2E(len(self.token_list), self.modality, ctc_weight=getattr(args, "ctc_weight", 0.1))
         load_pretrained(self.model, args)
 
+    # ---- cross-rank BatchNorm (train.py:31 `sync_batchnorm=True`)
+    def on_fit_start(self):
+        """Lightning's `sync_batchnorm=True` swaps nn.BatchNorm modules for torch.nn.SyncBatchNorm, whose forward this
+        build never calls (BatchNorm runs inside the fused HIP functions on the modules' parameters / buffers).  The
+        cross-rank statistics are therefore switched on here, on the kernels' own path (functional.set_bn_sync: one
+        all-gather per BatchNorm forward, one all-reduce per backward over RCCL)."""
+        import torch.distributed as dist
+
+        from auto_avsr_amd import functional as AF
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            AF.set_bn_sync(dist.group.WORLD)
+
+    def on_fit_end(self):
+        from auto_avsr_amd import functional as AF
+
+        AF.set_bn_sync(None)
+
     # ---- optimisation (lightning.py:48-52): AdamW(betas .9/.98) + per-step warm-up cosine
     def make_optimizer(self, steps_per_epoch):
         opt = torch.optim.AdamW(self.model.parameters(), lr=self.args.lr, weight_decay=self.args.weight_decay,

@@ -133,15 +133,10 @@ def test_batchnorm_two_rank_merge(dev):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
-def test_bn_act_pool_fused_matches_two_pass(emu_lib_path, dtype):
+def test_bn_act_pool_fused_matches_two_pass(dev, dtype):
     """maxpool(SiLU(bn(x))) in one pass (video stem) vs bn_act_fwd followed by maxpool2d_fwd: same pooled values (to one
     rounding of the storage type -- the two kernels may contract the affine map differently) and an argmax that points
-    at a maximal element of its window.  Emulator build only: the kernel is switched off in the product until it has been
-    run on the MI355X (then this test moves to the `dev` fixture like its neighbours)."""
-    from auto_avsr_amd import _lib
-
-    _lib._install_for_tests(emu_lib_path)
-    dev = "cpu"
+    at a maximal element of its window."""
     torch.manual_seed(9)
     N, H, W, C = 3, 11, 14, 64
     x = (torch.randn(N, H, W, C) * 2).to(dtype).to(dev)
@@ -168,21 +163,17 @@ def test_bn_act_pool_fused_matches_two_pass(emu_lib_path, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
-def test_bn_pool_bwd_fused_matches_three_pass(emu_lib_path, dtype):
+def test_bn_pool_bwd_fused_matches_three_pass(dev, dtype):
     """Backward of maxpool(SiLU(bn(x))) with the activation gradient gathered from the pooled gradient inside the two
-    BatchNorm backward passes vs maxpool2d_bwd -> bn_bwd_reduce -> bn_bwd_apply.  Emulator build only (the path is
-    switched off in the product until it has been run on the MI355X)."""
-    from auto_avsr_amd import _lib
-
-    _lib._install_for_tests(emu_lib_path)
+    BatchNorm backward passes vs maxpool2d_bwd -> bn_bwd_reduce -> bn_bwd_apply."""
     torch.manual_seed(10)
     N, H, W, C = 2, 9, 12, 64
-    x = (torch.randn(N, H, W, C) * 2).to(dtype)
-    mean, invstd = torch.randn(C) * 0.3, torch.rand(C) + 0.5
-    gamma, beta = torch.randn(C), torch.randn(C) * 0.2
+    x = (torch.randn(N, H, W, C) * 2).to(dtype).to(dev)
+    mean, invstd = (torch.randn(C) * 0.3).to(dev), (torch.rand(C) + 0.5).to(dev)
+    gamma, beta = torch.randn(C).to(dev), (torch.randn(C) * 0.2).to(dev)
     a = ops.bn_act_fwd(x.view(-1, C), None, mean, invstd, gamma, beta, N * H * W, C, 1).view(N, H, W, C)
     y, idx = ops.maxpool2d_fwd(a, N, H, W, C, 3, 2, 1)
-    dpool = torch.randn(y.shape).to(dtype)
+    dpool = torch.randn(y.shape).to(dtype).to(dev)
     rows = N * H * W
     da = ops.maxpool2d_bwd(idx, dpool, N, H, W, C, 3, 2, 1)
     sums0 = ops.bn_bwd_reduce(x.view(-1, C), da.view(-1, C), None, mean, invstd, gamma, beta, rows, C, 1)

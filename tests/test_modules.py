@@ -250,12 +250,9 @@ def test_linear_padded_head_f32_grad_bf16_mode(dev):
         AF.set_precise(was_precise)
 
 
-def test_stem_fused_pool_switch_equivalence(emu_lib_path):
-    """AVSR_FUSE_STEM_POOL (BN + SiLU + max-pool of the video stem in one pass; off by default until it has been run on
-    the MI355X): same losses and gradients as the two-pass path, bf16 mode, emulator build."""
-    from auto_avsr_amd import _lib
-
-    _lib._install_for_tests(emu_lib_path)
+def test_stem_fused_pool_switch_equivalence(dev):
+    """AVSR_FUSE_STEM_POOL (BN + SiLU + max-pool of the video stem in one pass): same losses and gradients as the two-pass
+    path, bf16 mode."""
     was_precise, was_fused = AF._state["precise"], AF._FUSE_STEM_POOL
     odim = 40
     res = []
@@ -267,11 +264,11 @@ def test_stem_fused_pool_switch_equivalence(emu_lib_path):
             torch.manual_seed(0)
             m = no_dropout(E2E(odim, "video", adim=64, aheads=1, eunits=64, elayers=1, dunits=64, dlayers=1, cnn_module_kernel=7))
             m.load_state_dict(synth_state_dict(m.state_dict(), 3), strict=True)
-            m.train()
-            x, lengths, y = synth_batch("video", 2, 7, 3, odim, seed=2)
+            m.to(dev).train()
+            x, lengths, y = (t.to(dev) for t in synth_batch("video", 2, 7, 3, odim, seed=2))
             loss, loss_ctc, loss_att, _ = m(x, lengths, y)
             loss.backward()
-            res.append((float(loss_ctc), float(loss_att), {k: p.grad.clone() for k, p in m.named_parameters()}))
+            res.append((float(loss_ctc), float(loss_att), {k: p.grad.cpu().clone() for k, p in m.named_parameters()}))
     finally:
         AF._FUSE_STEM_POOL = was_fused
         AF.set_precise(was_precise)

@@ -34,6 +34,8 @@ def parse_args(argv=None):
     # native-driver extras (not in the reference)
     p.add_argument("--synthetic", action="store_true", help="train on the synthetic LRS3-shaped workload")
     p.add_argument("--steps", default=None, type=int, help="stop after this many optimizer steps")
+    p.add_argument("--val-batches", default=8, type=int, help="synthetic validation batches per rank and epoch")
+    p.add_argument("--synthetic-utterances", default=0, type=int, help="size of the synthetic corpus (default 20000)")
     return p.parse_args(argv)
 
 
@@ -59,7 +61,7 @@ def cli_main(argv=None):
 
     if HAVE_LIGHTNING and not args.synthetic:
         from average_checkpoints import ensemble
-        from datamodule.data_module import DataModule  # needs the reference's data stack
+        from datamodule.data_module import DataModule  # file-backed AVDataset: needs torchvision / torchaudio at read time
 
         module = ModelModule(args)
         trainer = get_trainer(args)
