@@ -36,7 +36,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_fast_kernel(Params p) {
 template <int BM, int BN, int STAGES, int CV = 0, int WGM = 2, int WGN = 2, int ABL = 0>
 void launch_fast(Params& p, int split_k, hipStream_t stream) {
     using K = FastKernel<BM, BN, STAGES, CV, WGM, WGN, ABL>;
-    p.xcd_order = g_tune[1];
+    // XCD-aware tile order (knob 1: 0 = automatic, 1 = on, 2 = off).  Automatic: on for the 64x64 GEMM tile -- measured
+    // with operands that are NOT cache-resident (tools/microbench_xcd.py: A written by the previous kernel, weights
+    // streamed from HBM, as in the training step): every XCD otherwise pulls the whole problem through its own L2
+    // (rocprofv3 FETCH_SIZE ~8x the operand bytes); 1500x768x768 10.5 -> 9.4 us, 1500x768x3072 28.5 -> 22.6 us.
+    // Neutral-to-slower for the 128-row tiles with wide N and for operands that sit in the Infinity Cache.
+    p.xcd_order = g_tune[1] == 0 ? (CV == 0 && BM == 64 && BN == 64) : (g_tune[1] == 1);
     int gy;
     if (CV == 0) {
         int kc = (p.K + split_k - 1) / split_k;
@@ -61,6 +66,7 @@ void launch_fast(Params& p, int split_k, hipStream_t stream) {
 // tile codes shared by the GEMM and convolution entry points
 //   1 = 64x64 (3 stages, 4 waves)   2 = 128x64   3 = 128x128   4 = 128x128 with 2 stages (2 blocks per CU)
 //   5 = 256x128, 8 waves of 64x64   6 = 256x128, 4 waves of 128x64   7 = 128x64 with 2 stages   8 = 256x64, 8 waves
+//   9 / 10 = 64x64 with 5 / 8 stages   11 / 12 = 128x64 with 4 / 6 stages   13 = 128x128 with 4 stages (plain GEMM only)
 template <int CV>
 bool launch_tile(int tile, Params& p, int split_k, hipStream_t stream) {
     switch (tile) {
@@ -76,6 +82,15 @@ bool launch_tile(int tile, Params& p, int split_k, hipStream_t stream) {
         case 6: launch_fast<256, 128, 3, CV, 2, 2>(p, split_k, stream); return true;
         case 7: launch_fast<128, 64, 2, CV>(p, split_k, stream); return true;
         case 8: launch_fast<256, 64, 3, CV, 4, 2>(p, split_k, stream); return true;
+        // deeper rings for the skinny M = B*T GEMMs (one block per CU anyway: bytes in flight per CU = ring depth)
+        case 9: if (CV == 0) { launch_fast<64, 64, 5, 0>(p, split_k, stream); return true; } return false;
+        case 10: if (CV == 0) { launch_fast<64, 64, 8, 0>(p, split_k, stream); return true; } return false;
+        case 11: if (CV == 0) { launch_fast<128, 64, 4, 0>(p, split_k, stream); return true; } return false;
+        case 12: if (CV == 0) { launch_fast<128, 64, 6, 0>(p, split_k, stream); return true; } return false;
+        case 13: if (CV == 0) { launch_fast<128, 128, 4, 0>(p, split_k, stream); return true; } return false;
+        // ablations of the 64x64 GEMM tile (benchmarks only): 14 = no LDS reads / MFMA, 15 = no operand loads after the prologue
+        case 14: if (CV == 0) { launch_fast<64, 64, 3, 0, 2, 2, 1>(p, split_k, stream); return true; } return false;
+        case 15: if (CV == 0) { launch_fast<64, 64, 3, 0, 2, 2, 2>(p, split_k, stream); return true; } return false;
         default: return false;
     }
 }

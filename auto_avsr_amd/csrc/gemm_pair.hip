@@ -65,7 +65,7 @@ bool stash_nt(const Params& p, int tile, int split_k, hipStream_t stream) {
     if (!s.active || s.have_nt || split_k > 1 || p.accumulate || (tile != 1 && tile != 7)) return false;
     if (s.have_tn && s.stream != stream) return false;
     s.nt = p;
-    s.nt.xcd_order = 0;
+    s.nt.xcd_order = (tile == 1 && avsr_tune_knobs[1] != 2) ? 1 : 0;  // NT blocks are blocks [0, na) of the pair grid: id % 8 still names the XCD
     s.nt.k_chunk = ((p.K + 63) / 64) * 64;
     s.nt_tile = tile;
     const int BM = tile == 1 ? 64 : 128;

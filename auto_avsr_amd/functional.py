@@ -99,6 +99,11 @@ _wconv_table = {"n": 0, "dev": None, "blocks": 0, "built_for": -1}
 _wgen = {"cleared": 0, "owner": None, "owner_gen": None, "dirty": 0}
 
 
+def cached_weight_ptrs():
+    """(generation, addresses of every parameter that has a cached bf16 copy: Linear-type, conv-type)."""
+    return (_wgen["cleared"], len(_wcache), len(_wconv)), {k[0] for k in _wcache}, {k[0] for k in _wconv}
+
+
 def note_optimizer_step(linear_copies_rewritten: bool):
     """Called by an optimizer that updates parameters through raw pointers (optim.FusedAdamW: `_version` is not bumped):
     every cached bf16 copy it did not rewrite itself is stale from now on.  The next refresh_weight_cache() -- the explicit

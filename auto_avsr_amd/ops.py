@@ -52,17 +52,24 @@ PROFILE = None  # bench.py: list collecting (entry point, start event, end event
 RECORD = None   # bench.py: (entry point, list) -- the argument tuples of every launch of that entry point
 
 
-def call(name, *args, flops=0.0):
-    if RECORD is not None and name == RECORD[0]:
-        RECORD[1].append((args, flops))
+def call(name, *args, flops=0.0, nbytes=0.0):
+    """flops / nbytes: ALGORITHMIC work of the launch (2 * MACs; every operand read once + every result written once),
+    recorded by bench.py's roofline hooks."""
+    if RECORD is not None and name in RECORD[0]:
+        RECORD[1].append((name, args, flops, nbytes))
     if PROFILE is None:
         return _lib.lib().call(name, *args)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     rc = _lib.lib().call(name, *args)
     e1.record()
-    PROFILE.append((name, e0, e1, flops))
+    PROFILE.append((name, e0, e1, flops, nbytes))
     return rc
+
+
+def _nb(*ts):
+    """Bytes of the given tensors (None entries skipped)."""
+    return float(sum(t.numel() * t.element_size() for t in ts if t is not None))
 
 
 PAIR_GEMMS = os.environ.get("AVSR_PAIR_GEMMS", "1") != "0"  # A/B switch for the paired backward GEMMs
@@ -237,7 +244,7 @@ def bn_stats(x, rows, C, with_count=False):
     flat = torch.empty(3 * C + (1 if with_count else 0), dtype=torch.float32, device=x.device)
     ws = torch.empty(1024 * 2 * C, dtype=torch.float32, device=x.device)
     call("avsr_bn_stats", _ptr(x), dt(x), _ptr(flat), _ptr(ws), rows, C,
-         flat.data_ptr() + 12 * C if with_count else None, _stream(x))
+         flat.data_ptr() + 12 * C if with_count else None, _stream(x), nbytes=_nb(x))
     return flat if with_count else flat.view(3, C)
 
 
@@ -247,7 +254,7 @@ def bn_stats_finalize(x, rows, C, eps, momentum, running_mean, running_var, num_
     invstd = torch.empty(C, dtype=torch.float32, device=x.device)
     ws = torch.empty(1024 * 2 * C, dtype=torch.float32, device=x.device)
     call("avsr_bn_stats_finalize", _ptr(x), dt(x), _ptr(ws), rows, C, eps, momentum, _ptr(mean), _ptr(invstd),
-         _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _stream(x))
+         _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _stream(x), nbytes=_nb(x))
     return mean, invstd
 
 
@@ -274,7 +281,7 @@ def bn_eval_params(running_mean, running_var, eps):
 def bn_act_fwd(x, add, mean, invstd, gamma, beta, rows, C, act):
     y = torch.empty_like(x)
     call("avsr_bn_act_fwd", _ptr(x), _ptr(add), dt(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y),
-         rows, C, act, _stream(x))
+         rows, C, act, _stream(x), nbytes=_nb(x, add, y))
     return y
 
 
@@ -284,7 +291,7 @@ def bn_act_pool_fwd(x, mean, invstd, gamma, beta, N, H, W, C, K, S, P, act):
     y = torch.empty(N, OH, OW, C, dtype=x.dtype, device=x.device)
     idx = torch.empty(N, OH, OW, C, dtype=torch.uint8, device=x.device)
     call("avsr_bn_act_pool_fwd", _ptr(x), dt(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(idx),
-         N, H, W, C, K, S, P, act, _stream(x))
+         N, H, W, C, K, S, P, act, _stream(x), nbytes=_nb(x, y, idx))
     return y, idx
 
 
@@ -292,14 +299,15 @@ def bn_pool_bwd_reduce(x, dpool, idx, mean, invstd, gamma, beta, N, H, W, C, K, 
     sums = torch.empty(2, C, dtype=torch.float32, device=x.device)
     ws = torch.empty(1024 * 2 * C, dtype=torch.float32, device=x.device)
     call("avsr_bn_pool_bwd_reduce", _ptr(x), _ptr(dpool), _ptr(idx), dt(x), _ptr(mean), _ptr(invstd), _ptr(gamma),
-         _ptr(beta), _ptr(sums), _ptr(ws), N, H, W, C, K, S, P, act, _stream(x))
+         _ptr(beta), _ptr(sums), _ptr(ws), N, H, W, C, K, S, P, act, _stream(x), nbytes=_nb(x, dpool, idx))
     return sums
 
 
 def bn_pool_bwd_apply(x, dpool, idx, mean, invstd, gamma, beta, sums, inv_n, N, H, W, C, K, S, P, act, n_dev=None):
     dx = torch.empty_like(x)
     call("avsr_bn_pool_bwd_apply", _ptr(x), _ptr(dpool), _ptr(idx), dt(x), _ptr(mean), _ptr(invstd), _ptr(gamma),
-         _ptr(beta), _ptr(sums), inv_n, _ptr(n_dev), _ptr(dx), N, H, W, C, K, S, P, act, _stream(x))
+         _ptr(beta), _ptr(sums), inv_n, _ptr(n_dev), _ptr(dx), N, H, W, C, K, S, P, act, _stream(x),
+         nbytes=_nb(x, dpool, idx, dx))
     return dx
 
 
@@ -307,7 +315,7 @@ def bn_bwd_reduce(x, dy, add, mean, invstd, gamma, beta, rows, C, act):
     sums = torch.empty(2, C, dtype=torch.float32, device=x.device)
     ws = torch.empty(1024 * 2 * C, dtype=torch.float32, device=x.device)
     call("avsr_bn_bwd_reduce", _ptr(x), _ptr(dy), _ptr(add), dt(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
-         _ptr(sums), _ptr(ws), rows, C, act, _stream(x))
+         _ptr(sums), _ptr(ws), rows, C, act, _stream(x), nbytes=_nb(x, dy, add))
     return sums
 
 
@@ -315,7 +323,7 @@ def bn_bwd_apply(x, dy, add, mean, invstd, gamma, beta, sums, inv_n, rows, C, ac
     dx = torch.empty_like(x)
     dadd = torch.empty_like(x) if want_dadd else None
     call("avsr_bn_bwd_apply", _ptr(x), _ptr(dy), _ptr(add), dt(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
-         _ptr(sums), inv_n, _ptr(n_dev), _ptr(dx), _ptr(dadd), rows, C, act, _stream(x))
+         _ptr(sums), inv_n, _ptr(n_dev), _ptr(dx), _ptr(dadd), rows, C, act, _stream(x), nbytes=_nb(x, dy, add, dx, dadd))
     return dx, dadd
 
 
@@ -511,7 +519,9 @@ def gemm_bf16_nt(A, lda, B, ldb, M, N, K, C, ldc, *, bias=None, act=0, gate=None
     call("avsr_gemm_bf16_nt", _ptr(A), lda, _ptr(B), ldb, M, N, K, _ptr(bias), act, _ptr(gate),
          dt(gate) if gate is not None else 0, ldg, gate_scale, drop_p, seed, _ptr(seed_dev), alpha, _ptr(alpha_dev),
          _ptr(resid), dt(resid) if resid is not None else 0, ldr, _ptr(C), dt(C), ldc, int(accumulate), split_k, tile,
-         _ptr(colsum), _stream(A), flops=2.0 * M * N * K)
+         _ptr(colsum), _stream(A), flops=2.0 * M * N * K,
+         nbytes=2.0 * (M * K + N * K) + float(M * N * C.element_size()) + (float(M * N * resid.element_size()) if resid is not None else 0.0)
+         + (2.0 * M * N if gate is not None else 0.0))
     return C
 
 

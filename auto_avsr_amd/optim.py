@@ -138,7 +138,7 @@ class FusedAdamW:
             ops.call("avsr_adamw_step", ops._ptr(table), n, blk, ops._ptr(partial), ops._ptr(self.state), self.lr,
                      self.betas[0], self.betas[1], self.eps, self.weight_decay, self.max_grad_norm, self.warmup_steps,
                      self.total_steps, ops._stream(table))
-            AF.note_optimizer_step(False)  # parameters changed behind `_version`: every cached bf16 copy is stale
+            self._note_stale(AF, False)  # parameters changed behind `_version`: their cached bf16 copies are stale
             return
 
         gen, _, lin, lin_blk, trow, tile_blk, _ = plan
@@ -148,7 +148,19 @@ class FusedAdamW:
                  ops._ptr(partial), ops._ptr(self.state), self.lr, self.betas[0], self.betas[1], self.eps,
                  self.weight_decay, self.max_grad_norm, self.warmup_steps, self.total_steps, ops._stream(table))
         AF.claim_weight_casts(self, gen)  # refresh_weight_cache() now has nothing to do for the Linear copies
-        AF.note_optimizer_step(True)      # ... but the conv-weight permutes are stale until it runs
+        self._note_stale(AF, True)        # ... but the conv-weight permutes are stale until it runs
+
+    def _note_stale(self, AF, linear_rewritten):
+        """Tell the weight cache which of its copies this step left behind (only copies of OUR parameters count)."""
+        gen, lin, conv = AF.cached_weight_ptrs()
+        if getattr(self, "_stale_gen", None) != gen:
+            mine = {p.data_ptr() for p in self.params}
+            self._stale_gen, self._stale_kind = gen, (bool(mine & lin), bool(mine & conv))
+        has_lin, has_conv = self._stale_kind
+        if has_lin and not linear_rewritten:
+            AF.note_optimizer_step(False)
+        elif has_conv or has_lin:
+            AF.note_optimizer_step(True)
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:

@@ -244,7 +244,8 @@ int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int
                       float* colsum /* may be NULL: colsum[n] += sum_m C[m,n] (f32, before rounding; accumulate = 0) */,
                       avsr_stream_t stream);
 /* Tuning knobs of the tuned kernels (process-wide; meant for benchmarks, defaults are the measured best):
- * knob 0 = tile code forced on avsr_conv2d_bf16 (0 = auto), 1 = XCD-aware tile order (default 0: measured neutral to slower),
+ * knob 0 = tile code forced on avsr_conv2d_bf16 (0 = auto), 1 = XCD-aware tile order (0 = automatic: on for the 64x64 GEMM tile, whose
+ * operands are not cache-resident in the training step; 1 = always on; 2 = always off),
  * 2 = ablation mode of the 128x128 forward convolution kernel (1 = no MFMA, 2 = no operand loads; wrong results),
  * 3 = avsr_conv3x3_wgrad_bf16 output stage (0 = as the workspace argument says, 1 = always atomics, 2 = none),
  * 4 = 1 disables the XCD-aware work order of avsr_conv3x3_wgrad_bf16. */

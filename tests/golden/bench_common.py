@@ -1,0 +1,103 @@
+"""Inputs / weights / sampling shared by the bench-shape golden generator (make_golden_bench.py, runs the reference) and
+its consumers (tests/test_bench_parity.py, bench.py's `parity` block).  No reference import here: this module travels to
+the GPU box.  See make_golden_bench.py for what the fixture holds."""
+import os
+
+import torch
+
+from synth import _gen, synth_state_dict
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIXTURE = os.path.join(HERE, "golden_bench_v1.pt")
+FAV = 17
+ODIM = 5049
+NSAMP = 64
+BATCHES = {"A": dict(lengths=[400, 380, 360, 340], L=64, seed=21), "B": dict(lengths=[100] * 16, L=16, seed=22)}
+
+
+def sample_index(name, numel, seed=0):
+    return torch.randint(0, numel, (NSAMP,), generator=_gen("sample/" + name, seed))
+
+
+def bench_state_dict(template, seed):
+    sd = synth_state_dict(template, seed)
+    sd["decoder.output_layer.bias"] = sd["decoder.output_layer.bias"].clone()
+    sd["decoder.output_layer.bias"][FAV] += 6.0
+    return sd
+
+
+def bench_batch(lengths, L, seed):
+    """x (B, Tmax, 1, 88, 88) zero-padded, lengths, y (B, 1, L) with label length round(T / 6.25) capped at L, pad -1."""
+    g = torch.Generator().manual_seed(5000 + seed)
+    B, T = len(lengths), max(lengths)
+    x = torch.zeros(B, T, 1, 88, 88)
+    y = torch.full((B, 1, L), -1, dtype=torch.int64)
+    for b, t in enumerate(lengths):
+        x[b, :t] = torch.randn(t, 1, 88, 88, generator=g)
+        n = min(L, max(1, round(t / 6.25)))
+        lab = torch.randint(1, ODIM - 1, (n,), generator=g)
+        lab[::5] = FAV
+        y[b, 0, :n] = lab
+    return x, torch.tensor(lengths, dtype=torch.int64), y
+
+
+def rel(a, b):
+    a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def measure(model, case, device):
+    """Run `model` (an auto_avsr_amd E2E carrying bench_state_dict weights, training mode, dropout 0) on the case's batch in
+    the CURRENT numerical mode and compare with the reference numbers in `case`.  Returns a dict of measured errors:
+    relative errors of the three losses, accuracy difference, relative L2 error of the decoder-logit / CTC log-prob /
+    encoder-output slices, and over all parameter gradients: worst / median relative norm error, worst / mean cosine and
+    worst relative L2 error of the 64 sampled elements per tensor (tensors whose reference gradient is numerically zero
+    are skipped)."""
+    import statistics
+
+    x, lengths, y = bench_batch(case["lengths"], case["L"], case["seed"])
+    grab = {}
+    hooks = [model.encoder.register_forward_hook(lambda m, i, o: grab.__setitem__("enc", o[0].detach())),
+             model.decoder.register_forward_hook(lambda m, i, o: grab.__setitem__("dec", o[0].detach())),
+             model.ctc.ctc_lo.register_forward_hook(lambda m, i, o: grab.__setitem__("ctc", o.detach()))]
+    for p in model.parameters():
+        p.grad = None
+    try:
+        loss, loss_ctc, loss_att, acc = model(x.to(device), lengths.to(device), y.to(device))
+        loss.backward()
+    finally:
+        for h in hooks:
+            h.remove()
+    out = {"loss_rel_err": abs(float(loss) - case["loss"]) / abs(case["loss"]),
+           "ctc_rel_err": abs(float(loss_ctc) - case["loss_ctc"]) / abs(case["loss_ctc"]),
+           "att_rel_err": abs(float(loss_att) - case["loss_att"]) / abs(case["loss_att"]),
+           "acc": float(acc), "acc_ref": case["acc"]}
+    vcols, tsel = case["vcols"], case["tsel"]
+    dec = grab["dec"].float().cpu()[..., : ODIM][:, :, vcols]
+    out["dec_logits_rel_l2"] = rel(dec, case["dec_logits"])
+    ctc = grab["ctc"].float().cpu()[..., : ODIM]
+    ctc_logp = torch.log_softmax(ctc, -1)[:, tsel][:, :, vcols]
+    out["ctc_logp_rel_l2"] = rel(ctc_logp, case["ctc_logp"])
+    out["enc_rel_l2"] = rel(grab["enc"].float().cpu()[:, tsel, :32], case["enc"])
+    gmax = max(case["grad_norms"].values())
+    norm_err, cos, samp = [], [], []
+    worst = {}
+    for k, p in model.named_parameters():
+        ref_n = case["grad_norms"][k]
+        if ref_n < 1e-6 * gmax:
+            continue
+        g = p.grad.detach().float().cpu().reshape(-1)
+        ne = abs(float(g.double().norm()) - ref_n) / ref_n
+        got_s, ref_s = g[sample_index(k, g.numel())].double(), case["grad_samples"][k].double()
+        c = float(torch.dot(got_s, ref_s) / (got_s.norm() * ref_s.norm() + 1e-300))
+        se = float((got_s - ref_s).norm() / ref_s.norm().clamp_min(1e-300))
+        norm_err.append(ne)
+        cos.append(c)
+        samp.append(se)
+        if se >= max(samp):
+            worst = {"worst_sample_tensor": k}
+    out.update(grad_tensors=len(norm_err), grad_norm_rel_err_max=max(norm_err),
+               grad_norm_rel_err_median=statistics.median(norm_err), grad_sample_cos_min=min(cos),
+               grad_sample_cos_mean=sum(cos) / len(cos), grad_sample_rel_l2_max=max(samp),
+               grad_sample_rel_l2_median=statistics.median(samp), **worst)
+    return out

@@ -1,0 +1,68 @@
+"""Parity at the BENCHMARKED shapes: full-size video model on the survey's batch A (4 x 400 frames,
+64 labels) and batch B (16 x 100, 16 labels) against numbers produced by the REFERENCE implementation
+(tests/golden/make_golden_bench.py -> golden_bench_v1.pt), in BOTH numerical modes:
+
+* precise (split-bf16 contractions): the north-star bound -- losses / logits / CTC log-probs within 1e-3 relative;
+* bf16 (the mode bench.py times): measured and printed; bounds state what bf16 operands (2^-9 relative rounding per
+  contraction input) deliver at this depth, and the same numbers appear in bench.py's `parity` block.
+
+Gradients are checked element-wise on 64 sampled entries per tensor (+ cosine, + norm), not by norm alone."""
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import bench_common as BC  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return torch.load(BC.FIXTURE, weights_only=False)
+
+
+def _model(seed):
+    from auto_avsr_amd import _lib
+    from auto_avsr_amd import functional as AF
+    from auto_avsr_amd.e2e import E2E
+
+    _lib._lib = None
+    assert not _lib.lib().is_emulator
+    AF.invalidate_weight_cache()
+    m = E2E(BC.ODIM, "video")
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    m.load_state_dict(BC.bench_state_dict(m.state_dict(), seed))
+    return m.cuda().train()
+
+
+@pytest.mark.parametrize("tag", ["A", "B"])
+@pytest.mark.parametrize("mode", ["precise", "bf16"])
+def test_bench_shape_parity(gold, tag, mode):
+    from auto_avsr_amd import functional as AF
+
+    case = gold[tag]
+    m = _model(case["seed"])
+    with AF.precise(mode == "precise"):
+        r = BC.measure(m, case, torch.device("cuda"))
+    AF.invalidate_weight_cache()
+    print(f"\nPARITY batch {tag} ({len(case['lengths'])} x {max(case['lengths'])}) mode {mode}: " + json.dumps(
+        {k: (round(v, 7) if isinstance(v, float) else v) for k, v in r.items()}))
+    if mode == "precise":
+        assert r["loss_rel_err"] < 1e-3 and r["ctc_rel_err"] < 1e-3 and r["att_rel_err"] < 1e-3
+        assert r["dec_logits_rel_l2"] < 1e-3 and r["ctc_logp_rel_l2"] < 1e-3 and r["enc_rel_l2"] < 1e-3
+        assert r["acc"] == pytest.approx(r["acc_ref"], abs=1e-6) and r["acc_ref"] > 0.1
+        assert r["grad_norm_rel_err_max"] < 1e-2 and r["grad_sample_cos_min"] > 0.999
+        assert r["grad_sample_rel_l2_max"] < 2e-2, r.get("worst_sample_tensor")
+    else:
+        assert r["loss_rel_err"] < 5e-3 and r["ctc_rel_err"] < 5e-3 and r["att_rel_err"] < 5e-3
+        assert r["dec_logits_rel_l2"] < 3e-2 and r["ctc_logp_rel_l2"] < 3e-2 and r["enc_rel_l2"] < 3e-2
+        assert abs(r["acc"] - r["acc_ref"]) < 0.02
+        assert r["grad_sample_cos_min"] > 0.9 and r["grad_sample_cos_mean"] > 0.99
+        assert r["grad_norm_rel_err_median"] < 2e-2

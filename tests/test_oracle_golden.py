@@ -80,3 +80,34 @@ def test_e2e(golden, name):
     assert acc == c["acc"]
     loss.backward()
     _check_grad_norms(sd, c["grad_norms"], rtol=5e-3)
+
+
+def test_e2e_at_bench_shape():
+    """The oracle at the BENCHMARKED shape: the survey's batch B (16 x 100 frames, 16 labels, full-size video model)
+    against the reference numbers of tests/golden/make_golden_bench.py -- losses, accuracy (non-zero by construction) and
+    64 sampled elements of every parameter gradient, not just the norms."""
+    import bench_common as BC
+    from auto_avsr_amd.e2e import E2E
+
+    c = torch.load(BC.FIXTURE, weights_only=False)["B"]
+    shapes = {k: tuple(v.shape) for k, v in E2E(BC.ODIM, "video").state_dict().items()}
+    sd = BC.bench_state_dict({k: torch.empty(s, dtype=torch.int64 if k.endswith("num_batches_tracked") else torch.float32)
+                              for k, s in shapes.items()}, c["seed"])
+    sd = {k: (v.requires_grad_() if v.is_floating_point() and "running_" not in k else v) for k, v in sd.items()}
+    x, lengths, y = BC.bench_batch(c["lengths"], c["L"], c["seed"])
+    torch.set_num_threads(8)
+    (loss, loss_ctc, loss_att, acc), _ = O.e2e_forward(sd, x, lengths, y, modality="video")
+    for got, key in ((loss, "loss"), (loss_ctc, "loss_ctc"), (loss_att, "loss_att")):
+        assert abs(float(got) - c[key]) < 1e-4 * abs(c[key]), (key, float(got), c[key])
+    assert abs(float(acc) - c["acc"]) < 1e-9 and c["acc"] > 0.1
+    loss.backward()
+    gmax = max(c["grad_norms"].values())
+    bad = []
+    for k, ref in c["grad_samples"].items():
+        if c["grad_norms"][k] < 1e-6 * gmax:
+            continue
+        got = sd[k].grad.reshape(-1)[BC.sample_index(k, sd[k].numel())]
+        err = float((got.double() - ref.double()).norm() / ref.double().norm().clamp_min(1e-300))
+        if err > 5e-3:
+            bad.append((k, err))
+    assert not bad, bad[:5]

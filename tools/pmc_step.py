@@ -1,0 +1,75 @@
+"""Workload for the rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE need separate passes, MI355X_MICROARCH.md "rocprofv3
+PMC slots"): a calibration stream of KNOWN byte counts, then ONE eager full training step of the bench workload.
+
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -o r -- python tools/pmc_step.py
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_write -o r -- python tools/pmc_step.py
+    python tools/pmc_report.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r2_hbm_traffic.txt
+
+The calibration launches (scale_dropout_kernel<float, float> over 1 GiB: reads 1 GiB, writes 1 GiB, far beyond the 256 MiB
+Infinity Cache) give the counter -> byte factors for this tool chain (the guide: FETCH_SIZE under-reports wide coalesced
+reads 2x on gfx950, WRITE_SIZE is uncalibrated); pmc_report.py applies them.  AVSR_PMC_SHAPE=a|b picks the survey's
+fixed batch A (4 x 400) or B (16 x 100); default: the middle bucketed batch of the bench workload."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.getcwd())
+import torch
+
+from auto_avsr_amd import functional as AF
+from auto_avsr_amd import ops
+from auto_avsr_amd.e2e import E2E
+from auto_avsr_amd.optim import FusedAdamW
+from auto_avsr_amd.synthetic import bucket_batches, make_batch, rank_batches, utterance_lengths
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+model = E2E(5049, "video").to(dev).train()
+AF.set_precise(False)
+AF.manual_seed(1234)
+seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+AF.set_seed_tensor(seed_dev)
+opt = FusedAdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.98), weight_decay=0.03, max_grad_norm=10.0,
+                 warmup_steps=5000, total_steps=75000, cast_weights=True)
+lengths = utterance_lengths()
+shape = os.environ.get("AVSR_PMC_SHAPE", "")
+if shape == "a":
+    lengths, idxs = [400, 380, 360, 340], [0, 1, 2, 3]
+elif shape == "b":
+    lengths, idxs = [100] * 16, list(range(16))
+else:
+    batches = rank_batches(bucket_batches(lengths, 1600, 400), 0, 1, seed=0)
+    idxs = batches[len(batches) // 2]
+x, lens, y, frames = make_batch(lengths, idxs, "video", 5049, seed=0, device=dev)
+
+
+def step():
+    AF.new_step()
+    seed_dev.add_(1)
+    AF.refresh_weight_cache()
+    loss = model.forward_tensors(x, lens, y)[0]
+    loss.backward()
+    opt.step()
+    for p in model.parameters():
+        p.grad = None
+    return loss
+
+
+for _ in range(2):  # warm-up: weight caches, allocator
+    step()
+torch.cuda.synchronize()
+# ---- calibration: known bytes (marker kernels: the only scale_dropout_kernel<float, float> launches over 2^28 elements)
+n = 1 << 28
+src = torch.randn(n, device=dev)
+for _ in range(3):
+    dst = ops.scale_dropout(src, torch.float32, alpha=2.0)
+torch.cuda.synchronize()
+del src, dst
+# ---- the measured step, bracketed by two tiny marker launches (sum_scale on 3 elements)
+mark = torch.ones(3, device=dev)
+ops.sum_scale(mark, 1.0)
+loss = step()
+ops.sum_scale(mark, 1.0)
+torch.cuda.synchronize()
+print(json.dumps({"B": int(x.shape[0]), "T": int(x.shape[1]), "L": int(y.shape[2]), "real_frames": int(frames),
+                  "loss": float(loss.detach())}))
