@@ -243,6 +243,68 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(const T* __restr
     }
 }
 
+// The 3x3 / stride 2 / pad 1 case (the video stem) of bn_act_pool_fwd_kernel below, straight-line: all nine window loads
+// are issued up front from clamped addresses (out-of-image taps are masked afterwards), so a thread has 9 x 16 B in flight
+// instead of one load per loop trip.  Also records xsel = the RAW input at the arg-max: the backward reduce pass then
+// runs on the pooled tensors alone (sum over pooled outputs of dpool * act'(z(xsel)) == sum over pixels of dz).
+template <class T>
+__global__ __launch_bounds__(BN_THREADS) void bn_act_pool3_fwd_kernel(
+    const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y, uint8_t* __restrict__ idx,
+    T* __restrict__ xsel, long N, int H, int W, int C, int OH, int OW, int act) {
+    const int cv = C >> 3;
+    const long total = N * OH * OW * cv;
+    for (long i = (long)blockIdx.x * BN_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * BN_THREADS) {
+        const int c = (int)(i % cv) * 8;
+        long r = i / cv;
+        const int ow = (int)(r % OW);
+        r /= OW;
+        const int oh = (int)(r % OH);
+        const long n = r / OH;
+        float v[9][8];
+        unsigned ok = 0;
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const int ih = oh * 2 + t / 3 - 1, iw = ow * 2 + t % 3 - 1;
+            const bool in = ih >= 0 && ih < H && iw >= 0 && iw < W;
+            ok |= (in ? 1u : 0u) << t;
+            const int ihc = min(max(ih, 0), H - 1), iwc = min(max(iw, 0), W - 1);
+            load8(x + ((n * H + ihc) * W + iwc) * C + c, v[t]);
+        }
+        float mu[8], is[8], ga[8], be[8], m[8], xs[8];
+        int am[8];
+        load8(mean + c, mu);
+        load8(invstd + c, is);
+        load8(gamma + c, ga);
+        load8(beta + c, be);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            m[e] = -INFINITY;
+            am[e] = 0;
+            xs[e] = 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const bool in = (ok >> t) & 1u;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                float a = act_fwd((v[t][e] - mu[e]) * is[e] * ga[e] + be[e], act);
+                if (sizeof(T) == 2) a = bf2f(f2bf(a));  // the value the unfused path would have stored
+                const bool take = in && a > m[e];
+                m[e] = take ? a : m[e];
+                am[e] = take ? t : am[e];
+                xs[e] = take ? v[t][e] : xs[e];
+            }
+        }
+        store8(y + i * 8, m);
+        if (xsel) store8(xsel + i * 8, xs);
+        uint64_t pk = 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) pk |= (uint64_t)am[e] << (8 * e);
+        *reinterpret_cast<uint64_t*>(idx + i * 8) = pk;
+    }
+}
+
 // y[n,oh,ow,c] = max over the KxK / stride S / pad P window of act(bn(x[n,ih,iw,c])), idx = kh*K+kw of the first maximum:
 // bn_act_fwd + maxpool_fwd (pool.hip) without the full-resolution activation between them -- the video stem's BN + SiLU
 // output is 396 MB per 1600-frame batch, written once and read once only to be pooled 4:1.  Each activated value is
@@ -450,6 +512,83 @@ __global__ __launch_bounds__(BN_THREADS) void bn_pool_bwd_apply_kernel(
     }
 }
 
+// 3x3 / stride 2 / pad 1 case of bn_pool_bwd_apply_kernel: a pixel lies in at most 2 x 2 windows (one per dimension when
+// its coordinate is even, two when odd); the four candidate (idx, dpool) pairs are loaded unconditionally from clamped
+// addresses and masked, so the gather is branch-free and all loads of a thread are in flight together.
+template <class T>
+__global__ __launch_bounds__(BN_THREADS) void bn_pool3_bwd_apply_kernel(
+    const T* __restrict__ x, const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ sums, float inv_n0, const float* __restrict__ n_dev, T* __restrict__ dx, long rows, int H,
+    int W, int C, int OH, int OW, int act) {
+    const float inv_n = n_dev ? 1.0f / *n_dev : inv_n0;
+    const int cv = C >> 3;
+    const long nvec = rows * cv;
+    for (long i = (long)blockIdx.x * BN_THREADS + threadIdx.x; i < nvec; i += (long)gridDim.x * BN_THREADS) {
+        const int c = (int)(i % cv) * 8;
+        const long r = i / cv;
+        const int iw = (int)(r % W);
+        const long q = r / W;
+        const int ih = (int)(q % H);
+        const long n = q / H;
+        // candidate windows per dimension: coordinate even -> {ih/2 (tap 1)}; odd -> {(ih-1)/2 (tap 2), (ih+1)/2 (tap 0)}
+        int ohc[2], khc[2], owc[2], kwc[2];
+        bool hv[2], wv[2];
+        if (ih & 1) {
+            ohc[0] = (ih - 1) >> 1; khc[0] = 2; hv[0] = true;
+            ohc[1] = (ih + 1) >> 1; khc[1] = 0; hv[1] = ohc[1] < OH;
+        } else {
+            ohc[0] = ih >> 1; khc[0] = 1; hv[0] = ohc[0] < OH;
+            ohc[1] = ohc[0]; khc[1] = 1; hv[1] = false;
+        }
+        if (iw & 1) {
+            owc[0] = (iw - 1) >> 1; kwc[0] = 2; wv[0] = true;
+            owc[1] = (iw + 1) >> 1; kwc[1] = 0; wv[1] = owc[1] < OW;
+        } else {
+            owc[0] = iw >> 1; kwc[0] = 1; wv[0] = owc[0] < OW;
+            owc[1] = owc[0]; kwc[1] = 1; wv[1] = false;
+        }
+        float v[8], d[4][8];
+        uint64_t pk[4];
+        load8(x + i * 8, v);
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                const long o = ((n * OH + min(ohc[a], OH - 1)) * OW + min(owc[b], OW - 1)) * C + c;
+                pk[a * 2 + b] = *reinterpret_cast<const uint64_t*>(idx + o);
+                load8(dpool + o, d[a * 2 + b]);
+            }
+        float g[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) g[e] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                const bool valid = hv[a] && wv[b];
+                const int me = khc[a] * 3 + kwc[b];
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                    g[e] += (valid && (int)((pk[a * 2 + b] >> (8 * e)) & 0xff) == me) ? d[a * 2 + b][e] : 0.f;
+            }
+        float mu[8], is[8], ga[8], be[8], s1[8], s2[8], o[8];
+        load8(mean + c, mu);
+        load8(invstd + c, is);
+        load8(gamma + c, ga);
+        load8(beta + c, be);
+        load8(sums + c, s1);
+        load8(sums + C + c, s2);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float xh = (v[e] - mu[e]) * is[e];
+            const float dz = g[e] * act_grad(xh * ga[e] + be[e], act);
+            o[e] = ga[e] * is[e] * (dz - s1[e] * inv_n - xh * s2[e] * inv_n);
+        }
+        store8(dx + i * 8, o);
+    }
+}
+
 static inline int pick_cl(int cv) { return cv >= 32 ? 32 : (cv >= 16 ? 16 : 8); }
 static inline int ew_grid(long nvec) {
     long b = (nvec + BN_THREADS - 1) / BN_THREADS;
@@ -564,13 +703,24 @@ extern "C" int avsr_bn_act_fwd(const void* x, const void* add, int dtype, const 
 
 // y [N][OH][OW][C], idx uint8 [N][OH][OW][C] = maxpool(act(bn(x [N][H][W][C]))) with OH = (H + 2P - K)/S + 1
 extern "C" int avsr_bn_act_pool_fwd(const void* x, int dtype, const float* mean, const float* invstd, const float* gamma,
-                                    const float* beta, void* y, uint8_t* idx, int64_t N, int H, int W, int C, int K, int S,
-                                    int P, int act, hipStream_t stream) {
+                                    const float* beta, void* y, uint8_t* idx, void* xsel, int64_t N, int H, int W, int C,
+                                    int K, int S, int P, int act, hipStream_t stream) {
     AVSR_REQUIRE(C % 8 == 0, "batchnorm: C must be a multiple of 8");
     AVSR_REQUIRE(idx != nullptr, "bn_act_pool_fwd: idx required");
     const int OH = (H + 2 * P - K) / S + 1, OW = (W + 2 * P - K) / S + 1;
     if (N <= 0) return 0;
     dim3 grid(ew_grid((long)N * OH * OW * (C >> 3))), block(BN_THREADS);
+    if (K == 3 && S == 2 && P == 1) {
+        if (dtype == 0)
+            AVSR_LAUNCH((bn_act_pool3_fwd_kernel<float>), grid, block, 0, stream, (const float*)x, mean, invstd, gamma, beta,
+                        (float*)y, idx, (float*)xsel, (long)N, H, W, C, OH, OW, act);
+        else
+            AVSR_LAUNCH((bn_act_pool3_fwd_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, mean, invstd, gamma, beta,
+                        (bf16_t*)y, idx, (bf16_t*)xsel, (long)N, H, W, C, OH, OW, act);
+        AVSR_CHECK_LAUNCH("bn_act_pool_fwd");
+        return 0;
+    }
+    AVSR_REQUIRE(xsel == nullptr, "bn_act_pool_fwd: xsel is produced by the 3x3 / stride 2 / pad 1 kernel only");
     if (dtype == 0)
         AVSR_LAUNCH((bn_act_pool_fwd_kernel<float>), grid, block, 0, stream, (const float*)x, mean, invstd, gamma, beta,
                     (float*)y, idx, (long)N, H, W, C, OH, OW, K, S, P, act);
@@ -619,6 +769,16 @@ extern "C" int avsr_bn_pool_bwd_apply(const void* x, const void* dpool, const ui
     const long rows = (long)N * H * W;
     if (rows <= 0) return 0;
     dim3 grid(ew_grid(rows * (C >> 3))), block(BN_THREADS);
+    if (K == 3 && S == 2 && P == 1) {
+        if (dtype == 0)
+            AVSR_LAUNCH((bn_pool3_bwd_apply_kernel<float>), grid, block, 0, stream, (const float*)x, (const float*)dpool, idx,
+                        mean, invstd, gamma, beta, sums, inv_n, n_dev, (float*)dx, rows, H, W, C, OH, OW, act);
+        else
+            AVSR_LAUNCH((bn_pool3_bwd_apply_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dpool,
+                        idx, mean, invstd, gamma, beta, sums, inv_n, n_dev, (bf16_t*)dx, rows, H, W, C, OH, OW, act);
+        AVSR_CHECK_LAUNCH("bn_pool_bwd_apply");
+        return 0;
+    }
     if (dtype == 0)
         AVSR_LAUNCH((bn_pool_bwd_apply_kernel<float>), grid, block, 0, stream, (const float*)x, (const float*)dpool, idx, mean,
                     invstd, gamma, beta, sums, inv_n, n_dev, (float*)dx, rows, H, W, C, OH, OW, K, S, P, act);

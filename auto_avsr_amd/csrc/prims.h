@@ -193,7 +193,16 @@ AVSR_DEV float avsr_exp(float x) {
     return __expf(x);
 #endif
 }
-AVSR_DEV float avsr_sigmoid(float x) { return 1.0f / (1.0f + avsr_exp(-x)); }
+// 1 / (1 + e^-x) with the hardware reciprocal (v_rcp_f32, 1 ulp): an IEEE division costs ~10 VALU instructions, and the
+// BatchNorm + SiLU passes evaluate this once or more per activation element (the fused stem BN + pool kernel 9 times per
+// output) -- they were ALU-bound on it, not HBM-bound.
+AVSR_DEV float avsr_sigmoid(float x) {
+#ifdef AVSR_EMU
+    return 1.0f / (1.0f + avsr_exp(-x));
+#else
+    return __builtin_amdgcn_rcpf(1.0f + avsr_exp(-x));
+#endif
+}
 AVSR_DEV float avsr_silu(float x) { return x * avsr_sigmoid(x); }
 
 // ---------------------------------------------------------------- wave reductions (64 lanes)

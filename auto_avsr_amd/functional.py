@@ -84,9 +84,10 @@ def _rows(x):
 # ([in][out_padded_to_64], data gradient).  Copies are cached per parameter version: an optimizer step bumps
 # `_version`, so they are rebuilt exactly once per training step (bench.py invalidates explicitly).
 _FUSE_QKV = os.environ.get("AVSR_FUSE_QKV", "1") != "0"  # A/B switch for the fused self-attention projections
-# fused BN + SiLU + max-pool of the video stem: validated on the emulator, not yet on the MI355X (the round's GPU budget
-# was spent) -- off until it has been run and timed there
-_FUSE_STEM_POOL = os.environ.get("AVSR_FUSE_STEM_POOL", "0") == "1"
+# fused BN + SiLU + max-pool of the video stem (forward: the full-resolution activation is never written; backward: the
+# reduce pass runs on the pooled tensors, the apply pass gathers the pooled gradient).  Measured on MI355X (round 2):
+# 22.98 -> 22.39 ms per step together with the hardware-reciprocal sigmoid.  AVSR_FUSE_STEM_POOL=0 restores the three-pass path.
+_FUSE_STEM_POOL = os.environ.get("AVSR_FUSE_STEM_POOL", "1") != "0"
 _wcache = {}   # (data_ptr, transposed, shape) -> [version, bf16 copy, source weight, is a slice of a concatenation]
 _wcat = {}     # (data_ptrs..., transposed) -> concatenated bf16 buffer whose slices are registered in _wcache
 _wtable = {"n": 0, "dev": None, "blocks": 0, "built_for": -1}
@@ -1402,23 +1403,24 @@ class StemFn(torch.autograd.Function):
         rows = B * Tn * OH * OW
         bn = (g, b) + bn_rest
         m0, i0, n0 = _bn_fwd_params(c0, rows, Cout, bn, training)
-        idx = None
+        idx = xsel = None
         if pool and _FUSE_STEM_POOL:
             # BN + SiLU + max-pool in one pass: the full-resolution activation (396 MB per 1600 video frames) is never
             # written (the backward pass recomputes it from c0 anyway)
-            out, idx = ops.bn_act_pool_fwd(c0, m0, i0, g, b, B * Tn, OH, OW, Cout, 3, 2, 1, 1)
+            # xsel: the raw conv output at every arg-max -- all the backward reduce pass needs of c0
+            out, idx, xsel = ops.bn_act_pool_fwd(c0, m0, i0, g, b, B * Tn, OH, OW, Cout, 3, 2, 1, 1, want_xsel=True)
         elif pool:
             a0 = ops.bn_act_fwd(c0, None, m0, i0, g, b, rows, Cout, 1)
             out, idx = ops.maxpool2d_fwd(a0, B * Tn, OH, OW, Cout, 3, 2, 1)
         else:
             out = ops.bn_act_fwd(c0, None, m0, i0, g, b, rows, Cout, 1)
-        ctx.save_for_backward(x, c0, idx, g, b, m0, i0, n0)
+        ctx.save_for_backward(x, c0, idx, g, b, m0, i0, n0, xsel)
         ctx.meta = (geom, pool, training, bn_rest, (OH, OW), w.shape, dedicated)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, c0, idx, g, b, m0, i0, n0 = ctx.saved_tensors
+        x, c0, idx, g, b, m0, i0, n0, xsel = ctx.saved_tensors
         geom, pool, training, bn_rest, (OH, OW), wshape, dedicated = ctx.meta
         B, Tn, H, W, KT, KH, KW, stride, pt, ph, pw = geom
         Cout = wshape[0]
@@ -1428,7 +1430,10 @@ class StemFn(torch.autograd.Function):
             # the activation gradient is gathered from the pooled gradient inside both BatchNorm backward passes: the
             # full-resolution gradient (396 MB per 1600 video frames) is neither written nor read back
             dp = _to_act(dout)
-            sums = ops.bn_pool_bwd_reduce(c0, dp, idx, m0, i0, g, b, B * Tn, OH, OW, Cout, 3, 2, 1, 1)
+            # sum over pixels of dz == sum over pooled outputs of dpool * act'(z(arg-max pixel)): the reduce pass runs on
+            # the pooled tensors (a quarter of the pixels) and never reads c0
+            POH, POW = ops.conv_out(OH, 3, 2, 1), ops.conv_out(OW, 3, 2, 1)
+            sums = ops.bn_bwd_reduce(xsel, dp, None, m0, i0, g, b, B * Tn * POH * POW, Cout, 1)
             dg, db = sums[1], sums[0]
             if training:
                 sums_dx, inv_n, n_dev = _bn_bwd_sums(sums, n0, rows)

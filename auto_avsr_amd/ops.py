@@ -285,14 +285,16 @@ def bn_act_fwd(x, add, mean, invstd, gamma, beta, rows, C, act):
     return y
 
 
-def bn_act_pool_fwd(x, mean, invstd, gamma, beta, N, H, W, C, K, S, P, act):
-    """maxpool(act(bn(x))) without the full-resolution activation; returns (y, idx) like maxpool2d_fwd."""
+def bn_act_pool_fwd(x, mean, invstd, gamma, beta, N, H, W, C, K, S, P, act, want_xsel=False):
+    """maxpool(act(bn(x))) without the full-resolution activation; returns (y, idx) like maxpool2d_fwd -- and with
+    want_xsel (3x3 / stride 2 / pad 1 only) also xsel, the raw x at every arg-max."""
     OH, OW = conv_out(H, K, S, P), conv_out(W, K, S, P)
     y = torch.empty(N, OH, OW, C, dtype=x.dtype, device=x.device)
     idx = torch.empty(N, OH, OW, C, dtype=torch.uint8, device=x.device)
+    xsel = torch.empty_like(y) if want_xsel else None
     call("avsr_bn_act_pool_fwd", _ptr(x), dt(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(idx),
-         N, H, W, C, K, S, P, act, _stream(x), nbytes=_nb(x, y, idx))
-    return y, idx
+         _ptr(xsel), N, H, W, C, K, S, P, act, _stream(x), nbytes=_nb(x, y, idx, xsel))
+    return (y, idx, xsel) if want_xsel else (y, idx)
 
 
 def bn_pool_bwd_reduce(x, dpool, idx, mean, invstd, gamma, beta, N, H, W, C, K, S, P, act):
@@ -416,6 +418,14 @@ def zero_page(device):
     if z is None:
         z = _zero_pages[device] = torch.zeros(64, dtype=torch.float32, device=device)
     return z
+
+
+def apply_env_tuning():
+    """AVSR_TUNE="knob=value,knob=value": tuning knobs for A/B runs of unmodified entry points (bench.py, tests)."""
+    spec = os.environ.get("AVSR_TUNE", "")
+    for item in filter(None, spec.split(",")):
+        k, v = item.split("=")
+        call("avsr_tune", int(k), int(v))
 
 
 def tune(knob, value):

@@ -144,8 +144,11 @@ int avsr_bn_act_fwd(const void* x, const void* add, int dtype, const float* mean
  * x [N][H][W][C]; replaces BatchNorm3d + SiLU + MaxPool3d((1,3,3),(1,2,2),(0,1,1)) of the video stem
  * (frontend/resnet.py:212-218) without materialising the full-resolution activation */
 int avsr_bn_act_pool_fwd(const void* x, int dtype, const float* mean, const float* invstd, const float* gamma,
-                         const float* beta, void* y, uint8_t* idx, int64_t N, int H, int W, int C, int K, int S, int P,
-                         int act, avsr_stream_t stream);
+                         const float* beta, void* y, uint8_t* idx,
+                         void* xsel /* may be NULL; 3x3 / stride 2 / pad 1 only: [N][OH][OW][C], the RAW x at the arg-max --
+                                       with it the backward reduce pass is avsr_bn_bwd_reduce(xsel, dpool) on the pooled
+                                       tensors alone (sum over pooled outputs == sum over pixels) */,
+                         int64_t N, int H, int W, int C, int K, int S, int P, int act, avsr_stream_t stream);
 /* backward of avsr_bn_act_pool_fwd in the two BatchNorm backward passes, the activation gradient gathered from the pooled
  * gradient dpool [N][OH][OW][C] through idx (no full-resolution gradient tensor): sums [2][C] = (sum dz, sum dz*xhat),
  * then dx [N][H][W][C] from the (all-reduced) sums; workspace / inv_n / n_dev as avsr_bn_bwd_reduce / _apply */

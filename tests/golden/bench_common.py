@@ -59,7 +59,8 @@ def measure(model, case, device):
     grab = {}
     hooks = [model.encoder.register_forward_hook(lambda m, i, o: grab.__setitem__("enc", o[0].detach())),
              model.decoder.register_forward_hook(lambda m, i, o: grab.__setitem__("dec", o[0].detach())),
-             model.ctc.ctc_lo.register_forward_hook(lambda m, i, o: grab.__setitem__("ctc", o.detach()))]
+             # CTC.forward returns (loss, logits (T, B, V)) on both sides (ctc.py:62-65); this build never calls ctc_lo itself
+             model.ctc.register_forward_hook(lambda m, i, o: grab.__setitem__("ctc", o[1].detach().transpose(0, 1)))]
     for p in model.parameters():
         p.grad = None
     try:

@@ -144,8 +144,8 @@ def test_bn_act_pool_fused_matches_two_pass(dev, dtype):
     gamma, beta = torch.randn(C, device=dev), torch.randn(C, device=dev) * 0.2
     a = ops.bn_act_fwd(x.view(-1, C), None, mean, invstd, gamma, beta, N * H * W, C, 1).view(N, H, W, C)
     want, want_idx = ops.maxpool2d_fwd(a, N, H, W, C, 3, 2, 1)
-    got, got_idx = ops.bn_act_pool_fwd(x, mean, invstd, gamma, beta, N, H, W, C, 3, 2, 1, 1)
-    assert got.shape == want.shape and got_idx.shape == want_idx.shape
+    got, got_idx, xsel = ops.bn_act_pool_fwd(x, mean, invstd, gamma, beta, N, H, W, C, 3, 2, 1, 1, want_xsel=True)
+    assert got.shape == want.shape and got_idx.shape == want_idx.shape and xsel.shape == want.shape
     tol = 2.0 ** -7 if dtype == torch.bfloat16 else 1e-5
     assert ((got.float() - want.float()).abs() <= tol * want.float().abs().clamp_min(1.0)).all()
     # the recorded argmax addresses an element that attains the pooled value
@@ -160,6 +160,9 @@ def test_bn_act_pool_fused_matches_two_pass(dev, dtype):
     picked = ap[n, oh + kh, ow + kw, c]
     assert ((picked - want.float().cpu()).abs() <= tol * want.float().cpu().abs().clamp_min(1.0)).all()
     assert (got_idx == want_idx).float().mean() > 0.99
+    # xsel = the raw input at the recorded arg-max (what the pooled-only backward reduce pass normalises again)
+    xp = torch.nn.functional.pad(x.float().cpu(), (0, 0, 1, 1, 1, 1), value=0.0)
+    assert torch.equal(xsel.float().cpu(), xp[n, oh + kh, ow + kw, c])
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
@@ -180,6 +183,10 @@ def test_bn_pool_bwd_fused_matches_three_pass(dev, dtype):
     dx0, _ = ops.bn_bwd_apply(x.view(-1, C), da.view(-1, C), None, mean, invstd, gamma, beta, sums0, 1.0 / rows, rows, C, 1, False)
     sums1 = ops.bn_pool_bwd_reduce(x, dpool, idx, mean, invstd, gamma, beta, N, H, W, C, 3, 2, 1, 1)
     dx1 = ops.bn_pool_bwd_apply(x, dpool, idx, mean, invstd, gamma, beta, sums1, 1.0 / rows, N, H, W, C, 3, 2, 1, 1)
+    # the product path: the reduce pass on the pooled tensors alone, through xsel (raw x at every arg-max)
+    y2, idx2, xsel = ops.bn_act_pool_fwd(x, mean, invstd, gamma, beta, N, H, W, C, 3, 2, 1, 1, want_xsel=True)
+    assert torch.equal(idx2, idx)
+    sums2 = ops.bn_bwd_reduce(xsel.view(-1, C), dpool.view(-1, C), None, mean, invstd, gamma, beta, dpool.numel() // C, C, 1)
     # the three-pass path rounds the gathered gradient to the storage type before the BatchNorm passes; the fused one does not
     tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
 
@@ -187,5 +194,6 @@ def test_bn_pool_bwd_fused_matches_three_pass(dev, dtype):
         return float((a.double() - b.double()).norm() / b.double().norm())
 
     assert relerr(sums1, sums0) < tol and relerr(dx1.float().view(-1, C), dx0.float()) < tol
+    assert relerr(sums2, sums0) < tol
     if dtype == torch.float32:  # no intermediate rounding in either path: element-wise agreement
         assert ((dx1.view(-1, C) - dx0).abs() <= 1e-4 * dx0.abs().clamp_min(1.0)).all()

@@ -23,6 +23,7 @@ from auto_avsr_amd.optim import FusedAdamW
 from auto_avsr_amd.synthetic import bucket_batches, make_batch, rank_batches, utterance_lengths
 
 dev = torch.device("cuda:0")
+ops.apply_env_tuning()
 torch.manual_seed(0)
 model = E2E(5049, "video").to(dev).train()
 AF.set_precise(False)
