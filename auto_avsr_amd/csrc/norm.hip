@@ -70,56 +70,94 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(
     }
 }
 
-// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma ; optional  dx += dres.  One wave per row.
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma ; optional  dx += dres.  One wave per row, RPW rows
+// per wave.  When the consumer of dx is the output Linear of the previous pre-LN sub-layer, that Linear's whole "backward
+// prologue" is produced in the same pass: gout = bf16(alpha * dropout(dx)) (what its two backward GEMMs contract) and
+// gsum[c] += sum_r gout[r,c] (its bias gradient: per-lane partial sums over the wave's rows, combined across the block's
+// waves in LDS, one atomic per column and block), so the f32 dx is not re-read by a cast / column-sum launch.
 template <class TDY>
 AVSR_DEV void layernorm_bwd_dx_block(
     const TDY* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in, const float* __restrict__ dres,
-    float* __restrict__ dx, int rows, int cols, int blk) {
-    const int lane = threadIdx.x & 63;
-    const int row = blk * LN_WAVES + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    float* __restrict__ dx, bf16_t* __restrict__ gout, float* __restrict__ gsum, float alpha0, float drop_p, uint64_t seed,
+    int rows, int cols, int blk, int rpw, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = cols >> 3;
-    const float mean = mean_in[row], rstd = rstd_in[row];
-    const float* xr = x + (size_t)row * cols;
-    const TDY* dyr = dy + (size_t)row * cols;
-    float xh[LN_MAXV][8], g[LN_MAXV][8];
-    float s1 = 0.f, s2 = 0.f;
+    const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    float pc[LN_MAXV][8];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; i++) {
-        const int c = lane + 64 * i;
-        if (c < nvec) {
-            float xv[8], dv[8], gm[8];
-            load8(xr + c * 8, xv);
-            load8(dyr + c * 8, dv);
-            load8(gamma + c * 8, gm);
+    for (int i = 0; i < LN_MAXV; i++)
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                xh[i][e] = (xv[e] - mean) * rstd;
-                g[i][e] = dv[e] * gm[e];
-                s1 += g[i][e];
-                s2 += g[i][e] * xh[i][e];
+        for (int e = 0; e < 8; e++) pc[i][e] = 0.f;
+    for (int rr = 0; rr < rpw; rr++) {
+        const int row = (blk * rpw + rr) * LN_WAVES + wave;
+        if (row >= rows) break;  // wave-uniform
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        const float* xr = x + (size_t)row * cols;
+        const TDY* dyr = dy + (size_t)row * cols;
+        float xh[LN_MAXV][8], g[LN_MAXV][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; i++) {
+            const int c = lane + 64 * i;
+            if (c < nvec) {
+                float xv[8], dv[8], gm[8];
+                load8(xr + c * 8, xv);
+                load8(dyr + c * 8, dv);
+                load8(gamma + c * 8, gm);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    xh[i][e] = (xv[e] - mean) * rstd;
+                    g[i][e] = dv[e] * gm[e];
+                    s1 += g[i][e];
+                    s2 += g[i][e] * xh[i][e];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)cols;
+        s2 = wave_sum(s2) / (float)cols;
+        float* dxr = dx + (size_t)row * cols;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; i++) {
+            const int c = lane + 64 * i;
+            if (c < nvec) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) o[e] = rstd * (g[i][e] - s1 - xh[i][e] * s2);
+                if (dres) {
+                    float rv[8];
+                    load8(dres + (size_t)row * cols + c * 8, rv);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) o[e] += rv[e];
+                }
+                store8(dxr + c * 8, o);
+                if (gout) {
+                    float q[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const float v = o[e] * alpha0 *
+                            dropout_scale(seed, (uint64_t)row * (uint64_t)cols + c * 8 + e, drop_p, inv_keep);
+                        q[e] = bf2f(f2bf(v));
+                        pc[i][e] += q[e];
+                    }
+                    store8(gout + (size_t)row * cols + c * 8, q);
+                }
             }
         }
     }
-    s1 = wave_sum(s1) / (float)cols;
-    s2 = wave_sum(s2) / (float)cols;
-    float* dxr = dx + (size_t)row * cols;
+    if (!gsum) return;  // block-uniform
+    float* mine = red + (size_t)wave * cols;
 #pragma unroll
     for (int i = 0; i < LN_MAXV; i++) {
         const int c = lane + 64 * i;
-        if (c < nvec) {
-            float o[8];
+        if (c < nvec) store8(mine + c * 8, pc[i]);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < cols; j += LN_THREADS) {
+        float t = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; e++) o[e] = rstd * (g[i][e] - s1 - xh[i][e] * s2);
-            if (dres) {
-                float rr[8];
-                load8(dres + (size_t)row * cols + c * 8, rr);
-#pragma unroll
-                for (int e = 0; e < 8; e++) o[e] += rr[e];
-            }
-            store8(dxr + c * 8, o);
-        }
+        for (int w = 0; w < LN_WAVES; w++) t += red[(size_t)w * cols + j];
+        atomicAdd(gsum + j, t);
     }
 }
 
@@ -190,15 +228,18 @@ template <class TDY>
 __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(
     const TDY* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in, const float* __restrict__ dres,
-    float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int cols,
-    int rows_per_block, int CL, int npx, int npy) {
-    __shared__ float red[LN_THREADS * 16];
+    float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, bf16_t* __restrict__ gout,
+    float* __restrict__ gsum, float alpha0, float drop_p, uint64_t seed0, const uint64_t* __restrict__ seed_dev, int rows,
+    int cols, int rows_per_block, int CL, int npx, int npy, int rpw) {
+    AVSR_DYN_SMEM(smem);  // max(LN_THREADS * 16, LN_WAVES * cols) floats
+    float* red = reinterpret_cast<float*>(smem);
     const int b = blockIdx.x;
     if (b < npx * npy)
         layernorm_bwd_param_block<TDY>(dy, x, mean_in, rstd_in, dgamma, dbeta, rows, cols, rows_per_block, CL, b % npx,
                                        b / npx, red);
     else
-        layernorm_bwd_dx_block<TDY>(dy, x, gamma, mean_in, rstd_in, dres, dx, rows, cols, b - npx * npy);
+        layernorm_bwd_dx_block<TDY>(dy, x, gamma, mean_in, rstd_in, dres, dx, gout, gsum, alpha0, drop_p,
+                                    seed0 + (seed_dev ? *seed_dev : 0ull), rows, cols, b - npx * npy, rpw, red);
 }
 
 }  // namespace
@@ -219,25 +260,32 @@ extern "C" int avsr_layernorm_fwd(const float* x, const float* gamma, const floa
     return 0;
 }
 
-// dgamma / dbeta are ACCUMULATED into (caller zeroes them or carries grads over).
+// dgamma / dbeta (and gsum) are ACCUMULATED into (caller zeroes them or carries grads over).
+// gout (bf16 [rows][cols], may be NULL) = bf16(alpha * dropout(dx)) with the dropout stream of avsr_cast_transpose_colsum
+// (element index row * cols + col); gsum (f32 [cols], may be NULL, needs gout) += column sums of gout.
 extern "C" int avsr_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma,
                                   const float* mean, const float* rstd, const float* dres, float* dx,
-                                  float* dgamma, float* dbeta, int rows, int cols,
-                                  hipStream_t stream) {
+                                  float* dgamma, float* dbeta, void* gout, float* gsum, float alpha, float drop_p,
+                                  uint64_t seed, const uint64_t* seed_dev, int rows, int cols, hipStream_t stream) {
     AVSR_REQUIRE(cols % 8 == 0 && cols <= 64 * 8 * LN_MAXV, "layernorm: cols must be %8 and <= 2048");
+    AVSR_REQUIRE(gsum == nullptr || gout != nullptr, "layernorm_bwd: gsum needs gout");
     if (rows == 0) return 0;
-    const int ndx = (rows + LN_WAVES - 1) / LN_WAVES;
+    // with a column-sum output two rows per wave once the grid fills the chip anyway: half the atomics per launch
+    const int rpw = (gsum && rows > 1024) ? 2 : 1;
+    const int ndx = (rows + LN_WAVES * rpw - 1) / (LN_WAVES * rpw);
     const int cv = cols >> 3;
     const int CL = cv >= 32 ? 32 : (cv >= 16 ? 16 : 8);
     const int rpb = 8 * (LN_THREADS / CL);  // 64 rows per block; 32 was measured slower (more colliding atomics per column)
     const int npx = (cv + CL - 1) / CL, npy = (rows + rpb - 1) / rpb;
     dim3 grid(npx * npy + ndx), block(LN_THREADS);
+    size_t lds = (size_t)LN_THREADS * 16 * sizeof(float);
+    if (gsum && (size_t)LN_WAVES * cols * sizeof(float) > lds) lds = (size_t)LN_WAVES * cols * sizeof(float);
     if (dy_dtype == 0)
-        AVSR_LAUNCH((layernorm_bwd_kernel<float>), grid, block, 0, stream, (const float*)dy, x, gamma, mean, rstd, dres, dx,
-                    dgamma, dbeta, rows, cols, rpb, CL, npx, npy);
+        AVSR_LAUNCH((layernorm_bwd_kernel<float>), grid, block, lds, stream, (const float*)dy, x, gamma, mean, rstd, dres, dx,
+                    dgamma, dbeta, (bf16_t*)gout, gsum, alpha, drop_p, seed, seed_dev, rows, cols, rpb, CL, npx, npy, rpw);
     else
-        AVSR_LAUNCH((layernorm_bwd_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)dy, x, gamma, mean, rstd, dres,
-                    dx, dgamma, dbeta, rows, cols, rpb, CL, npx, npy);
+        AVSR_LAUNCH((layernorm_bwd_kernel<bf16_t>), grid, block, lds, stream, (const bf16_t*)dy, x, gamma, mean, rstd, dres,
+                    dx, dgamma, dbeta, (bf16_t*)gout, gsum, alpha, drop_p, seed, seed_dev, rows, cols, rpb, CL, npx, npy, rpw);
     AVSR_CHECK_LAUNCH("layernorm_bwd");
     return 0;
 }

@@ -357,6 +357,8 @@ def new_step():
     """Call at the start of every training step that may be captured into a hipGraph (bench.py, train_native.py):
     makes the zero-scratch arena start the step on a chunk whose fill belongs to the capture."""
     _arena.new_step()
+    _chain_spec.clear()
+    _chain_g.clear()
 
 
 def _zeros(shape, device):
@@ -373,11 +375,77 @@ def _fast_mode(t):
     return (not _state["precise"]) and t.dtype in (torch.bfloat16, torch.float32)
 
 
+# ---- residual-gradient hand-off between consecutive pre-LN sub-layers -------------------------------------------------
+# y_k = x_k + alpha_k * dropout_k(Linear_k(...)) feeds LN_{k+1}.  In the backward pass sub-layer k+1 finishes with its
+# LayerNorm backward, whose result dx is exactly the output gradient of sub-layer k: the kernel can emit that sub-layer's
+# backward prologue -- g = bf16(alpha_k * dropout_k(dx)) and the bias gradient colsum(g) -- in the same pass
+# (avsr_layernorm_bwd gout / gsum) instead of a separate cast / column-sum launch over dx.  Autograd functions cannot see
+# their neighbours, so the hand-off goes through two small registries keyed by device address:
+#   forward : sub-layer k tags its output with its prologue parameters; sub-layer k+1 (or a bare LayerNorm) picks the tag
+#             up from its input and remembers it for its backward pass;
+#   backward: the LayerNorm backward leaves (g, db) under the address of the dx it returns; sub-layer k's _prologue finds
+#             it under the address of the dy it was handed (autograd passes the tensor through unchanged when the residual
+#             has a single consumer; any copy / accumulation simply misses and the ordinary prologue runs).
+# Entries hold the tensors they describe alive (an address cannot be recycled while its entry exists) and are dropped by
+# new_step(); a stale tag can at worst make a LayerNorm backward emit a prologue nobody uses.
+_chain_spec = {}
+_chain_g = {}
+_CHAIN = os.environ.get("AVSR_CHAIN_PROLOGUE", "1") != "0"
+
+
+def _chain_tag(y, rows, n, alpha, drop):
+    """Forward of a sub-layer: y is its (f32 residual-stream) output, (alpha, drop) the epilogue of its output Linear."""
+    if not _CHAIN or _state["precise"] or y.dtype != torch.float32 or n % 8:
+        return
+    if len(_chain_spec) > 512:
+        _chain_spec.clear()
+    p, sd, sdev = drop
+    _chain_spec[y.data_ptr()] = (y, (rows, n, float(alpha), float(p), int(sd), sdev))
+
+
+def _chain_take(x):
+    """Forward of the consumer of a residual-stream tensor: the producer's tag, if x is one."""
+    ent = _chain_spec.pop(x.data_ptr(), None)
+    if ent is None or ent[0] is not x and ent[0].data_ptr() != x.data_ptr() or tuple(ent[0].shape) != tuple(x.shape):
+        return None
+    return ent[1]
+
+
+def _ln_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dres, spec):
+    """LayerNorm backward (+ residual gradient); with a producer tag also the producer's backward prologue."""
+    if spec is None or _state["precise"]:
+        return ops.layernorm_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dres=dres)
+    rows, n, alpha, p, sd, sdev = spec
+    g = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    db = _zeros(n, x.device)
+    dx = ops.layernorm_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dres=dres, gout=g, gsum=db, alpha=alpha, drop_p=p, seed=sd,
+                           seed_dev=sdev)
+    if len(_chain_g) > 512:
+        _chain_g.clear()
+    _chain_g[dx.data_ptr()] = (dx, g, db, spec)
+    return dx
+
+
+def _chain_prologue(src, rows, n, alpha, drop):
+    ent = _chain_g.pop(src.data_ptr(), None)
+    if ent is None:
+        return None
+    p, sd, sdev = drop
+    dx, g, db, spec = ent
+    if spec[:5] != (rows, n, float(alpha), float(p), int(sd)) or spec[5] is not sdev or dx.shape != src.shape:
+        return None
+    return g.view(rows, n), db
+
+
 def _prologue(src, rows, n, *, alpha=1.0, drop=(0.0, 0, None), want_dst=True, want_bias=True, ld_src=None):
     """Backward prologue of a Linear layer on its output gradient `src` [rows, n] (f32 or activation dtype):
     g = act_dtype(alpha * dropout(src)), g^T (bf16 fast path only, else None) and the bias gradient colsum(g).
     Returns (g or src when no copy was needed, gT, db)."""
     p, sd, sdev = drop
+    if want_dst and want_bias and ld_src is None and not _state["precise"]:
+        hit = _chain_prologue(src, rows, n, alpha, drop)  # already produced by the LayerNorm backward that made `src`
+        if hit is not None:
+            return hit[0], None, hit[1]
     db = _zeros(n, src.device) if want_bias else None
     if not _state["precise"]:
         need_dst = want_dst and (src.dtype != torch.bfloat16 or alpha != 1.0 or p > 0 or (ld_src or n) != n)
@@ -493,6 +561,7 @@ class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, out_dtype):
         x = x.contiguous()
+        ctx.chain = _chain_take(x)
         y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, out_dtype, eps)
         ctx.save_for_backward(x, gamma, mean, rstd)
         return y
@@ -503,7 +572,7 @@ class LayerNormFn(torch.autograd.Function):
         D = x.shape[-1]
         dg = _zeros(D, x.device)
         db = _zeros(D, x.device)
-        dx = ops.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dg, db)
+        dx = _ln_bwd(dy.contiguous(), x, gamma, mean, rstd, dg, db, None, ctx.chain)
         return dx, dg, db, None, None
 
 
@@ -578,6 +647,7 @@ class FfnSublayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, scale, p, eps):
         x = x.contiguous()
+        ctx.chain = _chain_take(x)
         rows, D = _rows(x), x.shape[-1]
         Fh = w1.shape[0]
         T = act_dtype()
@@ -590,6 +660,7 @@ class FfnSublayerFn(torch.autograd.Function):
         _gemm_nt(u, w2, rows, D, Fh, y, bias=b2, drop_p=p2, seed=s2, seed_dev=sd2, alpha=scale, resid=x, ldr=D)
         ctx.save_for_backward(x, ln_w, mean, rstd, h, u, w1, w2)
         ctx.meta = (scale, p1, p2, s2, sd2)
+        _chain_tag(y, rows, D, scale, (p2, s2, sd2))
         return y
 
     @staticmethod
@@ -613,7 +684,7 @@ class FfnSublayerFn(torch.autograd.Function):
             _gemm_nn(du, w1, rows, D, Fh, dh)
         dg = _zeros(D, x.device)
         dbt = _zeros(D, x.device)
-        dx = ops.layernorm_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dres=dy)
+        dx = _ln_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dy, ctx.chain)
         return dx, dg, dbt, dw1, db1, dw2, db2, None, None, None
 
 
@@ -824,6 +895,7 @@ class MhaSublayerFn(torch.autograd.Function):
     def forward(ctx, x, memory, pos_emb, mask, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, wpos, bias_u, bias_v, H,
                 p_attn, p_out, eps):
         x = x.contiguous()
+        ctx.chain = _chain_take(x)
         B, Tq, D = x.shape
         dk = D // H
         T = act_dtype()
@@ -867,6 +939,7 @@ class MhaSublayerFn(torch.autograd.Function):
         ctx.save_for_backward(x, ln_w, mean, rstd, h, ka if cross else None, pe, m, wq, wk, wv, wo, wpos, qu, qv, k4, v4,
                               pproj, ctxv, lse)
         ctx.meta = (H, pa, sa, sda, po, so, sdo, cross, relpos, fused)
+        _chain_tag(y, B * Tq, D, 1.0, (po, so, sdo))
         return y
 
     @staticmethod
@@ -954,7 +1027,7 @@ class MhaSublayerFn(torch.autograd.Function):
                     _gemm_nn(dv2, wv, B * Tq, D, D, dh, resid=t2, ldr=D)
         dg = _zeros(D, x.device)
         dbt = _zeros(D, x.device)
-        dx = ops.layernorm_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dres=dy)
+        dx = _ln_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dy, ctx.chain)
         return (dx, dmem, None, None, dg, dbt, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dwpos, du, dv_bias, None, None,
                 None, None)
 
@@ -1032,6 +1105,7 @@ class ConvSublayerFn(torch.autograd.Function):
         K = w_dw.shape[-1]
         T = act_dtype()
         fused = ln_w is not None  # False: bare ConvolutionModule.forward (no LayerNorm, no residual)
+        ctx.chain = _chain_take(x) if fused else None
         if fused:
             h, mean, rstd = ops.layernorm_fwd(x, ln_w, ln_b, T, eps)
         else:
@@ -1053,6 +1127,8 @@ class ConvSublayerFn(torch.autograd.Function):
                  resid=x if fused else None, ldr=D)
         ctx.save_for_backward(x, ln_w, mean, rstd, h, a, gl, c, bmean, binv, bn_w, bn_b, s, w_pw1, wdw, w_pw2, counts)
         ctx.meta = (training, po, so, sdo, K, fused)
+        if fused:
+            _chain_tag(y, rows, D, 1.0, (po, so, sdo))
         return y
 
     @staticmethod
@@ -1088,7 +1164,7 @@ class ConvSublayerFn(torch.autograd.Function):
                 _gemm_nn(da, w_pw1.view(2 * D, D), rows, D, 2 * D, dh)
             dg = _zeros(D, x.device)
             dbt = _zeros(D, x.device)
-            dx = ops.layernorm_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dres=dy)
+            dx = _ln_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dy, ctx.chain)
         else:
             dg = dbt = None
             dx = torch.empty(B, Tn, D, dtype=torch.float32, device=x.device)

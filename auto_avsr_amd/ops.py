@@ -101,11 +101,15 @@ def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-12):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, gout=None, gsum=None, alpha=1.0, drop_p=0.0,
+                  seed=0, seed_dev=None):
+    """gout (bf16, same shape as x) / gsum (f32 [cols], zero-initialised): also emit bf16(alpha * dropout(dx)) and its
+    column sums -- the backward prologue of the Linear that consumes dx."""
     rows, cols = x.numel() // x.shape[-1], x.shape[-1]
     dx = torch.empty_like(x)
     call("avsr_layernorm_bwd", _ptr(dy), dt(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres),
-         _ptr(dx), _ptr(dgamma), _ptr(dbeta), rows, cols, _stream(x))
+         _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(gout), _ptr(gsum), alpha, drop_p, seed, _ptr(seed_dev), rows, cols,
+         _stream(x))
     return dx
 
 

@@ -35,10 +35,15 @@ const char* avsr_last_error(void);
 int avsr_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype,
                        float* mean, float* rstd, int rows, int cols, float eps,
                        avsr_stream_t stream);
-/* dx = LN'(dy) (+ dres if non-null); dgamma/dbeta are accumulated into */
+/* dx = LN'(dy) (+ dres if non-null); dgamma/dbeta are accumulated into.
+ * gout (bf16 [rows][cols], may be NULL) = bf16(alpha * dropout(dx)) and gsum (f32 [cols], may be NULL; accumulated into)
+ * += column sums of gout: the backward prologue of the Linear whose output gradient dx is -- the output projection of the
+ * PREVIOUS pre-LN sub-layer (conformer_encoder.py:110-159: x + ff_scale * dropout(ff(LN(x))) etc.), fused here so that
+ * no separate cast / bias-gradient pass re-reads dx.  Dropout stream = avsr_cast_transpose_colsum's. */
 int avsr_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma,
                        const float* mean, const float* rstd, const float* dres, float* dx,
-                       float* dgamma, float* dbeta, int rows, int cols, avsr_stream_t stream);
+                       float* dgamma, float* dbeta, void* gout, float* gsum, float alpha, float drop_p, uint64_t seed,
+                       const uint64_t* seed_dev, int rows, int cols, avsr_stream_t stream);
 
 /* ---- MFMA GEMM family (Linear / pointwise conv and their gradients) ---------------------- */
 /* C[M,N] = epi(sum_k A[m,k]*B[n,k]);  layout 0 "NT": A [M][K], B [N][K] (Linear forward, B = weight)

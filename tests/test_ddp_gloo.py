@@ -242,3 +242,30 @@ def test_ddp_bench_configuration(emu_lib_path, tmp_path):
     mp.spawn(_worker_bench_like, args=(2, port, emu_lib_path, str(tmp_path)), nprocs=2, join=True)
     res = torch.load(os.path.join(tmp_path, "bench_like.pt"))
     assert res["ok"] and res["step"] == 2
+
+
+def test_bench_main_two_ranks(emu_lib_path, tmp_path):
+    """bench.py's own main(), launched exactly as the driver launches it for N = 2 (`python -m torch.distributed.run
+    --nproc-per-node 2 ... bench.py --gpus 2 ...`), on two CPU processes: gloo instead of RCCL, kernels through the host
+    emulator, a small instance of the same model (AVSR_BENCH_SELFTEST, a test-suite-only hook in bench.py).  Executes the
+    whole N > 1 control flow -- process group, cross-rank BatchNorm, DDP buckets, W / sum(B) rescale, barriers,
+    max-over-ranks timing, the rank-0 JSON line -- and checks the contract fields of that line."""
+    import json
+    import subprocess
+
+    cfg = {"emu": emu_lib_path, "odim": 41, "lengths": [5, 6, 5, 6, 7, 5, 6, 7],
+           "model": dict(adim=128, aheads=2, eunits=128, elayers=1, dunits=128, dlayers=1, cnn_module_kernel=7)}
+    env = dict(os.environ, AVSR_BENCH_SELFTEST=json.dumps(cfg), OMP_NUM_THREADS="2")
+    port = 35500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--max-frames", "12", "--shapes", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["value"] > 0 and out["ms_per_step"] > 0 and out["higher_is_better"] is True
+    assert "DDP grad all-reduce + SyncBN" in out["config"]["workload"] and "eager launches" in out["config"]["workload"]
+    assert out["config"]["final_loss"] == out["config"]["final_loss"]  # finite

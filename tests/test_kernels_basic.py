@@ -32,6 +32,38 @@ def test_layernorm_fwd_bwd(dev):
     assert (dx2.cpu() - xr.grad).abs().max() < 0.05
 
 
+@pytest.mark.parametrize("rows", [37, 1100])
+def test_layernorm_bwd_fused_prologue(dev, rows):
+    """avsr_layernorm_bwd gout / gsum: the consumer Linear's backward prologue (bf16(alpha * dropout(dx)) and its column
+    sums) produced in the LayerNorm backward pass must equal what the separate avsr_cast_transpose_colsum pass makes of the
+    same dx -- same dropout stream, same rounding -- and leave dx / dgamma / dbeta untouched.  rows = 1100: two rows per
+    wave."""
+    torch.manual_seed(1)
+    cols = 768
+    x, g, b = torch.randn(rows, cols), torch.randn(cols), torch.randn(cols)
+    dy, dres = torch.randn(rows, cols), torch.randn(rows, cols)
+    xd, gd, bd, dyd, dresd = (t.to(dev) for t in (x, g, b, dy.bfloat16(), dres))
+    _, mean, rstd = ops.layernorm_fwd(xd, gd, bd, torch.float32)
+    dg0, db0 = torch.zeros(cols, device=dev), torch.zeros(cols, device=dev)
+    dx0 = ops.layernorm_bwd(dyd, xd, gd, mean, rstd, dg0, db0, dres=dresd)
+    for (alpha, p, seed) in ((0.5, 0.1, 1234567), (1.0, 0.0, 0)):
+        cs0 = torch.zeros(cols, device=dev)
+        want, _ = ops.cast_transpose_colsum(dx0, rows, cols, want_dst=True, want_T=False, colsum=cs0, alpha=alpha, drop_p=p,
+                                            seed=seed)
+        dg1, db1, cs1 = torch.zeros(cols, device=dev), torch.zeros(cols, device=dev), torch.zeros(cols, device=dev)
+        gout = torch.empty(rows, cols, dtype=torch.bfloat16, device=dev)
+        dx1 = ops.layernorm_bwd(dyd, xd, gd, mean, rstd, dg1, db1, dres=dresd, gout=gout, gsum=cs1, alpha=alpha, drop_p=p,
+                                seed=seed)
+        assert torch.equal(dx1, dx0)
+        assert torch.equal(gout, want)
+        assert (cs1 - cs0).abs().max() <= 1e-4 * max(1.0, float(cs0.abs().max()))
+        assert (dg1 - dg0).abs().max() <= 1e-4 * max(1.0, float(dg0.abs().max()))
+        assert (db1 - db0).abs().max() <= 1e-4 * max(1.0, float(db0.abs().max()))
+        if p > 0:
+            frac = float((gout == 0).float().mean())
+            assert 0.05 < frac < 0.15
+
+
 def _pad(t):
     r, c = t.shape
     c8 = (c + 7) // 8 * 8 + 8

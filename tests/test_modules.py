@@ -278,3 +278,53 @@ def test_stem_fused_pool_switch_equivalence(dev):
     for k in g0:
         # bf16 mode: the fused path skips one bf16 rounding of the stem's activation gradient
         assert rel(g1[k], g0[k]) < 1e-2 or float(g0[k].abs().max()) < 1e-7, k
+
+
+def test_residual_gradient_handoff_equivalence(dev):
+    """The backward prologue of a sub-layer's output Linear produced inside the NEXT sub-layer's LayerNorm backward
+    (functional._chain_*) vs the stand-alone cast / column-sum launch: same gradients (dropout ON -- both paths must draw
+    the same masks), and the stand-alone launch really is gone from the encoder / decoder sub-layer chains."""
+    from auto_avsr_amd import ops
+
+    was_precise, was_chain = AF._state["precise"], AF._CHAIN
+    odim = 40
+    res, counts = [], []
+    orig = ops.cast_transpose_colsum
+    try:
+        AF.set_precise(False)
+        for chain in (False, True):
+            AF._CHAIN = chain
+            AF.invalidate_weight_cache()
+            AF.new_step()
+            AF.manual_seed(77)
+            torch.manual_seed(0)
+            m = E2E(odim, "video", adim=128, aheads=2, eunits=128, elayers=2, dunits=128, dlayers=2, cnn_module_kernel=7)
+            m.load_state_dict(synth_state_dict(m.state_dict(), 5), strict=True)
+            m.to(dev).train()  # dropout 0.1 active
+            x, lengths, y = (t.to(dev) for t in synth_batch("video", 2, 9, 3, odim, seed=4))
+            n = [0]
+
+            def counting(src, R, C, **kw):
+                if kw.get("want_dst") and src.dtype == torch.float32 and kw.get("colsum") is not None:
+                    n[0] += 1
+                return orig(src, R, C, **kw)
+
+            ops.cast_transpose_colsum = counting
+            loss, loss_ctc, loss_att, _ = m(x, lengths, y)
+            loss.backward()
+            ops.cast_transpose_colsum = orig
+            counts.append(n[0])
+            res.append((float(loss.detach()), {k: p.grad.float().cpu().clone() for k, p in m.named_parameters()}))
+    finally:
+        ops.cast_transpose_colsum = orig
+        AF._CHAIN = was_chain
+        AF.set_precise(was_precise)
+        AF.invalidate_weight_cache()
+        AF.new_step()
+    (l0, g0), (l1, g1) = res
+    assert l0 == l1
+    # 2 encoder layers x 4 sub-layers + 2 decoder layers x 3 = 14 f32 prologues without the hand-off; with it only the
+    # first sub-layer after a non-LayerNorm consumer... none: every sub-layer output feeds a LayerNorm
+    assert counts[0] - counts[1] >= 12, counts
+    for k in g0:
+        assert rel(g1[k], g0[k]) < 1e-5 or float(g0[k].abs().max()) < 1e-7, k

@@ -1,0 +1,5 @@
+#!/bin/bash
+mkdir -p gpurun_out; cd /root/repo; export TMPDIR=/tmp
+timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/c7_tests.log 2>&1; tail -2 gpurun_out/c7_tests.log
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-parity > gpurun_out/c7_bench.log 2>&1; tail -1 gpurun_out/c7_bench.log | cut -c100-260
+AVSR_CHAIN_PROLOGUE=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-parity > gpurun_out/c7_bench_nochain.log 2>&1; tail -1 gpurun_out/c7_bench_nochain.log | cut -c100-260
