@@ -49,12 +49,15 @@ zeros_f32 = lambda shape, device: torch.zeros(shape, dtype=torch.float32, device
 
 
 PROFILE = None  # bench.py: list collecting (entry point, start event, end event, flops) per launch
-RECORD = None   # bench.py: (entry point, list) -- the argument tuples of every launch of that entry point
+RECORD = None   # bench.py: (entry points, list) -- the argument tuples of every launch of those entry points
+TRACE = None    # tools/pmc_step.py: list collecting (entry point, algorithmic flops, algorithmic bytes) of every launch
 
 
 def call(name, *args, flops=0.0, nbytes=0.0):
     """flops / nbytes: ALGORITHMIC work of the launch (2 * MACs; every operand read once + every result written once),
     recorded by bench.py's roofline hooks."""
+    if TRACE is not None:
+        TRACE.append((name, flops, nbytes))
     if RECORD is not None and name in RECORD[0]:
         RECORD[1].append((name, args, flops, nbytes))
     if PROFILE is None:
@@ -97,7 +100,7 @@ def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-12):
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
     call("avsr_layernorm_fwd", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), dt(y), _ptr(mean), _ptr(rstd),
-         rows, cols, eps, _stream(x))
+         rows, cols, eps, _stream(x), nbytes=_nb(x, y))
     return y, mean, rstd
 
 
@@ -109,7 +112,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, gout=None,
     dx = torch.empty_like(x)
     call("avsr_layernorm_bwd", _ptr(dy), dt(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres),
          _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(gout), _ptr(gsum), alpha, drop_p, seed, _ptr(seed_dev), rows, cols,
-         _stream(x))
+         _stream(x), nbytes=_nb(dy, x, dres, dx, gout))
     return dx
 
 
@@ -235,12 +238,12 @@ def glu_bwd(a, dg, rows, C):
 
 def dwconv(x, w, bias, B, T, C, K, flip=False):
     y = torch.empty(B, T, C, dtype=x.dtype, device=x.device)
-    call("avsr_dwconv_fwd", _ptr(x), dt(x), _ptr(w), _ptr(bias), _ptr(y), B, T, C, K, int(flip), _stream(x))
+    call("avsr_dwconv_fwd", _ptr(x), dt(x), _ptr(w), _ptr(bias), _ptr(y), B, T, C, K, int(flip), _stream(x), nbytes=_nb(x, y))
     return y
 
 
 def dwconv_wgrad(x, dy, dw, db, B, T, C, K):
-    call("avsr_dwconv_wgrad", _ptr(x), _ptr(dy), dt(x), _ptr(dw), _ptr(db), B, T, C, K, _stream(x))
+    call("avsr_dwconv_wgrad", _ptr(x), _ptr(dy), dt(x), _ptr(dw), _ptr(db), B, T, C, K, _stream(x), nbytes=_nb(x, dy))
 
 
 def bn_stats(x, rows, C, with_count=False):
@@ -442,7 +445,8 @@ def conv2d_fwd(x, wp, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise):
     y = torch.empty(N, OH, OW, Cout, dtype=x.dtype, device=x.device)
     if not precise and x.dtype == torch.bfloat16 and wp.dtype == torch.bfloat16 and Cin % 64 == 0 and stride <= 2:
         call("avsr_conv2d_bf16", 0, _ptr(x), _ptr(wp), None, _ptr(y), _ptr(zero_page(x.device)), N, H, W, Cin, Cout, KH,
-             KW, stride, ph, pw, _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin)
+             KW, stride, ph, pw, _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin,
+             nbytes=_nb(x, wp) + 2.0 * N * OH * OW * Cout)
         return y
     call("avsr_conv2d_fwd", _ptr(x), dt(x), _ptr(wp), dt(wp), _ptr(y), N, H, W, Cin, Cout, KH, KW, stride, ph, pw,
          int(precise), _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin)
@@ -453,7 +457,8 @@ def conv2d_dgrad(dy, wpd, resid, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, pre
     dx = torch.empty(N, H, W, Cin, dtype=dy.dtype, device=dy.device)
     if not precise and dy.dtype == torch.bfloat16 and wpd.dtype == torch.bfloat16 and Cout % 64 == 0 and stride <= 2:
         call("avsr_conv2d_bf16", 1, _ptr(dy), _ptr(wpd), _ptr(resid), _ptr(dx), _ptr(zero_page(dy.device)), N, H, W, Cin,
-             Cout, KH, KW, stride, ph, pw, _stream(dy), flops=2.0 * N * H * W * Cin * KH * KW * Cout)
+             Cout, KH, KW, stride, ph, pw, _stream(dy), flops=2.0 * N * H * W * Cin * KH * KW * Cout,
+             nbytes=_nb(dy, wpd, resid) + 2.0 * N * H * W * Cin)
         return dx
     call("avsr_conv2d_dgrad", _ptr(dy), dt(dy), _ptr(wpd), dt(wpd), _ptr(resid), _ptr(dx), N, H, W, Cin, Cout, KH, KW,
          stride, ph, pw, int(precise), _stream(dy), flops=2.0 * N * H * W * Cin * KH * KW * Cout)
@@ -471,14 +476,15 @@ def conv2d_wgrad(dy, x, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise, tor
         nws = call("avsr_conv3x3_wgrad_workspace_bytes", N, H, W, Cin, Cout, stride)
         ws = torch.empty(nws // 4, dtype=torch.float32, device=x.device)
         call("avsr_conv3x3_wgrad_bf16", _ptr(dy), _ptr(x), _ptr(dwp), _ptr(zero_page(x.device)), _ptr(ws), nws, N, H, W, Cin,
-             Cout, stride, int(torch_layout), _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin)
+             Cout, stride, int(torch_layout), _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin,
+             nbytes=_nb(dy, x, dwp))
         return dwp
     if torch_layout:
         return conv_weight_unpermute(conv2d_wgrad(dy, x, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise), (Cout, Cin, KH, KW))
     dwp = torch.zeros(Cout, KH * KW * Cin, dtype=torch.float32, device=x.device)
     if bf and Cin % 64 == 0 and Cout % 8 == 0:
         call("avsr_conv2d_wgrad_bf16", _ptr(dy), _ptr(x), _ptr(dwp), _ptr(zero_page(x.device)), N, H, W, Cin, Cout, KH,
-             KW, stride, ph, pw, _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin)
+             KW, stride, ph, pw, _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin, nbytes=_nb(dy, x, dwp))
         return dwp
     call("avsr_conv2d_wgrad", _ptr(dy), _ptr(x), dt(x), _ptr(dwp), N, H, W, Cin, Cout, KH, KW, stride, ph, pw,
          int(precise), _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin)
@@ -505,13 +511,13 @@ def maxpool2d_fwd(x, N, H, W, C, K, S, P):
     OH, OW = conv_out(H, K, S, P), conv_out(W, K, S, P)
     y = torch.empty(N, OH, OW, C, dtype=x.dtype, device=x.device)
     idx = torch.empty(N, OH, OW, C, dtype=torch.uint8, device=x.device)
-    call("avsr_maxpool2d_fwd", _ptr(x), _ptr(y), _ptr(idx), dt(x), N, H, W, C, K, S, P, _stream(x))
+    call("avsr_maxpool2d_fwd", _ptr(x), _ptr(y), _ptr(idx), dt(x), N, H, W, C, K, S, P, _stream(x), nbytes=_nb(x, y, idx))
     return y, idx
 
 
 def maxpool2d_bwd(idx, dy, N, H, W, C, K, S, P):
     dx = torch.empty(N, H, W, C, dtype=dy.dtype, device=dy.device)
-    call("avsr_maxpool2d_bwd", _ptr(idx), _ptr(dy), _ptr(dx), dt(dy), N, H, W, C, K, S, P, _stream(dy))
+    call("avsr_maxpool2d_bwd", _ptr(idx), _ptr(dy), _ptr(dx), dt(dy), N, H, W, C, K, S, P, _stream(dy), nbytes=_nb(idx, dy, dx))
     return dx
 
 
@@ -582,7 +588,7 @@ def stem357_fwd(x, w, B, T, H, W):
     y = torch.empty(B * T, OH, OW, 64, dtype=torch.bfloat16, device=x.device)
     ws = torch.empty(call("avsr_stem357_workspace_bytes") // 4 + 16, dtype=torch.float32, device=x.device)
     call("avsr_stem357_fwd", _ptr(x), _ptr(w), _ptr(y), _ptr(ws), B, T, H, W, _stream(x),
-         flops=2.0 * B * T * OH * OW * 64 * 245)
+         flops=2.0 * B * T * OH * OW * 64 * 245, nbytes=_nb(x, y))
     return y
 
 
@@ -591,12 +597,12 @@ def stem357_wgrad(dy, x, B, T, H, W):
     ws = torch.empty(call("avsr_stem357_workspace_bytes") // 4 + 16, dtype=torch.float32, device=x.device)
     OH, OW = conv_out(H, 7, 2, 3), conv_out(W, 7, 2, 3)
     call("avsr_stem357_wgrad", _ptr(dy), _ptr(x), _ptr(dw), _ptr(ws), B, T, H, W, _stream(x),
-         flops=2.0 * B * T * OH * OW * 64 * 245)
+         flops=2.0 * B * T * OH * OW * 64 * 245, nbytes=_nb(dy, x))
     return dw
 
 
 def gemm_bf16_tn(A, lda, B, ldb, M, N, K, C, ldc, *, accumulate=False, split_k=1):
     """C[M,N] (f32) (+)= A[K,M]^T B[K,N], bf16 operands with the contraction index as the slow dimension."""
     call("avsr_gemm_bf16_tn", _ptr(A), lda, _ptr(B), ldb, M, N, K, _ptr(C), ldc, int(accumulate), split_k,
-         _ptr(zero_page(A.device)), _stream(A), flops=2.0 * M * N * K)
+         _ptr(zero_page(A.device)), _stream(A), flops=2.0 * M * N * K, nbytes=2.0 * K * (M + N) + 4.0 * M * N)
     return C

@@ -137,7 +137,7 @@ class FusedAdamW:
         if plan is None:
             ops.call("avsr_adamw_step", ops._ptr(table), n, blk, ops._ptr(partial), ops._ptr(self.state), self.lr,
                      self.betas[0], self.betas[1], self.eps, self.weight_decay, self.max_grad_norm, self.warmup_steps,
-                     self.total_steps, ops._stream(table))
+                     self.total_steps, ops._stream(table), nbytes=self._algo_bytes(False))
             self._note_stale(AF, False)  # parameters changed behind `_version`: their cached bf16 copies are stale
             return
 
@@ -146,9 +146,16 @@ class FusedAdamW:
         lin_ptr, tile_ptr = base + 48 * n, base + 48 * n + 48 * len(lin)
         ops.call("avsr_adamw_cast_step", base, n, blk, lin_ptr, len(lin), lin_blk, tile_ptr, len(trow), tile_blk,
                  ops._ptr(partial), ops._ptr(self.state), self.lr, self.betas[0], self.betas[1], self.eps,
-                 self.weight_decay, self.max_grad_norm, self.warmup_steps, self.total_steps, ops._stream(table))
+                 self.weight_decay, self.max_grad_norm, self.warmup_steps, self.total_steps, ops._stream(table),
+                 nbytes=self._algo_bytes(True))
         AF.claim_weight_casts(self, gen)  # refresh_weight_cache() now has nothing to do for the Linear copies
         self._note_stale(AF, True)        # ... but the conv-weight permutes are stale until it runs
+
+    def _algo_bytes(self, cast):
+        """Algorithmic HBM bytes of one step: the norm pass reads every gradient (4 B), the update reads p, g, m, v and
+        writes p, m, v (28 B); with cast_weights each Linear weight also gets its two bf16 copies written (4 B)."""
+        n = float(sum(p.numel() for p in self.params))
+        return 32.0 * n + (4.0 * n if cast else 0.0)
 
     def _note_stale(self, AF, linear_rewritten):
         """Tell the weight cache which of its copies this step left behind (only copies of OUR parameters count)."""

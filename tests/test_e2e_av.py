@@ -1,6 +1,6 @@
 """Audio-visual composition (auto_avsr_amd/e2e_av.py; no counterpart in the reference snapshot) against the
 composition of the reference-pinned oracle parts (oracle/avsr_oracle.py: e2e_av_forward), precise mode, dropout off.
-Runs on the emulator build in the CPU suite (the model only re-uses kernels that the -m gpu tests cover through E2E)."""
+Runs on the emulator build in the CPU suite and on the MI355X in the GPU suite."""
 import os
 import sys
 
@@ -17,8 +17,7 @@ from auto_avsr_amd import functional as AF  # noqa: E402
 from auto_avsr_amd.e2e_av import E2EAV  # noqa: E402
 
 
-def test_e2e_av_small_vs_oracle_composition(emu_lib_path):
-    _lib._install_for_tests(emu_lib_path)
+def test_e2e_av_small_vs_oracle_composition(dev):
     was_precise = AF._state["precise"]
     AF.set_precise(True)
     AF.invalidate_weight_cache()
@@ -31,14 +30,14 @@ def test_e2e_av_small_vs_oracle_composition(emu_lib_path):
                 mod.p = 0.0
         sd = synth_state_dict(m.state_dict(), 17)
         m.load_state_dict(sd, strict=True)
-        m.train()
+        m.to(dev).train()
         video, lengths, y = synth_batch("video", 2, 6, 3, odim, seed=4)
         audio, _, _ = synth_batch("audio", 2, 6, 3, odim, seed=5)
         osd = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running_" not in k else v.clone())
                for k, v in sd.items()}
         (loss_r, ctc_r, att_r, acc_r), _ = O.e2e_av_forward(osd, video, audio, lengths, y, heads=2)
         loss_r.backward()
-        loss, loss_ctc, loss_att, acc = m(video, audio, lengths, y)
+        loss, loss_ctc, loss_att, acc = m(video.to(dev), audio.to(dev), lengths.to(dev), y.to(dev))
         loss.backward()
         assert abs(float(loss_ctc) - float(ctc_r)) < 1e-3 * abs(float(ctc_r))
         assert abs(float(loss_att) - float(att_r)) < 1e-3 * abs(float(att_r))

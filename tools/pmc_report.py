@@ -45,6 +45,22 @@ def load(path, counter):
     return rows
 
 
+# kernel families: (label, regex over rocprofv3 kernel names, C-ABI entry points whose launches they are)
+FAMILIES = [
+    ("transformer GEMMs (Linear fwd / dgrad NT, wgrad TN, paired launches)", r"^(gemm_fast_kernel<\d+, \d+, \d+, 0,|gemm_pair_kernel|gemm_tn_fast_kernel<3, 0>)",
+     ("avsr_gemm_bf16_nt", "avsr_gemm_bf16_tn")),
+    ("ResNet conv fwd / dgrad (implicit GEMM)", r"^gemm_fast_kernel<\d+, \d+, \d+, [12],", ("avsr_conv2d_bf16",)),
+    ("ResNet 3x3 conv wgrad", r"^(conv3x3_wgrad_kernel|wgrad_reduce_kernel)", ("avsr_conv3x3_wgrad_bf16",)),
+    ("BatchNorm passes", r"^bn_", ("avsr_bn_stats", "avsr_bn_stats_finalize", "avsr_bn_act_fwd", "avsr_bn_bwd_reduce", "avsr_bn_bwd_apply",
+                                  "avsr_bn_act_pool_fwd", "avsr_bn_pool_bwd_reduce", "avsr_bn_pool_bwd_apply")),
+    ("LayerNorm fwd / bwd", r"^layernorm_", ("avsr_layernorm_fwd", "avsr_layernorm_bwd")),
+    ("optimizer (clip + AdamW + bf16 weight copies)", r"^(multi_adamw|multi_sumsq|clip_coef)", ("avsr_adamw_step", "avsr_adamw_cast_step")),
+    ("video stem conv fwd / wgrad", r"^stem_", ("avsr_stem357_fwd", "avsr_stem357_wgrad")),
+    ("depthwise conv fwd / dgrad / wgrad", r"^dwconv_", ("avsr_dwconv_fwd", "avsr_dwconv_wgrad")),
+    ("max-pool fwd / bwd", r"^maxpool_", ("avsr_maxpool2d_fwd", "avsr_maxpool2d_bwd")),
+]
+
+
 def split(rows):
     """(calibration rows, step rows)."""
     big = [i for i, r in enumerate(rows) if r[0].startswith("scale_dropout_kernel<float, float>") and r[3] >= (1 << 20)]
@@ -85,6 +101,24 @@ def main():
              f"FETCH_SIZE count = {kf:.1f} B (guide: nominal 1024 B, x2 under-report on gfx950), WRITE_SIZE count = {kw:.1f} B")
     L.append(f"step total: read {tot_rd / 1e9:.2f} GB, written {tot_wr / 1e9:.2f} GB -> {(tot_rd + tot_wr) / tot_us / 1e6:.2f} TB/s "
              f"averaged over kernel time (HBM peak 8 TB/s)")
+    entries = step_info.get("entries", {})
+    if entries:
+        L.append("")
+        L.append("per kernel family: algorithmic bytes (every operand read once + every result written once, from the binding layer) "
+                 "vs counter bytes")
+        L.append(f"{'launches':>8} {'tot_ms':>7} {'algo_MB':>9} {'counter_MB':>10} {'cnt/algo':>8} {'algo TB/s':>9} {'cnt TB/s':>8} {'TFLOP/s':>8}  family")
+        L.append("-" * 140)
+        for label, pat, ents in FAMILIES:
+            ks = [n for n in agg if re.search(pat, n)]
+            if not ks:
+                continue
+            n = sum(agg[k][0] for k in ks)
+            us = sum(agg[k][1] for k in ks)
+            cnt = sum(agg[k][2] + agg[k][3] for k in ks)
+            al = sum(entries[e]["bytes"] for e in ents if e in entries)
+            fl = sum(entries[e]["flops"] for e in ents if e in entries)
+            L.append(f"{n:8d} {us / 1e3:7.3f} {al / 1e6:9.1f} {cnt / 1e6:10.1f} {(cnt / al if al else float('nan')):8.2f} "
+                     f"{al / us / 1e6:9.2f} {cnt / us / 1e6:8.2f} {fl / us / 1e6:8.1f}  {label}")
     L.append("")
     L.append(f"{'calls':>5} {'avg_us':>8} {'tot_ms':>7} {'rd_MB':>9} {'wr_MB':>9} {'TB/s':>6} {'algo_MB':>9} {'cnt/algo':>8}  kernel")
     L.append("-" * 140)

@@ -72,5 +72,22 @@ ops.sum_scale(mark, 1.0)
 loss = step()
 ops.sum_scale(mark, 1.0)
 torch.cuda.synchronize()
-print(json.dumps({"B": int(x.shape[0]), "T": int(x.shape[1]), "L": int(y.shape[2]), "real_frames": int(frames),
-                  "loss": float(loss.detach())}))
+# ---- algorithmic work per C-ABI entry point of the same step (one more step, after the counters' region)
+ops.TRACE = []
+step()
+torch.cuda.synchronize()
+trace, ops.TRACE = ops.TRACE, None
+per_entry = {}
+for name, fl, nb in trace:
+    e = per_entry.setdefault(name, [0, 0.0, 0.0])
+    e[0] += 1
+    e[1] += fl
+    e[2] += nb
+info = {"B": int(x.shape[0]), "T": int(x.shape[1]), "L": int(y.shape[2]), "real_frames": int(frames),
+        "loss": float(loss.detach()),
+        "shape": f"video, B={int(x.shape[0])} T={int(x.shape[1])} L={int(y.shape[2])}, {int(frames)} real frames, bf16 mode, "
+                 "full training step (fwd + bwd + clip + AdamW), eager launches",
+        "entries": {k: {"calls": v[0], "flops": v[1], "bytes": v[2]} for k, v in per_entry.items()}}
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(info, open(os.environ.get("AVSR_PMC_INFO", "gpurun_out/pmc_step_info.json"), "w"), indent=1)
+print(json.dumps({k: info[k] for k in ("B", "T", "L", "real_frames", "loss")}))

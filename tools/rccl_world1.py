@@ -142,7 +142,8 @@ try:
     AF.refresh_weight_cache()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    # thread-local capture mode: the process group's watchdog thread queries events while we capture
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
         gl = step()
     before = [p.detach().clone() for p in m1.parameters()]
     for _ in range(2):
