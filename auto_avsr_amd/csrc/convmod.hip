@@ -127,7 +127,7 @@ extern "C" int avsr_dwconv_wgrad(const void* x, const void* dy, int dtype, float
     const int items = B * ((T + DW_TW - 1) / DW_TW), cblocks = (C + DW_CH - 1) / DW_CH;
     int chunks = (512 + cblocks - 1) / cblocks;  // about two blocks per CU, a few items each
     if (chunks > items) chunks = items;
-    if (chunks > 16) chunks = 16;
+    if (chunks > 16) chunks = 16;  // more, smaller blocks were measured slower (43 chunks: 31 -> 49 us): the per-block atomics dominate
     dim3 grid(cblocks, chunks), block(256);
     if (dtype == 0)
         AVSR_LAUNCH((dwconv_wgrad_kernel<float>), grid, block, 0, stream, (const float*)x, (const float*)dy, dw, db, B, T, C, K);

@@ -68,6 +68,8 @@ struct Params {
     // gradient is split into (row grid cls_h x cls_w starting at pixel (cls_y0, cls_x0) with step cS; taps
     // kh = cls_py + cS*i, kw = cls_px + cS*j; m-tiles [cls_tile0[c], cls_tile0[c+1]))
     float* colsum;  // LDS epilogue, non-accumulating outputs: colsum[n] += sum_m of the stored value (bias gradients)
+    float* colsum_a;  // TN tile kernel only: colsum_a[m] += sum_k A[k][m] -- the bias gradient of the Linear whose weight
+                      // gradient this contraction is (A = its output gradient), taken from the staged A tiles
     int cN, xcd_order, ncls;
     int cls_tile0[5], cls_py[4], cls_px[4], cls_y0[4], cls_x0[4], cls_h[4], cls_w[4], cls_nkh[4], cls_nkw[4];
 };

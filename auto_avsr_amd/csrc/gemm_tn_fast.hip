@@ -36,8 +36,9 @@ void launch_tn(Params& p, int split_k, hipStream_t stream) {
 }  // namespace
 
 // C[M][N] (f32; accumulate: atomicAdd into, else overwrite -- split_k > 1 needs accumulate) = sum_k A[k][m] B[k][n]
+// colsum_a (f32 [M], may be NULL; accumulated into): += sum_k A[k][m]
 extern "C" int avsr_gemm_bf16_tn(const void* A, int lda, const void* B, int ldb, int M, int N, int K, float* C, int ldc,
-                                 int accumulate, int split_k, const void* zero_page, hipStream_t stream) {
+                                 int accumulate, int split_k, const void* zero_page, float* colsum_a, hipStream_t stream) {
     AVSR_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && M % 8 == 0 && N % 8 == 0, "gemm_bf16_tn: M, N, lda, ldb must be multiples of 8");
     AVSR_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "gemm_bf16_tn: operands must be 16-byte aligned");
     AVSR_REQUIRE(zero_page != nullptr, "gemm_bf16_tn: zero page required");
@@ -47,6 +48,7 @@ extern "C" int avsr_gemm_bf16_tn(const void* A, int lda, const void* B, int ldb,
     p.A = A; p.B = B; p.lda = lda; p.ldb = ldb; p.M = M; p.N = N; p.K = K;
     p.alpha = 1.f; p.gate_scale = 1.f; p.gate = zero_page;
     p.C = C; p.c_dtype = 0; p.ldc = ldc; p.accumulate = accumulate;
+    p.colsum_a = colsum_a;
     p.nsplit = 1; p.batch_h = 1; p.nbatch = 1;
     if (avsr_pair::stash_tn(p, split_k, stream)) return 0;  // launched by avsr_gemm_pair_end (gemm_pair.hip)
     launch_tn<0>(p, split_k, stream);

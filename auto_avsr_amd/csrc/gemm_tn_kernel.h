@@ -75,6 +75,12 @@ struct TnKernel {
         f32x16 acc[1][1];
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[0][0][r] = 0.f;
+        // Bias gradient on the side: the blocks of the first n-tile column also sum the A tiles they stage over k (each wave
+        // 16 of the 64 k-rows, lane = column).  A is the output gradient of the Linear, so this IS colsum(dY) -- no separate
+        // pass over dY.  Read through a generic pointer: an LDS-address-space load would be ordered behind the LDS-DMA of the
+        // tiles still in flight (prims.h).
+        const bool do_cs = CV == 0 && p.colsum_a != nullptr && bx == 0;
+        float cs = 0.f;
 #pragma unroll
         for (int s = 0; s < STAGES - 1; s++)
             if (s < nt) issue(p, A, B, m0, n0, kbeg + s * BK, kend, smem + s * STAGE_BYTES, wave, lane);
@@ -87,6 +93,11 @@ struct TnKernel {
                       wave, lane);
             const char* As = smem + (t % STAGES) * STAGE_BYTES;
             const char* Bs = As + OP_BYTES;
+            if (do_cs) {
+                const bf16_t* col = reinterpret_cast<const bf16_t*>(As) + (wave * 16) * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < 16; r++) cs += bf2f(col[r * 64]);
+            }
             bf16x4 f[2][4];  // two register sets: k-step ks+1 is requested before the MFMA of k-step ks
             frag_async(As, wm * 32, 0, lane, f[0][0], f[0][1]);
             frag_async(Bs, wn * 32, 0, lane, f[0][2], f[0][3]);
@@ -108,6 +119,7 @@ struct TnKernel {
                 sched_fence();
             }
         }
+        if (do_cs && m0 + lane < p.M) atomicAdd(p.colsum_a + m0 + lane, cs);
         Params q = p;
         q.gate = nullptr;  // the field carries the zero page
         avsr_gemm_impl::epilogue_lds<64, 64, 1, 1>(acc, q, m0, n0, wm * 32, wn * 32, zs, 0, smem);

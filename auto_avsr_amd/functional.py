@@ -359,6 +359,7 @@ def new_step():
     _arena.new_step()
     _chain_spec.clear()
     _chain_g.clear()
+    _shared_act.clear()
 
 
 def _zeros(shape, device):
@@ -417,12 +418,12 @@ def _ln_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dres, spec):
         return ops.layernorm_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dres=dres)
     rows, n, alpha, p, sd, sdev = spec
     g = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    db = _zeros(n, x.device)
-    dx = ops.layernorm_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dres=dres, gout=g, gsum=db, alpha=alpha, drop_p=p, seed=sd,
-                           seed_dev=sdev)
+    # (the bias gradient colsum(g) is taken by the weight-gradient GEMM that contracts g, _wgrad(bias_out=...): column sums
+    # out of this kernel cost ~145 k float atomics per launch -- measured +3.5 us on a 9.5 us kernel)
+    dx = ops.layernorm_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dres=dres, gout=g, alpha=alpha, drop_p=p, seed=sd, seed_dev=sdev)
     if len(_chain_g) > 512:
         _chain_g.clear()
-    _chain_g[dx.data_ptr()] = (dx, g, db, spec)
+    _chain_g[dx.data_ptr()] = (dx, g, spec)
     return dx
 
 
@@ -431,10 +432,10 @@ def _chain_prologue(src, rows, n, alpha, drop):
     if ent is None:
         return None
     p, sd, sdev = drop
-    dx, g, db, spec = ent
+    dx, g, spec = ent
     if spec[:5] != (rows, n, float(alpha), float(p), int(sd)) or spec[5] is not sdev or dx.shape != src.shape:
         return None
-    return g.view(rows, n), db
+    return g.view(rows, n)
 
 
 def _prologue(src, rows, n, *, alpha=1.0, drop=(0.0, 0, None), want_dst=True, want_bias=True, ld_src=None):
@@ -442,10 +443,14 @@ def _prologue(src, rows, n, *, alpha=1.0, drop=(0.0, 0, None), want_dst=True, wa
     g = act_dtype(alpha * dropout(src)), g^T (bf16 fast path only, else None) and the bias gradient colsum(g).
     Returns (g or src when no copy was needed, gT, db)."""
     p, sd, sdev = drop
-    if want_dst and want_bias and ld_src is None and not _state["precise"]:
+    if want_dst and ld_src is None and not _state["precise"]:
         hit = _chain_prologue(src, rows, n, alpha, drop)  # already produced by the LayerNorm backward that made `src`
         if hit is not None:
-            return hit[0], None, hit[1]
+            db = None
+            if want_bias:
+                db = _zeros(n, src.device)
+                ops.colsum_into(hit, db, rows, n)
+            return hit, None, db
     db = _zeros(n, src.device) if want_bias else None
     if not _state["precise"]:
         need_dst = want_dst and (src.dtype != torch.bfloat16 or alpha != 1.0 or p > 0 or (ld_src or n) != n)
@@ -464,9 +469,11 @@ def _prologue(src, rows, n, *, alpha=1.0, drop=(0.0, 0, None), want_dst=True, wa
     return g, None, db
 
 
-def _wgrad(dy, x, rows, n_out, n_in, lda=None, ldb=None, xT=None, dyT=None):
+def _wgrad(dy, x, rows, n_out, n_in, lda=None, ldb=None, xT=None, dyT=None, bias_out=None):
     """dW[n_out, n_in] = dy[rows, n_out]^T x[rows, n_in] (f32).  Small outputs are split along the token
-    dimension so that the launch still fills the 256 CUs."""
+    dimension so that the launch still fills the 256 CUs.
+    bias_out (f32 [>= n_out], zero-initialised): also receives colsum(dy) -- the bias gradient of the same Linear -- from
+    the A tiles the tuned kernel stages anyway; on the other paths from a separate column-sum pass."""
     tiles = ((n_out + 63) // 64) * ((n_in + 63) // 64)
     if (not _state["precise"]) and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and n_in % 8 == 0 \
             and (lda or n_out) % 8 == 0 and (ldb or n_in) % 8 == 0:
@@ -479,7 +486,9 @@ def _wgrad(dy, x, rows, n_out, n_in, lda=None, ldb=None, xT=None, dyT=None):
             alloc = _zeros if split > 1 else (lambda shp, dev: torch.empty(shp, dtype=torch.float32, device=dev))
             dw = alloc((m_pad, n_in), dy.device)
             ops.gemm_bf16_tn(dy, lda or n_out, x, ldb or n_in, m_pad, n_in, rows, dw, n_in, accumulate=split > 1,
-                             split_k=split)
+                             split_k=split, colsum_a=bias_out if (bias_out is not None and bias_out.numel() >= m_pad) else None)
+            if bias_out is not None and bias_out.numel() < m_pad:
+                ops.colsum_into(dy if (lda or n_out) == n_out else dy.as_strided((rows, n_out), (lda, 1)), bias_out, rows, n_out)
             return dw if m_pad == n_out else dw[:n_out]
     split = 1
     if tiles < 192 and rows >= 512:
@@ -490,6 +499,9 @@ def _wgrad(dy, x, rows, n_out, n_in, lda=None, ldb=None, xT=None, dyT=None):
         dw = torch.empty(n_out, n_in, dtype=torch.float32, device=dy.device)
     ops.gemm(TN, dy, lda or n_out, x, ldb or n_in, n_out, n_in, rows, dw, n_in, precise=_state["precise"],
              accumulate=split > 1, split_k=split)
+    if bias_out is not None:
+        assert (lda or n_out) == n_out, "bias gradient of a pitched dy needs the tuned kernel"
+        ops.colsum_into(dy, bias_out, rows, n_out)
     return dw
 
 
@@ -510,6 +522,25 @@ def _to_act(x):
     if x.dtype == act_dtype() and x.is_contiguous():
         return x
     return ops.scale_dropout(x.contiguous(), act_dtype())
+
+
+_shared_act = {}
+
+
+def _to_act_shared(x):
+    """_to_act for a tensor that SEVERAL sub-layers of one step consume unchanged -- the encoder memory (6 decoder layers'
+    source attention) and the relative-position table (12 encoder layers): the activation-dtype copy is made once per step
+    and shared.  Entries keep their source alive (its address cannot be recycled meanwhile) and are dropped by new_step();
+    outside a step loop the cache is bounded."""
+    if x.dtype == act_dtype() and x.is_contiguous():
+        return x
+    key = (x.data_ptr(), tuple(x.shape), x.dtype, act_dtype(), x._version)
+    ent = _shared_act.get(key)
+    if ent is None:
+        if len(_shared_act) > 8:
+            _shared_act.clear()
+        ent = _shared_act[key] = (x, ops.scale_dropout(x.contiguous(), act_dtype()))
+    return ent[1]
 
 
 def _to_f32(x):
@@ -671,12 +702,13 @@ class FfnSublayerFn(torch.autograd.Function):
         rows, D = _rows(x), x.shape[-1]
         Fh = w1.shape[0]
         T = act_dtype()
-        g, gT, db2 = _prologue(dy, rows, D, alpha=scale, drop=(p2, s2, sd2))  # grad of the W2 output (+ g^T, bias grad)
+        g, gT, _ = _prologue(dy, rows, D, alpha=scale, drop=(p2, s2, sd2), want_bias=False)  # grad of the W2 output
+        db2 = _zeros(D, x.device)  # its column sums (bias gradient) come out of the weight-gradient GEMM below
         du = torch.empty(rows, Fh, dtype=T, device=x.device)
         # relu' and the hidden dropout mask are both "u > 0" on the saved post-dropout activation
         db1 = _zeros(Fh, x.device)  # bias gradient of W1: column sums of du, taken in the epilogue of the GEMM that makes du
         with ops.paired():  # every (weight gradient, data gradient) pair of a Linear leaves as one launch
-            dw2 = _wgrad(g, u, rows, D, Fh, dyT=gT, xT=_xT(u, rows, Fh))
+            dw2 = _wgrad(g, u, rows, D, Fh, dyT=gT, xT=_xT(u, rows, Fh), bias_out=db2)
             _gemm_nn(g, w2, rows, Fh, D, du, gate=u, ldg=Fh, gate_scale=1.0 / (1.0 - p1) if p1 > 0 else 1.0, colsum=db1)
         dh = torch.empty(rows, D, dtype=T, device=x.device)
         with ops.paired():
@@ -901,7 +933,7 @@ class MhaSublayerFn(torch.autograd.Function):
         T = act_dtype()
         h, mean, rstd = ops.layernorm_fwd(x, ln_w, ln_b, T, eps)
         cross = memory is not None
-        ka = _to_act(memory) if cross else h
+        ka = _to_act_shared(memory) if cross else h
         Tk = ka.shape[1]
         # self attention in bf16: ONE projection GEMM onto the concatenated [Wq; Wk; Wv] (N = 3D fills the chip where
         # three N = D launches do not); q / k / v are column thirds of its output, read in place by the attention kernel
@@ -922,7 +954,7 @@ class MhaSublayerFn(torch.autograd.Function):
             ldq = D
         pe = pproj = qv = None
         if relpos:
-            pe = _to_act(pos_emb.reshape(-1, D))
+            pe = _to_act_shared(pos_emb).reshape(-1, D)
             pproj = torch.empty(pe.shape[0], D, dtype=T, device=x.device)
             _gemm_nt(pe, wpos, pe.shape[0], D, D, pproj)
             qu, qv = ops.head_bias_fwd(q, ldq, B * Tq, D, bias_u.reshape(-1), bias_v.reshape(-1))
@@ -953,10 +985,11 @@ class MhaSublayerFn(torch.autograd.Function):
         Tk = ka.shape[1]
         dk = D // H
         T = act_dtype()
-        g, gT, dbo = _prologue(dy, B * Tq, D, drop=(po, so, sdo))
+        g, gT, _ = _prologue(dy, B * Tq, D, drop=(po, so, sdo), want_bias=False)
+        dbo = _zeros(D, x.device)
         dctx = torch.empty(B, Tq, D, dtype=T, device=x.device)
         with ops.paired():
-            dwo = _wgrad(g, ctxv, B * Tq, D, D, dyT=gT, xT=_xT(ctxv.view(B * Tq, D), B * Tq, D))
+            dwo = _wgrad(g, ctxv, B * Tq, D, D, dyT=gT, xT=_xT(ctxv.view(B * Tq, D), B * Tq, D), bias_out=dbo)
             _gemm_nn(g, wo, B * Tq, D, D, dctx)
         outs = {}
         if fused:  # dq | dk | dv land side by side: one bias-gradient pass, one weight-gradient GEMM, one data-gradient GEMM
@@ -980,11 +1013,11 @@ class MhaSublayerFn(torch.autograd.Function):
             dq = dqu.view(B * Tq, D)
         dmem = None
         if fused:
-            _, _, dbc = _prologue(dqkv, B * Tq, 3 * D, want_dst=False)
+            dbc = _zeros(3 * D, x.device)
             dh = torch.empty(B * Tq, D, dtype=torch.float32, device=x.device)
             wcT = _w_bf16_cat((wq, wk, wv), True)
             with ops.paired():
-                dwc = _wgrad(dqkv, h, B * Tq, 3 * D, D)
+                dwc = _wgrad(dqkv, h, B * Tq, 3 * D, D, bias_out=dbc)
                 ops.gemm_bf16_nt(dqkv, 3 * D, wcT, 3 * D, B * Tq, D, 3 * D, dh, D)
             dwq, dwk, dwv = dwc[:D], dwc[D:2 * D], dwc[2 * D:]
             dbq, dbk, dbv = dbc[:D], dbc[D:2 * D], dbc[2 * D:]
@@ -992,38 +1025,37 @@ class MhaSublayerFn(torch.autograd.Function):
             dk2, dv2 = dk_.view(B * Tk, D), dv_.view(B * Tk, D)
             hT = _xT(h.view(B * Tq, D), B * Tq, D)
             kaT = hT if not cross else _xT(ka.view(B * Tk, D), B * Tk, D)
-            _, dqT, dbq = _prologue(dq, B * Tq, D, want_dst=False)
-            _, dkT, dbk = _prologue(dk2, B * Tk, D, want_dst=False)
-            _, dvT, dbv = _prologue(dv2, B * Tk, D, want_dst=False)
+            dqT = dkT = dvT = None
+            dbq, dbk, dbv = _zeros(D, x.device), _zeros(D, x.device), _zeros(D, x.device)
             # each projection: weight gradient + data gradient as one launch (data gradients chain through `resid`)
             if cross:
                 dh = torch.empty(B * Tq, D, dtype=T, device=x.device)
                 with ops.paired():
-                    dwq = _wgrad(dq, h, B * Tq, D, D, xT=hT, dyT=dqT)
+                    dwq = _wgrad(dq, h, B * Tq, D, D, xT=hT, dyT=dqT, bias_out=dbq)
                     _gemm_nn(dq, wq, B * Tq, D, D, dh)
                 need_mem = ctx.needs_input_grad[1]
                 t2 = torch.empty(B * Tk, D, dtype=torch.float32, device=x.device) if need_mem else None
                 with ops.paired():
-                    dwk = _wgrad(dk2, ka, B * Tk, D, D, xT=kaT, dyT=dkT)
+                    dwk = _wgrad(dk2, ka, B * Tk, D, D, xT=kaT, dyT=dkT, bias_out=dbk)
                     if need_mem:
                         _gemm_nn(dk2, wk, B * Tk, D, D, t2)
                 with ops.paired():
-                    dwv = _wgrad(dv2, ka, B * Tk, D, D, xT=kaT, dyT=dvT)
+                    dwv = _wgrad(dv2, ka, B * Tk, D, D, xT=kaT, dyT=dvT, bias_out=dbv)
                     if need_mem:
                         dmem = torch.empty(B, Tk, D, dtype=torch.float32, device=x.device)
                         _gemm_nn(dv2, wv, B * Tk, D, D, dmem, resid=t2, ldr=D)
             else:
                 t1 = torch.empty(B * Tq, D, dtype=torch.float32, device=x.device)
                 with ops.paired():
-                    dwq = _wgrad(dq, h, B * Tq, D, D, xT=hT, dyT=dqT)
+                    dwq = _wgrad(dq, h, B * Tq, D, D, xT=hT, dyT=dqT, bias_out=dbq)
                     _gemm_nn(dq, wq, B * Tq, D, D, t1)
                 t2 = torch.empty_like(t1)
                 with ops.paired():
-                    dwk = _wgrad(dk2, ka, B * Tk, D, D, xT=kaT, dyT=dkT)
+                    dwk = _wgrad(dk2, ka, B * Tk, D, D, xT=kaT, dyT=dkT, bias_out=dbk)
                     _gemm_nn(dk2, wk, B * Tq, D, D, t2, resid=t1, ldr=D)
                 dh = torch.empty_like(t1)
                 with ops.paired():
-                    dwv = _wgrad(dv2, ka, B * Tk, D, D, xT=kaT, dyT=dvT)
+                    dwv = _wgrad(dv2, ka, B * Tk, D, D, xT=kaT, dyT=dvT, bias_out=dbv)
                     _gemm_nn(dv2, wv, B * Tq, D, D, dh, resid=t2, ldr=D)
         dg = _zeros(D, x.device)
         dbt = _zeros(D, x.device)
@@ -1139,10 +1171,11 @@ class ConvSublayerFn(torch.autograd.Function):
         B, Tn, D = x.shape
         rows = B * Tn
         T = act_dtype()
-        g, gT, db2 = _prologue(dy, rows, D, drop=(po, so, sdo))
+        g, gT, _ = _prologue(dy, rows, D, drop=(po, so, sdo), want_bias=False)
+        db2 = _zeros(D, x.device)
         ds = torch.empty(rows, D, dtype=T, device=x.device)
         with ops.paired():
-            dw2 = _wgrad(g, s, rows, D, D, dyT=gT, xT=_xT(s, rows, D)).view(D, D, 1)
+            dw2 = _wgrad(g, s, rows, D, D, dyT=gT, xT=_xT(s, rows, D), bias_out=db2).view(D, D, 1)
             _gemm_nn(g, w_pw2.view(D, D), rows, D, D, ds)
         sums = ops.bn_bwd_reduce(c, ds, None, bmean, binv, bn_w, bn_b, rows, D, 1)
         dbn_w, dbn_b = sums[1], sums[0]
@@ -1156,11 +1189,12 @@ class ConvSublayerFn(torch.autograd.Function):
         ops.dwconv_wgrad(gl, dc, dwdw, dbdw, B, Tn, D, K)
         dgl = ops.dwconv(dc, wdw, None, B, Tn, D, K, flip=True)
         da = ops.glu_bwd(a, dgl, rows, D)
-        _, daT, db1 = _prologue(da, rows, 2 * D, want_dst=False)
+        daT = None
+        db1 = _zeros(2 * D, x.device)
         if fused:
             dh = torch.empty(rows, D, dtype=T, device=x.device)
             with ops.paired():
-                dw1 = _wgrad(da, h, rows, 2 * D, D, dyT=daT, xT=_xT(h.view(rows, D), rows, D)).view(2 * D, D, 1)
+                dw1 = _wgrad(da, h, rows, 2 * D, D, dyT=daT, xT=_xT(h.view(rows, D), rows, D), bias_out=db1).view(2 * D, D, 1)
                 _gemm_nn(da, w_pw1.view(2 * D, D), rows, D, 2 * D, dh)
             dg = _zeros(D, x.device)
             dbt = _zeros(D, x.device)
@@ -1169,7 +1203,7 @@ class ConvSublayerFn(torch.autograd.Function):
             dg = dbt = None
             dx = torch.empty(B, Tn, D, dtype=torch.float32, device=x.device)
             with ops.paired():
-                dw1 = _wgrad(da, h, rows, 2 * D, D, dyT=daT, xT=_xT(h.view(rows, D), rows, D)).view(2 * D, D, 1)
+                dw1 = _wgrad(da, h, rows, 2 * D, D, dyT=daT, xT=_xT(h.view(rows, D), rows, D), bias_out=db1).view(2 * D, D, 1)
                 _gemm_nn(da, w_pw1.view(2 * D, D), rows, D, 2 * D, dx)
         return (dx, dg, dbt, dw1, db1, dwdw.view(D, 1, K), dbdw, dbn_w, dbn_b, None, None, None, dw2, db2, None, None,
                 None, None, None)

@@ -601,8 +601,10 @@ def stem357_wgrad(dy, x, B, T, H, W):
     return dw
 
 
-def gemm_bf16_tn(A, lda, B, ldb, M, N, K, C, ldc, *, accumulate=False, split_k=1):
-    """C[M,N] (f32) (+)= A[K,M]^T B[K,N], bf16 operands with the contraction index as the slow dimension."""
+def gemm_bf16_tn(A, lda, B, ldb, M, N, K, C, ldc, *, accumulate=False, split_k=1, colsum_a=None):
+    """C[M,N] (f32) (+)= A[K,M]^T B[K,N], bf16 operands with the contraction index as the slow dimension.
+    colsum_a (f32 [M], zero-initialised): also receives the column sums of A (the bias gradient when A = dY)."""
     call("avsr_gemm_bf16_tn", _ptr(A), lda, _ptr(B), ldb, M, N, K, _ptr(C), ldc, int(accumulate), split_k,
-         _ptr(zero_page(A.device)), _stream(A), flops=2.0 * M * N * K, nbytes=2.0 * K * (M + N) + 4.0 * M * N)
+         _ptr(zero_page(A.device)), _ptr(colsum_a), _stream(A), flops=2.0 * M * N * K,
+         nbytes=2.0 * K * (M + N) + 4.0 * M * N)
     return C

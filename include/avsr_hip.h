@@ -288,9 +288,11 @@ int avsr_stem357_wgrad(const void* dy, const float* x, float* dw, void* workspac
                        avsr_stream_t stream);
 
 /* bf16 weight-gradient contraction without transposed copies (gemm_tn_fast.hip: LDS-DMA k-major tiles +
- * ds_read_b64_tr_b16): C[M][N] (f32, ldc) (+)= sum_k A[k][m] B[k][n]; A [K][lda], B [K][ldb] bf16 */
+ * ds_read_b64_tr_b16): C[M][N] (f32, ldc) (+)= sum_k A[k][m] B[k][n]; A [K][lda], B [K][ldb] bf16.
+ * colsum_a (f32 [M], may be NULL; accumulated into) += sum_k A[k][m]: with A = dY this is the bias gradient of the Linear
+ * whose weight gradient the call computes (torch: grad_bias = dY.sum(0)), taken from the A tiles the kernel stages anyway */
 int avsr_gemm_bf16_tn(const void* A, int lda, const void* B, int ldb, int M, int N, int K, float* C, int ldc,
-                      int accumulate, int split_k, const void* zero_page, avsr_stream_t stream);
+                      int accumulate, int split_k, const void* zero_page, float* colsum_a, avsr_stream_t stream);
 /* Paired launch of the two GEMMs of a Linear backward pass (gemm_pair.hip): between begin and end, the first
  * avsr_gemm_bf16_nt call (split_k 1, non-accumulating, 64x64 / 128x64 tile shapes) and the first avsr_gemm_bf16_tn call
  * of the calling thread are recorded and then launched together by avsr_gemm_pair_end as ONE grid (NT tiles first, TN

@@ -102,7 +102,11 @@ def test_bucketed_batches_follow_reference_algorithm():
     assert all(sum(int(lengths[i]) for i in b) <= 1600 for b in got)
     assert sorted(i for b in got for i in b) == list(range(2000))
     r0, r1 = rank_batches(got, 0, 2, seed=3), rank_batches(got, 1, 2, seed=3)
-    assert len(r0) + len(r1) == len(got) and not ({tuple(b) for b in r0} & {tuple(b) for b in r1})
+    # DistributedSampler semantics: every rank gets ceil(n / world) batches (the tail is padded with the head of the
+    # shuffled list), together they cover every batch
+    assert len(r0) == len(r1) == (len(got) + 1) // 2
+    assert {tuple(b) for b in r0} | {tuple(b) for b in r1} == {tuple(b) for b in got}
+    assert len({tuple(b) for b in r0} & {tuple(b) for b in r1}) <= len(got) % 2
     x, lens, y, frames = make_batch(lengths, got[len(got) // 2], "video", 5049, seed=1)
     assert x.shape[1] == int(lens.max()) and frames == int(lens.sum()) and y.shape[1] == 1
     assert (x[0, int(lens[0]):] == 0).all() and y.max() < 5048 and (y[y != -1] >= 1).all()

@@ -183,8 +183,12 @@ def test_gemm_bf16_tn_transpose_read(dev, shape):
     assert ((C.cpu()[:, :N].double() - ref).abs().max() / ref.abs().max()) < 2e-6
     assert C.cpu()[:, N:].abs().max() == 0
     C2 = torch.zeros(M, N, device=dev)
-    ops.gemm_bf16_tn(A.to(dev), M, B.to(dev), N, M, N, K, C2, N, accumulate=True, split_k=3)
+    cs = torch.zeros(M, device=dev)
+    ops.gemm_bf16_tn(A.to(dev), M, B.to(dev), N, M, N, K, C2, N, accumulate=True, split_k=3, colsum_a=cs)
     assert ((C2.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    # the bias gradient on the side: column sums of A (= dY) from the staged tiles, across the k-splits
+    want = A.double().sum(0)
+    assert ((cs.cpu().double() - want).abs().max() / want.abs().max().clamp_min(1.0)) < 1e-5
 
 
 @pytest.mark.parametrize("tile", [1, 7])
@@ -207,8 +211,11 @@ def test_gemm_pair_nt_tn(dev, tile, split):
     def nt(out, cs):
         ops.gemm_bf16_nt(dy, Kp, wT, Kp, rows, n_in, Kp, out, n_in, bias=bias, act=1, tile=tile, colsum=cs)
 
+    csa = []
+
     def tn(out):
-        ops.gemm_bf16_tn(dy, Kp, x, n_in, n_out, n_in, rows, out, n_in, accumulate=split > 1, split_k=split)
+        csa.append(torch.zeros(n_out, device=dev))
+        ops.gemm_bf16_tn(dy, Kp, x, n_in, n_out, n_in, rows, out, n_in, accumulate=split > 1, split_k=split, colsum_a=csa[-1])
 
     dx0, cs0, dw0 = torch.zeros(rows, n_in, device=dev, dtype=torch.bfloat16), torch.zeros(n_in, device=dev), torch.zeros(n_out, n_in, device=dev)
     nt(dx0, cs0)
@@ -231,5 +238,8 @@ def test_gemm_pair_nt_tn(dev, tile, split):
     with ops.paired():
         pass
     assert torch.equal(dx2, dx0) and torch.equal(dw2, dw0)
+    want_cs = dy.cpu().double()[:, :n_out].sum(0)  # colsum(dY): stand-alone launch, paired launch, pair of one
+    for c in csa:
+        assert ((c.cpu().double() - want_cs).abs().max() / want_cs.abs().max().clamp_min(1.0)) < 1e-5
     ref_dx = dy.cpu().double() @ wT.cpu().double().t()
     assert ((dx3.cpu().double() - ref_dx).abs().max() / ref_dx.abs().max()) < 2e-6
