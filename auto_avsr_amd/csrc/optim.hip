@@ -80,19 +80,20 @@ __global__ __launch_bounds__(256) void multi_sumsq_kernel(const OptEntry* __rest
 
 // state[0] = step (incremented here), state[1] = lr of this step, state[2] = gradient norm, state[3] = clip coefficient
 // lr = base_lr * (step < warmup ? step / warmup : 0.5 (1 + cos(pi (step - warmup) / (total - warmup))))   cosine.py:20-25
-__global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict__ partial, int nparts, float max_norm,
+__global__ __launch_bounds__(1024) void clip_coef_kernel(const float* __restrict__ partial, int nparts, float max_norm,
                                                         float base_lr, float warmup_steps, float total_steps,
                                                         float* __restrict__ state) {
-    __shared__ double red[4];
-    // ~61 000 partials for the 250 M-parameter model, one block: eight independent loads / accumulators per thread and
-    // trip (a single dependent chain took 84 us of a 22 ms step)
+    __shared__ double red[16];
+    // ~61 000 partials for the 250 M-parameter model, ONE block (the result is a scalar): every trip of the loop is a
+    // memory round trip, so the block is 1024 threads wide with eight independent loads per thread and trip -- 8 trips
+    // instead of the 239 of a 256-thread single-load loop (84 us of a 22 ms step)
     double acc[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) acc[u] = 0.0;
-    for (int i0 = threadIdx.x; i0 < nparts; i0 += 256 * 8) {
+    for (int i0 = threadIdx.x; i0 < nparts; i0 += 1024 * 8) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = (i0 + 256 * u < nparts) ? partial[i0 + 256 * u] : 0.f;
+        for (int u = 0; u < 8; u++) v[u] = (i0 + 1024 * u < nparts) ? partial[i0 + 1024 * u] : 0.f;
 #pragma unroll
         for (int u = 0; u < 8; u++) acc[u] += (double)v[u];
     }
@@ -102,7 +103,9 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict_
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float norm = (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
+        double tot = 0.0;
+        for (int w = 0; w < 16; w++) tot += red[w];
+        const float norm = (float)sqrt(tot);
         const float step = state[0] + 1.f;
         float f;
         if (total_steps <= 0.f) f = 1.f;  // constant learning rate
@@ -261,7 +264,7 @@ extern "C" int avsr_adamw_step(const void* table, int n, int total_blocks, float
     AVSR_REQUIRE(table && partial && state, "adamw_step: null argument");
     const OptEntry* t = reinterpret_cast<const OptEntry*>(table);
     AVSR_LAUNCH(multi_sumsq_kernel, dim3(total_blocks), dim3(256), 0, stream, t, n, partial);
-    AVSR_LAUNCH(clip_coef_kernel, dim3(1), dim3(256), 0, stream, (const float*)partial, total_blocks, max_grad_norm, base_lr,
+    AVSR_LAUNCH(clip_coef_kernel, dim3(1), dim3(1024), 0, stream, (const float*)partial, total_blocks, max_grad_norm, base_lr,
                 (float)warmup_steps, (float)total_steps, state);
     AVSR_LAUNCH(multi_adamw_kernel, dim3(total_blocks), dim3(256), 0, stream, t, n, (const float*)state, beta1, beta2, eps,
                 weight_decay);
@@ -285,7 +288,7 @@ extern "C" int avsr_adamw_cast_step(const void* table, int n, int total_blocks, 
     AVSR_REQUIRE((lin_n <= 0 || lin_table) && (tile_n <= 0 || tile_table), "adamw_cast_step: null table");
     const OptEntry* t = reinterpret_cast<const OptEntry*>(table);
     AVSR_LAUNCH(multi_sumsq_kernel, dim3(total_blocks), dim3(256), 0, stream, t, n, partial);
-    AVSR_LAUNCH(clip_coef_kernel, dim3(1), dim3(256), 0, stream, (const float*)partial, total_blocks, max_grad_norm, base_lr,
+    AVSR_LAUNCH(clip_coef_kernel, dim3(1), dim3(1024), 0, stream, (const float*)partial, total_blocks, max_grad_norm, base_lr,
                 (float)warmup_steps, (float)total_steps, state);
     if (tile_n > 0 && tile_blocks > 0)
         AVSR_LAUNCH(multi_adamw_cast_kernel, dim3(tile_blocks), dim3(256), 0, stream,
