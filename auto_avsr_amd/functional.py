@@ -1144,9 +1144,11 @@ class ConvSublayerFn(torch.autograd.Function):
             h, mean, rstd = _to_act(x), None, None
         a = torch.empty(rows, 2 * D, dtype=T, device=x.device)
         _gemm_nt(h, w_pw1.view(2 * D, D), rows, 2 * D, D, a, bias=b_pw1)
-        gl = ops.glu_fwd(a, rows, D)
+        # GLU (conformer_encoder.py:32) is folded into the depthwise convolution: its window staging forms
+        # a[:, :D] * sigmoid(a[:, D:]) on the fly, the GLU output is never written
+        gl = None
         wdw = w_dw.view(D, K)
-        c = ops.dwconv(gl, wdw, b_dw, B, Tn, D, K)
+        c = ops.dwconv(a, wdw, b_dw, B, Tn, D, K, glu_in=True)
         if training:
             bmean, binv, counts = _bn_train_stats(c, rows, D, bn_eps, momentum, bn_rm, bn_rv, bn_nbt)
         else:
@@ -1186,9 +1188,9 @@ class ConvSublayerFn(torch.autograd.Function):
         dc, _ = ops.bn_bwd_apply(c, ds, None, bmean, binv, bn_w, bn_b, sums_dx, inv_n, rows, D, 1, False, n_dev=n_dev)
         dwdw = _zeros((D, K), x.device)
         dbdw = _zeros(D, x.device)
-        ops.dwconv_wgrad(gl, dc, dwdw, dbdw, B, Tn, D, K)
-        dgl = ops.dwconv(dc, wdw, None, B, Tn, D, K, flip=True)
-        da = ops.glu_bwd(a, dgl, rows, D)
+        ops.dwconv_wgrad(a, dc, dwdw, dbdw, B, Tn, D, K, glu_in=True)
+        # data gradient of the depthwise convolution with the GLU backward as its epilogue: d glu never reaches HBM
+        da = ops.dwconv(dc, wdw, None, B, Tn, D, K, flip=True, glu_a=a).view(rows, 2 * D)
         daT = None
         db1 = _zeros(2 * D, x.device)
         if fused:

@@ -236,14 +236,18 @@ def glu_bwd(a, dg, rows, C):
     return da
 
 
-def dwconv(x, w, bias, B, T, C, K, flip=False):
-    y = torch.empty(B, T, C, dtype=x.dtype, device=x.device)
-    call("avsr_dwconv_fwd", _ptr(x), dt(x), _ptr(w), _ptr(bias), _ptr(y), B, T, C, K, int(flip), _stream(x), nbytes=_nb(x, y))
+def dwconv(x, w, bias, B, T, C, K, flip=False, glu_in=False, glu_a=None):
+    """glu_in: x is the pre-GLU tensor [B*T, 2C] (the conv runs on glu(x)); glu_a (flip only): the result is pushed
+    through the GLU backward of glu_a = [a | g] -> returns da [B*T, 2C]."""
+    y = torch.empty(B, T, 2 * C if glu_a is not None else C, dtype=x.dtype, device=x.device)
+    call("avsr_dwconv_fwd", _ptr(x), dt(x), _ptr(w), _ptr(bias), _ptr(y), B, T, C, K, int(flip), int(glu_in), _ptr(glu_a),
+         _stream(x), nbytes=_nb(x, y, glu_a))
     return y
 
 
-def dwconv_wgrad(x, dy, dw, db, B, T, C, K):
-    call("avsr_dwconv_wgrad", _ptr(x), _ptr(dy), dt(x), _ptr(dw), _ptr(db), B, T, C, K, _stream(x), nbytes=_nb(x, dy))
+def dwconv_wgrad(x, dy, dw, db, B, T, C, K, glu_in=False):
+    call("avsr_dwconv_wgrad", _ptr(x), _ptr(dy), dt(x), _ptr(dw), _ptr(db), B, T, C, K, int(glu_in), _stream(x),
+         nbytes=_nb(x, dy))
 
 
 def bn_stats(x, rows, C, with_count=False):

@@ -115,12 +115,17 @@ int avsr_glu_bwd(const void* a, const void* dg, void* da, int dtype, int64_t row
                  avsr_stream_t stream);
 
 /* ---- depthwise conv over time on (B,T,C) (conformer_encoder.py:25,33) ------------------------ */
-/* y[b,t,c] = bias[c] + sum_k w[c,k] x[b,t+k-(K-1)/2,c]; flip=1 reverses taps (= data gradient, bias NULL) */
+/* y[b,t,c] = bias[c] + sum_k w[c,k] x[b,t+k-(K-1)/2,c]; flip=1 reverses taps (= data gradient, bias NULL).
+ * The GLU in front of the convolution (conformer_encoder.py:32 `nn.functional.glu(x, dim=1)`) is folded in on request:
+ *   glu_in = 1: x is the PRE-GLU tensor [B*T, 2C]; the convolution runs on x[:, :C] * sigmoid(x[:, C:]), formed while the
+ *               time window is staged (the GLU output is never written);
+ *   glu_a != NULL (flip = 1): the conv result r (= gradient w.r.t. the GLU output) goes through the GLU backward on the
+ *               way out: y is [B*T, 2C] = (r * sigmoid(g), r * a * sigmoid(g) * (1 - sigmoid(g))) for glu_a = [a | g]. */
 int avsr_dwconv_fwd(const void* x, int dtype, const float* w, const float* bias, void* y, int B, int T,
-                    int C, int K, int flip, avsr_stream_t stream);
-/* dw[c,k] += sum dy[b,t,c] x[b,t+k-pad,c]; db[c] += sum dy */
+                    int C, int K, int flip, int glu_in, const void* glu_a, avsr_stream_t stream);
+/* dw[c,k] += sum dy[b,t,c] x[b,t+k-pad,c]; db[c] += sum dy; glu_in = 1: x is the pre-GLU tensor [B*T, 2C] */
 int avsr_dwconv_wgrad(const void* x, const void* dy, int dtype, float* dw, float* db, int B, int T, int C,
-                      int K, avsr_stream_t stream);
+                      int K, int glu_in, avsr_stream_t stream);
 
 /* ---- training-mode BatchNorm (+SiLU, + residual add) on channels-last [rows, C] ------------------- */
 int64_t avsr_bn_workspace_floats(int C);

@@ -64,6 +64,41 @@ def test_dwconv(dev, K):
     assert (db.cpu() - bias.grad).abs().max() < 1e-3
 
 
+@pytest.mark.parametrize("K", [31, 7])
+def test_dwconv_with_folded_glu(dev, K):
+    """GLU folded into the depthwise convolution (conformer_encoder.py:32-33): forward on the pre-GLU tensor, weight gradient
+    on the pre-GLU tensor, and the data gradient with the GLU backward as its epilogue -- against torch's glu + conv1d."""
+    torch.manual_seed(3)
+    B, T, C = 2, 75, 136
+    a = torch.randn(B, T, 2 * C, requires_grad=True)
+    w = torch.randn(C, 1, K, requires_grad=True)
+    bias = torch.randn(C, requires_grad=True)
+    gl = F.glu(a, dim=-1)
+    y_ref = F.conv1d(gl.transpose(1, 2), w, bias, padding=(K - 1) // 2, groups=C).transpose(1, 2)
+    dy = torch.randn(B, T, C)
+    y_ref.backward(dy)
+    wd = w.detach().reshape(C, K).contiguous().to(dev)
+    ad = a.detach().to(dev)
+    y = ops.dwconv(ad, wd, bias.detach().to(dev), B, T, C, K, glu_in=True)
+    assert y.shape == (B, T, C) and (y.cpu() - y_ref).abs().max() < 1e-4
+    dw, db = torch.zeros(C, K, device=dev), torch.zeros(C, device=dev)
+    ops.dwconv_wgrad(ad, dy.to(dev), dw, db, B, T, C, K, glu_in=True)
+    assert (dw.cpu() - w.grad.reshape(C, K)).abs().max() < 1e-3
+    assert (db.cpu() - bias.grad).abs().max() < 1e-3
+    da = ops.dwconv(dy.to(dev), wd, None, B, T, C, K, flip=True, glu_a=ad)
+    assert da.shape == (B, T, 2 * C) and (da.cpu() - a.grad).abs().max() < 1e-4
+    # bf16 storage: same values as the stand-alone GLU kernels followed by the plain convolution (identical roundings)
+    ab = ad.bfloat16()
+    gb = ops.glu_fwd(ab.view(-1, 2 * C), B * T, C)
+    y0 = ops.dwconv(gb, wd, None, B, T, C, K)
+    y1 = ops.dwconv(ab, wd, None, B, T, C, K, glu_in=True)
+    assert torch.equal(y0, y1)
+    dyb = dy.to(dev).bfloat16()
+    d0 = ops.glu_bwd(ab.view(-1, 2 * C), ops.dwconv(dyb, wd, None, B, T, C, K, flip=True).view(-1, C), B * T, C)
+    d1 = ops.dwconv(dyb, wd, None, B, T, C, K, flip=True, glu_a=ab)
+    assert (d0.float().view(B, T, 2 * C) - d1.float()).abs().max() <= 2.0 ** -7 * d0.float().abs().max()
+
+
 @pytest.mark.parametrize("C,with_add,act", [(128, False, 1), (64, True, 1), (256, False, 0)])
 def test_batchnorm_train(dev, C, with_add, act):
     torch.manual_seed(3)
