@@ -278,6 +278,40 @@ def _w_bf16_cat(ws, transposed):
     return buf
 
 
+def _bias3(bq, bk, bv):
+    """[bq | bk | bv] for the fused Q/K/V projection: in place when the three parameters are thirds of one buffer
+    (nets.MultiHeadedAttention._pack_qkv_bias), else a concatenation."""
+    n = bq.numel()
+    if bq.is_contiguous() and bk.data_ptr() == bq.data_ptr() + 4 * n and bv.data_ptr() == bq.data_ptr() + 8 * n \
+            and bq.untyped_storage().nbytes() >= bq.storage_offset() * 4 + 12 * n:
+        return bq.detach().as_strided((3 * n,), (1,))
+    return torch.cat([bq, bk, bv])
+
+
+_pos_proj = {}
+
+
+def prepare_pos_proj(pos_emb, weights):
+    """bf16 mode: pos_emb [1, P, D] @ [W_0; W_1; ...]^T -> [P, n*D] in one launch; layer l's relative-position attention then
+    reads its D-column block in place (row pitch n*D) instead of running its own P x D x D projection.  The weight gradients
+    stay per layer (dW_l = dpos_l^T pe).  No-op in precise mode / for shapes the tuned kernel does not take -- the layers
+    then project on their own.  Entries are dropped by new_step()."""
+    _pos_proj.clear()
+    if _state["precise"] or len(weights) < 2 or pos_emb is None:
+        return
+    D = pos_emb.shape[-1]
+    if D % 64 or any(w.dtype != torch.float32 or not w.is_contiguous() or tuple(w.shape) != (D, D) for w in weights):
+        return
+    pe = _to_act_shared(pos_emb).reshape(-1, D)
+    if pe.dtype != torch.bfloat16:
+        return
+    n, P = len(weights), pe.shape[0]
+    out = torch.empty(P, n * D, dtype=torch.bfloat16, device=pe.device)
+    ops.gemm_bf16_nt(pe, D, _w_bf16_cat(tuple(weights), False), D, P, n * D, D, out, n * D)
+    for i, w in enumerate(weights):
+        _pos_proj[(pos_emb.data_ptr(), w.data_ptr())] = (pos_emb, out[:, i * D:(i + 1) * D])
+
+
 def _fast_ok(a, K, lda):
     return (not _state["precise"]) and a.dtype == torch.bfloat16 and K % 64 == 0 and (lda or K) % 8 == 0
 
@@ -360,6 +394,7 @@ def new_step():
     _chain_spec.clear()
     _chain_g.clear()
     _shared_act.clear()
+    _pos_proj.clear()
 
 
 def _zeros(shape, device):
@@ -943,7 +978,7 @@ class MhaSublayerFn(torch.autograd.Function):
         if fused:
             qkv = torch.empty(B * Tq, 3 * D, dtype=T, device=x.device)
             ops.gemm_bf16_nt(h, D, _w_bf16_cat((wq, wk, wv), False), D, B * Tq, 3 * D, D, qkv, 3 * D,
-                             bias=torch.cat([bq, bk, bv]))
+                             bias=_bias3(bq, bk, bv))
             q5 = qkv.view(B, Tq, 3, H, dk)
             q, k4, v4 = qkv, q5[:, :, 1], q5[:, :, 2]
             ldq = 3 * D
@@ -955,8 +990,12 @@ class MhaSublayerFn(torch.autograd.Function):
         pe = pproj = qv = None
         if relpos:
             pe = _to_act_shared(pos_emb).reshape(-1, D)
-            pproj = torch.empty(pe.shape[0], D, dtype=T, device=x.device)
-            _gemm_nt(pe, wpos, pe.shape[0], D, D, pproj)
+            pre = _pos_proj.get((pos_emb.data_ptr(), wpos.data_ptr()))
+            if pre is not None and pre[1].dtype == T:
+                pproj = pre[1]  # column block of the all-layer projection (prepare_pos_proj), row pitch n_layers * D
+            else:
+                pproj = torch.empty(pe.shape[0], D, dtype=T, device=x.device)
+                _gemm_nt(pe, wpos, pe.shape[0], D, D, pproj)
             qu, qv = ops.head_bias_fwd(q, ldq, B * Tq, D, bias_u.reshape(-1), bias_v.reshape(-1))
             qu, qv = qu.view(B, Tq, H, dk), qv.view(B, Tq, H, dk)
         else:

@@ -60,6 +60,27 @@ class MultiHeadedAttention(nn.Module):
         self.linear_out = nn.Linear(n_feat, n_feat)
         self.attn = None
         self.dropout = nn.Dropout(p=dropout_rate)
+        self._pack_qkv_bias()
+
+    def _pack_qkv_bias(self):
+        """Keep the three projection biases back to back in ONE buffer (each nn.Parameter is a view of its third): the
+        fused Q/K/V projection then reads its [3D] bias in place, without a per-step concatenation launch.  Names, shapes
+        and state_dict entries are untouched; if the layout is ever lost (e.g. copy.deepcopy) functional._bias3 simply
+        concatenates again."""
+        bq, bk, bv = self.linear_q.bias, self.linear_k.bias, self.linear_v.bias
+        n = bq.numel()
+        if bq.dtype != torch.float32 or bq.device.type == "meta":
+            return
+        if bk.data_ptr() == bq.data_ptr() + 4 * n and bv.data_ptr() == bq.data_ptr() + 8 * n:
+            return
+        with torch.no_grad():
+            buf = torch.cat([bq.data, bk.data, bv.data])
+            bq.data, bk.data, bv.data = buf[:n], buf[n:2 * n], buf[2 * n:]
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)  # .to() / .cuda() give every parameter a storage of its own again
+        self._pack_qkv_bias()
+        return out
 
     def _params(self):
         return (self.linear_q.weight, self.linear_q.bias, self.linear_k.weight, self.linear_k.bias,
@@ -322,6 +343,11 @@ class ConformerEncoder(nn.Module):
 
     def forward(self, xs, masks):
         xs = self.embed(xs)
+        if isinstance(xs, tuple):
+            # the position table is batch-shared and identical for every layer: project it for all layers in ONE GEMM
+            # against the concatenated linear_pos weights (attention.py:170 runs linear_pos once per layer)
+            AF.prepare_pos_proj(xs[1], [layer.self_attn.linear_pos.weight for layer in self.encoders
+                                        if hasattr(layer.self_attn, "linear_pos")])
         xs, masks = self.encoders(xs, masks)
         if isinstance(xs, tuple):
             xs = xs[0]

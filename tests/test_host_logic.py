@@ -149,3 +149,28 @@ def test_state_dict_contract():
     }.items():
         assert tuple(sd[k].shape) == shape, k
     assert sum(p.numel() for p in E2E(5049, "audio").parameters()) == 243_049_202
+
+
+def test_qkv_bias_packing():
+    """The three projection biases of an attention module are thirds of one buffer (no per-step concatenation for the fused
+    Q/K/V projection); names / shapes / state_dict are unaffected; a layout lost by deepcopy falls back to torch.cat."""
+    import copy
+
+    from auto_avsr_amd import functional as AF
+    from auto_avsr_amd.nets import MultiHeadedAttention
+
+    m = MultiHeadedAttention(2, 128, 0.0)
+    sd = {k: torch.randn_like(v) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    m = m.to(torch.float32)  # any _apply: parameters get fresh storages, then are packed again
+    bq, bk, bv = m.linear_q.bias, m.linear_k.bias, m.linear_v.bias
+    assert bk.data_ptr() == bq.data_ptr() + 4 * 128 and bv.data_ptr() == bq.data_ptr() + 8 * 128
+    cat = AF._bias3(bq, bk, bv)
+    assert cat.data_ptr() == bq.data_ptr() and torch.equal(cat, torch.cat([sd["linear_q.bias"], sd["linear_k.bias"], sd["linear_v.bias"]]))
+    assert set(m.state_dict()) == set(sd) and all(torch.equal(m.state_dict()[k], sd[k]) for k in sd)
+    with torch.no_grad():
+        bk.add_(1.0)  # an in-place update of one parameter is seen through the packed view
+    assert torch.equal(AF._bias3(bq, bk, bv)[128:256], sd["linear_k.bias"] + 1.0)
+    m2 = copy.deepcopy(m)
+    c2 = AF._bias3(m2.linear_q.bias, m2.linear_k.bias, m2.linear_v.bias)
+    assert torch.equal(c2, AF._bias3(bq, bk, bv))
