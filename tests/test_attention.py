@@ -53,6 +53,48 @@ CASES = [
 ]
 
 
+# the benchmarked geometry: multi-tile softmax at T = Tk = 400 with the 799-row position band, 12 heads, and the
+# decoder's source attention Tq = 65 against Tk = 400; bf16 cases use relative-L2 tolerances (an absolute bound on single
+# elements of a 400-term bf16 sum says little).  GPU only: the emulator needs minutes per case at this size.
+BENCH_CASES = [
+    # B, T, Tk, H, relpos, mask, dtype, precise, rel-L2 tol fwd, rel-L2 tol bwd
+    (2, 400, 400, 3, True, "pad", torch.float32, True, 2e-5, 1e-4),
+    (2, 400, 400, 3, True, "pad", torch.bfloat16, False, 1e-2, 2e-2),
+    (2, 65, 400, 3, False, "pad", torch.float32, True, 2e-5, 1e-4),
+    (2, 65, 400, 3, False, "pad", torch.bfloat16, False, 1e-2, 2e-2),
+    (2, 65, 65, 3, False, "causal", torch.bfloat16, False, 1e-2, 2e-2),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", BENCH_CASES, ids=[f"b{i}" for i in range(len(BENCH_CASES))])
+def test_attention_bench_geometry(case):
+    B, T, Tk, H, relpos, mkind, dtype, precise, tol_f, tol_b = case
+    dev = torch.device("cuda:0")
+    torch.manual_seed(B * 1000 + T + Tk)
+    D = 64
+    qu, qv = torch.randn(B, T, H, D).to(dtype), torch.randn(B, T, H, D).to(dtype)
+    k, v = torch.randn(B, Tk, H, D).to(dtype), torch.randn(B, Tk, H, D).to(dtype)
+    pos = torch.randn(2 * T - 1, H * D).to(dtype) if relpos else None
+    mask = make_mask(mkind, B, T, Tk)
+    dout = torch.randn(B, T, H * D).to(dtype)
+    scale = 1 / math.sqrt(D)
+    d = lambda t: None if t is None else t.to(dev)
+    out, lse = ops.attention_fwd(d(qu), d(qv) if relpos else None, d(k), d(v), d(pos), d(mask), scale, precise=precise)
+    leaf = lambda t: None if t is None else t.double().requires_grad_()
+    rqu, rqv, rk, rv, rpos = leaf(qu), leaf(qv), leaf(k), leaf(v), leaf(pos)
+    ref = ref_attn(rqu, rqv, rk, rv, rpos, mask, scale)
+    rel = lambda a, b: float((a.cpu().double() - b.detach()).norm() / b.detach().norm())
+    assert rel(out, ref) < tol_f
+    ref.backward(dout.double())
+    dqu, dqv, dk, dv, dpos = ops.attention_bwd(d(qu), d(qv) if relpos else None, d(k), d(v), d(pos), d(mask), out,
+                                               lse, d(dout), scale, precise=precise)
+    errs = {"dqu": rel(dqu, rqu.grad), "dk": rel(dk, rk.grad), "dv": rel(dv, rv.grad)}
+    if relpos:
+        errs.update(dqv=rel(dqv, rqv.grad), dpos=rel(dpos, rpos.grad))
+    assert max(errs.values()) < tol_b, errs
+
+
 @pytest.mark.parametrize("case", CASES, ids=[f"c{i}" for i in range(len(CASES))])
 def test_attention_fwd_bwd(dev, case):
     B, T, Tk, H, relpos, mkind, dtype, precise, tol_f, tol_b = case
