@@ -272,7 +272,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(const T* __restr
 
 // The 3x3 / stride 2 / pad 1 case (the video stem) of bn_act_pool_fwd_kernel below, straight-line: all nine window loads
 // are issued up front from clamped addresses (out-of-image taps are masked afterwards), so a thread has 9 x 16 B in flight
-// instead of one load per loop trip.  Also records xsel = the RAW input at the arg-max: the backward reduce pass then
+// instead of one load per loop trip.  (A 2 x 2-windows-per-thread variant -- 25 taps for four outputs -- was measured 2.5x
+// SLOWER: 96 accumulator registers per thread on top of the taps.)  Also records xsel = the RAW input at the arg-max: the backward reduce pass then
 // runs on the pooled tensors alone (sum over pooled outputs of dpool * act'(z(xsel)) == sum over pixels of dz).
 template <class T>
 __global__ __launch_bounds__(BN_THREADS) void bn_act_pool3_fwd_kernel(
@@ -539,80 +540,87 @@ __global__ __launch_bounds__(BN_THREADS) void bn_pool_bwd_apply_kernel(
     }
 }
 
-// 3x3 / stride 2 / pad 1 case of bn_pool_bwd_apply_kernel: a pixel lies in at most 2 x 2 windows (one per dimension when
-// its coordinate is even, two when odd); the four candidate (idx, dpool) pairs are loaded unconditionally from clamped
-// addresses and masked, so the gather is branch-free and all loads of a thread are in flight together.
+// 3x3 / stride 2 / pad 1 case of bn_pool_bwd_apply_kernel, one thread per 2 x 2 PIXEL QUAD (rows 2a, 2a+1; columns 2b,
+// 2b+1) and 8-channel chunk.  The quad's pixels lie in the four windows (a, b), (a, b+1), (a+1, b), (a+1, b+1) only --
+// pixel (2a, 2b) is tap (1,1) of window (a, b); (2a, 2b+1) is tap (1,2) of (a, b) and (1,0) of (a, b+1); (2a+1, 2b) is tap
+// (2,1) of (a, b) and (0,1) of (a+1, b); (2a+1, 2b+1) is tap (2,2), (2,0), (0,2), (0,0) of the four -- so a thread loads
+// four (idx, dpool) pairs for four pixels (a pixel-per-thread gather loads up to four pairs per PIXEL) and all twelve
+// loads of a thread are in flight together; out-of-range windows / pixels are clamped and masked.
 template <class T>
 __global__ __launch_bounds__(BN_THREADS) void bn_pool3_bwd_apply_kernel(
     const T* __restrict__ x, const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ sums, float inv_n0, const float* __restrict__ n_dev, T* __restrict__ dx, long rows, int H,
+    const float* __restrict__ sums, float inv_n0, const float* __restrict__ n_dev, T* __restrict__ dx, long N, int H,
     int W, int C, int OH, int OW, int act) {
     const float inv_n = n_dev ? 1.0f / *n_dev : inv_n0;
-    const int cv = C >> 3;
-    const long nvec = rows * cv;
-    for (long i = (long)blockIdx.x * BN_THREADS + threadIdx.x; i < nvec; i += (long)gridDim.x * BN_THREADS) {
+    const int cv = C >> 3, QH = (H + 1) >> 1, QW = (W + 1) >> 1;
+    const long nq = N * QH * QW * cv;
+    for (long i = (long)blockIdx.x * BN_THREADS + threadIdx.x; i < nq; i += (long)gridDim.x * BN_THREADS) {
         const int c = (int)(i % cv) * 8;
-        const long r = i / cv;
-        const int iw = (int)(r % W);
-        const long q = r / W;
-        const int ih = (int)(q % H);
-        const long n = q / H;
-        // candidate windows per dimension: coordinate even -> {ih/2 (tap 1)}; odd -> {(ih-1)/2 (tap 2), (ih+1)/2 (tap 0)}
-        int ohc[2], khc[2], owc[2], kwc[2];
-        bool hv[2], wv[2];
-        if (ih & 1) {
-            ohc[0] = (ih - 1) >> 1; khc[0] = 2; hv[0] = true;
-            ohc[1] = (ih + 1) >> 1; khc[1] = 0; hv[1] = ohc[1] < OH;
-        } else {
-            ohc[0] = ih >> 1; khc[0] = 1; hv[0] = ohc[0] < OH;
-            ohc[1] = ohc[0]; khc[1] = 1; hv[1] = false;
-        }
-        if (iw & 1) {
-            owc[0] = (iw - 1) >> 1; kwc[0] = 2; wv[0] = true;
-            owc[1] = (iw + 1) >> 1; kwc[1] = 0; wv[1] = owc[1] < OW;
-        } else {
-            owc[0] = iw >> 1; kwc[0] = 1; wv[0] = owc[0] < OW;
-            owc[1] = owc[0]; kwc[1] = 1; wv[1] = false;
-        }
-        float v[8], d[4][8];
+        long r = i / cv;
+        const int qb = (int)(r % QW);
+        r /= QW;
+        const int qa = (int)(r % QH);
+        const long n = r / QH;
+        // the four windows
         uint64_t pk[4];
-        load8(x + i * 8, v);
+        float d[4][8];
+        bool wok[4];
 #pragma unroll
-        for (int a = 0; a < 2; a++)
+        for (int wa = 0; wa < 2; wa++)
 #pragma unroll
-            for (int b = 0; b < 2; b++) {
-                const long o = ((n * OH + min(ohc[a], OH - 1)) * OW + min(owc[b], OW - 1)) * C + c;
-                pk[a * 2 + b] = *reinterpret_cast<const uint64_t*>(idx + o);
-                load8(dpool + o, d[a * 2 + b]);
+            for (int wb = 0; wb < 2; wb++) {
+                const int oh = qa + wa, ow = qb + wb;
+                wok[wa * 2 + wb] = oh < OH && ow < OW;
+                const long o = ((n * OH + min(oh, OH - 1)) * OW + min(ow, OW - 1)) * C + c;
+                pk[wa * 2 + wb] = *reinterpret_cast<const uint64_t*>(idx + o);
+                load8(dpool + o, d[wa * 2 + wb]);
             }
-        float g[8];
+        // the four pixels
+        float v[4][8];
+        bool pok[4];
+        long poff[4];
 #pragma unroll
-        for (int e = 0; e < 8; e++) g[e] = 0.f;
+        for (int pa = 0; pa < 2; pa++)
 #pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int b = 0; b < 2; b++) {
-                const bool valid = hv[a] && wv[b];
-                const int me = khc[a] * 3 + kwc[b];
-#pragma unroll
-                for (int e = 0; e < 8; e++)
-                    g[e] += (valid && (int)((pk[a * 2 + b] >> (8 * e)) & 0xff) == me) ? d[a * 2 + b][e] : 0.f;
+            for (int pb = 0; pb < 2; pb++) {
+                const int ih = 2 * qa + pa, iw = 2 * qb + pb;
+                pok[pa * 2 + pb] = ih < H && iw < W;
+                poff[pa * 2 + pb] = ((n * H + min(ih, H - 1)) * W + min(iw, W - 1)) * C + c;
+                load8(x + poff[pa * 2 + pb], v[pa * 2 + pb]);
             }
-        float mu[8], is[8], ga[8], be[8], s1[8], s2[8], o[8];
+        float mu[8], is[8], ga[8], be[8], s1[8], s2[8];
         load8(mean + c, mu);
         load8(invstd + c, is);
         load8(gamma + c, ga);
         load8(beta + c, be);
         load8(sums + c, s1);
         load8(sums + C + c, s2);
+        // (window, tap) pairs of every pixel: tap index kh * 3 + kw
+        constexpr int NW[4] = {1, 2, 2, 4};
+        constexpr int WIN[4][4] = {{0, 0, 0, 0}, {0, 1, 0, 0}, {0, 2, 0, 0}, {0, 1, 2, 3}};
+        constexpr int TAP[4][4] = {{4, 0, 0, 0}, {5, 3, 0, 0}, {7, 1, 0, 0}, {8, 6, 2, 0}};
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const float xh = (v[e] - mu[e]) * is[e];
-            const float dz = g[e] * act_grad(xh * ga[e] + be[e], act);
-            o[e] = ga[e] * is[e] * (dz - s1[e] * inv_n - xh * s2[e] * inv_n);
+        for (int p = 0; p < 4; p++) {
+            float g[8], o[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) g[e] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (q >= NW[p]) continue;
+                const int wi = WIN[p][q], tap = TAP[p][q];
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                    g[e] += (wok[wi] && (int)((pk[wi] >> (8 * e)) & 0xff) == tap) ? d[wi][e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float xh = (v[p][e] - mu[e]) * is[e];
+                const float dz = g[e] * act_grad(xh * ga[e] + be[e], act);
+                o[e] = ga[e] * is[e] * (dz - s1[e] * inv_n - xh * s2[e] * inv_n);
+            }
+            if (pok[p]) store8(dx + poff[p], o);
         }
-        store8(dx + i * 8, o);
     }
 }
 
@@ -797,12 +805,13 @@ extern "C" int avsr_bn_pool_bwd_apply(const void* x, const void* dpool, const ui
     if (rows <= 0) return 0;
     dim3 grid(ew_grid(rows * (C >> 3))), block(BN_THREADS);
     if (K == 3 && S == 2 && P == 1) {
+        dim3 gq(ew_grid((long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C >> 3)));  // one thread per 2 x 2 pixel quad and chunk
         if (dtype == 0)
-            AVSR_LAUNCH((bn_pool3_bwd_apply_kernel<float>), grid, block, 0, stream, (const float*)x, (const float*)dpool, idx,
-                        mean, invstd, gamma, beta, sums, inv_n, n_dev, (float*)dx, rows, H, W, C, OH, OW, act);
+            AVSR_LAUNCH((bn_pool3_bwd_apply_kernel<float>), gq, block, 0, stream, (const float*)x, (const float*)dpool, idx,
+                        mean, invstd, gamma, beta, sums, inv_n, n_dev, (float*)dx, (long)N, H, W, C, OH, OW, act);
         else
-            AVSR_LAUNCH((bn_pool3_bwd_apply_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dpool,
-                        idx, mean, invstd, gamma, beta, sums, inv_n, n_dev, (bf16_t*)dx, rows, H, W, C, OH, OW, act);
+            AVSR_LAUNCH((bn_pool3_bwd_apply_kernel<bf16_t>), gq, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dpool,
+                        idx, mean, invstd, gamma, beta, sums, inv_n, n_dev, (bf16_t*)dx, (long)N, H, W, C, OH, OW, act);
         AVSR_CHECK_LAUNCH("bn_pool_bwd_apply");
         return 0;
     }

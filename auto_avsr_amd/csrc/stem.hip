@@ -1,8 +1,9 @@
 // stem.hip -- dedicated kernels for the visual front-end stem  Conv3d(1, 64, (5,7,7), stride (1,2,2), padding (2,3,3))
 // (frontend/resnet.py:204-211) in bf16 mode.  C_in = 1 makes the generic im2col gather element-wise; here the 35
 // (kt,kh) input rows an output row needs are staged ONCE in LDS (as bf16, zero padded), and the MFMA operands are
-// read from that patch: K is re-indexed as (kt*7+kh)*8 + kw with a zero 8th tap, so a lane's 8 consecutive k values
-// are 8 consecutive input columns -- four aligned ds_read_b32.
+// read from that patch: K is re-indexed as (kt*7+kh)*8 + 1 + kw with a zero FIRST tap, so a lane's 8 consecutive k values
+// are 8 consecutive input columns starting at an even (4-byte aligned) patch column -- four aligned ds_read_b32 -- while
+// the patch itself is staged with its data at column 4 (8-byte aligned): one ds_write_b64 per float4 of input.
 //   forward : a block walks 8 output rows (n, oh) with its weights (64 x 288 bf16) in registers; wave w owns 16 output
 //             channels; 3 pixel tiles x 9 k-steps of v_mfma_f32_16x16x32_bf16 per row; the row is assembled in LDS and
 //             leaves as 128-byte pixels with 16-byte stores.
@@ -16,17 +17,18 @@ namespace {
 constexpr int KT = 5, KH = 7, KW = 7, ROWS = KT * KH;  // 35 (kt,kh) rows
 constexpr int KP = 288;                                // padded K: 36 rows x 8 taps
 constexpr int CO = 64;
-constexpr int LP = 104;                                // LDS row pitch (bf16): >= 2*47+8, multiple of 8
+constexpr int LP = 104;                                // LDS row pitch (bf16): >= 2*47+8 and >= 4 + W (W <= 96), multiple of 8
 
-// wp[co][(kt*7+kh)*8 + kw] = w[co][0][kt][kh][kw]; zero for kw = 7 and rows >= 35
+// wp[co][(kt*7+kh)*8 + 1 + kw] = w[co][0][kt][kh][kw]; zero for slot 0 and rows >= 35
 __global__ void stem_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ wp) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= CO * KP) return;
-    const int co = i / KP, k = i % KP, r = k >> 3, kw = k & 7;
-    wp[i] = (r < ROWS && kw < KW) ? f2bf(w[(co * ROWS + r) * KW + kw]) : (bf16_t)0;
+    const int co = i / KP, k = i % KP, r = k >> 3, j = k & 7;
+    wp[i] = (r < ROWS && j >= 1) ? f2bf(w[(co * ROWS + r) * KW + j - 1]) : (bf16_t)0;
 }
 
-// The 36 x LP bf16 patch of output row (n, oh): patch[r][3 + iw] = x[b][t+kt-2][2*oh+kh-3][iw].  Padding columns and
+// The 36 x LP bf16 patch of output row (n, oh): patch[r][4 + iw] = x[b][t+kt-2][2*oh+kh-3][iw]; output pixel ow reads the
+// columns 2*ow .. 2*ow+7 = input columns 2*ow-4 .. 2*ow+3 (the first one under the zero tap).  Padding columns and
 // the dummy row 35 are zeroed once per block (patch_init); a row's data is fetched into registers (patch_load) one
 // row AHEAD of its use and written to LDS (patch_store) after the previous row's compute -- the global-load latency
 // of row i+1 hides behind the MFMAs of row i.
@@ -34,7 +36,7 @@ constexpr int PATCH_V = 4;  // float4 per thread: 35 rows x (W/4 <= 24) <= 840 <
 AVSR_DEV void patch_init(bf16_t* patch, int W) {
     for (int i = threadIdx.x; i < 36 * LP; i += 256) {
         const int r = i / LP, c = i - r * LP;
-        if (r == 35 || c < 3 || c >= 3 + W) patch[i] = 0;
+        if (r == 35 || c < 4 || c >= 4 + W) patch[i] = 0;
     }
 }
 AVSR_DEV void patch_load(f32x4 (&q)[PATCH_V], const float* __restrict__ x, long row, int OH, int T, int H, int W) {
@@ -61,8 +63,8 @@ AVSR_DEV void patch_store(bf16_t* patch, const f32x4 (&q)[PATCH_V], int W) {
         const int i = threadIdx.x + 256 * j;
         if (i < ROWS * nv) {
             const int r = i / nv, v = i - r * nv;
-#pragma unroll
-            for (int e = 0; e < 4; e++) patch[r * LP + 3 + v * 4 + e] = f2bf(q[j][e]);
+            const bf16x4 o = bf16x4{(short)f2bf(q[j][0]), (short)f2bf(q[j][1]), (short)f2bf(q[j][2]), (short)f2bf(q[j][3])};
+            *reinterpret_cast<bf16x4*>(patch + r * LP + 4 + v * 4) = o;  // 8-byte aligned (LP and 4 + 4 v are multiples of 4)
         }
     }
 }
@@ -108,10 +110,14 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
         for (int mt = 0; mt < ntile; mt++) {
             const int ow = min(mt * 16 + lc, OW - 1);
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            // D^T = W . X^T: the weights are the A operand (rows = this wave's 16 channels), the patch the B operand (columns =
+            // 16 pixels) -- the per-lane fragments are the same registers either way, but the accumulator then holds FOUR
+            // CONSECUTIVE CHANNELS of one pixel (row 4*quad + r = channel, column lc = pixel): one 8-byte LDS store per tile
+            // instead of four 2-byte ones (the 2-byte stores were a quarter of the kernel's LDS instruction issue)
 #pragma unroll
-            for (int ks = 0; ks < 9; ks++) acc = mfma16(patch_frag(patch, ks * 4 + quad, ow), fb[ks], acc);
-#pragma unroll
-            for (int r = 0; r < 4; r++) orow[(mt * 16 + 4 * quad + r) * OP + 16 * w + lc] = f2bf(acc[r]);
+            for (int ks = 0; ks < 9; ks++) acc = mfma16(fb[ks], patch_frag(patch, ks * 4 + quad, ow), acc);
+            const bf16x4 o = bf16x4{(short)f2bf(acc[0]), (short)f2bf(acc[1]), (short)f2bf(acc[2]), (short)f2bf(acc[3])};
+            *reinterpret_cast<bf16x4*>(orow + (mt * 16 + lc) * OP + 16 * w + 4 * quad) = o;
         }
         __syncthreads();
         // the four waves' 16-channel slices are now one [OW][64] row: 128-byte pixels, 16-byte stores
@@ -286,7 +292,8 @@ __global__ __launch_bounds__(1024) void stem_wgrad_reduce_kernel(const float* __
 
 }  // namespace
 
-extern "C" int64_t avsr_stem357_workspace_bytes(void) { return (int64_t)512 * KP * CO * 4 + (int64_t)CO * KP * 2; }
+constexpr int WG_MAX = 1024;  // upper bound of the weight-gradient grid (per-block partials live in the workspace)
+extern "C" int64_t avsr_stem357_workspace_bytes(void) { return (int64_t)WG_MAX * KP * CO * 4 + (int64_t)CO * KP * 2; }
 
 // y[B*T, OH, OW, 64] (bf16) = conv3d(x[B,T,H,W] f32, w[64,1,5,7,7] f32), stride (1,2,2), padding (2,3,3).
 // workspace: avsr_stem357_workspace_bytes() bytes (holds the re-laid-out bf16 weights)
@@ -296,7 +303,7 @@ extern "C" int avsr_stem357_fwd(const float* x, const float* w, void* y, void* w
     static_assert(ROWS * 24 <= PATCH_V * 256, "patch prefetch registers");
     if (B <= 0 || T <= 0) return 0;
     const int OH = (H + 6 - KH) / 2 + 1, OW = (W + 6 - KW) / 2 + 1;
-    bf16_t* wp = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(workspace) + (size_t)512 * KP * CO * 4);
+    bf16_t* wp = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(workspace) + (size_t)WG_MAX * KP * CO * 4);
     AVSR_LAUNCH(stem_weight_kernel, dim3((CO * KP + 255) / 256), dim3(256), 0, stream, w, wp);
     const long rows = (long)B * T * OH;
     AVSR_REQUIRE(OW <= 64, "stem357: at most 64 output columns");
@@ -314,7 +321,9 @@ extern "C" int avsr_stem357_wgrad(const void* dy, const float* x, float* dw, voi
     const int OH = (H + 6 - KH) / 2 + 1, OW = (W + 6 - KW) / 2 + 1;
     AVSR_REQUIRE(OW <= 64, "stem357: at most 64 output columns");
     const long rows = (long)B * T * OH;
-    const int G = (int)(rows < 512 ? rows : 512);
+    int gmax = avsr_tune_knobs[6] > 0 ? avsr_tune_knobs[6] : 512;  // knob 6: persistent blocks (benchmarks)
+    if (gmax > WG_MAX) gmax = WG_MAX;
+    const int G = (int)(rows < gmax ? rows : gmax);
     float* partial = reinterpret_cast<float*>(workspace);
     AVSR_LAUNCH(stem_wgrad_kernel, dim3(G), dim3(256), 0, stream, (const bf16_t*)dy, x, partial, T, H, W, OH, OW, rows);
     AVSR_LAUNCH(stem_wgrad_reduce_kernel, dim3((KP * CO + 63) / 64), dim3(1024), 0, stream, (const float*)partial, G, dw);
