@@ -80,14 +80,16 @@ extern "C" int avsr_gemm_tn_batched(const void* A, int a_dtype, int lda, int64_t
 // The key/value side of the attention backward (attention.py:59-104,131-193 under autograd) in ONE launch:
 //   dV[b,h] = Pd[b,h]^T dO[b,h]      dK[b,h] = dS[b,h]^T Qu[b,h]      dpos += sum_{b,h} skew(dS[b,h])^T Qv[b,h]
 // pd / ds: [B,H,Tq,lds] (avsr_attention_bwd_dq); dout / qu / qv: [B,Tq,H,64] views (row pitch ld*, batch stride sb*);
-// dk / dv: [B,Tk,H,64] views; dpos (may be NULL together with qv): f32 [2Tq-1, H*64], accumulated into (caller zeroes).
+// dk / dv: [B,Tk,H,64] views; dpos (may be NULL together with qv): f32 [2Tq-1, H*64] with row pitch ldpos (a column block
+// of an all-layer buffer), accumulated into (caller zeroes).
 // The three contractions are independent and individually far too small for 256 CUs.
 extern "C" int avsr_attention_bwd_kv(const void* pd, const void* ds, int lds, const void* dout, int ldo, int64_t sbo,
                                      const void* qu, const void* qv, int ldq, int64_t sbq, void* dk, int ldk, int64_t sbk,
-                                     void* dv, int ldv, int64_t sbv, float* dpos, int dtype, int precise, int B, int H,
-                                     int Tq, int Tk, int dk_dim, hipStream_t stream) {
+                                     void* dv, int ldv, int64_t sbv, float* dpos, int ldpos, int dtype, int precise, int B,
+                                     int H, int Tq, int Tk, int dk_dim, hipStream_t stream) {
     AVSR_REQUIRE(lds % 8 == 0 && ldo % 8 == 0 && ldq % 8 == 0, "attention_bwd_kv: pitches must be multiples of 8 elements");
     AVSR_REQUIRE((dpos == nullptr) == (qv == nullptr), "attention_bwd_kv: dpos and qv go together");
+    AVSR_REQUIRE(dpos == nullptr || ldpos >= H * dk_dim, "attention_bwd_kv: dpos row pitch smaller than H * dk");
     if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return 0;
     avsr_gemm_impl::Params ps[3];
     int n = 0;
@@ -107,7 +109,7 @@ extern "C" int avsr_attention_bwd_kv(const void* pd, const void* ds, int lds, co
     ps[n++] = base(pd, dout, ldo, sbo, dv, dtype, ldv, sbv, dk_dim, Tk);
     ps[n++] = base(ds, qu, ldq, sbq, dk, dtype, ldk, sbk, dk_dim, Tk);
     if (dpos) {
-        avsr_gemm_impl::Params p = base(ds, qv, ldq, sbq, dpos, 0, H * dk_dim, 0, dk_dim, 2 * Tq - 1);
+        avsr_gemm_impl::Params p = base(ds, qv, ldq, sbq, dpos, 0, ldpos, 0, dk_dim, 2 * Tq - 1);
         p.accumulate = 1;
         p.a_skew = 1; p.skew_off = Tq - 1; p.skew_lim = Tk;
         ps[n++] = p;

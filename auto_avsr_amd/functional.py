@@ -306,10 +306,60 @@ def prepare_pos_proj(pos_emb, weights):
     if pe.dtype != torch.bfloat16:
         return
     n, P = len(weights), pe.shape[0]
+    if torch.is_grad_enabled() and all(w.requires_grad for w in weights):
+        # training: the projection is an autograd node of its own, so that the n weight gradients are ONE contraction too
+        holder = {}
+        out = PosProjFn.apply(pos_emb, holder, *weights)
+        for i, w in enumerate(weights):
+            _pos_proj[(pos_emb.data_ptr(), w.data_ptr())] = (pos_emb, None, out, i, holder)
+        return
     out = torch.empty(P, n * D, dtype=torch.bfloat16, device=pe.device)
     ops.gemm_bf16_nt(pe, D, _w_bf16_cat(tuple(weights), False), D, P, n * D, D, out, n * D)
     for i, w in enumerate(weights):
-        _pos_proj[(pos_emb.data_ptr(), w.data_ptr())] = (pos_emb, out[:, i * D:(i + 1) * D])
+        _pos_proj[(pos_emb.data_ptr(), w.data_ptr())] = (pos_emb, out[:, i * D:(i + 1) * D], None, i, None)
+
+
+_placeholders = {}
+
+
+def _placeholder_grad(shape, dtype, device):
+    """A zero 'gradient' of the right shape / dtype that costs no launch and no memory (an expanded scalar): tells autograd
+    that the producer's backward may run, while the real gradient sits in a side buffer."""
+    z = _placeholders.get((dtype, device))
+    if z is None:
+        z = _placeholders[(dtype, device)] = torch.zeros((), dtype=dtype, device=device)
+    return z.expand(shape)
+
+
+class PosProjFn(torch.autograd.Function):
+    """linear_pos of every encoder layer applied to the (batch-shared, layer-independent) position table
+    (attention.py:170): forward one [P, D] x [D, n*D] GEMM; backward one [n*D, D] = dpos_all^T pe contraction over the
+    buffer whose column blocks the layers' attention backward accumulated into (MhaSublayerFn, ctx.pp) -- instead of n
+    zero-fills and n 144-tile GEMMs that each leave half of the chip idle."""
+
+    @staticmethod
+    def forward(ctx, pos_emb, holder, *weights):
+        D = pos_emb.shape[-1]
+        pe = _to_act_shared(pos_emb).reshape(-1, D)
+        n, P = len(weights), pe.shape[0]
+        out = torch.empty(P, n * D, dtype=torch.bfloat16, device=pe.device)
+        ops.gemm_bf16_nt(pe, D, _w_bf16_cat(tuple(weights), False), D, P, n * D, D, out, n * D)
+        ctx.save_for_backward(pe)
+        ctx.holder, ctx.meta = holder, (P, D, n)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (pe,) = ctx.saved_tensors
+        P, D, n = ctx.meta
+        holder = ctx.holder
+        assert holder.get("filled", 0) == n and holder.get("dpos") is not None, \
+            "PosProjFn: every encoder layer must have accumulated its position gradient"
+        # (`dout` is a placeholder: autograd would round a real f32 gradient to the bf16 of the forward output)
+        dW = _wgrad(holder["dpos"], pe, P, n * D, D)
+        holder["dpos"] = None
+        holder["filled"] = 0
+        return (None, None) + tuple(dW[i * D:(i + 1) * D] for i in range(n))
 
 
 def _fast_ok(a, K, lda):
@@ -905,7 +955,7 @@ class AttentionCoreFn(torch.autograd.Function):
             dv_bias = torch.zeros(D, dtype=torch.float32, device=g.device)
             ops.head_bias_bwd(dqu, dqv, dq, D, du, dv_bias, B * Tq, D)
             du, dv_bias = du.view(H, dk), dv_bias.view(H, dk)
-            dwpos = _wgrad(dpos, pe, pe.shape[0], D, D)
+            dwpos = _wgrad(dpos, pe, pe.shape[0], D, D) if ctx.pp is None else None
         else:
             dq = dqu.view(B * Tq, D)
         dk2, dv2 = dk_.view(B * Tk, D), dv_.view(B * Tk, D)
@@ -960,16 +1010,21 @@ class MhaSublayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, memory, pos_emb, mask, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, wpos, bias_u, bias_v, H,
-                p_attn, p_out, eps):
+                p_attn, p_out, eps, kv_all=None, kv_slot=0, kv_holder=None, pp_all=None, pp_slot=0, pp_holder=None):
         x = x.contiguous()
         ctx.chain = _chain_take(x)
         B, Tq, D = x.shape
         dk = D // H
         T = act_dtype()
         h, mean, rstd = ops.layernorm_fwd(x, ln_w, ln_b, T, eps)
-        cross = memory is not None
-        ka = _to_act_shared(memory) if cross else h
-        Tk = ka.shape[1]
+        shared_kv = kv_all is not None  # source attention on the all-layer K/V projection of the memory (MemoryKVFn)
+        cross = memory is not None or shared_kv
+        if shared_kv:
+            ka = None
+            Tk = kv_all.shape[0] // B
+        else:
+            ka = _to_act_shared(memory) if cross else h
+            Tk = ka.shape[1]
         # self attention in bf16: ONE projection GEMM onto the concatenated [Wq; Wk; Wv] (N = 3D fills the chip where
         # three N = D launches do not); q / k / v are column thirds of its output, read in place by the attention kernel
         fused = _FUSE_QKV and (not cross) and (not _state["precise"]) and D % 64 == 0 and T == torch.bfloat16 \
@@ -982,6 +1037,11 @@ class MhaSublayerFn(torch.autograd.Function):
             q5 = qkv.view(B, Tq, 3, H, dk)
             q, k4, v4 = qkv, q5[:, :, 1], q5[:, :, 2]
             ldq = 3 * D
+        elif shared_kv:
+            q = _proj(h, wq, bq, B * Tq, D)
+            kv5 = kv_all.view(B, Tk, kv_all.shape[1] // D, H, dk)  # [.., 2 * slot] = K, [.., 2 * slot + 1] = V of this layer
+            k4, v4 = kv5[:, :, 2 * kv_slot], kv5[:, :, 2 * kv_slot + 1]
+            ldq = D
         else:
             q = _proj(h, wq, bq, B * Tq, D)
             k4 = _proj(ka, wk, bk, B * Tk, D).view(B, Tk, H, dk)
@@ -990,9 +1050,11 @@ class MhaSublayerFn(torch.autograd.Function):
         pe = pproj = qv = None
         if relpos:
             pe = _to_act_shared(pos_emb).reshape(-1, D)
-            pre = _pos_proj.get((pos_emb.data_ptr(), wpos.data_ptr()))
-            if pre is not None and pre[1].dtype == T:
-                pproj = pre[1]  # column block of the all-layer projection (prepare_pos_proj), row pitch n_layers * D
+            pre = _pos_proj.get((pos_emb.data_ptr(), wpos.data_ptr())) if pp_all is None else None
+            if pp_all is not None:
+                pproj = pp_all[:, pp_slot * D:(pp_slot + 1) * D]  # column block of the all-layer projection (PosProjFn)
+            elif pre is not None and pre[1] is not None and pre[1].dtype == T:
+                pproj = pre[1]  # the same, without autograd (prepare_pos_proj under no_grad), row pitch n_layers * D
             else:
                 pproj = torch.empty(pe.shape[0], D, dtype=T, device=x.device)
                 _gemm_nt(pe, wpos, pe.shape[0], D, D, pproj)
@@ -1007,9 +1069,11 @@ class MhaSublayerFn(torch.autograd.Function):
         po, so, sdo = _drop_args(p_out, x)
         y = torch.empty_like(x)
         _gemm_nt(ctxv, wo, B * Tq, D, D, y, bias=bo, drop_p=po, seed=so, seed_dev=sdo, resid=x, ldr=D)
-        ctx.save_for_backward(x, ln_w, mean, rstd, h, ka if cross else None, pe, m, wq, wk, wv, wo, wpos, qu, qv, k4, v4,
-                              pproj, ctxv, lse)
+        ctx.save_for_backward(x, ln_w, mean, rstd, h, ka if (cross and not shared_kv) else None, pe, m, wq, wk, wv, wo, wpos,
+                              qu, qv, k4, v4, pproj, ctxv, lse)
         ctx.meta = (H, pa, sa, sda, po, so, sdo, cross, relpos, fused)
+        ctx.kv = (kv_slot, kv_holder, tuple(kv_all.shape)) if shared_kv else None
+        ctx.pp = (pp_slot, pp_holder, tuple(pp_all.shape)) if (relpos and pp_all is not None) else None
         _chain_tag(y, B * Tq, D, 1.0, (po, so, sdo))
         return y
 
@@ -1019,9 +1083,10 @@ class MhaSublayerFn(torch.autograd.Function):
         H, pa, sa, sda, po, so, sdo, cross, relpos, fused = ctx.meta
         dy = dy.contiguous()
         B, Tq, D = x.shape
+        shared_kv = ctx.kv is not None
         if not cross:
             ka = h
-        Tk = ka.shape[1]
+        Tk = k4.shape[1]
         dk = D // H
         T = act_dtype()
         g, gT, _ = _prologue(dy, B * Tq, D, drop=(po, so, sdo), want_bias=False)
@@ -1037,6 +1102,27 @@ class MhaSublayerFn(torch.autograd.Function):
             outs = dict(dk_out=d5[:, :, 1], dv_out=d5[:, :, 2])
             if not relpos:
                 outs["dqu_out"] = d5[:, :, 0]
+        dkv_grad = None
+        if shared_kv:
+            # dK / dV go straight into this layer's columns of the shared gradient buffer; the projection's own backward
+            # (weight, bias and memory gradients of ALL layers) runs once, in MemoryKVFn.backward
+            slot, holder, shape = ctx.kv
+            if holder.get("dkv") is None:
+                holder["dkv"] = torch.empty(shape, dtype=T, device=x.device)
+            g5 = holder["dkv"].view(B, Tk, shape[1] // D, H, dk)
+            outs = dict(dk_out=g5[:, :, 2 * slot], dv_out=g5[:, :, 2 * slot + 1])
+            holder["filled"] = holder.get("filled", 0) + 1
+            dkv_grad = holder["dkv"] if slot == 0 else None  # ONE consumer hands the buffer to autograd, the others None
+        dpp_grad = None
+        if ctx.pp is not None:
+            # this layer's position gradient accumulates into its column block of ONE zero-filled buffer; the weight
+            # gradients of all layers come from it in PosProjFn.backward
+            slot, holder, shape = ctx.pp
+            if holder.get("dpos") is None:
+                holder["dpos"] = _zeros(shape, x.device)
+            outs = dict(outs, dpos_out=holder["dpos"][:, slot * D:(slot + 1) * D])
+            holder["filled"] = holder.get("filled", 0) + 1
+            dpp_grad = _placeholder_grad(shape, T, x.device) if slot == 0 else None  # the f32 buffer travels in `holder`
         dqu, dqv, dk_, dv_, dpos = ops.attention_bwd(
             qu, qv, k4, v4, pproj, m, ctxv, lse, dctx, 1.0 / math.sqrt(dk), precise=_state["precise"],
             drop_p=pa, seed=sa, seed_dev=sda, **outs)
@@ -1047,7 +1133,7 @@ class MhaSublayerFn(torch.autograd.Function):
             dv_bias = _zeros(D, x.device)
             ops.head_bias_bwd(dqu, dqv, dq, 3 * D if fused else D, du, dv_bias, B * Tq, D)
             du, dv_bias = du.view(H, dk), dv_bias.view(H, dk)
-            dwpos = _wgrad(dpos, pe, pe.shape[0], D, D)
+            dwpos = _wgrad(dpos, pe, pe.shape[0], D, D) if ctx.pp is None else None
         elif not fused:
             dq = dqu.view(B * Tq, D)
         dmem = None
@@ -1061,13 +1147,20 @@ class MhaSublayerFn(torch.autograd.Function):
             dwq, dwk, dwv = dwc[:D], dwc[D:2 * D], dwc[2 * D:]
             dbq, dbk, dbv = dbc[:D], dbc[D:2 * D], dbc[2 * D:]
         else:
-            dk2, dv2 = dk_.view(B * Tk, D), dv_.view(B * Tk, D)
+            if not shared_kv:
+                dk2, dv2 = dk_.view(B * Tk, D), dv_.view(B * Tk, D)
             hT = _xT(h.view(B * Tq, D), B * Tq, D)
-            kaT = hT if not cross else _xT(ka.view(B * Tk, D), B * Tk, D)
+            kaT = None
             dqT = dkT = dvT = None
             dbq, dbk, dbv = _zeros(D, x.device), _zeros(D, x.device), _zeros(D, x.device)
             # each projection: weight gradient + data gradient as one launch (data gradients chain through `resid`)
-            if cross:
+            if shared_kv:
+                dh = torch.empty(B * Tq, D, dtype=T, device=x.device)
+                with ops.paired():
+                    dwq = _wgrad(dq, h, B * Tq, D, D, xT=hT, dyT=dqT, bias_out=dbq)
+                    _gemm_nn(dq, wq, B * Tq, D, D, dh)
+                dwk = dwv = dbk = dbv = None
+            elif cross:
                 dh = torch.empty(B * Tq, D, dtype=T, device=x.device)
                 with ops.paired():
                     dwq = _wgrad(dq, h, B * Tq, D, D, xT=hT, dyT=dqT, bias_out=dbq)
@@ -1100,13 +1193,85 @@ class MhaSublayerFn(torch.autograd.Function):
         dbt = _zeros(D, x.device)
         dx = _ln_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dy, ctx.chain)
         return (dx, dmem, None, None, dg, dbt, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dwpos, du, dv_bias, None, None,
-                None, None)
+                None, None, dkv_grad, None, None, dpp_grad, None, None)
 
 
 def mha_sublayer(x, memory, pos_emb, mask, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, wpos, bias_u, bias_v, H, p_attn,
-                 p_out, eps=1e-12):
+                 p_out, eps=1e-12, kv=None):
+    """kv = (kv_all, slot, holder) from memory_kv(): source attention reads its K / V from the all-layer projection."""
+    if kv is not None:
+        return MhaSublayerFn.apply(_to_f32(x), None, pos_emb, mask, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, wpos,
+                                   bias_u, bias_v, H, float(p_attn), float(p_out), eps, kv[0], kv[1], kv[2])
+    if pos_emb is not None and wpos is not None:
+        pre = _pos_proj.get((pos_emb.data_ptr(), wpos.data_ptr()))
+        if pre is not None and pre[2] is not None and torch.is_grad_enabled():
+            return MhaSublayerFn.apply(_to_f32(x), memory, pos_emb, mask, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, wpos,
+                                       bias_u, bias_v, H, float(p_attn), float(p_out), eps, None, 0, None, pre[2], pre[3],
+                                       pre[4])
     return MhaSublayerFn.apply(_to_f32(x), memory, pos_emb, mask, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, wpos,
                                bias_u, bias_v, H, float(p_attn), float(p_out), eps)
+
+
+class MemoryKVFn(torch.autograd.Function):
+    """K and V projections of the encoder memory for ALL decoder layers at once (transformer_decoder.py:100-108 runs
+    linear_k / linear_v of every layer's src_attn on the same memory, attention.py:50-52):
+        forward : kv_all [B*Tk, 2*n*D] = memory @ [Wk_0; Wv_0; Wk_1; ...]^T + [bk_0 | bv_0 | ...]   -- ONE GEMM instead of 2n;
+        backward: the n source-attention sub-layers write dK_l / dV_l into their columns of one shared buffer
+                  (MhaSublayerFn, shared_kv); when all of them have run, ONE paired launch gives the weight gradients of
+                  all 2n projections (+ bias gradients) and the memory gradient sum_l (dK_l Wk_l + dV_l Wv_l) -- instead of
+                  2n paired launches chained through `resid` and n - 1 autograd additions of [B, Tk, D] tensors.
+    The contraction of the memory gradient runs over K = 2*n*D = 9216 in one launch: long k loops are where the tile kernel
+    is efficient."""
+
+    @staticmethod
+    def forward(ctx, memory, holder, *wb):
+        B, Tk, D = memory.shape
+        ws, bs = wb[0::2], wb[1::2]
+        n = len(ws)
+        ma = _to_act_shared(memory).reshape(B * Tk, D)
+        kv = torch.empty(B * Tk, n * D, dtype=torch.bfloat16, device=memory.device)
+        ops.gemm_bf16_nt(ma, D, _w_bf16_cat(tuple(ws), False), D, B * Tk, n * D, D, kv, n * D, bias=torch.cat(bs))
+        ctx.save_for_backward(ma, *ws)
+        ctx.holder = holder
+        ctx.meta = (B, Tk, D, n)
+        return kv
+
+    @staticmethod
+    def backward(ctx, dkv):
+        ma, *ws = ctx.saved_tensors
+        B, Tk, D, n = ctx.meta
+        holder = ctx.holder
+        assert holder.get("filled", 0) == n // 2 and dkv.data_ptr() == holder["dkv"].data_ptr(), \
+            "MemoryKVFn: every source-attention sub-layer must have written its dK / dV"
+        rows = B * Tk
+        dbias = _zeros(n * D, dkv.device)
+        dmem = torch.empty(B, Tk, D, dtype=torch.float32, device=dkv.device)
+        wcT = _w_bf16_cat(tuple(ws), True)
+        with ops.paired():
+            dW = _wgrad(dkv, ma, rows, n * D, D, bias_out=dbias)
+            ops.gemm_bf16_nt(dkv, n * D, wcT, n * D, rows, D, n * D, dmem.view(rows, D), D)
+        holder["dkv"] = None
+        holder["filled"] = 0
+        grads = [dmem, None]
+        for i in range(n):
+            grads += [dW[i * D:(i + 1) * D], dbias[i * D:(i + 1) * D]]
+        return tuple(grads)
+
+
+def memory_kv(memory, layers_kv):
+    """layers_kv: [(Wk, bk, Wv, bv)] per decoder layer.  Returns (kv_all, holder) for mha_sublayer(kv=(kv_all, l, holder)),
+    or None when the shared projection does not apply (precise mode, shapes the tuned kernel does not take)."""
+    if _state["precise"] or not _FUSE_QKV or len(layers_kv) < 2 or not torch.is_grad_enabled():
+        return None
+    D = memory.shape[-1]
+    flat = []
+    for (wk, bk, wv, bv) in layers_kv:
+        flat += [wk, bk, wv, bv]
+    if D % 64 or any(w.dtype != torch.float32 or not w.is_contiguous() or tuple(w.shape) != (D, D) for w in flat[0::2]) \
+            or any(b is None for b in flat[1::2]) or not memory.requires_grad:
+        return None
+    holder = {}
+    return MemoryKVFn.apply(memory, holder, *flat), holder
 
 
 # ------------------------------------------------------------------------------------------------ BatchNorm plumbing

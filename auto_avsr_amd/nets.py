@@ -379,7 +379,9 @@ class DecoderLayer(nn.Module):
         self.normalize_before = normalize_before
         self.concat_after = concat_after
 
-    def forward(self, tgt, tgt_mask, memory, memory_mask, cache=None):
+    def forward(self, tgt, tgt_mask, memory, memory_mask, cache=None, kv=None):
+        """kv (not in the reference): (kv_all, slot, holder) from functional.memory_kv -- this layer's source-attention K / V
+        are columns of the all-layer projection of the memory (TransformerDecoder.forward)."""
         p = self.dropout.p if self.training else 0.0
         sa, ca, ff = self.self_attn, self.src_attn, self.feed_forward
         if cache is None:
@@ -394,7 +396,7 @@ class DecoderLayer(nn.Module):
                                            None, sa.h, sa._p_attn(), False)
             x = AF.add(tgt[:, -1:, :], att)
         x = AF.mha_sublayer(x, memory, None, memory_mask, self.norm2.weight, self.norm2.bias, *ca._params(), None, None,
-                            None, ca.h, ca._p_attn(), p, self.norm2.eps)
+                            None, ca.h, ca._p_attn(), p, self.norm2.eps, kv=kv)
         x = AF.ffn_sublayer(x, self.norm3.weight, self.norm3.bias, ff.w_1.weight, ff.w_1.bias, ff.w_2.weight,
                             ff.w_2.bias, 1.0, p, self.norm3.eps)
         if cache is not None:
@@ -442,7 +444,14 @@ class TransformerDecoder(BatchScorerInterface, nn.Module):
 
     def forward(self, tgt, tgt_mask, memory, memory_mask):
         x = self._embed(tgt)
-        x, tgt_mask, memory, memory_mask = self.decoders(x, tgt_mask, memory, memory_mask)
+        # the source-attention K / V projections of all layers act on the same memory: one GEMM (functional.MemoryKVFn)
+        shared = AF.memory_kv(memory, [(d.src_attn.linear_k.weight, d.src_attn.linear_k.bias, d.src_attn.linear_v.weight,
+                                        d.src_attn.linear_v.bias) for d in self.decoders])
+        if shared is None:
+            x, tgt_mask, memory, memory_mask = self.decoders(x, tgt_mask, memory, memory_mask)
+        else:
+            for i, layer in enumerate(self.decoders):  # (layer_drop_rate is 0.0 in the reference model: plain loop)
+                x, tgt_mask, memory, memory_mask = layer(x, tgt_mask, memory, memory_mask, kv=(shared[0], i, shared[1]))
         if self.normalize_before:
             x = self.after_norm(x)
         if self.output_layer is not None:

@@ -177,9 +177,10 @@ def gemm_tn_batched(A, lda, sAb, sAh, Bm, ldb, sBb, sBh, C, ldc, sCb, sCh, nb, n
 
 
 def attention_bwd(qu, qv, k, v, pos, mask, out, lse, dout, scale, *, precise=False, drop_p=0.0, seed=0,
-                  seed_dev=None, dqu_out=None, dk_out=None, dv_out=None):
+                  seed_dev=None, dqu_out=None, dk_out=None, dv_out=None, dpos_out=None):
     """Full attention backward.  Returns dqu, dqv (or None), dk, dv, dpos (f32 [2T-1, H*64] or None).
-    dqu_out / dk_out / dv_out: optional [B,T,H,64] destination views (slices of a fused d(qkv) buffer)."""
+    dqu_out / dk_out / dv_out: optional [B,T,H,64] destination views (slices of a fused d(qkv) buffer).
+    dpos_out: optional ZEROED f32 [2T-1, H*64] destination view (a column block of an all-layer buffer)."""
     B, Tq, H, dk = qu.shape
     Tk = k.shape[1]
     D = H * dk
@@ -190,12 +191,16 @@ def attention_bwd(qu, qv, k, v, pos, mask, out, lse, dout, scale, *, precise=Fal
     dvv = dv_out if dv_out is not None else torch.empty(B, Tk, H, dk, dtype=qu.dtype, device=qu.device)
     do4 = dout.view(B, Tq, H, dk)
     # dV[b,h] = Pd[b,h]^T dO[b,h] ; dK[b,h] = dS[b,h]^T Qu[b,h] ; dpos += skew(dS[b,h])^T Qv[b,h] -- one launch
-    dpos = zeros_f32((2 * Tq - 1, D), qu.device) if pos is not None else None  # accumulated into
+    dpos = None
+    if pos is not None:  # accumulated into
+        dpos = dpos_out if dpos_out is not None else zeros_f32((2 * Tq - 1, D), qu.device)
+        assert dpos.dtype == torch.float32 and dpos.shape == (2 * Tq - 1, D) and dpos.stride(1) == 1
     assert qv is None or qv.stride() == qu.stride()
     assert dkk.stride(2) == dk and dvv.stride(2) == dk and do4.stride(2) == dk and qu.stride(2) == dk
     call("avsr_attention_bwd_kv", _ptr(pd), _ptr(ds), lds, _ptr(do4), do4.stride(1), do4.stride(0), _ptr(qu),
          _ptr(qv) if pos is not None else None, qu.stride(1), qu.stride(0), _ptr(dkk), dkk.stride(1), dkk.stride(0),
-         _ptr(dvv), dvv.stride(1), dvv.stride(0), _ptr(dpos), dt(qu), int(precise), B, H, Tq, Tk, dk, _stream(qu))
+         _ptr(dvv), dvv.stride(1), dvv.stride(0), _ptr(dpos), dpos.stride(0) if dpos is not None else 0, dt(qu),
+         int(precise), B, H, Tq, Tk, dk, _stream(qu))
     return dqu, dqv, dkk, dvv, dpos
 
 

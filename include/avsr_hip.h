@@ -83,11 +83,11 @@ int avsr_attention_bwd_dq(const void* qu, const void* qv, const void* k, const v
 
 /* key/value side of the attention backward in ONE launch (three independent batched TN contractions):
  * dV = Pd^T dO, dK = dS^T Qu, dpos += skew(dS)^T Qv (dpos / qv may both be NULL); pd/ds from avsr_attention_bwd_dq;
- * dout/qu/qv/dk/dv are [B,T,H,64] views (row pitch ld*, batch stride sb*); dpos f32 [2Tq-1, H*64], caller zeroes */
+ * dout/qu/qv/dk/dv are [B,T,H,64] views (row pitch ld*, batch stride sb*); dpos f32 [2Tq-1, H*64] with row pitch ldpos, caller zeroes */
 int avsr_attention_bwd_kv(const void* pd, const void* ds, int lds, const void* dout, int ldo, int64_t sbo,
                           const void* qu, const void* qv, int ldq, int64_t sbq, void* dk, int ldk, int64_t sbk, void* dv,
-                          int ldv, int64_t sbv, float* dpos, int dtype, int precise, int B, int H, int Tq, int Tk,
-                          int dk_dim, avsr_stream_t stream);
+                          int ldv, int64_t sbv, float* dpos, int ldpos, int dtype, int precise, int B, int H, int Tq,
+                          int Tk, int dk_dim, avsr_stream_t stream);
 /* batched TN contraction over (b,h) for the attention backward (dV = Pd^T dO, dK = dS^T Qu, dpos = skew(dS)^T Qv):
  * C[b,h][M,N] (+)= sum_k A[b,h][k,m] * B[b,h][k,n]; operand (b,h) slices start at b*s?b + h*s?h elements.
  * a_skew: A[m][k] = src[k*lda + m + k - skew_off], valid iff that column lies in [0, skew_lim)  (inverse of

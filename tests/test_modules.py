@@ -328,3 +328,98 @@ def test_residual_gradient_handoff_equivalence(dev):
     assert counts[0] - counts[1] >= 12, counts
     for k in g0:
         assert rel(g1[k], g0[k]) < 1e-5 or float(g0[k].abs().max()) < 1e-7, k
+
+
+def test_decoder_shared_memory_projection_equivalence(dev):
+    """Source-attention K / V of all decoder layers from ONE projection of the memory (functional.MemoryKVFn) vs the
+    per-layer projections: same loss and gradients (bf16 mode, dropout on), and 2 * dlayers - 1 fewer forward GEMMs."""
+    from auto_avsr_amd import ops
+
+    was_precise, was_fuse = AF._state["precise"], AF._FUSE_QKV
+    odim = 40
+    res, counts = [], []
+    orig = ops.gemm_bf16_nt
+    try:
+        AF.set_precise(False)
+        for shared in (False, True):
+            AF.invalidate_weight_cache()
+            AF.new_step()
+            AF.manual_seed(78)
+            torch.manual_seed(0)
+            m = E2E(odim, "video", adim=128, aheads=2, eunits=128, elayers=1, dunits=128, dlayers=3, cnn_module_kernel=7)
+            m.load_state_dict(synth_state_dict(m.state_dict(), 6), strict=True)
+            m.to(dev).train()
+            x, lengths, y = (t.to(dev) for t in synth_batch("video", 2, 9, 3, odim, seed=5))
+            n = [0]
+
+            def counting(*a, **kw):
+                n[0] += 1
+                return orig(*a, **kw)
+
+            real = AF.memory_kv
+            if not shared:
+                AF.memory_kv = lambda *a, **k: None
+            ops.gemm_bf16_nt = counting
+            try:
+                loss, _, _, _ = m(x, lengths, y)
+                fwd = n[0]
+                loss.backward()
+            finally:
+                ops.gemm_bf16_nt = orig
+                AF.memory_kv = real
+            counts.append(fwd)
+            res.append((float(loss.detach()), {k: p.grad.float().cpu().clone() for k, p in m.named_parameters()}))
+    finally:
+        AF._FUSE_QKV = was_fuse
+        AF.set_precise(was_precise)
+        AF.invalidate_weight_cache()
+        AF.new_step()
+    (l0, g0), (l1, g1) = res
+    assert abs(l0 - l1) < 1e-6 * abs(l0), (l0, l1)
+    assert counts[0] - counts[1] == 2 * 3 - 1, counts
+    for k in g0:
+        # the memory gradient is one K = 2*n*D contraction instead of a chain of bf16-rounded partial sums: equal to bf16 noise
+        assert rel(g1[k], g0[k]) < 2e-2 or float(g0[k].abs().max()) < 1e-7, (k, rel(g1[k], g0[k]))
+    for k in g0:
+        if "decoder" in k and "src_attn" in k:
+            assert rel(g1[k], g0[k]) < 2e-3, (k, rel(g1[k], g0[k]))
+
+
+def test_encoder_shared_position_projection_equivalence(dev):
+    """linear_pos of all encoder layers as one autograd node (functional.PosProjFn: one forward GEMM, one weight-gradient
+    contraction over a shared [P, n*D] f32 buffer) vs per-layer projections: identical loss, gradients to rounding."""
+    was_precise = AF._state["precise"]
+    odim = 40
+    res = []
+    real = AF.prepare_pos_proj
+    try:
+        AF.set_precise(False)
+        for shared in (False, True):
+            AF.invalidate_weight_cache()
+            AF.new_step()
+            AF.manual_seed(79)
+            torch.manual_seed(0)
+            m = E2E(odim, "video", adim=128, aheads=2, eunits=128, elayers=3, dunits=128, dlayers=1, cnn_module_kernel=7)
+            m.load_state_dict(synth_state_dict(m.state_dict(), 7), strict=True)
+            m.to(dev).train()
+            x, lengths, y = (t.to(dev) for t in synth_batch("video", 2, 9, 3, odim, seed=6))
+            AF.prepare_pos_proj = real if shared else (lambda *a, **k: AF._pos_proj.clear())
+            try:
+                loss, _, _, _ = m(x, lengths, y)
+                loss.backward()
+            finally:
+                AF.prepare_pos_proj = real
+            res.append((float(loss.detach()), {k: p.grad.float().cpu().clone() for k, p in m.named_parameters()}))
+    finally:
+        AF.prepare_pos_proj = real
+        AF.set_precise(was_precise)
+        AF.invalidate_weight_cache()
+        AF.new_step()
+    (l0, g0), (l1, g1) = res
+    assert l0 == l1
+    seen = 0
+    for k in g0:
+        tol = 1e-5
+        assert rel(g1[k], g0[k]) < tol or float(g0[k].abs().max()) < 1e-7, (k, rel(g1[k], g0[k]))
+        seen += "linear_pos" in k
+    assert seen == 3
