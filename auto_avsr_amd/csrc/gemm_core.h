@@ -71,6 +71,7 @@ struct Params {
     float* colsum_a;  // TN tile kernel only: colsum_a[m] += sum_k A[k][m] -- the bias gradient of the Linear whose weight
                       // gradient this contraction is (A = its output gradient), taken from the staged A tiles
     int cN, xcd_order, ncls;
+    int k_rot;  // tuned NT kernel, plain GEMM: block b starts its k loop at tile (b * k_rot) % nt (0 = every block at k = 0)
     int cls_tile0[5], cls_py[4], cls_px[4], cls_y0[4], cls_x0[4], cls_h[4], cls_w[4], cls_nkh[4], cls_nkw[4];
 };
 
@@ -175,20 +176,29 @@ AVSR_DEV void epilogue(f32x16 (&acc)[TM][TN], const Params& p, int row0, int col
 // Measured on the short-K problems of this model (K = 576..768), the per-element epilogue above was ~40 % of the
 // kernel time; `smem` is the (now idle) operand staging area and must hold BM*(BN+4) floats.
 // rowmap (LDS, may be null): output row of every tile row, -1 = none; default is row m0 + r.
-template <int BM, int BN, int TM, int TN, int NTHR = 256>
+// KS > 1 (kgroup = this wave's group): KS wave groups hold partial sums of the same tile; group 0 stores, the others add
+// into the LDS tile one after the other.
+template <int BM, int BN, int TM, int TN, int NTHR = 256, int KS = 1>
 AVSR_DEV void epilogue_lds(f32x16 (&acc)[TM][TN], const Params& p, int m0, int n0, int wrow, int wcol, int zs, long c_off,
-                           char* smem, const int* rowmap = nullptr) {
+                           char* smem, const int* rowmap = nullptr, int kgroup = 0) {
     constexpr int PITCH = BN + 4;
     float* tile = reinterpret_cast<float*>(smem);
     const int lane = threadIdx.x & 63;
     __syncthreads();  // every wave is done reading operands from LDS
 #pragma unroll
-    for (int i = 0; i < TM; i++)
+    for (int g = 0; g < KS; g++) {
+        if (g > 0) __syncthreads();
+        if (kgroup != g) continue;
 #pragma unroll
-        for (int j = 0; j < TN; j++)
+        for (int i = 0; i < TM; i++)
 #pragma unroll
-            for (int r = 0; r < 16; r++)
-                tile[(wrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * PITCH + wcol + j * 32 + (lane & 31)] = acc[i][j][r];
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    float* dst = tile + (wrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * PITCH + wcol + j * 32 + (lane & 31);
+                    *dst = g == 0 ? acc[i][j][r] : *dst + acc[i][j][r];
+                }
+    }
     __syncthreads();
     const float inv_keep = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
     const float alpha = p.alpha * (p.alpha_dev ? *p.alpha_dev : 1.f);

@@ -27,20 +27,21 @@ using avsr_gemm_impl::Params;
 
 using avsr_fast::FastKernel;
 
-template <int BM, int BN, int STAGES, int CV, int WGM, int WGN, int ABL>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_fast_kernel(Params p) {
+template <int BM, int BN, int STAGES, int CV, int WGM, int WGN, int ABL, int KS>
+__global__ __launch_bounds__(64 * WGM * WGN * KS) void gemm_fast_kernel(Params p) {
     AVSR_DYN_SMEM(smem);
-    FastKernel<BM, BN, STAGES, CV, WGM, WGN, ABL>::run(p, smem);
+    FastKernel<BM, BN, STAGES, CV, WGM, WGN, ABL, KS>::run(p, smem);
 }
 
-template <int BM, int BN, int STAGES, int CV = 0, int WGM = 2, int WGN = 2, int ABL = 0>
+template <int BM, int BN, int STAGES, int CV = 0, int WGM = 2, int WGN = 2, int ABL = 0, int KS = 1>
 void launch_fast(Params& p, int split_k, hipStream_t stream) {
-    using K = FastKernel<BM, BN, STAGES, CV, WGM, WGN, ABL>;
+    using K = FastKernel<BM, BN, STAGES, CV, WGM, WGN, ABL, KS>;
     // XCD-aware tile order (knob 1: 0 = automatic, 1 = on, 2 = off).  Automatic: on for the 64x64 GEMM tile -- measured
     // with operands that are NOT cache-resident (tools/microbench_xcd.py: A written by the previous kernel, weights
     // streamed from HBM, as in the training step): every XCD otherwise pulls the whole problem through its own L2
     // (rocprofv3 FETCH_SIZE ~8x the operand bytes); 1500x768x768 10.5 -> 9.4 us, 1500x768x3072 28.5 -> 22.6 us.
     // Neutral-to-slower for the 128-row tiles with wide N and for operands that sit in the Infinity Cache.
+    p.k_rot = CV == 0 ? g_tune[7] : 0;
     p.xcd_order = g_tune[1] == 0 ? (CV == 0 && BM == 64 && BN == 64) : (g_tune[1] == 1);
     int gy;
     if (CV == 0) {
@@ -60,7 +61,7 @@ void launch_fast(Params& p, int split_k, hipStream_t stream) {
         gy = t0;
     }
     dim3 grid((p.N + BN - 1) / BN, gy, split_k), block(K::NTHR);
-    AVSR_LAUNCH((gemm_fast_kernel<BM, BN, STAGES, CV, WGM, WGN, ABL>), grid, block, K::LDS_BYTES, stream, p);
+    AVSR_LAUNCH((gemm_fast_kernel<BM, BN, STAGES, CV, WGM, WGN, ABL, KS>), grid, block, K::LDS_BYTES, stream, p);
 }
 
 // tile codes shared by the GEMM and convolution entry points
@@ -91,6 +92,11 @@ bool launch_tile(int tile, Params& p, int split_k, hipStream_t stream) {
         // ablations of the 64x64 GEMM tile (benchmarks only): 14 = no LDS reads / MFMA, 15 = no operand loads after the prologue
         case 14: if (CV == 0) { launch_fast<64, 64, 3, 0, 2, 2, 1>(p, split_k, stream); return true; } return false;
         case 15: if (CV == 0) { launch_fast<64, 64, 3, 0, 2, 2, 2>(p, split_k, stream); return true; } return false;
+        // 8 waves = two k groups on one output tile (two waves per SIMD for the one-block-per-CU GEMMs): 16 = 64x64, 17 = 128x64,
+        // 18 = 128x128
+        case 16: if (CV == 0) { launch_fast<64, 64, 3, 0, 2, 2, 0, 2>(p, split_k, stream); return true; } return false;
+        case 17: if (CV == 0) { launch_fast<128, 64, 3, 0, 2, 2, 0, 2>(p, split_k, stream); return true; } return false;
+        case 18: if (CV == 0) { launch_fast<128, 128, 3, 0, 2, 2, 0, 2>(p, split_k, stream); return true; } return false;
         default: return false;
     }
 }

@@ -21,9 +21,15 @@ using avsr_gemm_impl::Params;
 //
 // WGM x WGN waves per block (64*WGM*WGN threads), each wave a (BM/WGM) x (BN/WGN) grid of 32x32x16 accumulators.
 // ABL (benchmarks only): 1 = no LDS reads / MFMA, 2 = no operand loads in the steady state.
-template <int BM, int BN, int STAGES, int CV = 0, int WGM = 2, int WGN = 2, int ABL = 0>
+// KS > 1: KS groups of WGM x WGN waves work on the SAME output tile, group g multiplying k-steps [g*4/KS, (g+1)*4/KS) of
+// every staged 64-wide k-tile; the partial tiles meet in LDS before the epilogue.  A skinny M = B*T GEMM gives every CU
+// about one block: with 4 waves that is ONE wave per SIMD and nothing to cover the LDS-read -> MFMA latency of the
+// dependent accumulator chain; 8 waves put two on every SIMD without a second pass over the output.
+template <int BM, int BN, int STAGES, int CV = 0, int WGM = 2, int WGN = 2, int ABL = 0, int KS = 1>
 struct FastKernel {
-    static constexpr int BK = 64, NW = WGM * WGN, NTHR = 64 * NW;
+    static constexpr int BK = 64, NQ = WGM * WGN, NW = NQ * KS, NTHR = 64 * NW;
+    static constexpr int KPG = (BK / 16) / KS;  // 16-wide k-steps per wave group and k-tile
+    static_assert(KS == 1 || KS == 2 || KS == 4, "k-split of the 64-wide tile");
     static constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
     static constexpr int A_LOADS = BM / (8 * NW), B_LOADS = BN / (8 * NW);  // wave-instructions per wave per stage
@@ -103,11 +109,14 @@ struct FastKernel {
     }
 
     // stage k-tile t of this block
-    static AVSR_DEV void issue(const Params& p, const Rows& ri, const Taps& tp, int kbeg, int t, char* stage, int wave) {
+    static AVSR_DEV void issue(const Params& p, const Rows& ri, const Taps& tp, int kbeg, int t, char* stage, int wave,
+                               int rot = 0, int nt = 1) {
         long da, db;
         int tap = 0;
         if (CV == 0) {
-            da = db = kbeg + t * BK;
+            int tt = t + rot;
+            if (tt >= nt) tt -= nt;
+            da = db = kbeg + tt * BK;
         } else {
             tap = t / tp.cpt;
             const int cb = (t - tap * tp.cpt) * BK;
@@ -142,7 +151,8 @@ struct FastKernel {
         const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
         const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
         const int lane = threadIdx.x & 63, wave = wave_id();
-        const int wm = wave / WGN, wn = wave % WGN;
+        const int kg = wave / NQ, wq = wave - kg * NQ;  // k group, wave inside the group
+        const int wm = wq / WGN, wn = wq % WGN;
         if (p.xcd_order && gz_ == 1) {
             // block b runs on XCD b % 8 (observed): hand every XCD one contiguous run of tiles so that tiles sharing
             // A rows (the n-tiles of an m-tile, the halo rows of neighbouring m-tiles) meet in the same L2
@@ -191,10 +201,13 @@ struct FastKernel {
                 for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
         const Rows ri = decode_rows(p, A, B, m0, n0, cls, tp, wave, lane);
+        // blocks walk k in lockstep: with a row pitch that is a multiple of the channel interleave, every block's loads of
+        // one k-tile land on the same few L2 channels.  A per-block rotation of the k order spreads them.
+        const int rot = (CV == 0 && p.k_rot) ? (int)(((unsigned)(by * gx_ + bx) * (unsigned)p.k_rot) % (unsigned)nt) : 0;
         // prologue: tiles 0 .. STAGES-2 in flight
 #pragma unroll
         for (int s = 0; s < STAGES - 1; s++)
-            if (s < nt) issue(p, ri, tp, kbeg, s, smem + s * STAGE_BYTES, wave);
+            if (s < nt) issue(p, ri, tp, kbeg, s, smem + s * STAGE_BYTES, wave, rot, nt);
 
         // One k-tile: retire its loads, barrier, first fragments, (optionally) stage tile t+STAGES-1, multiply.
         // ISSUE is a compile-time flag -- the steady state (every iteration stages a tile) and the drain (none does)
@@ -226,22 +239,23 @@ struct FastKernel {
 #pragma unroll
                 for (int j = 0; j < TN; j++) fb[set][j] = frag(Bs, brow + j * 32, chunk);
             };
+            const int ks0 = kg * KPG;
             if (ABL != 1) {
-                load_frags(0, 0);
-                load_frags(1, 1);
+                load_frags(0, ks0);
+                if (KPG > 1) load_frags(1, ks0 + 1);
             }
             sched_fence();
             if (ISSUE && ABL != 2)
-                issue(p, ri, tp, kbeg, t + STAGES - 1, smem + ((t + STAGES - 1) % STAGES) * STAGE_BYTES, wave);
+                issue(p, ri, tp, kbeg, t + STAGES - 1, smem + ((t + STAGES - 1) % STAGES) * STAGE_BYTES, wave, rot, nt);
             sched_fence();
             if (ABL == 1) return;
 #pragma unroll
-            for (int ks = 0; ks < BK / 16; ks++) {
+            for (int ks = 0; ks < KPG; ks++) {
 #pragma unroll
                 for (int i = 0; i < TM; i++)
 #pragma unroll
                     for (int j = 0; j < TN; j++) acc[i][j] = mfma32(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
-                if (ks + 2 < BK / 16) load_frags(ks & 1, ks + 2);
+                if (ks + 2 < KPG) load_frags(ks & 1, ks0 + ks + 2);
                 sched_fence();
             }
         };
@@ -251,9 +265,9 @@ struct FastKernel {
         if (CV != 0) {
             Params q = p;
             q.gate = nullptr;  // in conv mode the field carries the zero page, not an activation gate
-            avsr_gemm_impl::epilogue_lds<BM, BN, TM, TN, NTHR>(acc, q, m0, n0, wm * WM, wn * WN, zs, 0, smem, rowmap);
+            avsr_gemm_impl::epilogue_lds<BM, BN, TM, TN, NTHR, KS>(acc, q, m0, n0, wm * WM, wn * WN, zs, 0, smem, rowmap, kg);
         } else {
-            avsr_gemm_impl::epilogue_lds<BM, BN, TM, TN, NTHR>(acc, p, m0, n0, wm * WM, wn * WN, zs, 0, smem, nullptr);
+            avsr_gemm_impl::epilogue_lds<BM, BN, TM, TN, NTHR, KS>(acc, p, m0, n0, wm * WM, wn * WN, zs, 0, smem, nullptr, kg);
         }
     }
 };

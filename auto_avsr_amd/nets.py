@@ -71,8 +71,9 @@ class MultiHeadedAttention(nn.Module):
         n = bq.numel()
         if bq.dtype != torch.float32 or bq.device.type == "meta":
             return
-        if bk.data_ptr() == bq.data_ptr() + 4 * n and bv.data_ptr() == bq.data_ptr() + 8 * n:
-            return
+        if bk.data_ptr() == bq.data_ptr() + 4 * n and bv.data_ptr() == bq.data_ptr() + 8 * n \
+                and bq.untyped_storage().data_ptr() == bv.untyped_storage().data_ptr():
+            return  # (adjacent addresses alone do not do: three separate allocations often ARE back to back on the device)
         with torch.no_grad():
             buf = torch.cat([bq.data, bk.data, bv.data])
             bq.data, bk.data, bv.data = buf[:n], buf[n:2 * n], buf[2 * n:]

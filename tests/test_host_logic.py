@@ -174,3 +174,30 @@ def test_qkv_bias_packing():
     m2 = copy.deepcopy(m)
     c2 = AF._bias3(m2.linear_q.bias, m2.linear_k.bias, m2.linear_v.bias)
     assert torch.equal(c2, AF._bias3(bq, bk, bv))
+
+
+def test_qkv_bias_packing_with_adjacent_separate_storages():
+    """Three biases that merely SIT back to back in memory (separate storages: what a device allocator hands out for three
+    small consecutive allocations) must still be packed into one storage -- adjacency alone once made the packer return
+    early and every fused projection pay a torch.cat."""
+    from auto_avsr_amd import functional as AF
+    from auto_avsr_amd.nets import MultiHeadedAttention
+
+    m = MultiHeadedAttention(2, 128, 0.0)
+    arena = torch.randn(3 * 128)
+    vals = [arena[i * 128:(i + 1) * 128].clone() for i in range(3)]
+    # emulate "adjacent but separate": each bias a view of the arena is ONE storage, so fake the storage test instead
+    for lin, i in ((m.linear_q, 0), (m.linear_k, 1), (m.linear_v, 2)):
+        lin.bias.data = vals[i]
+    real = torch.Tensor.data_ptr
+    base = 1 << 20
+    fake = {id(m.linear_q.bias): base, id(m.linear_k.bias): base + 512, id(m.linear_v.bias): base + 1024}
+    try:
+        torch.Tensor.data_ptr = lambda t: fake.get(id(t), real(t))
+        m._pack_qkv_bias()
+    finally:
+        torch.Tensor.data_ptr = real
+    bq, bk, bv = m.linear_q.bias, m.linear_k.bias, m.linear_v.bias
+    assert bq.untyped_storage().data_ptr() == bv.untyped_storage().data_ptr()
+    assert AF._bias3(bq, bk, bv).data_ptr() == bq.data_ptr()
+    assert torch.equal(AF._bias3(bq, bk, bv), torch.cat(vals))
