@@ -56,6 +56,14 @@ struct AttnParams {
     void* pd;          // [B,H,Tq,lds] dropout-applied probabilities
     void* ds;          // [B,H,Tq,lds] scale * dS
     int lds;           // row pitch of pd/ds (multiple of 8, >= Tk)
+    // backward, relative-position form, optional: instead of dqu / dqv write their SUM (the gradient of q itself,
+    // attention.py:171-177: q_with_bias_u = q + pos_bias_u, q_with_bias_v = q + pos_bias_v) and add the column sums of the
+    // two parts -- the gradients of pos_bias_u / pos_bias_v -- to du / dv [H*64] (f32, caller zeroes)
+    void* dq_sum;      // [B,Tq,H,64] view, row pitch lddq, batch stride sbdq
+    int lddq;
+    long sbdq;
+    float* du;
+    float* dv;
 };
 
 AVSR_DEV void wave_sync() {
@@ -442,6 +450,10 @@ struct Attn {
 #pragma unroll
                 for (int n = 0; n < 4; n++) Elem<T>::st(o + n * 16 + lc, acc0[n][r] * inv);
                 if (lc == 0) p.lse[((long)b * p.H + h) * Tq + ig] = l_run[r] > 0.f ? m_run[r] + logf(l_run[r]) : 0.f;
+            } else if (RELPOS && p.dq_sum) {
+                T* dq = reinterpret_cast<T*>(p.dq_sum) + b * p.sbdq + (long)ig * p.lddq + h * DK;
+#pragma unroll
+                for (int n = 0; n < 4; n++) Elem<T>::st(dq + n * 16 + lc, acc0[n][r] + acc1[n][r]);
             } else {
                 T* dqu = reinterpret_cast<T*>(p.dqu) + b * p.sbq + (long)ig * p.ldq + h * DK;
 #pragma unroll
@@ -451,6 +463,38 @@ struct Attn {
 #pragma unroll
                     for (int n = 0; n < 4; n++) Elem<T>::st(dqv + n * 16 + lc, acc1[n][r]);
                 }
+            }
+        }
+        if (BWD && RELPOS && p.dq_sum) {
+            // gradients of the two position biases: column sums of dQu / dQv over this block's query rows.  Rows past Tq
+            // hold exact zeros (their dS is masked), so every accumulator row counts.  Wave: 4 rows per lane, then the 4
+            // quads; block: through LDS (the key / value tiles are dead); one atomic per column and block.
+            float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][64]
+            __syncthreads();
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+                float su = 0.f, sv = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const bool ok = i0 + 16 * w + 4 * quad + r < Tq;
+                    su += ok ? acc0[n][r] : 0.f;
+                    sv += ok ? acc1[n][r] : 0.f;
+                }
+                su += __shfl_xor(su, 16);
+                su += __shfl_xor(su, 32);
+                sv += __shfl_xor(sv, 16);
+                sv += __shfl_xor(sv, 32);
+                if (quad == 0) {
+                    red[(w * 2 + 0) * 64 + n * 16 + lc] = su;
+                    red[(w * 2 + 1) * 64 + n * 16 + lc] = sv;
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < 128) {
+                const int which = threadIdx.x >> 6, d = threadIdx.x & 63;
+                const float t = (red[(0 * 2 + which) * 64 + d] + red[(1 * 2 + which) * 64 + d]) +
+                                (red[(2 * 2 + which) * 64 + d] + red[(3 * 2 + which) * 64 + d]);
+                atomicAdd((which ? p.dv : p.du) + h * DK + d, t);
             }
         }
     }
@@ -510,7 +554,10 @@ extern "C" int avsr_attention_bwd_dq(const void* qu, const void* qv, const void*
                                      void* pd, void* ds, int lds, int B, int H, int Tq, int Tk, int dk, int ldq,
                                      int ldk, int ldv, int ldp, int ldo, int64_t sbq, int64_t sbk, int64_t sbv,
                                      int64_t sbo, float scale, float drop_p, uint64_t seed, const uint64_t* seed_dev,
-                                     hipStream_t stream) {
+                                     void* dq_sum, int lddq, int64_t sbdq, float* du, float* dv, hipStream_t stream) {
+    AVSR_REQUIRE(dq_sum == nullptr || (pos != nullptr && du != nullptr && dv != nullptr && lddq % 8 == 0),
+                 "attention_bwd_dq: dq_sum needs the relative-position form, du, dv and a row pitch that is a multiple of 8");
+    AVSR_REQUIRE(dq_sum != nullptr || dqu != nullptr, "attention_bwd_dq: no destination for the query gradient");
     AVSR_REQUIRE(dk == DK, "attention: d_k must be 64");
     AVSR_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && (pos == nullptr || ldp % 8 == 0),
                  "attention: row strides must be multiples of 8");
@@ -526,6 +573,7 @@ extern "C" int avsr_attention_bwd_dq(const void* qu, const void* qv, const void*
     p.sbq = sbq; p.sbk = sbk; p.sbv = sbv; p.sbo = sbo;
     p.scale = scale; p.drop_p = drop_p; p.seed = seed; p.seed_dev = seed_dev;
     p.dout = dout; p.dqu = dqu; p.dqv = dqv; p.pd = pd; p.ds = ds; p.lds = lds;
+    p.dq_sum = dq_sum; p.lddq = lddq; p.sbdq = sbdq; p.du = du; p.dv = dv;
     AVSR_REQUIRE(launch_attn<true>(p, dtype, precise, pos != nullptr, stream) == 0, "attention: bad dtype/precise combination");
     AVSR_CHECK_LAUNCH("attention_bwd_dq");
     return 0;

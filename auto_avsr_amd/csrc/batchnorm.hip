@@ -424,6 +424,166 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
     }
 }
 
+// ---- single-launch BatchNorm(+activation) for SMALL [rows, C] activations on one rank (the ConvolutionModule's
+// BatchNorm1d over rows = B*T <= 2048 frames, conformer_encoder.py:26,33): a block owns 8 channels and keeps its whole
+// column slab (rows x 8 values) in registers, so statistics, running-stat update and the normalised output are one pass
+// over HBM and ONE launch instead of three (column reduce -> finalize -> apply, ~5 us of launch boundary each on a
+// 2.4 MB tensor).  Same arithmetic as that chain: shifted sums in f32, the channel finished in double.
+constexpr int BNS_THREADS = 512, BNS_R = 4;  // rows <= 2048
+
+AVSR_DEV void bns_block_sum16(float (&a)[8], float (&b)[8], float* red /* [8 waves][16] */) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        a[e] = wave_sum(a[e]);
+        b[e] = wave_sum(b[e]);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            red[w * 16 + e] = a[e];
+            red[w * 16 + 8 + e] = b[e];
+        }
+    }
+    __syncthreads();
+}
+
+template <class T>
+__global__ __launch_bounds__(BNS_THREADS) void bn_small_fwd_kernel(
+    const T* __restrict__ x, int rows, int C, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+    int64_t* __restrict__ num_batches_tracked, int act, T* __restrict__ y, float* __restrict__ mean_out,
+    float* __restrict__ invstd_out) {
+    __shared__ float red[8 * 16];
+    __shared__ float mu_s[8], is_s[8];
+    const int c0 = blockIdx.x * 8;
+    float v[BNS_R][8], sh[8], a[8], b[8];
+    load8(x + c0, sh);
+#pragma unroll
+    for (int e = 0; e < 8; e++) a[e] = b[e] = 0.f;
+#pragma unroll
+    for (int u = 0; u < BNS_R; u++) {
+        const int r = threadIdx.x + u * BNS_THREADS;
+        if (r < rows) load8(x + (long)r * C + c0, v[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < BNS_R; u++) {
+        const int r = threadIdx.x + u * BNS_THREADS;
+        if (r >= rows) continue;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float d = v[u][e] - sh[e];
+            a[e] += d;
+            b[e] += d * d;
+        }
+    }
+    bns_block_sum16(a, b, red);
+    if (threadIdx.x < 8) {
+        const int e = threadIdx.x, c = c0 + e;
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < BNS_THREADS / 64; w++) {
+            s1 += (double)red[w * 16 + e];
+            s2 += (double)red[w * 16 + 8 + e];
+        }
+        const double nn = (double)rows;
+        const double mean = (double)Elem<T>::ld(x + c) + s1 / nn;
+        const double m2 = s2 - s1 * s1 / nn;
+        const double var = m2 / nn;
+        const float mf = (float)mean, isf = (float)(1.0 / sqrt(var + (double)eps));
+        mean_out[c] = mf;
+        invstd_out[c] = isf;
+        mu_s[e] = mf;
+        is_s[e] = isf;
+        if (running_mean) {
+            const double unbiased = nn > 1.0 ? m2 / (nn - 1.0) : var;
+            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+        }
+        if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    }
+    __syncthreads();
+    float ga[8], be[8];
+    load8(gamma + c0, ga);
+    load8(beta + c0, be);
+#pragma unroll
+    for (int u = 0; u < BNS_R; u++) {
+        const int r = threadIdx.x + u * BNS_THREADS;
+        if (r >= rows) continue;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = act_fwd((v[u][e] - mu_s[e]) * is_s[e] * ga[e] + be[e], act);
+        store8(y + (long)r * C + c0, o);
+    }
+}
+
+// backward of the same: dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)), dgamma = sum dz*xhat, dbeta = sum dz,
+// dz = dy * act'(z) -- reduce and apply in one launch (the slab of x and dy stays in registers between them)
+template <class T>
+__global__ __launch_bounds__(BNS_THREADS) void bn_small_bwd_kernel(
+    const T* __restrict__ x, const T* __restrict__ dy, int rows, int C, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+    T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[8 * 16];
+    __shared__ float s1_s[8], s2_s[8];
+    const int c0 = blockIdx.x * 8;
+    float xh[BNS_R][8], dz[BNS_R][8], mu[8], is[8], ga[8], be[8], a[8], b[8];
+    load8(mean + c0, mu);
+    load8(invstd + c0, is);
+    load8(gamma + c0, ga);
+    load8(beta + c0, be);
+#pragma unroll
+    for (int e = 0; e < 8; e++) a[e] = b[e] = 0.f;
+#pragma unroll
+    for (int u = 0; u < BNS_R; u++) {
+        const int r = threadIdx.x + u * BNS_THREADS;
+        if (r < rows) {
+            load8(x + (long)r * C + c0, xh[u]);
+            load8(dy + (long)r * C + c0, dz[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < BNS_R; u++) {
+        const int r = threadIdx.x + u * BNS_THREADS;
+        if (r >= rows) continue;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float h = (xh[u][e] - mu[e]) * is[e];
+            const float z = h * ga[e] + be[e];
+            const float d = dz[u][e] * act_grad(z, act);
+            xh[u][e] = h;
+            dz[u][e] = d;
+            a[e] += d;
+            b[e] += d * h;
+        }
+    }
+    bns_block_sum16(a, b, red);
+    if (threadIdx.x < 8) {
+        const int e = threadIdx.x;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < BNS_THREADS / 64; w++) {
+            s1 += red[w * 16 + e];
+            s2 += red[w * 16 + 8 + e];
+        }
+        s1_s[e] = s1;
+        s2_s[e] = s2;
+        dbeta[c0 + e] = s1;
+        dgamma[c0 + e] = s2;
+    }
+    __syncthreads();
+    const float inv_n = 1.0f / (float)rows;
+#pragma unroll
+    for (int u = 0; u < BNS_R; u++) {
+        const int r = threadIdx.x + u * BNS_THREADS;
+        if (r >= rows) continue;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = ga[e] * is[e] * (dz[u][e] - s1_s[e] * inv_n - xh[u][e] * s2_s[e] * inv_n);
+        store8(dx + (long)r * C + c0, o);
+    }
+}
+
 // ---- backward of maxpool(act(bn(x))) without the full-resolution gradient tensor: the gradient of the activation at
 // (n, ih, iw) is gathered from the pooled gradient -- sum over the (at most 4 for K=3, S=2) windows that contain the pixel
 // and whose recorded argmax is that pixel -- wherever the two BatchNorm backward passes need it (pool.hip maxpool_bwd
@@ -863,5 +1023,39 @@ extern "C" int avsr_bn_bwd_apply(const void* x, const void* dy, const void* add,
         AVSR_LAUNCH((bn_bwd_apply_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dy,
                     (const bf16_t*)add, mean, invstd, gamma, beta, sums, inv_n, n_dev, (bf16_t*)dx, (bf16_t*)dadd, (long)rows, C, act);
     AVSR_CHECK_LAUNCH("bn_bwd_apply");
+    return 0;
+}
+
+extern "C" int avsr_bn_small_max_rows(void) { return BNS_THREADS * BNS_R; }
+
+extern "C" int avsr_bn_small_fwd(const void* x, int dtype, int64_t rows, int C, const float* gamma, const float* beta, float eps,
+                                 float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                 int act, void* y, float* mean, float* invstd, hipStream_t stream) {
+    AVSR_REQUIRE(C % 8 == 0, "bn_small: C must be a multiple of 8");
+    AVSR_REQUIRE(rows >= 1 && rows <= BNS_THREADS * BNS_R, "bn_small: rows out of range (avsr_bn_small_max_rows)");
+    dim3 grid(C / 8), block(BNS_THREADS);
+    if (dtype == 0)
+        AVSR_LAUNCH((bn_small_fwd_kernel<float>), grid, block, 0, stream, (const float*)x, (int)rows, C, gamma, beta, eps, momentum,
+                    running_mean, running_var, num_batches_tracked, act, (float*)y, mean, invstd);
+    else
+        AVSR_LAUNCH((bn_small_fwd_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, (int)rows, C, gamma, beta, eps,
+                    momentum, running_mean, running_var, num_batches_tracked, act, (bf16_t*)y, mean, invstd);
+    AVSR_CHECK_LAUNCH("bn_small_fwd");
+    return 0;
+}
+
+extern "C" int avsr_bn_small_bwd(const void* x, const void* dy, int dtype, int64_t rows, int C, const float* mean,
+                                 const float* invstd, const float* gamma, const float* beta, int act, void* dx, float* dgamma,
+                                 float* dbeta, hipStream_t stream) {
+    AVSR_REQUIRE(C % 8 == 0, "bn_small: C must be a multiple of 8");
+    AVSR_REQUIRE(rows >= 1 && rows <= BNS_THREADS * BNS_R, "bn_small: rows out of range (avsr_bn_small_max_rows)");
+    dim3 grid(C / 8), block(BNS_THREADS);
+    if (dtype == 0)
+        AVSR_LAUNCH((bn_small_bwd_kernel<float>), grid, block, 0, stream, (const float*)x, (const float*)dy, (int)rows, C, mean,
+                    invstd, gamma, beta, act, (float*)dx, dgamma, dbeta);
+    else
+        AVSR_LAUNCH((bn_small_bwd_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dy, (int)rows, C,
+                    mean, invstd, gamma, beta, act, (bf16_t*)dx, dgamma, dbeta);
+    AVSR_CHECK_LAUNCH("bn_small_bwd");
     return 0;
 }

@@ -336,6 +336,55 @@ __global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict_
     if (threadIdx.x == 0) out[0] = (red[0] + red[1] + red[2] + red[3]) * scale;
 }
 
+// ---- attention-branch targets (add_sos_eos.py:12-31 + mask.py:11-37) for a [B, L] label matrix padded with ignore_id, with
+// the static width L + 1: labels compacted to the left, ys_in = <sos> y <eos ...>, ys_out = y <eos> <ignore ...>,
+// mask[b,i,j] = (ys_in[b,j] != ignore_id) & (j <= i), n_tokens = #(ys_out != ignore_id).  One block per utterance; the
+// torch formulation of the same (sort / gather / where / tril ...) is ~30 launches of a few hundred bytes each.
+__global__ __launch_bounds__(256) void prepare_targets_kernel(const int64_t* __restrict__ ys_pad, int B, int L, int64_t sos,
+                                                              int64_t eos, int64_t ignore_id, int64_t* __restrict__ ys_in,
+                                                              int64_t* __restrict__ ys_out, uint8_t* __restrict__ mask,
+                                                              int64_t* __restrict__ n_tokens) {
+    AVSR_DYN_SMEM(smem);
+    int64_t* comp = reinterpret_cast<int64_t*>(smem);  // [L] compacted labels, then [L + 1] "ys_in != ignore" flags as bytes
+    __shared__ int n_keep;
+    const int b = blockIdx.x, W = L + 1;
+    const int64_t* y = ys_pad + (long)b * L;
+    if (threadIdx.x == 0) {  // L is a few hundred at most: a serial stable compaction is a microsecond
+        int n = 0;
+        for (int j = 0; j < L; j++)
+            if (y[j] != ignore_id) comp[n++] = y[j];
+        n_keep = n;
+    }
+    __syncthreads();
+    const int n = n_keep;
+    uint8_t* ok = reinterpret_cast<uint8_t*>(comp + L);
+    for (int j = threadIdx.x; j < W; j += 256) {
+        const int64_t vin = j == 0 ? sos : (j <= n ? comp[j - 1] : eos);
+        const int64_t vout = j < n ? comp[j] : (j == n ? eos : ignore_id);
+        ys_in[(long)b * W + j] = vin;
+        ys_out[(long)b * W + j] = vout;
+        ok[j] = vin != ignore_id;
+    }
+    __syncthreads();
+    if (mask)
+        for (int id = threadIdx.x; id < W * W; id += 256) {
+            const int i = id / W, j = id - i * W;
+            mask[(long)b * W * W + id] = (uint8_t)(ok[j] && j <= i);
+        }
+    if (b == 0 && n_tokens) {  // block 0 also counts the scored tokens of the whole batch: labels + one <eos> per utterance
+        __shared__ int red[4];
+        int cnt = 0;
+        for (int r = threadIdx.x; r < B; r += 256) {
+            for (int j = 0; j < L; j++) cnt += ys_pad[(long)r * L + j] != ignore_id;
+            cnt += eos != ignore_id;
+        }
+        cnt = (int)wave_sum((float)cnt);  // exact: counts are far below 2^24
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+        __syncthreads();
+        if (threadIdx.x == 0) n_tokens[0] = (int64_t)(red[0] + red[1] + red[2] + red[3]);
+    }
+}
+
 // ---- decoder input embedding: out[r,:] = table[id[r],:]*scale + pe[r % L,:], inverted dropout
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
                                                         const float* __restrict__ pe, float* __restrict__ out, long rows,
@@ -439,6 +488,16 @@ extern "C" int avsr_ce_smooth(const void* logits, int dtype, int64_t ld, const i
 extern "C" int avsr_sum_scale(const float* a, int n, float scale, float* out, int finite_only, hipStream_t stream) {
     AVSR_LAUNCH(sum_scale_kernel, dim3(1), dim3(256), 0, stream, a, n, scale, out, finite_only);
     AVSR_CHECK_LAUNCH("sum_scale");
+    return 0;
+}
+
+extern "C" int avsr_prepare_targets(const int64_t* ys_pad, int B, int L, int64_t sos, int64_t eos, int64_t ignore_id,
+                                    int64_t* ys_in, int64_t* ys_out, uint8_t* mask, int64_t* n_tokens, hipStream_t stream) {
+    AVSR_REQUIRE(L >= 1 && L <= 4096, "prepare_targets: label width out of range");
+    if (B <= 0) return 0;
+    const size_t lds = (size_t)L * sizeof(int64_t) + ((L + 1 + 7) / 8) * 8;
+    AVSR_LAUNCH(prepare_targets_kernel, dim3(B), dim3(256), lds, stream, ys_pad, B, L, sos, eos, ignore_id, ys_in, ys_out, mask, n_tokens);
+    AVSR_CHECK_LAUNCH("prepare_targets");
     return 0;
 }
 

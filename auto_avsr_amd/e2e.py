@@ -9,6 +9,7 @@ from torch import nn
 
 from . import functional as AF
 from . import nets
+from . import ops
 from .frontend import audio_resnet, video_resnet
 
 
@@ -52,13 +53,14 @@ class E2E(nn.Module):
         h = AF.linear(feats, self.proj_encoder.weight, self.proj_encoder.bias, out_dtype=torch.float32)
         enc, _ = self.encoder(h, padding_mask)
         loss_ctc, _ = self.ctc(enc, lengths, label)
-        ys_in, ys_out = nets.add_sos_eos_static(label.to(feats.device), self.sos, self.eos, self.ignore_id)
-        ys_mask = nets.target_mask(ys_in, self.ignore_id)
+        # add_sos_eos + target_mask (e2e_asr_conformer.py:138-139) with the static width Lmax + 1, and the token count of
+        # th_accuracy's denominator: one launch (csrc/loss.hip prepare_targets_kernel; nets.add_sos_eos_static /
+        # nets.target_mask are the torch statement of the same, kept as the test reference)
+        ys_in, ys_out, ys_mask, n_tok = ops.prepare_targets(label.to(feats.device), self.sos, self.eos, self.ignore_id)
         pred, _ = self.decoder(ys_in, ys_mask, enc, padding_mask)
         loss_att = self.criterion(pred, ys_out)
         loss = self.ctc_weight * loss_ctc + (1 - self.ctc_weight) * loss_att
-        n_tok = (ys_out != self.ignore_id).sum()
-        return loss, loss_ctc, loss_att, self.criterion.last_hits, n_tok
+        return loss, loss_ctc, loss_att, self.criterion.last_hits, n_tok[0]
 
     def forward(self, x, lengths, label):
         loss, loss_ctc, loss_att, hits, n_tok = self.forward_tensors(x, lengths, label)

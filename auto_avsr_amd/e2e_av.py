@@ -13,6 +13,7 @@ from torch import nn
 
 from . import functional as AF
 from . import nets
+from . import ops
 from .frontend import audio_resnet, video_resnet
 
 
@@ -66,11 +67,11 @@ class E2EAV(nn.Module):
         mem, mask = self.encode(video, audio, lengths)
         lengths = lengths.to(mem.device)
         loss_ctc, _ = self.ctc(mem, lengths, label)
-        ys_in, ys_out = nets.add_sos_eos_static(label.to(mem.device), self.sos, self.eos, self.ignore_id)
-        pred, _ = self.decoder(ys_in, nets.target_mask(ys_in, self.ignore_id), mem, mask)
+        ys_in, ys_out, ys_mask, n_tok = ops.prepare_targets(label.to(mem.device), self.sos, self.eos, self.ignore_id)
+        pred, _ = self.decoder(ys_in, ys_mask, mem, mask)
         loss_att = self.criterion(pred, ys_out)
         loss = self.ctc_weight * loss_ctc + (1 - self.ctc_weight) * loss_att
-        return loss, loss_ctc, loss_att, self.criterion.last_hits, (ys_out != self.ignore_id).sum()
+        return loss, loss_ctc, loss_att, self.criterion.last_hits, n_tok[0]
 
     def forward(self, video, audio, lengths, label):
         loss, loss_ctc, loss_att, hits, n_tok = self.forward_tensors(video, audio, lengths, label)

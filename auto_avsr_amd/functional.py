@@ -83,6 +83,7 @@ def _rows(x):
 # (csrc/gemm_fast.hip).  Weights therefore need a bf16 copy ([out][in], Linear forward) and a transposed bf16 copy
 # ([in][out_padded_to_64], data gradient).  Copies are cached per parameter version: an optimizer step bumps
 # `_version`, so they are rebuilt exactly once per training step (bench.py invalidates explicitly).
+_BN_SMALL = os.environ.get("AVSR_BN_SMALL", "1") != "0"  # A/B switch: single-launch BatchNorm1d of the convolution module
 _FUSE_QKV = os.environ.get("AVSR_FUSE_QKV", "1") != "0"  # A/B switch for the fused self-attention projections
 # fused BN + SiLU + max-pool of the video stem (forward: the full-resolution activation is never written; backward: the
 # reduce pass runs on the pooled tensors, the apply pass gathers the pooled gradient).  Measured on MI355X (round 2):
@@ -955,7 +956,7 @@ class AttentionCoreFn(torch.autograd.Function):
             dv_bias = torch.zeros(D, dtype=torch.float32, device=g.device)
             ops.head_bias_bwd(dqu, dqv, dq, D, du, dv_bias, B * Tq, D)
             du, dv_bias = du.view(H, dk), dv_bias.view(H, dk)
-            dwpos = _wgrad(dpos, pe, pe.shape[0], D, D) if ctx.pp is None else None
+            dwpos = _wgrad(dpos, pe, pe.shape[0], D, D)
         else:
             dq = dqu.view(B * Tq, D)
         dk2, dv2 = dk_.view(B * Tk, D), dv_.view(B * Tk, D)
@@ -1123,15 +1124,17 @@ class MhaSublayerFn(torch.autograd.Function):
             outs = dict(outs, dpos_out=holder["dpos"][:, slot * D:(slot + 1) * D])
             holder["filled"] = holder.get("filled", 0) + 1
             dpp_grad = _placeholder_grad(shape, T, x.device) if slot == 0 else None  # the f32 buffer travels in `holder`
-        dqu, dqv, dk_, dv_, dpos = ops.attention_bwd(
-            qu, qv, k4, v4, pproj, m, ctxv, lse, dctx, 1.0 / math.sqrt(dk), precise=_state["precise"],
-            drop_p=pa, seed=sa, seed_dev=sda, **outs)
         du = dv_bias = dwpos = None
         if relpos:
+            # the attention backward itself emits dq = dqu + dqv and the two position-bias gradients (their column sums)
             dq = dqkv if fused else torch.empty(B * Tq, D, dtype=T, device=x.device)
             du = _zeros(D, x.device)
             dv_bias = _zeros(D, x.device)
-            ops.head_bias_bwd(dqu, dqv, dq, 3 * D if fused else D, du, dv_bias, B * Tq, D)
+            outs = dict(outs, dq_sum=d5[:, :, 0] if fused else dq.view(B, Tq, H, dk), du=du, dv_bias=dv_bias)
+        dqu, dqv, dk_, dv_, dpos = ops.attention_bwd(
+            qu, qv, k4, v4, pproj, m, ctxv, lse, dctx, 1.0 / math.sqrt(dk), precise=_state["precise"],
+            drop_p=pa, seed=sa, seed_dev=sda, **outs)
+        if relpos:
             du, dv_bias = du.view(H, dk), dv_bias.view(H, dk)
             dwpos = _wgrad(dpos, pe, pe.shape[0], D, D) if ctx.pp is None else None
         elif not fused:
@@ -1353,12 +1356,17 @@ class ConvSublayerFn(torch.autograd.Function):
         gl = None
         wdw = w_dw.view(D, K)
         c = ops.dwconv(a, wdw, b_dw, B, Tn, D, K, glu_in=True)
-        if training:
-            bmean, binv, counts = _bn_train_stats(c, rows, D, bn_eps, momentum, bn_rm, bn_rv, bn_nbt)
-        else:
-            bmean, binv = ops.bn_eval_params(bn_rm, bn_rv, bn_eps)
+        one_launch = training and _BN_SMALL and _state["bn_sync"] is None and rows <= ops.BN_SMALL_MAX_ROWS
+        if one_launch:  # statistics + running stats + normalise + Swish in one pass (no cross-rank merge to wait for)
+            s, bmean, binv = ops.bn_small_fwd(c, rows, D, bn_w, bn_b, bn_eps, momentum, bn_rm, bn_rv, bn_nbt, 1)
             counts = None
-        s = ops.bn_act_fwd(c, None, bmean, binv, bn_w, bn_b, rows, D, 1)
+        else:
+            if training:
+                bmean, binv, counts = _bn_train_stats(c, rows, D, bn_eps, momentum, bn_rm, bn_rv, bn_nbt)
+            else:
+                bmean, binv = ops.bn_eval_params(bn_rm, bn_rv, bn_eps)
+                counts = None
+            s = ops.bn_act_fwd(c, None, bmean, binv, bn_w, bn_b, rows, D, 1)
         po, so, sdo = _drop_args(p_out, x)
         y = torch.empty_like(x)
         _gemm_nt(s, w_pw2.view(D, D), rows, D, D, y, bias=b_pw2, drop_p=po, seed=so, seed_dev=sdo,
@@ -1383,13 +1391,16 @@ class ConvSublayerFn(torch.autograd.Function):
         with ops.paired():
             dw2 = _wgrad(g, s, rows, D, D, dyT=gT, xT=_xT(s, rows, D), bias_out=db2).view(D, D, 1)
             _gemm_nn(g, w_pw2.view(D, D), rows, D, D, ds)
-        sums = ops.bn_bwd_reduce(c, ds, None, bmean, binv, bn_w, bn_b, rows, D, 1)
-        dbn_w, dbn_b = sums[1], sums[0]
-        if training:
-            sums_dx, inv_n, n_dev = _bn_bwd_sums(sums, counts, rows)
+        if training and _BN_SMALL and _state["bn_sync"] is None and rows <= ops.BN_SMALL_MAX_ROWS:
+            dc, dbn_w, dbn_b = ops.bn_small_bwd(c, ds, rows, D, bmean, binv, bn_w, bn_b, 1)
         else:
-            sums_dx, inv_n, n_dev = torch.zeros_like(sums), 0.0, None
-        dc, _ = ops.bn_bwd_apply(c, ds, None, bmean, binv, bn_w, bn_b, sums_dx, inv_n, rows, D, 1, False, n_dev=n_dev)
+            sums = ops.bn_bwd_reduce(c, ds, None, bmean, binv, bn_w, bn_b, rows, D, 1)
+            dbn_w, dbn_b = sums[1], sums[0]
+            if training:
+                sums_dx, inv_n, n_dev = _bn_bwd_sums(sums, counts, rows)
+            else:
+                sums_dx, inv_n, n_dev = torch.zeros_like(sums), 0.0, None
+            dc, _ = ops.bn_bwd_apply(c, ds, None, bmean, binv, bn_w, bn_b, sums_dx, inv_n, rows, D, 1, False, n_dev=n_dev)
         dwdw = _zeros((D, K), x.device)
         dbdw = _zeros(D, x.device)
         ops.dwconv_wgrad(a, dc, dwdw, dbdw, B, Tn, D, K, glu_in=True)

@@ -145,14 +145,21 @@ def attention_fwd(qu, qv, k, v, pos, mask, scale, *, precise=False, drop_p=0.0, 
 
 
 def attention_bwd_dq(qu, qv, k, v, pos, mask, out, lse, dout, scale, *, precise=False, drop_p=0.0, seed=0,
-                     seed_dev=None, dqu_out=None):
+                     seed_dev=None, dqu_out=None, dq_sum=None, du=None, dv=None):
+    """dq_sum (+ du, dv; relative-position form): the kernel writes dqu + dqv into the [B,Tq,H,64] view dq_sum and adds the
+    column sums of dqu / dqv to du / dv (f32 [H*64], zeroed by the caller); dqu / dqv themselves are then not produced."""
     B, Tq, H, dk = qu.shape
     Tk = k.shape[1]
     lds = (Tk + 7) // 8 * 8
     # the kernel addresses dqu / dqv with qu's strides: dqu_out (a [B,Tq,H,64] view, e.g. the q third of a fused
     # d(qkv) buffer) must be laid out like qu
-    dqu = dqu_out if dqu_out is not None else torch.empty(B, Tq, H, dk, dtype=qu.dtype, device=qu.device)
-    dqv = torch.empty(B, Tq, H, dk, dtype=qu.dtype, device=qu.device) if pos is not None else None
+    if dq_sum is not None:
+        assert pos is not None and du is not None and dv is not None and dq_sum.shape == qu.shape and dq_sum.stride(2) == dk \
+            and dq_sum.stride(3) == 1 and du.dtype == dv.dtype == torch.float32 and du.numel() == dv.numel() == H * dk
+        dqu = dqv = None
+    else:
+        dqu = dqu_out if dqu_out is not None else torch.empty(B, Tq, H, dk, dtype=qu.dtype, device=qu.device)
+        dqv = torch.empty(B, Tq, H, dk, dtype=qu.dtype, device=qu.device) if pos is not None else None
     # pad columns [Tk, lds) are never read: the TN loaders mask by the logical width
     pd = torch.empty(B, H, Tq, lds, dtype=qu.dtype, device=qu.device)
     ds = torch.empty(B, H, Tq, lds, dtype=qu.dtype, device=qu.device)
@@ -160,12 +167,15 @@ def attention_bwd_dq(qu, qv, k, v, pos, mask, out, lse, dout, scale, *, precise=
     if mask is not None:
         msb = mask.shape[1] * mask.shape[2] if mask.shape[0] > 1 else 0  # a batch-1 mask is shared by every sequence
         msq = mask.shape[2] if mask.shape[1] > 1 else 0
-    assert dqu.stride() == qu.stride() and (dqv is None or (dqv.stride() == qu.stride() and qv.stride() == qu.stride())), \
+    assert dq_sum is not None or (dqu.stride() == qu.stride() and
+                                  (dqv is None or (dqv.stride() == qu.stride() and qv.stride() == qu.stride()))), \
         "bwd writes dqu/dqv with qu's strides"
     call("avsr_attention_bwd_dq", _ptr(qu), _ptr(qv), _ptr(k), _ptr(v), _ptr(pos), dt(qu), int(precise), _ptr(mask),
          msb, msq, _ptr(out), _ptr(lse), _ptr(dout), _ptr(dqu), _ptr(dqv), _ptr(pd), _ptr(ds), lds, B, H, Tq, Tk, dk,
          qu.stride(1), k.stride(1), v.stride(1), pos.stride(0) if pos is not None else 0, out.stride(1),
-         qu.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, drop_p, seed, _ptr(seed_dev), _stream(qu))
+         qu.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, drop_p, seed, _ptr(seed_dev), _ptr(dq_sum),
+         dq_sum.stride(1) if dq_sum is not None else 0, dq_sum.stride(0) if dq_sum is not None else 0, _ptr(du), _ptr(dv),
+         _stream(qu))
     return dqu, dqv, pd, ds
 
 
@@ -177,7 +187,7 @@ def gemm_tn_batched(A, lda, sAb, sAh, Bm, ldb, sBb, sBh, C, ldc, sCb, sCh, nb, n
 
 
 def attention_bwd(qu, qv, k, v, pos, mask, out, lse, dout, scale, *, precise=False, drop_p=0.0, seed=0,
-                  seed_dev=None, dqu_out=None, dk_out=None, dv_out=None, dpos_out=None):
+                  seed_dev=None, dqu_out=None, dk_out=None, dv_out=None, dpos_out=None, dq_sum=None, du=None, dv_bias=None):
     """Full attention backward.  Returns dqu, dqv (or None), dk, dv, dpos (f32 [2T-1, H*64] or None).
     dqu_out / dk_out / dv_out: optional [B,T,H,64] destination views (slices of a fused d(qkv) buffer).
     dpos_out: optional ZEROED f32 [2T-1, H*64] destination view (a column block of an all-layer buffer)."""
@@ -185,7 +195,8 @@ def attention_bwd(qu, qv, k, v, pos, mask, out, lse, dout, scale, *, precise=Fal
     Tk = k.shape[1]
     D = H * dk
     dqu, dqv, pd, ds = attention_bwd_dq(qu, qv, k, v, pos, mask, out, lse, dout, scale, precise=precise,
-                                        drop_p=drop_p, seed=seed, seed_dev=seed_dev, dqu_out=dqu_out)
+                                        drop_p=drop_p, seed=seed, seed_dev=seed_dev, dqu_out=dqu_out, dq_sum=dq_sum, du=du,
+                                        dv=dv_bias)
     lds = pd.shape[-1]
     dkk = dk_out if dk_out is not None else torch.empty(B, Tk, H, dk, dtype=qu.dtype, device=qu.device)
     dvv = dv_out if dv_out is not None else torch.empty(B, Tk, H, dk, dtype=qu.dtype, device=qu.device)
@@ -272,6 +283,30 @@ def bn_stats_finalize(x, rows, C, eps, momentum, running_mean, running_var, num_
     call("avsr_bn_stats_finalize", _ptr(x), dt(x), _ptr(ws), rows, C, eps, momentum, _ptr(mean), _ptr(invstd),
          _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _stream(x), nbytes=_nb(x))
     return mean, invstd
+
+
+BN_SMALL_MAX_ROWS = 2048  # avsr_bn_small_max_rows()
+
+
+def bn_small_fwd(x, rows, C, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, act):
+    """Single-rank BatchNorm + activation of a small [rows, C] activation in ONE launch: (y, mean, invstd)."""
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    y = torch.empty(rows, C, dtype=x.dtype, device=x.device)
+    call("avsr_bn_small_fwd", _ptr(x), dt(x), rows, C, _ptr(gamma), _ptr(beta), eps, momentum, _ptr(running_mean),
+         _ptr(running_var), _ptr(num_batches_tracked), act, _ptr(y), _ptr(mean), _ptr(invstd), _stream(x),
+         nbytes=2.0 * _nb(x))
+    return y, mean, invstd
+
+
+def bn_small_bwd(x, dy, rows, C, mean, invstd, gamma, beta, act):
+    """Backward of bn_small_fwd in ONE launch: (dx, dgamma, dbeta)."""
+    dx = torch.empty(rows, C, dtype=x.dtype, device=x.device)
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    call("avsr_bn_small_bwd", _ptr(x), _ptr(dy), dt(x), rows, C, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), act,
+         _ptr(dx), _ptr(dgamma), _ptr(dbeta), _stream(x), nbytes=3.0 * _nb(x))
+    return dx, dgamma, dbeta
 
 
 def bn_finalize(stats, counts, world, C, eps, momentum, running_mean, running_var, num_batches_tracked=None,
@@ -376,6 +411,20 @@ def sum_scale(a, scale, finite_only=False):
 
 def sum_finite_scale(a, scale):
     return sum_scale(a, scale, finite_only=True)
+
+
+def prepare_targets(ys_pad, sos, eos, ignore_id, want_mask=True):
+    """(ys_in, ys_out [B, L+1] int64, mask [B, L+1, L+1] bool or None, n_tokens [1] int64) -- csrc/loss.hip
+    prepare_targets_kernel: add_sos_eos + target_mask of the reference with the static width L + 1, one launch."""
+    y = ys_pad.reshape(ys_pad.shape[0], -1).to(torch.int64).contiguous()
+    B, L = y.shape
+    ys_in = torch.empty(B, L + 1, dtype=torch.int64, device=y.device)
+    ys_out = torch.empty(B, L + 1, dtype=torch.int64, device=y.device)
+    mask = torch.empty(B, L + 1, L + 1, dtype=torch.bool, device=y.device) if want_mask else None
+    n_tok = torch.empty(1, dtype=torch.int64, device=y.device)
+    call("avsr_prepare_targets", _ptr(y), B, L, int(sos), int(eos), int(ignore_id), _ptr(ys_in), _ptr(ys_out), _ptr(mask),
+         _ptr(n_tok), _stream(y))
+    return ys_in, ys_out, mask, n_tok
 
 
 def embed_fwd(ids, table, pe, L, scale, drop_p=0.0, seed=0, seed_dev=None):

@@ -79,7 +79,11 @@ int avsr_attention_bwd_dq(const void* qu, const void* qv, const void* k, const v
                           void* pd, void* ds, int lds, int B, int H, int Tq, int Tk, int dk, int ldq,
                           int ldk, int ldv, int ldp, int ldo, int64_t sbq, int64_t sbk, int64_t sbv,
                           int64_t sbo, float scale, float drop_p, uint64_t seed, const uint64_t* seed_dev,
-                          avsr_stream_t stream);
+                          void* dq_sum /* may be NULL; else (relative-position form): dq_sum = dqu + dqv is written as a
+                          [B,Tq,H,64] view (row pitch lddq, batch stride sbdq) INSTEAD of dqu / dqv, and the column sums of
+                          the two parts are added to du / dv [H*64] (f32, zeroed by the caller): the gradients of q, pos_bias_u
+                          and pos_bias_v of attention.py:171-177 without a separate pass */,
+                          int lddq, int64_t sbdq, float* du, float* dv, avsr_stream_t stream);
 
 /* key/value side of the attention backward in ONE launch (three independent batched TN contractions):
  * dV = Pd^T dO, dK = dS^T Qu, dpos += skew(dS)^T Qv (dpos / qv may both be NULL); pd/ds from avsr_attention_bwd_dq;
@@ -146,6 +150,19 @@ int avsr_bn_stats_finalize(const void* x, int dtype, float* workspace, int64_t r
                            int64_t* num_batches_tracked, avsr_stream_t stream);
 int avsr_bn_eval_params(const float* running_mean, const float* running_var, float eps, int C, float* mean,
                         float* invstd, avsr_stream_t stream);
+/* Single-launch BatchNorm(+activation) of a SMALL [rows, C] activation on ONE rank (the ConvolutionModule's BatchNorm1d,
+ * conformer_encoder.py:26,33 + Swish :28; rows = B*T <= avsr_bn_small_max_rows()): batch statistics, running-stat /
+ * num_batches_tracked update (as avsr_bn_stats_finalize) and y = act(gamma*(x-mean)*invstd + beta) (as avsr_bn_act_fwd);
+ * mean / invstd [C] are kept for the backward.  avsr_bn_small_bwd: dx, dgamma = sum dz*xhat, dbeta = sum dz of the same
+ * (as avsr_bn_bwd_reduce + avsr_bn_bwd_apply with n = rows).  Cross-rank synchronised BatchNorm keeps the three-phase entry
+ * points (the collective sits between the phases). */
+int avsr_bn_small_max_rows(void);
+int avsr_bn_small_fwd(const void* x, int dtype, int64_t rows, int C, const float* gamma, const float* beta, float eps,
+                      float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, int act, void* y,
+                      float* mean, float* invstd, avsr_stream_t stream);
+int avsr_bn_small_bwd(const void* x, const void* dy, int dtype, int64_t rows, int C, const float* mean, const float* invstd,
+                      const float* gamma, const float* beta, int act, void* dx, float* dgamma, float* dbeta,
+                      avsr_stream_t stream);
 /* y = act(gamma*(x-mean)*invstd + beta (+ add)); act 0 none, 1 SiLU */
 int avsr_bn_act_fwd(const void* x, const void* add, int dtype, const float* mean, const float* invstd,
                     const float* gamma, const float* beta, void* y, int64_t rows, int C, int act,
@@ -196,6 +213,12 @@ int avsr_ce_smooth(const void* logits, int dtype, int64_t ld, const int64_t* tar
                    avsr_stream_t stream);
 /* out[0] = scale * sum(a[0..n)); finite_only skips +-inf entries (zero_infinity of ctc.py:26-28) */
 int avsr_sum_scale(const float* a, int n, float scale, float* out, int finite_only, avsr_stream_t stream);
+/* decoder targets of the attention branch in one launch (e2e_asr_conformer.py:138-139: add_sos_eos, add_sos_eos.py:12-31, and
+ * target_mask, mask.py:11-37) with the static width L + 1: ys_pad [B, L] padded with ignore_id anywhere -> ys_in [B, L+1]
+ * (<sos> labels <eos>...), ys_out [B, L+1] (labels <eos> <ignore_id>...), mask [B, L+1, L+1] bytes (may be NULL),
+ * n_tokens[0] = #(ys_out != ignore_id) (may be NULL) */
+int avsr_prepare_targets(const int64_t* ys_pad, int B, int L, int64_t sos, int64_t eos, int64_t ignore_id, int64_t* ys_in,
+                         int64_t* ys_out, uint8_t* mask, int64_t* n_tokens, avsr_stream_t stream);
 /* out[r,:] = dropout(table[ids[r],:]*scale + pe[r % L,:])  (transformer_decoder.py:186-189, embedding.py:78-87) */
 int avsr_embed_fwd(const int64_t* ids, const float* table, const float* pe, float* out, int64_t rows, int L,
                    int D, float scale, float drop_p, uint64_t seed, const uint64_t* seed_dev, avsr_stream_t stream);

@@ -123,6 +123,44 @@ def test_attention_fwd_bwd(dev, case):
         assert (dpos.cpu().double() - rpos.grad).abs().max() < tol_b
 
 
+@pytest.mark.parametrize("dtype,precise,T", [(torch.float32, True, 70), (torch.bfloat16, False, 130)])
+def test_attention_bwd_emits_query_and_bias_gradients(dev, dtype, precise, T):
+    """dq_sum / du / dv of avsr_attention_bwd_dq: the gradient of q (= dqu + dqv) written straight into a pitched view
+    (the q third of a fused d(qkv) buffer) and the pos_bias_u / pos_bias_v gradients (column sums of dqu / dqv over
+    (batch, time), attention.py:171-177 under autograd) -- against float64 autograd; ragged last query tile."""
+    torch.manual_seed(T)
+    B, H, D = 2, 3, 64
+    q = torch.randn(B, T, H, D).to(dtype)
+    u, v_b = torch.randn(H, D), torch.randn(H, D)
+    qu, qv = (q.float() + u).to(dtype), (q.float() + v_b).to(dtype)
+    k, v = torch.randn(B, T, H, D).to(dtype), torch.randn(B, T, H, D).to(dtype)
+    pos = torch.randn(2 * T - 1, H * D).to(dtype)
+    mask = make_mask("pad", B, T, T)
+    dout = torch.randn(B, T, H * D).to(dtype)
+    scale = 1 / math.sqrt(D)
+    d = lambda t: t.to(dev)
+    out, lse = ops.attention_fwd(d(qu), d(qv), d(k), d(v), d(pos), d(mask), scale, precise=precise)
+    rqu, rqv = qu.double().requires_grad_(), qv.double().requires_grad_()
+    ref = ref_attn(rqu, rqv, k.double(), v.double(), pos.double(), mask, scale)
+    ref.backward(dout.double())
+    dqkv = torch.full((B, T, 3, H, D), 7.0, dtype=dtype, device=dev)  # k / v thirds must stay untouched
+    du = torch.zeros(H * D, dtype=torch.float32, device=dev)
+    dv = torch.zeros(H * D, dtype=torch.float32, device=dev)
+    dqu, dqv, pd, ds = ops.attention_bwd_dq(d(qu), d(qv), d(k), d(v), d(pos), d(mask), out, lse, d(dout), scale,
+                                            precise=precise, dq_sum=dqkv[:, :, 0], du=du, dv=dv)
+    assert dqu is None and dqv is None
+    rel = lambda a, b: float((a.cpu().double() - b).norm() / b.norm())
+    tol = 1e-4 if precise else 2e-2
+    assert rel(dqkv[:, :, 0], rqu.grad + rqv.grad) < tol
+    assert rel(du.view(H, D), rqu.grad.sum((0, 1))) < tol and rel(dv.view(H, D), rqv.grad.sum((0, 1))) < tol
+    assert bool((dqkv[:, :, 1:] == 7.0).all())
+    # same launch without the fused outputs: identical pd / ds, and dqu + dqv equals dq_sum to rounding
+    dqu2, dqv2, pd2, ds2 = ops.attention_bwd_dq(d(qu), d(qv), d(k), d(v), d(pos), d(mask), out, lse, d(dout), scale,
+                                                precise=precise)
+    assert torch.equal(pd[..., :T], pd2[..., :T]) and torch.equal(ds[..., :T], ds2[..., :T])  # (pad columns are never read)
+    assert rel(dqkv[:, :, 0].float(), (dqu2.float() + dqv2.float()).cpu().double()) < (1e-6 if precise else 8e-3)
+
+
 def test_attention_dropout_consistency(dev):
     """Dropout on the probabilities: forward and backward must draw the same keep-mask (finite-difference free
     check: with V = I-like probes the output equals the dropped probabilities that the backward re-creates)."""

@@ -232,3 +232,50 @@ def test_bn_pool_bwd_fused_matches_three_pass(dev, dtype):
     assert relerr(sums2, sums0) < tol
     if dtype == torch.float32:  # no intermediate rounding in either path: element-wise agreement
         assert ((dx1.view(-1, C) - dx0).abs() <= 1e-4 * dx0.abs().clamp_min(1.0)).all()
+
+
+@pytest.mark.parametrize("rows,C,dtype", [(1, 8, torch.float32), (37, 64, torch.float32), (1600, 256, torch.bfloat16),
+                                          (2048, 16, torch.float32), (513, 40, torch.bfloat16)])
+def test_batchnorm_single_launch_small(dev, rows, C, dtype):
+    """avsr_bn_small_fwd / _bwd (one launch each) vs torch.nn.BatchNorm1d in training mode + SiLU under autograd (fp64),
+    including the running statistics and num_batches_tracked, and vs the three-phase entry points on the same input."""
+    torch.manual_seed(rows + C)
+    x = (torch.randn(rows, C) * 1.7 + 0.6).to(dtype)
+    dy = torch.randn(rows, C).to(dtype)
+    bn = torch.nn.BatchNorm1d(C, momentum=0.1).double().train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C) + 0.5)
+        bn.bias.copy_(torch.randn(C) * 0.1)
+        bn.running_mean.copy_(torch.randn(C))
+        bn.running_var.copy_(torch.rand(C) + 0.5)
+    rm, rv = bn.running_mean.float().to(dev), bn.running_var.float().to(dev)
+    nbt = torch.zeros((), dtype=torch.int64, device=dev)
+    g, b = bn.weight.detach().float().to(dev), bn.bias.detach().float().to(dev)
+    xd, dyd = x.to(dev), dy.to(dev)
+    y, mean, invstd = ops.bn_small_fwd(xd, rows, C, g, b, bn.eps, bn.momentum, rm, rv, nbt, 1)
+    xr = x.double().requires_grad_()
+    if rows > 1:
+        yr = F.silu(bn(xr))
+        yr.backward(dy.double())
+        tol = 1e-5 if dtype == torch.float32 else 2e-2
+        assert (y.cpu().double() - yr.detach()).abs().max() < tol * max(1.0, float(yr.detach().abs().max()))
+        assert (rm.cpu().double() - bn.running_mean).abs().max() < 1e-5
+        assert (rv.cpu().double() - bn.running_var).abs().max() < 1e-5 * max(1.0, float(bn.running_var.max()))
+        assert int(nbt) == 1
+        dx, dgamma, dbeta = ops.bn_small_bwd(xd, dyd, rows, C, mean, invstd, g, b, 1)
+        rel = lambda a, r: float((a.cpu().double() - r).norm() / (r.norm() + 1e-30))
+        tolg = 1e-4 if dtype == torch.float32 else 2e-2
+        assert rel(dx, xr.grad) < tolg and rel(dgamma, bn.weight.grad) < tolg and rel(dbeta, bn.bias.grad) < tolg
+    # against the three-phase path (what the synchronised multi-rank BatchNorm runs): same statistics, same outputs
+    rm2, rv2 = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    mean2, invstd2 = ops.bn_stats_finalize(xd, rows, C, bn.eps, bn.momentum, rm2, rv2, None)
+    assert (mean - mean2).abs().max() < 1e-6 and ((invstd - invstd2).abs() / invstd2).max() < 1e-5
+    y2 = ops.bn_act_fwd(xd, None, mean, invstd, g, b, rows, C, 1)
+    assert torch.equal(y, y2)
+    sums = ops.bn_bwd_reduce(xd, dyd, None, mean, invstd, g, b, rows, C, 1)
+    dx2, _ = ops.bn_bwd_apply(xd, dyd, None, mean, invstd, g, b, sums, 1.0 / rows, rows, C, 1, False)
+    dx, dgamma, dbeta = ops.bn_small_bwd(xd, dyd, rows, C, mean, invstd, g, b, 1)
+    scale = max(1.0, float(dx2.float().abs().max()))
+    assert (dx.float() - dx2.float()).abs().max() < (1e-5 if dtype == torch.float32 else 2e-2) * scale
+    assert (dgamma - sums[1]).abs().max() < 1e-3 * max(1.0, float(sums[1].abs().max()))
+    assert (dbeta - sums[0]).abs().max() < 1e-3 * max(1.0, float(sums[0].abs().max()))

@@ -86,3 +86,34 @@ def test_embedding(dev):
     dt = torch.zeros(V, D, device=dev)
     ops.embed_bwd(ids.to(dev), dout.to(dev), dt, math.sqrt(D))
     assert (dt.cpu() - table.grad).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize("B,L", [(1, 1), (3, 7), (5, 64), (2, 300)])
+def test_prepare_targets_matches_reference_formulation(dev, B, L):
+    """avsr_prepare_targets vs the reference's add_sos_eos + target_mask (add_sos_eos.py:12-31, mask.py:27-37; here their
+    static-width torch statement nets.add_sos_eos_static / nets.target_mask): bit-exact integers, ragged rows, an empty
+    row, and padding in the MIDDLE of a row (the reference filters `y != ignore_id`, wherever the padding sits)."""
+    from auto_avsr_amd import nets, ops
+
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    sos = eos = 5048
+    ys = torch.randint(1, 5000, (B, L), generator=g)
+    lens = torch.randint(0, L + 1, (B,), generator=g)
+    lens[0] = L
+    if B > 1:
+        lens[1] = 0
+    for b in range(B):
+        ys[b, int(lens[b]):] = -1
+    if L > 4:
+        ys[0, 2] = -1  # a hole
+    ys = ys.to(dev)
+    ys_in, ys_out, mask, n_tok = ops.prepare_targets(ys, sos, eos, -1)
+    ref_in, ref_out = nets.add_sos_eos_static(ys, sos, eos, -1)
+    assert torch.equal(ys_in, ref_in) and torch.equal(ys_out, ref_out)
+    assert mask.dtype == torch.bool and torch.equal(mask, nets.target_mask(ref_in, -1))
+    assert int(n_tok) == int((ref_out != -1).sum())
+    # and against the reference's own list-based form on the non-empty rows
+    lst_in, lst_out = nets.add_sos_eos(ys.cpu(), sos, eos, -1)
+    w = lst_in.shape[1]
+    assert torch.equal(ys_in.cpu()[:, :w], lst_in) and torch.equal(ys_out.cpu()[:, :w], lst_out)
+    assert bool((ys_out.cpu()[:, w:] == -1).all()) and bool((ys_in.cpu()[:, w:] == eos).all())

@@ -378,10 +378,12 @@ def test_decoder_shared_memory_projection_equivalence(dev):
     assert abs(l0 - l1) < 1e-6 * abs(l0), (l0, l1)
     assert counts[0] - counts[1] == 2 * 3 - 1, counts
     for k in g0:
+        if k.endswith("linear_k.bias"):
+            continue  # zero in exact arithmetic (softmax is invariant to a shift of every score of a row): pure rounding noise
         # the memory gradient is one K = 2*n*D contraction instead of a chain of bf16-rounded partial sums: equal to bf16 noise
         assert rel(g1[k], g0[k]) < 2e-2 or float(g0[k].abs().max()) < 1e-7, (k, rel(g1[k], g0[k]))
     for k in g0:
-        if "decoder" in k and "src_attn" in k:
+        if "decoder" in k and "src_attn" in k and not k.endswith("linear_k.bias"):
             assert rel(g1[k], g0[k]) < 2e-3, (k, rel(g1[k], g0[k]))
 
 
