@@ -80,6 +80,18 @@ AVSR_DEV void wave_sync() {
 // 0 <= row0+r < row_lim, else zeros.  LDS image [NS][ROWS][PITCH].
 template <class T, int NS, int ROWS>
 AVSR_DEV void stage_rows(bf16_t* lds, const T* src, long ld, int row0, int row_lim) {
+    if (sizeof(T) == 2 && NS == 1) {
+        // bf16 in, one bf16 plane out: a plain 16-byte copy (the generic path below unpacks to f32 and rounds back: ~30 VALU
+        // instructions per chunk, a fifth of the instructions of the whole key-tile iteration)
+        for (int id = threadIdx.x; id < ROWS * 8; id += 256) {
+            const int r = id >> 3, c = (id & 7) * 8;
+            const int gr = row0 + r;
+            bf16x8 v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (gr >= 0 && gr < row_lim) v = *reinterpret_cast<const bf16x8*>(src + (long)gr * ld + c);
+            *reinterpret_cast<bf16x8*>(lds + r * PITCH + c) = v;
+        }
+        return;
+    }
     for (int id = threadIdx.x; id < ROWS * 8; id += 256) {
         const int r = id >> 3, c = (id & 7) * 8;
         const int gr = row0 + r;

@@ -20,11 +20,25 @@ namespace {
 
 constexpr float LOG_ZERO = -1e30f;
 constexpr int CTC_MAXSPL = 8;  // states per lane -> S <= 512, L <= 255
+constexpr int CTC_PF = 6;      // frames of emissions kept in flight ahead of the alpha / beta recursion
 
 AVSR_DEV float log_add(float a, float b) {
     const float m = fmaxf(a, b);
     if (m <= LOG_ZERO) return LOG_ZERO;
     return m + logf(avsr_exp(a - m) + avsr_exp(b - m));
+}
+// log(e^a + e^b + e^c) in one go for the alpha / beta recursions (one wave walks T dependent frames: the instruction count of a
+// step IS the kernel time).  The argument of the logarithm lies in [1, 3]: the hardware log2 (v_log_f32, 1 ulp) is exact
+// enough there -- absolute error ~1e-7 per frame on log-likelihoods of order 1e2.
+AVSR_DEV float log_add3(float a, float b, float c) {
+    const float m = fmaxf(a, fmaxf(b, c));
+    if (m <= LOG_ZERO) return LOG_ZERO;
+    const float sum = avsr_exp(a - m) + avsr_exp(b - m) + avsr_exp(c - m);
+#ifdef AVSR_EMU
+    return m + logf(sum);
+#else
+    return m + __logf(sum);
+#endif
 }
 
 // ---- row-wise log-sum-exp over the first V columns: one wave per row
@@ -145,7 +159,25 @@ __global__ __launch_bounds__(64) void ctc_alphabeta_kernel(const float* __restri
             out[(long)tfirst * Smax + s] = cur[i];
         }
     }
-    for (int step = 1; step < Tb; step++) {
+    // The recursion is a chain of Tb dependent steps on ONE wave: a global load of this step's emissions inside the step
+    // puts a full memory round trip (~1 us) on every link of the chain (measured: 0.88 us per frame, 352 us at T = 400).
+    // The emissions do not depend on the recursion, so they are fetched CTC_PF frames ahead into registers.
+    float pre[CTC_PF][CTC_MAXSPL];
+    auto fetch = [&](int step, float (&dst)[CTC_MAXSPL]) {
+        const int t = dir == 0 ? step : Tb - 1 - step;
+#pragma unroll
+        for (int i = 0; i < CTC_MAXSPL; i++) {
+            const int s = s0 + i;
+            dst[i] = (step < Tb && i < spl && s < S) ? lp[(long)t * Smax + s] : 0.f;
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < CTC_PF; j++) fetch(1 + j, pre[j]);
+    for (int step0 = 1; step0 < Tb; step0 += CTC_PF) {
+#pragma unroll
+    for (int j = 0; j < CTC_PF; j++) {
+        const int step = step0 + j;
+        if (step >= Tb) break;
         const int t = dir == 0 ? step : Tb - 1 - step;
         // values owned by the neighbouring lanes: n1 = state one step away, n2 = two steps away
         float edge1 = LOG_ZERO, edge2 = LOG_ZERO;  // what this lane exports
@@ -187,15 +219,16 @@ __global__ __launch_bounds__(64) void ctc_alphabeta_kernel(const float* __restri
                     a1 = (i + 1 < spl) ? c1 : n1;
                     a2 = (i + 2 < spl) ? c2 : ((i + 1 < spl) ? n1 : n2);
                 }
-                float v = log_add(cur[i], a1);
-                if (skip[i]) v = log_add(v, a2);
-                nxt[i] = v + lp[(long)t * Smax + s];
+                const float v = log_add3(cur[i], a1, skip[i] ? a2 : LOG_ZERO);
+                nxt[i] = v + pre[j][i];
                 if (nxt[i] < LOG_ZERO) nxt[i] = LOG_ZERO;
                 out[(long)t * Smax + s] = nxt[i];
             }
         }
 #pragma unroll
         for (int i = 0; i < CTC_MAXSPL; i++) cur[i] = nxt[i];
+        fetch(step + CTC_PF, pre[j]);
+    }
     }
     if (dir == 0) {
         // log P = logaddexp(alpha_{Tb-1}(S-1), alpha_{Tb-1}(S-2)); gather from the owning lanes
@@ -345,19 +378,22 @@ __global__ __launch_bounds__(256) void prepare_targets_kernel(const int64_t* __r
                                                               int64_t* __restrict__ ys_out, uint8_t* __restrict__ mask,
                                                               int64_t* __restrict__ n_tokens) {
     AVSR_DYN_SMEM(smem);
-    int64_t* comp = reinterpret_cast<int64_t*>(smem);  // [L] compacted labels, then [L + 1] "ys_in != ignore" flags as bytes
+    int64_t* comp = reinterpret_cast<int64_t*>(smem);  // [L] compacted labels | [L] the raw row | [L + 1] "ys_in != ignore" bytes
     __shared__ int n_keep;
     const int b = blockIdx.x, W = L + 1;
     const int64_t* y = ys_pad + (long)b * L;
-    if (threadIdx.x == 0) {  // L is a few hundred at most: a serial stable compaction is a microsecond
+    uint8_t* ok = reinterpret_cast<uint8_t*>(comp + 2 * L);
+    int64_t* raw = comp + L;  // the row, staged with coalesced loads (a serial walk over global memory is a chain of round trips)
+    for (int j = threadIdx.x; j < L; j += 256) raw[j] = y[j];
+    __syncthreads();
+    if (threadIdx.x == 0) {  // L is a few hundred at most: a serial stable compaction out of LDS is a microsecond
         int n = 0;
         for (int j = 0; j < L; j++)
-            if (y[j] != ignore_id) comp[n++] = y[j];
+            if (raw[j] != ignore_id) comp[n++] = raw[j];
         n_keep = n;
     }
     __syncthreads();
     const int n = n_keep;
-    uint8_t* ok = reinterpret_cast<uint8_t*>(comp + L);
     for (int j = threadIdx.x; j < W; j += 256) {
         const int64_t vin = j == 0 ? sos : (j <= n ? comp[j - 1] : eos);
         const int64_t vout = j < n ? comp[j] : (j == n ? eos : ignore_id);
@@ -374,10 +410,8 @@ __global__ __launch_bounds__(256) void prepare_targets_kernel(const int64_t* __r
     if (b == 0 && n_tokens) {  // block 0 also counts the scored tokens of the whole batch: labels + one <eos> per utterance
         __shared__ int red[4];
         int cnt = 0;
-        for (int r = threadIdx.x; r < B; r += 256) {
-            for (int j = 0; j < L; j++) cnt += ys_pad[(long)r * L + j] != ignore_id;
-            cnt += eos != ignore_id;
-        }
+        for (long i = threadIdx.x; i < (long)B * L; i += 256) cnt += ys_pad[i] != ignore_id;
+        if (threadIdx.x == 0 && eos != ignore_id) cnt += B;  // one <eos> per utterance
         cnt = (int)wave_sum((float)cnt);  // exact: counts are far below 2^24
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
         __syncthreads();
@@ -495,7 +529,7 @@ extern "C" int avsr_prepare_targets(const int64_t* ys_pad, int B, int L, int64_t
                                     int64_t* ys_in, int64_t* ys_out, uint8_t* mask, int64_t* n_tokens, hipStream_t stream) {
     AVSR_REQUIRE(L >= 1 && L <= 4096, "prepare_targets: label width out of range");
     if (B <= 0) return 0;
-    const size_t lds = (size_t)L * sizeof(int64_t) + ((L + 1 + 7) / 8) * 8;
+    const size_t lds = (size_t)2 * L * sizeof(int64_t) + ((L + 1 + 7) / 8) * 8;
     AVSR_LAUNCH(prepare_targets_kernel, dim3(B), dim3(256), lds, stream, ys_pad, B, L, sos, eos, ignore_id, ys_in, ys_out, mask, n_tokens);
     AVSR_CHECK_LAUNCH("prepare_targets");
     return 0;

@@ -303,14 +303,34 @@ template <int NS> AVSR_DEV void split_bf16(float x, bf16_t* out) {
 }
 
 // ---------------------------------------------------------------- stateless dropout RNG
-// keep-mask for element `idx` of a tensor under (seed, p): a 32-bit mix of the
-// 64-bit (seed, idx) counter; forward and backward recompute the same bits.
-AVSR_DEV uint32_t avsr_hash(uint64_t seed, uint64_t idx) {
-    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+// keep-mask for element `idx` of a tensor under (seed, p): a 32-bit mix of the 64-bit (seed, idx) counter; forward and
+// backward recompute the same bits.
+// Cost matters: the attention kernels draw one number per score element, the GEMM epilogues one per output.  A 64-bit
+// splitmix (three 64-bit multiplies = ~9 quarter-rate 32-bit multiplies + carries per element) made the RNG ~8x the MFMA
+// time of the attention inner loop.  Now the seed -- wave-uniform in every caller -- goes through the 64-bit mixer ONCE into
+// a 32-bit key (scalar ALU, hoisted out of the element loops), and the per-element work is a 32-bit finalizer with two
+// multiplies ("lowbias32", Wellons: bias 0.17 over all 2^32 inputs) of (low index word ^ key); the high index word
+// (non-zero only beyond 2^32 elements) costs one more round.
+AVSR_DEV uint32_t avsr_hash_key(uint64_t seed) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     z = z ^ (z >> 31);
     return (uint32_t)(z >> 32);
+}
+AVSR_DEV uint32_t avsr_mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+AVSR_DEV uint32_t avsr_hash(uint64_t seed, uint64_t idx) {
+    uint32_t x = avsr_mix32((uint32_t)idx ^ avsr_hash_key(seed));
+    const uint32_t hi = (uint32_t)(idx >> 32);
+    if (hi) x = avsr_mix32(x + hi * 0x9E3779B1u);
+    return x;
 }
 // returns scale to apply: 0 if dropped, 1/(1-p) if kept; p == 0 -> 1
 AVSR_DEV float dropout_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
