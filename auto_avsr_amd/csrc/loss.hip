@@ -116,7 +116,13 @@ __global__ __launch_bounds__(256) void ctc_gather_kernel(const T* __restrict__ l
         lpg[bt * Smax + s] = Elem<T>::ld(logits + bt * ld + ext[(long)b * Smax + s]) - l;
 }
 
-// ---- alpha (blockIdx.y == 0) / beta (== 1) recursions: one wave per utterance, lane owns SPL contiguous states
+// ---- alpha (blockIdx.y == 0) / beta (== 1) recursions: one wave per utterance, lane owns SPL contiguous states.
+// The recursion is a chain of T_b dependent steps executed by ONE wave: its instruction count per step IS the kernel time.
+// SPL is a template parameter (from the batch's widest label row), so the per-state loops are exact and branch-free --
+// states beyond an utterance's S = 2L + 1 are carried as LOG_ZERO -- and the emissions of the next CTC_PF frames, which do
+// not depend on the recursion, are kept in flight in registers (a load inside the step would put a memory round trip on
+// every link of the chain).
+template <int SPL>
 __global__ __launch_bounds__(64) void ctc_alphabeta_kernel(const float* __restrict__ lpg, const int* __restrict__ ext,
                                                            const int* __restrict__ lens,
                                                            const int64_t* __restrict__ in_lens, float* __restrict__ alpha,
@@ -129,17 +135,17 @@ __global__ __launch_bounds__(64) void ctc_alphabeta_kernel(const float* __restri
     const int* e = ext + (long)b * Smax;
     const float* lp = lpg + (long)b * Tlen * Smax;
     float* out = (dir == 0 ? alpha : beta) + (long)b * Tlen * Smax;
-    const int spl = (S + 63) / 64;  // states per lane (<= CTC_MAXSPL)
-    const int s0 = lane * spl;
+    const int s0 = lane * SPL;
     // can state s take the skip transition from s-2 (alpha) / to s+2 (beta)?
-    bool skip[CTC_MAXSPL];
-    float cur[CTC_MAXSPL];
+    bool skip[SPL], valid[SPL];
+    float cur[SPL];
 #pragma unroll
-    for (int i = 0; i < CTC_MAXSPL; i++) {
+    for (int i = 0; i < SPL; i++) {
         const int s = s0 + i;
+        valid[i] = s < S;
         skip[i] = false;
         cur[i] = LOG_ZERO;
-        if (i < spl && s < S) {
+        if (valid[i]) {
             if (dir == 0) skip[i] = (s >= 2) && (e[s] != 0) && (e[s] != e[s - 2]);
             else skip[i] = (s + 2 < S) && (e[s] != 0) && (e[s] != e[s + 2]);
         }
@@ -151,92 +157,65 @@ __global__ __launch_bounds__(64) void ctc_alphabeta_kernel(const float* __restri
     // t = first step
     const int tfirst = dir == 0 ? 0 : Tb - 1;
 #pragma unroll
-    for (int i = 0; i < CTC_MAXSPL; i++) {
+    for (int i = 0; i < SPL; i++) {
         const int s = s0 + i;
-        if (i < spl && s < S) {
+        if (valid[i]) {
             const bool start = dir == 0 ? (s < 2) : (s >= S - 2);
             cur[i] = start ? lp[(long)tfirst * Smax + s] : LOG_ZERO;
             out[(long)tfirst * Smax + s] = cur[i];
         }
     }
-    // The recursion is a chain of Tb dependent steps on ONE wave: a global load of this step's emissions inside the step
-    // puts a full memory round trip (~1 us) on every link of the chain (measured: 0.88 us per frame, 352 us at T = 400).
-    // The emissions do not depend on the recursion, so they are fetched CTC_PF frames ahead into registers.
-    float pre[CTC_PF][CTC_MAXSPL];
-    auto fetch = [&](int step, float (&dst)[CTC_MAXSPL]) {
+    float pre[CTC_PF][SPL];
+    auto fetch = [&](int step, float (&dst)[SPL]) {
         const int t = dir == 0 ? step : Tb - 1 - step;
 #pragma unroll
-        for (int i = 0; i < CTC_MAXSPL; i++) {
-            const int s = s0 + i;
-            dst[i] = (step < Tb && i < spl && s < S) ? lp[(long)t * Smax + s] : 0.f;
-        }
+        for (int i = 0; i < SPL; i++) dst[i] = (step < Tb && valid[i]) ? lp[(long)t * Smax + s0 + i] : 0.f;
     };
 #pragma unroll
     for (int j = 0; j < CTC_PF; j++) fetch(1 + j, pre[j]);
     for (int step0 = 1; step0 < Tb; step0 += CTC_PF) {
 #pragma unroll
-    for (int j = 0; j < CTC_PF; j++) {
-        const int step = step0 + j;
-        if (step >= Tb) break;
-        const int t = dir == 0 ? step : Tb - 1 - step;
-        // values owned by the neighbouring lanes: n1 = state one step away, n2 = two steps away
-        float edge1 = LOG_ZERO, edge2 = LOG_ZERO;  // what this lane exports
-        if (dir == 0) {
-#pragma unroll
-            for (int i = 0; i < CTC_MAXSPL; i++) {
-                if (i == spl - 1) edge1 = cur[i];
-                if (i == spl - 2) edge2 = cur[i];
+        for (int j = 0; j < CTC_PF; j++) {
+            const int step = step0 + j;
+            if (step >= Tb) break;
+            const int t = dir == 0 ? step : Tb - 1 - step;
+            // values owned by the neighbouring lane: n1 = the state one step away, n2 = two steps away
+            float n1, n2;
+            if (dir == 0) {
+                n1 = wave_up1(cur[SPL - 1], LOG_ZERO);
+                n2 = SPL >= 2 ? wave_up1(cur[SPL >= 2 ? SPL - 2 : 0], LOG_ZERO) : wave_up1(n1, LOG_ZERO);
+            } else {
+                n1 = wave_down1(cur[0], LOG_ZERO);
+                n2 = SPL >= 2 ? wave_down1(cur[SPL >= 2 ? 1 : 0], LOG_ZERO) : wave_down1(n1, LOG_ZERO);
             }
-        } else {
-            edge1 = cur[0];
-            edge2 = cur[1];
-        }
-        float n1, n2;
-        if (dir == 0) {
-            n1 = __shfl_up(edge1, 1);
-            n2 = spl >= 2 ? __shfl_up(edge2, 1) : __shfl_up(edge1, 2);
-            if (lane < 1) n1 = LOG_ZERO;
-            if (lane < (spl >= 2 ? 1 : 2)) n2 = LOG_ZERO;
-        } else {
-            n1 = __shfl_down(edge1, 1);
-            n2 = spl >= 2 ? __shfl_down(edge2, 1) : __shfl_down(edge1, 2);
-            if (lane > 62) n1 = LOG_ZERO;
-            if (lane > (spl >= 2 ? 62 : 61)) n2 = LOG_ZERO;
-        }
-        float nxt[CTC_MAXSPL];
+            float nxt[SPL];
 #pragma unroll
-        for (int i = 0; i < CTC_MAXSPL; i++) {
-            nxt[i] = LOG_ZERO;
-            const int s = s0 + i;
-            if (i < spl && s < S) {
+            for (int i = 0; i < SPL; i++) {
                 float a1, a2;
                 if (dir == 0) {
                     a1 = i >= 1 ? cur[i >= 1 ? i - 1 : 0] : n1;
                     a2 = i >= 2 ? cur[i >= 2 ? i - 2 : 0] : (i == 1 ? n1 : n2);
                 } else {
-                    const float c1 = (i + 1 < CTC_MAXSPL) ? cur[(i + 1 < CTC_MAXSPL) ? i + 1 : 0] : LOG_ZERO;
-                    const float c2 = (i + 2 < CTC_MAXSPL) ? cur[(i + 2 < CTC_MAXSPL) ? i + 2 : 0] : LOG_ZERO;
-                    a1 = (i + 1 < spl) ? c1 : n1;
-                    a2 = (i + 2 < spl) ? c2 : ((i + 1 < spl) ? n1 : n2);
+                    a1 = (i + 1 < SPL) ? cur[(i + 1 < SPL) ? i + 1 : 0] : n1;
+                    a2 = (i + 2 < SPL) ? cur[(i + 2 < SPL) ? i + 2 : 0] : ((i + 1 < SPL) ? n1 : n2);
                 }
-                const float v = log_add3(cur[i], a1, skip[i] ? a2 : LOG_ZERO);
-                nxt[i] = v + pre[j][i];
-                if (nxt[i] < LOG_ZERO) nxt[i] = LOG_ZERO;
-                out[(long)t * Smax + s] = nxt[i];
+                float v = log_add3(cur[i], a1, skip[i] ? a2 : LOG_ZERO) + pre[j][i];
+                v = (valid[i] && v > LOG_ZERO) ? v : LOG_ZERO;
+                nxt[i] = v;
+                if (valid[i]) out[(long)t * Smax + s0 + i] = v;
             }
-        }
 #pragma unroll
-        for (int i = 0; i < CTC_MAXSPL; i++) cur[i] = nxt[i];
-        fetch(step + CTC_PF, pre[j]);
-    }
+            for (int i = 0; i < SPL; i++) cur[i] = nxt[i];
+            fetch(step + CTC_PF, pre[j]);
+        }
     }
     if (dir == 0) {
         // log P = logaddexp(alpha_{Tb-1}(S-1), alpha_{Tb-1}(S-2)); gather from the owning lanes
         float mine = LOG_ZERO;
 #pragma unroll
-        for (int i = 0; i < CTC_MAXSPL; i++) {
+        for (int i = 0; i < SPL; i++) {
             const int s = s0 + i;
-            if (i < spl && s < S && (s == S - 1 || s == S - 2)) mine = log_add(mine, cur[i]);
+            if (valid[i] && (s == S - 1 || s == S - 2)) mine = log_add(mine, cur[i]);
         }
         // combine across lanes (at most two lanes hold a contribution)
         float tot = mine;
@@ -491,7 +470,17 @@ extern "C" int avsr_ctc_loss(const void* logits, int dtype, int64_t ld, const in
         AVSR_LAUNCH((ctc_gather_kernel<float>), dim3(B * T), dim3(256), 0, stream, (const float*)logits, (long)ld, lse, ext, lens, lpg, T, Smax);
     else
         AVSR_LAUNCH((ctc_gather_kernel<bf16_t>), dim3(B * T), dim3(256), 0, stream, (const bf16_t*)logits, (long)ld, lse, ext, lens, lpg, T, Smax);
-    AVSR_LAUNCH(ctc_alphabeta_kernel, dim3(B, 2), dim3(64), 0, stream, lpg, ext, lens, in_lens, alpha, beta, nll, T, Smax);
+    {
+        const int spl = (Smax + 63) / 64;  // states per lane for the widest row of the batch (Lmax <= 255 -> at most 8)
+#define AVSR_CTC_AB(N) AVSR_LAUNCH(ctc_alphabeta_kernel<N>, dim3(B, 2), dim3(64), 0, stream, lpg, ext, lens, in_lens, alpha, beta, nll, T, Smax)
+        if (spl <= 1) AVSR_CTC_AB(1);
+        else if (spl == 2) AVSR_CTC_AB(2);
+        else if (spl == 3) AVSR_CTC_AB(3);
+        else if (spl == 4) AVSR_CTC_AB(4);
+        else if (spl <= 6) AVSR_CTC_AB(6);
+        else AVSR_CTC_AB(8);
+#undef AVSR_CTC_AB
+    }
     if (grad) {
         const size_t sm = (size_t)V * sizeof(float);
         if (dtype == 0)

@@ -205,6 +205,28 @@ AVSR_DEV float avsr_sigmoid(float x) {
 }
 AVSR_DEV float avsr_silu(float x) { return x * avsr_sigmoid(x); }
 
+// ---------------------------------------------------------------- neighbour exchange across the 64 lanes of a wave
+// lane i <- lane i-1 (up) / lane i+1 (down); the lane that has no such neighbour receives `fill`.  DPP wave shifts
+// (wave_shr:1 / wave_shl:1, verified on gfx950 with tools/probes/dpp_probe.hip) move through the VALU data path in one
+// instruction; __shfl_up / __shfl_down go through ds_bpermute, an LDS-crossbar round trip of ~100 clocks -- on the critical
+// path of every step of a serial recursion (CTC alpha / beta).
+AVSR_DEV float wave_up1(float x, float fill) {
+#ifdef AVSR_EMU
+    const float v = __shfl_up(x, 1);
+    return emu::lane_id() == 0 ? fill : v;
+#else
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), 0x138, 0xf, 0xf, false));
+#endif
+}
+AVSR_DEV float wave_down1(float x, float fill) {
+#ifdef AVSR_EMU
+    const float v = __shfl_down(x, 1);
+    return emu::lane_id() == 63 ? fill : v;
+#else
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), 0x130, 0xf, 0xf, false));
+#endif
+}
+
 // ---------------------------------------------------------------- wave reductions (64 lanes)
 AVSR_DEV float wave_sum(float v) {
 #pragma unroll

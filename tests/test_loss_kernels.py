@@ -14,7 +14,10 @@ def _pad_cols(x, ld):
     return out
 
 
-@pytest.mark.parametrize("B,T,V,L", [(3, 40, 53, 9), (2, 150, 301, 70), (2, 12, 20, 1), (1, 300, 64, 140)])
+# label widths chosen to hit every states-per-lane instantiation of the alpha / beta kernel (S = 2L + 1 over 64 lanes:
+# 1, 2, 3, 4, 6, 8 states per lane)
+@pytest.mark.parametrize("B,T,V,L", [(3, 40, 53, 9), (2, 150, 301, 70), (2, 12, 20, 1), (1, 300, 64, 140),
+                                     (2, 90, 64, 40), (1, 260, 40, 100), (1, 520, 40, 230)])
 def test_ctc(dev, B, T, V, L):
     torch.manual_seed(B * 100 + T)
     logits = torch.randn(B, T, V) * 2
@@ -42,7 +45,7 @@ def test_ctc(dev, B, T, V, L):
     assert (nll - ref_rows).abs().max() < 2e-3 * max(1.0, ref_rows.abs().max().item()), (nll, ref_rows)
     g = grad.cpu()[:, :V].reshape(B, T, V)
     # log-space f32 recursions over T steps: both sides carry ~1e-3 relative noise at T=300, L=140
-    assert (g - lg.grad).abs().max() < (2e-4 if T <= 150 else 2e-3)
+    assert (g - lg.grad).abs().max() < (2e-4 if T <= 150 else (2e-3 if T <= 300 else 5e-3))
 
 
 def test_ce_smooth(dev):

@@ -346,10 +346,10 @@ def test_decoder_shared_memory_projection_equivalence(dev):
             AF.new_step()
             AF.manual_seed(78)
             torch.manual_seed(0)
-            m = E2E(odim, "video", adim=128, aheads=2, eunits=128, elayers=1, dunits=128, dlayers=3, cnn_module_kernel=7)
+            m = E2E(odim, "audio", adim=128, aheads=2, eunits=128, elayers=1, dunits=128, dlayers=3, cnn_module_kernel=7)
             m.load_state_dict(synth_state_dict(m.state_dict(), 6), strict=True)
             m.to(dev).train()
-            x, lengths, y = (t.to(dev) for t in synth_batch("video", 2, 9, 3, odim, seed=5))
+            x, lengths, y = (t.to(dev) for t in synth_batch("audio", 2, 9, 3, odim, seed=5))
             n = [0]
 
             def counting(*a, **kw):
@@ -401,10 +401,10 @@ def test_encoder_shared_position_projection_equivalence(dev):
             AF.new_step()
             AF.manual_seed(79)
             torch.manual_seed(0)
-            m = E2E(odim, "video", adim=128, aheads=2, eunits=128, elayers=3, dunits=128, dlayers=1, cnn_module_kernel=7)
+            m = E2E(odim, "audio", adim=128, aheads=2, eunits=128, elayers=3, dunits=128, dlayers=1, cnn_module_kernel=7)
             m.load_state_dict(synth_state_dict(m.state_dict(), 7), strict=True)
             m.to(dev).train()
-            x, lengths, y = (t.to(dev) for t in synth_batch("video", 2, 9, 3, odim, seed=6))
+            x, lengths, y = (t.to(dev) for t in synth_batch("audio", 2, 9, 3, odim, seed=6))
             AF.prepare_pos_proj = real if shared else (lambda *a, **k: AF._pos_proj.clear())
             try:
                 loss, _, _, _ = m(x, lengths, y)

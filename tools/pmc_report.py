@@ -52,7 +52,8 @@ FAMILIES = [
     ("ResNet conv fwd / dgrad (implicit GEMM)", r"^gemm_fast_kernel<\d+, \d+, \d+, [12],", ("avsr_conv2d_bf16",)),
     ("ResNet 3x3 conv wgrad", r"^(conv3x3_wgrad_kernel|wgrad_reduce_kernel)", ("avsr_conv3x3_wgrad_bf16",)),
     ("BatchNorm passes", r"^bn_", ("avsr_bn_stats", "avsr_bn_stats_finalize", "avsr_bn_act_fwd", "avsr_bn_bwd_reduce", "avsr_bn_bwd_apply",
-                                  "avsr_bn_act_pool_fwd", "avsr_bn_pool_bwd_reduce", "avsr_bn_pool_bwd_apply")),
+                                  "avsr_bn_act_pool_fwd", "avsr_bn_pool_bwd_reduce", "avsr_bn_pool_bwd_apply", "avsr_bn_small_fwd",
+                                  "avsr_bn_small_bwd")),
     ("LayerNorm fwd / bwd", r"^layernorm_", ("avsr_layernorm_fwd", "avsr_layernorm_bwd")),
     ("optimizer (clip + AdamW + bf16 weight copies)", r"^(multi_adamw|multi_sumsq|clip_coef)", ("avsr_adamw_step", "avsr_adamw_cast_step")),
     ("video stem conv fwd / wgrad", r"^stem_", ("avsr_stem357_fwd", "avsr_stem357_wgrad")),
