@@ -167,6 +167,51 @@ AVSR_DEV float group16_sum(float v) {
     return v;
 }
 
+// Register-staged prefetch of the NEXT key tile (bf16, one plane): the K / V / position-band rows of tile kt+1 are fetched
+// into registers while tile kt is being multiplied and stored to LDS at the top of the next iteration -- a block pays the
+// global-memory latency of its operands once, not once per key tile (synchronous staging: load, wait, store, barrier,
+// compute; measured 37 -> 24 us on the T = 400 forward).
+template <bool RELPOS>
+struct TilePrefetch {
+    static constexpr int PB_CH = RELPOS ? (PB_ROWS * 8 + 255) / 256 : 0;  // 16-byte chunks per thread
+    bf16x8 rk[2], rv[2], rp[PB_CH > 0 ? PB_CH : 1];
+    AVSR_DEV void fetch(const bf16_t* kk, long ldk, const bf16_t* vv, long ldv, const bf16_t* pos, long ldp, int j0, int Tk,
+                        int prow0, int plim) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int id = threadIdx.x + 256 * c, r = id >> 3, ch = (id & 7) * 8, gr = j0 + r;
+            rk[c] = rv[c] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (gr < Tk) {
+                rk[c] = *reinterpret_cast<const bf16x8*>(kk + (long)gr * ldk + ch);
+                rv[c] = *reinterpret_cast<const bf16x8*>(vv + (long)gr * ldv + ch);
+            }
+        }
+        if (RELPOS) {
+#pragma unroll
+            for (int c = 0; c < PB_CH; c++) {
+                const int id = threadIdx.x + 256 * c, r = id >> 3, ch = (id & 7) * 8, gr = prow0 + r;
+                rp[c] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (id < PB_ROWS * 8 && gr >= 0 && gr < plim) rp[c] = *reinterpret_cast<const bf16x8*>(pos + (long)gr * ldp + ch);
+            }
+        }
+    }
+    AVSR_DEV void commit(bf16_t* Ks, bf16_t* Vs, bf16_t* Pb) const {
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int id = threadIdx.x + 256 * c, r = id >> 3, ch = (id & 7) * 8;
+            *reinterpret_cast<bf16x8*>(Ks + r * PITCH + ch) = rk[c];
+            *reinterpret_cast<bf16x8*>(Vs + r * PITCH + ch) = rv[c];
+        }
+        if (RELPOS) {
+#pragma unroll
+            for (int c = 0; c < PB_CH; c++) {
+                const int id = threadIdx.x + 256 * c, r = id >> 3, ch = (id & 7) * 8;
+                if (id < PB_ROWS * 8) *reinterpret_cast<bf16x8*>(Pb + r * PITCH + ch) = rp[c];
+            }
+        }
+    }
+};
+
 template <class T, int NS, bool RELPOS, bool BWD>
 struct Attn {
     // LDS carve (bf16 elements unless noted)
@@ -251,13 +296,27 @@ struct Attn {
         const int ntiles = (Tk + KT - 1) / KT;
         const bool wave_active = i0 + 16 * w < Tq;
         const bool row_mask = p.mask && p.mask_sq != 0;  // false: one mask row per batch item (padding mask)
+        // bf16, one plane: next tile prefetched into registers -- except in the relative-position backward kernel, where the
+        // 40 extra VGPRs push the wave past 256 (288) and cost the second resident block per CU (54 -> 62 us measured)
+        constexpr bool PREF = sizeof(T) == 2 && NS == 1 && !(RELPOS && BWD);
+        TilePrefetch<RELPOS> tp;
+        const bf16_t* kk16 = reinterpret_cast<const bf16_t*>(kk);
+        const bf16_t* vv16 = reinterpret_cast<const bf16_t*>(vv);
+        const bf16_t* pos16 = reinterpret_cast<const bf16_t*>(pos);
+        if (PREF) tp.fetch(kk16, p.ldk, vv16, p.ldv, pos16, p.ldp, 0, Tk, -i0 + Tq - 1 - 63, 2 * Tq - 1);
         for (int kt = 0; kt < ntiles; kt++) {
             const int j0 = kt * KT;
             __syncthreads();
-            stage_rows<T, NS, KT>(Ks, kk, p.ldk, j0, Tk);
-            stage_rows<T, NS, KT>(Vs, vv, p.ldv, j0, Tk);
-            if (RELPOS) stage_rows<T, NS, PB_ROWS>(Pb, pos, p.ldp, j0 - i0 + Tq - 1 - 63, 2 * Tq - 1);
+            if (PREF) {
+                tp.commit(Ks, Vs, Pb);
+            } else {
+                stage_rows<T, NS, KT>(Ks, kk, p.ldk, j0, Tk);
+                stage_rows<T, NS, KT>(Vs, vv, p.ldv, j0, Tk);
+                if (RELPOS) stage_rows<T, NS, PB_ROWS>(Pb, pos, p.ldp, j0 - i0 + Tq - 1 - 63, 2 * Tq - 1);
+            }
             __syncthreads();
+            if (PREF && kt + 1 < ntiles)
+                tp.fetch(kk16, p.ldk, vv16, p.ldv, pos16, p.ldp, j0 + KT, Tk, j0 + KT - i0 + Tq - 1 - 63, 2 * Tq - 1);
             if (!wave_active) continue;  // wave-uniform: this wave's 16 query rows are all past Tq
 
             // ---- scores: (q+u).k
@@ -512,6 +571,207 @@ struct Attn {
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Forward pass, bf16, TRANSPOSED formulation: the score tile is computed as S^T = K Q^T (keys along the MFMA M
+// dimension, the wave's 16 query rows along N), so that a lane ends up with 16 scores OF ONE query row (lane & 15) -- keys
+// 16j + 4*quad + r -- and
+//   * the probabilities are already laid out as the B operand of O^T = V^T P^T (8 keys per lane and k-step, with the key
+//     order of the contraction permuted consistently on the V^T side): P never travels through LDS (the generic kernel
+//     converts, stores 2 bytes per element, synchronises and reads it back as an A operand);
+//   * the row statistics live in ONE register each per lane (not four), the running sum stays a per-lane partial until
+//     the end, and the per-tile maximum needs two cross-quad exchanges instead of 4 x 4 within-row shuffle steps;
+//   * scale * log2(e) is folded into the score scale (v_exp_f32 is an exp2), the key-padding mask is an additive bias
+//     staged once per key tile, the relative-position band product leaves as 16-byte LDS stores, and the output row
+//     pieces leave as 8-byte stores.
+// The key-tile iteration of the generic kernel is ~1400 VALU/LDS instructions per wave against 26 MFMAs (416 clocks) --
+// at two waves per SIMD the kernel time IS that instruction count.  Same grid, same staging, same
+// arithmetic (online softmax in f32, dropout keep mask by (row, key) index), so the backward kernel pairs with it unchanged.
+template <bool RELPOS>
+struct AttnFwdT {
+    static constexpr int KS_E = KT * PITCH, VS_E = KT * PITCH, PB_E = RELPOS ? PB_ROWS * PITCH : 0;
+    static constexpr int G_F = RELPOS ? 4 * 16 * G_PITCH : 0;  // f32, per wave [16 q][G_PITCH]
+    static constexpr size_t LDS_BYTES = (size_t)(KS_E + VS_E + PB_E) * 2 + (size_t)(G_F + KT) * 4;
+
+    static AVSR_DEV void run(const AttnParams& p, char* smem) {
+        bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
+        bf16_t* Vs = Ks + KS_E;
+        bf16_t* Pb = Vs + VS_E;
+        float* Gs = reinterpret_cast<float*>(Pb + PB_E);
+        float* bias = Gs + G_F;  // [KT] additive key mask of the staged tile (0 / NEG_BIG)
+
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const int quad = lane >> 4, lc = lane & 15;
+        const int i0 = blockIdx.x * QT, h = blockIdx.y, b = blockIdx.z;
+        const int Tq = p.Tq, Tk = p.Tk;
+        const bf16_t* qu = reinterpret_cast<const bf16_t*>(p.qu) + b * p.sbq + h * DK;
+        const bf16_t* qv = RELPOS ? reinterpret_cast<const bf16_t*>(p.qv) + b * p.sbq + h * DK : nullptr;
+        const bf16_t* kk = reinterpret_cast<const bf16_t*>(p.k) + b * p.sbk + h * DK;
+        const bf16_t* vv = reinterpret_cast<const bf16_t*>(p.v) + b * p.sbv + h * DK;
+        const bf16_t* pos = RELPOS ? reinterpret_cast<const bf16_t*>(p.pos) + h * DK : nullptr;
+        const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+        const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
+        const float scale2 = p.scale * 1.4426950408889634f;  // scores in log2 units
+
+        // this lane's query row and its Q fragments (B operand: n = lc, k chunk = quad)
+        const int qrow = i0 + 16 * w + lc;
+        const bool q_ok = qrow < Tq;
+        bf16x8 fq_u[2], fq_v[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            fq_u[ks] = fq_v[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (q_ok) {
+                fq_u[ks] = *reinterpret_cast<const bf16x8*>(qu + (long)qrow * p.ldq + ks * 32 + 8 * quad);
+                if (RELPOS) fq_v[ks] = *reinterpret_cast<const bf16x8*>(qv + (long)qrow * p.ldq + ks * 32 + 8 * quad);
+            }
+        }
+        float m_run = NEG_BIG, l_part = 0.f;
+        f32x4 acc[4];  // O^T[d = 16n + 4*quad + r][q = lc]
+#pragma unroll
+        for (int n = 0; n < 4; n++) acc[n] = f32x4{0, 0, 0, 0};
+
+        const int ntiles = (Tk + KT - 1) / KT;
+        const bool wave_active = i0 + 16 * w < Tq;
+        const bool row_mask = p.mask && p.mask_sq != 0;  // false: one mask row per batch item (key-padding mask)
+        const long mrow = row_mask ? (long)b * p.mask_sb + (long)(q_ok ? qrow : 0) * p.mask_sq : 0;
+        const uint64_t drop_row = (((uint64_t)b * p.H + h) * Tq + (q_ok ? qrow : 0)) * (uint64_t)Tk;
+        TilePrefetch<RELPOS> tp;  // next tile's K / V / band rows in registers while this one is multiplied
+        float rbias = 0.f;
+        auto fetch_bias = [&](int j0) {
+            if (threadIdx.x < KT) {
+                const int jg = j0 + threadIdx.x;
+                bool ok = jg < Tk;
+                if (ok && p.mask && !row_mask) ok = p.mask[(long)b * p.mask_sb + jg] != 0;
+                rbias = ok ? 0.f : NEG_BIG;
+            }
+        };
+        tp.fetch(kk, p.ldk, vv, p.ldv, pos, p.ldp, 0, Tk, -i0 + Tq - 1 - 63, 2 * Tq - 1);
+        fetch_bias(0);
+        for (int kt = 0; kt < ntiles; kt++) {
+            const int j0 = kt * KT;
+            __syncthreads();  // every wave is done reading the previous tile
+            tp.commit(Ks, Vs, Pb);
+            if (threadIdx.x < KT) bias[threadIdx.x] = rbias;
+            __syncthreads();
+            if (kt + 1 < ntiles) {
+                tp.fetch(kk, p.ldk, vv, p.ldv, pos, p.ldp, j0 + KT, Tk, j0 + KT - i0 + Tq - 1 - 63, 2 * Tq - 1);
+                fetch_bias(j0 + KT);
+            }
+            if (!wave_active) continue;  // wave-uniform: this wave's 16 query rows are all past Tq
+
+            // ---- S^T tiles: st[j][r] = score(key 16j + 4quad + r, query lc)
+            f32x4 st[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                st[j] = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++)
+                    st[j] = mfma16(ldfrag<1>(Ks, KT * PITCH, PITCH, j * 16 + lc, ks * 32 + 8 * quad).p[0], fq_u[ks], st[j]);
+            }
+            if (RELPOS) {
+                // G^T = Pband (q+v)^T: lane holds G[q = lc][band 16t + 4quad .. +3] -> one 16-byte store per band tile
+                const int sb = 48 - 16 * w;
+                float* Gw = Gs + w * 16 * G_PITCH;
+#pragma unroll
+                for (int t = 0; t < 5; t++) {
+                    f32x4 g = f32x4{0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++)
+                        g = mfma16(ldfrag<1>(Pb, PB_ROWS * PITCH, PITCH, sb + t * 16 + lc, ks * 32 + 8 * quad).p[0], fq_v[ks], g);
+                    *reinterpret_cast<f32x4*>(Gw + lc * G_PITCH + t * 16 + 4 * quad) = g;
+                }
+                wave_sync();
+                // bd[q, key] = G[q, key - q + 15] (rel_shift as an index map, inside this wave's 16 x 80 band window)
+                const float* grow = Gw + lc * G_PITCH - lc + 15 + 4 * quad;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) st[j][r] += grow[j * 16 + r];
+            }
+            // ---- scale (log2 units) + mask, tile maximum of this query row
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const f32x4 bj = *reinterpret_cast<const f32x4*>(bias + j * 16 + 4 * quad);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float sv = st[j][r] * scale2 + bj[r];
+                    if (row_mask) {
+                        const int jg = j0 + j * 16 + 4 * quad + r;
+                        if (jg < Tk && p.mask[mrow + jg] == 0) sv = NEG_BIG;
+                    }
+                    sv = fmaxf(sv, NEG_BIG);
+                    st[j][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float m_safe = m_new <= 0.5f * NEG_BIG ? 0.f : m_new;  // nothing attended yet: exp2(NEG_BIG - 0) = 0
+            const float corr = exp2f(m_run - m_safe);                    // (0 when m_run is still NEG_BIG)
+            float rs = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    st[j][r] = exp2f(st[j][r] - m_safe);
+                    rs += st[j][r];
+                }
+            l_part = l_part * corr + rs;
+            m_run = m_new;
+#pragma unroll
+            for (int n = 0; n < 4; n++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[n][r] *= corr;
+            if (p.drop_p > 0.f) {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        st[j][r] *= dropout_scale(seed, drop_row + (uint64_t)(j0 + j * 16 + 4 * quad + r), p.drop_p, inv_keep);
+            }
+            // ---- O^T += V^T P^T.  k-step ks contracts the 32 keys of score tiles 2ks and 2ks+1; inside it the lane's 8 keys
+            // are {16(2ks) + 4quad + r} and {16(2ks+1) + 4quad + r}, and the V^T fragment is fetched in the same order
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                bf16x8 pb;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    pb[r] = (short)f2bf(st[2 * ks][r]);
+                    pb[4 + r] = (short)f2bf(st[2 * ks + 1][r]);
+                }
+#pragma unroll
+                for (int n = 0; n < 4; n++) {
+                    const bf16_t* p0 = Vs + (ks * 32 + 4 * quad + (lc >> 2)) * PITCH + n * 16 + 4 * (lc & 3);
+                    const bf16x4 lo = lds_tr16(p0), hi = lds_tr16(p0 + 16 * PITCH);
+                    acc[n] = mfma16(bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, pb, acc[n]);
+                }
+            }
+        }
+        // ---- epilogue: full row sum, normalise, 8-byte row pieces
+        float l = l_part;
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        if (!q_ok) return;
+        const float inv = l > 0.f ? 1.f / l : 0.f;
+        bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + b * p.sbo + (long)qrow * p.ldo + h * DK;
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            bf16x4 v4;
+#pragma unroll
+            for (int r = 0; r < 4; r++) v4[r] = (short)f2bf(acc[n][r] * inv);
+            *reinterpret_cast<bf16x4*>(o + n * 16 + 4 * quad) = v4;
+        }
+        if (quad == 0) p.lse[((long)b * p.H + h) * Tq + qrow] = l > 0.f ? (m_run + log2f(l)) * 0.6931471805599453f : 0.f;
+    }
+};
+
+template <bool RELPOS>
+__global__ __launch_bounds__(256) void attn_fwd_t_kernel(AttnParams p) {
+    AVSR_DYN_SMEM(smem);
+    AttnFwdT<RELPOS>::run(p, smem);
+}
+
 template <class T, int NS, bool RELPOS, bool BWD>
 __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     AVSR_DYN_SMEM(smem);
@@ -527,7 +787,11 @@ int launch_attn(const AttnParams& p, int dtype, int precise, bool relpos, hipStr
         if (dtype != 0) return -1;
         if (relpos) AVSR_ATTN_GO(float, 2, true); else AVSR_ATTN_GO(float, 2, false);
     } else if (dtype == 1) {
-        if (relpos) AVSR_ATTN_GO(bf16_t, 1, true); else AVSR_ATTN_GO(bf16_t, 1, false);
+        if (!BWD && avsr_tune_knobs[8] != 1) {  // knob 8 = 1: the generic kernel (A/B runs)
+            if (relpos) AVSR_LAUNCH((attn_fwd_t_kernel<true>), grid, block, (AttnFwdT<true>::LDS_BYTES), stream, p);
+            else AVSR_LAUNCH((attn_fwd_t_kernel<false>), grid, block, (AttnFwdT<false>::LDS_BYTES), stream, p);
+        } else if (relpos) AVSR_ATTN_GO(bf16_t, 1, true);
+        else AVSR_ATTN_GO(bf16_t, 1, false);
     } else {
         if (relpos) AVSR_ATTN_GO(float, 1, true); else AVSR_ATTN_GO(float, 1, false);
     }

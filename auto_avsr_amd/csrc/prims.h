@@ -362,7 +362,7 @@ AVSR_DEV float dropout_scale(uint64_t seed, uint64_t idx, float p, float inv_kee
 }
 
 // ---------------------------------------------------------------- status plumbing
-extern int avsr_tune_knobs[8];  // common.hip (avsr_tune)
+extern int avsr_tune_knobs[16];  // common.hip (avsr_tune)
 extern "C" void avsr_set_error(const char* msg);
 extern "C" void avsr_set_error2(const char* where, const char* what);
 #define AVSR_CHECK_LAUNCH(name)                                                   \

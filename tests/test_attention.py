@@ -50,6 +50,11 @@ CASES = [
     (2, 17, 40, 2, False, "allmasked", torch.float32, True, 1e-4, 3e-4),
     (2, 70, 70, 2, True, "pad", torch.bfloat16, False, 3e-2, 0.3),
     (1, 64, 64, 1, True, None, torch.float32, False, 5e-2, 0.3),
+    # bf16 forward = the transposed-formulation kernel (attention.hip AttnFwdT): every mask kind, ragged tiles, Tq != Tk
+    (1, 130, 130, 1, True, None, torch.bfloat16, False, 3e-2, 0.3),
+    (2, 33, 33, 2, False, "causal", torch.bfloat16, False, 3e-2, 0.3),
+    (2, 17, 100, 2, False, "pad", torch.bfloat16, False, 3e-2, 0.3),
+    (2, 17, 40, 2, False, "allmasked", torch.bfloat16, False, 3e-2, 0.3),
 ]
 
 
@@ -159,6 +164,38 @@ def test_attention_bwd_emits_query_and_bias_gradients(dev, dtype, precise, T):
                                                 precise=precise)
     assert torch.equal(pd[..., :T], pd2[..., :T]) and torch.equal(ds[..., :T], ds2[..., :T])  # (pad columns are never read)
     assert rel(dqkv[:, :, 0].float(), (dqu2.float() + dqv2.float()).cpu().double()) < (1e-6 if precise else 8e-3)
+
+
+@pytest.mark.parametrize("relpos", [False, True])
+def test_attention_bf16_forward_kernels_agree(dev, relpos):
+    """The bf16 forward has two kernels (transposed formulation = default; generic = avsr_tune knob 8): same output to bf16
+    rounding, same log-sum-exp, and -- with dropout on -- the SAME keep mask (the backward kernel recomputes it from the
+    (row, key) index, so both forward kernels must draw it identically): compared through the dropped positions of a
+    V = identity probe."""
+    torch.manual_seed(11)
+    B, T, H, D = 2, 100, 2, 64
+    qu, qv, k = (torch.randn(B, T, H, D).bfloat16() for _ in range(3))
+    v = torch.randn(B, T, H, D).bfloat16()
+    pos = torch.randn(2 * T - 1, H * D).bfloat16() if relpos else None
+    mask = make_mask("pad", B, T, T)
+    d = lambda t: None if t is None else t.to(dev)
+    res = []
+    try:
+        for knob in (0, 1):
+            ops.tune(8, knob)
+            o, l = ops.attention_fwd(d(qu), d(qv) if relpos else None, d(k), d(v), d(pos), d(mask), 0.125)
+            vI = torch.zeros(B, T, H, D)
+            vI[:, :64, :, :] = torch.eye(64).view(1, 64, 1, 64)
+            od, _ = ops.attention_fwd(d(qu), d(qv) if relpos else None, d(k), d(vI.bfloat16()), d(pos), d(mask), 0.125,
+                                      drop_p=0.25, seed=99)
+            res.append((o.float().cpu(), l.cpu(), od.float().cpu()))
+    finally:
+        ops.tune(8, 0)
+    (o0, l0, d0), (o1, l1, d1) = res
+    assert (o0 - o1).abs().max() < 2e-2 * max(1.0, float(o1.abs().max()))
+    assert (l0 - l1).abs().max() < 1e-3
+    assert torch.equal(d0 == 0, d1 == 0), "the two forward kernels drew different dropout masks"
+    assert 0.15 < float((d0 == 0).float().mean()) < 0.6
 
 
 def test_attention_dropout_consistency(dev):
