@@ -772,6 +772,248 @@ __global__ __launch_bounds__(256) void attn_fwd_t_kernel(AttnParams p) {
     AttnFwdT<RELPOS>::run(p, smem);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward "dq" pass, bf16, in the same transposed formulation (see AttnFwdT): S^T = K Q^T and dP^T = V dO^T put 16 keys of
+// ONE query row into each lane, so P, dP and dS are elementwise register work, dS is already the B operand of
+// dQu^T += K^T dS^T (key order of the contraction permuted consistently on the K^T side), delta / lse are one register
+// each, pd = dropout(P) and ds = scale * dS leave as 8-byte row pieces straight from registers, and -- with 40 VGPRs less
+// than the generic kernel -- the next key tile fits into registers as a prefetch.  Only the position term still crosses
+// LDS: dQv += skew(dS) Pband needs dS re-indexed by (key - query), a lane-dependent shift.
+template <bool RELPOS>
+struct AttnBwdT {
+    static constexpr int KS_E = KT * PITCH, VS_E = KT * PITCH, PB_E = RELPOS ? PB_ROWS * PITCH : 0;
+    static constexpr int G_F = RELPOS ? 4 * 16 * G_PITCH : 0;  // f32 per wave [16 q][G_PITCH]; re-used as the bf16 dS skew scratch
+    static constexpr size_t LDS_BYTES = (size_t)(KS_E + VS_E + PB_E) * 2 + (size_t)(G_F + KT) * 4 + 4 * 2 * 64 * 4;
+    static_assert(16 * DG_PITCH * 2 <= 16 * G_PITCH * 4, "dS skew scratch must fit the G scratch");
+
+    static AVSR_DEV void run(const AttnParams& p, char* smem) {
+        bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
+        bf16_t* Vs = Ks + KS_E;
+        bf16_t* Pb = Vs + VS_E;
+        float* Gs = reinterpret_cast<float*>(Pb + PB_E);
+        float* bias = Gs + G_F;  // [KT]
+        float* red = bias + KT;  // [4 waves][2][64] (epilogue)
+
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const int quad = lane >> 4, lc = lane & 15;
+        const int i0 = blockIdx.x * QT, h = blockIdx.y, b = blockIdx.z;
+        const int Tq = p.Tq, Tk = p.Tk;
+        const bf16_t* qu = reinterpret_cast<const bf16_t*>(p.qu) + b * p.sbq + h * DK;
+        const bf16_t* qv = RELPOS ? reinterpret_cast<const bf16_t*>(p.qv) + b * p.sbq + h * DK : nullptr;
+        const bf16_t* kk = reinterpret_cast<const bf16_t*>(p.k) + b * p.sbk + h * DK;
+        const bf16_t* vv = reinterpret_cast<const bf16_t*>(p.v) + b * p.sbv + h * DK;
+        const bf16_t* pos = RELPOS ? reinterpret_cast<const bf16_t*>(p.pos) + h * DK : nullptr;
+        const bf16_t* dout = reinterpret_cast<const bf16_t*>(p.dout) + b * p.sbo + h * DK;
+        const bf16_t* outp = reinterpret_cast<const bf16_t*>(p.out) + b * p.sbo + h * DK;
+        const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+        const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
+        constexpr float LOG2E = 1.4426950408889634f;
+        const float scale2 = p.scale * LOG2E;
+
+        const int qrow = i0 + 16 * w + lc;
+        const bool q_ok = qrow < Tq;
+        bf16x8 fq_u[2], fq_v[2], fdo[2];
+        float delta = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            fq_u[ks] = fq_v[ks] = fdo[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (q_ok) {
+                const int d0 = ks * 32 + 8 * quad;
+                fq_u[ks] = *reinterpret_cast<const bf16x8*>(qu + (long)qrow * p.ldq + d0);
+                if (RELPOS) fq_v[ks] = *reinterpret_cast<const bf16x8*>(qv + (long)qrow * p.ldq + d0);
+                fdo[ks] = *reinterpret_cast<const bf16x8*>(dout + (long)qrow * p.ldo + d0);
+                const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(outp + (long)qrow * p.ldo + d0);
+#pragma unroll
+                for (int e = 0; e < 8; e++) delta += bf2f((bf16_t)fdo[ks][e]) * bf2f((bf16_t)o8[e]);
+            }
+        }
+        delta += __shfl_xor(delta, 16);
+        delta += __shfl_xor(delta, 32);  // delta(query lc) in all four quads
+        const float lse2 = q_ok ? p.lse[((long)b * p.H + h) * Tq + qrow] * LOG2E : 0.f;
+        f32x4 acc_u[4], acc_v[4];  // dQu^T / dQv^T [d = 16n + 4*quad + r][q = lc]
+#pragma unroll
+        for (int n = 0; n < 4; n++) acc_u[n] = acc_v[n] = f32x4{0, 0, 0, 0};
+
+        const int ntiles = (Tk + KT - 1) / KT;
+        const bool wave_active = i0 + 16 * w < Tq;
+        const bool row_mask = p.mask && p.mask_sq != 0;
+        const long mrow = row_mask ? (long)b * p.mask_sb + (long)(q_ok ? qrow : 0) * p.mask_sq : 0;
+        const uint64_t drop_row = (((uint64_t)b * p.H + h) * Tq + (q_ok ? qrow : 0)) * (uint64_t)Tk;
+        bf16_t* pd_g = reinterpret_cast<bf16_t*>(p.pd) + (((long)b * p.H + h) * Tq + (q_ok ? qrow : 0)) * p.lds;
+        bf16_t* ds_g = reinterpret_cast<bf16_t*>(p.ds) + (((long)b * p.H + h) * Tq + (q_ok ? qrow : 0)) * p.lds;
+
+        TilePrefetch<RELPOS> tp;
+        float rbias = 0.f;
+        auto fetch_bias = [&](int j0) {
+            if (threadIdx.x < KT) {
+                const int jg = j0 + threadIdx.x;
+                bool ok = jg < Tk;
+                if (ok && p.mask && !row_mask) ok = p.mask[(long)b * p.mask_sb + jg] != 0;
+                rbias = ok ? 0.f : NEG_BIG;
+            }
+        };
+        tp.fetch(kk, p.ldk, vv, p.ldv, pos, p.ldp, 0, Tk, -i0 + Tq - 1 - 63, 2 * Tq - 1);
+        fetch_bias(0);
+        for (int kt = 0; kt < ntiles; kt++) {
+            const int j0 = kt * KT;
+            __syncthreads();
+            tp.commit(Ks, Vs, Pb);
+            if (threadIdx.x < KT) bias[threadIdx.x] = rbias;
+            __syncthreads();
+            if (kt + 1 < ntiles) {
+                tp.fetch(kk, p.ldk, vv, p.ldv, pos, p.ldp, j0 + KT, Tk, j0 + KT - i0 + Tq - 1 - 63, 2 * Tq - 1);
+                fetch_bias(j0 + KT);
+            }
+            if (!wave_active) continue;
+
+            // ---- S^T and dP^T tiles: [key 16j + 4quad + r][query lc]
+            f32x4 st[4], dp[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                st[j] = dp[j] = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) {
+                    st[j] = mfma16(ldfrag<1>(Ks, KT * PITCH, PITCH, j * 16 + lc, ks * 32 + 8 * quad).p[0], fq_u[ks], st[j]);
+                    dp[j] = mfma16(ldfrag<1>(Vs, KT * PITCH, PITCH, j * 16 + lc, ks * 32 + 8 * quad).p[0], fdo[ks], dp[j]);
+                }
+            }
+            const int sb = 48 - 16 * w;
+            float* Gw = Gs + w * 16 * G_PITCH;
+            if (RELPOS) {
+#pragma unroll
+                for (int t = 0; t < 5; t++) {
+                    f32x4 g = f32x4{0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++)
+                        g = mfma16(ldfrag<1>(Pb, PB_ROWS * PITCH, PITCH, sb + t * 16 + lc, ks * 32 + 8 * quad).p[0], fq_v[ks], g);
+                    *reinterpret_cast<f32x4*>(Gw + lc * G_PITCH + t * 16 + 4 * quad) = g;
+                }
+                wave_sync();
+                const float* grow = Gw + lc * G_PITCH - lc + 15 + 4 * quad;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) st[j][r] += grow[j * 16 + r];
+                wave_sync();  // the G scratch is consumed: it becomes the dS skew scratch below
+            }
+            // ---- P = exp(S - lse), dS = P (keep dP - delta) scale; pd / ds row pieces to HBM
+            bf16x8 dsb[2];
+            bf16_t* DGw = reinterpret_cast<bf16_t*>(Gw);
+            if (RELPOS) {  // zero the skew scratch (16 x DG_PITCH bf16 per wave)
+                for (int id = lane; id < 16 * DG_PITCH / 8; id += 64)
+                    *reinterpret_cast<bf16x8*>(DGw + id * 8) = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                wave_sync();
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const f32x4 bj = *reinterpret_cast<const f32x4*>(bias + j * 16 + 4 * quad);
+                bf16x4 pd4, ds4;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int jg = j0 + j * 16 + 4 * quad + r;
+                    float sv = st[j][r] * scale2 + bj[r];
+                    if (row_mask && jg < Tk && p.mask[mrow + jg] == 0) sv = NEG_BIG;
+                    const float pr = sv > 0.5f * NEG_BIG ? exp2f(sv - lse2) : 0.f;
+                    const float keep = dropout_scale(seed, drop_row + (uint64_t)jg, p.drop_p, inv_keep);
+                    const float dsv = pr * (keep * dp[j][r] - delta) * p.scale;
+                    pd4[r] = (short)f2bf(pr * keep);
+                    ds4[r] = (short)f2bf(dsv);
+                    if (RELPOS) DGw[lc * DG_PITCH + j * 16 + 4 * quad + r - lc + 15] = (bf16_t)ds4[r];
+                }
+                const int jg0 = j0 + j * 16 + 4 * quad;
+                if (q_ok && jg0 < p.lds) {
+                    *reinterpret_cast<bf16x4*>(pd_g + jg0) = pd4;
+                    *reinterpret_cast<bf16x4*>(ds_g + jg0) = ds4;
+                }
+                // B operand of the key contraction: k-step j/2 takes tiles 2ks and 2ks+1
+#pragma unroll
+                for (int r = 0; r < 4; r++) dsb[j >> 1][(j & 1) * 4 + r] = ds4[r];
+            }
+            // ---- dQu^T += K^T dS^T (K^T fragments: transposed reads in the permuted key order)
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                for (int n = 0; n < 4; n++) {
+                    const bf16_t* p0 = Ks + (ks * 32 + 4 * quad + (lc >> 2)) * PITCH + n * 16 + 4 * (lc & 3);
+                    const bf16x4 lo = lds_tr16(p0), hi = lds_tr16(p0 + 16 * PITCH);
+                    acc_u[n] = mfma16(bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, dsb[ks], acc_u[n]);
+                }
+            if (RELPOS) {  // dQv^T += Pband^T dG^T, dG[q][band] = dS[q][key = band + q - 15] read back as the B operand
+                wave_sync();
+#pragma unroll
+                for (int ks = 0; ks < 3; ks++) {
+                    const bf16x8 dgb = *reinterpret_cast<const bf16x8*>(DGw + lc * DG_PITCH + ks * 32 + 8 * quad);
+#pragma unroll
+                    for (int n = 0; n < 4; n++)
+                        acc_v[n] = mfma16(ldfrag_tr<1>(Pb, PB_ROWS * PITCH, PITCH, sb + ks * 32, n * 16).p[0], dgb, acc_v[n]);
+                }
+            }
+        }
+
+        // ---- epilogue: dQ row pieces (8 bytes), optionally summed, + the position-bias gradients
+        const bool sum_out = RELPOS && p.dq_sum;
+        if (q_ok) {
+            if (sum_out) {
+                bf16_t* dq = reinterpret_cast<bf16_t*>(p.dq_sum) + b * p.sbdq + (long)qrow * p.lddq + h * DK;
+#pragma unroll
+                for (int n = 0; n < 4; n++) {
+                    bf16x4 v4;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) v4[r] = (short)f2bf(acc_u[n][r] + acc_v[n][r]);
+                    *reinterpret_cast<bf16x4*>(dq + n * 16 + 4 * quad) = v4;
+                }
+            } else {
+                bf16_t* dqu = reinterpret_cast<bf16_t*>(p.dqu) + b * p.sbq + (long)qrow * p.ldq + h * DK;
+                bf16_t* dqv = RELPOS ? reinterpret_cast<bf16_t*>(p.dqv) + b * p.sbq + (long)qrow * p.ldq + h * DK : nullptr;
+#pragma unroll
+                for (int n = 0; n < 4; n++) {
+                    bf16x4 a4, b4;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        a4[r] = (short)f2bf(acc_u[n][r]);
+                        b4[r] = (short)f2bf(acc_v[n][r]);
+                    }
+                    *reinterpret_cast<bf16x4*>(dqu + n * 16 + 4 * quad) = a4;
+                    if (RELPOS) *reinterpret_cast<bf16x4*>(dqv + n * 16 + 4 * quad) = b4;
+                }
+            }
+        }
+        if (sum_out) {
+            // du / dv: column sums over this block's queries.  Lane (quad, lc) holds d = 16n + 4quad + r of query lc: sum the 16
+            // lanes of a quad (rows past Tq hold exact zeros), then the four waves through LDS, one atomic per column
+            __syncthreads();
+#pragma unroll
+            for (int n = 0; n < 4; n++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float su = acc_u[n][r], sv = acc_v[n][r];
+#pragma unroll
+                    for (int m = 8; m >= 1; m >>= 1) {
+                        su += __shfl_xor(su, m);
+                        sv += __shfl_xor(sv, m);
+                    }
+                    if (lc == 0) {
+                        red[(w * 2 + 0) * 64 + n * 16 + 4 * quad + r] = su;
+                        red[(w * 2 + 1) * 64 + n * 16 + 4 * quad + r] = sv;
+                    }
+                }
+            __syncthreads();
+            if (threadIdx.x < 128) {
+                const int which = threadIdx.x >> 6, d = threadIdx.x & 63;
+                const float t = (red[(0 * 2 + which) * 64 + d] + red[(1 * 2 + which) * 64 + d]) +
+                                (red[(2 * 2 + which) * 64 + d] + red[(3 * 2 + which) * 64 + d]);
+                atomicAdd((which ? p.dv : p.du) + h * DK + d, t);
+            }
+        }
+    }
+};
+
+template <bool RELPOS>
+__global__ __launch_bounds__(256) void attn_bwd_t_kernel(AttnParams p) {
+    AVSR_DYN_SMEM(smem);
+    AttnBwdT<RELPOS>::run(p, smem);
+}
+
 template <class T, int NS, bool RELPOS, bool BWD>
 __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     AVSR_DYN_SMEM(smem);
@@ -790,6 +1032,9 @@ int launch_attn(const AttnParams& p, int dtype, int precise, bool relpos, hipStr
         if (!BWD && avsr_tune_knobs[8] != 1) {  // knob 8 = 1: the generic kernel (A/B runs)
             if (relpos) AVSR_LAUNCH((attn_fwd_t_kernel<true>), grid, block, (AttnFwdT<true>::LDS_BYTES), stream, p);
             else AVSR_LAUNCH((attn_fwd_t_kernel<false>), grid, block, (AttnFwdT<false>::LDS_BYTES), stream, p);
+        } else if (BWD && avsr_tune_knobs[9] != 1) {  // knob 9 = 1: the generic backward kernel
+            if (relpos) AVSR_LAUNCH((attn_bwd_t_kernel<true>), grid, block, (AttnBwdT<true>::LDS_BYTES), stream, p);
+            else AVSR_LAUNCH((attn_bwd_t_kernel<false>), grid, block, (AttnBwdT<false>::LDS_BYTES), stream, p);
         } else if (relpos) AVSR_ATTN_GO(bf16_t, 1, true);
         else AVSR_ATTN_GO(bf16_t, 1, false);
     } else {

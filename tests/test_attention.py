@@ -198,6 +198,49 @@ def test_attention_bf16_forward_kernels_agree(dev, relpos):
     assert 0.15 < float((d0 == 0).float().mean()) < 0.6
 
 
+@pytest.mark.parametrize("relpos,mkind,T,Tk", [(True, "pad", 100, 100), (False, "causal", 70, 70), (False, "pad", 33, 130),
+                                                (True, None, 64, 64)])
+def test_attention_bf16_backward_kernels_agree(dev, relpos, mkind, T, Tk):
+    """The bf16 backward-dq pass has two kernels (transposed formulation = default; generic = avsr_tune knob 9): same dqu /
+    dqv, same pd = dropout(P) and ds = scale * dS (what the key / value side contracts), same fused dq_sum / du / dv, with
+    dropout on (identical keep mask) -- every mask kind, ragged tiles, Tq != Tk."""
+    torch.manual_seed(T + Tk)
+    B, H, D = 2, 2, 64
+    qu, qv = torch.randn(B, T, H, D).bfloat16(), torch.randn(B, T, H, D).bfloat16()
+    k, v = torch.randn(B, Tk, H, D).bfloat16(), torch.randn(B, Tk, H, D).bfloat16()
+    pos = torch.randn(2 * T - 1, H * D).bfloat16() if relpos else None
+    mask = make_mask(mkind, B, T, Tk)
+    dout = torch.randn(B, T, H * D).bfloat16()
+    d = lambda t: None if t is None else t.to(dev)
+    out, lse = ops.attention_fwd(d(qu), d(qv) if relpos else None, d(k), d(v), d(pos), d(mask), 0.125, drop_p=0.2, seed=5)
+    res = []
+    try:
+        for knob in (0, 1):
+            ops.tune(9, knob)
+            dqu, dqv, pd, ds = ops.attention_bwd_dq(d(qu), d(qv) if relpos else None, d(k), d(v), d(pos), d(mask), out, lse,
+                                                    d(dout), 0.125, drop_p=0.2, seed=5)
+            extra = None
+            if relpos:
+                dq = torch.zeros(B, T, H, D, dtype=torch.bfloat16, device=dev)
+                du, dv = torch.zeros(H * D, device=dev), torch.zeros(H * D, device=dev)
+                ops.attention_bwd_dq(d(qu), d(qv), d(k), d(v), d(pos), d(mask), out, lse, d(dout), 0.125, drop_p=0.2, seed=5,
+                                     dq_sum=dq, du=du, dv=dv)
+                extra = (dq.float().cpu(), du.cpu(), dv.cpu())
+            res.append((dqu.float().cpu(), None if dqv is None else dqv.float().cpu(), pd[..., :Tk].float().cpu(),
+                        ds[..., :Tk].float().cpu(), extra))
+    finally:
+        ops.tune(9, 0)
+    a, g = res
+    rel = lambda x, y: float((x - y).norm() / (y.norm() + 1e-30))
+    assert torch.equal(a[2] == 0, g[2] == 0), "different dropout / mask pattern in pd"
+    assert rel(a[2], g[2]) < 4e-3 and rel(a[3], g[3]) < 8e-3, (rel(a[2], g[2]), rel(a[3], g[3]))
+    assert rel(a[0], g[0]) < 8e-3, rel(a[0], g[0])
+    if relpos:
+        assert rel(a[1], g[1]) < 8e-3, rel(a[1], g[1])
+        for x, y in zip(a[4], g[4]):
+            assert rel(x, y) < 8e-3, rel(x, y)
+
+
 def test_attention_dropout_consistency(dev):
     """Dropout on the probabilities: forward and backward must draw the same keep-mask (finite-difference free
     check: with V = I-like probes the output equals the dropped probabilities that the backward re-creates)."""
