@@ -15,6 +15,11 @@ int run_nt(const Params&, int, int, int, int, int, hipStream_t);
 int run_nn(const Params&, int, int, int, int, int, hipStream_t);
 int run_tn(const Params&, int, int, int, int, int, hipStream_t);
 int run_tn_multi(const Params*, int, int, int, int, hipStream_t);
+}
+int avsr_attention_bwd_kv_fast(const void* pd, const void* ds, int lds, const void* dout, int ldo, int64_t sbo, const void* qu,
+                               const void* qv, int ldq, int64_t sbq, void* dk, int ldk, int64_t sbk, void* dv, int ldv,
+                               int64_t sbv, float* dpos, int ldpos, int B, int H, int Tq, int Tk, hipStream_t stream);
+namespace avsr_gemm_impl {
 }  // namespace avsr_gemm_impl
 
 extern "C" int avsr_gemm(int layout, const void* A, int a_dtype, int lda, const void* B, int b_dtype,
@@ -91,6 +96,16 @@ extern "C" int avsr_attention_bwd_kv(const void* pd, const void* ds, int lds, co
     AVSR_REQUIRE((dpos == nullptr) == (qv == nullptr), "attention_bwd_kv: dpos and qv go together");
     AVSR_REQUIRE(dpos == nullptr || ldpos >= H * dk_dim, "attention_bwd_kv: dpos row pitch smaller than H * dk");
     if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return 0;
+    // bf16, OPT-IN (avsr_tune knob 10 = 2): the k-major tile kernel with LDS transpose reads (attention_kv.hip).  It agrees
+    // with the generic path on the host emulator, but its first run on an MI355X ended in a GPU memory access fault that
+    // could not be diagnosed within the round's GPU budget -- it stays off until it has passed the -m gpu suite.
+    if (dtype == 1 && !precise && dk_dim == 64 && avsr_tune_knobs[10] == 2 && lds % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 &&
+        (dpos == nullptr || ldpos % 4 == 0)) {
+        avsr_attention_bwd_kv_fast(pd, ds, lds, dout, ldo, sbo, qu, qv, ldq, sbq, dk, ldk, sbk, dv, ldv, sbv, dpos, ldpos, B, H,
+                                   Tq, Tk, stream);
+        AVSR_CHECK_LAUNCH("attention_bwd_kv");
+        return 0;
+    }
     avsr_gemm_impl::Params ps[3];
     int n = 0;
     auto base = [&](const void* A, const void* Bm, int ldb, int64_t sBb, void* C, int c_dtype, int ldc, int64_t sCb, int64_t sCh,

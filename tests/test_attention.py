@@ -241,6 +241,59 @@ def test_attention_bf16_backward_kernels_agree(dev, relpos, mkind, T, Tk):
             assert rel(x, y) < 8e-3, rel(x, y)
 
 
+@pytest.mark.parametrize("relpos,B,T,Tk,H", [(True, 3, 100, 100, 2), (True, 1, 64, 64, 1), (False, 2, 33, 130, 2),
+                                             (False, 2, 70, 70, 3), (True, 2, 129, 129, 1)])
+def test_attention_bwd_kv_fast_matches_generic(emu_lib_path, relpos, B, T, Tk, H):
+    """Key / value side of the bf16 backward: the OPT-IN k-major tile kernel (attention_kv.hip, avsr_tune knob 10 = 2; dpos
+    contracted over (batch, query) jointly, skewed dS rows read at 2-byte-aligned addresses) vs the generic batched TN path on
+    the SAME stored pd / ds: dK / dV to bf16 rounding, dpos (f32) to summation order; dpos lands in a pitched column block
+    and ACCUMULATES (a second call doubles it); ragged tiles, Tq != Tk, batch sum.
+    EMULATOR ONLY: the kernel's first MI355X run ended in a GPU memory access fault (undiagnosed: the round's GPU budget was
+    gone) -- it is off by default and must not run in the -m gpu suite until that is understood."""
+    from auto_avsr_amd import _lib
+
+    _lib._install_for_tests(emu_lib_path)
+    dev = torch.device("cpu")
+    try:
+        _kv_fast_vs_generic(dev, relpos, B, T, Tk, H)
+    finally:
+        _lib._lib = None
+
+
+def _kv_fast_vs_generic(dev, relpos, B, T, Tk, H):
+    torch.manual_seed(B * 100 + T + Tk)
+    D = 64
+    qu, qv = torch.randn(B, T, H, D).bfloat16(), torch.randn(B, T, H, D).bfloat16()
+    k, v = torch.randn(B, Tk, H, D).bfloat16(), torch.randn(B, Tk, H, D).bfloat16()
+    pos = torch.randn(2 * T - 1, H * D).bfloat16() if relpos else None
+    mask = make_mask("pad", B, T, Tk)
+    dout = torch.randn(B, T, H * D).bfloat16()
+    d = lambda t: None if t is None else t.to(dev)
+    out, lse = ops.attention_fwd(d(qu), d(qv) if relpos else None, d(k), d(v), d(pos), d(mask), 0.125)
+    res = []
+    try:
+        for knob in (2, 0):  # 2 = the tile kernel, 0 = generic (default)
+            ops.tune(10, knob)
+            wide = torch.zeros(2 * T - 1, 3 * H * D, device=dev) if relpos else None
+            kw = dict(dpos_out=wide[:, H * D:2 * H * D]) if relpos else {}
+            _, _, dk, dv, dpos = ops.attention_bwd(d(qu), d(qv) if relpos else None, d(k), d(v), d(pos), d(mask), out, lse,
+                                                   d(dout), 0.125, **kw)
+            if relpos:
+                once = dpos.clone()
+                ops.attention_bwd(d(qu), d(qv), d(k), d(v), d(pos), d(mask), out, lse, d(dout), 0.125, **kw)
+                assert float((wide[:, H * D:2 * H * D] - 2 * once).abs().max()) <= 1e-5 * max(1.0, float(once.abs().max()))
+                assert float(wide[:, :H * D].abs().max()) == 0.0 and float(wide[:, 2 * H * D:].abs().max()) == 0.0
+                dpos = once
+            res.append((dk.float().cpu(), dv.float().cpu(), None if dpos is None else dpos.cpu()))
+    finally:
+        ops.tune(10, 0)
+    (dk0, dv0, dp0), (dk1, dv1, dp1) = res
+    rel = lambda x, y: float((x - y).norm() / (y.norm() + 1e-30))
+    assert rel(dk0, dk1) < 5e-3 and rel(dv0, dv1) < 5e-3, (rel(dk0, dk1), rel(dv0, dv1))
+    if relpos:
+        assert rel(dp0, dp1) < 1e-5, rel(dp0, dp1)
+
+
 def test_attention_dropout_consistency(dev):
     """Dropout on the probabilities: forward and backward must draw the same keep-mask (finite-difference free
     check: with V = I-like probes the output equals the dropped probabilities that the backward re-creates)."""
