@@ -367,14 +367,10 @@ def _fast_ok(a, K, lda):
     return (not _state["precise"]) and a.dtype == torch.bfloat16 and K % 64 == 0 and (lda or K) % 8 == 0
 
 
-def _pick_tile(M, N):
-    return 0  # the library's measured heuristic (gemm_fast.hip)
-
-
 def _gemm_nt(a, w, M, N, K, out, *, lda=None, ldc=None, **kw):
     """out[M,N] = epi(a[M,K] @ w[N,K]^T)."""
     if _fast_ok(a, K, lda) and w.dim() == 2 and w.dtype == torch.float32 and w.is_contiguous():
-        return ops.gemm_bf16_nt(a, lda or K, _w_bf16(w, False), K, M, N, K, out, ldc or N, tile=_pick_tile(M, N), **kw)
+        return ops.gemm_bf16_nt(a, lda or K, _w_bf16(w, False), K, M, N, K, out, ldc or N, **kw)
     return ops.gemm(NT, a, lda or K, w, K, M, N, K, out, ldc or N, precise=_state["precise"], **kw)
 
 
@@ -387,7 +383,7 @@ def _gemm_nn(a, w, M, N, K, out, *, lda=None, ldb=None, ldc=None, colsum=None, *
             and w.is_contiguous() and (ldb or N) == N and (lda or K) >= Kp and (lda or K) % 8 == 0:
         # a's row pitch covers the 64-padded K (its pad columns are zero or multiply the zero tail of w^T)
         wt = _w_bf16(w, True)  # [N][Kp]
-        return ops.gemm_bf16_nt(a, lda or K, wt, wt.shape[1], M, N, Kp, out, ldc or N, tile=_pick_tile(M, N),
+        return ops.gemm_bf16_nt(a, lda or K, wt, wt.shape[1], M, N, Kp, out, ldc or N,
                                 colsum=colsum, **kw)
     ops.gemm(NN, a, lda or K, w, ldb or N, M, N, K, out, ldc or N, precise=_state["precise"], **kw)
     if colsum is not None:
@@ -526,8 +522,9 @@ def _chain_prologue(src, rows, n, alpha, drop):
 
 def _prologue(src, rows, n, *, alpha=1.0, drop=(0.0, 0, None), want_dst=True, want_bias=True, ld_src=None):
     """Backward prologue of a Linear layer on its output gradient `src` [rows, n] (f32 or activation dtype):
-    g = act_dtype(alpha * dropout(src)), g^T (bf16 fast path only, else None) and the bias gradient colsum(g).
-    Returns (g or src when no copy was needed, gT, db)."""
+    g = act_dtype(alpha * dropout(src)) and the bias gradient colsum(g).
+    Returns (g or src when no copy was needed, None, db) -- the middle slot carried a transposed copy of g until the
+    weight-gradient kernel learnt to read k-major operands through LDS transpose reads."""
     p, sd, sdev = drop
     if want_dst and ld_src is None and not _state["precise"]:
         hit = _chain_prologue(src, rows, n, alpha, drop)  # already produced by the LayerNorm backward that made `src`
@@ -555,7 +552,7 @@ def _prologue(src, rows, n, *, alpha=1.0, drop=(0.0, 0, None), want_dst=True, wa
     return g, None, db
 
 
-def _wgrad(dy, x, rows, n_out, n_in, lda=None, ldb=None, xT=None, dyT=None, bias_out=None):
+def _wgrad(dy, x, rows, n_out, n_in, lda=None, ldb=None, bias_out=None):
     """dW[n_out, n_in] = dy[rows, n_out]^T x[rows, n_in] (f32).  Small outputs are split along the token
     dimension so that the launch still fills the 256 CUs.
     bias_out (f32 [>= n_out], zero-initialised): also receives colsum(dy) -- the bias gradient of the same Linear -- from
@@ -589,12 +586,6 @@ def _wgrad(dy, x, rows, n_out, n_in, lda=None, ldb=None, xT=None, dyT=None, bias
         assert (lda or n_out) == n_out, "bias gradient of a pitched dy needs the tuned kernel"
         ops.colsum_into(dy, bias_out, rows, n_out)
     return dw
-
-
-def _xT(x, rows, n):
-    """(historical) transposed activation copies are no longer needed: the weight-gradient kernel reads the
-    k-major operands directly through LDS transpose reads."""
-    return None
 
 
 def _bgrad(dy, rows, n):
@@ -794,7 +785,7 @@ class FfnSublayerFn(torch.autograd.Function):
         # relu' and the hidden dropout mask are both "u > 0" on the saved post-dropout activation
         db1 = _zeros(Fh, x.device)  # bias gradient of W1: column sums of du, taken in the epilogue of the GEMM that makes du
         with ops.paired():  # every (weight gradient, data gradient) pair of a Linear leaves as one launch
-            dw2 = _wgrad(g, u, rows, D, Fh, dyT=gT, xT=_xT(u, rows, Fh), bias_out=db2)
+            dw2 = _wgrad(g, u, rows, D, Fh, bias_out=db2)
             _gemm_nn(g, w2, rows, Fh, D, du, gate=u, ldg=Fh, gate_scale=1.0 / (1.0 - p1) if p1 > 0 else 1.0, colsum=db1)
         dh = torch.empty(rows, D, dtype=T, device=x.device)
         with ops.paired():
@@ -1094,7 +1085,7 @@ class MhaSublayerFn(torch.autograd.Function):
         dbo = _zeros(D, x.device)
         dctx = torch.empty(B, Tq, D, dtype=T, device=x.device)
         with ops.paired():
-            dwo = _wgrad(g, ctxv, B * Tq, D, D, dyT=gT, xT=_xT(ctxv.view(B * Tq, D), B * Tq, D), bias_out=dbo)
+            dwo = _wgrad(g, ctxv, B * Tq, D, D, bias_out=dbo)
             _gemm_nn(g, wo, B * Tq, D, D, dctx)
         outs = {}
         if fused:  # dq | dk | dv land side by side: one bias-gradient pass, one weight-gradient GEMM, one data-gradient GEMM
@@ -1152,45 +1143,42 @@ class MhaSublayerFn(torch.autograd.Function):
         else:
             if not shared_kv:
                 dk2, dv2 = dk_.view(B * Tk, D), dv_.view(B * Tk, D)
-            hT = _xT(h.view(B * Tq, D), B * Tq, D)
-            kaT = None
-            dqT = dkT = dvT = None
             dbq, dbk, dbv = _zeros(D, x.device), _zeros(D, x.device), _zeros(D, x.device)
             # each projection: weight gradient + data gradient as one launch (data gradients chain through `resid`)
             if shared_kv:
                 dh = torch.empty(B * Tq, D, dtype=T, device=x.device)
                 with ops.paired():
-                    dwq = _wgrad(dq, h, B * Tq, D, D, xT=hT, dyT=dqT, bias_out=dbq)
+                    dwq = _wgrad(dq, h, B * Tq, D, D, bias_out=dbq)
                     _gemm_nn(dq, wq, B * Tq, D, D, dh)
                 dwk = dwv = dbk = dbv = None
             elif cross:
                 dh = torch.empty(B * Tq, D, dtype=T, device=x.device)
                 with ops.paired():
-                    dwq = _wgrad(dq, h, B * Tq, D, D, xT=hT, dyT=dqT, bias_out=dbq)
+                    dwq = _wgrad(dq, h, B * Tq, D, D, bias_out=dbq)
                     _gemm_nn(dq, wq, B * Tq, D, D, dh)
                 need_mem = ctx.needs_input_grad[1]
                 t2 = torch.empty(B * Tk, D, dtype=torch.float32, device=x.device) if need_mem else None
                 with ops.paired():
-                    dwk = _wgrad(dk2, ka, B * Tk, D, D, xT=kaT, dyT=dkT, bias_out=dbk)
+                    dwk = _wgrad(dk2, ka, B * Tk, D, D, bias_out=dbk)
                     if need_mem:
                         _gemm_nn(dk2, wk, B * Tk, D, D, t2)
                 with ops.paired():
-                    dwv = _wgrad(dv2, ka, B * Tk, D, D, xT=kaT, dyT=dvT, bias_out=dbv)
+                    dwv = _wgrad(dv2, ka, B * Tk, D, D, bias_out=dbv)
                     if need_mem:
                         dmem = torch.empty(B, Tk, D, dtype=torch.float32, device=x.device)
                         _gemm_nn(dv2, wv, B * Tk, D, D, dmem, resid=t2, ldr=D)
             else:
                 t1 = torch.empty(B * Tq, D, dtype=torch.float32, device=x.device)
                 with ops.paired():
-                    dwq = _wgrad(dq, h, B * Tq, D, D, xT=hT, dyT=dqT, bias_out=dbq)
+                    dwq = _wgrad(dq, h, B * Tq, D, D, bias_out=dbq)
                     _gemm_nn(dq, wq, B * Tq, D, D, t1)
                 t2 = torch.empty_like(t1)
                 with ops.paired():
-                    dwk = _wgrad(dk2, ka, B * Tk, D, D, xT=kaT, dyT=dkT, bias_out=dbk)
+                    dwk = _wgrad(dk2, ka, B * Tk, D, D, bias_out=dbk)
                     _gemm_nn(dk2, wk, B * Tq, D, D, t2, resid=t1, ldr=D)
                 dh = torch.empty_like(t1)
                 with ops.paired():
-                    dwv = _wgrad(dv2, ka, B * Tk, D, D, xT=kaT, dyT=dvT, bias_out=dbv)
+                    dwv = _wgrad(dv2, ka, B * Tk, D, D, bias_out=dbv)
                     _gemm_nn(dv2, wv, B * Tq, D, D, dh, resid=t2, ldr=D)
         dg = _zeros(D, x.device)
         dbt = _zeros(D, x.device)
@@ -1389,7 +1377,7 @@ class ConvSublayerFn(torch.autograd.Function):
         db2 = _zeros(D, x.device)
         ds = torch.empty(rows, D, dtype=T, device=x.device)
         with ops.paired():
-            dw2 = _wgrad(g, s, rows, D, D, dyT=gT, xT=_xT(s, rows, D), bias_out=db2).view(D, D, 1)
+            dw2 = _wgrad(g, s, rows, D, D, bias_out=db2).view(D, D, 1)
             _gemm_nn(g, w_pw2.view(D, D), rows, D, D, ds)
         if training and _BN_SMALL and _state["bn_sync"] is None and rows <= ops.BN_SMALL_MAX_ROWS:
             dc, dbn_w, dbn_b = ops.bn_small_bwd(c, ds, rows, D, bmean, binv, bn_w, bn_b, 1)
@@ -1406,12 +1394,11 @@ class ConvSublayerFn(torch.autograd.Function):
         ops.dwconv_wgrad(a, dc, dwdw, dbdw, B, Tn, D, K, glu_in=True)
         # data gradient of the depthwise convolution with the GLU backward as its epilogue: d glu never reaches HBM
         da = ops.dwconv(dc, wdw, None, B, Tn, D, K, flip=True, glu_a=a).view(rows, 2 * D)
-        daT = None
         db1 = _zeros(2 * D, x.device)
         if fused:
             dh = torch.empty(rows, D, dtype=T, device=x.device)
             with ops.paired():
-                dw1 = _wgrad(da, h, rows, 2 * D, D, dyT=daT, xT=_xT(h.view(rows, D), rows, D), bias_out=db1).view(2 * D, D, 1)
+                dw1 = _wgrad(da, h, rows, 2 * D, D, bias_out=db1).view(2 * D, D, 1)
                 _gemm_nn(da, w_pw1.view(2 * D, D), rows, D, 2 * D, dh)
             dg = _zeros(D, x.device)
             dbt = _zeros(D, x.device)
@@ -1420,7 +1407,7 @@ class ConvSublayerFn(torch.autograd.Function):
             dg = dbt = None
             dx = torch.empty(B, Tn, D, dtype=torch.float32, device=x.device)
             with ops.paired():
-                dw1 = _wgrad(da, h, rows, 2 * D, D, dyT=daT, xT=_xT(h.view(rows, D), rows, D), bias_out=db1).view(2 * D, D, 1)
+                dw1 = _wgrad(da, h, rows, 2 * D, D, bias_out=db1).view(2 * D, D, 1)
                 _gemm_nn(da, w_pw1.view(2 * D, D), rows, D, 2 * D, dx)
         return (dx, dg, dbt, dw1, db1, dwdw.view(D, 1, K), dbdw, dbn_w, dbn_b, None, None, None, dw2, db2, None, None,
                 None, None, None)
