@@ -17,6 +17,10 @@
 // STATUS: opt-in (avsr_tune knob 10 = 2, see avsr_attention_bwd_kv in gemm.hip).  Agrees with the generic path on the host
 // emulator (tests/test_attention.py::test_attention_bwd_kv_fast_matches_generic); its first and only run on an MI355X ended
 // in a GPU memory access fault that could not be diagnosed inside the round's GPU budget.  Not part of any reported number.
+// What is known: (1) with every operand bracketed by unmapped pages the emulated kernel touches nothing outside its operands
+// (tests/test_guard_pages.py), so a plain overrun is unlikely; (2) the runtime reported "Reason: Unknown", not "page not
+// present" -- what one would expect from an alignment violation rather than an unmapped address; (3) that first version read
+// the skewed rows with 16-byte loads at 2-byte-aligned addresses.  Those loads are gone (aligned dwords + funnel shift).
 #include "gemm_core.h"
 #include "avsr_hip.h"
 
