@@ -120,3 +120,33 @@ def test_prepare_targets_matches_reference_formulation(dev, B, L):
     w = lst_in.shape[1]
     assert torch.equal(ys_in.cpu()[:, :w], lst_in) and torch.equal(ys_out.cpu()[:, :w], lst_out)
     assert bool((ys_out.cpu()[:, w:] == -1).all()) and bool((ys_in.cpu()[:, w:] == eos).all())
+
+
+def test_prepare_targets_vs_reference_golden(emu_lib_path):
+    """avsr_prepare_targets against outputs of the REFERENCE's add_sos_eos + target_mask (tests/golden/make_golden_targets.py):
+    ys_in / ys_out / mask bit-exact on the reference's (data-dependent) width, padding beyond it, token count.
+    (Emulator build: added after the round's GPU budget was spent; the same kernel runs on the MI355X in
+    test_prepare_targets_matches_reference_formulation[hip-*].)"""
+    import os
+
+    from auto_avsr_amd import _lib
+
+    _lib._install_for_tests(emu_lib_path)
+    dev = torch.device("cpu")
+    try:
+        _targets_vs_golden(dev)
+    finally:
+        _lib._lib = None
+
+
+def _targets_vs_golden(dev):
+    import os
+
+    cases = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_targets_v1.pt"))
+    for c in cases:
+        ys_in, ys_out, mask, n_tok = ops.prepare_targets(c["ys_pad"].to(dev), c["sos"], c["eos"], -1)
+        w = c["ys_in"].shape[1]
+        assert torch.equal(ys_in.cpu()[:, :w], c["ys_in"]) and torch.equal(ys_out.cpu()[:, :w], c["ys_out"])
+        assert torch.equal(mask.cpu()[:, :w, :w], c["mask"])
+        assert bool((ys_out.cpu()[:, w:] == -1).all()) and bool((ys_in.cpu()[:, w:] == c["eos"]).all())
+        assert int(n_tok) == c["n_tokens"]
