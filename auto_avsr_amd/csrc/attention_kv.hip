@@ -14,13 +14,11 @@
 // shifted by a per-row offset, i.e. eight elements at a 2-byte-aligned address (out of reach of LDS-DMA): fetched as aligned
 // dwords and funnel-shifted in registers.
 //
-// STATUS: opt-in (avsr_tune knob 10 = 2, see avsr_attention_bwd_kv in gemm.hip).  Agrees with the generic path on the host
-// emulator (tests/test_attention.py::test_attention_bwd_kv_fast_matches_generic); its first and only run on an MI355X ended
-// in a GPU memory access fault that could not be diagnosed inside the round's GPU budget.  Not part of any reported number.
-// What is known: (1) with every operand bracketed by unmapped pages the emulated kernel touches nothing outside its operands
-// (tests/test_guard_pages.py), so a plain overrun is unlikely; (2) the runtime reported "Reason: Unknown", not "page not
-// present" -- what one would expect from an alignment violation rather than an unmapped address; (3) that first version read
-// the skewed rows with 16-byte loads at 2-byte-aligned addresses.  Those loads are gone (aligned dwords + funnel shift).
+// pd / ds pad columns [Tk, lds) are never written by the producer: the position term masks them, the other two contractions
+// only let them reach output rows >= Tk, which are not stored.
+// History: the first MI355X runs of this kernel ended in a GPU memory access fault.  Round 3 isolated it contraction by
+// contraction (tools/kv_fault_probe.py, avsr_tune knob 11): dV / dK were correct, the f32 atomics of the dpos epilogue
+// faulted -- the compiler had left their row pitch in an undefined scalar register (see kv_block below).
 #include "gemm_core.h"
 #include "avsr_hip.h"
 
@@ -32,16 +30,19 @@ struct KvParams {
     float* dpos;
     int lds, ldo, ldq, ldk, ldv, ldpos;
     long sbo, sbq, sbk, sbv;
-    int B, H, Tq, Tk;
+    int B, H, Tq, Tk, skip;
 };
 
 
 constexpr int KV_OP_BYTES = 64 * 128, KV_STAGE_BYTES = 2 * KV_OP_BYTES;
 constexpr size_t KV_LDS_BYTES = 2 * KV_STAGE_BYTES;  // two stages; also covers the 64 x 68 f32 epilogue tile
 
-__global__ __launch_bounds__(256) void attn_bwd_kv_fast_kernel(KvParams p) {
-    AVSR_DYN_SMEM(smem);
-    const int which = blockIdx.z;  // 0: dV, 1: dK, 2: dpos
+// One block of contraction `which` (0: dV, 1: dK, 2: dpos).  A template parameter, not a run-time value: with `which` as a
+// wave-uniform run-time variable hipcc (ROCm 7.2) left the output pitch of the which == 2 path in an UNDEFINED scalar
+// register (the s_mov of p.ldpos was tail-merged into the which == 0 path; found in the ISA after the kernel's dpos atomics
+// faulted on the MI355X while the host-emulator build of the same source was correct).
+template <int which>
+AVSR_DEV void kv_block(const KvParams& p, char* smem) {
     const int m0 = blockIdx.x * 64;
     const int lane = threadIdx.x & 63, wave = wave_id();
     const int wm = wave >> 1, wn = wave & 1;
@@ -81,9 +82,6 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_fast_kernel(KvParams p) {
                 const int jb = j & ~1;  // even element index: a 4-byte-aligned address (rows start 16-byte aligned)
                 if (j >= 0 && jb + 10 <= p.lds) {
                     // eight elements from a 2-byte-aligned position as five ALIGNED dwords + a 16-bit funnel shift for odd j
-                    // (pad columns [Tk, lds) hold zeros).  The first version read them with one 16-byte load at the
-                    // 2-byte-aligned address -- the compiler emits global_load_dwordx4 for it -- and the kernel's first
-                    // MI355X run died with a GPU memory access fault; whether that load was the cause is unverified.
                     const uint32_t* w = reinterpret_cast<const uint32_t*>(row + jb);
                     uint32_t d[5];
 #pragma unroll
@@ -93,8 +91,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_fast_kernel(KvParams p) {
                     for (int e = 0; e < 4; e++) o[e] = (j & 1) ? ((d[e] >> 16) | (d[e + 1] << 16)) : d[e];
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
-                        ra[i][2 * e] = (short)(o[e] & 0xffffu);
-                        ra[i][2 * e + 1] = (short)(o[e] >> 16);
+                        // columns [Tk, lds) of pd / ds are never written (torch.empty): mask them
+                        ra[i][2 * e] = j + 2 * e < p.Tk ? (short)(o[e] & 0xffffu) : (short)0;
+                        ra[i][2 * e + 1] = j + 2 * e + 1 < p.Tk ? (short)(o[e] >> 16) : (short)0;
                     }
                 } else if (j > -8 && j < p.Tk) {
 #pragma unroll
@@ -147,6 +146,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_fast_kernel(KvParams p) {
     avsr_gemm_impl::epilogue_lds<64, 64, 1, 1>(acc, q, m0, 0, wm * 32, wn * 32, 0, 0, smem);
 }
 
+__global__ __launch_bounds__(256) void attn_bwd_kv_fast_kernel(KvParams p) {
+    AVSR_DYN_SMEM(smem);
+    if ((p.skip >> blockIdx.z) & 1) return;  // avsr_tune knob 11: bit mask of contractions to skip (fault isolation)
+    switch (blockIdx.z) {
+        case 0: kv_block<0>(p, smem); break;
+        case 1: kv_block<1>(p, smem); break;
+        default: kv_block<2>(p, smem); break;
+    }
+}
+
 }  // namespace
 
 // bf16 fast path of avsr_attention_bwd_kv (gemm.hip); same arguments, dk_dim == 64.  Returns 0 when launched.
@@ -159,7 +168,7 @@ int avsr_attention_bwd_kv_fast(const void* pd, const void* ds, int lds, const vo
     p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.dpos = dpos;
     p.lds = lds; p.ldo = ldo; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldpos = ldpos;
     p.sbo = sbo; p.sbq = sbq; p.sbk = sbk; p.sbv = sbv;
-    p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk;
+    p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk; p.skip = avsr_tune_knobs[11];
     const int mt_kv = (Tk + 63) / 64, mt_pos = dpos ? (2 * Tq - 1 + 63) / 64 : 0;
     dim3 grid(mt_kv > mt_pos ? mt_kv : mt_pos, B * H, dpos ? 3 : 2), block(256);
     AVSR_LAUNCH(attn_bwd_kv_fast_kernel, grid, block, KV_LDS_BYTES, stream, p);

@@ -96,10 +96,9 @@ extern "C" int avsr_attention_bwd_kv(const void* pd, const void* ds, int lds, co
     AVSR_REQUIRE((dpos == nullptr) == (qv == nullptr), "attention_bwd_kv: dpos and qv go together");
     AVSR_REQUIRE(dpos == nullptr || ldpos >= H * dk_dim, "attention_bwd_kv: dpos row pitch smaller than H * dk");
     if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return 0;
-    // bf16, OPT-IN (avsr_tune knob 10 = 2): the k-major tile kernel with LDS transpose reads (attention_kv.hip).  It agrees
-    // with the generic path on the host emulator, but its first run on an MI355X ended in a GPU memory access fault that
-    // could not be diagnosed within the round's GPU budget -- it stays off until it has passed the -m gpu suite.
-    if (dtype == 1 && !precise && dk_dim == 64 && avsr_tune_knobs[10] == 2 && lds % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 &&
+    // bf16: the k-major tile kernel with LDS transpose reads (attention_kv.hip); avsr_tune knob 10 = 1 selects the generic
+    // batched TN path below for A/B runs
+    if (dtype == 1 && !precise && dk_dim == 64 && avsr_tune_knobs[10] != 1 && lds % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 &&
         (dpos == nullptr || ldpos % 4 == 0)) {
         avsr_attention_bwd_kv_fast(pd, ds, lds, dout, ldo, sbo, qu, qv, ldq, sbq, dk, ldk, sbk, dv, ldv, sbv, dpos, ldpos, B, H,
                                    Tq, Tk, stream);

@@ -18,11 +18,60 @@ import torch
 from . import ops
 from .ops import NN, NT, TN
 
-_state = {"precise": False, "seed": 0x5EED, "counter": 0, "seed_dev": None, "bn_sync": None}
+_state = {"precise": False, "hpf": False, "seed": 0x5EED, "counter": 0, "seed_dev": None, "bn_sync": None}
 
 
 def set_precise(flag: bool):
     _state["precise"] = bool(flag)
+    _state["hpf"] = False
+
+
+def set_mode(mode: str):
+    """Numerical mode of the hot path:
+      "bf16"    -- bf16 activations / operands, f32 accumulation (the benchmarked mode);
+      "precise" -- f32 activations, every contraction on split hi+lo bf16 planes (3 MFMAs per product), forward and backward;
+      "hpf"     -- high-precision FORWARD: the forward pass of every autograd function runs exactly as in "precise" (so losses,
+                   logits, CTC log-probabilities and decoding meet the 1e-3 parity bound against an fp32 reference), what it saves
+                   for the backward pass is stored as bf16, and the backward pass runs exactly as in "bf16" (gradients of bf16
+                   quality at the bf16 cost)."""
+    assert mode in ("bf16", "precise", "hpf"), mode
+    _state["precise"] = mode != "bf16"
+    _state["hpf"] = mode == "hpf"
+
+
+def mode() -> str:
+    return "hpf" if _state["hpf"] else ("precise" if _state["precise"] else "bf16")
+
+
+def _bwd_precise():
+    """Will the BACKWARD pass of the function whose forward is running use the precise kernels?"""
+    return _state["precise"] and not _state["hpf"]
+
+
+def _bwd_mode(fn):
+    """Decorator of every autograd backward: in the "hpf" mode the backward pass runs in the bf16 mode."""
+    import functools
+
+    @functools.wraps(fn)
+    def backward(ctx, *grads):
+        if not _state["hpf"]:
+            return fn(ctx, *grads)
+        old = _state["precise"]
+        _state["precise"] = False
+        try:
+            return fn(ctx, *grads)
+        finally:
+            _state["precise"] = old
+
+    return backward
+
+
+def _A(t):
+    """An ACTIVATION-dtype tensor on its way into save_for_backward: in the "hpf" mode (f32 forward, bf16 backward) the
+    backward pass gets a bf16 copy; identity in the other modes."""
+    if t is None or not _state["hpf"] or t.dtype != torch.float32:
+        return t
+    return ops.scale_dropout(t.contiguous(), torch.bfloat16)
 
 
 def is_precise() -> bool:
@@ -31,12 +80,22 @@ def is_precise() -> bool:
 
 @contextlib.contextmanager
 def precise(flag=True):
-    old = _state["precise"]
-    _state["precise"] = bool(flag)
+    old = (_state["precise"], _state["hpf"])
+    _state["precise"], _state["hpf"] = bool(flag), False
     try:
         yield
     finally:
-        _state["precise"] = old
+        _state["precise"], _state["hpf"] = old
+
+
+@contextlib.contextmanager
+def numerics(mode_name):
+    old = (_state["precise"], _state["hpf"])
+    set_mode(mode_name)
+    try:
+        yield
+    finally:
+        _state["precise"], _state["hpf"] = old
 
 
 def act_dtype():
@@ -350,6 +409,7 @@ class PosProjFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, dout):
         (pe,) = ctx.saved_tensors
         P, D, n = ctx.meta
@@ -620,6 +680,19 @@ def _to_act_shared(x):
     return ent[1]
 
 
+def _A_shared(t):
+    """_A for a tensor that several sub-layers of one step save unchanged (encoder memory, position table)."""
+    if t is None or not _state["hpf"] or t.dtype != torch.float32:
+        return t
+    key = (t.data_ptr(), tuple(t.shape), "hpf-save", t._version)
+    ent = _shared_act.get(key)
+    if ent is None:
+        if len(_shared_act) > 8:
+            _shared_act.clear()
+        ent = _shared_act[key] = (t, ops.scale_dropout(t.contiguous(), torch.bfloat16))
+    return ent[1]
+
+
 def _to_f32(x):
     if x.dtype == torch.float32 and x.is_contiguous():
         return x
@@ -675,6 +748,7 @@ class LayerNormFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, dy):
         x, gamma, mean, rstd = ctx.saved_tensors
         D = x.shape[-1]
@@ -702,11 +776,12 @@ class LinearFn(torch.autograd.Function):
         alloc = torch.zeros if ldc != N else torch.empty
         y = alloc(x.shape[:-1] + (ldc,), dtype=out_dtype, device=x.device)
         _gemm_nt(x2, w, rows, N, K, y, ldc=ldc, bias=b)
-        ctx.save_for_backward(x2, w)
+        ctx.save_for_backward(_A(x2), w)
         ctx.meta = (b is not None, x.shape)
         return y if ldc == N else y[..., :N]
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, dy):
         x2, w = ctx.saved_tensors
         has_b, xshape = ctx.meta
@@ -766,12 +841,13 @@ class FfnSublayerFn(torch.autograd.Function):
         p2, s2, sd2 = _drop_args(p, x)
         y = torch.empty_like(x)
         _gemm_nt(u, w2, rows, D, Fh, y, bias=b2, drop_p=p2, seed=s2, seed_dev=sd2, alpha=scale, resid=x, ldr=D)
-        ctx.save_for_backward(x, ln_w, mean, rstd, h, u, w1, w2)
+        ctx.save_for_backward(x, ln_w, mean, rstd, _A(h), _A(u), w1, w2)
         ctx.meta = (scale, p1, p2, s2, sd2)
         _chain_tag(y, rows, D, scale, (p2, s2, sd2))
         return y
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, dy):
         x, ln_w, mean, rstd, h, u, w1, w2 = ctx.saved_tensors
         scale, p1, p2, s2, sd2 = ctx.meta
@@ -815,11 +891,12 @@ class FfnFn(torch.autograd.Function):
         _gemm_nt(x2, w1, rows, Fh, D, u, bias=b1, act=1, drop_p=p1, seed=s1, seed_dev=sd1)
         y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
         _gemm_nt(u, w2, rows, D, Fh, y, bias=b2)
-        ctx.save_for_backward(x2, u, w1, w2)
+        ctx.save_for_backward(_A(x2), _A(u), w1, w2)
         ctx.p1 = p1
         return y
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, dy):
         x2, u, w1, w2 = ctx.saved_tensors
         p1 = ctx.p1
@@ -853,10 +930,11 @@ class MlpFn(torch.autograd.Function):
         _gemm_nt(x2, w1, rows, Fh, Din, u, bias=b1, act=1)
         y = torch.empty(x.shape[:-1] + (Dout,), dtype=torch.float32, device=x.device)
         _gemm_nt(u, w2, rows, Dout, Fh, y, bias=b2)
-        ctx.save_for_backward(x2, u, w1, w2)
+        ctx.save_for_backward(_A(x2), _A(u), w1, w2)
         return y
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, dy):
         x2, u, w1, w2 = ctx.saved_tensors
         rows, Din = _rows(x2), x2.shape[-1]
@@ -918,11 +996,14 @@ class AttentionCoreFn(torch.autograd.Function):
                                       precise=_state["precise"], drop_p=pa, seed=sa, seed_dev=sda)
         y = torch.empty(B, Tq, D, dtype=torch.float32, device=q.device)
         _gemm_nt(ctxv, wo, B * Tq, D, D, y, bias=bo)
-        ctx.save_for_backward(qa, ka, pe, m, wq, wk, wv, wo, wpos, qu, qv, k, v, pproj, ctxv, lse)
+        qa_s = _A(qa)
+        ctx.save_for_backward(qa_s, qa_s if ka is qa else _A(ka), _A(pe), m, wq, wk, wv, wo, wpos, _A(qu), _A(qv), _A(k), _A(v),
+                              _A(pproj), _A(ctxv), lse)
         ctx.meta = (H, pa, sa, sda, same_kv, relpos, bq is not None)
         return y
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, dy):
         qa, ka, pe, m, wq, wk, wv, wo, wpos, qu, qv, k, v, pproj, ctxv, lse = ctx.saved_tensors
         H, pa, sa, sda, same_kv, relpos, has_b = ctx.meta
@@ -1061,8 +1142,8 @@ class MhaSublayerFn(torch.autograd.Function):
         po, so, sdo = _drop_args(p_out, x)
         y = torch.empty_like(x)
         _gemm_nt(ctxv, wo, B * Tq, D, D, y, bias=bo, drop_p=po, seed=so, seed_dev=sdo, resid=x, ldr=D)
-        ctx.save_for_backward(x, ln_w, mean, rstd, h, ka if (cross and not shared_kv) else None, pe, m, wq, wk, wv, wo, wpos,
-                              qu, qv, k4, v4, pproj, ctxv, lse)
+        ctx.save_for_backward(x, ln_w, mean, rstd, _A(h), _A_shared(ka) if (cross and not shared_kv) else None, _A_shared(pe), m,
+                              wq, wk, wv, wo, wpos, _A(qu), _A(qv), _A(k4), _A(v4), _A(pproj), _A(ctxv), lse)
         ctx.meta = (H, pa, sa, sda, po, so, sdo, cross, relpos, fused)
         ctx.kv = (kv_slot, kv_holder, tuple(kv_all.shape)) if shared_kv else None
         ctx.pp = (pp_slot, pp_holder, tuple(pp_all.shape)) if (relpos and pp_all is not None) else None
@@ -1070,6 +1151,7 @@ class MhaSublayerFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, dy):
         (x, ln_w, mean, rstd, h, ka, pe, m, wq, wk, wv, wo, wpos, qu, qv, k4, v4, pproj, ctxv, lse) = ctx.saved_tensors
         H, pa, sa, sda, po, so, sdo, cross, relpos, fused = ctx.meta
@@ -1228,6 +1310,7 @@ class MemoryKVFn(torch.autograd.Function):
         return kv
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, dkv):
         ma, *ws = ctx.saved_tensors
         B, Tk, D, n = ctx.meta
@@ -1359,13 +1442,14 @@ class ConvSublayerFn(torch.autograd.Function):
         y = torch.empty_like(x)
         _gemm_nt(s, w_pw2.view(D, D), rows, D, D, y, bias=b_pw2, drop_p=po, seed=so, seed_dev=sdo,
                  resid=x if fused else None, ldr=D)
-        ctx.save_for_backward(x, ln_w, mean, rstd, h, a, gl, c, bmean, binv, bn_w, bn_b, s, w_pw1, wdw, w_pw2, counts)
+        ctx.save_for_backward(x, ln_w, mean, rstd, _A(h), _A(a), gl, _A(c), bmean, binv, bn_w, bn_b, _A(s), w_pw1, wdw, w_pw2, counts)
         ctx.meta = (training, po, so, sdo, K, fused)
         if fused:
             _chain_tag(y, rows, D, 1.0, (po, so, sdo))
         return y
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, dy):
         (x, ln_w, mean, rstd, h, a, gl, c, bmean, binv, bn_w, bn_b, s, w_pw1, wdw, w_pw2, counts) = ctx.saved_tensors
         training, po, so, sdo, K, fused = ctx.meta
@@ -1435,6 +1519,7 @@ class ScaleDropoutFn(torch.autograd.Function):
         return ops.scale_dropout(x.contiguous(), out_dtype, alpha=alpha, drop_p=pp, seed=s, seed_dev=sd)
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, dy):
         alpha, pp, s, sd, in_dtype = ctx.meta
         out = torch.float32 if in_dtype == torch.float32 else act_dtype()
@@ -1458,6 +1543,7 @@ class EmbedFn(torch.autograd.Function):
         return ops.embed_fwd(ids, table, pe[:L].contiguous(), L, scale, pp, s, sd)
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, dy):
         (ids,) = ctx.saved_tensors
         scale, pp, s, sd, tshape = ctx.meta
@@ -1494,6 +1580,7 @@ class CtcLossFn(torch.autograd.Function):
         return loss.view(())
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
         B, Tn, V, ld = ctx.meta
@@ -1530,6 +1617,7 @@ class CeSmoothFn(torch.autograd.Function):
         return loss.view(()), hits.view(())
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, g, _gh):
         (grad,) = ctx.saved_tensors
         shape, ld, denom = ctx.meta
@@ -1553,6 +1641,7 @@ class AddRowsFn(torch.autograd.Function):
                                  add=table, add_period=table.numel())
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, dy):
         scale, pp, s, sd = ctx.meta
         return ops.scale_dropout(dy.contiguous(), torch.float32, alpha=scale, drop_p=pp, seed=s, seed_dev=sd), None, None, None
@@ -1641,12 +1730,13 @@ class BasicBlockFn(torch.autograd.Function):
         else:
             r = x
         out = ops.bn_act_fwd(c2, r, m2, i2, g2, b2, rows, Cout, 1)
-        ctx.save_for_backward(x, c1, a1, c2, cd, r if wd is not None else None, w1, w2, wd, g1, b1, g2, b2, gd, bd, m1, i1,
-                              n1, m2, i2, n2, md, idd, nd)
+        ctx.save_for_backward(_A(x), _A(c1), _A(a1), _A(c2), _A(cd), _A(r) if wd is not None else None, w1, w2, wd, g1, b1, g2, b2,
+                              gd, bd, m1, i1, n1, m2, i2, n2, md, idd, nd)
         ctx.meta = (dims, stride, training, (OH, OW), bn1[2:], bn2[2:], bnd[2:] if wd is not None else None)
         return out
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, dout):
         (x, c1, a1, c2, cd, r, w1, w2, wd, g1, b1, g2, b2, gd, bd, m1, i1, n1, m2, i2, n2, md, idd, nd) = ctx.saved_tensors
         dims, stride, training, (OH, OW), r1, r2, rd = ctx.meta
@@ -1657,7 +1747,7 @@ class BasicBlockFn(torch.autograd.Function):
         T = act_dtype()
         pr = _state["precise"]
         rows = N * OH * OW
-        dout = dout.contiguous()
+        dout = _to_act(dout)
         if wd is None:
             r = x
         dc2, dr, dg2, db2 = _bn_bwd(c2, dout, r, m2, i2, (g2, b2) + r2, n2, rows, Cout, 1, True, training)
@@ -1706,8 +1796,9 @@ class StemFn(torch.autograd.Function):
         x = x.contiguous()
         taps = KT * KH * KW
         ldw = padded_cols(taps)
-        dedicated = (not pr) and (KT, KH, KW, stride, pt, ph, pw, Cout) == (5, 7, 7, 2, 2, 3, 3, 64) \
-            and W % 4 == 0 and W <= 96 and (W - 1) // 2 + 1 <= 64
+        geom_ok = (KT, KH, KW, stride, pt, ph, pw, Cout) == (5, 7, 7, 2, 2, 3, 3, 64) and W % 4 == 0 and W <= 96 \
+            and (W - 1) // 2 + 1 <= 64
+        dedicated = geom_ok and not pr
         if dedicated:  # csrc/stem.hip: input rows staged once in LDS
             c0 = ops.stem357_fwd(x, w, B, Tn, H, W)
         else:
@@ -1728,18 +1819,19 @@ class StemFn(torch.autograd.Function):
             out, idx = ops.maxpool2d_fwd(a0, B * Tn, OH, OW, Cout, 3, 2, 1)
         else:
             out = ops.bn_act_fwd(c0, None, m0, i0, g, b, rows, Cout, 1)
-        ctx.save_for_backward(x, c0, idx, g, b, m0, i0, n0, xsel)
-        ctx.meta = (geom, pool, training, bn_rest, (OH, OW), w.shape, dedicated)
+        ctx.save_for_backward(x, _A(c0), idx, g, b, m0, i0, n0, _A(xsel))
+        ctx.meta = (geom, pool, training, bn_rest, (OH, OW), w.shape, geom_ok and not _bwd_precise())
         return out
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, dout):
         x, c0, idx, g, b, m0, i0, n0, xsel = ctx.saved_tensors
         geom, pool, training, bn_rest, (OH, OW), wshape, dedicated = ctx.meta
         B, Tn, H, W, KT, KH, KW, stride, pt, ph, pw = geom
         Cout = wshape[0]
         rows = B * Tn * OH * OW
-        dout = dout.contiguous()
+        dout = _to_act(dout)
         if pool and _FUSE_STEM_POOL:
             # the activation gradient is gathered from the pooled gradient inside both BatchNorm backward passes: the
             # full-resolution gradient (396 MB per 1600 video frames) is neither written nor read back
@@ -1780,6 +1872,7 @@ class AvgPoolFn(torch.autograd.Function):
         return ops.avgpool_fwd(x.contiguous(), groups, win, C)
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, dy):
         groups, win, C, dtype, shape = ctx.meta
         return ops.avgpool_bwd(_to_f32(dy), dtype, groups, win, C).view(shape), None, None, None

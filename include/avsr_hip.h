@@ -287,7 +287,9 @@ int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int
  * 4 = 1 disables the XCD-aware work order of avsr_conv3x3_wgrad_bf16, 5 = ablation mode of avsr_conv3x3_wgrad_bf16,
  * 6 = persistent-block count of the video-stem weight gradient (0 = default 512), 7 = per-block rotation of the k order in
  * avsr_gemm_bf16_nt (0 = off; measured neutral), 8 / 9 = 1 selects the generic attention forward / backward-dq kernel for
- * bf16 inputs instead of the transposed-formulation kernels.  Knobs 0..15 exist. */
+ * bf16 inputs instead of the transposed-formulation kernels, 10 = 1 selects the generic batched TN path of
+ * avsr_attention_bwd_kv instead of the k-major tile kernel, 11 = bit mask of that kernel's contractions to skip (fault isolation).
+ * Knobs 0..15 exist. */
 int avsr_tune(int knob, int value);
 /* bf16 implicit-GEMM convolution on the tuned LDS-DMA kernel: dgrad = 0 forward, 1 data gradient (see
  * avsr_conv2d_fwd / avsr_conv2d_dgrad for the tensor conventions); gathered channel count % 64 == 0; stride 1 or 2

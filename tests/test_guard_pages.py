@@ -145,13 +145,13 @@ def _child(emu_path, case, q):
 
 
 CASES = [
-    ("attn", True, 2, 100, 100, 2, "pad", 0),
-    ("attn", True, 2, 100, 100, 2, "pad", 2),     # opt-in k-major key / value kernel
-    ("attn", True, 1, 129, 129, 1, None, 2),
+    ("attn", True, 2, 100, 100, 2, "pad", 1),     # generic key / value path
+    ("attn", True, 2, 100, 100, 2, "pad", 0),     # k-major key / value kernel (default)
+    ("attn", True, 1, 129, 129, 1, None, 0),
+    ("attn", False, 2, 33, 130, 2, "pad", 1),
     ("attn", False, 2, 33, 130, 2, "pad", 0),
-    ("attn", False, 2, 33, 130, 2, "pad", 2),
+    ("attn", False, 2, 65, 65, 2, "causal", 1),
     ("attn", False, 2, 65, 65, 2, "causal", 0),
-    ("attn", False, 2, 65, 65, 2, "causal", 2),
     ("bn_small", 1, 8, "f32"), ("bn_small", 513, 40, "bf16"), ("bn_small", 2048, 16, "f32"),
     ("targets", 3, 7), ("targets", 2, 300),
     # long-standing kernels with ragged edges (clamped / zero-page loads, pitched rows): cheap to keep under the same guard

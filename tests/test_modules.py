@@ -138,6 +138,46 @@ def test_e2e_small_bf16_mode(dev, modality):
     assert min(cos)[0] > 0.9, sorted(cos)[:5]
 
 
+@pytest.mark.parametrize("modality", ["video", "audio"])
+def test_e2e_small_hpf_mode(dev, modality):
+    """"hpf" numerical mode (functional.set_mode): the FORWARD pass is the precise one -- losses bit-identical to the precise
+    mode and within 1e-3 of the fp32 oracle (the north-star bound) -- while the backward pass runs the bf16 kernels on bf16
+    copies of the saved activations: gradients aligned with the oracle's like the bf16 mode's."""
+    torch.manual_seed(0)
+    odim = 72
+    m = no_dropout(E2E(odim, modality, adim=128, aheads=2, eunits=256, elayers=2, dunits=256, dlayers=2,
+                       cnn_module_kernel=7))
+    sd = synth_state_dict(m.state_dict(), 13)
+    m.load_state_dict(sd, strict=True)
+    m.to(dev).train()
+    x, lengths, y = synth_batch(modality, 2, 9, 4, odim, seed=8)
+    osd = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running_" not in k else v.clone())
+           for k, v in sd.items()}
+    (loss_r, ctc_r, att_r, acc_r), _ = O.e2e_forward(osd, x, lengths, y, modality=modality, heads=2)
+    loss_r.backward()
+    AF.invalidate_weight_cache()
+    with AF.precise():
+        ref = [float(v) for v in m(x.to(dev), lengths.to(dev), y.to(dev))[:3]]
+    m.load_state_dict(sd, strict=True)  # (running statistics back to the start)
+    with AF.numerics("hpf"):
+        assert AF.mode() == "hpf"
+        loss, loss_ctc, loss_att, acc = m(x.to(dev), lengths.to(dev), y.to(dev))
+        loss.backward()
+    assert AF.mode() == "bf16"
+    assert [float(loss), float(loss_ctc), float(loss_att)] == ref, "hpf forward must be the precise forward"
+    assert abs(float(loss_ctc) - float(ctc_r)) < 1e-3 * abs(float(ctc_r))
+    assert abs(float(loss_att) - float(att_r)) < 1e-3 * abs(float(att_r))
+    assert acc == acc_r
+    cos = []
+    for k, p in m.named_parameters():
+        assert p.grad is not None and p.grad.dtype == torch.float32, k
+        a, b = p.grad.double().flatten().cpu(), osd[k].grad.double().flatten()
+        if b.norm() > 1e-4 * max(1.0, float(osd[k].double().norm())):
+            cos.append((float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)), k))
+    assert min(cos)[0] > 0.9, sorted(cos)[:5]
+    AF.invalidate_weight_cache()
+
+
 def test_weight_cache_refresh(dev):
     """bf16 weight copies: lazy build, in-place refresh after an optimizer-style update, multi-tensor refresh."""
     torch.manual_seed(3)

@@ -1,5 +1,5 @@
 """Throughput of the audio-visual composition (auto_avsr_amd/e2e_av.py) at BASELINE config 5 (max-frames 3200):
-full training step (fwd + bwd + fused clip / AdamW), eager launches, one batch shape.  Not part of bench.py's contract
+full training step (fwd + bwd + fused clip / AdamW), hipGraph replay (--no-graph: eager), one batch shape.  Not part of bench.py's contract
 (the reference snapshot has no AV model to compare with).  GPU box:  python tools/bench_av.py [--frames 3200] [--steps 8]"""
 import argparse
 import os
@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--T", type=int, default=400, help="frames per utterance (SURVEY 8d: max-frames 3200 => (8, 400, 64))")
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -46,12 +47,25 @@ def main():
         opt.step()
         opt.zero_grad()
 
+    run = step
+    if not args.no_graph:  # the same capture protocol as bench.py: one eager step on a side stream, then capture
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        AF.refresh_weight_cache()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step()
+        run = g.replay
     for _ in range(args.warmup):
-        step()
+        run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     n = sum(p.numel() for p in model.parameters())
@@ -62,7 +76,7 @@ def main():
                       "value": round(B * T / dt, 1), "unit": "video-frames/sec", "n_gpus": 1, "steps": args.steps,
                       "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 2), "dtype": "bf16", "data": "synthetic",
                       "config": {"workload": f"configs[4] single-GPU leg: E2EAV {n / 1e6:.0f} M parameters, max-frames {args.frames} "
-                                             f"=> batch ({B}, {T}, {label.shape[2]}), eager launches",
+                                             f"=> batch ({B}, {T}, {label.shape[2]}), " + ("eager launches" if args.no_graph else "hipGraph replay"),
                                  "parity": "n/a (no AV model in the reference snapshot, SURVEY F4)"}}))
 
 
