@@ -20,11 +20,16 @@ constexpr int CO = 64;
 constexpr int LP = 104;                                // LDS row pitch (bf16): >= 2*47+8 and >= 4 + W (W <= 96), multiple of 8
 
 // wp[co][(kt*7+kh)*8 + 1 + kw] = w[co][0][kt][kh][kw]; zero for slot 0 and rows >= 35
+// NS = 2 (precise mode): wp[plane][...], plane 0 = hi, plane 1 = lo of the split value (prims.h split_bf16)
+template <int NS>
 __global__ void stem_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ wp) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= CO * KP) return;
     const int co = i / KP, k = i % KP, r = k >> 3, j = k & 7;
-    wp[i] = (r < ROWS && j >= 1) ? f2bf(w[(co * ROWS + r) * KW + j - 1]) : (bf16_t)0;
+    bf16_t pl[NS];
+    split_bf16<NS>((r < ROWS && j >= 1) ? w[(co * ROWS + r) * KW + j - 1] : 0.f, pl);
+#pragma unroll
+    for (int q = 0; q < NS; q++) wp[q * CO * KP + i] = pl[q];
 }
 
 // The 36 x LP bf16 patch of output row (n, oh): patch[r][4 + iw] = x[b][t+kt-2][2*oh+kh-3][iw]; output pixel ow reads the
@@ -33,10 +38,13 @@ __global__ void stem_weight_kernel(const float* __restrict__ w, bf16_t* __restri
 // row AHEAD of its use and written to LDS (patch_store) after the previous row's compute -- the global-load latency
 // of row i+1 hides behind the MFMAs of row i.
 constexpr int PATCH_V = 4;  // float4 per thread: 35 rows x (W/4 <= 24) <= 840 <= 4 * 256
+template <int NS = 1>
 AVSR_DEV void patch_init(bf16_t* patch, int W) {
     for (int i = threadIdx.x; i < 36 * LP; i += 256) {
         const int r = i / LP, c = i - r * LP;
-        if (r == 35 || c < 4 || c >= 4 + W) patch[i] = 0;
+        if (r == 35 || c < 4 || c >= 4 + W)
+#pragma unroll
+            for (int q = 0; q < NS; q++) patch[q * 36 * LP + i] = 0;
     }
 }
 AVSR_DEV void patch_load(f32x4 (&q)[PATCH_V], const float* __restrict__ x, long row, int OH, int T, int H, int W) {
@@ -56,6 +64,7 @@ AVSR_DEV void patch_load(f32x4 (&q)[PATCH_V], const float* __restrict__ x, long 
         }
     }
 }
+template <int NS = 1>
 AVSR_DEV void patch_store(bf16_t* patch, const f32x4 (&q)[PATCH_V], int W) {
     const int nv = W >> 2;
 #pragma unroll
@@ -63,8 +72,17 @@ AVSR_DEV void patch_store(bf16_t* patch, const f32x4 (&q)[PATCH_V], int W) {
         const int i = threadIdx.x + 256 * j;
         if (i < ROWS * nv) {
             const int r = i / nv, v = i - r * nv;
-            const bf16x4 o = bf16x4{(short)f2bf(q[j][0]), (short)f2bf(q[j][1]), (short)f2bf(q[j][2]), (short)f2bf(q[j][3])};
-            *reinterpret_cast<bf16x4*>(patch + r * LP + 4 + v * 4) = o;  // 8-byte aligned (LP and 4 + 4 v are multiples of 4)
+            bf16x4 o[NS];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                bf16_t pl[NS];
+                split_bf16<NS>(q[j][e], pl);
+#pragma unroll
+                for (int s = 0; s < NS; s++) o[s][e] = (short)pl[s];
+            }
+#pragma unroll
+            for (int s = 0; s < NS; s++)  // 8-byte aligned (LP and 4 + 4 v are multiples of 4)
+                *reinterpret_cast<bf16x4*>(patch + s * 36 * LP + r * LP + 4 + v * 4) = o[s];
         }
     }
 }
@@ -85,26 +103,32 @@ AVSR_DEV bf16x8 patch_frag(const bf16_t* patch, int r, int ow) {
 constexpr int FWD_ROWS = 8;  // output rows per block: the 36 KB of weights a block holds in registers are fetched once
 constexpr int OP = 72;       // pitch (bf16) of the LDS output row [pixel][64 channels]
 
+// NS = 1: bf16 operands (bench mode).  NS = 2: split hi + lo planes of the f32 input and weights, three MFMAs per product
+// (precise / hpf modes).  TO: output element type (bf16 / f32).
+template <int NS, class TO>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wp,
-                                                       bf16_t* __restrict__ y, int T, int H, int W, int OH, int OW,
+                                                       TO* __restrict__ y, int T, int H, int W, int OH, int OW,
                                                        long total_rows) {
-    __shared__ __attribute__((aligned(16))) bf16_t patch[36 * LP];
-    __shared__ __attribute__((aligned(16))) bf16_t orow[64 * OP];
+    constexpr int OPT = sizeof(TO) == 2 ? OP : 68;  // pitch of the LDS output row in elements (16-byte multiple, bank-skewed)
+    __shared__ __attribute__((aligned(16))) bf16_t patch[NS * 36 * LP];
+    __shared__ __attribute__((aligned(16))) TO orow[64 * OPT];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int quad = lane >> 4, lc = lane & 15;
     // this wave's weights: channel 16w + lc, k-step ks: taps [ks*32 + 8*quad, +8)
-    bf16x8 fb[9];
+    Frag<NS> fb[9];
 #pragma unroll
     for (int ks = 0; ks < 9; ks++)
-        fb[ks] = *reinterpret_cast<const bf16x8*>(wp + (16 * w + lc) * KP + ks * 32 + 8 * quad);
+#pragma unroll
+        for (int q = 0; q < NS; q++)
+            fb[ks].p[q] = *reinterpret_cast<const bf16x8*>(wp + q * CO * KP + (16 * w + lc) * KP + ks * 32 + 8 * quad);
     const int ntile = (OW + 15) / 16;
     const long row_end = min(total_rows, ((long)blockIdx.x + 1) * FWD_ROWS);
-    patch_init(patch, W);
+    patch_init<NS>(patch, W);
     f32x4 q[PATCH_V];
     patch_load(q, x, (long)blockIdx.x * FWD_ROWS, OH, T, H, W);
     for (long row = (long)blockIdx.x * FWD_ROWS; row < row_end; row++) {
         __syncthreads();  // the previous row's patch and output row are no longer read
-        patch_store(patch, q, W);
+        patch_store<NS>(patch, q, W);
         if (row + 1 < row_end) patch_load(q, x, row + 1, OH, T, H, W);  // in flight during this row's MFMAs
         __syncthreads();
         for (int mt = 0; mt < ntile; mt++) {
@@ -115,16 +139,26 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
             // CONSECUTIVE CHANNELS of one pixel (row 4*quad + r = channel, column lc = pixel): one 8-byte LDS store per tile
             // instead of four 2-byte ones (the 2-byte stores were a quarter of the kernel's LDS instruction issue)
 #pragma unroll
-            for (int ks = 0; ks < 9; ks++) acc = mfma16(fb[ks], patch_frag(patch, ks * 4 + quad, ow), acc);
-            const bf16x4 o = bf16x4{(short)f2bf(acc[0]), (short)f2bf(acc[1]), (short)f2bf(acc[2]), (short)f2bf(acc[3])};
-            *reinterpret_cast<bf16x4*>(orow + (mt * 16 + lc) * OP + 16 * w + 4 * quad) = o;
+            for (int ks = 0; ks < 9; ks++) {
+                Frag<NS> fx;
+#pragma unroll
+                for (int s = 0; s < NS; s++) fx.p[s] = patch_frag(patch + s * 36 * LP, ks * 4 + quad, ow);
+                acc = mma16<NS>(fb[ks], fx, acc);
+            }
+            TO* o = orow + (mt * 16 + lc) * OPT + 16 * w + 4 * quad;
+            if (sizeof(TO) == 2) {
+                *reinterpret_cast<bf16x4*>(o) = bf16x4{(short)f2bf(acc[0]), (short)f2bf(acc[1]), (short)f2bf(acc[2]), (short)f2bf(acc[3])};
+            } else {
+                *reinterpret_cast<f32x4*>(o) = acc;
+            }
         }
         __syncthreads();
-        // the four waves' 16-channel slices are now one [OW][64] row: 128-byte pixels, 16-byte stores
-        bf16_t* dst = y + (row * OW) * CO;
-        for (int i = threadIdx.x; i < OW * 8; i += 256) {
-            const int pix = i >> 3, c8 = (i & 7) * 8;
-            *reinterpret_cast<bf16x8*>(dst + pix * CO + c8) = *reinterpret_cast<const bf16x8*>(orow + pix * OP + c8);
+        // the four waves' 16-channel slices are now one [OW][64] row: whole pixels, 16-byte stores
+        TO* dst = y + (row * OW) * CO;
+        constexpr int EPC = 16 / sizeof(TO), CPP = CO / EPC;  // elements per 16-byte chunk, chunks per pixel
+        for (int i = threadIdx.x; i < OW * CPP; i += 256) {
+            const int pix = i / CPP, c = (i % CPP) * EPC;
+            *reinterpret_cast<f32x4*>(dst + pix * CO + c) = *reinterpret_cast<const f32x4*>(orow + pix * OPT + c);
         }
     }
 }
@@ -293,7 +327,7 @@ __global__ __launch_bounds__(1024) void stem_wgrad_reduce_kernel(const float* __
 }  // namespace
 
 constexpr int WG_MAX = 1024;  // upper bound of the weight-gradient grid (per-block partials live in the workspace)
-extern "C" int64_t avsr_stem357_workspace_bytes(void) { return (int64_t)WG_MAX * KP * CO * 4 + (int64_t)CO * KP * 2; }
+extern "C" int64_t avsr_stem357_workspace_bytes(void) { return (int64_t)WG_MAX * KP * CO * 4 + (int64_t)2 * CO * KP * 2; }
 
 // y[B*T, OH, OW, 64] (bf16) = conv3d(x[B,T,H,W] f32, w[64,1,5,7,7] f32), stride (1,2,2), padding (2,3,3).
 // workspace: avsr_stem357_workspace_bytes() bytes (holds the re-laid-out bf16 weights)
@@ -304,12 +338,29 @@ extern "C" int avsr_stem357_fwd(const float* x, const float* w, void* y, void* w
     if (B <= 0 || T <= 0) return 0;
     const int OH = (H + 6 - KH) / 2 + 1, OW = (W + 6 - KW) / 2 + 1;
     bf16_t* wp = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(workspace) + (size_t)WG_MAX * KP * CO * 4);
-    AVSR_LAUNCH(stem_weight_kernel, dim3((CO * KP + 255) / 256), dim3(256), 0, stream, w, wp);
+    AVSR_LAUNCH(stem_weight_kernel<1>, dim3((CO * KP + 255) / 256), dim3(256), 0, stream, w, wp);
     const long rows = (long)B * T * OH;
     AVSR_REQUIRE(OW <= 64, "stem357: at most 64 output columns");
-    AVSR_LAUNCH(stem_fwd_kernel, dim3((unsigned)((rows + FWD_ROWS - 1) / FWD_ROWS)), dim3(256), 0, stream, x, (const bf16_t*)wp,
-                (bf16_t*)y, T, H, W, OH, OW, rows);
+    AVSR_LAUNCH((stem_fwd_kernel<1, bf16_t>), dim3((unsigned)((rows + FWD_ROWS - 1) / FWD_ROWS)), dim3(256), 0, stream, x,
+                (const bf16_t*)wp, (bf16_t*)y, T, H, W, OH, OW, rows);
     AVSR_CHECK_LAUNCH("stem357_fwd");
+    return 0;
+}
+
+// The same convolution for the precise / hpf modes: y (f32) from split hi + lo bf16 planes of x and w (three MFMAs per
+// product, ~2^-16 relative error -- the arithmetic of avsr_conv_stem_fwd with precise = 1).  Same workspace.
+extern "C" int avsr_stem357_fwd_f32s(const float* x, const float* w, float* y, void* workspace, int B, int T, int H, int W,
+                                     hipStream_t stream) {
+    AVSR_REQUIRE(W % 4 == 0 && W <= 96 && H >= 1, "stem357: W must be a multiple of 4 and <= 96");
+    if (B <= 0 || T <= 0) return 0;
+    const int OH = (H + 6 - KH) / 2 + 1, OW = (W + 6 - KW) / 2 + 1;
+    bf16_t* wp = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(workspace) + (size_t)WG_MAX * KP * CO * 4);
+    AVSR_LAUNCH(stem_weight_kernel<2>, dim3((CO * KP + 255) / 256), dim3(256), 0, stream, w, wp);
+    const long rows = (long)B * T * OH;
+    AVSR_REQUIRE(OW <= 64, "stem357: at most 64 output columns");
+    AVSR_LAUNCH((stem_fwd_kernel<2, float>), dim3((unsigned)((rows + FWD_ROWS - 1) / FWD_ROWS)), dim3(256), 0, stream, x,
+                (const bf16_t*)wp, y, T, H, W, OH, OW, rows);
+    AVSR_CHECK_LAUNCH("stem357_fwd_f32s");
     return 0;
 }
 

@@ -431,6 +431,10 @@ def _gemm_nt(a, w, M, N, K, out, *, lda=None, ldc=None, **kw):
     """out[M,N] = epi(a[M,K] @ w[N,K]^T)."""
     if _fast_ok(a, K, lda) and w.dim() == 2 and w.dtype == torch.float32 and w.is_contiguous():
         return ops.gemm_bf16_nt(a, lda or K, _w_bf16(w, False), K, M, N, K, out, ldc or N, **kw)
+    if _state["precise"] and ops.SPLIT_FAST and a.dtype == torch.float32 and w.dim() == 2 and w.dtype == torch.float32 \
+            and w.is_contiguous() and K % 64 == 0 and (lda or K) % 4 == 0 and a.data_ptr() % 16 == 0:
+        # precise / hpf forward: the same split-bf16 arithmetic on the LDS-DMA operand ring (csrc/gemm_split.hip)
+        return ops.gemm_f32s_nt(a, lda or K, w, K, M, N, K, out, ldc or N, **kw)
     return ops.gemm(NT, a, lda or K, w, K, M, N, K, out, ldc or N, precise=_state["precise"], **kw)
 
 
@@ -1801,6 +1805,8 @@ class StemFn(torch.autograd.Function):
         dedicated = geom_ok and not pr
         if dedicated:  # csrc/stem.hip: input rows staged once in LDS
             c0 = ops.stem357_fwd(x, w, B, Tn, H, W)
+        elif geom_ok and pr and ops.SPLIT_FAST and x.dtype == torch.float32 and w.dtype == torch.float32:
+            c0 = ops.stem357_fwd_f32s(x, w.contiguous(), B, Tn, H, W)  # the same kernel on split hi / lo planes, f32 result
         else:
             wp = ops.conv_weight_permute(w, T, ld_out=ldw)
             c0 = ops.conv_stem_fwd(x, wp, ldw, T, B, Tn, H, W, Cout, KT, KH, KW, stride, pt, ph, pw, pr)

@@ -75,6 +75,7 @@ def _nb(*ts):
     return float(sum(t.numel() * t.element_size() for t in ts if t is not None))
 
 
+SPLIT_FAST = os.environ.get("AVSR_SPLIT_FAST", "1") != "0"  # A/B switch: precise-mode forward GEMMs / convs on csrc/gemm_split.hip
 PAIR_GEMMS = os.environ.get("AVSR_PAIR_GEMMS", "1") != "0"  # A/B switch for the paired backward GEMMs
 
 
@@ -506,6 +507,10 @@ def conv2d_fwd(x, wp, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise):
              KW, stride, ph, pw, _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin,
              nbytes=_nb(x, wp) + 2.0 * N * OH * OW * Cout)
         return y
+    if precise and SPLIT_FAST and x.dtype == torch.float32 and wp.dtype == torch.float32 and Cin % 64 == 0 and KH * KW <= 32:
+        call("avsr_conv2d_f32s", _ptr(x), _ptr(wp), _ptr(y), _ptr(zero_page(x.device)), N, H, W, Cin, Cout, KH, KW, stride,
+             ph, pw, 0, _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin, nbytes=_nb(x, wp, y))
+        return y
     call("avsr_conv2d_fwd", _ptr(x), dt(x), _ptr(wp), dt(wp), _ptr(y), N, H, W, Cin, Cout, KH, KW, stride, ph, pw,
          int(precise), _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin)
     return y
@@ -603,6 +608,18 @@ def gemm_bf16_nt(A, lda, B, ldb, M, N, K, C, ldc, *, bias=None, act=0, gate=None
     return C
 
 
+def gemm_f32s_nt(A, lda, B, ldb, M, N, K, C, ldc, *, bias=None, act=0, gate=None, ldg=0, gate_scale=1.0, drop_p=0.0,
+                 seed=0, seed_dev=None, alpha=1.0, alpha_dev=None, resid=None, ldr=0, accumulate=False, split_k=1,
+                 tile=0, colsum=None):
+    """Precise-mode NT GEMM on the LDS-DMA ring (csrc/gemm_split.hip): f32 operands, three bf16 MFMAs per product."""
+    call("avsr_gemm_f32s_nt", _ptr(A), lda, _ptr(B), ldb, M, N, K, _ptr(bias), act, _ptr(gate),
+         dt(gate) if gate is not None else 0, ldg, gate_scale, drop_p, seed, _ptr(seed_dev), alpha, _ptr(alpha_dev),
+         _ptr(resid), dt(resid) if resid is not None else 0, ldr, _ptr(C), dt(C), ldc, int(accumulate), split_k, tile,
+         _ptr(colsum), _stream(A), flops=2.0 * M * N * K,
+         nbytes=4.0 * (M * K + N * K) + float(M * N * C.element_size()) + (float(M * N * resid.element_size()) if resid is not None else 0.0))
+    return C
+
+
 def transpose_cast(src, R, Ccols, ld_src=None, pad_to=64):
     """bf16 [Ccols, ldd] = src[R, Ccols]^T with ldd = R rounded up to `pad_to` (zero tail)."""
     ldd = (R + pad_to - 1) // pad_to * pad_to
@@ -646,6 +663,16 @@ def stem357_fwd(x, w, B, T, H, W):
     y = torch.empty(B * T, OH, OW, 64, dtype=torch.bfloat16, device=x.device)
     ws = torch.empty(call("avsr_stem357_workspace_bytes") // 4 + 16, dtype=torch.float32, device=x.device)
     call("avsr_stem357_fwd", _ptr(x), _ptr(w), _ptr(y), _ptr(ws), B, T, H, W, _stream(x),
+         flops=2.0 * B * T * OH * OW * 64 * 245, nbytes=_nb(x, y))
+    return y
+
+
+def stem357_fwd_f32s(x, w, B, T, H, W):
+    """Precise-mode video stem forward (f32 result, split hi / lo bf16 planes, csrc/stem.hip)."""
+    OH, OW = conv_out(H, 7, 2, 3), conv_out(W, 7, 2, 3)
+    y = torch.empty(B * T, OH, OW, 64, dtype=torch.float32, device=x.device)
+    ws = torch.empty(call("avsr_stem357_workspace_bytes") // 4 + 16, dtype=torch.float32, device=x.device)
+    call("avsr_stem357_fwd_f32s", _ptr(x), _ptr(w), _ptr(y), _ptr(ws), B, T, H, W, _stream(x),
          flops=2.0 * B * T * OH * OW * 64 * 245, nbytes=_nb(x, y))
     return y
 

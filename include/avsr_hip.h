@@ -279,6 +279,21 @@ int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int
                       int ldr, void* C, int c_dtype, int ldc, int accumulate, int split_k, int tile,
                       float* colsum /* may be NULL: colsum[n] += sum_m C[m,n] (f32, before rounding; accumulate = 0) */,
                       avsr_stream_t stream);
+/* ---- tuned NT GEMM of the precise mode (gemm_split.hip): f32 operands, split hi + lo bf16 planes formed in registers --------- */
+/* C[M,N] = epi(A[M,K] . B[N,K]^T), A and B f32 k-contiguous (lda, ldb % 4 == 0), K % 64 == 0; three bf16 MFMAs per product
+ * (the arithmetic of avsr_gemm with precise = 1) on the LDS-DMA operand ring of avsr_gemm_bf16_nt; epilogue and arguments as
+ * avsr_gemm_bf16_nt; tile: 0 auto, 1 = 64x64 / 3 stages, 2 = 64x64 / 2 stages, 3 = 128x64 / 2 stages, 4 = 128x128 / 2 stages.
+ * Forward contractions of the precise / hpf modes: positionwise_feed_forward.py:24-30, attention.py:31-34,123,
+ * conformer_encoder.py:24,27, e2e_asr_conformer.py:31, ctc.py:21, transformer_decoder.py:225. */
+int avsr_gemm_f32s_nt(const float* A, int lda, const float* B, int ldb, int M, int N, int K, const float* bias, int act,
+                      const void* gate, int gate_dtype, int ldg, float gate_scale, float drop_p, uint64_t seed,
+                      const uint64_t* seed_dev, float alpha, const float* alpha_dev, const void* resid, int resid_dtype,
+                      int ldr, void* C, int c_dtype, int ldc, int accumulate, int split_k, int tile, float* colsum,
+                      avsr_stream_t stream);
+/* f32 convolution forward on the same kernel (implicit GEMM, channels-last, Cin % 64 == 0; frontend/resnet.py:10-35):
+ * x[N,H,W,Cin] * wp[Cout][KH][KW][Cin] -> y[N,OH,OW,Cout], all f32; zero_page: >= 16 zero bytes of device memory */
+int avsr_conv2d_f32s(const float* x, const float* wp, float* y, const void* zero_page, int N, int H, int W, int Cin, int Cout,
+                     int KH, int KW, int stride, int pad_h, int pad_w, int tile, avsr_stream_t stream);
 /* Tuning knobs of the tuned kernels (process-wide; meant for benchmarks, defaults are the measured best):
  * knob 0 = tile code forced on avsr_conv2d_bf16 (0 = auto), 1 = XCD-aware tile order (0 = automatic: on for the 64x64 GEMM tile, whose
  * operands are not cache-resident in the training step; 1 = always on; 2 = always off),
@@ -319,6 +334,9 @@ int avsr_stem357_fwd(const float* x, const float* w, void* y, void* workspace, i
                      avsr_stream_t stream);
 int avsr_stem357_wgrad(const void* dy, const float* x, float* dw, void* workspace, int B, int T, int H, int W,
                        avsr_stream_t stream);
+/* precise / hpf modes: the same convolution with an f32 result from split hi + lo bf16 planes (three MFMAs per product) */
+int avsr_stem357_fwd_f32s(const float* x, const float* w, float* y, void* workspace, int B, int T, int H, int W,
+                          avsr_stream_t stream);
 
 /* bf16 weight-gradient contraction without transposed copies (gemm_tn_fast.hip: LDS-DMA k-major tiles +
  * ds_read_b64_tr_b16): C[M][N] (f32, ldc) (+)= sum_k A[k][m] B[k][n]; A [K][lda], B [K][ldb] bf16.

@@ -76,6 +76,31 @@ def test_conv2d_bf16_tiles(dev, cfg, tile):
     assert (dx.float().cpu() - nhwc(x.grad) - res.float()).abs().max() < 4e-2 * max(1.0, x.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("cfg", [(5, 9, 10, 64, 128, 3, 1, 1), (4, 11, 12, 128, 64, 3, 2, 1), (9, 7, 7, 64, 192, 1, 2, 0),
+                                 (2, 1, 37, 64, 64, 3, 2, 1)])
+def test_conv2d_f32_split_forward(dev, cfg):
+    """Precise-mode forward convolution on the LDS-DMA ring (gemm_split.hip CV = 1) vs torch conv2d in f32 and vs the generic
+    precise kernel it replaces (AVSR_SPLIT_FAST switch)."""
+    N, H, W, Cin, Cout, K, s, p = cfg
+    torch.manual_seed(N)
+    KH, ph = (1, 0) if H == 1 else (K, p)
+    x = torch.randn(N, Cin, H, W)
+    w = torch.randn(Cout, Cin, KH, K) / (Cin * KH * K) ** 0.5
+    y_ref = F.conv2d(x.double(), w.double(), stride=s, padding=(ph, p)).float()
+    xd = nhwc(x).to(dev)
+    wp = ops.conv_weight_permute(w.to(dev), torch.float32)
+    assert ops.SPLIT_FAST
+    y = ops.conv2d_fwd(xd, wp, N, H, W, Cin, Cout, KH, K, s, ph, p, True)
+    ops.SPLIT_FAST = False
+    try:
+        yg = ops.conv2d_fwd(xd, wp, N, H, W, Cin, Cout, KH, K, s, ph, p, True)
+    finally:
+        ops.SPLIT_FAST = True
+    scale = max(1.0, y_ref.abs().max().item())
+    assert (y.cpu() - nhwc(y_ref)).abs().max() < 2e-5 * scale
+    assert (y.cpu() - yg.cpu()).abs().max() < 2e-6 * scale
+
+
 @pytest.mark.parametrize("cfg", [
     # N, H, W, Cin, Cout, stride -- trunk geometries in miniature: row bands (tall images), several whole images per
     # tile (small images), ragged last band / last image group, stride 2 with odd and even extents
@@ -187,3 +212,16 @@ def test_stem357_dedicated(dev):
     dyd = dy.permute(0, 2, 3, 4, 1).reshape(ref.shape).contiguous().bfloat16().to(dev)
     dw = ops.stem357_wgrad(dyd, x.to(dev), B, T, H, W)
     assert (dw.cpu() - wq.grad).abs().max() < 2e-2 * max(1.0, wq.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("geom", [(2, 4, 20, 24), (1, 3, 88, 88)])
+def test_stem357_split_forward(dev, geom):
+    """Precise-mode video stem on the dedicated kernel (split hi / lo planes, f32 result) vs torch conv3d in f64."""
+    torch.manual_seed(7)
+    B, T, H, W = geom
+    x = torch.randn(B, T, H, W)
+    w = torch.randn(64, 1, 5, 7, 7) / 245 ** 0.5
+    y_ref = F.conv3d(x.double().unsqueeze(1), w.double(), stride=(1, 2, 2), padding=(2, 3, 3)).float()
+    y = ops.stem357_fwd_f32s(x.to(dev), w.to(dev), B, T, H, W)
+    ref = y_ref.permute(0, 2, 3, 4, 1).reshape(B * T, y_ref.shape[3], y_ref.shape[4], 64)
+    assert y.dtype == torch.float32 and (y.cpu() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())

@@ -144,6 +144,39 @@ def test_gemm_fast_nt(dev, tile, shape):
     assert ((C3.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-6
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("shape", [(150, 70, 192), (200, 130, 64), (257, 300, 448)])
+def test_gemm_split_f32_nt(dev, tile, shape):
+    """Precise-mode NT kernel on the LDS-DMA ring (gemm_split.hip): f32 operands, split hi / lo bf16 planes formed on the
+    fragments, three MFMAs per product -- f32-class accuracy vs fp64 (same bound as the generic precise kernel), pitched
+    operands, all tiles, ragged M / N, ring depths shorter and longer than the k loop, epilogue, split-K, column sums."""
+    M, N, K = shape
+    torch.manual_seed(M + tile)
+    A, B = torch.randn(M, K), torch.randn(N, K)
+    ref = A.double() @ B.double().t()
+    Ap = torch.zeros(M, K + 8)
+    Ap[:, :K] = A
+    C = torch.zeros(M, N + 3, device=dev)
+    ops.gemm_f32s_nt(Ap.to(dev), K + 8, B.to(dev), K, M, N, K, C, N + 3, tile=tile)
+    assert ((C.cpu()[:, :N].double() - ref).abs().max() / ref.abs().max()) < 2e-5
+    assert C.cpu()[:, N:].abs().max() == 0
+    # the generic precise kernel does the same arithmetic: results agree to summation order
+    Cg = torch.zeros(M, N, device=dev)
+    ops.gemm(0, A.to(dev), K, B.to(dev), K, M, N, K, Cg, N, precise=True)
+    assert ((C.cpu()[:, :N] - Cg.cpu()).abs().max() / ref.abs().max()) < 2e-6
+    bias, resid = torch.randn(N), torch.randn(M, N)
+    C2 = torch.zeros(M, N, device=dev)
+    cs = torch.full((N,), 3.0, device=dev)
+    ops.gemm_f32s_nt(A.to(dev), K, B.to(dev), K, M, N, K, C2, N, bias=bias.to(dev), act=1, alpha=0.5,
+                     resid=resid.to(dev), ldr=N, tile=tile, colsum=cs)
+    ref2 = torch.relu(ref + bias.double()) * 0.5 + resid.double()
+    assert ((C2.cpu().double() - ref2).abs().max() / ref2.abs().max()) < 2e-5
+    assert ((cs.cpu().double() - 3.0 - ref2.sum(0)).abs().max() / ref2.sum(0).abs().max()) < 1e-4
+    C3 = torch.zeros(M, N, device=dev)
+    ops.gemm_f32s_nt(A.to(dev), K, B.to(dev), K, M, N, K, C3, N, accumulate=True, split_k=3, tile=tile)
+    assert ((C3.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-5
+
+
 def test_transpose_cast(dev):
     torch.manual_seed(9)
     x = torch.randn(150, 70)
