@@ -9,10 +9,10 @@
 // element into k-contiguous LDS tiles and gathers the skewed dS operand of the position term with eight guarded scalar
 // loads per chunk: 61 us per encoder layer at T = 400 against 24 us for the whole forward kernel.
 //
-// The position term contracts over (b, q) jointly: one block owns a 64-band x 64 tile of dpos[h] for ALL batch items,
-// so nothing but that block ever adds to it.  Its A operand A[(b,q)][band] = dS[b,q][band + q - (Tq-1)] is a row of dS
-// shifted by a per-row offset, i.e. eight elements at a 2-byte-aligned address (out of reach of LDS-DMA): fetched as aligned
-// dwords and funnel-shifted in registers.
+// The position term: block (b, h, band tile) contracts batch item b's queries and ADDS into dpos[h] (f32 atomics); of the
+// Tq queries only those whose key index band + q - (Tq-1) falls into [0, Tk) are visited.  Its A operand
+// A[q][band] = dS[b,q][band + q - (Tq-1)] is a row of dS shifted by a per-row offset, i.e. eight elements at a 2-byte-aligned
+// address (out of reach of LDS-DMA): fetched as aligned dwords and funnel-shifted in registers.
 //
 // pd / ds pad columns [Tk, lds) are never written by the producer: the position term masks them, the other two contractions
 // only let them reach output rows >= Tk, which are not stored.
@@ -46,20 +46,20 @@ AVSR_DEV void kv_block(const KvParams& p, char* smem) {
     const int m0 = blockIdx.x * 64;
     const int lane = threadIdx.x & 63, wave = wave_id();
     const int wm = wave >> 1, wn = wave & 1;
-    int M, K, b = 0, h;
-    if (which < 2) {
-        b = blockIdx.y / p.H;
-        h = blockIdx.y - b * p.H;
-        M = p.Tk;
-        K = p.Tq;
-    } else {
-        h = blockIdx.y;
-        if (h >= p.H) return;
-        M = 2 * p.Tq - 1;
-        K = p.B * p.Tq;
-    }
+    // every contraction runs per (batch item, head); the position term's blocks ADD their batch item's share into dpos[h]
+    // (f32 atomics of the accumulate epilogue; the first version gave one block all B * Tq rows of a band tile: 156 long
+    // blocks were the launch's critical path, 37 us at B = 4, T = 400)
+    const int b = blockIdx.y / p.H, h = blockIdx.y - b * p.H;
+    const int M = which < 2 ? p.Tk : 2 * p.Tq - 1, K = p.Tq;
     if (m0 >= M) return;
-    const int nt = (K + 63) / 64;
+    int t_lo = 0, nt = (K + 63) / 64;
+    if (which == 2) {
+        // band rows m0 .. m0+63 only meet queries q with a key index j = m + q - (Tq-1) in [0, Tk): skip the k-tiles outside
+        const int q_lo = max(0, p.Tq - 1 - m0 - 63), q_hi = min(p.Tq, p.Tq - 1 - m0 + p.Tk);  // [q_lo, q_hi)
+        if (q_hi <= q_lo) return;
+        t_lo = q_lo / 64;
+        nt = (q_hi + 63) / 64;
+    }
     const bf16_t* Abase = (which == 0 ? p.pd : p.ds) + ((long)b * p.H + h) * p.Tq * p.lds;  // which < 2
     const bf16_t* Bbase = which == 0 ? p.dout + b * p.sbo + h * 64 : p.qu + b * p.sbq + h * 64;
     const int ldb = which == 0 ? p.ldo : p.ldq;
@@ -76,7 +76,7 @@ AVSR_DEV void kv_block(const KvParams& p, char* smem) {
                 if (m0 + chunk < p.lds) ra[i] = *reinterpret_cast<const bf16x8*>(Abase + (long)k * p.lds + m0 + chunk);
                 rb[i] = *reinterpret_cast<const bf16x8*>(Bbase + (long)k * ldb + chunk);
             } else {
-                const int bb = k / p.Tq, q = k - bb * p.Tq;
+                const int bb = b, q = k;
                 const bf16_t* row = p.ds + (((long)bb * p.H + h) * p.Tq + q) * p.lds;
                 const int j = m0 + chunk + q - (p.Tq - 1);  // key index of band column m0 + chunk for this query
                 const int jb = j & ~1;  // even element index: a 4-byte-aligned address (rows start 16-byte aligned)
@@ -125,10 +125,10 @@ AVSR_DEV void kv_block(const KvParams& p, char* smem) {
     f32x16 acc[1][1];
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[0][0][r] = 0.f;
-    fetch(0);
-    commit(smem);
+    fetch(t_lo);
+    commit(smem + (t_lo & 1) * KV_STAGE_BYTES);
     __syncthreads();
-    for (int t = 0; t < nt; t++) {
+    for (int t = t_lo; t < nt; t++) {
         const char* As = smem + (t & 1) * KV_STAGE_BYTES;
         const char* Bs = As + KV_OP_BYTES;
         if (t + 1 < nt) fetch(t + 1);  // in flight during the multiply

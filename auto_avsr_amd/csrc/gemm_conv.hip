@@ -62,6 +62,24 @@ __global__ __launch_bounds__(256) void weight_permute_kernel(const float* __rest
         Elem<TO>::st(out + (long)a * ld_out + (long)tap * Bc + b, w[((long)co * Cin + ci) * taps + tap]);
     }
 }
+// the same permutation into the split8 layout (gemm_split.hip: every 8 consecutive elements of the dense [a][tap][b] order
+// as 8 hi bf16 + 8 lo bf16) -- the pre-split weight operand of the precise-mode forward convolution
+__global__ __launch_bounds__(256) void weight_permute_split_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout,
+                                                                   int Cin, int taps, int to_dgrad) {
+    const long total = (long)Cout * Cin * taps;
+    const int Bc = to_dgrad ? Cout : Cin;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int b = (int)(i % Bc);
+        const int tap = (int)((i / Bc) % taps);
+        const int a = (int)(i / ((long)Bc * taps));
+        const int co = to_dgrad ? b : a, ci = to_dgrad ? a : b;
+        bf16_t pl[2];
+        split_bf16<2>(w[((long)co * Cin + ci) * taps + tap], pl);
+        bf16_t* blk = out + (i >> 3) * 16 + (i & 7);
+        blk[0] = pl[0];
+        blk[8] = pl[1];
+    }
+}
 // every conv weight of the model in ONE launch (the per-step refresh of the bf16 [Cout][taps][Cin] / [Cin][taps][Cout]
 // copies): table entries {w, out, Cout, Cin, taps, to_dgrad, blk0}, 2048 output elements per block
 struct AvsrPermEntry {
@@ -110,7 +128,10 @@ extern "C" int avsr_conv_weight_permute(const float* w, void* out, int out_dtype
     if (total <= 0) return 0;
     long nb = (total + 255) / 256;
     dim3 grid((unsigned)(nb > 2048 ? 2048 : nb)), block(256);
-    if (out_dtype == 0)
+    if (out_dtype == 2) {
+        AVSR_REQUIRE(total % 8 == 0 && ld_out == (int64_t)taps * (to_dgrad ? Cout : Cin), "conv_weight_permute: split8 output must be dense");
+        AVSR_LAUNCH(weight_permute_split_kernel, grid, block, 0, stream, w, (bf16_t*)out, Cout, Cin, taps, to_dgrad);
+    } else if (out_dtype == 0)
         AVSR_LAUNCH((weight_permute_kernel<float>), grid, block, 0, stream, w, (float*)out, Cout, Cin, taps, to_dgrad, (long)ld_out);
     else
         AVSR_LAUNCH((weight_permute_kernel<bf16_t>), grid, block, 0, stream, w, (bf16_t*)out, Cout, Cin, taps, to_dgrad, (long)ld_out);

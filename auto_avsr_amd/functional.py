@@ -159,6 +159,74 @@ _wconv_table = {"n": 0, "dev": None, "blocks": 0, "built_for": -1}
 
 _wgen = {"cleared": 0, "owner": None, "owner_gen": None, "dirty": 0}
 
+# ---- pre-split weights of the precise / hpf forward pass (csrc/gemm_split.hip, split8 layout) ---------------------------------
+# The B operand of every forward contraction is a parameter: its hi / lo bf16 planes are formed once per step (ONE multi-tensor
+# launch for all Linear-type weights, one small launch per conv weight for the permuted copies) instead of on every fragment
+# of every tile that reads it.  Cached per parameter version like the bf16 copies; addresses stay stable for captured graphs.
+_SPLIT_W = os.environ.get("AVSR_SPLIT_WEIGHTS", "1") != "0"
+_wsplit = {}    # (data_ptr, shape) -> [version, Split8 copy, weight]
+_wsplit_conv = {}  # (data_ptr, shape) -> [version, Split8 permuted copy, conv weight]
+_wsplit_table = {"n": 0, "dev": None, "blocks": 0, "built_for": -1}
+
+
+def _refresh_split_weights():
+    for ent in _wsplit_conv.values():
+        ops.conv_weight_permute_split(ent[2], out=ent[1])
+        ent[0] = ent[2]._version
+    if not _wsplit:
+        return
+    if _wsplit_table["built_for"] != len(_wsplit):
+        import struct
+
+        blob, blk = b"", 0
+        for ent in _wsplit.values():
+            n = ent[2].numel()
+            blob += struct.pack("<QQqq", ent[2].data_ptr(), ent[1].data_ptr(), n // 8, blk)
+            blk += (n + 2047) // 2048
+        dev = next(iter(_wsplit.values()))[2].device
+        host = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+        _wsplit_table.update(n=len(_wsplit), dev=host.to(dev), blocks=blk, built_for=len(_wsplit))
+    ops.multi_split_pack(_wsplit_table["dev"], _wsplit_table["n"], _wsplit_table["blocks"])
+    for ent in _wsplit.values():
+        ent[0] = ent[2]._version
+
+
+def _w_split(w2d):
+    """split8 copy of a Linear-type weight [out, in] (in % 32 == 0), or None when the layout does not apply."""
+    if not _SPLIT_W or w2d.numel() % 32 or w2d.shape[-1] % 32 or not w2d.is_contiguous() or w2d.dtype != torch.float32:
+        return None
+    if _wgen["dirty"]:
+        refresh_weight_cache()
+    key = (w2d.data_ptr(), tuple(w2d.shape))
+    ent = _wsplit.get(key)
+    if ent is not None and ent[0] == w2d._version:
+        return ent[1]
+    if ent is None:
+        ent = _wsplit[key] = [-1, ops.split_pack(w2d), w2d]
+        _wsplit_table["built_for"] = -1
+    else:
+        ops.split_pack(w2d, out=ent[1])
+    ent[0] = w2d._version
+    return ent[1]
+
+
+def _w_conv_split(w):
+    """split8 copy of the permuted ([Cout][taps][Cin]) conv weight, or None."""
+    if not _SPLIT_W or w.dtype != torch.float32 or not w.is_contiguous() or w.numel() % 32 or w.shape[1] % 32:
+        return None
+    if _wgen["dirty"]:
+        refresh_weight_cache()
+    key = (w.data_ptr(), tuple(w.shape))
+    ent = _wsplit_conv.get(key)
+    if ent is not None and ent[0] == w._version:
+        return ent[1]
+    if ent is None:
+        ent = _wsplit_conv[key] = [-1, ops.conv_weight_permute_split(w), w]
+    else:
+        ops.conv_weight_permute_split(w, out=ent[1])
+    ent[0] = w._version
+    return ent[1]
+
 
 def cached_weight_ptrs():
     """(generation, addresses of every parameter that has a cached bf16 copy: Linear-type, conv-type)."""
@@ -207,6 +275,9 @@ def invalidate_weight_cache():
     _wcache.clear()
     _wcat.clear()
     _wconv.clear()
+    _wsplit.clear()
+    _wsplit_conv.clear()
+    _wsplit_table.update(n=0, dev=None, blocks=0, built_for=-1)
     _wgen["cleared"] += 1
     _wgen["owner"] = None
     _wgen["dirty"] = 0
@@ -256,6 +327,16 @@ def _w_conv(w, to_dgrad):
     return ent[1]
 
 
+def _w_conv_fwd(w, x):
+    """Forward operand of a convolution weight in the current mode: bf16 / f32 permuted copy, or -- precise mode, shapes the
+    split kernel takes -- its pre-split (split8) form."""
+    if _state["precise"] and ops.SPLIT_FAST and x.dtype == torch.float32 and w.shape[1] % 64 == 0 and w[0, 0].numel() <= 32:
+        ws = _w_conv_split(w)
+        if ws is not None:
+            return ws
+    return _w_conv(w, False)
+
+
 def refresh_weight_cache(force=False):
     """Rebuild every registered bf16 weight copy in place with ONE multi-tensor launch (what a training step needs
     after the optimizer changed the weights).  Falls back to lazy per-weight casts until weights are registered.
@@ -263,6 +344,8 @@ def refresh_weight_cache(force=False):
     load_state_dict -- detected through the tensor version in _w_bf16)."""
     dirty, _wgen["dirty"] = _wgen["dirty"], 0
     _refresh_conv_weights()
+    if _state["precise"] and (_wsplit or _wsplit_conv):
+        _refresh_split_weights()
     if not _wcache:
         return
     owner = _wgen["owner"]() if _wgen["owner"] is not None else None
@@ -434,7 +517,8 @@ def _gemm_nt(a, w, M, N, K, out, *, lda=None, ldc=None, **kw):
     if _state["precise"] and ops.SPLIT_FAST and a.dtype == torch.float32 and w.dim() == 2 and w.dtype == torch.float32 \
             and w.is_contiguous() and K % 64 == 0 and (lda or K) % 4 == 0 and a.data_ptr() % 16 == 0:
         # precise / hpf forward: the same split-bf16 arithmetic on the LDS-DMA operand ring (csrc/gemm_split.hip)
-        return ops.gemm_f32s_nt(a, lda or K, w, K, M, N, K, out, ldc or N, **kw)
+        ws = _w_split(w)
+        return ops.gemm_f32s_nt(a, lda or K, ws if ws is not None else w, K, M, N, K, out, ldc or N, **kw)
     return ops.gemm(NT, a, lda or K, w, K, M, N, K, out, ldc or N, precise=_state["precise"], **kw)
 
 
@@ -1720,15 +1804,15 @@ class BasicBlockFn(torch.autograd.Function):
         rows = N * OH * OW
         bn1 = (g1, b1) + bn1
         bn2 = (g2, b2) + bn2
-        c1 = ops.conv2d_fwd(x, _w_conv(w1, False), N, H, W, Cin, Cout, KH, KW, stride, ph, pw, pr)
+        c1 = ops.conv2d_fwd(x, _w_conv_fwd(w1, x), N, H, W, Cin, Cout, KH, KW, stride, ph, pw, pr)
         m1, i1, n1 = _bn_fwd_params(c1, rows, Cout, bn1, training)
         a1 = ops.bn_act_fwd(c1, None, m1, i1, g1, b1, rows, Cout, 1)
-        c2 = ops.conv2d_fwd(a1, _w_conv(w2, False), N, OH, OW, Cout, Cout, KH, KW, 1, ph, pw, pr)
+        c2 = ops.conv2d_fwd(a1, _w_conv_fwd(w2, a1), N, OH, OW, Cout, Cout, KH, KW, 1, ph, pw, pr)
         m2, i2, n2 = _bn_fwd_params(c2, rows, Cout, bn2, training)
         cd = md = idd = nd = None
         if wd is not None:
             bnd = (gd, bd) + bnd
-            cd = ops.conv2d_fwd(x, _w_conv(wd, False), N, H, W, Cin, Cout, 1, 1, stride, 0, 0, pr)
+            cd = ops.conv2d_fwd(x, _w_conv_fwd(wd, x), N, H, W, Cin, Cout, 1, 1, stride, 0, 0, pr)
             md, idd, nd = _bn_fwd_params(cd, rows, Cout, bnd, training)
             r = ops.bn_act_fwd(cd, None, md, idd, gd, bd, rows, Cout, 0)
         else:

@@ -462,6 +462,35 @@ def conv_weight_permute(w, out_dtype, to_dgrad=False, ld_out=None):
     return out
 
 
+class Split8(torch.Tensor):
+    """Marker type of a buffer in the split8 layout (csrc/gemm_split.hip): an f32-shaped tensor whose every group of 8
+    consecutive elements holds 8 hi bf16 + 8 lo bf16 of the values it replaces.  Only the precise-mode GEMM / convolution
+    entry points read it (as their pre-split B operand)."""
+
+
+def conv_weight_permute_split(w, to_dgrad=False, out=None):
+    """conv_weight_permute into the split8 layout ([Cout][taps*Cin] f32-shaped buffer)."""
+    Cout, Cin = w.shape[0], w.shape[1]
+    taps = w[0, 0].numel()
+    a, b = (Cin, Cout) if to_dgrad else (Cout, Cin)
+    if out is None:
+        out = torch.empty(a, taps * b, dtype=torch.float32, device=w.device).as_subclass(Split8)
+    call("avsr_conv_weight_permute", _ptr(w), _ptr(out), 2, Cout, Cin, taps, int(to_dgrad), taps * b, _stream(w))
+    return out
+
+
+def split_pack(src, out=None):
+    """f32 tensor (numel % 8 == 0, contiguous) -> the same shape in the split8 layout."""
+    if out is None:
+        out = torch.empty(src.shape, dtype=torch.float32, device=src.device).as_subclass(Split8)
+    call("avsr_split_pack", _ptr(src), _ptr(out), src.numel(), _stream(src), nbytes=8.0 * src.numel())
+    return out
+
+
+def multi_split_pack(table_dev, n, blocks):
+    call("avsr_multi_split_pack", _ptr(table_dev), n, blocks, _stream(table_dev))
+
+
 def conv_weight_unpermute(dwp, shape):
     Cout, Cin = shape[0], shape[1]
     taps = 1
@@ -509,7 +538,8 @@ def conv2d_fwd(x, wp, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise):
         return y
     if precise and SPLIT_FAST and x.dtype == torch.float32 and wp.dtype == torch.float32 and Cin % 64 == 0 and KH * KW <= 32:
         call("avsr_conv2d_f32s", _ptr(x), _ptr(wp), _ptr(y), _ptr(zero_page(x.device)), N, H, W, Cin, Cout, KH, KW, stride,
-             ph, pw, 0, _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin, nbytes=_nb(x, wp, y))
+             ph, pw, 0, int(isinstance(wp, Split8)), _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin,
+             nbytes=_nb(x, wp, y))
         return y
     call("avsr_conv2d_fwd", _ptr(x), dt(x), _ptr(wp), dt(wp), _ptr(y), N, H, W, Cin, Cout, KH, KW, stride, ph, pw,
          int(precise), _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin)
@@ -615,7 +645,7 @@ def gemm_f32s_nt(A, lda, B, ldb, M, N, K, C, ldc, *, bias=None, act=0, gate=None
     call("avsr_gemm_f32s_nt", _ptr(A), lda, _ptr(B), ldb, M, N, K, _ptr(bias), act, _ptr(gate),
          dt(gate) if gate is not None else 0, ldg, gate_scale, drop_p, seed, _ptr(seed_dev), alpha, _ptr(alpha_dev),
          _ptr(resid), dt(resid) if resid is not None else 0, ldr, _ptr(C), dt(C), ldc, int(accumulate), split_k, tile,
-         _ptr(colsum), _stream(A), flops=2.0 * M * N * K,
+         _ptr(colsum), int(isinstance(B, Split8)), _stream(A), flops=2.0 * M * N * K,
          nbytes=4.0 * (M * K + N * K) + float(M * N * C.element_size()) + (float(M * N * resid.element_size()) if resid is not None else 0.0))
     return C
 

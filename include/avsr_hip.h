@@ -231,7 +231,8 @@ int avsr_log_softmax(const float* x, int64_t ld, float* lse_ws, float* out, int6
 
 /* ---- implicit-GEMM convolutions on channels-last activations (gemm_conv.hip) -------------------- */
 /* torch weight [Cout][Cin][taps] (f32) -> out[a][tap][b] with row pitch ld_out, a/b = co/ci (to_dgrad=0: forward and
- * weight-gradient layout) or ci/co (to_dgrad=1: data-gradient layout), cast to out_dtype */
+ * weight-gradient layout) or ci/co (to_dgrad=1: data-gradient layout), cast to out_dtype (0 f32, 1 bf16, 2 = the split8 layout of
+ * avsr_split_pack over the dense [a][tap][b] order; ld_out must then be taps * b) */
 int avsr_conv_weight_permute(const float* w, void* out, int out_dtype, int Cout, int Cin, int taps, int to_dgrad,
                              int64_t ld_out, avsr_stream_t stream);
 /* dw[Cout][Cin][taps] = dwp[Cout][taps][Cin] */
@@ -282,18 +283,26 @@ int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int
 /* ---- tuned NT GEMM of the precise mode (gemm_split.hip): f32 operands, split hi + lo bf16 planes formed in registers --------- */
 /* C[M,N] = epi(A[M,K] . B[N,K]^T), A and B f32 k-contiguous (lda, ldb % 4 == 0), K % 64 == 0; three bf16 MFMAs per product
  * (the arithmetic of avsr_gemm with precise = 1) on the LDS-DMA operand ring of avsr_gemm_bf16_nt; epilogue and arguments as
- * avsr_gemm_bf16_nt; tile: 0 auto, 1 = 64x64 / 3 stages, 2 = 64x64 / 2 stages, 3 = 128x64 / 2 stages, 4 = 128x128 / 2 stages.
+ * avsr_gemm_bf16_nt; tile: 0 auto, 1 = 64x64 / 3 stages, 2 = 64x64 / 2 stages, 3 = 128x64 / 2 stages, 4 = 128x128 / 2 stages,
+ * 5 / 6 = 3 / 4 with 3 stages, 7 = 128x64 / 2 stages with a 4 x 1 wave grid, 11 .. 16 = 1 .. 6 with the staged A tile converted to
+ * split8 in place once per stage (the default) instead of on every fragment read.
  * Forward contractions of the precise / hpf modes: positionwise_feed_forward.py:24-30, attention.py:31-34,123,
  * conformer_encoder.py:24,27, e2e_asr_conformer.py:31, ctc.py:21, transformer_decoder.py:225. */
 int avsr_gemm_f32s_nt(const float* A, int lda, const float* B, int ldb, int M, int N, int K, const float* bias, int act,
                       const void* gate, int gate_dtype, int ldg, float gate_scale, float drop_p, uint64_t seed,
                       const uint64_t* seed_dev, float alpha, const float* alpha_dev, const void* resid, int resid_dtype,
                       int ldr, void* C, int c_dtype, int ldc, int accumulate, int split_k, int tile, float* colsum,
-                      avsr_stream_t stream);
+                      int b_split /* 1: B is in the split8 layout of avsr_split_pack (same pitch) */, avsr_stream_t stream);
+/* split8 layout: every group of 8 consecutive f32 of a buffer replaced, in place of its 32 bytes, by its 8 hi bf16 followed
+ * by its 8 lo bf16 (hi = bf16(x), lo = bf16(x - hi)); n % 8 == 0.  avsr_multi_split_pack: many tensors in one launch, table
+ * of 32-byte entries {const float* src, void* dst, int64 n / 8, int64 blk0}, blk0 = running sum of ceil(n / 2048). */
+int avsr_split_pack(const float* src, void* dst, int64_t n, avsr_stream_t stream);
+int avsr_multi_split_pack(const void* table, int n, int total_blocks, avsr_stream_t stream);
 /* f32 convolution forward on the same kernel (implicit GEMM, channels-last, Cin % 64 == 0; frontend/resnet.py:10-35):
  * x[N,H,W,Cin] * wp[Cout][KH][KW][Cin] -> y[N,OH,OW,Cout], all f32; zero_page: >= 16 zero bytes of device memory */
 int avsr_conv2d_f32s(const float* x, const float* wp, float* y, const void* zero_page, int N, int H, int W, int Cin, int Cout,
-                     int KH, int KW, int stride, int pad_h, int pad_w, int tile, avsr_stream_t stream);
+                     int KH, int KW, int stride, int pad_h, int pad_w, int tile, int w_split /* 1: wp in the split8 layout */,
+                     avsr_stream_t stream);
 /* Tuning knobs of the tuned kernels (process-wide; meant for benchmarks, defaults are the measured best):
  * knob 0 = tile code forced on avsr_conv2d_bf16 (0 = auto), 1 = XCD-aware tile order (0 = automatic: on for the 64x64 GEMM tile, whose
  * operands are not cache-resident in the training step; 1 = always on; 2 = always off),

@@ -99,6 +99,8 @@ def test_conv2d_f32_split_forward(dev, cfg):
     scale = max(1.0, y_ref.abs().max().item())
     assert (y.cpu() - nhwc(y_ref)).abs().max() < 2e-5 * scale
     assert (y.cpu() - yg.cpu()).abs().max() < 2e-6 * scale
+    ys = ops.conv2d_fwd(xd, ops.conv_weight_permute_split(w.to(dev)), N, H, W, Cin, Cout, KH, K, s, ph, p, True)
+    assert torch.equal(ys.cpu(), y.cpu()), "pre-split weights must give bit-identical results"
 
 
 @pytest.mark.parametrize("cfg", [

@@ -144,7 +144,7 @@ def test_gemm_fast_nt(dev, tile, shape):
     assert ((C3.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-6
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 11, 12, 13, 14, 15, 16])
 @pytest.mark.parametrize("shape", [(150, 70, 192), (200, 130, 64), (257, 300, 448)])
 def test_gemm_split_f32_nt(dev, tile, shape):
     """Precise-mode NT kernel on the LDS-DMA ring (gemm_split.hip): f32 operands, split hi / lo bf16 planes formed on the
@@ -175,6 +175,12 @@ def test_gemm_split_f32_nt(dev, tile, shape):
     C3 = torch.zeros(M, N, device=dev)
     ops.gemm_f32s_nt(A.to(dev), K, B.to(dev), K, M, N, K, C3, N, accumulate=True, split_k=3, tile=tile)
     assert ((C3.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-5
+    # B pre-split into hi / lo planes (split8 layout, what the weights of the precise forward pass use): the same products
+    Bs = ops.split_pack(B.to(dev))
+    assert isinstance(Bs, ops.Split8) and Bs.shape == B.shape
+    C4 = torch.zeros(M, N + 3, device=dev)
+    ops.gemm_f32s_nt(Ap.to(dev), K + 8, Bs, K, M, N, K, C4, N + 3, tile=tile)
+    assert torch.equal(C4.cpu(), C.cpu()), "pre-split B must give bit-identical results"
 
 
 def test_transpose_cast(dev):
