@@ -103,6 +103,10 @@ bool launch_tile(int tile, Params& p, int split_k, hipStream_t stream) {
 
 }  // namespace
 
+int avsr_conv3x3_c64_supported(int H, int W);
+int avsr_conv3x3_c64_launch(int flip, const void* src, const void* wq, const void* resid, void* out, const void* zero_page, int N,
+                            int H, int W, hipStream_t stream);
+
 extern "C" int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
                                  int act, const void* gate, int gate_dtype, int ldg, float gate_scale, float drop_p,
                                  uint64_t seed, const uint64_t* seed_dev, float alpha, const float* alpha_dev,
@@ -155,6 +159,14 @@ extern "C" int avsr_conv2d_bf16(int dgrad, const void* src, const void* wp, cons
     AVSR_REQUIRE(stride == 1 || (stride == 2 && KH <= 8 && KW <= 8), "conv2d_bf16: stride must be 1 or 2");
     AVSR_REQUIRE((long)N * H * W < (1l << 31) && (long)N * OH * OW < (1l << 31), "conv2d_bf16: pixel count exceeds int32");
     if (N <= 0) return 0;
+    // 64 -> 64 channels, 3x3 / stride 1 / pad 1 (the trunk's first stage): weights in registers, patch-staged persistent kernel
+    // (conv3x3_c64.hip); knob 12 = 1 keeps the tiled kernel for A/B runs
+    if (Cin == 64 && Cout == 64 && KH == 3 && KW == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && g_tune[12] != 1 &&
+        avsr_conv3x3_c64_supported(H, W)) {
+        avsr_conv3x3_c64_launch(dgrad, src, wp, resid, out, zero_page, N, H, W, stream);
+        AVSR_CHECK_LAUNCH("conv2d_bf16");
+        return 0;
+    }
     Params p{};
     p.A = src; p.B = wp;
     p.K = KH * KW * Cg; p.lda = Cg; p.ldb = p.K;

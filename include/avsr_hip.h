@@ -312,8 +312,8 @@ int avsr_conv2d_f32s(const float* x, const float* wp, float* y, const void* zero
  * 6 = persistent-block count of the video-stem weight gradient (0 = default 512), 7 = per-block rotation of the k order in
  * avsr_gemm_bf16_nt (0 = off; measured neutral), 8 / 9 = 1 selects the generic attention forward / backward-dq kernel for
  * bf16 inputs instead of the transposed-formulation kernels, 10 = 1 selects the generic batched TN path of
- * avsr_attention_bwd_kv instead of the k-major tile kernel, 11 = bit mask of that kernel's contractions to skip (fault isolation).
- * Knobs 0..15 exist. */
+ * avsr_attention_bwd_kv instead of the k-major tile kernel, 11 = bit mask of that kernel's contractions to skip (fault isolation),
+ * 12 = 1 keeps 64 -> 64 channel 3x3 / stride-1 convolutions on the tiled kernel instead of conv3x3_c64.hip.  Knobs 0..15 exist. */
 int avsr_tune(int knob, int value);
 /* bf16 implicit-GEMM convolution on the tuned LDS-DMA kernel: dgrad = 0 forward, 1 data gradient (see
  * avsr_conv2d_fwd / avsr_conv2d_dgrad for the tensor conventions); gathered channel count % 64 == 0; stride 1 or 2

@@ -227,3 +227,37 @@ def test_stem357_split_forward(dev, geom):
     y = ops.stem357_fwd_f32s(x.to(dev), w.to(dev), B, T, H, W)
     ref = y_ref.permute(0, 2, 3, 4, 1).reshape(B * T, y_ref.shape[3], y_ref.shape[4], 64)
     assert y.dtype == torch.float32 and (y.cpu() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("cfg", [(3, 22, 22), (2, 9, 10), (5, 1, 37), (2, 30, 12), (300, 7, 5), (1100, 6, 4)])
+def test_conv3x3_c64_persistent(dev, cfg):
+    """64 -> 64 channel 3x3 / stride-1 convolution on the weights-in-registers, patch-staged persistent kernel
+    (conv3x3_c64.hip; forward and data gradient + residual) vs torch conv2d autograd on bf16-rounded operands and vs the
+    tiled kernel it replaces (avsr_tune knob 12): several bands per image, ragged last band, more tiles than blocks."""
+    N, H, W = cfg
+    torch.manual_seed(H * 100 + W)
+    C = 64
+    x = torch.randn(N, C, H, W).bfloat16().float().requires_grad_()
+    w = torch.randn(C, C, 3, 3) / (C * 9) ** 0.5
+    wq = w.bfloat16().float()
+    y_ref = F.conv2d(x, wq, stride=1, padding=1)
+    dy = torch.randn_like(y_ref).bfloat16().float()
+    y_ref.backward(dy)
+    xd = nhwc(x.detach()).bfloat16().to(dev)
+    dyd = nhwc(dy).bfloat16().to(dev)
+    res = torch.randn(N, H, W, C).bfloat16()
+    wp = ops.conv_weight_permute(w.to(dev), torch.bfloat16)
+    wpd = ops.conv_weight_permute(w.to(dev), torch.bfloat16, to_dgrad=True)
+    outs = []
+    try:
+        for knob in (0, 1):
+            ops.tune(12, knob)
+            y = ops.conv2d_fwd(xd, wp, N, H, W, C, C, 3, 3, 1, 1, 1, False)
+            dx = ops.conv2d_dgrad(dyd, wpd, res.to(dev), N, H, W, C, C, 3, 3, 1, 1, 1, False)
+            outs.append((y.float().cpu(), dx.float().cpu()))
+    finally:
+        ops.tune(12, 0)
+    (y, dx), (yt, dxt) = outs
+    assert (y - nhwc(y_ref.detach())).abs().max() < 2e-2 * max(1.0, y_ref.abs().max().item())
+    assert (dx - nhwc(x.grad) - res.float()).abs().max() < 4e-2 * max(1.0, x.grad.abs().max().item())
+    assert (y - yt).abs().max() < 2e-2 * max(1.0, y_ref.abs().max().item()) and (dx - dxt).abs().max() < 4e-2 * max(1.0, x.grad.abs().max().item())
