@@ -628,6 +628,9 @@ def _chain_tag(y, rows, n, alpha, drop):
     """Forward of a sub-layer: y is its (f32 residual-stream) output, (alpha, drop) the epilogue of its output Linear."""
     if not _CHAIN or _state["precise"] or y.dtype != torch.float32 or n % 8:
         return
+    if not _state.get("tag_ok", True):
+        return  # the sub-layer runs under no_grad (evaluation / decoding): no backward pass will ever consume the tag, it
+                # would only keep the activation alive (beam search with the decoder cache piled up hundreds of them)
     if len(_chain_spec) > 512:
         _chain_spec.clear()
     p, sd, sdev = drop
@@ -762,7 +765,7 @@ def _to_act_shared(x):
     key = (x.data_ptr(), tuple(x.shape), x.dtype, act_dtype(), x._version)
     ent = _shared_act.get(key)
     if ent is None:
-        if len(_shared_act) > 8:
+        if len(_shared_act) > (8 if x.requires_grad else 2):  # decoding never calls new_step(): keep the cache tiny there
             _shared_act.clear()
         ent = _shared_act[key] = (x, ops.scale_dropout(x.contiguous(), act_dtype()))
     return ent[1]
@@ -962,6 +965,7 @@ class FfnSublayerFn(torch.autograd.Function):
 
 
 def ffn_sublayer(x, ln_w, ln_b, w1, b1, w2, b2, scale, p, eps=1e-12):
+    _state["tag_ok"] = torch.is_grad_enabled()
     return FfnSublayerFn.apply(_to_f32(x), ln_w, ln_b, w1, b1, w2, b2, float(scale), float(p), eps)
 
 
@@ -1360,6 +1364,7 @@ class MhaSublayerFn(torch.autograd.Function):
 def mha_sublayer(x, memory, pos_emb, mask, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, wpos, bias_u, bias_v, H, p_attn,
                  p_out, eps=1e-12, kv=None):
     """kv = (kv_all, slot, holder) from memory_kv(): source attention reads its K / V from the all-layer projection."""
+    _state["tag_ok"] = torch.is_grad_enabled()
     if kv is not None:
         return MhaSublayerFn.apply(_to_f32(x), None, pos_emb, mask, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, wpos,
                                    bias_u, bias_v, H, float(p_attn), float(p_out), eps, kv[0], kv[1], kv[2])
@@ -1589,6 +1594,7 @@ def conv_sublayer(x, ln_w, ln_b, w_pw1, b_pw1, w_dw, b_dw, bn, w_pw2, b_pw2, p_o
     """bn: the torch.nn.BatchNorm1d module holding weight / bias / running stats (updated in place in training).
     ln_w = ln_b = None gives the bare module (no LayerNorm, no residual, no output dropout)."""
     training = bn.training
+    _state["tag_ok"] = torch.is_grad_enabled()
     momentum = bn.momentum if bn.momentum is not None else 0.1
     # the batch counter of the BatchNorm is incremented by its statistics kernel (bn_finalize)
     return ConvSublayerFn.apply(_to_f32(x), ln_w, ln_b, w_pw1, b_pw1, w_dw, b_dw, bn.weight, bn.bias, bn.running_mean,

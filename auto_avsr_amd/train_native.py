@@ -46,10 +46,19 @@ def load_checkpoint(path, model, opt):
 
     ck = torch.load(path, map_location="cpu")
     model.load_state_dict({k[len("model."):]: v for k, v in ck["state_dict"].items() if k.startswith("model.")})
+    global_step = int(ck.get("global_step", 0))
     if "optimizer" in ck:
         opt.load_state_dict(ck["optimizer"])
+    else:
+        # a weights-only file (an `epoch=N.ckpt` written without optimizer state, a Lightning checkpoint whose
+        # `optimizer_states` use torch's layout): the moments restart from zero, but the step counter -- which drives the
+        # warm-up / cosine schedule and Adam's bias correction -- must not: continue it from the stored global step
+        import warnings
+
+        warnings.warn(f"{path}: no native optimizer state; resuming with zero Adam moments at step {global_step} of the schedule")
+        opt.state[0] = float(global_step)
     AF.invalidate_weight_cache()  # every cached bf16 copy belongs to the old weights
-    return int(ck.get("epoch", -1)) + 1, int(ck.get("global_step", 0))
+    return int(ck.get("epoch", -1)) + 1, global_step
 
 
 @torch.no_grad()

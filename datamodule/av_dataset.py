@@ -42,8 +42,17 @@ def load_audio(path):
 
 
 class AVDataset(torch.utils.data.Dataset):
+    """Items are RAW: {"input": decoded clip [T, 3, H, W] uint8 / waveform [T, 1] f32 on the HOST, "target": token ids}.
+    The reference applies `video_transform` / `audio_transform` here, on the CPU, inside DataLoader workers; this build's
+    transforms are device kernels (auto_avsr_amd/transforms.py, csrc/augment.hip), which can run neither on host tensors nor in
+    forked workers -- so decoding stays in `__getitem__` (workers welcome) and `DataModule` applies the transform + padding
+    collation as ONE launch per batch in the main process, after the upload (`raw = True` tells it to).  The two transform
+    objects are kept for the reference's constructor signature and carry the configuration (subset, noise, target SNR)."""
+
+    raw = True
+
     def __init__(self, root_dir, label_path, subset, modality, audio_transform, video_transform, rate_ratio=640):
-        self.root_dir, self.modality, self.rate_ratio = root_dir, modality, rate_ratio
+        self.root_dir, self.modality, self.rate_ratio, self.subset = root_dir, modality, rate_ratio, subset
         self.list = self.load_list(label_path)
         self.input_lengths = [int(row[2]) for row in self.list]
         self.audio_transform, self.video_transform = audio_transform, video_transform
@@ -61,8 +70,8 @@ class AVDataset(torch.utils.data.Dataset):
         dataset_name, rel_path, _, token_id = self.list[idx]
         path = os.path.join(self.root_dir, dataset_name, rel_path)
         if self.modality == "video":
-            return {"input": self.video_transform(load_video(path)), "target": token_id}
-        return {"input": self.audio_transform(load_audio(path)), "target": token_id}
+            return {"input": load_video(path), "target": token_id}
+        return {"input": load_audio(path), "target": token_id}
 
     def __len__(self):
         return len(self.list)

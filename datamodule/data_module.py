@@ -36,6 +36,41 @@ def collate_pad(batch):
     return res
 
 
+class DeviceBatches:
+    """Iterates a DataLoader of RAW items (AVDataset) and finishes every item in the MAIN process: upload, then the
+    reference's per-sample transform chain + padding collation as one device launch per batch (transforms.video_batch /
+    audio_batch).  `single` = the test loader (one utterance per item, no padding)."""
+
+    def __init__(self, loader, dataset, device, single=False):
+        self.loader, self.ds, self.device, self.single = loader, dataset, torch.device(device), single
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _inputs(self, raws):
+        from auto_avsr_amd import transforms as TR
+
+        xs = [r.to(self.device, non_blocking=True) for r in raws]
+        if self.ds.modality == "video":
+            return TR.video_batch(xs, self.ds.video_transform.subset)
+        at = self.ds.audio_transform
+        return TR.audio_batch(xs, at.subset, at.add_noise)
+
+    def __iter__(self):
+        for item in self.loader:
+            if self.single:
+                x, _ = self._inputs([item["input"]])
+                yield {"input": x[0], "target": item["target"].to(self.device)}
+                continue
+            x, lens = self._inputs([s["input"] for s in item])
+            t, tl = pad([s["target"].to(self.device) for s in item], -1)
+            yield {"inputs": x, "input_lengths": torch.tensor(lens), "targets": t, "target_lengths": torch.tensor(tl)}
+
+
+def _identity(x):
+    return x
+
+
 class CustomBucketDataset(torch.utils.data.Dataset):
     """Pre-formed batches: sort into `num_buckets` length buckets, pack greedily up to `max_frames` real frames."""
 
@@ -59,13 +94,15 @@ class DataModule(_DMBase):
     IS a batch), the test loader yields single utterances.  `args.synthetic_utterances = n` (an extra of this build)
     replaces the file-backed AVDataset by n synthetic utterances."""
 
-    def __init__(self, args=None, batch_size=None, train_num_buckets=50, train_shuffle=True, num_workers=10):
+    def __init__(self, args=None, batch_size=None, train_num_buckets=50, train_shuffle=True, num_workers=10, device=None):
         super().__init__()
         self.args = args
         self.batch_size = batch_size
         self.train_num_buckets = train_num_buckets
         self.train_shuffle = train_shuffle
         self.num_workers = num_workers
+        # where the input transforms run (file-backed datasets): the GPU; the CPU only through the test suite's emulator build
+        self.device = device or getattr(args, "device", None) or ("cuda" if torch.cuda.is_available() else "cpu")
 
     def _dataset(self, subset, label_file):
         from .av_dataset import AVDataset, SyntheticAVDataset
@@ -74,28 +111,40 @@ class DataModule(_DMBase):
         n_syn = getattr(self.args, "synthetic_utterances", 0)
         if n_syn:
             return SyntheticAVDataset(n_syn, self.args.modality, seed={"train": 0, "val": 1, "test": 2}[subset])
-        if subset == "test":
-            at = AudioTransform("test", snr_target=getattr(self.args, "decode_snr_target", 999999))
+        # only the transform of the selected modality is built (the audio one loads the babble recording, which is data and
+        # not part of this repository); at test time noise is added only for a real target SNR (999999 = the reference's "clean")
+        at = vt = None
+        if self.args.modality == "video":
+            vt = VideoTransform(subset)
+        elif subset == "test":
+            snr = getattr(self.args, "decode_snr_target", 999999)
+            at = AudioTransform("test", snr_target=snr if snr is not None and snr < 999999 else None)
         else:
             at = AudioTransform(subset)
         return AVDataset(root_dir=self.args.root_dir, label_path=os.path.join(self.args.root_dir, "labels", label_file),
-                         subset=subset, modality=self.args.modality, audio_transform=at,
-                         video_transform=VideoTransform(subset))
+                         subset=subset, modality=self.args.modality, audio_transform=at, video_transform=vt)
+
+    def _finish(self, loader, dataset, single=False):
+        return DeviceBatches(loader, dataset, self.device, single) if getattr(dataset, "raw", False) else loader
 
     def _workers(self):
         return 0 if getattr(self.args, "synthetic_utterances", 0) else self.num_workers
 
     def train_dataloader(self):
-        ds = self._dataset("train", self.args.train_file)
-        ds = CustomBucketDataset(ds, ds.input_lengths, self.args.max_frames, self.train_num_buckets,
+        base = self._dataset("train", self.args.train_file)
+        ds = CustomBucketDataset(base, base.input_lengths, self.args.max_frames, self.train_num_buckets,
                                  batch_size=self.batch_size)
-        return torch.utils.data.DataLoader(ds, num_workers=self._workers(), batch_size=None, shuffle=self.train_shuffle,
-                                           collate_fn=collate_pad)
+        raw = getattr(base, "raw", False)
+        return self._finish(torch.utils.data.DataLoader(ds, num_workers=self._workers(), batch_size=None, shuffle=self.train_shuffle,
+                                                        collate_fn=_identity if raw else collate_pad), base)
 
     def val_dataloader(self):
-        ds = self._dataset("val", self.args.val_file)
-        ds = CustomBucketDataset(ds, ds.input_lengths, 1000, 1, batch_size=self.batch_size)
-        return torch.utils.data.DataLoader(ds, batch_size=None, num_workers=self._workers(), collate_fn=collate_pad)
+        base = self._dataset("val", self.args.val_file)
+        ds = CustomBucketDataset(base, base.input_lengths, 1000, 1, batch_size=self.batch_size)
+        raw = getattr(base, "raw", False)
+        return self._finish(torch.utils.data.DataLoader(ds, batch_size=None, num_workers=self._workers(),
+                                                        collate_fn=_identity if raw else collate_pad), base)
 
     def test_dataloader(self):
-        return torch.utils.data.DataLoader(self._dataset("test", self.args.test_file), batch_size=None)
+        base = self._dataset("test", self.args.test_file)
+        return self._finish(torch.utils.data.DataLoader(base, batch_size=None), base, single=True)

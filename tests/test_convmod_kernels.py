@@ -234,6 +234,44 @@ def test_bn_pool_bwd_fused_matches_three_pass(dev, dtype):
         assert ((dx1.view(-1, C) - dx0).abs() <= 1e-4 * dx0.abs().clamp_min(1.0)).all()
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+def test_bn_act_pool_chain_vs_torch_autograd(dev, dtype):
+    """The fused stem chain as the product runs it (StemFn: batch statistics -> bn_act_pool_fwd -> backward reduce on the pooled
+    tensors through xsel -> bn_pool_bwd_apply) DIRECTLY against torch in fp64: BatchNorm2d in training mode + SiLU +
+    MaxPool2d(3, 2, 1) under autograd -- forward values, the input gradient through the batch statistics, and the affine
+    parameter gradients.  (The two tests above compare this path with the unfused kernels only.)"""
+    torch.manual_seed(11)
+    N, H, W, C = 3, 10, 12, 64
+    x = (torch.randn(N, H, W, C) * 1.5 + 0.3).to(dtype)
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C) * 0.2
+    xr = x.double().permute(0, 3, 1, 2).contiguous().requires_grad_()
+    bn = torch.nn.BatchNorm2d(C, eps=1e-5, momentum=0.1).double().train()
+    with torch.no_grad():
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    y_ref = torch.nn.functional.max_pool2d(torch.nn.functional.silu(bn(xr)), 3, 2, 1)
+    dpool = torch.randn(y_ref.shape).to(dtype)
+    y_ref.backward(dpool.double())
+    rows = N * H * W
+    xd = x.to(dev)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    mean, invstd = ops.bn_stats_finalize(xd.view(-1, C), rows, C, 1e-5, 0.1, rm, rv)
+    g, b = gamma.to(dev), beta.to(dev)
+    y, idx, xsel = ops.bn_act_pool_fwd(xd, mean, invstd, g, b, N, H, W, C, 3, 2, 1, 1, want_xsel=True)
+    dp = dpool.permute(0, 2, 3, 1).contiguous().to(dev)
+    sums = ops.bn_bwd_reduce(xsel.view(-1, C), dp.view(-1, C), None, mean, invstd, g, b, dp.numel() // C, C, 1)
+    dx = ops.bn_pool_bwd_apply(xd, dp, idx, mean, invstd, g, b, sums, 1.0 / rows, N, H, W, C, 3, 2, 1, 1)
+    tol = 3e-2 if dtype == torch.bfloat16 else 2e-5
+
+    def relerr(a, ref):
+        return float((a.double().cpu() - ref.double()).norm() / ref.double().norm())
+
+    assert relerr(y.float(), y_ref.detach().permute(0, 2, 3, 1)) < tol
+    assert relerr(dx.float().view(N, H, W, C), xr.grad.permute(0, 2, 3, 1)) < tol
+    assert relerr(sums[1], bn.weight.grad) < tol and relerr(sums[0], bn.bias.grad) < tol
+    assert (rm.cpu() - bn.running_mean.float()).abs().max() < 1e-5 and (rv.cpu() - bn.running_var.float()).abs().max() < 1e-4
+
+
 @pytest.mark.parametrize("rows,C,dtype", [(1, 8, torch.float32), (37, 64, torch.float32), (1600, 256, torch.bfloat16),
                                           (2048, 16, torch.float32), (513, 40, torch.bfloat16)])
 def test_batchnorm_single_launch_small(dev, rows, C, dtype):

@@ -1,0 +1,82 @@
+"""File-backed data path (datamodule/av_dataset.py AVDataset behind DataModule's three loaders): decoding on the host, the
+reference's transforms + collation on the device, in the main process.  Audio reads real wav files written by the test; video
+decoding needs torchvision (absent), so `load_video` is replaced by a synthetic decoder -- everything downstream is the product."""
+import os
+import types
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+from auto_avsr_amd import transforms as TR
+
+
+def _write_tree(root, n, modality):
+    os.makedirs(os.path.join(root, "labels"), exist_ok=True)
+    os.makedirs(os.path.join(root, "lrs3", "clips"), exist_ok=True)
+    rng = np.random.default_rng(0)
+    rows, wavs = [], {}
+    for i in range(n):
+        frames = int(rng.integers(5, 14))
+        rel = f"clips/u{i}.mp4"
+        pcm = (rng.standard_normal(frames * 640) * 3000).astype("<i2")
+        with wave.open(os.path.join(root, "lrs3", rel[:-4] + ".wav"), "wb") as f:
+            f.setnchannels(1)
+            f.setsampwidth(2)
+            f.setframerate(16000)
+            f.writeframes(pcm.tobytes())
+        wavs[rel] = pcm
+        ids = " ".join(str(int(v)) for v in rng.integers(1, 30, size=max(1, frames // 3)))
+        rows.append(f"lrs3,{rel},{frames},{ids}")
+    for name in ("train.csv", "val.csv", "test.csv"):
+        with open(os.path.join(root, "labels", name), "w") as f:
+            f.write("\n".join(rows))
+    return rows, wavs
+
+
+@pytest.mark.parametrize("modality", ["audio", "video"])
+def test_datamodule_file_backed_loaders(dev, tmp_path, monkeypatch, modality):
+    from datamodule import av_dataset
+    from datamodule.data_module import DataModule
+
+    root = str(tmp_path)
+    rows, wavs = _write_tree(root, 7, modality)
+    clips = {}
+
+    def fake_load_video(path):  # [T, 3, 96, 96] uint8, as torchvision.io.read_video(...).permute(0, 3, 1, 2) would give
+        rel = os.path.relpath(path, os.path.join(root, "lrs3"))
+        t = int([r for r in rows if rel in r][0].split(",")[2])
+        g = torch.Generator().manual_seed(len(rel) + t)
+        clips[rel] = torch.randint(0, 256, (t, 96, 96, 3), generator=g, dtype=torch.uint8)
+        return clips[rel].permute(0, 3, 1, 2)
+
+    monkeypatch.setattr(av_dataset, "load_video", fake_load_video)
+    args = types.SimpleNamespace(root_dir=root, modality=modality, train_file="train.csv", val_file="val.csv", test_file="test.csv",
+                                 max_frames=30, synthetic_utterances=0)
+    dm = DataModule(args, num_workers=0, device=str(dev))
+    if modality == "audio":
+        monkeypatch.setattr(TR, "load_default_noise", lambda: torch.randn(1, 40000, generator=torch.Generator().manual_seed(3)))
+    seen = 0
+    for b in dm.train_dataloader():
+        B = b["inputs"].shape[0]
+        assert b["inputs"].device.type == dev.type and b["targets"].shape[:2] == (B, 1)
+        per = 640 if modality == "audio" else 1
+        assert b["inputs"].shape[1] == int(b["input_lengths"].max()) and int(b["input_lengths"].sum()) // per <= 30
+        assert b["inputs"].shape[2:] == ((1,) if modality == "audio" else (1, 88, 88))
+        assert torch.isfinite(b["inputs"].float()).all()
+        seen += B
+    assert seen == 7
+    val = list(dm.val_dataloader())
+    assert sum(v["inputs"].shape[0] for v in val) == 7
+    tests = list(dm.test_dataloader())
+    assert len(tests) == 7
+    # the evaluation transforms are deterministic: the loader's item equals the transform applied by hand
+    rel = rows[0].split(",")[1]
+    if modality == "audio":
+        wav = torch.from_numpy(wavs[rel].astype(np.float32) / 32768.0).view(-1, 1)
+        want = TR.AudioTransform("test")(wav.to(dev))
+    else:
+        want = TR.VideoTransform("test")(clips[rel].permute(0, 3, 1, 2).to(dev))
+    assert torch.equal(tests[0]["input"].cpu(), want.cpu())
+    assert tests[0]["target"].tolist() == [int(v) for v in rows[0].split(",")[3].split()]

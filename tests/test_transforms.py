@@ -148,3 +148,65 @@ def test_pad_targets():
     out, lens = TR.pad_targets([torch.tensor([3, 4, 5]), torch.tensor([7])])
     want, wl = TO.pad([torch.tensor([3, 4, 5]), torch.tensor([7])], -1)
     assert torch.equal(out, want) and lens == wl
+
+
+# ---------------------------------------------------------------------------------------------- third-party known answers
+def _third_party():
+    import json
+
+    return json.load(open(os.path.join(HERE, "golden", "golden_thirdparty_v1.json")))
+
+
+def test_third_party_ops_oracle_known_answers():
+    """The five torchvision / torchaudio operations of the reference's input path (absent from the reference tree and from this
+    image) against known-answer vectors computed from their PUBLISHED definitions with exact rational arithmetic
+    (tests/golden/make_golden_thirdparty.py) -- the oracle's restatements, one by one."""
+    g = _third_party()
+    rgb = torch.tensor(g["rgb"], dtype=torch.float32).view(-1, 3, 1, 1) / 255.0
+    gray = TO.rgb_to_grayscale(rgb).flatten()
+    assert (gray - torch.tensor(g["gray"])).abs().max() < 2e-7
+    assert (TO.normalize(gray, 0.421, 0.165) - torch.tensor(g["gray_normalized"])).abs().max() < 2e-6
+    for c in g["center_crop"]:
+        assert TO.center_crop_params(c["H"], c["W"], c["size"]) == (c["top"], c["left"])
+    for c in g["random_crop"]:
+        torch.manual_seed(c["seed"])
+        assert TO.random_crop_params(c["H"], c["W"], c["size"]) == (c["i"], c["j"])
+    for c in g["add_noise"]:
+        y = TO.add_noise(torch.tensor([c["x"]], dtype=torch.float32), torch.tensor([c["n"]], dtype=torch.float32),
+                         torch.tensor([float(c["snr_db"])]))
+        assert (y[0] - torch.tensor(c["y"])).abs().max() < 1e-5 * max(abs(v) for v in c["y"])
+
+
+def test_third_party_ops_kernels_known_answers(dev):
+    """The same known answers through the PRODUCT (csrc/augment.hip): constant-colour clips through the evaluation pipeline
+    (CenterCrop -> Grayscale -> Normalize, transforms.py:100-105) must give the hand-computed luma, normalised; the train
+    pipeline's crop origin must be RandomCrop.get_params's draw (a clip whose pixel values encode their own coordinates);
+    AddNoise at a fixed SNR on a constant noise recording must give add_noise's closed form (before the final layer norm,
+    which is undone here with the known mean / variance of the expected signal)."""
+    g = _third_party()
+    for (r, gg, b), want in zip(g["rgb"], g["gray_normalized"]):
+        clip = torch.tensor([r, gg, b], dtype=torch.uint8).view(1, 1, 1, 3).expand(2, 96, 96, 3).contiguous()
+        out = TR.VideoTransform("val")(clip.to(dev).permute(0, 3, 1, 2)).cpu()
+        assert tuple(out.shape) == (2, 1, 88, 88) and (out - want).abs().max() < 2e-6, (r, gg, b)
+    # crop origin: red channel = row index, green = column index, blue = 0  ->  luma(i + y, j + x) identifies (i, j)
+    yy, xx = torch.meshgrid(torch.arange(96), torch.arange(96), indexing="ij")
+    clip = torch.stack([yy, xx, torch.zeros_like(yy)], dim=-1).to(torch.uint8).unsqueeze(0).contiguous()
+    for c in g["random_crop"]:
+        seed_all(c["seed"])
+        torch.manual_seed(c["seed"])
+        out = TR.VideoTransform("train")(clip.to(dev).permute(0, 3, 1, 2)).cpu()[0, 0]
+        luma = out * 0.165 + 0.421
+        if float(out.abs().max()) and not bool((out == (0.0 - 0.421) / 0.165).all()):  # (a one-frame clip may be time-masked)
+            want00 = (0.2989 * c["i"] + 0.587 * c["j"]) / 255.0
+            assert abs(float(luma[0, 0]) - want00) < 1e-5, (c, float(luma[0, 0]), want00)
+    for c in g["add_noise"]:
+        x = torch.tensor(c["x"], dtype=torch.float32).view(-1, 1)
+        n = torch.tensor([c["n"]], dtype=torch.float32)
+        seed_all(0)
+        tr = TR.AudioTransform("val", snr_target=c["snr_db"] if c["snr_db"] else None, noise=n.to(dev))
+        if not c["snr_db"]:  # snr_target = 0 means "none" to the reference's truthiness test (transforms.py:72): plain layer norm
+            continue
+        out = tr(x.to(dev)).cpu().flatten()
+        y = torch.tensor(c["y"], dtype=torch.float64)
+        want = (y - y.mean()) / torch.sqrt(y.var(unbiased=False) + 1e-8)
+        assert (out.double() - want).abs().max() < 2e-5
