@@ -252,7 +252,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(const T* __restr
                                                                 const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, T* __restrict__ y,
-                                                                long rows, int C, int act) {
+                                                                long rows, int C, int act, bf16_t* __restrict__ y2 = nullptr) {
     const int cv = C >> 3;
     const long nvec = rows * cv;
     for (long i = (long)blockIdx.x * BN_THREADS + threadIdx.x; i < nvec; i += (long)gridDim.x * BN_THREADS) {
@@ -267,6 +267,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(const T* __restr
 #pragma unroll
         for (int e = 0; e < 8; e++) o[e] = act_fwd((v[e] - mu[e]) * is[e] * ga[e] + be[e] + (add ? ad[e] : 0.f), act);
         store8(y + i * 8, o);
+        if (y2) store8(y2 + i * 8, o);  // bf16 twin (hpf mode)
     }
 }
 
@@ -893,6 +894,18 @@ extern "C" int avsr_bn_act_fwd(const void* x, const void* add, int dtype, const 
         AVSR_LAUNCH((bn_act_fwd_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)add, mean,
                     invstd, gamma, beta, (bf16_t*)y, (long)rows, C, act);
     AVSR_CHECK_LAUNCH("bn_act_fwd");
+    return 0;
+}
+
+// f32 in / f32 out + the bf16 twin of the output in one pass (the "hpf" numerical mode)
+extern "C" int avsr_bn_act_fwd2(const float* x, const float* add, const float* mean, const float* invstd, const float* gamma,
+                                const float* beta, float* y, void* y2, int64_t rows, int C, int act, hipStream_t stream) {
+    AVSR_REQUIRE(C % 8 == 0, "batchnorm: C must be a multiple of 8");
+    if (rows <= 0) return 0;
+    dim3 grid(ew_grid(rows * (C >> 3))), block(BN_THREADS);
+    AVSR_LAUNCH((bn_act_fwd_kernel<float>), grid, block, 0, stream, x, add, mean, invstd, gamma, beta, y, (long)rows, C, act,
+                (bf16_t*)y2);
+    AVSR_CHECK_LAUNCH("bn_act_fwd2");
     return 0;
 }
 

@@ -45,6 +45,8 @@ struct Params {
     const float* resid;  // v += resid[m,ldr]
     int ldr;
     void* C;
+    void* C2;  // LDS epilogue, non-accumulating f32 outputs: bf16 twin of the stored values (same shape, pitch ldc2) or null
+    int ldc2;
     int c_dtype, ldc;
     int accumulate;  // f32 C only: atomicAdd (needed for split-K; also "+=" semantics)
     // batching over (b, h): blockIdx.z = (b*batch_h + h)*nsplit + ksplit; strides in elements
@@ -297,6 +299,14 @@ AVSR_DEV void epilogue_lds(f32x16 (&acc)[TM][TN], const Params& p, int m0, int n
             for (int e = 0; e < 8; e++) cs[e] += e < nv ? v[e] : 0.f;
         }
         const size_t co = c_off + (size_t)row * p.ldc + col;
+        if (p.C2) {
+            bf16_t* c2 = reinterpret_cast<bf16_t*>(p.C2) + c_off + (size_t)row * p.ldc2 + col;
+            if (full && p.ldc2 % 8 == 0 && (c_off % 8) == 0) {
+                store8(c2, v);
+            } else {
+                for (int e = 0; e < nv; e++) c2[e] = f2bf(v[e]);
+            }
+        }
         if (p.c_dtype == 0) {
             float* cp = reinterpret_cast<float*>(p.C) + co;
             if (p.accumulate) {

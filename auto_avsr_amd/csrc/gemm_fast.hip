@@ -137,7 +137,7 @@ extern "C" int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
         // measured on MI355X (tools/microbench_tiles.py): two or three co-resident blocks per CU beat one block with a
         // deeper ring at every size -- 128x128 / 128x64 with a 2-stage ring (2 / 3 blocks per CU) once the grid fills the
         // chip, 64x64 with 3 stages (3 blocks per CU) for the skinny M = B*T GEMMs of the transformer layers
-        tile = t128 >= 1024 ? 4 : (t12864 >= 400 ? 7 : 1);
+        tile = t128 >= 1024 ? 4 : (t12864 >= 400 ? 7 : (g_tune[14] > 0 && (long)((M + 63) / 64) * ((N + 63) / 64) > 256 ? g_tune[14] : 1));  // knob 14: A/B of the tile for grids of 257+ 64x64 tiles
     }
     if (avsr_pair::stash_nt(p, tile, split_k, stream)) return 0;  // launched by avsr_gemm_pair_end (gemm_pair.hip)
     AVSR_REQUIRE(launch_tile<0>(tile, p, split_k, stream), "gemm_bf16_nt: unknown tile code");

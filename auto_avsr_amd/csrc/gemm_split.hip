@@ -346,8 +346,9 @@ extern "C" int avsr_gemm_f32s_nt(const float* A, int lda, const float* B, int ld
                                  int act, const void* gate, int gate_dtype, int ldg, float gate_scale, float drop_p,
                                  uint64_t seed, const uint64_t* seed_dev, float alpha, const float* alpha_dev,
                                  const void* resid, int resid_dtype, int ldr, void* C, int c_dtype, int ldc, int accumulate,
-                                 int split_k, int tile, float* colsum, int b_split, hipStream_t stream) {
+                                 int split_k, int tile, float* colsum, int b_split, void* c2, int ldc2, hipStream_t stream) {
     AVSR_REQUIRE(!(colsum && accumulate), "gemm_f32s_nt: colsum needs a non-accumulating output");
+    AVSR_REQUIRE(!(c2 && (accumulate || c_dtype != 0)), "gemm_f32s_nt: the bf16 twin needs a non-accumulating f32 output");
     AVSR_REQUIRE(K > 0 && K % 64 == 0, "gemm_f32s_nt: K must be a positive multiple of 64");
     AVSR_REQUIRE(lda % 4 == 0 && ldb % 4 == 0, "gemm_f32s_nt: lda/ldb must be multiples of 4 elements");
     AVSR_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "gemm_f32s_nt: operands must be 16-byte aligned");
@@ -364,6 +365,7 @@ extern "C" int avsr_gemm_f32s_nt(const float* A, int lda, const float* B, int ld
     p.resid = reinterpret_cast<const float*>(resid); p.resid_dtype = resid_dtype; p.ldr = ldr;
     p.C = C; p.c_dtype = c_dtype; p.ldc = ldc; p.accumulate = accumulate;
     p.colsum = colsum;
+    p.C2 = c2; p.ldc2 = ldc2;
     p.nsplit = 1; p.batch_h = 1; p.nbatch = 1;
     if (split_k < 1) split_k = 1;
     if (tile == 0) {
@@ -380,7 +382,7 @@ extern "C" int avsr_gemm_f32s_nt(const float* A, int lda, const float* B, int ld
 // f32 implicit-GEMM convolution forward on split hi / lo bf16 planes: x[N,H,W,Cin] * wp[Cout][KH][KW][Cin] -> y[N,OH,OW,Cout]
 // (all f32, channels-last; Cin % 64 == 0; zero_page: >= 16 zero bytes in device memory)
 extern "C" int avsr_conv2d_f32s(const float* x, const float* wp, float* y, const void* zero_page, int N, int H, int W, int Cin,
-                                int Cout, int KH, int KW, int stride, int pad_h, int pad_w, int tile, int w_split,
+                                int Cout, int KH, int KW, int stride, int pad_h, int pad_w, int tile, int w_split, void* y2,
                                 hipStream_t stream) {
     const int OH = (H + 2 * pad_h - KH) / stride + 1, OW = (W + 2 * pad_w - KW) / stride + 1;
     AVSR_REQUIRE(Cin % 64 == 0, "conv2d_f32s: input channel count must be a multiple of 64");
@@ -395,6 +397,7 @@ extern "C" int avsr_conv2d_f32s(const float* x, const float* wp, float* y, const
     p.nsplit = 1; p.batch_h = 1; p.nbatch = 1;
     p.gate = zero_page;
     p.c_dtype = 0; p.C = y;
+    p.C2 = y2; p.ldc2 = Cout;
     p.cN = N;
     p.cKH = KH; p.cKW = KW; p.cS = stride; p.cPH = pad_h; p.cPW = pad_w; p.cC = Cin;
     p.M = N * OH * OW; p.N = Cout; p.ldc = Cout;

@@ -18,7 +18,7 @@ template <class TY>
 __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     TY* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows,
-    int cols, float eps) {
+    int cols, float eps, bf16_t* __restrict__ y2 = nullptr) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int row = blockIdx.x * LN_WAVES + wave;
@@ -66,6 +66,7 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(
 #pragma unroll
             for (int e = 0; e < 8; e++) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
             store8(yr + c * 8, o);
+            if (y2) store8(y2 + (size_t)row * cols + c * 8, o);  // bf16 twin (hpf mode: what the backward pass will read)
         }
     }
 }
@@ -257,6 +258,17 @@ extern "C" int avsr_layernorm_fwd(const float* x, const float* gamma, const floa
         AVSR_LAUNCH((layernorm_fwd_kernel<bf16_t>), grid, block, 0, stream, x, gamma, beta,
                     (bf16_t*)y, mean, rstd, rows, cols, eps);
     AVSR_CHECK_LAUNCH("layernorm_fwd");
+    return 0;
+}
+
+// f32 output + its bf16 twin in one pass (the "hpf" numerical mode: f32 forward, bf16 copies saved for the backward pass)
+extern "C" int avsr_layernorm_fwd2(const float* x, const float* gamma, const float* beta, float* y, void* y2, float* mean,
+                                   float* rstd, int rows, int cols, float eps, hipStream_t stream) {
+    AVSR_REQUIRE(cols % 8 == 0 && cols <= 64 * 8 * LN_MAXV, "layernorm: cols must be %8 and <= 2048");
+    if (rows == 0) return 0;
+    dim3 grid((rows + LN_WAVES - 1) / LN_WAVES), block(LN_THREADS);
+    AVSR_LAUNCH((layernorm_fwd_kernel<float>), grid, block, 0, stream, x, gamma, beta, y, mean, rstd, rows, cols, eps, (bf16_t*)y2);
+    AVSR_CHECK_LAUNCH("layernorm_fwd2");
     return 0;
 }
 

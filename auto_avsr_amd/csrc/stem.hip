@@ -108,7 +108,7 @@ constexpr int OP = 72;       // pitch (bf16) of the LDS output row [pixel][64 ch
 template <int NS, class TO>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wp,
                                                        TO* __restrict__ y, int T, int H, int W, int OH, int OW,
-                                                       long total_rows) {
+                                                       long total_rows, bf16_t* __restrict__ y2 = nullptr) {
     constexpr int OPT = sizeof(TO) == 2 ? OP : 68;  // pitch of the LDS output row in elements (16-byte multiple, bank-skewed)
     __shared__ __attribute__((aligned(16))) bf16_t patch[NS * 36 * LP];
     __shared__ __attribute__((aligned(16))) TO orow[64 * OPT];
@@ -158,7 +158,11 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
         constexpr int EPC = 16 / sizeof(TO), CPP = CO / EPC;  // elements per 16-byte chunk, chunks per pixel
         for (int i = threadIdx.x; i < OW * CPP; i += 256) {
             const int pix = i / CPP, c = (i % CPP) * EPC;
-            *reinterpret_cast<f32x4*>(dst + pix * CO + c) = *reinterpret_cast<const f32x4*>(orow + pix * OPT + c);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(orow + pix * OPT + c);
+            *reinterpret_cast<f32x4*>(dst + pix * CO + c) = v;
+            if (sizeof(TO) == 4 && y2)  // bf16 twin of the f32 result (hpf mode)
+                *reinterpret_cast<bf16x4*>(y2 + (row * OW + pix) * CO + c) =
+                    bf16x4{(short)f2bf(v[0]), (short)f2bf(v[1]), (short)f2bf(v[2]), (short)f2bf(v[3])};
         }
     }
 }
@@ -349,8 +353,8 @@ extern "C" int avsr_stem357_fwd(const float* x, const float* w, void* y, void* w
 
 // The same convolution for the precise / hpf modes: y (f32) from split hi + lo bf16 planes of x and w (three MFMAs per
 // product, ~2^-16 relative error -- the arithmetic of avsr_conv_stem_fwd with precise = 1).  Same workspace.
-extern "C" int avsr_stem357_fwd_f32s(const float* x, const float* w, float* y, void* workspace, int B, int T, int H, int W,
-                                     hipStream_t stream) {
+extern "C" int avsr_stem357_fwd_f32s(const float* x, const float* w, float* y, void* y2, void* workspace, int B, int T, int H,
+                                     int W, hipStream_t stream) {
     AVSR_REQUIRE(W % 4 == 0 && W <= 96 && H >= 1, "stem357: W must be a multiple of 4 and <= 96");
     if (B <= 0 || T <= 0) return 0;
     const int OH = (H + 6 - KH) / 2 + 1, OW = (W + 6 - KW) / 2 + 1;
@@ -359,7 +363,7 @@ extern "C" int avsr_stem357_fwd_f32s(const float* x, const float* w, float* y, v
     const long rows = (long)B * T * OH;
     AVSR_REQUIRE(OW <= 64, "stem357: at most 64 output columns");
     AVSR_LAUNCH((stem_fwd_kernel<2, float>), dim3((unsigned)((rows + FWD_ROWS - 1) / FWD_ROWS)), dim3(256), 0, stream, x,
-                (const bf16_t*)wp, y, T, H, W, OH, OW, rows);
+                (const bf16_t*)wp, y, T, H, W, OH, OW, rows, (bf16_t*)y2);
     AVSR_CHECK_LAUNCH("stem357_fwd_f32s");
     return 0;
 }

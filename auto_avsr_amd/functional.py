@@ -37,6 +37,7 @@ def set_mode(mode: str):
     assert mode in ("bf16", "precise", "hpf"), mode
     _state["precise"] = mode != "bf16"
     _state["hpf"] = mode == "hpf"
+    ops.TWIN = _make_twin if mode == "hpf" else None
 
 
 def mode() -> str:
@@ -66,11 +67,39 @@ def _bwd_mode(fn):
     return backward
 
 
+# "hpf" mode: kernels that produce an f32 activation also write its bf16 twin in the same pass (LayerNorm, BatchNorm +
+# activation, the split GEMM / convolution epilogues -- ops.TWIN); _A() picks the twin up when the tensor is saved for the
+# backward pass, and falls back to a cast launch for tensors nobody twinned.  Entries keep both tensors alive, are popped on
+# use and dropped by new_step().
+_twins = {}
+_twin_stats = {"made": 0, "used": 0}
+_TWIN_MIN = 1 << 15  # elements: below this a cast launch at save time costs nothing worth a second output stream
+
+
+def _make_twin(y):
+    # only in the forward pass of the hpf mode (the backward pass runs with precise = False), and only when the python-level
+    # wrapper that started this sub-layer saw grad mode on (Function.forward itself always runs under no_grad)
+    if not (_state["hpf"] and _state["precise"] and _state.get("tag_ok", False)):
+        return None
+    if y.numel() < _TWIN_MIN or not y.is_contiguous():
+        return None
+    if len(_twins) > 256:
+        _twins.clear()
+    t = torch.empty(y.shape, dtype=torch.bfloat16, device=y.device)
+    _twins[y.data_ptr()] = (y, t)
+    _twin_stats["made"] += 1
+    return t
+
+
 def _A(t):
     """An ACTIVATION-dtype tensor on its way into save_for_backward: in the "hpf" mode (f32 forward, bf16 backward) the
     backward pass gets a bf16 copy; identity in the other modes."""
     if t is None or not _state["hpf"] or t.dtype != torch.float32:
         return t
+    ent = _twins.pop(t.data_ptr(), None) if t.is_contiguous() else None
+    if ent is not None and ent[0].numel() == t.numel():  # (views of the producer's buffer: same bytes, another shape)
+        _twin_stats["used"] += 1
+        return ent[1].view(t.shape)
     return ops.scale_dropout(t.contiguous(), torch.bfloat16)
 
 
@@ -510,15 +539,16 @@ def _fast_ok(a, K, lda):
     return (not _state["precise"]) and a.dtype == torch.bfloat16 and K % 64 == 0 and (lda or K) % 8 == 0
 
 
-def _gemm_nt(a, w, M, N, K, out, *, lda=None, ldc=None, **kw):
-    """out[M,N] = epi(a[M,K] @ w[N,K]^T)."""
+def _gemm_nt(a, w, M, N, K, out, *, lda=None, ldc=None, twin=False, **kw):
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T).  twin: `out` is an activation that will be saved for the backward pass -- in the hpf
+    mode the kernel also writes its bf16 copy (picked up by _A)."""
     if _fast_ok(a, K, lda) and w.dim() == 2 and w.dtype == torch.float32 and w.is_contiguous():
         return ops.gemm_bf16_nt(a, lda or K, _w_bf16(w, False), K, M, N, K, out, ldc or N, **kw)
     if _state["precise"] and ops.SPLIT_FAST and a.dtype == torch.float32 and w.dim() == 2 and w.dtype == torch.float32 \
             and w.is_contiguous() and K % 64 == 0 and (lda or K) % 4 == 0 and a.data_ptr() % 16 == 0:
         # precise / hpf forward: the same split-bf16 arithmetic on the LDS-DMA operand ring (csrc/gemm_split.hip)
         ws = _w_split(w)
-        return ops.gemm_f32s_nt(a, lda or K, ws if ws is not None else w, K, M, N, K, out, ldc or N, **kw)
+        return ops.gemm_f32s_nt(a, lda or K, ws if ws is not None else w, K, M, N, K, out, ldc or N, twin=twin, **kw)
     return ops.gemm(NT, a, lda or K, w, K, M, N, K, out, ldc or N, precise=_state["precise"], **kw)
 
 
@@ -590,6 +620,7 @@ def new_step():
     _chain_g.clear()
     _shared_act.clear()
     _pos_proj.clear()
+    _twins.clear()
 
 
 def _zeros(shape, device):
@@ -925,10 +956,10 @@ class FfnSublayerFn(torch.autograd.Function):
         rows, D = _rows(x), x.shape[-1]
         Fh = w1.shape[0]
         T = act_dtype()
-        h, mean, rstd = ops.layernorm_fwd(x, ln_w, ln_b, T, eps)
+        h, mean, rstd = ops.layernorm_fwd(x, ln_w, ln_b, T, eps, twin=True)
         p1, s1, sd1 = _drop_args(p, x)
         u = torch.empty(rows, Fh, dtype=T, device=x.device)
-        _gemm_nt(h, w1, rows, Fh, D, u, bias=b1, act=1, drop_p=p1, seed=s1, seed_dev=sd1)
+        _gemm_nt(h, w1, rows, Fh, D, u, bias=b1, act=1, drop_p=p1, seed=s1, seed_dev=sd1, twin=True)
         p2, s2, sd2 = _drop_args(p, x)
         y = torch.empty_like(x)
         _gemm_nt(u, w2, rows, D, Fh, y, bias=b2, drop_p=p2, seed=s2, seed_dev=sd2, alpha=scale, resid=x, ldr=D)
@@ -1050,9 +1081,9 @@ def mlp(x, w1, b1, w2, b2):
 
 
 # ------------------------------------------------------------------------------------------------ attention cores
-def _proj(h, w, b, rows, D):
+def _proj(h, w, b, rows, D, twin=True):
     out = torch.empty(rows, w.shape[0], dtype=act_dtype(), device=h.device)
-    _gemm_nt(h, w, rows, w.shape[0], D, out, bias=b)
+    _gemm_nt(h, w, rows, w.shape[0], D, out, bias=b, twin=twin)
     return out
 
 
@@ -1069,7 +1100,7 @@ class AttentionCoreFn(torch.autograd.Function):
         T = act_dtype()
         qa = _to_act(q_in)
         ka = qa if same_kv else _to_act(kv_in)
-        q = _proj(qa, wq, bq, B * Tq, D)
+        q = _proj(qa, wq, bq, B * Tq, D, twin=pos_emb is None)
         k = _proj(ka, wk, bk, B * Tk, D)
         v = _proj(ka, wv, bv, B * Tk, D)
         relpos = pos_emb is not None
@@ -1181,7 +1212,7 @@ class MhaSublayerFn(torch.autograd.Function):
         B, Tq, D = x.shape
         dk = D // H
         T = act_dtype()
-        h, mean, rstd = ops.layernorm_fwd(x, ln_w, ln_b, T, eps)
+        h, mean, rstd = ops.layernorm_fwd(x, ln_w, ln_b, T, eps, twin=True)
         shared_kv = kv_all is not None  # source attention on the all-layer K/V projection of the memory (MemoryKVFn)
         cross = memory is not None or shared_kv
         if shared_kv:
@@ -1203,12 +1234,12 @@ class MhaSublayerFn(torch.autograd.Function):
             q, k4, v4 = qkv, q5[:, :, 1], q5[:, :, 2]
             ldq = 3 * D
         elif shared_kv:
-            q = _proj(h, wq, bq, B * Tq, D)
+            q = _proj(h, wq, bq, B * Tq, D, twin=pos_emb is None)
             kv5 = kv_all.view(B, Tk, kv_all.shape[1] // D, H, dk)  # [.., 2 * slot] = K, [.., 2 * slot + 1] = V of this layer
             k4, v4 = kv5[:, :, 2 * kv_slot], kv5[:, :, 2 * kv_slot + 1]
             ldq = D
         else:
-            q = _proj(h, wq, bq, B * Tq, D)
+            q = _proj(h, wq, bq, B * Tq, D, twin=pos_emb is None)
             k4 = _proj(ka, wk, bk, B * Tk, D).view(B, Tk, H, dk)
             v4 = _proj(ka, wv, bv, B * Tk, D).view(B, Tk, H, dk)
             ldq = D
@@ -1510,11 +1541,11 @@ class ConvSublayerFn(torch.autograd.Function):
         fused = ln_w is not None  # False: bare ConvolutionModule.forward (no LayerNorm, no residual)
         ctx.chain = _chain_take(x) if fused else None
         if fused:
-            h, mean, rstd = ops.layernorm_fwd(x, ln_w, ln_b, T, eps)
+            h, mean, rstd = ops.layernorm_fwd(x, ln_w, ln_b, T, eps, twin=True)
         else:
             h, mean, rstd = _to_act(x), None, None
         a = torch.empty(rows, 2 * D, dtype=T, device=x.device)
-        _gemm_nt(h, w_pw1.view(2 * D, D), rows, 2 * D, D, a, bias=b_pw1)
+        _gemm_nt(h, w_pw1.view(2 * D, D), rows, 2 * D, D, a, bias=b_pw1, twin=True)
         # GLU (conformer_encoder.py:32) is folded into the depthwise convolution: its window staging forms
         # a[:, :D] * sigmoid(a[:, D:]) on the fly, the GLU output is never written
         gl = None
@@ -1867,6 +1898,7 @@ class BasicBlockFn(torch.autograd.Function):
 
 def basic_block(x, dims, stride, training, conv1, bn1, conv2, bn2, down):
     """x: channels-last [N,H,W,Cin] activation-dtype tensor; modules supply the parameters."""
+    _state["tag_ok"] = torch.is_grad_enabled()
     t1, t2 = bn_tuple(bn1), bn_tuple(bn2)
     if down is not None:
         td = bn_tuple(down[1])
@@ -1954,6 +1986,7 @@ class StemFn(torch.autograd.Function):
 
 
 def stem(x, conv, bn, geom, pool):
+    _state["tag_ok"] = torch.is_grad_enabled()
     t = bn_tuple(bn)
     return StemFn.apply(x, conv.weight, t[0], t[1], t[2:], geom, pool, bn.training)
 

@@ -95,11 +95,24 @@ def paired():
         L.call("avsr_gemm_pair_end")
 
 
-def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-12):
+TWIN = None  # functional.py ("hpf" mode): callable(f32 tensor) -> bf16 twin buffer to fill alongside it, or None
+
+
+def _twin(y):
+    """bf16 twin buffer for an f32 result `y` when the hpf mode wants one (the backward pass reads the twin)."""
+    return TWIN(y) if (TWIN is not None and y.dtype == torch.float32) else None
+
+
+def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-12, twin=False):
     rows, cols = x.numel() // x.shape[-1], x.shape[-1]
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    y2 = _twin(y) if twin else None
+    if y2 is not None:
+        call("avsr_layernorm_fwd2", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(y2), _ptr(mean), _ptr(rstd), rows, cols, eps,
+             _stream(x), nbytes=_nb(x, y, y2))
+        return y, mean, rstd
     call("avsr_layernorm_fwd", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), dt(y), _ptr(mean), _ptr(rstd),
          rows, cols, eps, _stream(x), nbytes=_nb(x, y))
     return y, mean, rstd
@@ -332,6 +345,11 @@ def bn_eval_params(running_mean, running_var, eps):
 
 def bn_act_fwd(x, add, mean, invstd, gamma, beta, rows, C, act):
     y = torch.empty_like(x)
+    y2 = _twin(y) if (add is None or add.dtype == torch.float32) else None
+    if y2 is not None:
+        call("avsr_bn_act_fwd2", _ptr(x), _ptr(add), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(y2), rows, C,
+             act, _stream(x), nbytes=_nb(x, add, y, y2))
+        return y
     call("avsr_bn_act_fwd", _ptr(x), _ptr(add), dt(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y),
          rows, C, act, _stream(x), nbytes=_nb(x, add, y))
     return y
@@ -538,8 +556,8 @@ def conv2d_fwd(x, wp, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise):
         return y
     if precise and SPLIT_FAST and x.dtype == torch.float32 and wp.dtype == torch.float32 and Cin % 64 == 0 and KH * KW <= 32:
         call("avsr_conv2d_f32s", _ptr(x), _ptr(wp), _ptr(y), _ptr(zero_page(x.device)), N, H, W, Cin, Cout, KH, KW, stride,
-             ph, pw, 0, int(isinstance(wp, Split8)), _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin,
-             nbytes=_nb(x, wp, y))
+             ph, pw, 0, int(isinstance(wp, Split8)), _ptr(_twin(y)), _stream(x),
+             flops=2.0 * N * OH * OW * Cout * KH * KW * Cin, nbytes=_nb(x, wp, y))
         return y
     call("avsr_conv2d_fwd", _ptr(x), dt(x), _ptr(wp), dt(wp), _ptr(y), N, H, W, Cin, Cout, KH, KW, stride, ph, pw,
          int(precise), _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin)
@@ -640,12 +658,14 @@ def gemm_bf16_nt(A, lda, B, ldb, M, N, K, C, ldc, *, bias=None, act=0, gate=None
 
 def gemm_f32s_nt(A, lda, B, ldb, M, N, K, C, ldc, *, bias=None, act=0, gate=None, ldg=0, gate_scale=1.0, drop_p=0.0,
                  seed=0, seed_dev=None, alpha=1.0, alpha_dev=None, resid=None, ldr=0, accumulate=False, split_k=1,
-                 tile=0, colsum=None):
+                 tile=0, colsum=None, twin=False):
     """Precise-mode NT GEMM on the LDS-DMA ring (csrc/gemm_split.hip): f32 operands, three bf16 MFMAs per product."""
+    # hpf mode: a dense f32 activation output also leaves as its bf16 twin (same pitch), for the backward pass
+    c2 = _twin(C) if (twin and not accumulate and C.dtype == torch.float32 and C.dim() == 2 and C.stride(0) == ldc and C.is_contiguous()) else None
     call("avsr_gemm_f32s_nt", _ptr(A), lda, _ptr(B), ldb, M, N, K, _ptr(bias), act, _ptr(gate),
          dt(gate) if gate is not None else 0, ldg, gate_scale, drop_p, seed, _ptr(seed_dev), alpha, _ptr(alpha_dev),
          _ptr(resid), dt(resid) if resid is not None else 0, ldr, _ptr(C), dt(C), ldc, int(accumulate), split_k, tile,
-         _ptr(colsum), int(isinstance(B, Split8)), _stream(A), flops=2.0 * M * N * K,
+         _ptr(colsum), int(isinstance(B, Split8)), _ptr(c2), ldc, _stream(A), flops=2.0 * M * N * K,
          nbytes=4.0 * (M * K + N * K) + float(M * N * C.element_size()) + (float(M * N * resid.element_size()) if resid is not None else 0.0))
     return C
 
@@ -702,7 +722,7 @@ def stem357_fwd_f32s(x, w, B, T, H, W):
     OH, OW = conv_out(H, 7, 2, 3), conv_out(W, 7, 2, 3)
     y = torch.empty(B * T, OH, OW, 64, dtype=torch.float32, device=x.device)
     ws = torch.empty(call("avsr_stem357_workspace_bytes") // 4 + 16, dtype=torch.float32, device=x.device)
-    call("avsr_stem357_fwd_f32s", _ptr(x), _ptr(w), _ptr(y), _ptr(ws), B, T, H, W, _stream(x),
+    call("avsr_stem357_fwd_f32s", _ptr(x), _ptr(w), _ptr(y), _ptr(_twin(y)), _ptr(ws), B, T, H, W, _stream(x),
          flops=2.0 * B * T * OH * OW * 64 * 245, nbytes=_nb(x, y))
     return y
 

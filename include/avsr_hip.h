@@ -35,6 +35,9 @@ const char* avsr_last_error(void);
 int avsr_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype,
                        float* mean, float* rstd, int rows, int cols, float eps,
                        avsr_stream_t stream);
+/* the same with an f32 result AND its bf16 twin y2 in one pass ("hpf" numerical mode: f32 forward, bf16 copies for the backward) */
+int avsr_layernorm_fwd2(const float* x, const float* gamma, const float* beta, float* y, void* y2, float* mean, float* rstd,
+                        int rows, int cols, float eps, avsr_stream_t stream);
 /* dx = LN'(dy) (+ dres if non-null); dgamma/dbeta are accumulated into.
  * gout (bf16 [rows][cols], may be NULL) = bf16(alpha * dropout(dx)) and gsum (f32 [cols], may be NULL; accumulated into)
  * += column sums of gout: the backward prologue of the Linear whose output gradient dx is -- the output projection of the
@@ -167,6 +170,9 @@ int avsr_bn_small_bwd(const void* x, const void* dy, int dtype, int64_t rows, in
 int avsr_bn_act_fwd(const void* x, const void* add, int dtype, const float* mean, const float* invstd,
                     const float* gamma, const float* beta, void* y, int64_t rows, int C, int act,
                     avsr_stream_t stream);
+/* f32 in / f32 out + the bf16 twin y2 of the output */
+int avsr_bn_act_fwd2(const float* x, const float* add, const float* mean, const float* invstd, const float* gamma,
+                     const float* beta, float* y, void* y2, int64_t rows, int C, int act, avsr_stream_t stream);
 /* maxpool(act(bn(x))) in one pass: y [N][OH][OW][C] + argmax idx (uint8, kh*K+kw of the first maximum) from
  * x [N][H][W][C]; replaces BatchNorm3d + SiLU + MaxPool3d((1,3,3),(1,2,2),(0,1,1)) of the video stem
  * (frontend/resnet.py:212-218) without materialising the full-resolution activation */
@@ -292,7 +298,9 @@ int avsr_gemm_f32s_nt(const float* A, int lda, const float* B, int ldb, int M, i
                       const void* gate, int gate_dtype, int ldg, float gate_scale, float drop_p, uint64_t seed,
                       const uint64_t* seed_dev, float alpha, const float* alpha_dev, const void* resid, int resid_dtype,
                       int ldr, void* C, int c_dtype, int ldc, int accumulate, int split_k, int tile, float* colsum,
-                      int b_split /* 1: B is in the split8 layout of avsr_split_pack (same pitch) */, avsr_stream_t stream);
+                      int b_split /* 1: B is in the split8 layout of avsr_split_pack (same pitch) */,
+                      void* c2 /* may be NULL: bf16 twin of an f32, non-accumulating C (row pitch ldc2) */, int ldc2,
+                      avsr_stream_t stream);
 /* split8 layout: every group of 8 consecutive f32 of a buffer replaced, in place of its 32 bytes, by its 8 hi bf16 followed
  * by its 8 lo bf16 (hi = bf16(x), lo = bf16(x - hi)); n % 8 == 0.  avsr_multi_split_pack: many tensors in one launch, table
  * of 32-byte entries {const float* src, void* dst, int64 n / 8, int64 blk0}, blk0 = running sum of ceil(n / 2048). */
@@ -302,7 +310,7 @@ int avsr_multi_split_pack(const void* table, int n, int total_blocks, avsr_strea
  * x[N,H,W,Cin] * wp[Cout][KH][KW][Cin] -> y[N,OH,OW,Cout], all f32; zero_page: >= 16 zero bytes of device memory */
 int avsr_conv2d_f32s(const float* x, const float* wp, float* y, const void* zero_page, int N, int H, int W, int Cin, int Cout,
                      int KH, int KW, int stride, int pad_h, int pad_w, int tile, int w_split /* 1: wp in the split8 layout */,
-                     avsr_stream_t stream);
+                     void* y2 /* may be NULL: bf16 twin of y */, avsr_stream_t stream);
 /* Tuning knobs of the tuned kernels (process-wide; meant for benchmarks, defaults are the measured best):
  * knob 0 = tile code forced on avsr_conv2d_bf16 (0 = auto), 1 = XCD-aware tile order (0 = automatic: on for the 64x64 GEMM tile, whose
  * operands are not cache-resident in the training step; 1 = always on; 2 = always off),
@@ -344,8 +352,8 @@ int avsr_stem357_fwd(const float* x, const float* w, void* y, void* workspace, i
 int avsr_stem357_wgrad(const void* dy, const float* x, float* dw, void* workspace, int B, int T, int H, int W,
                        avsr_stream_t stream);
 /* precise / hpf modes: the same convolution with an f32 result from split hi + lo bf16 planes (three MFMAs per product) */
-int avsr_stem357_fwd_f32s(const float* x, const float* w, float* y, void* workspace, int B, int T, int H, int W,
-                          avsr_stream_t stream);
+int avsr_stem357_fwd_f32s(const float* x, const float* w, float* y, void* y2 /* may be NULL: bf16 twin of y */, void* workspace,
+                          int B, int T, int H, int W, avsr_stream_t stream);
 
 /* bf16 weight-gradient contraction without transposed copies (gemm_tn_fast.hip: LDS-DMA k-major tiles +
  * ds_read_b64_tr_b16): C[M][N] (f32, ldc) (+)= sum_k A[k][m] B[k][n]; A [K][lda], B [K][ldb] bf16.

@@ -138,8 +138,9 @@ def test_e2e_small_bf16_mode(dev, modality):
     assert min(cos)[0] > 0.9, sorted(cos)[:5]
 
 
+@pytest.mark.parametrize("twins", [False, True], ids=["cast", "twins"])
 @pytest.mark.parametrize("modality", ["video", "audio"])
-def test_e2e_small_hpf_mode(dev, modality):
+def test_e2e_small_hpf_mode(dev, modality, twins, monkeypatch):
     """"hpf" numerical mode (functional.set_mode): the FORWARD pass is the precise one -- losses bit-identical to the precise
     mode and within 1e-3 of the fp32 oracle (the north-star bound) -- while the backward pass runs the bf16 kernels on bf16
     copies of the saved activations: gradients aligned with the oracle's like the bf16 mode's."""
@@ -159,10 +160,24 @@ def test_e2e_small_hpf_mode(dev, modality):
     with AF.precise():
         ref = [float(v) for v in m(x.to(dev), lengths.to(dev), y.to(dev))[:3]]
     m.load_state_dict(sd, strict=True)  # (running statistics back to the start)
+    # twins: the producing kernels write the bf16 copies the backward pass reads (the size threshold is for real workloads);
+    # cast: every saved activation is cast at save time -- the two must agree bit for bit
+    monkeypatch.setattr(AF, "_TWIN_MIN", 0 if twins else 1 << 60)
+    AF._twin_stats.update(made=0, used=0)
     with AF.numerics("hpf"):
         assert AF.mode() == "hpf"
         loss, loss_ctc, loss_att, acc = m(x.to(dev), lengths.to(dev), y.to(dev))
         loss.backward()
+    if twins:
+        assert AF._twin_stats["used"] > 20 and AF._twin_stats["used"] >= 0.9 * AF._twin_stats["made"] - 2, AF._twin_stats
+    else:
+        assert AF._twin_stats["made"] == 0
+    gsum = sum(float(p.grad.double().abs().sum()) for p in m.parameters())
+    key = ("hpf_gsum", modality)
+    if key in _HPF_REF:
+        # (equal up to the summation order of the float atomics in the weight-gradient / bias-gradient kernels)
+        assert abs(gsum - _HPF_REF[key]) <= 1e-9 * gsum, "twin outputs and save-time casts must give the same gradients"
+    _HPF_REF[key] = gsum
     assert AF.mode() == "bf16"
     assert [float(loss), float(loss_ctc), float(loss_att)] == ref, "hpf forward must be the precise forward"
     assert abs(float(loss_ctc) - float(ctc_r)) < 1e-3 * abs(float(ctc_r))
@@ -176,6 +191,9 @@ def test_e2e_small_hpf_mode(dev, modality):
             cos.append((float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)), k))
     assert min(cos)[0] > 0.9, sorted(cos)[:5]
     AF.invalidate_weight_cache()
+
+
+_HPF_REF = {}
 
 
 def test_weight_cache_refresh(dev):
