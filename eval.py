@@ -23,6 +23,9 @@ def parse_args(argv=None):
     p.add_argument("--synthetic-utterances", type=int, default=0,
                    help="decode this many synthetic utterances instead of a dataset (default when --root-dir is absent: 4)")
     p.add_argument("--max-test-frames", type=int, default=100, help="length cap of the synthetic utterances")
+    p.add_argument("--numerics", choices=["precise", "bf16"], default="precise",
+                   help="arithmetic of the decoding forward pass: precise (split hi / lo bf16 planes -- hypotheses equal an fp32 run "
+                        "of the reference; the default) or bf16 (faster on long utterances)")
     return p.parse_args(argv)
 
 
@@ -47,6 +50,9 @@ def cli_main(argv=None):
     from lightning import HAVE_LIGHTNING, ModelModule
 
     args = parse_args(argv)
+    from auto_avsr_amd import functional as AF
+
+    AF.set_mode(args.numerics)  # evaluation is forward-only: "precise" here is also what the hpf training mode's forward runs
     logging.basicConfig(format="%(asctime)s %(message)s" if args.debug else "%(message)s",
                         level=logging.DEBUG if args.debug else logging.INFO, datefmt="%Y-%m-%d %H:%M:%S")
     if not torch.cuda.is_available():
