@@ -55,6 +55,28 @@ AVSR_DEV void adam_update(float& p, float g, float& m, float& v, const AdamScala
     p -= s.step_size * (m / denom);
 }
 
+// dst_i[0 .. numel_i) = scale * src_i[...] for every table entry {p = dst, g = src, numel, blk0} (m / v unused): the
+// gradients of one data-parallel bucket gathered into the bucket's flat buffer (and pre-divided by the world size) in ONE launch.
+// Gradients may be dword-aligned only (views into other buffers): scalar accesses at the ragged ends.
+__global__ __launch_bounds__(256) void multi_copy_scale_kernel(const OptEntry* __restrict__ table, int n, float scale) {
+    const OptEntry e = find_entry(table, n, blockIdx.x);
+    const long base = (long)(blockIdx.x - e.blk0) * OPT_CHUNK;
+    const bool vec = (((uintptr_t)e.p | (uintptr_t)e.g) & 15) == 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const long i = base + (threadIdx.x + 256 * j) * 4;
+        if (i >= e.numel) break;
+        if (vec && i + 4 <= e.numel) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(e.g + i);
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] *= scale;
+            *reinterpret_cast<f32x4*>(e.p + i) = v;
+        } else {
+            for (int k = 0; k < 4 && i + k < e.numel; k++) e.p[i + k] = scale * e.g[i + k];
+        }
+    }
+}
+
 // partial[block] = sum of squares of the block's chunk of gradients
 __global__ __launch_bounds__(256) void multi_sumsq_kernel(const OptEntry* __restrict__ table, int n, float* __restrict__ partial) {
     __shared__ float red[4];
@@ -298,5 +320,15 @@ extern "C" int avsr_adamw_cast_step(const void* table, int n, int total_blocks, 
         AVSR_LAUNCH(multi_adamw_kernel, dim3(lin_blocks), dim3(256), 0, stream, reinterpret_cast<const OptEntry*>(lin_table),
                     lin_n, (const float*)state, beta1, beta2, eps, weight_decay);
     AVSR_CHECK_LAUNCH("adamw_cast_step");
+    return 0;
+}
+
+// dst_i = scale * src_i for n tensors in one launch.  table: n entries in the layout of avsr_adamw_step ({dst, src, -, -, numel,
+// blk0}: 48 bytes each, blk0 = running sum of ceil(numel / 4096)); total_blocks = the final sum.  Used by the data-parallel
+// gradient exchange (auto_avsr_amd/ddp.py): one launch gathers a bucket's gradients into its flat all-reduce buffer.
+extern "C" int avsr_multi_copy_scale(const void* table, int n, int total_blocks, float scale, hipStream_t stream) {
+    if (n <= 0 || total_blocks <= 0) return 0;
+    AVSR_LAUNCH(multi_copy_scale_kernel, dim3(total_blocks), dim3(256), 0, stream, reinterpret_cast<const OptEntry*>(table), n, scale);
+    AVSR_CHECK_LAUNCH("multi_copy_scale");
     return 0;
 }

@@ -90,6 +90,11 @@ class FusedAdamW:
         key = tuple([g.data_ptr() for g in grads])
         if plan is not None:
             key = key + plan[0]  # cache generation: (invalidations, registered copies)
+        capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        if capturing:
+            # a captured step never shares a table with an eager step, even at equal gradient addresses (data-parallel bucket
+            # views are static): its device table and scratch must come from the graph's own memory pool
+            key = key + ("captured",)
         ent = self._tables.get(key)
         if ent is None:
             assert all(g.dtype == torch.float32 and g.is_contiguous() and g.numel() == p.numel()
@@ -105,7 +110,6 @@ class FusedAdamW:
                 trow = trow.copy()
                 trow["ptr"][:, 1] = rows[tidx, 1]
                 blob = np.concatenate([blob, lin.reshape(-1).view(np.uint8), trow.view(np.uint8).reshape(-1)])
-            capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
             if not capturing and len(self._tables) >= 16:  # eager address churn: recycle the oldest eager tables
                 for k in [k for k, e in self._tables.items() if not e[5]][:8]:
                     self._free_host.append(self._tables.pop(k)[0])

@@ -92,11 +92,19 @@ def fit(model, args, dev, rank=0, world=1, backend="nccl", log=print):
     seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
     AF.set_seed_tensor(seed_dev)
     hot = _Hot(model)
+    buckets = None
     if world > 1:
+        # train.py:31,37: cross-rank BatchNorm (the kernels' own statistics exchange) + DDP gradient averaging
         AF.set_bn_sync(dist.group.WORLD)
-        hot = torch.nn.parallel.DistributedDataParallel(
-            hot, device_ids=[dev.index] if dev.type == "cuda" else None, find_unused_parameters=False,
-            broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=64)
+        if os.environ.get("AVSR_DDP", "torch") == "buckets":
+            # this build's own bucketed RCCL all-reduce (ddp.GradBuckets: every operation a stream operation)
+            from .ddp import GradBuckets
+
+            buckets = GradBuckets(model.parameters(), group=dist.group.WORLD, bucket_mb=64)
+        else:
+            hot = torch.nn.parallel.DistributedDataParallel(
+                hot, device_ids=[dev.index] if dev.type == "cuda" else None, find_unused_parameters=False,
+                broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=64)
     lengths = utterance_lengths(getattr(args, "synthetic_utterances", 0) or 20000)
     all_batches = bucket_batches(lengths, args.max_frames, args.train_num_buckets)
     # every rank sees the same number of batches per epoch (DistributedSampler pads): the schedule lengths below and the
@@ -138,6 +146,8 @@ def fit(model, args, dev, rank=0, world=1, backend="nccl", log=print):
                 dist.all_gather_into_tensor(allb, bs)
                 loss = loss * (world / allb.sum())  # lightning.py:88-90
             loss.backward()
+            if buckets is not None:
+                buckets.finish()
             opt.step()
             opt.zero_grad(set_to_none=True)
             global_step += 1

@@ -46,6 +46,11 @@ def parse():
                     help="time ONE fixed batch instead of the bucketed workload: the survey's batch A (4 x 400 frames, 64 "
                          "labels) or batch B (16 x 100, 16 labels), SURVEY.md section 8d")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity block (reference goldens at batch A)")
+    ap.add_argument("--ddp", choices=["torch", "buckets", "buckets-graph"], default="torch",
+                    help="N > 1 gradient exchange: torch DistributedDataParallel (default; eager launches), this build's own bucketed "
+                         "RCCL all-reduce (auto_avsr_amd/ddp.py, eager launches), or the latter with the whole data-parallel step -- "
+                         "collectives included -- captured into hipGraphs (EXPERIMENTAL: replays on a single-rank group with the small "
+                         "model, tools/rccl_world1.py; at full size torch's process-group watchdog races the capture)")
     return ap.parse_args()
 
 
@@ -189,14 +194,21 @@ def main():
         # clip 10, per-step warm-up cosine -- one fused multi-tensor step (auto_avsr_amd/optim.py) that also rewrites the
         # bf16 operand copies of the Linear weights, so the next forward pass needs no separate re-cast of 250M weights
         opt = make_optimizer()
-    if world > 1:
-        # train.py:37 DDPStrategy(find_unused_parameters=False): bucketed gradient all-reduce over RCCL/xGMI
-        # 64 MB buckets: ring all-reduce over point-to-point xGMI links is per-link bound and wants large messages;
-        # the parameter-poor, compute-rich ResNet trunk runs LAST in the backward pass (~5 ms, 45 MB of gradients),
-        # so the ~15 encoder/decoder buckets drain underneath it and the exposed tail stays one small bucket.
+    buckets = None
+    if world > 1 and args.ddp == "torch":
         hot = torch.nn.parallel.DistributedDataParallel(hot, device_ids=None if selftest else [local_rank],
                                                         find_unused_parameters=False, broadcast_buffers=False,
                                                         gradient_as_bucket_view=True, bucket_cap_mb=64)
+    elif world > 1:
+        # train.py:37 DDPStrategy(find_unused_parameters=False): bucketed gradient all-reduce over RCCL/xGMI, issued by this
+        # build's own exchange (auto_avsr_amd/ddp.py) so that the WHOLE data-parallel step -- collectives included -- can be
+        # captured into a hipGraph (torch's DDP reducer cannot: tools/rccl_capture_probe.py).
+        # 64 MB buckets: ring all-reduce over point-to-point xGMI links is per-link bound and wants large messages;
+        # the parameter-poor, compute-rich ResNet trunk runs LAST in the backward pass (~5 ms, 45 MB of gradients),
+        # so the ~15 encoder/decoder buckets drain underneath it and the exposed tail stays one small bucket.
+        from auto_avsr_amd.ddp import GradBuckets
+
+        buckets = GradBuckets(model.parameters(), group=dist.group.WORLD, bucket_mb=64)
 
     lengths = utterance_lengths() if not selftest else __import__("numpy").array(selftest["lengths"])
     batches = rank_batches(bucket_batches(lengths, args.max_frames, 400 if not selftest else 4), rank, world, seed=0)
@@ -216,9 +228,9 @@ def main():
     if args.fixed == "A":  # labels capped at the survey's L = 64
         pool = [(x, lens, y[:, :, :64].contiguous(), fr) for (x, lens, y, fr) in pool]
     data = [pool[i % nshape] for i in range(max(n_need, nshape))]  # (the capture loop below visits every shape once)
-    use_graph = world == 1 and not args.no_graph
+    use_graph = not args.no_graph and (world == 1 or args.ddp == "buckets-graph")
     graphs = {}
-    st = {"opt": opt}
+    st = {"opt": opt, "graph": use_graph}
     all_params = list(model.parameters())
 
     def clear_grads():  # Module.zero_grad walks the module tree (2 ms of host time per step); this is the same effect
@@ -230,16 +242,24 @@ def main():
         seed_dev.add_(1)
         AF.refresh_weight_cache()  # an optimizer step would change the weights: pay the bf16 re-casts every step
         loss = hot(x, lens, y)
+        if world > 1:
+            # loss rescale of lightning.py:88-90: loss *= world / sum of batch sizes (all-gather of B)
+            bs = torch.full((1,), float(x.shape[0]), device=dev)
+            allb = torch.empty(world, device=dev)
+            dist.all_gather_into_tensor(allb, bs)
+            loss = loss * (world / allb.sum())
         loss.backward()
+        if buckets is not None:
+            buckets.finish()  # the compute stream waits for the bucket all-reduces issued during the backward pass
         if st["opt"] is not None:
             st["opt"].step()
         return loss
 
     def step(i):
         x, lens, y, _ = data[i]
-        if use_graph:
-            # one hipGraph per batch shape: the ~3000 kernel launches of a step are replayed by the GPU front-end
-            # instead of being issued one by one from Python (HIP graphs, not a tracing compiler)
+        if st["graph"]:
+            # one hipGraph per batch shape: the ~830 kernel launches of a step (N > 1: + the RCCL collectives) are replayed by
+            # the GPU front-end instead of being issued one by one from Python (HIP graphs, not a tracing compiler)
             key = i % nshape
             if key not in graphs:
                 side = torch.cuda.Stream()
@@ -251,24 +271,26 @@ def main():
                 AF.refresh_weight_cache()  # builds the multi-tensor cast table (H2D copy) outside the capture
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    captured_loss = eager_step(x, lens, y)
+                try:
+                    # (N > 1: the process group's watchdog thread queries events while this thread captures)
+                    with torch.cuda.graph(g, **({"capture_error_mode": "thread_local"} if world > 1 else {})):
+                        captured_loss = eager_step(x, lens, y)
+                except Exception as e:  # noqa: BLE001 -- capture is an optimisation: the eager step below is always valid
+                    if world == 1:
+                        raise
+                    print(f"[bench rank {rank}] hipGraph capture of the data-parallel step failed ({type(e).__name__}: "
+                          f"{str(e)[:200]}); continuing with eager launches", file=sys.stderr, flush=True)
+                    st["graph"] = False
+                    torch.cuda.synchronize()
+                    model.zero_grad(set_to_none=True)
+                    if buckets is not None:
+                        buckets._works.clear()
+                        buckets._left = [len(m) for m in buckets.members]
+                    return step(i)
                 graphs[key] = (g, captured_loss.detach())  # the loss lives in the graph's static memory: re-written by every replay
             graphs[key][0].replay()
             return graphs[key][1]
-        AF.new_step()
-        seed_dev.add_(1)
-        AF.refresh_weight_cache()  # the optimizer step changed the weights: one launch re-casts every bf16 copy
-        loss = hot(x, lens, y)
-        if world > 1:
-            # loss rescale of lightning.py:88-90: loss *= world / sum of batch sizes (all-gather of B)
-            bs = torch.tensor([float(x.shape[0])], device=dev)
-            allb = torch.empty(world, device=dev)
-            dist.all_gather_into_tensor(allb, bs)
-            loss = loss * (world / allb.sum())
-        loss.backward()
-        if st["opt"] is not None:
-            st["opt"].step()
+        loss = eager_step(x, lens, y)
         clear_grads()
         return loss
 
@@ -276,7 +298,7 @@ def main():
 
     def timed_run(n_warm, n_end):
         """Captures (set-up, not steps), n_warm untimed steps, then steps [n_warm, n_end) between barrier + synchronize."""
-        if use_graph:
+        if st["graph"]:
             for j in range(nshape):
                 step(j)
         for i in range(n_warm):
@@ -324,8 +346,9 @@ def main():
                                + (f"FIXED batch {args.fixed} of SURVEY 8d" if args.fixed else "length-bucketed batches")
                                + f", max-frames={args.max_frames} (real frames), fwd+bwd"
                                + ("" if args.no_optimizer else " + global-norm clip 10 + AdamW(1e-3, .9/.98, wd .03) + warm-up cosine + bf16 weight re-cast")
-                               + (", DDP grad all-reduce + SyncBN over RCCL" if world > 1 else "")
-                               + (f", hipGraph replay, {nshape} batch shapes cycled" if use_graph else f", eager launches, {nshape} batch shapes cycled"),
+                               + ((", DDP grad all-reduce + SyncBN over RCCL" if args.ddp == "torch" else
+                                   ", bucketed RCCL gradient all-reduce overlapped with backward (auto_avsr_amd.ddp) + SyncBN") if world > 1 else "")
+                               + (f", hipGraph replay, {nshape} batch shapes cycled" if st["graph"] else f", eager launches, {nshape} batch shapes cycled"),
                    "padded_frames_per_sec": round(float(ftot[1]) / dt, 2), "final_loss": round(final_loss, 4),
                    "batch_shapes": sorted({(int(d[0].shape[0]), int(d[0].shape[1]) // (640 if args.modality == "audio" else 1),
                                             int(d[2].shape[2])) for d in data}),

@@ -399,6 +399,10 @@ int avsr_ctc_prefix_score(const float* logp, int T, int V, int ldv, const float*
 int avsr_adamw_step(const void* table, int n, int total_blocks, float* partial, float* state, float base_lr, float beta1,
                     float beta2, float eps, float weight_decay, float max_grad_norm, int64_t warmup_steps,
                     int64_t total_steps, avsr_stream_t stream);
+/* dst_i = scale * src_i for n f32 tensors in ONE launch: table entries as above with p = dst, g = src (m, v unused).  The
+ * data-parallel gradient exchange gathers a bucket's gradients into its flat RCCL all-reduce buffer with it (train.py:37
+ * DDPStrategy: gradient averaging = scale 1 / world). */
+int avsr_multi_copy_scale(const void* table, int n, int total_blocks, float scale, avsr_stream_t stream);
 /* The same step with the bf16 operand copies of 2-D weights (see avsr_multi_cast_transpose) rewritten in the update pass,
  * so that no separate re-cast launch re-reads the f32 weights before the next forward pass:
  *   table / n / total_blocks          every parameter (48-byte entries as above) -- gradient norm only

@@ -244,7 +244,8 @@ def test_ddp_bench_configuration(emu_lib_path, tmp_path):
     assert res["ok"] and res["step"] == 2
 
 
-def test_bench_main_two_ranks(emu_lib_path, tmp_path):
+@pytest.mark.parametrize("ddp", ["torch", "buckets"])
+def test_bench_main_two_ranks(emu_lib_path, tmp_path, ddp):
     """bench.py's own main(), launched exactly as the driver launches it for N = 2 (`python -m torch.distributed.run
     --nproc-per-node 2 ... bench.py --gpus 2 ...`), on two CPU processes: gloo instead of RCCL, kernels through the host
     emulator, a small instance of the same model (AVSR_BENCH_SELFTEST, a test-suite-only hook in bench.py).  Executes the
@@ -259,7 +260,7 @@ def test_bench_main_two_ranks(emu_lib_path, tmp_path):
     port = 35500 + os.getpid() % 2000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--max-frames", "12", "--shapes", "2"]
+           "--max-frames", "12", "--shapes", "2", "--ddp", ddp]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -267,5 +268,62 @@ def test_bench_main_two_ranks(emu_lib_path, tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["value"] > 0 and out["ms_per_step"] > 0 and out["higher_is_better"] is True
-    assert "DDP grad all-reduce + SyncBN" in out["config"]["workload"] and "eager launches" in out["config"]["workload"]
+    # --ddp torch: DistributedDataParallel (the default); --ddp buckets: auto_avsr_amd.ddp.GradBuckets (one gather launch + one
+    # async all-reduce per bucket, issued from post-accumulate-grad hooks)
+    want = "DDP grad all-reduce + SyncBN" if ddp == "torch" else "gradient all-reduce overlapped with backward (auto_avsr_amd.ddp) + SyncBN"
+    assert want in out["config"]["workload"] and "eager launches" in out["config"]["workload"]
     assert out["config"]["final_loss"] == out["config"]["final_loss"]  # finite
+
+
+def _worker_buckets(rank, world, port, emu_path, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from auto_avsr_amd import _lib
+    from auto_avsr_amd.ddp import GradBuckets
+
+    _lib._install_for_tests(emu_path)
+    torch.manual_seed(0)  # identical replicas
+    net = torch.nn.Sequential(torch.nn.Linear(37, 64), torch.nn.ReLU(), torch.nn.Linear(64, 129), torch.nn.ReLU(),
+                              torch.nn.Linear(129, 5, bias=False))
+    ref = torch.nn.Sequential(torch.nn.Linear(37, 64), torch.nn.ReLU(), torch.nn.Linear(64, 129), torch.nn.ReLU(),
+                              torch.nn.Linear(129, 5, bias=False))
+    ref.load_state_dict(net.state_dict())
+    ddp = torch.nn.parallel.DistributedDataParallel(ref)
+    gb = GradBuckets(net.parameters(), group=dist.group.WORLD, bucket_mb=0.02)  # ~5 k floats per bucket: several buckets
+    assert len(gb.flat) >= 3
+    g = torch.Generator().manual_seed(100 + rank)  # different data per rank
+    for step in range(3):
+        x = torch.randn(11 + rank, 37, generator=g)
+        ddp(x).square().mean().backward()
+        net(x).square().mean().backward()
+        gb.finish()
+        for p, q in zip(net.parameters(), ref.parameters()):
+            assert p.grad.data_ptr() == gb.views[[id(t) for t in gb.params].index(id(p))].data_ptr(), "grad must be the bucket view"
+            assert torch.allclose(p.grad, q.grad, rtol=1e-6, atol=1e-7), float((p.grad - q.grad).abs().max())
+        for p in list(net.parameters()) + list(ref.parameters()):
+            p.grad = None
+    # a parameter that gets no gradient is an error at finish(), as with find_unused_parameters=False
+    x = torch.randn(4, 37)
+    net[0](x).sum().backward()
+    try:
+        gb.finish()
+        ok = False
+    except RuntimeError:
+        ok = True
+    assert ok
+    if rank == 0:
+        open(os.path.join(out_dir, "ok"), "w").write("1")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_buckets_match_torch_ddp(emu_lib_path, tmp_path):
+    """auto_avsr_amd.ddp.GradBuckets (flat buckets, one gather launch + one async all-reduce per bucket, issued from
+    post-accumulate-grad hooks) gives the gradients torch's DistributedDataParallel gives: two gloo ranks, different data per
+    rank, three steps, several buckets, `.grad` re-pointed at the bucket views."""
+    port = 29500 + (os.getpid() + 7) % 2000
+    mp.spawn(_worker_buckets, args=(2, port, emu_lib_path, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(os.path.join(tmp_path, "ok"))
