@@ -317,7 +317,8 @@ bool make_plan(int N, int H, int W, int Cin, int Cout, int stride, Plan& pl) {
     if (best <= 0.0) return false;
     p.ntiles = (N + p.G - 1) / p.G * p.nbands;
     const int pairs = (Cin / 64) * (Cout / 64);
-    int split = (512 + pairs - 1) / pairs;  // two blocks per CU
+    const int target = avsr_tune_knobs[15] > 0 ? avsr_tune_knobs[15] : 512;  // knob 15: block-count target (A/B runs)
+    int split = (target + pairs - 1) / pairs;  // default: two blocks per CU
     if (split > p.ntiles) split = p.ntiles;
     p.tiles_per_block = (p.ntiles + split - 1) / split;
     pl.split = (p.ntiles + p.tiles_per_block - 1) / p.tiles_per_block;

@@ -275,6 +275,25 @@ def test_bench_main_two_ranks(emu_lib_path, tmp_path, ddp):
     assert out["config"]["final_loss"] == out["config"]["final_loss"]  # finite
 
 
+def test_bench_main_audio_babble_leg(emu_lib_path):
+    """bench.py --modality audio --babble (configs[3] as specified: raw waveforms -> time mask + babble noise at SNR 0 dB +
+    layer norm + padding collation inside every timed step), one CPU process, kernels through the host emulator."""
+    import json
+    import subprocess
+
+    cfg = {"emu": emu_lib_path, "odim": 41, "lengths": [5, 6, 5, 6, 7, 5, 6, 7],
+           "model": dict(adim=128, aheads=2, eunits=128, elayers=1, dunits=128, dlayers=1, cnn_module_kernel=7)}
+    env = dict(os.environ, AVSR_BENCH_SELFTEST=json.dumps(cfg), OMP_NUM_THREADS="2")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--modality", "audio", "--babble", "--no-graph", "--steps", "2",
+           "--warmup", "1", "--max-frames", "12", "--shapes", "2", "--no-roofline", "--no-cpu-baseline", "--no-parity"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["unit"] == "audio-frames/sec" and out["value"] > 0
+    assert "babble noise at SNR 0 dB" in out["config"]["workload"]
+    assert out["config"]["final_loss"] == out["config"]["final_loss"]
+
+
 def _worker_buckets(rank, world, port, emu_path, out_dir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"

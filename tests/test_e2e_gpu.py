@@ -132,9 +132,12 @@ def test_hipgraph_replay_matches_eager():
     AF.invalidate_weight_cache()
 
 
-def test_full_e2e_beam_search_vs_reference():
-    """Evaluation path at full size (eval mode, precise contractions): front-end -> encoder -> hybrid CTC/attention beam
-    search as lightning.ModelModule.forward wires it; hypotheses equal the reference's (tests/golden/make_golden_decode.py)."""
+@pytest.mark.parametrize("mode", ["precise", "bf16"])
+def test_full_e2e_beam_search_vs_reference(mode):
+    """Evaluation path at full size (eval mode): front-end -> encoder -> hybrid CTC/attention beam search as
+    lightning.ModelModule.forward wires it; hypotheses equal the reference's (tests/golden/make_golden_decode.py) -- in the
+    precise arithmetic (what eval.py decodes in, and the forward pass of the hpf training mode) token for token with scores
+    within 1e-3; in the bf16 arithmetic the BEST hypothesis still has the reference's token sequence, its score within 2e-2."""
     import lightning
     from auto_avsr_amd import functional as AF
 
@@ -143,17 +146,22 @@ def test_full_e2e_beam_search_vs_reference():
     m.eval()
     x, _, _ = synth_batch("video", 1, c["T"], 3, 5049, seed=c["seed"], lengths=[c["T"]])
     bs = lightning.get_beam_search_decoder(m, [str(i) for i in range(5049)], beam_size=c["beam"])
-    AF.set_precise(True)
+    AF.set_mode(mode)
+    AF.invalidate_weight_cache()
+    tol = 1e-3 if mode == "precise" else 2e-2
     try:
         with torch.no_grad():
             feats = m.proj_encoder(m.frontend(x.cuda()))
             enc, _ = m.encoder(feats, None)
-            assert (enc[0, :, :8].float().cpu() - c["enc_sample"]).abs().max() < 1e-3 * float(c["enc_sample"].abs().max())
+            assert (enc[0, :, :8].float().cpu() - c["enc_sample"]).abs().max() < tol * float(c["enc_sample"].abs().max())
             nbest = bs(enc.squeeze(0).float())
     finally:
-        AF.set_precise(False)
-    assert len(nbest) == c["n_ended"]
-    for got, ref in zip(nbest, c["hyps"]):
+        AF.set_mode("bf16")
+        AF.invalidate_weight_cache()
+    if mode == "precise":
+        assert len(nbest) == c["n_ended"]
+    for i, (got, ref) in enumerate(zip(nbest, c["hyps"])):
         d = got.asdict()
-        assert d["yseq"] == ref["yseq"]
-        assert abs(d["score"] - ref["score"]) < 1e-3 * max(1.0, abs(ref["score"]))
+        if mode == "precise" or i == 0:
+            assert d["yseq"] == ref["yseq"], (mode, i)
+            assert abs(d["score"] - ref["score"]) < tol * max(1.0, abs(ref["score"])), (mode, i, d["score"], ref["score"])
