@@ -13,7 +13,10 @@
 //   * both operands have the contraction index (pixels) as the slow LDS dimension: MFMA fragments are fetched with the
 //     CDNA4 transpose read ds_read_b64_tr_b16; a 64-byte XOR swizzle keeps the 4-row x 64-byte footprint of a
 //     transpose read on distinct banks (rows r and r+2 are 256 bytes apart);
-//   * 4 waves = 2 (co halves) x 2 (ci halves), each 9 accumulators of v_mfma_f32_32x32x16_bf16 (144 AGPRs);
+//   * 4 waves = 2 (co halves) x 2 (ci halves), each 9 accumulators of v_mfma_f32_32x32x16_bf16 (144 registers);
+//   * the fragment requests are software-pipelined ACROSS the 16-pixel k-steps (round 3: started cold, the chain table ->
+//     address -> transpose read -> MFMA left the matrix pipe idle 3/4 of the time) and every LDS read of the loop is in the
+//     caller-ordered asm form: a plain LDS load beside an LDS-DMA ring makes the compiler drain the DMA queue first;
 //   * split over the pixel tiles across blockIdx.z; every block stores its partial gradient (plain 128-byte-line
 //     stores) and a second kernel sums the partials in a fixed order -- deterministic, and cheaper than device-scope
 //     float atomics from 512 blocks onto one small tensor (atomics remain available without a workspace).
@@ -30,7 +33,7 @@ struct WgParams {
     float* dw;         // atomics: dwp ; partial mode: workspace [split][Cout][9][Cin]
     int partial;       // 0: atomicAdd into dw, 1: plain stores of this block's slice into dw + z * |dwp|, 2: none
     int xcd_order;     // 1: XCD-aware work order
-    int abl;           // benchmarks only (wrong results): 1 no MFMA, 2 no B reads, 4 no staging after tile 0, 8 no view reads
+    int abl;           // benchmarks only (wrong results): 4 no staging after tile 0, 16 no tiles (per-k-step switches cost time themselves)
     const bf16_t* zero;
     int N, H, W, OH, OW, Cin, Cout, S;
     int G, R;          // images / output rows per tile
@@ -42,7 +45,6 @@ struct WgParams {
     int tiles_per_block;
 };
 
-constexpr int STAGES = 2;
 // staging descriptor of one LDS row: byte offset from the tile's base pointer; image | row << 8 | swizzle << 24
 // (row = kNever for rows that are always zero)
 struct RowDesc { int off, meta; };
@@ -56,10 +58,18 @@ struct ViewEnt { int v[4]; };
 // (4 consecutive pixels) alternate s in pairs: rows 256 bytes apart would otherwise hit the same banks.
 //   dy rows: s = bit 1 of the row index k;   x patch rows: s = bit 1 of the patch COLUMN (invariant under the kh
 //   shift of a tap, so a pixel needs only three pre-swizzled addresses, one per kw).
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgParams p) {
+//
+// KG = number of k groups.  KG = 1: 4 waves, two blocks per CU, 2-stage ring.  KG = 2: 8 waves = two groups of the four
+// (co half, ci half) waves that SHARE every staged tile and take alternate 16-pixel k-steps of it; one block per CU, 3-stage
+// ring with a counted vmcnt wait (every wave issues exactly NPT DMA instructions per tile: rows past the tile go from the
+// zero page to a scratch kilobyte), and the two groups' accumulators are added through LDS before the store -- half the
+// partial-gradient bytes per launch (the partials' write + ordered re-read was a quarter of the kernel's time at KG = 1).
+template <int KG>
+__global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv3x3_wgrad_kernel(WgParams p) {
     AVSR_DYN_SMEM(smem);
+    constexpr int NT = 256 * KG, NW = 4 * KG, NSTAGE = KG == 1 ? 2 : 3;
     const int lane = threadIdx.x & 63, wave = wave_id(), tid = threadIdx.x;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int kg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
     // Work item w = (pixel-tile range z, ci block, co block).  All (ci, co) blocks of one z stage the same dy / x rows
     // (a different 128-byte slice each), so they should meet in one L2: block b runs on XCD b % 8 (observed), hence
     // XCD x is handed the contiguous run of work items [x * total/8, (x+1) * total/8) with z slowest.
@@ -73,12 +83,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgParams p) {
     const int ci0 = (pr % (p.Cin >> 6)) * 64, co0 = (pr / (p.Cin >> 6)) * 64;
     const int KP = p.KP, XROWS = p.XROWS, nbands = p.nbands, G = p.G, R = p.R, S = p.S, N = p.N, H = p.H, OH = p.OH;
     const int stage_bytes = (KP + XROWS) * 128;
-    ViewEnt* view = reinterpret_cast<ViewEnt*>(smem + STAGES * stage_bytes);  // [KP]
+    ViewEnt* view = reinterpret_cast<ViewEnt*>(smem + NSTAGE * stage_bytes);  // [KP]
     RowDesc* desc = reinterpret_cast<RowDesc*>(view + KP);                    // [KP + XROWS]
+    char* const scratch = reinterpret_cast<char*>(desc + KP + XROWS) + wave * 1024;  // KG = 2: target of the padding DMAs
     const int kvalid = G * R * p.OW;
 
     // ---- once per block: the tile geometry (identical for every tile)
-    for (int k = tid; k < KP; k += 256) {
+    for (int k = tid; k < KP; k += NT) {
         int g = 0, y = 0, xx = 0;
         const bool ok = k < kvalid;
         if (ok) {
@@ -97,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgParams p) {
         desc[k] = ok ? RowDesc{((g * OH + y) * p.OW + xx) * p.Cout * 2, g | (y << 8) | ((k & 2) << 23)}
                      : RowDesc{0, kNever << 8};
     }
-    for (int j = tid; j < XROWS; j += 256) {
+    for (int j = tid; j < XROWS; j += NT) {
         const int g = j / (p.XR * p.XW);
         const int rem = j - g * p.XR * p.XW;
         const int yy = rem / p.XW, xx = rem - yy * p.XW;
@@ -114,12 +125,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgParams p) {
         for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
 
     const int t_begin = zid * p.tiles_per_block;
-    const int t_end = min(p.ntiles, t_begin + p.tiles_per_block);
+    const int t_end = (p.abl & 16) ? t_begin : min(p.ntiles, t_begin + p.tiles_per_block);
 
     // stage tile t: every wave instruction moves 8 LDS rows (64 lanes x 16 B); rows are padded to whole instructions.
     // Fixed trip counts (KP <= 256, XROWS <= 288) with wave-uniform guards: the descriptors of all of a lane's rows are
     // fetched first, then turned into addresses -- one LDS round trip per tile instead of one per row.
-    constexpr int DY_PASSES = 8, X_PASSES = 9;
+    constexpr int DY_PASSES = 8 / KG, X_PASSES = KG == 1 ? 9 : 5, NPT = DY_PASSES + X_PASSES, RPP = 8 * NW;  // rows per pass
     const char* const zero = reinterpret_cast<const char*>(p.zero);
     const int rsub = lane >> 3;
     const int chunk0 = (lane & 7) * 16, chunk1 = ((lane & 7) ^ 4) * 16;  // source chunk of this lane for s = 0 / 1
@@ -133,35 +144,53 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgParams p) {
         const int ytop = r0 * S - 1;  // image row of patch row 0
         const char* const dy_tile = dy_blk + (((long)n0 * OH + r0) * p.OW) * p.Cout * 2;
         const char* const x_tile = x_blk + (((long)n0 * H + ytop) * p.W - 1) * p.Cin * 2;
-        RowDesc dd[DY_PASSES], dx[X_PASSES];
+        // (caller-ordered reads, prims.h: a plain LDS load here makes the compiler drain every LDS-DMA still in flight)
+        i32x2 dd[DY_PASSES], dx[X_PASSES];
 #pragma unroll
         for (int j = 0; j < DY_PASSES; j++)
-            if (wave * 8 + j * 32 < KP) dd[j] = desc[wave * 8 + j * 32 + rsub];
+            if (wave * 8 + j * RPP < KP) dd[j] = lds_read8_async(desc + wave * 8 + j * RPP + rsub);
 #pragma unroll
         for (int j = 0; j < X_PASSES; j++)
-            if (wave * 8 + j * 32 < XROWS) dx[j] = desc[KP + wave * 8 + j * 32 + rsub];
+            if (wave * 8 + j * RPP < XROWS) dx[j] = lds_read8_async(desc + KP + wave * 8 + j * RPP + rsub);
+        lds_wait<0>();
+#pragma unroll
+        for (int j = 0; j < DY_PASSES; j++) lds_tie(dd[j]);
+#pragma unroll
+        for (int j = 0; j < X_PASSES; j++) lds_tie(dx[j]);
 #pragma unroll
         for (int j = 0; j < DY_PASSES; j++) {
-            const int row0 = wave * 8 + j * 32;
+            const int row0 = wave * 8 + j * RPP;
             if (row0 < KP) {
-                const int m = dd[j].meta;
+                const int m = dd[j][1];
                 const bool ok = (m & 255) < gmax && ((m >> 8) & 0xfff) < ymax;
-                glds16(ok ? dy_tile + (dd[j].off + ((m >> 24) ? chunk1 : chunk0)) : zero, stage + row0 * 128);
+                glds16(ok ? dy_tile + (dd[j][0] + ((m >> 24) ? chunk1 : chunk0)) : zero, stage + row0 * 128);
+            } else if (KG > 1) {
+                glds16(zero, scratch);
             }
         }
         char* xs = stage + KP * 128;
 #pragma unroll
         for (int j = 0; j < X_PASSES; j++) {
-            const int row0 = wave * 8 + j * 32;
+            const int row0 = wave * 8 + j * RPP;
             if (row0 < XROWS) {
-                const int m = dx[j].meta;
+                const int m = dx[j][1];
                 const bool ok = (m & 255) < gmax && (unsigned)(ytop + ((m >> 8) & 0xfff)) < (unsigned)H;
-                glds16(ok ? x_tile + (dx[j].off + ((m >> 24) ? chunk1 : chunk0)) : zero, xs + row0 * 128);
+                glds16(ok ? x_tile + (dx[j][0] + ((m >> 24) ? chunk1 : chunk0)) : zero, xs + row0 * 128);
+            } else if (KG > 1) {
+                glds16(zero, scratch);
             }
         }
     };
+    auto issue_padding = [&]() {  // KG = 2: keeps the number of DMA instructions per loop trip constant
+#pragma unroll
+        for (int j = 0; j < NPT; j++) glds16(zero, scratch);
+    };
 
     if (t_begin < t_end) issue(t_begin, smem);
+    if (KG > 1) {
+        if (t_begin + 1 < t_end) issue(t_begin + 1, smem + stage_bytes);
+        else issue_padding();
+    }
     // per-lane constants of the transpose reads (prims.h lds_tr16): lane (g4, i) addresses row 8*(g4>>1) + (i>>2) (+4)
     // of a 16-row k-step, 4 consecutive columns starting at 16*(g4&1) + 4*(i&3) of the wave's 32-column slice
     const int g4 = lane >> 4, li = lane & 15;
@@ -170,64 +199,142 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgParams p) {
     const int bcol = (wn * 32 + 16 * (g4 & 1) + 4 * (li & 3)) * 2;                         // byte column, x patch
     const int kh_bytes = p.XW * 128;                                                       // one patch row of pixels
 
+    struct FragSet {
+        bf16x4 alo, ahi;        // dy fragment of the step
+        bf16x4 blo[5], bhi[5];  // patch fragments of taps 0..4
+        i32x4 cvlo, cvhi;       // view entries of the step itself (its taps 5..8 are requested while it runs)
+        i32x4 vlo, vhi;         // view entries of the FOLLOWING step
+    };
+    const int nks = KP / 16;
+    auto view_of = [&](int ks_, int hi) { return view + (ks_ < nks ? ks_ : nks - 1) * 16 + krow + 4 * hi; };
+    auto tap_lo = [&](const i32x4& v, const char* xs_, int tap) {
+        return reinterpret_cast<const bf16_t*>(xs_ + (v[tap % 3] ^ bcol) + (tap / 3) * kh_bytes);
+    };
+    // dy fragment + taps 0..4 of step ks_ whose view entries are (vl, vh): 12 reads
+    auto request_set = [&](FragSet& f, const i32x4& vl, const i32x4& vh, const char* dys_, const char* xs_, int ks_) {
+        f.alo = lds_tr16_async(reinterpret_cast<const bf16_t*>(dys_ + ks_ * 2048));
+        f.ahi = lds_tr16_async(reinterpret_cast<const bf16_t*>(dys_ + ks_ * 2048 + 512));
+#pragma unroll
+        for (int tap = 0; tap < 5; tap++) {
+            f.blo[tap] = lds_tr16_async(tap_lo(vl, xs_, tap));
+            f.bhi[tap] = lds_tr16_async(tap_lo(vh, xs_, tap));
+        }
+    };
+    // One k-step on set `cur`, which it replaces by the set of step ks_ + KG.  Read order of a step:
+    //   [view entries of step + 2] | tap 0..3: MFMA, request tap + 5 | tap 4: MFMA, request next dy + next tap 0 |
+    //   tap 5..8: MFMA, request next tap 1..4            -- ten reads are issued between a fragment and its use.
+    // A tile's last step requests a set nobody uses (clamped view entries, addresses inside the ring): one loop body, no
+    // tail variants -- the caller drains the queue after the last step.
+    auto run_step = [&](FragSet& cur, const char* dys_, const char* xs_, int ks_, f32x16 (&acc_)[9]) {
+        FragSet nxt;
+        nxt.vlo = lds_read16_async(view_of(ks_ + 2 * KG, 0));
+        nxt.vhi = lds_read16_async(view_of(ks_ + 2 * KG, 1));
+        bf16x4 blo[4], bhi[4];
+        bf16x8 a;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            lds_wait<10>();
+            bf16x8 b;
+            if (tap == 0) {
+                lds_tie(cur.alo);
+                lds_tie(cur.ahi);
+                a = bf16x8{cur.alo[0], cur.alo[1], cur.alo[2], cur.alo[3], cur.ahi[0], cur.ahi[1], cur.ahi[2], cur.ahi[3]};
+            }
+            if (tap < 5) {
+                lds_tie(cur.blo[tap]);
+                lds_tie(cur.bhi[tap]);
+                b = bf16x8{cur.blo[tap][0], cur.blo[tap][1], cur.blo[tap][2], cur.blo[tap][3],
+                           cur.bhi[tap][0], cur.bhi[tap][1], cur.bhi[tap][2], cur.bhi[tap][3]};
+            } else {
+                lds_tie(blo[tap - 5]);
+                lds_tie(bhi[tap - 5]);
+                b = bf16x8{blo[tap - 5][0], blo[tap - 5][1], blo[tap - 5][2], blo[tap - 5][3],
+                           bhi[tap - 5][0], bhi[tap - 5][1], bhi[tap - 5][2], bhi[tap - 5][3]};
+            }
+            acc_[tap] = mfma32(a, b, acc_[tap]);
+            if (tap < 4) {
+                blo[tap] = lds_tr16_async(tap_lo(cur.cvlo, xs_, tap + 5));
+                bhi[tap] = lds_tr16_async(tap_lo(cur.cvhi, xs_, tap + 5));
+            } else {
+                if (tap == 4) {
+                    lds_tie(cur.vlo);  // requested two steps ago
+                    lds_tie(cur.vhi);
+                    nxt.cvlo = cur.vlo;
+                    nxt.cvhi = cur.vhi;
+                    nxt.alo = lds_tr16_async(reinterpret_cast<const bf16_t*>(dys_ + (ks_ + KG) * 2048));
+                    nxt.ahi = lds_tr16_async(reinterpret_cast<const bf16_t*>(dys_ + (ks_ + KG) * 2048 + 512));
+                }
+                nxt.blo[tap - 4] = lds_tr16_async(tap_lo(nxt.cvlo, xs_, tap - 4));
+                nxt.bhi[tap - 4] = lds_tr16_async(tap_lo(nxt.cvhi, xs_, tap - 4));
+            }
+            sched_fence();  // keep each MFMA right behind its own wait
+        }
+        cur = nxt;
+    };
+    // view entries of this wave's first two steps: the same for every tile
+    i32x4 v_first[4] = {lds_read16_async(view_of(kg, 0)), lds_read16_async(view_of(kg, 1)),
+                        lds_read16_async(view_of(kg + KG, 0)), lds_read16_async(view_of(kg + KG, 1))};
+    lds_wait<0>();
+#pragma unroll
+    for (int i = 0; i < 4; i++) lds_tie(v_first[i]);
+
+    int buf = 0;
     for (int t = t_begin; t < t_end; t++) {
-        wait_vmcnt<0>();
-        __syncthreads();  // tile t has landed for every wave; everyone is done with the other buffer
-        const int buf = (t - t_begin) & 1;
-        if (t + 1 < t_end && !(p.abl & 4)) issue(t + 1, smem + (buf ^ 1) * stage_bytes);
+        if (KG == 1) {
+            wait_vmcnt<0>();
+            __syncthreads();  // tile t has landed for every wave; everyone is done with the other buffer
+            buf = (t - t_begin) & 1;
+            if (t + 1 < t_end && !(p.abl & 4)) issue(t + 1, smem + (buf ^ 1) * stage_bytes);
+        } else {
+            wait_vmcnt<NPT>();    // everything but the newest group (tile t + 1 or its padding) has landed: tile t is in
+            block_barrier_raw();  // ... for every wave, and everyone is done with tile t - 1 = the buffer of tile t + 2
+                                  // (__syncthreads() would drain the DMA queue; this wave's LDS reads ended with the last tap)
+            const int nb = buf >= 1 ? buf - 1 : 2;  // (buf + 2) % 3
+            if (t + 2 < t_end && !(p.abl & 4)) issue(t + 2, smem + nb * stage_bytes);
+            else issue_padding();
+        }
         const char* dys = smem + buf * stage_bytes + krow * 128 + acol;
         const char* xs = smem + buf * stage_bytes + KP * 128;
-        for (int ks = 0; ks < KP / 16; ks++) {
-            const ViewEnt vlo = view[(p.abl & 8) ? krow : ks * 16 + krow], vhi = view[(p.abl & 8) ? krow + 4 : ks * 16 + krow + 4];
-            // Transpose reads in the asm form (they must not wait for the next tile's LDS-DMA, see prims.h), software
-            // pipelined six taps ahead of the MFMAs: the LGKM counter is 4 bits, so at most 15 reads may be in flight.
-            // Each MFMA waits only for its own fragments: lgkmcnt(n) = reads issued after them that may still be pending.
-            bf16x4 alo = lds_tr16_async(reinterpret_cast<const bf16_t*>(dys + ks * 2048));
-            bf16x4 ahi = lds_tr16_async(reinterpret_cast<const bf16_t*>(dys + ks * 2048 + 512));
-            const char* plo[3];
-            const char* phi[3];
-#pragma unroll
-            for (int kw = 0; kw < 3; kw++) {
-                plo[kw] = xs + (vlo.v[kw] ^ bcol);
-                phi[kw] = xs + (vhi.v[kw] ^ bcol);
-            }
-            bf16x4 blo[9], bhi[9];
-            auto read_tap = [&](int tap) {
-                if (p.abl & 2) return;
-                blo[tap] = lds_tr16_async(reinterpret_cast<const bf16_t*>(plo[tap % 3] + (tap / 3) * kh_bytes));
-                bhi[tap] = lds_tr16_async(reinterpret_cast<const bf16_t*>(phi[tap % 3] + (tap / 3) * kh_bytes));
-            };
-            constexpr int AHEAD = 6;
-#pragma unroll
-            for (int tap = 0; tap < AHEAD; tap++) read_tap(tap);
-            bf16x8 a;
-#pragma unroll
-            for (int tap = 0; tap < 9; tap++) {
-                // issued after this tap's pair: taps tap+1 .. min(tap+AHEAD-1, 8)
-                switch (2 * ((tap + AHEAD - 1 < 8 ? tap + AHEAD - 1 : 8) - tap)) {
-                    case 10: lds_wait<10>(); break;
-                    case 8: lds_wait<8>(); break;
-                    case 6: lds_wait<6>(); break;
-                    case 4: lds_wait<4>(); break;
-                    case 2: lds_wait<2>(); break;
-                    default: lds_wait<0>(); break;
-                }
-                if (tap == 0) {
-                    lds_tie(alo);
-                    lds_tie(ahi);
-                    a = bf16x8{alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
-                }
-                lds_tie(blo[tap]);
-                lds_tie(bhi[tap]);
-                const bf16x8 b{blo[tap][0], blo[tap][1], blo[tap][2], blo[tap][3], bhi[tap][0], bhi[tap][1], bhi[tap][2], bhi[tap][3]};
-                if (!(p.abl & 1)) acc[tap] = mfma32(a, b, acc[tap]);
-                if (tap + AHEAD < 9) read_tap(tap + AHEAD);
-                sched_fence();  // keep each MFMA right behind its own wait
-            }
+        if (KG > 1) buf = buf == 2 ? 0 : buf + 1;
+        // ---- the tile's k-steps (16 pixels each; this wave's are ks = kg, kg + KG, ...), software-pipelined ACROSS steps.
+        // The chain view table -> patch addresses -> transpose reads -> MFMA is two LDS round trips long; started cold in
+        // every step it left the matrix pipe idle 3/4 of the time.  Step k therefore runs on a fragment set that step k - 1
+        // requested: its dy fragment, its first five patch taps and the view entries of step k + 1; it requests its own last
+        // four taps, and -- from tap 4 on, interleaved with its MFMAs -- the set of step k + 1.  All reads are in the
+        // caller-ordered asm form (prims.h) and return in order, so every wait is "lgkmcnt(number of reads issued after the
+        // fragment needed now)": 10 in the steady state, 12 reads in flight at most (the counter has 4 bits).
+        const int nsteps = (KP / 16 - kg + KG - 1) / KG;
+        if (nsteps > 0) {
+            FragSet f;
+            lds_tie(v_first[0]);
+            lds_tie(v_first[1]);
+            request_set(f, v_first[0], v_first[1], dys, xs, kg);  // (the first steps' view entries are tile-invariant)
+            f.cvlo = v_first[0];
+            f.cvhi = v_first[1];
+            f.vlo = v_first[2];
+            f.vhi = v_first[3];
+            for (int i = 0, ks = kg; i < nsteps; i++, ks += KG) run_step(f, dys, xs, ks, acc);
+            lds_wait<0>();  // the set requested by the last step
+            lds_tie(f.alo);
         }
     }
 
-    // ---- dwp[co][tap][ci] (+)= acc.  A wave instruction covers 2 rows x 32 consecutive ci = whole 128-byte lines.
+    if (KG > 1) {
+        // the second k group hands its accumulators over through LDS (lane-contiguous dwords: no bank conflicts); the staging
+        // ring, the tables and the padding DMAs are finished with first
+        wait_vmcnt<0>();
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem) + (size_t)(wave & 3) * 144 * 64 + lane;
+        if (kg == 1) {
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) red[(tap * 16 + r) * 64] = acc[tap][r];
+        }
+        __syncthreads();
+        if (kg == 1) return;
+    }
+    const float* const red = reinterpret_cast<const float*>(smem) + (size_t)(wave & 3) * 144 * 64 + lane;
     if (p.partial == 2) return;
     float* out = p.dw + (p.partial ? (size_t)zid * p.Cout * 9 * p.Cin : 0);
 #pragma unroll
@@ -237,8 +344,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgParams p) {
             const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             const int ci = ci0 + wn * 32 + (lane & 31);
             float* dst = out + ((size_t)co * 9 + tap) * p.Cin + ci;
-            if (p.partial) *dst = acc[tap][r];
-            else atomicAdd(dst, acc[tap][r]);
+            const float v = KG > 1 ? acc[tap][r] + red[(tap * 16 + r) * 64] : acc[tap][r];
+            if (p.partial) *dst = v;
+            else atomicAdd(dst, v);
         }
 }
 
@@ -288,7 +396,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
     }
 }
 
-struct Plan { WgParams p; int split; size_t lds; };
+struct Plan { WgParams p; int split; size_t lds; int kg; };
 
 // tile geometry: G whole images (small images) or one band of R output rows; at most 256 pixels and 38 KiB per stage
 // (two stages, two blocks per CU); maximise useful pixels per unit of max(MFMA time, staging time)
@@ -317,12 +425,19 @@ bool make_plan(int N, int H, int W, int Cin, int Cout, int stride, Plan& pl) {
     if (best <= 0.0) return false;
     p.ntiles = (N + p.G - 1) / p.G * p.nbands;
     const int pairs = (Cin / 64) * (Cout / 64);
-    const int target = avsr_tune_knobs[15] > 0 ? avsr_tune_knobs[15] : 512;  // knob 15: block-count target (A/B runs)
-    int split = (target + pairs - 1) / pairs;  // default: two blocks per CU
+    // knob 16 = 2: the 8-wave / one-block-per-CU variant (A/B runs; measured 2-6 % slower: its output stage -- LDS hand-over,
+    // four storing waves -- costs more than the halved partial-gradient traffic saves); knob 15: block-count target (A/B runs)
+    pl.kg = avsr_tune_knobs[16] == 2 ? 2 : 1;
+    const int target = avsr_tune_knobs[15] > 0 ? avsr_tune_knobs[15] : (pl.kg == 1 ? 512 : 256);
+    int split = (target + pairs - 1) / pairs;  // default: fill every CU
     if (split > p.ntiles) split = p.ntiles;
     p.tiles_per_block = (p.ntiles + split - 1) / split;
     pl.split = (p.ntiles + p.tiles_per_block - 1) / p.tiles_per_block;
-    pl.lds = (size_t)STAGES * (p.KP + p.XROWS) * 128 + (size_t)p.KP * 16 + (size_t)(p.KP + p.XROWS) * 8;
+    pl.lds = (size_t)(pl.kg == 1 ? 2 : 3) * (p.KP + p.XROWS) * 128 + (size_t)p.KP * 16 + (size_t)(p.KP + p.XROWS) * 8;
+    if (pl.kg == 2) {
+        pl.lds += 8 * 1024;                                                     // one scratch kilobyte per wave
+        if (pl.lds < (size_t)4 * 144 * 64 * 4) pl.lds = (size_t)4 * 144 * 64 * 4;  // the k groups' hand-over
+    }
     return true;
 }
 
@@ -360,8 +475,9 @@ extern "C" int avsr_conv3x3_wgrad_bf16(const void* dy, const void* x, float* dwp
     p.partial = avsr_tune_knobs[3] == 2 ? 2 : (partial ? 1 : 0);
     p.xcd_order = avsr_tune_knobs[4] != 1;
     p.abl = avsr_tune_knobs[5];
-    dim3 grid((Cin / 64) * (Cout / 64) * pl.split), block(256);
-    AVSR_LAUNCH(conv3x3_wgrad_kernel, grid, block, pl.lds, stream, p);
+    dim3 grid((Cin / 64) * (Cout / 64) * pl.split);
+    if (pl.kg == 1) AVSR_LAUNCH(conv3x3_wgrad_kernel<1>, grid, dim3(256), pl.lds, stream, p);
+    else AVSR_LAUNCH(conv3x3_wgrad_kernel<2>, grid, dim3(512), pl.lds, stream, p);
     if (partial) {
         const long n4 = (long)Cout * 9 * Cin / 4;
         AVSR_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(1024), 0, stream,

@@ -174,6 +174,33 @@ AVSR_DEV bf16x4 lds_tr16_async(const bf16_t* p) {
     return v;
 #endif
 }
+// Plain 16- / 8-byte LDS reads in the same caller-ordered form (tables that live beside an LDS-DMA ring).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+AVSR_DEV i32x4 lds_read16_async(const void* p) {
+#ifdef AVSR_EMU
+    i32x4 v;
+    memcpy(&v, p, 16);
+    return v;
+#else
+    const uint32_t addr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+    i32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+#endif
+}
+AVSR_DEV i32x2 lds_read8_async(const void* p) {
+#ifdef AVSR_EMU
+    i32x2 v;
+    memcpy(&v, p, 8);
+    return v;
+#else
+    const uint32_t addr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+    i32x2 v;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+#endif
+}
 template <int N> AVSR_DEV void lds_wait() {
 #ifndef AVSR_EMU
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
@@ -362,7 +389,7 @@ AVSR_DEV float dropout_scale(uint64_t seed, uint64_t idx, float p, float inv_kee
 }
 
 // ---------------------------------------------------------------- status plumbing
-extern int avsr_tune_knobs[16];  // common.hip (avsr_tune)
+extern int avsr_tune_knobs[24];  // common.hip (avsr_tune)
 extern "C" void avsr_set_error(const char* msg);
 extern "C" void avsr_set_error2(const char* where, const char* what);
 #define AVSR_CHECK_LAUNCH(name)                                                   \

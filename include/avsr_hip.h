@@ -316,12 +316,17 @@ int avsr_conv2d_f32s(const float* x, const float* wp, float* y, const void* zero
  * operands are not cache-resident in the training step; 1 = always on; 2 = always off),
  * 2 = ablation mode of the 128x128 forward convolution kernel (1 = no MFMA, 2 = no operand loads; wrong results),
  * 3 = avsr_conv3x3_wgrad_bf16 output stage (0 = as the workspace argument says, 1 = always atomics, 2 = none),
- * 4 = 1 disables the XCD-aware work order of avsr_conv3x3_wgrad_bf16, 5 = ablation mode of avsr_conv3x3_wgrad_bf16,
+ * 4 = 1 disables the XCD-aware work order of avsr_conv3x3_wgrad_bf16, 5 = ablation bits of avsr_conv3x3_wgrad_bf16 (4 = no staging
+ * after the first tile, 16 = no tiles),
  * 6 = persistent-block count of the video-stem weight gradient (0 = default 512), 7 = per-block rotation of the k order in
  * avsr_gemm_bf16_nt (0 = off; measured neutral), 8 / 9 = 1 selects the generic attention forward / backward-dq kernel for
  * bf16 inputs instead of the transposed-formulation kernels, 10 = 1 selects the generic batched TN path of
  * avsr_attention_bwd_kv instead of the k-major tile kernel, 11 = bit mask of that kernel's contractions to skip (fault isolation),
- * 12 = 1 keeps 64 -> 64 channel 3x3 / stride-1 convolutions on the tiled kernel instead of conv3x3_c64.hip.  Knobs 0..15 exist. */
+ * 12 = 1 keeps 64 -> 64 channel 3x3 / stride-1 convolutions on the tiled kernel instead of conv3x3_c64.hip, 13 = ablation bits
+ * of conv3x3_c64.hip (1 = no MFMA loop, 2 = no staging, 4 = no copy-out; wrong results), 14 = tile code forced on the
+ * avsr_gemm_bf16_nt problems whose 64x64 grid has 257..512 tiles (0 = auto), 15 = block-count target of avsr_conv3x3_wgrad_bf16
+ * (0 = one resident set: 512 blocks of 4 waves, or 256 of 8 with knob 16), 16 = 2 selects the 8-wave / one-block-per-CU / two-k-group
+ * variant of avsr_conv3x3_wgrad_bf16 instead of the 4-wave one.  Knobs 0..23 exist. */
 int avsr_tune(int knob, int value);
 /* bf16 implicit-GEMM convolution on the tuned LDS-DMA kernel: dgrad = 0 forward, 1 data gradient (see
  * avsr_conv2d_fwd / avsr_conv2d_dgrad for the tensor conventions); gathered channel count % 64 == 0; stride 1 or 2
