@@ -59,17 +59,21 @@ struct ViewEnt { int v[4]; };
 //   dy rows: s = bit 1 of the row index k;   x patch rows: s = bit 1 of the patch COLUMN (invariant under the kh
 //   shift of a tap, so a pixel needs only three pre-swizzled addresses, one per kw).
 //
-// KG = number of k groups.  KG = 1: 4 waves, two blocks per CU, 2-stage ring.  KG = 2: 8 waves = two groups of the four
-// (co half, ci half) waves that SHARE every staged tile and take alternate 16-pixel k-steps of it; one block per CU, 3-stage
-// ring with a counted vmcnt wait (every wave issues exactly NPT DMA instructions per tile: rows past the tile go from the
-// zero page to a scratch kilobyte), and the two groups' accumulators are added through LDS before the store -- half the
-// partial-gradient bytes per launch (the partials' write + ordered re-read was a quarter of the kernel's time at KG = 1).
-template <int KG>
-__global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv3x3_wgrad_kernel(WgParams p) {
+// KG = number of k groups, MW = 32-row co fragments per wave.
+//   <1, 1>: 4 waves = 2 co halves x 2 ci halves, two blocks per CU, 2-stage ring.
+//   <2, 2>: 4 "fat" waves = 2 k groups x 2 ci halves, each wave BOTH co halves (18 accumulators, 288 registers: one wave
+//           per SIMD, one block per CU): a patch fragment feeds two MFMAs, so the LDS bytes per MFMA halve (the thin
+//           variant is LDS-read-bound: 22 transpose reads per 9 MFMAs); the two k groups share every staged tile and take
+//           alternate 16-pixel k-steps of it; 3-stage ring with a counted vmcnt wait (every wave issues exactly NPT DMA
+//           instructions per tile: rows past the tile go from the zero page to a scratch kilobyte); the groups' accumulators
+//           are added through LDS before the store -- half the partial-gradient bytes per launch.
+//   <2, 1>: 8 thin waves = 2 k groups x the four (co half, ci half) waves (measured slower than <1, 1>; kept for A/B).
+template <int KG, int MW>
+__global__ __launch_bounds__(64 * (MW == 2 ? 2 : 4) * KG, (KG == 1 && MW == 1) ? 2 : 1) void conv3x3_wgrad_kernel(WgParams p) {
     AVSR_DYN_SMEM(smem);
-    constexpr int NT = 256 * KG, NW = 4 * KG, NSTAGE = KG == 1 ? 2 : 3;
+    constexpr int NW = (MW == 2 ? 2 : 4) * KG, NT = 64 * NW, NSTAGE = KG == 1 ? 2 : 3, WPG = NW / KG;  // waves per k group
     const int lane = threadIdx.x & 63, wave = wave_id(), tid = threadIdx.x;
-    const int kg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int kg = wave / WPG, wm = MW == 2 ? 0 : (wave >> 1) & 1, wn = wave & 1;
     // Work item w = (pixel-tile range z, ci block, co block).  All (ci, co) blocks of one z stage the same dy / x rows
     // (a different 128-byte slice each), so they should meet in one L2: block b runs on XCD b % 8 (observed), hence
     // XCD x is handed the contiguous run of work items [x * total/8, (x+1) * total/8) with z slowest.
@@ -118,11 +122,13 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv3x3_wgrad_kerne
     }
     __syncthreads();
 
-    f32x16 acc[9];
+    f32x16 acc[MW][9];
 #pragma unroll
-    for (int t = 0; t < 9; t++)
+    for (int m = 0; m < MW; m++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+        for (int t = 0; t < 9; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][t][r] = 0.f;
 
     const int t_begin = zid * p.tiles_per_block;
     const int t_end = (p.abl & 16) ? t_begin : min(p.ntiles, t_begin + p.tiles_per_block);
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv3x3_wgrad_kerne
     // stage tile t: every wave instruction moves 8 LDS rows (64 lanes x 16 B); rows are padded to whole instructions.
     // Fixed trip counts (KP <= 256, XROWS <= 288) with wave-uniform guards: the descriptors of all of a lane's rows are
     // fetched first, then turned into addresses -- one LDS round trip per tile instead of one per row.
-    constexpr int DY_PASSES = 8 / KG, X_PASSES = KG == 1 ? 9 : 5, NPT = DY_PASSES + X_PASSES, RPP = 8 * NW;  // rows per pass
+    constexpr int RPP = 8 * NW, DY_PASSES = 256 / RPP, X_PASSES = (288 + RPP - 1) / RPP, NPT = DY_PASSES + X_PASSES;  // RPP rows per pass
     const char* const zero = reinterpret_cast<const char*>(p.zero);
     const int rsub = lane >> 3;
     const int chunk0 = (lane & 7) * 16, chunk1 = ((lane & 7) ^ 4) * 16;  // source chunk of this lane for s = 0 / 1
@@ -195,12 +201,14 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv3x3_wgrad_kerne
     // of a 16-row k-step, 4 consecutive columns starting at 16*(g4&1) + 4*(i&3) of the wave's 32-column slice
     const int g4 = lane >> 4, li = lane & 15;
     const int krow = 8 * (g4 >> 1) + (li >> 2);  // bit 1 of krow == bit 1 of krow + 4 == bit 1 of the dy row
-    const int acol = ((wm * 32 + 16 * (g4 & 1) + 4 * (li & 3)) * 2) ^ ((krow & 2) << 5);  // swizzled byte column, dy tile
+    int acol[MW];  // swizzled byte column in the dy tile, per co fragment
+#pragma unroll
+    for (int m = 0; m < MW; m++) acol[m] = (((wm + m) * 32 + 16 * (g4 & 1) + 4 * (li & 3)) * 2) ^ ((krow & 2) << 5);
     const int bcol = (wn * 32 + 16 * (g4 & 1) + 4 * (li & 3)) * 2;                         // byte column, x patch
     const int kh_bytes = p.XW * 128;                                                       // one patch row of pixels
 
     struct FragSet {
-        bf16x4 alo, ahi;        // dy fragment of the step
+        bf16x4 alo[MW], ahi[MW];  // dy fragment(s) of the step
         bf16x4 blo[5], bhi[5];  // patch fragments of taps 0..4
         i32x4 cvlo, cvhi;       // view entries of the step itself (its taps 5..8 are requested while it runs)
         i32x4 vlo, vhi;         // view entries of the FOLLOWING step
@@ -210,10 +218,17 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv3x3_wgrad_kerne
     auto tap_lo = [&](const i32x4& v, const char* xs_, int tap) {
         return reinterpret_cast<const bf16_t*>(xs_ + (v[tap % 3] ^ bcol) + (tap / 3) * kh_bytes);
     };
-    // dy fragment + taps 0..4 of step ks_ whose view entries are (vl, vh): 12 reads
+    // dy fragment(s) + taps 0..4 of step ks_ whose view entries are (vl, vh): 2 MW + 10 reads
+    // (dys_ = the tile's dy rows at this lane's krow; xs_ = its patch)
+    auto request_a = [&](FragSet& f, const char* dys_, int ks_) {
+#pragma unroll
+        for (int m = 0; m < MW; m++) {
+            f.alo[m] = lds_tr16_async(reinterpret_cast<const bf16_t*>(dys_ + acol[m] + ks_ * 2048));
+            f.ahi[m] = lds_tr16_async(reinterpret_cast<const bf16_t*>(dys_ + acol[m] + ks_ * 2048 + 512));
+        }
+    };
     auto request_set = [&](FragSet& f, const i32x4& vl, const i32x4& vh, const char* dys_, const char* xs_, int ks_) {
-        f.alo = lds_tr16_async(reinterpret_cast<const bf16_t*>(dys_ + ks_ * 2048));
-        f.ahi = lds_tr16_async(reinterpret_cast<const bf16_t*>(dys_ + ks_ * 2048 + 512));
+        request_a(f, dys_, ks_);
 #pragma unroll
         for (int tap = 0; tap < 5; tap++) {
             f.blo[tap] = lds_tr16_async(tap_lo(vl, xs_, tap));
@@ -222,23 +237,28 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv3x3_wgrad_kerne
     };
     // One k-step on set `cur`, which it replaces by the set of step ks_ + KG.  Read order of a step:
     //   [view entries of step + 2] | tap 0..3: MFMA, request tap + 5 | tap 4: MFMA, request next dy + next tap 0 |
-    //   tap 5..8: MFMA, request next tap 1..4            -- ten reads are issued between a fragment and its use.
+    //   tap 5..8: MFMA, request next tap 1..4     -- 10 (taps 5..8: 8 + 2 MW) reads are issued between a fragment and its use.
     // A tile's last step requests a set nobody uses (clamped view entries, addresses inside the ring): one loop body, no
     // tail variants -- the caller drains the queue after the last step.
-    auto run_step = [&](FragSet& cur, const char* dys_, const char* xs_, int ks_, f32x16 (&acc_)[9]) {
+    auto run_step = [&](FragSet& cur, const char* dys_, const char* xs_, int ks_, f32x16 (&acc_)[MW][9]) {
         FragSet nxt;
         nxt.vlo = lds_read16_async(view_of(ks_ + 2 * KG, 0));
         nxt.vhi = lds_read16_async(view_of(ks_ + 2 * KG, 1));
         bf16x4 blo[4], bhi[4];
-        bf16x8 a;
+        bf16x8 a[MW];
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
-            lds_wait<10>();
+            if (tap < 5) lds_wait<10>();
+            else lds_wait<8 + 2 * MW>();
             bf16x8 b;
             if (tap == 0) {
-                lds_tie(cur.alo);
-                lds_tie(cur.ahi);
-                a = bf16x8{cur.alo[0], cur.alo[1], cur.alo[2], cur.alo[3], cur.ahi[0], cur.ahi[1], cur.ahi[2], cur.ahi[3]};
+#pragma unroll
+                for (int m = 0; m < MW; m++) {
+                    lds_tie(cur.alo[m]);
+                    lds_tie(cur.ahi[m]);
+                    a[m] = bf16x8{cur.alo[m][0], cur.alo[m][1], cur.alo[m][2], cur.alo[m][3],
+                                  cur.ahi[m][0], cur.ahi[m][1], cur.ahi[m][2], cur.ahi[m][3]};
+                }
             }
             if (tap < 5) {
                 lds_tie(cur.blo[tap]);
@@ -251,7 +271,12 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv3x3_wgrad_kerne
                 b = bf16x8{blo[tap - 5][0], blo[tap - 5][1], blo[tap - 5][2], blo[tap - 5][3],
                            bhi[tap - 5][0], bhi[tap - 5][1], bhi[tap - 5][2], bhi[tap - 5][3]};
             }
-            acc_[tap] = mfma32(a, b, acc_[tap]);
+#pragma unroll
+            for (int m = 0; m < MW; m++) {
+                // 18 accumulators = 288 registers: four of them live in architectural VGPRs (prims.h mfma32_vgpr)
+                if (MW == 2 && m == 1 && tap >= 5) acc_[m][tap] = mfma32_vgpr(a[m], b, acc_[m][tap]);
+                else acc_[m][tap] = mfma32(a[m], b, acc_[m][tap]);
+            }
             if (tap < 4) {
                 blo[tap] = lds_tr16_async(tap_lo(cur.cvlo, xs_, tap + 5));
                 bhi[tap] = lds_tr16_async(tap_lo(cur.cvhi, xs_, tap + 5));
@@ -261,8 +286,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv3x3_wgrad_kerne
                     lds_tie(cur.vhi);
                     nxt.cvlo = cur.vlo;
                     nxt.cvhi = cur.vhi;
-                    nxt.alo = lds_tr16_async(reinterpret_cast<const bf16_t*>(dys_ + (ks_ + KG) * 2048));
-                    nxt.ahi = lds_tr16_async(reinterpret_cast<const bf16_t*>(dys_ + (ks_ + KG) * 2048 + 512));
+                    request_a(nxt, dys_, ks_ + KG);
                 }
                 nxt.blo[tap - 4] = lds_tr16_async(tap_lo(nxt.cvlo, xs_, tap - 4));
                 nxt.bhi[tap - 4] = lds_tr16_async(tap_lo(nxt.cvhi, xs_, tap - 4));
@@ -293,7 +317,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv3x3_wgrad_kerne
             if (t + 2 < t_end && !(p.abl & 4)) issue(t + 2, smem + nb * stage_bytes);
             else issue_padding();
         }
-        const char* dys = smem + buf * stage_bytes + krow * 128 + acol;
+        const char* dys = smem + buf * stage_bytes + krow * 128;
         const char* xs = smem + buf * stage_bytes + KP * 128;
         if (KG > 1) buf = buf == 2 ? 0 : buf + 1;
         // ---- the tile's k-steps (16 pixels each; this wave's are ks = kg, kg + KG, ...), software-pipelined ACROSS steps.
@@ -315,7 +339,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv3x3_wgrad_kerne
             f.vhi = v_first[3];
             for (int i = 0, ks = kg; i < nsteps; i++, ks += KG) run_step(f, dys, xs, ks, acc);
             lds_wait<0>();  // the set requested by the last step
-            lds_tie(f.alo);
+            lds_tie(f.alo[0]);
         }
     }
 
@@ -324,30 +348,34 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv3x3_wgrad_kerne
         // ring, the tables and the padding DMAs are finished with first
         wait_vmcnt<0>();
         __syncthreads();
-        float* red = reinterpret_cast<float*>(smem) + (size_t)(wave & 3) * 144 * 64 + lane;
+        float* red = reinterpret_cast<float*>(smem) + (size_t)(wave % WPG) * MW * 144 * 64 + lane;
         if (kg == 1) {
 #pragma unroll
-            for (int tap = 0; tap < 9; tap++)
+            for (int m = 0; m < MW; m++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) red[(tap * 16 + r) * 64] = acc[tap][r];
+                for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) red[((m * 9 + tap) * 16 + r) * 64] = acc[m][tap][r];
         }
         __syncthreads();
         if (kg == 1) return;
     }
-    const float* const red = reinterpret_cast<const float*>(smem) + (size_t)(wave & 3) * 144 * 64 + lane;
+    const float* const red = reinterpret_cast<const float*>(smem) + (size_t)(wave % WPG) * MW * 144 * 64 + lane;
     if (p.partial == 2) return;
     float* out = p.dw + (p.partial ? (size_t)zid * p.Cout * 9 * p.Cin : 0);
 #pragma unroll
-    for (int tap = 0; tap < 9; tap++)
+    for (int m = 0; m < MW; m++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int ci = ci0 + wn * 32 + (lane & 31);
-            float* dst = out + ((size_t)co * 9 + tap) * p.Cin + ci;
-            const float v = KG > 1 ? acc[tap][r] + red[(tap * 16 + r) * 64] : acc[tap][r];
-            if (p.partial) *dst = v;
-            else atomicAdd(dst, v);
-        }
+        for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int co = co0 + (wm + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int ci = ci0 + wn * 32 + (lane & 31);
+                float* dst = out + ((size_t)co * 9 + tap) * p.Cin + ci;
+                const float v = KG > 1 ? acc[m][tap][r] + red[((m * 9 + tap) * 16 + r) * 64] : acc[m][tap][r];
+                if (p.partial) *dst = v;
+                else atomicAdd(dst, v);
+            }
 }
 
 // dwp[i] = sum_z ws[z][i]: the blocks' partial gradients are combined in a fixed order (deterministic, no atomics).
@@ -396,7 +424,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
     }
 }
 
-struct Plan { WgParams p; int split; size_t lds; int kg; };
+struct Plan { WgParams p; int split; size_t lds; int kg, variant; };
 
 // tile geometry: G whole images (small images) or one band of R output rows; at most 256 pixels and 38 KiB per stage
 // (two stages, two blocks per CU); maximise useful pixels per unit of max(MFMA time, staging time)
@@ -425,9 +453,9 @@ bool make_plan(int N, int H, int W, int Cin, int Cout, int stride, Plan& pl) {
     if (best <= 0.0) return false;
     p.ntiles = (N + p.G - 1) / p.G * p.nbands;
     const int pairs = (Cin / 64) * (Cout / 64);
-    // knob 16 = 2: the 8-wave / one-block-per-CU variant (A/B runs; measured 2-6 % slower: its output stage -- LDS hand-over,
-    // four storing waves -- costs more than the halved partial-gradient traffic saves); knob 15: block-count target (A/B runs)
-    pl.kg = avsr_tune_knobs[16] == 2 ? 2 : 1;
+    // knob 16: kernel variant (see the kernel): 0 / 1 = <1, 1>, 2 = <2, 2> "fat waves", 3 = <2, 1>; knob 15: block-count target
+    pl.variant = avsr_tune_knobs[16] == 2 ? 2 : (avsr_tune_knobs[16] == 3 ? 3 : 1);
+    pl.kg = pl.variant == 1 ? 1 : 2;
     const int target = avsr_tune_knobs[15] > 0 ? avsr_tune_knobs[15] : (pl.kg == 1 ? 512 : 256);
     int split = (target + pairs - 1) / pairs;  // default: fill every CU
     if (split > p.ntiles) split = p.ntiles;
@@ -435,7 +463,7 @@ bool make_plan(int N, int H, int W, int Cin, int Cout, int stride, Plan& pl) {
     pl.split = (p.ntiles + p.tiles_per_block - 1) / p.tiles_per_block;
     pl.lds = (size_t)(pl.kg == 1 ? 2 : 3) * (p.KP + p.XROWS) * 128 + (size_t)p.KP * 16 + (size_t)(p.KP + p.XROWS) * 8;
     if (pl.kg == 2) {
-        pl.lds += 8 * 1024;                                                     // one scratch kilobyte per wave
+        pl.lds += 8 * 1024;                                                     // one scratch kilobyte per wave (at most 8)
         if (pl.lds < (size_t)4 * 144 * 64 * 4) pl.lds = (size_t)4 * 144 * 64 * 4;  // the k groups' hand-over
     }
     return true;
@@ -476,8 +504,9 @@ extern "C" int avsr_conv3x3_wgrad_bf16(const void* dy, const void* x, float* dwp
     p.xcd_order = avsr_tune_knobs[4] != 1;
     p.abl = avsr_tune_knobs[5];
     dim3 grid((Cin / 64) * (Cout / 64) * pl.split);
-    if (pl.kg == 1) AVSR_LAUNCH(conv3x3_wgrad_kernel<1>, grid, dim3(256), pl.lds, stream, p);
-    else AVSR_LAUNCH(conv3x3_wgrad_kernel<2>, grid, dim3(512), pl.lds, stream, p);
+    if (pl.variant == 1) AVSR_LAUNCH((conv3x3_wgrad_kernel<1, 1>), grid, dim3(256), pl.lds, stream, p);
+    else if (pl.variant == 2) AVSR_LAUNCH((conv3x3_wgrad_kernel<2, 2>), grid, dim3(256), pl.lds, stream, p);
+    else AVSR_LAUNCH((conv3x3_wgrad_kernel<2, 1>), grid, dim3(512), pl.lds, stream, p);
     if (partial) {
         const long n4 = (long)Cout * 9 * Cin / 4;
         AVSR_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(1024), 0, stream,

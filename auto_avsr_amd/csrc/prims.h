@@ -294,6 +294,19 @@ AVSR_DEV f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
                                                    __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
 #endif
 }
+// The same MFMA with the accumulator pinned to ARCHITECTURAL VGPRs.  The compiler selects the AGPR form of an MFMA in kernels
+// that may use more than 256 registers and "spills" the accumulators that do not fit the 256 AGPRs by swapping them through
+// VGPRs around every use (32 v_accvgpr moves per MFMA); a kernel with more than 16 accumulators names the overflow here.
+// (Inline asm: the compiler inserts no hazard no-ops around it -- keep dependent uses of the result tens of cycles away;
+// back-to-back MFMAs on different accumulators and MFMA -> MFMA chains on the same one are interlocked by hardware.)
+AVSR_DEV f32x16 mfma32_vgpr(bf16x8 a, bf16x8 b, f32x16 c) {
+#ifdef AVSR_EMU
+    return mfma32(a, b, c);
+#else
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    return c;
+#endif
+}
 // v_mfma_f32_16x16x32_bf16: A lane l holds row (l&15), k = 8*(l>>4)+e; B lane l
 // holds col (l&15); D reg r of lane l is row 4*(l>>4)+r, col l&15.
 AVSR_DEV f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {

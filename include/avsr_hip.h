@@ -325,8 +325,9 @@ int avsr_conv2d_f32s(const float* x, const float* wp, float* y, const void* zero
  * 12 = 1 keeps 64 -> 64 channel 3x3 / stride-1 convolutions on the tiled kernel instead of conv3x3_c64.hip, 13 = ablation bits
  * of conv3x3_c64.hip (1 = no MFMA loop, 2 = no staging, 4 = no copy-out; wrong results), 14 = tile code forced on the
  * avsr_gemm_bf16_nt problems whose 64x64 grid has 257..512 tiles (0 = auto), 15 = block-count target of avsr_conv3x3_wgrad_bf16
- * (0 = one resident set: 512 blocks of 4 waves, or 256 of 8 with knob 16), 16 = 2 selects the 8-wave / one-block-per-CU / two-k-group
- * variant of avsr_conv3x3_wgrad_bf16 instead of the 4-wave one.  Knobs 0..23 exist. */
+ * (0 = one resident set: 512 blocks for the default variant, 256 for the others), 16 = variant of avsr_conv3x3_wgrad_bf16 (0 / 1 =
+ * four thin waves, two blocks per CU; 2 = four fat waves in two k groups, one block per CU; 3 = eight thin waves in two k groups --
+ * both measured slower, kept for A/B runs).  Knobs 0..23 exist. */
 int avsr_tune(int knob, int value);
 /* bf16 implicit-GEMM convolution on the tuned LDS-DMA kernel: dgrad = 0 forward, 1 data gradient (see
  * avsr_conv2d_fwd / avsr_conv2d_dgrad for the tensor conventions); gathered channel count % 64 == 0; stride 1 or 2

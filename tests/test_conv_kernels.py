@@ -110,13 +110,14 @@ def test_conv2d_f32_split_forward(dev, cfg):
     (3, 22, 22, 64, 128, 2), (4, 11, 11, 64, 64, 2), (5, 6, 6, 128, 64, 2), (2, 9, 13, 64, 64, 1), (2, 7, 10, 64, 64, 2),
 ])
 @pytest.mark.parametrize("partial", [True, False])
-@pytest.mark.parametrize("variant", ["kg1", "kg1-long", "kg2", "kg2-long"])
+@pytest.mark.parametrize("variant", ["thin", "thin-long", "fat", "fat-long", "thin8", "thin8-long"])
 def test_conv3x3_wgrad_direct(dev, cfg, partial, variant):
     """Dedicated 3x3 weight-gradient kernel (shifted LDS views of one padded patch, fragment requests pipelined across the
-    16-pixel k-steps) vs torch autograd.  Variants: the default 4-wave kernel; the same with ONE block per (co, ci) pair so that
-    the staging ring and the k-step pipeline run over every tile of the problem; the 8-wave kernel (two k groups sharing each
-    staged tile, 3-stage ring, avsr_tune knob 16 = 2), short and long."""
-    ops.tune(16, 2 if variant.startswith("kg2") else 0)
+    16-pixel k-steps) vs torch autograd.  Variants (avsr_tune knob 16): thin = 4 waves of 32 co x 32 ci; fat = 4 waves of
+    64 co x 32 ci in two k groups that share each staged tile (3-stage ring, LDS hand-over of the accumulators); thin8 = 8 thin
+    waves in two k groups.  "-long": ONE block per (co, ci) pair, so that the staging ring and the k-step pipeline run over
+    every tile of the problem."""
+    ops.tune(16, {"thin": 1, "fat": 2, "thin8": 3}[variant.split("-")[0]])
     ops.tune(15, 1 if variant.endswith("long") else 0)
     try:
         _wgrad_direct(dev, cfg, partial)

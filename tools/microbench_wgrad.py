@@ -34,9 +34,11 @@ def t(fn, reps=20):
 
 
 N = 1600
-for kg2 in (0, 2):
-  ops.tune(16, kg2)
-  print("8 waves = two k groups per staged tile, one block per CU, 3-stage ring (knob 16 = 2)" if kg2 else "4 waves, two blocks per CU, 2-stage ring (default)")
+for variant, name in ((1, "thin: 4 waves of 32 co x 32 ci, two blocks per CU, 2-stage ring"),
+                      (2, "fat: 4 waves of 64 co x 32 ci = 2 k groups x 2 ci halves, one block per CU, 3-stage ring"),
+                      (3, "thin8: 8 thin waves = 2 k groups, one block per CU, 3-stage ring")):
+  ops.tune(16, variant)
+  print(name)
   for (H, C) in ((22, 64), (11, 128), (6, 256), (3, 512)):
       x = torch.randn(N, H, H, C, device=dev).bfloat16()
       dy = torch.randn(N, H, H, C, device=dev).bfloat16()

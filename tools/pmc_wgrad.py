@@ -10,8 +10,8 @@ from auto_avsr_amd import ops
 
 dev = torch.device("cuda:0")
 N = 1600
-for kg in (0, 2):
-    ops.tune(16, kg)
+for variant in (1, 2):
+    ops.tune(16, variant)
     for (H, C) in ((22, 64), (11, 128), (6, 256), (3, 512)):
         x = torch.randn(N, H, H, C, device=dev).bfloat16()
         dy = torch.randn(N, H, H, C, device=dev).bfloat16()
