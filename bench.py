@@ -419,7 +419,7 @@ def main():
 BN_FAMILY = ("avsr_bn_stats", "avsr_bn_stats_finalize", "avsr_bn_act_fwd", "avsr_bn_bwd_reduce", "avsr_bn_bwd_apply",
              "avsr_bn_act_pool_fwd", "avsr_bn_pool_bwd_reduce", "avsr_bn_pool_bwd_apply", "avsr_bn_small_fwd", "avsr_bn_small_bwd")
 # C-ABI entry point -> the kernel names it launches, as rocprofv3 prints them (profiles/*_hbm_traffic.json keys)
-KERNELS_OF = {"avsr_gemm_bf16_nt": r"^gemm_fast_kernel<\d+, \d+, \d+, 0,", "avsr_conv2d_bf16": r"^gemm_fast_kernel<\d+, \d+, \d+, [12],",
+KERNELS_OF = {"avsr_gemm_bf16_nt": r"^gemm_fast_kernel<\d+, \d+, \d+, 0,", "avsr_conv2d_bf16": r"^(gemm_fast_kernel<\d+, \d+, \d+, [12],|conv3x3_c64_kernel)",
               "avsr_conv3x3_wgrad_bf16": r"^(conv3x3_wgrad_kernel|wgrad_reduce_kernel)", "avsr_gemm_bf16_tn": r"^gemm_tn_fast_kernel",
               "bn": r"^bn_(colreduce|bwd_apply|act_fwd|partial_finalize|partial_sum|act_pool3?_fwd|pool_bwd_reduce|pool3?_bwd_apply|stats|small_fwd|small_bwd)"}
 
@@ -427,11 +427,11 @@ KERNELS_OF = {"avsr_gemm_bf16_nt": r"^gemm_fast_kernel<\d+, \d+, \d+, 0,", "avsr
 def counter_traffic(pattern):
     """HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, calibrated) of the kernels matching `pattern`, from the committed
     summary of the two rocprofv3 --pmc passes over one eager step of this workload (tools/pmc_step.py, tools/pmc_report.py ->
-    profiles/r2_hbm_traffic.json).  PMC counters cannot be read from inside this process; the passes are separate runs, as
-    the profiling guide prescribes.  None when the summary is absent."""
+    profiles/r3_hbm_traffic.json; tools/r3_pmc.sh is the recipe).  PMC counters cannot be read from inside this process; the
+    passes are separate runs, as the profiling guide prescribes.  None when the summary is absent."""
     import re
 
-    path = os.path.join(ROOT, "profiles", "r2_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r3_hbm_traffic.json")
     if not os.path.exists(path):
         return None, None
     tr = json.load(open(path))
@@ -443,7 +443,7 @@ def counter_traffic(pattern):
             wr += k["wr_bytes"]
     if n == 0:
         return None, None
-    return round((rd + wr) / n), f"profiles/r2_hbm_traffic.json ({tr.get('shape', '')}): {int(n)} launches, read {rd / 1e6:.0f} MB + written {wr / 1e6:.0f} MB"
+    return round((rd + wr) / n), f"profiles/r3_hbm_traffic.json ({tr.get('shape', '')}): {int(n)} launches, read {rd / 1e6:.0f} MB + written {wr / 1e6:.0f} MB"
 
 
 def roofline(model, batch, ops):

@@ -49,7 +49,7 @@ def load(path, counter):
 FAMILIES = [
     ("transformer GEMMs (Linear fwd / dgrad NT, wgrad TN, paired launches)", r"^(gemm_fast_kernel<\d+, \d+, \d+, 0,|gemm_pair_kernel|gemm_tn_fast_kernel<3, 0>)",
      ("avsr_gemm_bf16_nt", "avsr_gemm_bf16_tn")),
-    ("ResNet conv fwd / dgrad (implicit GEMM)", r"^gemm_fast_kernel<\d+, \d+, \d+, [12],", ("avsr_conv2d_bf16",)),
+    ("ResNet conv fwd / dgrad (implicit GEMM + the patch-staged 64-channel kernel)", r"^(gemm_fast_kernel<\d+, \d+, \d+, [12],|conv3x3_c64_kernel)", ("avsr_conv2d_bf16",)),
     ("ResNet 3x3 conv wgrad", r"^(conv3x3_wgrad_kernel|wgrad_reduce_kernel)", ("avsr_conv3x3_wgrad_bf16",)),
     ("BatchNorm passes", r"^bn_", ("avsr_bn_stats", "avsr_bn_stats_finalize", "avsr_bn_act_fwd", "avsr_bn_bwd_reduce", "avsr_bn_bwd_apply",
                                   "avsr_bn_act_pool_fwd", "avsr_bn_pool_bwd_reduce", "avsr_bn_pool_bwd_apply", "avsr_bn_small_fwd",
