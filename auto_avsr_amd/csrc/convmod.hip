@@ -11,7 +11,6 @@ namespace {
 
 constexpr int DW_CH = 64;     // channels per block (one per lane)
 constexpr int DW_TT = 32;     // outputs per block along time (forward / data gradient)
-constexpr int DW_TW = 64;     // time steps per block (weight gradient)
 constexpr int DW_MAXK = 31;
 
 template <class T>
@@ -98,50 +97,81 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
 }
 
 // dw[c,k] += sum_{b,t} dy[b,t,c] x[b,t+k-pad,c] ;  db[c] += sum dy
-// A block owns 64 channels and walks every gridDim.y-th (batch element, 64-step time tile) pair with its sums in
-// registers; one round of atomics per block at the end.  (One block per tile put B*T/64 colliding atomics on every
-// 128-byte line of dw -- one line per channel -- and the serialised atomics, not the arithmetic, set the kernel time.)
+// A block owns EIGHT channels x all taps: thread = (tap lane k = 0..31, channel 0..7); lane 31 carries the bias sum.  It walks
+// every gridDim.y-th (batch element, 256-step time tile) pair: the tile's dy rows and x rows (+ K - 1 halo) are fetched into
+// registers one item ahead, parked in LDS (row pitch 9 floats: the 32 tap lanes of a channel read 32 different banks) and
+// each thread runs its own 256-term sum -- no cross-thread reduction, and (C / 8) x gridDim.y x 256 atomics at the end.
+// (Round 2's version put 64 channels x 4 tap groups in a block: 16 x more atomics onto the same 95 KB of dw; they, not the
+// arithmetic, set its 29 us.)
+constexpr int DW_W2 = 256;  // time steps per item
+constexpr int DW_P2 = 9;    // LDS row pitch (floats)
 template <class T>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                            float* __restrict__ dw, float* __restrict__ db, int B, int Tlen,
                                                            int C, int K, int glu_in) {
-    __shared__ float xs[(DW_TW + DW_MAXK - 1) * DW_CH];
-    __shared__ float ds[DW_TW * DW_CH];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c0 = blockIdx.x * DW_CH;
-    const int pad = (K - 1) / 2;
-    const int tiles_t = (Tlen + DW_TW - 1) / DW_TW, items = B * tiles_t;
-    float acc[8];
+    __shared__ float xs[(DW_W2 + DW_MAXK - 1) * DW_P2];
+    __shared__ float ds[DW_W2 * DW_P2];
+    const int k = threadIdx.x & 31, cl = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 8;
+    const int pad = (K - 1) / 2, xrows = DW_W2 + K - 1;
+    const int tiles_t = (Tlen + DW_W2 - 1) / DW_W2, items = B * tiles_t;
+    const int kk = min(k, K - 1);
+    float vx[2][8], vd[8];
+    auto fetch_row = [&](const T* src, int b, int t, bool glu, float (&v)[8]) {
+        if (t >= 0 && t < Tlen) {
+            if (glu) {
+                const T* row = src + ((long)b * Tlen + t) * 2 * C + c0;
+                float g[8];
+                load8(row, v);
+                load8(row + C, g);
 #pragma unroll
-    for (int i = 0; i < 8; i++) acc[i] = 0.f;
-    float sb = 0.f;
-    for (int it = blockIdx.y; it < items; it += gridDim.y) {
-        const int b = it / tiles_t, t0 = (it - b * tiles_t) * DW_TW;
+                for (int e = 0; e < 8; e++) {
+                    v[e] *= avsr_sigmoid(g[e]);
+                    if (sizeof(T) == 2) v[e] = bf2f(f2bf(v[e]));  // as the stand-alone GLU kernel would have stored it
+                }
+            } else {
+                load8(src + ((long)b * Tlen + t) * C + c0, v);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = 0.f;
+        }
+    };
+    auto fetch = [&](int it) {
+        const int b = it / tiles_t, t0 = (it - b * tiles_t) * DW_W2;
+        fetch_row(x, b, t0 - pad + (int)threadIdx.x, glu_in != 0, vx[0]);
+        if ((int)threadIdx.x + 256 < xrows) fetch_row(x, b, t0 - pad + (int)threadIdx.x + 256, glu_in != 0, vx[1]);
+        fetch_row(dy, b, t0 + (int)threadIdx.x, false, vd);
+    };
+    float acc = 0.f, sb = 0.f;
+    int it = blockIdx.y;
+    if (it < items) fetch(it);
+    for (; it < items; it += gridDim.y) {
         __syncthreads();  // the previous item's tiles are no longer read
-        if (glu_in) stage_time_tile_glu<T>(xs, x, b, t0 - pad, DW_TW + K - 1, Tlen, C, c0);
-        else stage_time_tile<T>(xs, x, b, t0 - pad, DW_TW + K - 1, Tlen, C, c0);
-        stage_time_tile<T>(ds, dy, b, t0, DW_TW, Tlen, C, c0);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            xs[threadIdx.x * DW_P2 + e] = vx[0][e];
+            if ((int)threadIdx.x + 256 < xrows) xs[(threadIdx.x + 256) * DW_P2 + e] = vx[1][e];
+            ds[threadIdx.x * DW_P2 + e] = vd[e];
+        }
         __syncthreads();
-        // branch-free inner loop: taps beyond K read a clamped (valid) row and are simply never written back, so the
-        // eight LDS reads of a time step issue together instead of one latency-exposed round trip per tap
-#pragma unroll 2
-        for (int t = 0; t < DW_TW; t++) {
-            const float g = ds[t * DW_CH + tx];
-            sb += g;
-            float xv[8];
+        if (it + (int)gridDim.y < items) fetch(it + gridDim.y);  // in flight during the sums below
+        float a4[4] = {0.f, 0.f, 0.f, 0.f}, s4 = 0.f;
+#pragma unroll 4
+        for (int t = 0; t < DW_W2; t += 4) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) xv[i] = xs[(t + min(ty + 4 * i, K - 1)) * DW_CH + tx];
-#pragma unroll
-            for (int i = 0; i < 8; i++) acc[i] += g * xv[i];
+            for (int u = 0; u < 4; u++) {
+                const float g = ds[(t + u) * DW_P2 + cl];
+                a4[u] += g * xs[(t + u + kk) * DW_P2 + cl];
+                s4 += g;
+            }
         }
+        acc += (a4[0] + a4[1]) + (a4[2] + a4[3]);
+        sb += s4;
     }
-    if (c0 + tx < C) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int k = ty + 4 * i;
-            if (k < K) atomicAdd(dw + (long)(c0 + tx) * K + k, acc[i]);
-        }
-        if (ty == 0 && db) atomicAdd(db + c0 + tx, sb);
+    if (c0 + cl < C) {
+        if (k < K) atomicAdd(dw + (long)(c0 + cl) * K + k, acc);
+        if (k == 31 && db) atomicAdd(db + c0 + cl, sb);
     }
 }
 
@@ -168,10 +198,10 @@ extern "C" int avsr_dwconv_wgrad(const void* x, const void* dy, int dtype, float
     AVSR_REQUIRE(K >= 1 && K <= DW_MAXK && (K & 1), "dwconv: K must be odd and <= 31");
     AVSR_REQUIRE(C % 8 == 0, "dwconv: C must be a multiple of 8");
     if (B <= 0 || T <= 0) return 0;
-    const int items = B * ((T + DW_TW - 1) / DW_TW), cblocks = (C + DW_CH - 1) / DW_CH;
-    int chunks = (512 + cblocks - 1) / cblocks;  // about two blocks per CU, a few items each
+    const int items = B * ((T + DW_W2 - 1) / DW_W2), cblocks = C / 8;
+    int chunks = (512 + cblocks - 1) / cblocks;  // about two blocks per CU
     if (chunks > items) chunks = items;
-    if (chunks > 16) chunks = 16;  // more, smaller blocks were measured slower (43 chunks: 31 -> 49 us): the per-block atomics dominate
+    if (chunks > 8) chunks = 8;
     dim3 grid(cblocks, chunks), block(256);
     if (dtype == 0)
         AVSR_LAUNCH((dwconv_wgrad_kernel<float>), grid, block, 0, stream, (const float*)x, (const float*)dy, dw, db, B, T, C, K,

@@ -320,16 +320,17 @@ def _refresh_conv_weights():
     if _wconv_table["built_for"] != len(_wconv):
         import struct
 
-        blob, blk = b"", 0
+        blob, blk, max_taps = b"", 0, 1
         for (ptr, to_dgrad, shape), ent in _wconv.items():
             Cout, Cin = shape[0], shape[1]
             taps = ent[2][0, 0].numel()
             blob += struct.pack("<QQiiiiiiii", ent[2].data_ptr(), ent[1].data_ptr(), Cout, Cin, taps, int(to_dgrad), blk, 0, 0, 0)
-            blk += (Cout * Cin * taps + 2047) // 2048
+            blk += ops.weight_permute_blocks(Cout, Cin, to_dgrad)
+            max_taps = max(max_taps, taps)
         dev = next(iter(_wconv.values()))[2].device
         host = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
-        _wconv_table.update(n=len(_wconv), dev=host.to(dev), blocks=blk, built_for=len(_wconv))
-    ops.multi_weight_permute(_wconv_table["dev"], _wconv_table["n"], _wconv_table["blocks"])
+        _wconv_table.update(n=len(_wconv), dev=host.to(dev), blocks=blk, built_for=len(_wconv), max_taps=max_taps)
+    ops.multi_weight_permute(_wconv_table["dev"], _wconv_table["n"], _wconv_table["blocks"], _wconv_table["max_taps"])
     for ent in _wconv.values():
         ent[0] = ent[2]._version
 

@@ -700,8 +700,12 @@ def cast_into(src, dst):
          _stream(src))
 
 
-def multi_weight_permute(table_dev, n, blocks):
-    call("avsr_multi_weight_permute", _ptr(table_dev), n, blocks, _stream(table_dev))
+def weight_permute_blocks(Cout, Cin, to_dgrad):
+    return int(call("avsr_weight_permute_blocks", Cout, Cin, int(to_dgrad)))
+
+
+def multi_weight_permute(table_dev, n, blocks, max_taps):
+    call("avsr_multi_weight_permute", _ptr(table_dev), n, blocks, max_taps, _stream(table_dev))
 
 
 def multi_cast_transpose(table_dev, n, blocks):

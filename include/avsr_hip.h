@@ -243,8 +243,10 @@ int avsr_conv_weight_permute(const float* w, void* out, int out_dtype, int Cout,
                              int64_t ld_out, avsr_stream_t stream);
 /* dw[Cout][Cin][taps] = dwp[Cout][taps][Cin] */
 /* all conv weights of a model in one launch: table of 48-byte entries {const float* w, bf16* out, int Cout, Cin, taps,
- * to_dgrad, blk0, 0, 0, 0} in device memory, blk0 = running sum of ceil(Cout*Cin*taps / 2048) */
-int avsr_multi_weight_permute(const void* table, int n, int total_blocks, avsr_stream_t stream);
+ * to_dgrad, blk0, 0, 0, 0} in device memory, blk0 = running sum of avsr_weight_permute_blocks(Cout, Cin, to_dgrad) (one block =
+ * one 8 x 64 / 64 x 8 (co, ci) tile x all taps, transposed through LDS); max_taps = the largest taps of the table (<= 64) */
+int64_t avsr_weight_permute_blocks(int Cout, int Cin, int to_dgrad);
+int avsr_multi_weight_permute(const void* table, int n, int total_blocks, int max_taps, avsr_stream_t stream);
 int avsr_conv_weight_unpermute(const float* dwp, float* dw, int Cout, int Cin, int taps, avsr_stream_t stream);
 /* y[N,OH,OW,Cout] = conv(x[N,H,W,Cin], wp[Cout][KH][KW][Cin])   (frontend/resnet.py:10-17,20-35; H = 1 for 1-D) */
 int avsr_conv2d_fwd(const void* x, int dtype, const void* wp, int w_dtype, void* y, int N, int H, int W, int Cin,

@@ -276,3 +276,26 @@ def test_conv3x3_c64_persistent(dev, cfg):
     assert (y - nhwc(y_ref.detach())).abs().max() < 2e-2 * max(1.0, y_ref.abs().max().item())
     assert (dx - nhwc(x.grad) - res.float()).abs().max() < 4e-2 * max(1.0, x.grad.abs().max().item())
     assert (y - yt).abs().max() < 2e-2 * max(1.0, y_ref.abs().max().item()) and (dx - dxt).abs().max() < 4e-2 * max(1.0, x.grad.abs().max().item())
+
+
+def test_multi_weight_permute_matches_single(dev):
+    """All conv-weight copies of a model in ONE launch (LDS-transposed tiles: 8 co x 64 ci forward copies, 64 co x 8 ci
+    data-gradient copies, all taps) == the per-tensor permute, bit for bit; ragged channel counts and 1 / 3 / 9 taps included."""
+    import struct
+
+    torch.manual_seed(11)
+    shapes = [(64, 64, 9, 0), (64, 64, 9, 1), (128, 64, 9, 0), (128, 64, 9, 1), (128, 64, 1, 0), (128, 64, 1, 1), (72, 40, 3, 0),
+              (72, 40, 3, 1), (8, 200, 9, 1), (200, 8, 9, 0)]
+    ws, outs, blob, blk = [], [], b"", 0
+    for (Cout, Cin, taps, dg) in shapes:
+        w = torch.randn(Cout, Cin, taps, device=dev)
+        o = torch.full((Cout * Cin * taps,), float("nan"), dtype=torch.bfloat16, device=dev)
+        blob += struct.pack("<QQiiiiiiii", w.data_ptr(), o.data_ptr(), Cout, Cin, taps, dg, blk, 0, 0, 0)
+        blk += ops.weight_permute_blocks(Cout, Cin, dg)
+        ws.append(w)
+        outs.append(o)
+    table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    ops.multi_weight_permute(table, len(shapes), blk, 9)
+    for (Cout, Cin, taps, dg), w, o in zip(shapes, ws, outs):
+        ref = ops.conv_weight_permute(w.view(Cout, Cin, taps, 1), torch.bfloat16, to_dgrad=bool(dg))
+        assert torch.equal(o.cpu().view(-1), ref.cpu().view(-1)), (Cout, Cin, taps, dg)

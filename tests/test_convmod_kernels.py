@@ -64,6 +64,26 @@ def test_dwconv(dev, K):
     assert (db.cpu() - bias.grad).abs().max() < 1e-3
 
 
+@pytest.mark.parametrize("glu", [False, True])
+def test_dwconv_wgrad_long_sequences(dev, glu):
+    """Weight gradient over several 256-step time tiles per utterance and more (utterance, tile) items than blocks along the
+    item axis: halo rows across tile boundaries, the register prefetch of the next item, ragged last tile."""
+    torch.manual_seed(5)
+    B, T, C, K = 11, 300, 24, 31
+    a = torch.randn(B, T, 2 * C if glu else C, requires_grad=True)
+    w = torch.randn(C, 1, K, requires_grad=True)
+    bias = torch.randn(C, requires_grad=True)
+    xin = F.glu(a, dim=-1) if glu else a
+    y_ref = F.conv1d(xin.transpose(1, 2), w, bias, padding=(K - 1) // 2, groups=C).transpose(1, 2)
+    dy = torch.randn(B, T, C)
+    y_ref.backward(dy)
+    dw, db = torch.zeros(C, K, device=dev), torch.zeros(C, device=dev)
+    ops.dwconv_wgrad(a.detach().to(dev), dy.to(dev), dw, db, B, T, C, K, glu_in=glu)
+    scale = w.grad.abs().max().item()
+    assert (dw.cpu() - w.grad.reshape(C, K)).abs().max() < 2e-5 * scale * 10
+    assert (db.cpu() - bias.grad).abs().max() < 1e-3
+
+
 @pytest.mark.parametrize("K", [31, 7])
 def test_dwconv_with_folded_glu(dev, K):
     """GLU folded into the depthwise convolution (conformer_encoder.py:32-33): forward on the pre-GLU tensor, weight gradient
