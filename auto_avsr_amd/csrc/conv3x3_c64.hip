@@ -50,7 +50,9 @@ struct C64Params {
 };
 
 // FLIP (data gradient: taps reversed) is a template parameter so that every tap offset is a compile-time multiple of the patch pitch.
-template <bool FLIP>
+// XABL (benchmarks only, compile-time so that the measured loop carries no switches): 1 = no fragment reads after the first two
+// quads (MFMAs on stale registers), 2 = no MFMAs (fragment reads only)
+template <bool FLIP, int XABL = 0>
 __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(C64Params p) {
     AVSR_DYN_SMEM(smem);
     char* ost0 = smem + 2 * p.patch_bytes;
@@ -197,24 +199,32 @@ __global__ __launch_bounds__(NTHR) void conv3x3_c64_kernel(C64Params p) {
             for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
         // 36 k-steps (tap, 16 channels); the four pixel fragments of step s + 2 are requested right after the MFMAs of step s
         // were issued (into the registers those MFMAs read: they are issued, hence have read their operands)
-        auto frag_quad = [&](int s, bf16x8 (&xf)[4]) {
+        auto frag_quad = [&](int s, i32x4 (&xf)[4]) {
             const int tap = s >> 2, ks = s & 3;
 #pragma unroll
-            for (int i = 0; i < 4; i++) xf[i] = *reinterpret_cast<const bf16x8*>(patch + (fbase[tap][i] ^ (ks << 5)));
+            for (int i = 0; i < 4; i++) xf[i] = lds_read16_async(patch + (fbase[tap][i] ^ (ks << 5)));
         };
-        // Order inside a step: the four MFMAs FIRST, then the fragment requests of step s + 2 and the woven piece.  The compiler
-        // waits with a full lgkmcnt(0) in front of the MFMAs whenever an LDS-DMA or a scalar load is in flight; with the
-        // requests issued right BEFORE that wait the wave sat out a whole LDS round trip per step with an idle MFMA pipe (every
-        // phase of the tile added up: 93 us); issued right AFTER the previous step's MFMAs, the wait runs under those MFMAs.
-        bf16x8 xf[2][4], cv = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        // Order inside a step: the four MFMAs FIRST, then the fragment requests of step s + 2 and the woven piece.  The
+        // fragment reads are in the caller-ordered asm form (prims.h): with plain LDS loads the compiler put a full lgkmcnt(0)
+        // in front of every step's MFMAs (an LDS-DMA is always in flight here), i.e. each step also waited for the fragments of
+        // step s + 2 it had just requested -- one exposed LDS round trip per 128 MFMA cycles.  Now a step waits for its own
+        // four fragments only: lgkmcnt(4) = the four requests of the following step may still be out (reads return in order;
+        // a woven LDS read issued in between only makes the wait slightly conservative).
+        i32x4 xf[2][4];
+        bf16x8 cv = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         frag_quad(0, xf[0]);
         frag_quad(1, xf[1]);
 #pragma unroll
         for (int s = 0; s < KTOT / 16; s++) {
+            if (s + 1 < KTOT / 16) lds_wait<4>();
+            else lds_wait<0>();
 #pragma unroll
-            for (int i = 0; i < 4; i++) acc[i] = mfma32(bw[s], xf[s & 1][i], acc[i]);  // rows = channels, columns = pixels
+            for (int i = 0; i < 4; i++) {
+                lds_tie(xf[s & 1][i]);
+                if (XABL != 2) acc[i] = mfma32(bw[s], __builtin_bit_cast(bf16x8, xf[s & 1][i]), acc[i]);  // rows = channels, columns = pixels
+            }
             sched_fence();
-            if (s + 2 < KTOT / 16) frag_quad(s + 2, xf[s & 1]);
+            if (s + 2 < KTOT / 16 && XABL != 1) frag_quad(s + 2, xf[s & 1]);
             // the woven piece of this step
             if (s < DMA_PER_WAVE) {
                 if (do_stage) stage_one(st, s);
@@ -288,7 +298,9 @@ int avsr_conv3x3_c64_launch(int flip, const void* src, const void* wq, const voi
     p.abl = avsr_tune_knobs[13];
     const int grid = p.ntiles < 256 ? p.ntiles : 256;  // one persistent block per CU
     const size_t lds = 2 * (size_t)p.patch_bytes + OST_BYTES;
-    if (flip) AVSR_LAUNCH(conv3x3_c64_kernel<true>, dim3(grid), dim3(NTHR), lds, stream, p);
+    if (p.abl & 8) AVSR_LAUNCH((conv3x3_c64_kernel<false, 1>), dim3(grid), dim3(NTHR), lds, stream, p);
+    else if (p.abl & 16) AVSR_LAUNCH((conv3x3_c64_kernel<false, 2>), dim3(grid), dim3(NTHR), lds, stream, p);
+    else if (flip) AVSR_LAUNCH(conv3x3_c64_kernel<true>, dim3(grid), dim3(NTHR), lds, stream, p);
     else AVSR_LAUNCH(conv3x3_c64_kernel<false>, dim3(grid), dim3(NTHR), lds, stream, p);
     return 0;
 }

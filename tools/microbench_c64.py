@@ -18,15 +18,26 @@ wpd = ops.conv_weight_permute(w, torch.bfloat16, to_dgrad=True)
 
 
 def t(fn, reps=20):
-    for _ in range(3):
+    """us per call, replayed from a hipGraph (the Python side of one call costs about as much as the kernel)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
         fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        fn()
+    for _ in range(3):
+        g.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e3
+    return e0.elapsed_time(e1) / (3 * reps) * 1e3
 
 
 fwd = lambda: ops.conv2d_fwd(x, wp, N, H, W, C, C, 3, 3, 1, 1, 1, False)
@@ -34,8 +45,9 @@ dgr = lambda: ops.conv2d_dgrad(x, wpd, res, N, H, W, C, C, 3, 3, 1, 1, 1, False)
 ops.tune(12, 1)
 print(f"tiled kernel      : fwd {t(fwd):7.1f} us   dgrad+resid {t(dgr):7.1f} us")
 ops.tune(12, 0)
-for abl, name in ((0, "full"), (1, "no MFMA loop"), (2, "no staging"), (4, "no copy-out"), (3, "no MFMA, no staging"),
-                  (5, "no MFMA, no copy-out"), (6, "no staging, no copy-out"), (7, "barriers + weights only")):
+for abl, name in ((0, "full"), (2, "no staging"), (4, "no copy-out"), (6, "no staging, no copy-out"),
+                  (8 + 6, "MFMA loop without fragment reads, no staging, no copy-out"),
+                  (16 + 6, "fragment reads without MFMAs, no staging, no copy-out")):
     ops.tune(13, abl)
-    print(f"persistent {name:24s}: fwd {t(fwd):7.1f} us   dgrad+resid {t(dgr):7.1f} us")
+    print(f"persistent {name:60s}: fwd {t(fwd):7.1f} us   dgrad+resid {t(dgr):7.1f} us")
 ops.tune(13, 0)

@@ -14,3 +14,9 @@ run r3_final_bench_audio $B --modality audio --no-roofline --no-precise-leg
 run r3_final_bench_eager $B --no-graph --no-roofline --no-parity --no-precise-leg
 run r3_final_bench_av3200 python tools/bench_av.py
 run r3_final_bench_av3200_eager python tools/bench_av.py --no-graph
+run r3_final_bench_audio_babble $B --modality audio --babble --no-roofline --no-precise-leg
+run r3_final_decode_throughput python tools/bench_decode.py
+bash tools/gpu_timeline.sh r3_final_bf16 --no-precise-leg > /dev/null 2>&1; echo "timeline bf16 rc=$?"
+bash tools/gpu_timeline.sh r3_final_hpf --mode hpf > /dev/null 2>&1; echo "timeline hpf rc=$?"
+bash tools/gpu_prof.sh r3_final --no-precise-leg > /dev/null 2>&1; echo "kernel stats rc=$?"
+ls -la $O | grep r3_final
