@@ -1,0 +1,68 @@
+"""Stream-ordered collectives of the data-parallel step (csrc/comm.hip): RCCL's C API called from `libavsr_hip.so`, up to four
+communicators per process, every operation ONE operation on the current HIP stream -- no torch Work objects, no events for a
+process-group watchdog to poll, hence safe inside a hipGraph capture.
+
+    comm = StreamComm.from_process_group()      # bootstrap: rank 0's 128-byte RCCL id travels over torch.distributed
+    comm.all_reduce(flat_f32)                   # in place, sum, on torch.cuda.current_stream()
+    comm.all_gather(out_f32, mine_f32)
+
+Users: `ddp.GradBuckets(comm=...)` (gradient buckets on a side stream), `functional.set_bn_sync(group, comm=...)` (the
+cross-rank BatchNorm statistics), `bench.py --ddp buckets-graph` (W / sum(B) all-gather).  GPU only: the CPU test suite runs the
+same callers on torch.distributed / gloo (comm=None)."""
+import ctypes
+
+import torch
+
+from . import _lib, ops
+
+
+class StreamComm:
+    _live = {}  # slot -> communicator (the library holds up to four)
+
+    def __init__(self, unique_id: bytes, world: int, rank: int):
+        assert len(unique_id) == 128
+        free = [s for s in range(4) if s not in StreamComm._live]
+        if not free:
+            raise RuntimeError("StreamComm: four communicators per process (close() one)")
+        self.slot = free[0]
+        buf = ctypes.create_string_buffer(unique_id, 128)
+        _lib.lib().call("avsr_comm_init", self.slot, ctypes.cast(buf, ctypes.c_void_p).value, world, rank)
+        self.world, self.rank = world, rank
+        StreamComm._live[self.slot] = self
+
+    @staticmethod
+    def new_unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        _lib.lib().call("avsr_comm_unique_id", ctypes.cast(buf, ctypes.c_void_p).value)
+        return buf.raw
+
+    @classmethod
+    def from_process_group(cls, group=None):
+        """Collective over the torch process group `group` (default: WORLD): every rank must call it."""
+        import torch.distributed as dist
+
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        box = [cls.new_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(box[0], world, rank)
+
+    @classmethod
+    def single(cls):
+        """A one-rank communicator (tools/rccl_capi_world1.py: the whole N > 1 code path on one GPU)."""
+        return cls(cls.new_unique_id(), 1, 0)
+
+    def all_reduce(self, t):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+        ops.call("avsr_comm_all_reduce_f32", self.slot, ops._ptr(t), t.numel(), ops._stream(t), nbytes=8.0 * t.numel())
+        return t
+
+    def all_gather(self, out, mine):
+        assert out.dtype == mine.dtype == torch.float32 and out.is_contiguous() and mine.is_contiguous()
+        assert out.numel() == self.world * mine.numel()
+        ops.call("avsr_comm_all_gather_f32", self.slot, ops._ptr(mine), ops._ptr(out), mine.numel(), ops._stream(out))
+        return out
+
+    def close(self):
+        if StreamComm._live.get(self.slot) is self:
+            _lib.lib().call("avsr_comm_destroy", self.slot)
+            del StreamComm._live[self.slot]

@@ -25,12 +25,23 @@ from . import ops
 _CHUNK = 4096  # elements per block of avsr_multi_copy_scale (csrc/optim.hip OPT_CHUNK)
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class GradBuckets:
-    def __init__(self, params, group=None, bucket_mb=64.0):
+    def __init__(self, params, group=None, bucket_mb=64.0, comm=None):
         self.params = [p for p in params if p.requires_grad]
         assert self.params and all(p.dtype == torch.float32 for p in self.params)
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # comm: a comm.StreamComm over the same ranks -- the bucket all-reduces then go straight to RCCL on a side stream of
+        # this object (forked from / joined to the compute stream with events: capturable), not through torch.distributed
+        self.comm = comm
+        self.world = comm.world if comm is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.device = self.params[0].device
         cap = max(1, int(bucket_mb * (1 << 20) / 4))
         # buckets over the parameters in reverse order; every slice starts 16-byte aligned
@@ -53,18 +64,35 @@ class GradBuckets:
                       for i in range(len(self.params))}
         self._left = [len(m) for m in members]
         self._works = []
-        self._tables = {}  # (bucket, gradient addresses) -> (pinned host rows, device table, blocks)
-        # pinned staging for the pointer tables is allocated HERE (hipHostMalloc is not allowed under stream capture)
-        self._free_host = [[self._new_host(len(m)) for _ in range(24)] for m in members]
+        # Pointer tables of the gather launches.  A captured step keeps ONE (pinned host rows, device table) pair per bucket for
+        # good -- the capture records a copy node that reads the pinned rows on every replay.  Eager steps (gradient addresses
+        # change from step to step) rotate through a small ring per bucket whose slots carry an event: a slot's pinned rows are
+        # rewritten only after the asynchronous copy that last read them has completed.  Everything pinned is allocated HERE
+        # (hipHostMalloc is not allowed under stream capture).
+        self._captured = {}  # (bucket, gradient addresses) -> (host rows, device table, blocks)
+        self._spare = [[self._new_slot(len(m)) for _ in range(24)] for m in members]  # for captured steps (one per batch shape)
+        self._ring = [[self._new_slot(len(m)) for _ in range(4)] for m in members]    # for eager steps
+        self._ring_pos = [0] * len(members)
+        self.compute_stream = None  # set by begin_step(): the stream the step's kernels are issued on
+        self._seen = [dict() for _ in members]  # per bucket: the streams its parameters' hooks ran on in this step
+        self._side = torch.cuda.Stream(device=self.device) if comm is not None else None
+        self._side_used = False
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
 
-    def _new_host(self, n):
-        t = torch.empty(48 * n, dtype=torch.uint8)
-        return t.pin_memory() if self.device.type == "cuda" else t
+    def _new_slot(self, n):
+        host = torch.empty(48 * n, dtype=torch.uint8)
+        if self.device.type == "cuda":
+            host = host.pin_memory()
+        return [host, torch.empty(48 * n, dtype=torch.uint8, device=self.device), None]  # rows, device table, event of the last copy
 
     def _make_hook(self, i):
         def hook(param):
             b = self.bucket_of[i]
+            if self.device.type == "cuda":
+                # a post-accumulate hook runs on the stream of its parameter's AccumulateGrad node -- not necessarily the
+                # same stream for every parameter of the bucket (nodes that survived from an earlier iteration keep theirs)
+                st = torch.cuda.current_stream()
+                self._seen[b][st.cuda_stream] = st
             self._left[b] -= 1
             if self._left[b] == 0:
                 self._flush(b)
@@ -74,36 +102,79 @@ class GradBuckets:
         idx = self.members[b]
         grads = [self.params[i].grad for i in idx]
         assert all(g is not None and g.dtype == torch.float32 and g.is_contiguous() for g in grads)
-        key = (b,) + tuple(g.data_ptr() for g in grads)
-        ent = self._tables.get(key)
-        if ent is None:
+        ptrs = tuple(g.data_ptr() for g in grads)
+        numel = np.array([self.params[i].numel() for i in idx], dtype=np.int64)
+        nblk = (numel + _CHUNK - 1) // _CHUNK
+        blocks = int(nblk.sum())
+
+        def fill(host):
             rows = np.zeros((len(idx), 6), dtype=np.uint64)
-            numel = np.array([self.params[i].numel() for i in idx], dtype=np.int64)
-            blocks = (numel + _CHUNK - 1) // _CHUNK
             rows[:, 0] = [self.views[i].data_ptr() for i in idx]
-            rows[:, 1] = key[1:]
+            rows[:, 1] = ptrs
             rows[:, 4] = numel.astype(np.uint64)
-            rows[:, 5] = (np.cumsum(blocks) - blocks).astype(np.uint64)
-            capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
-            if not capturing and len(self._tables) >= 64:  # eager address churn: recycle the eager tables
-                for k in [k for k, e in self._tables.items() if not e[3]]:
-                    self._free_host[k[0]].append(self._tables.pop(k)[0])
-            if not self._free_host[b]:
-                if capturing:
-                    raise RuntimeError("GradBuckets: out of pre-pinned table buffers under hipGraph capture")
-                self._free_host[b].append(self._new_host(len(idx)))
-            host = self._free_host[b].pop()
+            rows[:, 5] = (np.cumsum(nblk) - nblk).astype(np.uint64)
             host.numpy()[:] = rows.reshape(-1).view(np.uint8)
-            ent = self._tables[key] = (host, torch.empty(host.numel(), dtype=torch.uint8, device=self.device), int(blocks.sum()),
-                                       capturing)
-        host, dev, blocks, _ = ent
-        dev.copy_(host, non_blocking=True)  # (under capture: a memcpy node reading this pinned buffer on every replay)
-        ops.call("avsr_multi_copy_scale", ops._ptr(dev), len(idx), blocks, 1.0 / self.world, ops._stream(dev),
-                 nbytes=8.0 * self.flat[b].numel())
-        for i in idx:
-            self.params[i].grad = self.views[i]
-        if self.world > 1 or self.group is not None:
-            self._works.append(dist.all_reduce(self.flat[b], group=self.group, async_op=True))
+
+        capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        slot = None
+        if capturing:
+            ent = self._captured.get((b,) + ptrs)
+            if ent is None:
+                if not self._spare[b]:
+                    raise RuntimeError("GradBuckets: out of pre-pinned table buffers under hipGraph capture (24 captured step shapes per bucket)")
+                host, dev, _ = self._spare[b].pop()
+                fill(host)
+                ent = self._captured[(b,) + ptrs] = (host, dev, blocks)
+            host, dev, _ = ent
+        else:
+            slot = self._ring[b][self._ring_pos[b]]
+            self._ring_pos[b] = (self._ring_pos[b] + 1) % len(self._ring[b])
+            if slot[2] is not None:
+                slot[2].synchronize()  # the copy that last read these pinned rows (four steps ago: long done)
+            host, dev = slot[0], slot[1]
+            fill(host)
+        # Which stream issues the gather.  This hook runs on the stream of the last parameter's AccumulateGrad node, which need
+        # not be the stream that produced (and allocated) the gradients: autograd orders the two with events, but (a) the hooks
+        # of one bucket may have run on several streams, (b) the caching allocator knows nothing of a launch on a foreign
+        # stream and may hand a gradient's block to the producer stream's next allocation before the gather has read it.  In a
+        # replayed hipGraph nothing else orders such pairs and the races showed as NaN gradients.  After begin_step() the
+        # gather is therefore issued on the COMPUTE stream itself -- the producers' stream; this (autograd) thread issues the
+        # backward kernels on it one after the other, so program order is stream order and no allocator hazard exists.
+        issue = self.compute_stream if self.compute_stream is not None else (
+            torch.cuda.current_stream() if self.device.type == "cuda" else None)
+        if self.device.type == "cuda":
+            cur = torch.cuda.current_stream()
+            if self.compute_stream is None:
+                for sid, st in self._seen[b].items():
+                    if sid != cur.cuda_stream:
+                        cur.wait_stream(st)  # everything the other hooks' streams have accumulated so far
+                for g in grads:
+                    g.record_stream(cur)
+            self._seen[b].clear()
+        ctx = torch.cuda.stream(issue) if issue is not None else _NullCtx()
+        with ctx:
+            dev.copy_(host, non_blocking=True)  # (under capture: a memcpy node reading this pinned buffer on every replay)
+            if slot is not None and self.device.type == "cuda":
+                slot[2] = torch.cuda.Event()
+                slot[2].record()
+            ops.call("avsr_multi_copy_scale", ops._ptr(dev), len(idx), blocks, 1.0 / self.world, ops._stream(dev),
+                     nbytes=8.0 * self.flat[b].numel())
+            for i in idx:
+                self.params[i].grad = self.views[i]
+            if self.comm is not None:
+                # RCCL's C API on the side stream, behind the gather launch; the compute stream goes on with the backward pass
+                self._side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._side):
+                    self.comm.all_reduce(self.flat[b])
+                self._side_used = True
+            elif self.world > 1 or self.group is not None:
+                self._works.append(dist.all_reduce(self.flat[b], group=self.group, async_op=True))
+
+    def begin_step(self):
+        """Before the forward pass, on the thread / stream that issues the step: remembers the compute stream, so that every
+        bucket's gather is ordered behind it explicitly (see _flush)."""
+        if self.device.type == "cuda":
+            self.compute_stream = torch.cuda.current_stream()
 
     def finish(self):
         """After loss.backward(): every bucket has been flushed; the compute stream waits for the reductions."""
@@ -114,6 +185,9 @@ class GradBuckets:
         for w in self._works:
             w.wait()
         self._works.clear()
+        if self._side_used:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._side_used = False
         self._left = [len(m) for m in self.members]
 
     def remove(self):

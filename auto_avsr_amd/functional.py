@@ -142,10 +142,12 @@ def set_seed_tensor(t):
     _state["seed_dev"] = t
 
 
-def set_bn_sync(group_or_none):
+def set_bn_sync(group_or_none, comm=None):
     """Cross-rank BatchNorm statistics (train.py:31 sync_batchnorm=True): a torch.distributed process group, or
-    None for single-process statistics."""
-    _state["bn_sync"] = group_or_none
+    None for single-process statistics.  comm: a `comm.StreamComm` over the same ranks -- the two collectives per BatchNorm
+    then go straight to RCCL on the current stream (graph-capturable) instead of through torch.distributed."""
+    _state["bn_sync"] = group_or_none if comm is None else comm
+    _state["bn_comm"] = comm
 
 
 def _next_seed():
@@ -1502,10 +1504,14 @@ def _bn_train_stats(c2, rows, C, eps, momentum, running_mean, running_var, nbt=N
         # one all-gather of {shifted statistics, row count} per BatchNorm (ranks hold different row counts); the
         # payload is written by the statistics kernel and read in place (strided) by the merge kernel, which also
         # leaves the global row count on the device for the backward pass -- no glue launches around the collective
-        W = dist.get_world_size(group)
+        comm = _state.get("bn_comm")
+        W = comm.world if comm is not None else dist.get_world_size(group)
         mine = ops.bn_stats(c2, rows, C, with_count=True)
         flat = torch.empty(W * mine.numel(), dtype=torch.float32, device=c2.device)
-        dist.all_gather_into_tensor(flat, mine, group=group)
+        if comm is not None:
+            comm.all_gather(flat, mine)
+        else:
+            dist.all_gather_into_tensor(flat, mine, group=group)
         n_total = torch.empty(1, dtype=torch.float32, device=c2.device)
         mean, invstd = ops.bn_finalize(flat, flat.data_ptr() + 12 * C, W, C, eps, momentum, running_mean, running_var,
                                        nbt, stats_stride=3 * C + 1, counts_stride=3 * C + 1, n_total=n_total)
@@ -1523,7 +1529,10 @@ def _bn_bwd_sums(sums, counts, rows):
     import torch.distributed as dist
 
     tot = sums.clone()
-    dist.all_reduce(tot, group=group)
+    if _state.get("bn_comm") is not None:
+        _state["bn_comm"].all_reduce(tot)
+    else:
+        dist.all_reduce(tot, group=group)
     return tot, 0.0, counts  # global row count stays on the device (no host sync)
 
 

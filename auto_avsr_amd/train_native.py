@@ -137,6 +137,8 @@ def fit(model, args, dev, rank=0, world=1, backend="nccl", log=print):
             x, lens, y, frames = make_batch(lengths, idxs, args.modality, model.odim, seed=global_step, device=dev)
             seed_dev.add_(1)
             AF.manual_seed(42 + rank)  # restart the per-site counter: mask = f(rank, site index, seed_dev = global step)
+            if buckets is not None:
+                buckets.begin_step()
             AF.new_step()
             AF.refresh_weight_cache()  # conv-weight permutes; the Linear copies were rewritten by the optimizer step itself
             loss, loss_ctc, loss_att, hits, ntok = hot(x, lens, y)

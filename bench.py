@@ -49,11 +49,13 @@ def parse():
                     help="time ONE fixed batch instead of the bucketed workload: the survey's batch A (4 x 400 frames, 64 "
                          "labels) or batch B (16 x 100, 16 labels), SURVEY.md section 8d")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity block (reference goldens at batch A)")
-    ap.add_argument("--ddp", choices=["torch", "buckets", "buckets-graph"], default="torch",
-                    help="N > 1 gradient exchange: torch DistributedDataParallel (default; eager launches), this build's own bucketed "
-                         "RCCL all-reduce (auto_avsr_amd/ddp.py, eager launches), or the latter with the whole data-parallel step -- "
-                         "collectives included -- captured into hipGraphs (EXPERIMENTAL: replays on a single-rank group with the small "
-                         "model, tools/rccl_world1.py; at full size torch's process-group watchdog races the capture)")
+    ap.add_argument("--ddp", choices=["auto", "torch", "buckets", "buckets-graph"], default="auto",
+                    help="N > 1 gradient exchange.  buckets-graph: this build's bucketed RCCL all-reduce (auto_avsr_amd/ddp.py) with every "
+                         "collective of the step issued through RCCL's C API as a plain stream operation (auto_avsr_amd/comm.py), the "
+                         "WHOLE data-parallel step captured into hipGraphs (one-rank evidence: 20.1 ms / step against 31.2 ms for torch "
+                         "DDP's eager step, profiles/r3_dp1_*.json); buckets: the same exchange on torch.distributed, eager launches; "
+                         "torch: DistributedDataParallel, eager launches.  auto (default) = buckets-graph, falling back to torch if the "
+                         "RCCL binding cannot be set up and to eager launches if a capture fails")
     return ap.parse_args()
 
 
@@ -159,7 +161,16 @@ def main():
         dev = torch.device("cuda", local_rank)
         assert not _lib.lib().is_emulator
     ops.apply_env_tuning()
-    if world > 1:
+    # dp: the data-parallel machinery (process group, cross-rank BatchNorm, gradient exchange, W / sum(B) rescale) is active.
+    # AVSR_BENCH_FORCE_DP=1 switches it on for ONE rank (a single-rank RCCL group): the N > 1 code path of this file measured on
+    # a one-GPU box (gpurun boxes have one GPU; RCCL refuses two ranks on one device) -- evidence runs only.
+    dp = world > 1 or os.environ.get("AVSR_BENCH_FORCE_DP") == "1"
+    if dp:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if selftest:
             dist.init_process_group("gloo")
         else:
@@ -197,12 +208,27 @@ def main():
         # clip 10, per-step warm-up cosine -- one fused multi-tensor step (auto_avsr_amd/optim.py) that also rewrites the
         # bf16 operand copies of the Linear weights, so the next forward pass needs no separate re-cast of 250M weights
         opt = make_optimizer()
-    buckets = None
-    if world > 1 and args.ddp == "torch":
+    buckets = comm = comm_grads = None
+    if dp and args.ddp == "auto":
+        args.ddp = "torch" if selftest else "buckets-graph"
+        if not selftest:
+            try:
+                from auto_avsr_amd.comm import StreamComm
+
+                # two communicators: RCCL runs the operations of ONE communicator in issue order even across streams -- the
+                # small BatchNorm collectives on the compute stream must not queue behind 64 MB bucket all-reduces
+                comm = StreamComm.from_process_group()
+                comm_grads = StreamComm.from_process_group()
+            except Exception as e:  # noqa: BLE001 -- symmetrical across ranks (same library, same call): all ranks fall back
+                print(f"[bench rank {rank}] RCCL C-API communicators unavailable ({type(e).__name__}: {str(e)[:200]}); "
+                      "falling back to --ddp torch", file=sys.stderr, flush=True)
+                comm = comm_grads = None
+                args.ddp = "torch"
+    if dp and args.ddp == "torch":
         hot = torch.nn.parallel.DistributedDataParallel(hot, device_ids=None if selftest else [local_rank],
                                                         find_unused_parameters=False, broadcast_buffers=False,
                                                         gradient_as_bucket_view=True, bucket_cap_mb=64)
-    elif world > 1:
+    elif dp:
         # train.py:37 DDPStrategy(find_unused_parameters=False): bucketed gradient all-reduce over RCCL/xGMI, issued by this
         # build's own exchange (auto_avsr_amd/ddp.py) so that the WHOLE data-parallel step -- collectives included -- can be
         # captured into a hipGraph (torch's DDP reducer cannot: tools/rccl_capture_probe.py).
@@ -211,7 +237,16 @@ def main():
         # so the ~15 encoder/decoder buckets drain underneath it and the exposed tail stays one small bucket.
         from auto_avsr_amd.ddp import GradBuckets
 
-        buckets = GradBuckets(model.parameters(), group=dist.group.WORLD, bucket_mb=64)
+        if args.ddp == "buckets-graph" and not selftest:
+            # every collective of the step straight on RCCL's C API (auto_avsr_amd/comm.py): stream operations only, so the
+            # capture below has no torch Work objects in it (the process group stays for rendezvous, barriers and the timing)
+            if comm is None:
+                from auto_avsr_amd.comm import StreamComm
+
+                comm = StreamComm.from_process_group()
+                comm_grads = StreamComm.from_process_group()
+            AF.set_bn_sync(dist.group.WORLD, comm=comm)
+        buckets = GradBuckets(model.parameters(), group=dist.group.WORLD, bucket_mb=64, comm=comm_grads)
 
     lengths = utterance_lengths() if not selftest else __import__("numpy").array(selftest["lengths"])
     batches = rank_batches(bucket_batches(lengths, args.max_frames, 400 if not selftest else 4), rank, world, seed=0)
@@ -245,7 +280,7 @@ def main():
         babble = TR.AddNoise(noise=noise.to(dev))
         babble.snr_levels = [0]
         raw = [[0.1 * torch.randn(int(n), generator=g).to(dev) for n in lens.tolist()] for (_, lens, _, _) in pool]
-    use_graph = not args.no_graph and (world == 1 or args.ddp == "buckets-graph")
+    use_graph = not args.no_graph and (not dp or args.ddp == "buckets-graph")
     graphs = {}
     st = {"opt": opt, "graph": use_graph}
     all_params = list(model.parameters())
@@ -255,15 +290,20 @@ def main():
             p.grad = None
 
     def eager_step(x, lens, y):
+        if buckets is not None:
+            buckets.begin_step()  # the bucket gathers are issued on THIS stream (ddp.py: no foreign-stream launches)
         AF.new_step()
         seed_dev.add_(1)
         AF.refresh_weight_cache()  # an optimizer step would change the weights: pay the bf16 re-casts every step
         loss = hot(x, lens, y)
-        if world > 1:
+        if dp:
             # loss rescale of lightning.py:88-90: loss *= world / sum of batch sizes (all-gather of B)
             bs = torch.full((1,), float(x.shape[0]), device=dev)
             allb = torch.empty(world, device=dev)
-            dist.all_gather_into_tensor(allb, bs)
+            if comm is not None:
+                comm.all_gather(allb, bs)
+            else:
+                dist.all_gather_into_tensor(allb, bs)
             loss = loss * (world / allb.sum())
         loss.backward()
         if buckets is not None:
@@ -295,10 +335,10 @@ def main():
                 g = torch.cuda.CUDAGraph()
                 try:
                     # (N > 1: the process group's watchdog thread queries events while this thread captures)
-                    with torch.cuda.graph(g, **({"capture_error_mode": "thread_local"} if world > 1 else {})):
+                    with torch.cuda.graph(g, **({"capture_error_mode": "thread_local"} if dp else {})):
                         captured_loss = eager_step(x, lens, y)
                 except Exception as e:  # noqa: BLE001 -- capture is an optimisation: the eager step below is always valid
-                    if world == 1:
+                    if not dp:
                         raise
                     print(f"[bench rank {rank}] hipGraph capture of the data-parallel step failed ({type(e).__name__}: "
                           f"{str(e)[:200]}); continuing with eager launches", file=sys.stderr, flush=True)
@@ -369,7 +409,9 @@ def main():
                                + f", max-frames={args.max_frames} (real frames), fwd+bwd"
                                + ("" if args.no_optimizer else " + global-norm clip 10 + AdamW(1e-3, .9/.98, wd .03) + warm-up cosine + bf16 weight re-cast")
                                + ((", DDP grad all-reduce + SyncBN over RCCL" if args.ddp == "torch" else
-                                   ", bucketed RCCL gradient all-reduce overlapped with backward (auto_avsr_amd.ddp) + SyncBN") if world > 1 else "")
+                                   ", bucketed RCCL gradient all-reduce overlapped with backward (auto_avsr_amd.ddp) + SyncBN"
+                                   + (", every collective a stream operation on RCCL's C API (auto_avsr_amd.comm)" if comm is not None else "")) if dp else "")
+                               + (" [AVSR_BENCH_FORCE_DP: data-parallel machinery on ONE rank]" if dp and world == 1 else "")
                                + (", every step from RAW waveforms: AudioTransform('train') with babble noise at SNR 0 dB + collation "
                                   "on the device inside the timed region" if args.babble else "")
                                + (f", hipGraph replay, {nshape} batch shapes cycled" if st["graph"] else f", eager launches, {nshape} batch shapes cycled"),
@@ -378,14 +420,14 @@ def main():
                                             int(d[2].shape[2])) for d in data}),
                    "all_hot_path_compute": "libavsr_hip.so (hand-written HIP, gfx950)"},
     }
-    if rank == 0 and world == 1 and not args.no_roofline:
+    if rank == 0 and not dp and not args.no_roofline:
         # (N > 1: an extra rank-0-only step would dead-lock the DDP / BatchNorm collectives; the kernels are the same)
         out["roofline"], hbm = roofline(model, data[args.warmup], ops)
         if hbm is not None:
             out["roofline_hbm"] = hbm
-    if rank == 0 and world == 1 and not args.no_parity and args.modality == "video":
+    if rank == 0 and not dp and not args.no_parity and args.modality == "video":
         out["parity"] = parity_block(mode)
-    if rank == 0 and world == 1 and mode == "bf16" and args.modality == "video" and not args.no_precise_leg \
+    if rank == 0 and not dp and mode == "bf16" and args.modality == "video" and not args.no_precise_leg \
             and not args.no_optimizer and not selftest:
         # The mode that meets the north-star tolerance on logits (1e-3): the SAME workload and step, forward pass on split hi /
         # lo bf16 planes (three MFMAs per product, f32 activations), backward pass as above.  Fewer steps; same protocol.
@@ -408,11 +450,14 @@ def main():
                           "parity": None if args.no_parity else parity_block("hpf")}
         AF.set_mode(mode)
         AF.invalidate_weight_cache()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not dp and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.modality, odim)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dp:
+        for c in (comm, comm_grads):
+            if c is not None:
+                c.close()
         dist.destroy_process_group()
 
 

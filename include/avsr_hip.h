@@ -313,6 +313,18 @@ int avsr_multi_split_pack(const void* table, int n, int total_blocks, avsr_strea
 int avsr_conv2d_f32s(const float* x, const float* wp, float* y, const void* zero_page, int N, int H, int W, int Cin, int Cout,
                      int KH, int KW, int stride, int pad_h, int pad_w, int tile, int w_split /* 1: wp in the split8 layout */,
                      void* y2 /* may be NULL: bf16 twin of y */, avsr_stream_t stream);
+/* ---- collectives of the data-parallel step straight on RCCL (csrc/comm.hip; RCCL is bound with dlopen at the first call).
+ * Replaces, for graph-captured steps, the torch.distributed calls of train.py:30-42 (DDP gradient all-reduce, SyncBatchNorm
+ * statistics) and lightning.py:88-90 (batch-size all-gather): every call is ONE stream operation on `stream`, nothing else.
+ * Up to four communicators per process (slot 0..3; RCCL serialises the operations of one communicator across streams -- the
+ * gradient buckets and the BatchNorm collectives use one each).  avsr_comm_unique_id: rank 0 fills 128 bytes, the host side
+ * distributes them; avsr_comm_init: collective over all ranks (device = the calling thread's current HIP device). */
+int avsr_comm_unique_id(void* out128);
+int avsr_comm_init(int slot, const void* id128, int nranks, int rank);
+int avsr_comm_destroy(int slot);
+int64_t avsr_comm_size(int slot); /* 0 without a communicator */
+int avsr_comm_all_reduce_f32(int slot, void* buf, int64_t count, avsr_stream_t stream);                          /* in place, sum */
+int avsr_comm_all_gather_f32(int slot, const void* send, void* recv, int64_t count_per_rank, avsr_stream_t stream); /* recv: nranks x count */
 /* Tuning knobs of the tuned kernels (process-wide; meant for benchmarks, defaults are the measured best):
  * knob 0 = tile code forced on avsr_conv2d_bf16 (0 = auto), 1 = XCD-aware tile order (0 = automatic: on for the 64x64 GEMM tile, whose
  * operands are not cache-resident in the training step; 1 = always on; 2 = always off),

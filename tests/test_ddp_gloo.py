@@ -244,7 +244,7 @@ def test_ddp_bench_configuration(emu_lib_path, tmp_path):
     assert res["ok"] and res["step"] == 2
 
 
-@pytest.mark.parametrize("ddp", ["torch", "buckets"])
+@pytest.mark.parametrize("ddp", ["auto", "torch", "buckets"])
 def test_bench_main_two_ranks(emu_lib_path, tmp_path, ddp):
     """bench.py's own main(), launched exactly as the driver launches it for N = 2 (`python -m torch.distributed.run
     --nproc-per-node 2 ... bench.py --gpus 2 ...`), on two CPU processes: gloo instead of RCCL, kernels through the host
@@ -260,7 +260,7 @@ def test_bench_main_two_ranks(emu_lib_path, tmp_path, ddp):
     port = 35500 + os.getpid() % 2000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--max-frames", "12", "--shapes", "2", "--ddp", ddp]
+           "--max-frames", "12", "--shapes", "2"] + ([] if ddp == "auto" else ["--ddp", ddp])  # auto = what the driver runs
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -270,7 +270,8 @@ def test_bench_main_two_ranks(emu_lib_path, tmp_path, ddp):
     assert out["value"] > 0 and out["ms_per_step"] > 0 and out["higher_is_better"] is True
     # --ddp torch: DistributedDataParallel (the default); --ddp buckets: auto_avsr_amd.ddp.GradBuckets (one gather launch + one
     # async all-reduce per bucket, issued from post-accumulate-grad hooks)
-    want = "DDP grad all-reduce + SyncBN" if ddp == "torch" else "gradient all-reduce overlapped with backward (auto_avsr_amd.ddp) + SyncBN"
+    # (auto: on GPUs the graph-replayed bucket exchange on RCCL's C API; under the CPU self-test hook it resolves to torch DDP)
+    want = "DDP grad all-reduce + SyncBN" if ddp in ("torch", "auto") else "gradient all-reduce overlapped with backward (auto_avsr_amd.ddp) + SyncBN"
     assert want in out["config"]["workload"] and "eager launches" in out["config"]["workload"]
     assert out["config"]["final_loss"] == out["config"]["final_loss"]  # finite
 
