@@ -97,10 +97,18 @@ def fit(model, args, dev, rank=0, world=1, backend="nccl", log=print):
         # train.py:31,37: cross-rank BatchNorm (the kernels' own statistics exchange) + DDP gradient averaging
         AF.set_bn_sync(dist.group.WORLD)
         if os.environ.get("AVSR_DDP", "torch") == "buckets":
-            # this build's own bucketed RCCL all-reduce (ddp.GradBuckets: every operation a stream operation)
+            # this build's own bucketed RCCL all-reduce (ddp.GradBuckets); on GPUs every collective of the step -- gradient
+            # buckets, BatchNorm statistics -- goes straight to RCCL's C API (comm.StreamComm: a ctypes call instead of a
+            # c10d Work object per collective; 64 BatchNorm collectives per step make that the larger share of the host time)
             from .ddp import GradBuckets
 
-            buckets = GradBuckets(model.parameters(), group=dist.group.WORLD, bucket_mb=64)
+            comm_grads = None
+            if dev.type == "cuda":
+                from .comm import StreamComm
+
+                comm_bn, comm_grads = StreamComm.from_process_group(), StreamComm.from_process_group()
+                AF.set_bn_sync(dist.group.WORLD, comm=comm_bn)
+            buckets = GradBuckets(model.parameters(), group=dist.group.WORLD, bucket_mb=64, comm=comm_grads)
         else:
             hot = torch.nn.parallel.DistributedDataParallel(
                 hot, device_ids=[dev.index] if dev.type == "cuda" else None, find_unused_parameters=False,
@@ -143,9 +151,12 @@ def fit(model, args, dev, rank=0, world=1, backend="nccl", log=print):
             AF.refresh_weight_cache()  # conv-weight permutes; the Linear copies were rewritten by the optimizer step itself
             loss, loss_ctc, loss_att, hits, ntok = hot(x, lens, y)
             if world > 1:
-                bs = torch.tensor([float(x.shape[0])], device=dev)
+                bs = torch.full((1,), float(x.shape[0]), device=dev)
                 allb = torch.empty(world, device=dev)
-                dist.all_gather_into_tensor(allb, bs)
+                if buckets is not None and buckets.comm is not None:
+                    AF._state["bn_comm"].all_gather(allb, bs)
+                else:
+                    dist.all_gather_into_tensor(allb, bs)
                 loss = loss * (world / allb.sum())  # lightning.py:88-90
             loss.backward()
             if buckets is not None:
