@@ -110,7 +110,7 @@ def test_conv2d_f32_split_forward(dev, cfg):
     (3, 22, 22, 64, 128, 2), (4, 11, 11, 64, 64, 2), (5, 6, 6, 128, 64, 2), (2, 9, 13, 64, 64, 1), (2, 7, 10, 64, 64, 2),
 ])
 @pytest.mark.parametrize("partial", [True, False])
-@pytest.mark.parametrize("variant", ["thin", "thin-long", "fat", "fat-long", "thin8", "thin8-long"])
+@pytest.mark.parametrize("variant", ["thin", "thin-long", "fat-long", "thin8-long"])
 def test_conv3x3_wgrad_direct(dev, cfg, partial, variant):
     """Dedicated 3x3 weight-gradient kernel (shifted LDS views of one padded patch, fragment requests pipelined across the
     16-pixel k-steps) vs torch autograd.  Variants (avsr_tune knob 16): thin = 4 waves of 32 co x 32 ci; fat = 4 waves of

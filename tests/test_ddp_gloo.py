@@ -244,7 +244,7 @@ def test_ddp_bench_configuration(emu_lib_path, tmp_path):
     assert res["ok"] and res["step"] == 2
 
 
-@pytest.mark.parametrize("ddp", ["auto", "torch", "buckets"])
+@pytest.mark.parametrize("ddp", ["auto", "buckets"])
 def test_bench_main_two_ranks(emu_lib_path, tmp_path, ddp):
     """bench.py's own main(), launched exactly as the driver launches it for N = 2 (`python -m torch.distributed.run
     --nproc-per-node 2 ... bench.py --gpus 2 ...`), on two CPU processes: gloo instead of RCCL, kernels through the host
