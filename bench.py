@@ -209,6 +209,8 @@ def main():
         # bf16 operand copies of the Linear weights, so the next forward pass needs no separate re-cast of 250M weights
         opt = make_optimizer()
     buckets = comm = comm_grads = None
+    if dp and args.ddp == "auto" and os.environ.get("AVSR_DDP") in ("torch", "buckets", "buckets-graph"):
+        args.ddp = os.environ["AVSR_DDP"]  # override without touching the command line (e.g. AVSR_DDP=torch: the conservative path)
     if dp and args.ddp == "auto":
         args.ddp = "torch" if selftest else "buckets-graph"
         if not selftest:
@@ -248,6 +250,9 @@ def main():
             AF.set_bn_sync(dist.group.WORLD, comm=comm)
         buckets = GradBuckets(model.parameters(), group=dist.group.WORLD, bucket_mb=64, comm=comm_grads)
 
+    if dp and rank == 0:
+        print(f"[bench] data-parallel mode: --ddp {args.ddp}" + (" (RCCL C-API communicators, hipGraph replay)" if comm is not None else ""),
+              file=sys.stderr, flush=True)
     lengths = utterance_lengths() if not selftest else __import__("numpy").array(selftest["lengths"])
     batches = rank_batches(bucket_batches(lengths, args.max_frames, 400 if not selftest else 4), rank, world, seed=0)
     if args.fixed:  # SURVEY.md section 8d fixed-shape lines
