@@ -179,45 +179,6 @@ _FUSE_QKV = os.environ.get("AVSR_FUSE_QKV", "1") != "0"  # A/B switch for the fu
 # reduce pass runs on the pooled tensors, the apply pass gathers the pooled gradient).  Measured on MI355X (round 2):
 # 22.98 -> 22.39 ms per step together with the hardware-reciprocal sigmoid.  AVSR_FUSE_STEM_POOL=0 restores the three-pass path.
 _FUSE_STEM_POOL = os.environ.get("AVSR_FUSE_STEM_POOL", "1") != "0"
-# A/B switch (experiment): the trunk's weight-gradient launches on a side stream beside the data-gradient chain (they are leaves
-# of the backward pass); joined one residual block later and, finally, at the end of the stem's backward pass
-_WGRAD_SIDE = os.environ.get("AVSR_WGRAD_STREAM", "0") == "1"
-_wside = {"stream": None, "prev": None, "used": False}
-
-
-def _wgrad_side(fn):
-    """fn() on the weight-gradient side stream, behind everything issued so far on the current stream."""
-    if not (_WGRAD_SIDE and _state["bn_sync"] is None and torch.cuda.is_available()):
-        return fn()
-    cur = torch.cuda.current_stream()
-    if _wside["stream"] is None:
-        _wside["stream"] = torch.cuda.Stream()
-    side = _wside["stream"]
-    side.wait_stream(cur)
-    with torch.cuda.stream(side):
-        out = fn()
-    out.record_stream(cur)
-    _wside["used"] = True
-    return out
-
-
-def _wgrad_side_lag():
-    """End of a residual block's backward pass: wait for the side work of the PREVIOUS block, remember this block's."""
-    if not _wside["used"]:
-        return
-    cur = torch.cuda.current_stream()
-    if _wside["prev"] is not None:
-        cur.wait_event(_wside["prev"])
-    ev = torch.cuda.Event()
-    ev.record(_wside["stream"])
-    _wside["prev"] = ev
-
-
-def _wgrad_side_join():
-    if _wside["used"]:
-        torch.cuda.current_stream().wait_stream(_wside["stream"])
-        _wside["used"] = False
-        _wside["prev"] = None
 _wcache = {}   # (data_ptr, transposed, shape) -> [version, bf16 copy, source weight, is a slice of a concatenation]
 _wcat = {}     # (data_ptrs..., transposed) -> concatenated bf16 buffer whose slices are registered in _wcache
 _wtable = {"n": 0, "dev": None, "blocks": 0, "built_for": -1}
@@ -1925,15 +1886,15 @@ class BasicBlockFn(torch.autograd.Function):
         if wd is None:
             r = x
         dc2, dr, dg2, db2 = _bn_bwd(c2, dout, r, m2, i2, (g2, b2) + r2, n2, rows, Cout, 1, True, training)
-        dw2 = _wgrad_side(lambda: ops.conv2d_wgrad(dc2, a1, N, OH, OW, Cout, Cout, KH, KW, 1, ph, pw, pr, torch_layout=True))
+        dw2 = ops.conv2d_wgrad(dc2, a1, N, OH, OW, Cout, Cout, KH, KW, 1, ph, pw, pr, torch_layout=True)
         da1 = ops.conv2d_dgrad(dc2, _w_conv(w2, True), None, N, OH, OW, Cout, Cout, KH, KW, 1,
                                ph, pw, pr)
         dc1, _, dg1, db1 = _bn_bwd(c1, da1, None, m1, i1, (g1, b1) + r1, n1, rows, Cout, 1, False, training)
-        dw1 = _wgrad_side(lambda: ops.conv2d_wgrad(dc1, x, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, pr, torch_layout=True))
+        dw1 = ops.conv2d_wgrad(dc1, x, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, pr, torch_layout=True)
         dwd = dgd = dbd = None
         if wd is not None:
             dcd, _, dgd, dbd = _bn_bwd(cd, dr, None, md, idd, (gd, bd) + rd, nd, rows, Cout, 0, False, training)
-            dwd = _wgrad_side(lambda: ops.conv2d_wgrad(dcd, x, N, H, W, Cin, Cout, 1, 1, stride, 0, 0, pr, torch_layout=True))
+            dwd = ops.conv2d_wgrad(dcd, x, N, H, W, Cin, Cout, 1, 1, stride, 0, 0, pr, torch_layout=True)
             skip = ops.conv2d_dgrad(dcd, _w_conv(wd, True), None, N, H, W, Cin, Cout, 1, 1,
                                     stride, 0, 0, pr)
         else:
@@ -1942,7 +1903,6 @@ class BasicBlockFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.conv2d_dgrad(dc1, _w_conv(w1, True), skip, N, H, W, Cin, Cout, KH, KW,
                                   stride, ph, pw, pr)
-        _wgrad_side_lag()
         return (dx, None, None, None, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None)
 
 
@@ -2032,7 +1992,6 @@ class StemFn(torch.autograd.Function):
             dw = ops.stem357_wgrad(dc0, x, B, Tn, H, W)
         else:
             dw = ops.conv_stem_wgrad(dc0, x, B, Tn, H, W, Cout, KT, KH, KW, stride, pt, ph, pw, _state["precise"])
-        _wgrad_side_join()
         return None, dw.view(wshape), dg, db, None, None, None, None
 
 
