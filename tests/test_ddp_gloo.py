@@ -347,3 +347,18 @@ def test_grad_buckets_match_torch_ddp(emu_lib_path, tmp_path):
     port = 29500 + (os.getpid() + 7) % 2000
     mp.spawn(_worker_buckets, args=(2, port, emu_lib_path, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(os.path.join(tmp_path, "ok"))
+
+
+def test_stream_comm_needs_the_gpu_library(emu_lib_path):
+    """auto_avsr_amd.comm binds RCCL inside libavsr_hip.so; the host emulator build has no RCCL and says so (no silent
+    fallback to torch.distributed inside StreamComm -- callers pick comm=None explicitly on CPU)."""
+    from auto_avsr_amd import _lib
+    from auto_avsr_amd.comm import StreamComm
+
+    _lib._install_for_tests(emu_lib_path)
+    try:
+        with pytest.raises(_lib.AvsrLibraryError, match="not available in the emulator build"):
+            StreamComm.single()
+        assert StreamComm._live == {}
+    finally:
+        _lib._lib = None
