@@ -42,6 +42,7 @@ struct AttnParams {
     const uint8_t* mask;  // mask[b*mask_sb + i*mask_sq + j] != 0 means "attend"; null = no mask
     long mask_sb, mask_sq;
     void* out;   // [B,Tq,H,64]
+    void* out2;  // forward, optional: bf16 twin of an f32 `out` (same strides)
     float* lse;  // [B,H,Tq]
     int B, H, Tq, Tk;
     int ldq, ldk, ldv, ldp, ldo;       // row strides (elements)
@@ -520,6 +521,11 @@ struct Attn {
                 T* o = reinterpret_cast<T*>(p.out) + b * p.sbo + (long)ig * p.ldo + h * DK;
 #pragma unroll
                 for (int n = 0; n < 4; n++) Elem<T>::st(o + n * 16 + lc, acc0[n][r] * inv);
+                if (p.out2) {
+                    bf16_t* o2 = reinterpret_cast<bf16_t*>(p.out2) + b * p.sbo + (long)ig * p.ldo + h * DK;
+#pragma unroll
+                    for (int n = 0; n < 4; n++) o2[n * 16 + lc] = f2bf(acc0[n][r] * inv);
+                }
                 if (lc == 0) p.lse[((long)b * p.H + h) * Tq + ig] = l_run[r] > 0.f ? m_run[r] + logf(l_run[r]) : 0.f;
             } else if (RELPOS && p.dq_sum) {
                 T* dq = reinterpret_cast<T*>(p.dq_sum) + b * p.sbdq + (long)ig * p.lddq + h * DK;
@@ -1046,11 +1052,11 @@ int launch_attn(const AttnParams& p, int dtype, int precise, bool relpos, hipStr
 
 }  // namespace
 
-extern "C" int avsr_attention_fwd(const void* qu, const void* qv, const void* k, const void* v, const void* pos,
-                                  int dtype, int precise, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq,
-                                  void* out, float* lse, int B, int H, int Tq, int Tk, int dk, int ldq, int ldk,
-                                  int ldv, int ldp, int ldo, int64_t sbq, int64_t sbk, int64_t sbv, int64_t sbo,
-                                  float scale, float drop_p, uint64_t seed, const uint64_t* seed_dev, hipStream_t stream) {
+static int attention_fwd_impl(const void* qu, const void* qv, const void* k, const void* v, const void* pos,
+                              int dtype, int precise, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq,
+                              void* out, void* out2, float* lse, int B, int H, int Tq, int Tk, int dk, int ldq, int ldk,
+                              int ldv, int ldp, int ldo, int64_t sbq, int64_t sbk, int64_t sbv, int64_t sbo,
+                              float scale, float drop_p, uint64_t seed, const uint64_t* seed_dev, hipStream_t stream) {
     AVSR_REQUIRE(dk == DK, "attention: d_k must be 64");
     AVSR_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && (pos == nullptr || ldp % 8 == 0),
                  "attention: row strides must be multiples of 8");
@@ -1060,6 +1066,7 @@ extern "C" int avsr_attention_fwd(const void* qu, const void* qv, const void* k,
     p.qu = qu; p.qv = qv; p.k = k; p.v = v; p.pos = pos;
     p.mask = mask; p.mask_sb = mask_sb; p.mask_sq = mask_sq;
     p.out = out; p.lse = lse;
+    p.out2 = out2;
     p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldp = ldp; p.ldo = ldo;
     p.sbq = sbq; p.sbk = sbk; p.sbv = sbv; p.sbo = sbo;
@@ -1067,6 +1074,25 @@ extern "C" int avsr_attention_fwd(const void* qu, const void* qv, const void* k,
     AVSR_REQUIRE(launch_attn<false>(p, dtype, precise, pos != nullptr, stream) == 0, "attention: bad dtype/precise combination");
     AVSR_CHECK_LAUNCH("attention_fwd");
     return 0;
+}
+
+extern "C" int avsr_attention_fwd(const void* qu, const void* qv, const void* k, const void* v, const void* pos,
+                                  int dtype, int precise, const uint8_t* mask, int64_t mask_sb, int64_t mask_sq,
+                                  void* out, float* lse, int B, int H, int Tq, int Tk, int dk, int ldq, int ldk,
+                                  int ldv, int ldp, int ldo, int64_t sbq, int64_t sbk, int64_t sbv, int64_t sbo,
+                                  float scale, float drop_p, uint64_t seed, const uint64_t* seed_dev, hipStream_t stream) {
+    return attention_fwd_impl(qu, qv, k, v, pos, dtype, precise, mask, mask_sb, mask_sq, out, nullptr, lse, B, H, Tq, Tk, dk, ldq,
+                              ldk, ldv, ldp, ldo, sbq, sbk, sbv, sbo, scale, drop_p, seed, seed_dev, stream);
+}
+
+// f32 (precise) forward + the bf16 twin of its output (same strides) in one pass
+extern "C" int avsr_attention_fwd2(const void* qu, const void* qv, const void* k, const void* v, const void* pos,
+                                   const uint8_t* mask, int64_t mask_sb, int64_t mask_sq, void* out, void* out2, float* lse,
+                                   int B, int H, int Tq, int Tk, int dk, int ldq, int ldk, int ldv, int ldp, int ldo,
+                                   int64_t sbq, int64_t sbk, int64_t sbv, int64_t sbo, float scale, float drop_p, uint64_t seed,
+                                   const uint64_t* seed_dev, hipStream_t stream) {
+    return attention_fwd_impl(qu, qv, k, v, pos, 0, 1, mask, mask_sb, mask_sq, out, out2, lse, B, H, Tq, Tk, dk, ldq, ldk, ldv, ldp,
+                              ldo, sbq, sbk, sbv, sbo, scale, drop_p, seed, seed_dev, stream);
 }
 
 extern "C" int avsr_attention_bwd_dq(const void* qu, const void* qv, const void* k, const void* v, const void* pos,

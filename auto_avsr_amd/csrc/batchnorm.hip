@@ -454,7 +454,7 @@ __global__ __launch_bounds__(BNS_THREADS) void bn_small_fwd_kernel(
     const T* __restrict__ x, int rows, int C, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
     int64_t* __restrict__ num_batches_tracked, int act, T* __restrict__ y, float* __restrict__ mean_out,
-    float* __restrict__ invstd_out) {
+    float* __restrict__ invstd_out, bf16_t* __restrict__ y2 = nullptr) {
     __shared__ float red[8 * 16];
     __shared__ float mu_s[8], is_s[8];
     const int c0 = blockIdx.x * 8;
@@ -515,6 +515,7 @@ __global__ __launch_bounds__(BNS_THREADS) void bn_small_fwd_kernel(
 #pragma unroll
         for (int e = 0; e < 8; e++) o[e] = act_fwd((v[u][e] - mu_s[e]) * is_s[e] * ga[e] + be[e], act);
         store8(y + (long)r * C + c0, o);
+        if (y2) store8(y2 + (long)r * C + c0, o);  // bf16 twin (hpf mode)
     }
 }
 
@@ -1054,6 +1055,18 @@ extern "C" int avsr_bn_small_fwd(const void* x, int dtype, int64_t rows, int C, 
         AVSR_LAUNCH((bn_small_fwd_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, (int)rows, C, gamma, beta, eps,
                     momentum, running_mean, running_var, num_batches_tracked, act, (bf16_t*)y, mean, invstd);
     AVSR_CHECK_LAUNCH("bn_small_fwd");
+    return 0;
+}
+
+// f32 input / output + the bf16 twin y2 of the output in one pass
+extern "C" int avsr_bn_small_fwd2(const float* x, int64_t rows, int C, const float* gamma, const float* beta, float eps,
+                                  float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                  int act, float* y, void* y2, float* mean, float* invstd, hipStream_t stream) {
+    AVSR_REQUIRE(C % 8 == 0, "bn_small: C must be a multiple of 8");
+    AVSR_REQUIRE(rows >= 1 && rows <= BNS_THREADS * BNS_R, "bn_small: rows out of range (avsr_bn_small_max_rows)");
+    AVSR_LAUNCH((bn_small_fwd_kernel<float>), dim3(C / 8), dim3(BNS_THREADS), 0, stream, x, (int)rows, C, gamma, beta, eps, momentum,
+                running_mean, running_var, num_batches_tracked, act, y, mean, invstd, (bf16_t*)y2);
+    AVSR_CHECK_LAUNCH("bn_small_fwd2");
     return 0;
 }
 

@@ -62,7 +62,8 @@ AVSR_DEV void stage_time_tile_glu(float* xs, const T* a, int b, int t_first, int
 template <class T>
 __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, T* __restrict__ y, int Tlen,
-                                                     int C, int K, int flip, int glu_in, const T* __restrict__ glu_a) {
+                                                     int C, int K, int flip, int glu_in, const T* __restrict__ glu_a,
+                                                     bf16_t* __restrict__ y2 = nullptr) {
     __shared__ float xs[(DW_TT + DW_MAXK - 1) * DW_CH];
     __shared__ float ws[DW_MAXK * DW_CH];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
                 Elem<T>::st(y + row * 2 * C + C + c0 + tx, acc * lin * sg * (1.f - sg));
             } else {
                 Elem<T>::st(y + row * C + c0 + tx, acc);
+                if (y2) y2[row * C + c0 + tx] = f2bf(acc);  // bf16 twin of an f32 output ("hpf" mode)
             }
         }
     }
@@ -190,6 +192,19 @@ extern "C" int avsr_dwconv_fwd(const void* x, int dtype, const float* w, const f
         AVSR_LAUNCH((dwconv_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, w, bias, (bf16_t*)y, T, C, K, flip,
                     glu_in, (const bf16_t*)glu_a);
     AVSR_CHECK_LAUNCH("dwconv_fwd");
+    return 0;
+}
+
+// f32 forward + the bf16 twin of its output in one pass
+extern "C" int avsr_dwconv_fwd2(const float* x, const float* w, const float* bias, float* y, void* y2, int B, int T, int C, int K,
+                                int glu_in, hipStream_t stream) {
+    AVSR_REQUIRE(K >= 1 && K <= DW_MAXK && (K & 1), "dwconv: K must be odd and <= 31");
+    AVSR_REQUIRE(C % 8 == 0, "dwconv: C must be a multiple of 8");
+    if (B <= 0 || T <= 0) return 0;
+    dim3 grid((C + DW_CH - 1) / DW_CH, (T + DW_TT - 1) / DW_TT, B), block(256);
+    AVSR_LAUNCH((dwconv_kernel<float>), grid, block, 0, stream, x, w, bias, y, T, C, K, 0, glu_in, (const float*)nullptr,
+                (bf16_t*)y2);
+    AVSR_CHECK_LAUNCH("dwconv_fwd2");
     return 0;
 }
 

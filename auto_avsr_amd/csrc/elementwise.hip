@@ -49,7 +49,8 @@ template <class T>
 __global__ __launch_bounds__(EW_THREADS) void head_bias_kernel(const T* __restrict__ x, long ldx,
                                                                const float* __restrict__ b1,
                                                                const float* __restrict__ b2, T* __restrict__ o1,
-                                                               T* __restrict__ o2, long rows, int cols) {
+                                                               T* __restrict__ o2, long rows, int cols,
+                                                               bf16_t* __restrict__ t1 = nullptr, bf16_t* __restrict__ t2 = nullptr) {
     const int cv = cols >> 3;
     const long nvec = rows * cv;
     for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < nvec; i += (long)gridDim.x * EW_THREADS) {
@@ -66,6 +67,10 @@ __global__ __launch_bounds__(EW_THREADS) void head_bias_kernel(const T* __restri
         }
         store8(o1 + r * cols + c, a);
         store8(o2 + r * cols + c, b);
+        if (t1) {  // bf16 twins of f32 outputs (the "hpf" numerical mode: f32 forward, bf16 copies saved for the backward pass)
+            store8(t1 + r * cols + c, a);
+            store8(t2 + r * cols + c, b);
+        }
     }
 }
 
@@ -199,6 +204,19 @@ extern "C" int avsr_head_bias_fwd(const void* x, int dtype, int64_t ldx, const f
         AVSR_LAUNCH((head_bias_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, (long)ldx, b1, b2,
                     (bf16_t*)o1, (bf16_t*)o2, (long)rows, cols);
     AVSR_CHECK_LAUNCH("head_bias_fwd");
+    return 0;
+}
+
+// f32 outputs + their bf16 twins in one pass
+extern "C" int avsr_head_bias_fwd2(const float* x, int64_t ldx, const float* b1, const float* b2, float* o1, float* o2, void* t1,
+                                   void* t2, int64_t rows, int cols, hipStream_t stream) {
+    AVSR_REQUIRE(cols % 8 == 0 && ldx % 8 == 0, "head_bias_fwd: cols/ldx must be multiples of 8");
+    AVSR_REQUIRE((t1 == nullptr) == (t2 == nullptr), "head_bias_fwd2: both twins or none");
+    if (rows <= 0) return 0;
+    dim3 grid(ew_grid(rows * (cols >> 3))), block(EW_THREADS);
+    AVSR_LAUNCH((head_bias_kernel<float>), grid, block, 0, stream, x, (long)ldx, b1, b2, o1, o2, (long)rows, cols, (bf16_t*)t1,
+                (bf16_t*)t2);
+    AVSR_CHECK_LAUNCH("head_bias_fwd2");
     return 0;
 }
 

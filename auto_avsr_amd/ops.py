@@ -151,6 +151,12 @@ def attention_fwd(qu, qv, k, v, pos, mask, scale, *, precise=False, drop_p=0.0, 
         assert mask.dtype in (torch.uint8, torch.bool) and mask.is_contiguous() and mask.dim() == 3
         msb = mask.shape[1] * mask.shape[2] if mask.shape[0] > 1 else 0  # a batch-1 mask is shared by every sequence
         msq = mask.shape[2] if mask.shape[1] > 1 else 0
+    out2 = _twin(out) if (precise and out.dtype == torch.float32) else None
+    if out2 is not None:  # f32 forward + the bf16 twin of its output in one pass ("hpf" mode)
+        call("avsr_attention_fwd2", _ptr(qu), _ptr(qv), _ptr(k), _ptr(v), _ptr(pos), _ptr(mask), msb, msq, _ptr(out), _ptr(out2),
+             _ptr(lse), B, H, Tq, Tk, dk, qu.stride(1), k.stride(1), v.stride(1), pos.stride(0) if pos is not None else 0,
+             out.stride(1), qu.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, drop_p, seed, _ptr(seed_dev), _stream(qu))
+        return out, lse
     call("avsr_attention_fwd", _ptr(qu), _ptr(qv), _ptr(k), _ptr(v), _ptr(pos), dt(qu), int(precise), _ptr(mask),
          msb, msq, _ptr(out), _ptr(lse), B, H, Tq, Tk, dk, qu.stride(1), k.stride(1), v.stride(1),
          pos.stride(0) if pos is not None else 0, out.stride(1), qu.stride(0), k.stride(0), v.stride(0),
@@ -240,6 +246,11 @@ def scale_dropout(x, out_dtype, alpha=1.0, drop_p=0.0, seed=0, alpha_dev=None, s
 def head_bias_fwd(x, ldx, rows, cols, b1, b2):
     o1 = torch.empty(rows, cols, dtype=x.dtype, device=x.device)
     o2 = torch.empty(rows, cols, dtype=x.dtype, device=x.device)
+    t1 = _twin(o1)
+    t2 = _twin(o2) if t1 is not None else None
+    if t2 is not None:
+        call("avsr_head_bias_fwd2", _ptr(x), ldx, _ptr(b1), _ptr(b2), _ptr(o1), _ptr(o2), _ptr(t1), _ptr(t2), rows, cols, _stream(x))
+        return o1, o2
     call("avsr_head_bias_fwd", _ptr(x), dt(x), ldx, _ptr(b1), _ptr(b2), _ptr(o1), _ptr(o2), rows, cols, _stream(x))
     return o1, o2
 
@@ -270,6 +281,11 @@ def dwconv(x, w, bias, B, T, C, K, flip=False, glu_in=False, glu_a=None):
     """glu_in: x is the pre-GLU tensor [B*T, 2C] (the conv runs on glu(x)); glu_a (flip only): the result is pushed
     through the GLU backward of glu_a = [a | g] -> returns da [B*T, 2C]."""
     y = torch.empty(B, T, 2 * C if glu_a is not None else C, dtype=x.dtype, device=x.device)
+    y2 = _twin(y) if (glu_a is None and not flip) else None
+    if y2 is not None:  # f32 forward + the bf16 twin of its output ("hpf" mode)
+        call("avsr_dwconv_fwd2", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(y2), B, T, C, K, int(glu_in), _stream(x),
+             nbytes=_nb(x, y, y2))
+        return y
     call("avsr_dwconv_fwd", _ptr(x), dt(x), _ptr(w), _ptr(bias), _ptr(y), B, T, C, K, int(flip), int(glu_in), _ptr(glu_a),
          _stream(x), nbytes=_nb(x, y, glu_a))
     return y
@@ -307,6 +323,12 @@ def bn_small_fwd(x, rows, C, gamma, beta, eps, momentum, running_mean, running_v
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
     invstd = torch.empty(C, dtype=torch.float32, device=x.device)
     y = torch.empty(rows, C, dtype=x.dtype, device=x.device)
+    y2 = _twin(y)
+    if y2 is not None:
+        call("avsr_bn_small_fwd2", _ptr(x), rows, C, _ptr(gamma), _ptr(beta), eps, momentum, _ptr(running_mean),
+             _ptr(running_var), _ptr(num_batches_tracked), act, _ptr(y), _ptr(y2), _ptr(mean), _ptr(invstd), _stream(x),
+             nbytes=2.0 * _nb(x) + _nb(y2))
+        return y, mean, invstd
     call("avsr_bn_small_fwd", _ptr(x), dt(x), rows, C, _ptr(gamma), _ptr(beta), eps, momentum, _ptr(running_mean),
          _ptr(running_var), _ptr(num_batches_tracked), act, _ptr(y), _ptr(mean), _ptr(invstd), _stream(x),
          nbytes=2.0 * _nb(x))

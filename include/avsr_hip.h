@@ -74,6 +74,11 @@ int avsr_attention_fwd(const void* qu, const void* qv, const void* k, const void
                        void* out, float* lse, int B, int H, int Tq, int Tk, int dk, int ldq, int ldk,
                        int ldv, int ldp, int ldo, int64_t sbq, int64_t sbk, int64_t sbv, int64_t sbo,
                        float scale, float drop_p, uint64_t seed, const uint64_t* seed_dev, avsr_stream_t stream);
+/* the precise (f32) forward + the bf16 twin of its output (same strides as out) in one pass: the "hpf" numerical mode */
+int avsr_attention_fwd2(const void* qu, const void* qv, const void* k, const void* v, const void* pos, const uint8_t* mask,
+                        int64_t mask_sb, int64_t mask_sq, void* out, void* out2, float* lse, int B, int H, int Tq, int Tk, int dk,
+                        int ldq, int ldk, int ldv, int ldp, int ldo, int64_t sbq, int64_t sbk, int64_t sbv, int64_t sbo, float scale,
+                        float drop_p, uint64_t seed, const uint64_t* seed_dev, avsr_stream_t stream);
 /* backward, query side: recomputes P from lse; writes dqu (and dqv), plus pd = dropout(P) and
  * ds = scale*dS as [B,H,Tq,lds] tensors from which dK, dV and dpos follow as batched TN GEMMs. */
 int avsr_attention_bwd_dq(const void* qu, const void* qv, const void* k, const void* v, const void* pos,
@@ -113,6 +118,9 @@ int avsr_scale_dropout(const void* x, int x_dtype, void* out, int out_dtype, int
 /* o1 = x + b1[col], o2 = x + b2[col]  (q + pos_bias_u / q + pos_bias_v, attention.py:176-178); o1,o2 dense */
 int avsr_head_bias_fwd(const void* x, int dtype, int64_t ldx, const float* b1, const float* b2, void* o1,
                        void* o2, int64_t rows, int cols, avsr_stream_t stream);
+/* f32 outputs + their bf16 twins (t1, t2: both or none) */
+int avsr_head_bias_fwd2(const float* x, int64_t ldx, const float* b1, const float* b2, float* o1, float* o2, void* t1, void* t2,
+                        int64_t rows, int cols, avsr_stream_t stream);
 /* dq = d1 + d2 (row stride ldo; d2/dq may be NULL); db1 += colsum(d1); db2 += colsum(d2) (NULL skips) */
 int avsr_head_bias_bwd(const void* d1, const void* d2, int dtype, void* dq, int64_t ldo, float* db1,
                        float* db2, int64_t rows, int cols, avsr_stream_t stream);
@@ -130,6 +138,9 @@ int avsr_glu_bwd(const void* a, const void* dg, void* da, int dtype, int64_t row
  *               way out: y is [B*T, 2C] = (r * sigmoid(g), r * a * sigmoid(g) * (1 - sigmoid(g))) for glu_a = [a | g]. */
 int avsr_dwconv_fwd(const void* x, int dtype, const float* w, const float* bias, void* y, int B, int T,
                     int C, int K, int flip, int glu_in, const void* glu_a, avsr_stream_t stream);
+/* f32 forward (flip = 0, no GLU backward epilogue) + the bf16 twin y2 of its output */
+int avsr_dwconv_fwd2(const float* x, const float* w, const float* bias, float* y, void* y2, int B, int T, int C, int K, int glu_in,
+                     avsr_stream_t stream);
 /* dw[c,k] += sum dy[b,t,c] x[b,t+k-pad,c]; db[c] += sum dy; glu_in = 1: x is the pre-GLU tensor [B*T, 2C] */
 int avsr_dwconv_wgrad(const void* x, const void* dy, int dtype, float* dw, float* db, int B, int T, int C,
                       int K, int glu_in, avsr_stream_t stream);
@@ -163,6 +174,10 @@ int avsr_bn_small_max_rows(void);
 int avsr_bn_small_fwd(const void* x, int dtype, int64_t rows, int C, const float* gamma, const float* beta, float eps,
                       float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, int act, void* y,
                       float* mean, float* invstd, avsr_stream_t stream);
+/* f32 in / out + the bf16 twin y2 of the output (the "hpf" numerical mode) */
+int avsr_bn_small_fwd2(const float* x, int64_t rows, int C, const float* gamma, const float* beta, float eps, float momentum,
+                       float* running_mean, float* running_var, int64_t* num_batches_tracked, int act, float* y, void* y2,
+                       float* mean, float* invstd, avsr_stream_t stream);
 int avsr_bn_small_bwd(const void* x, const void* dy, int dtype, int64_t rows, int C, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, int act, void* dx, float* dgamma, float* dbeta,
                       avsr_stream_t stream);
