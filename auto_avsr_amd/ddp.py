@@ -9,12 +9,17 @@ instead of `torch.nn.parallel.DistributedDataParallel`:
   (`avsr_multi_copy_scale`) gathers the bucket's gradients into the flat buffer, pre-divided by the world size, the parameters'
   `.grad` are re-pointed at their slices of it, and `all_reduce(async_op=True)` goes out on RCCL's own stream -- overlapped
   with the rest of the backward pass (the parameter-poor, compute-rich ResNet trunk runs last);
+* `begin_step()` (before the forward pass, on the thread and stream that issue the step) records the compute stream; every
+  gather is then issued ON that stream from the hook -- not on the AccumulateGrad node's own stream, which need not be the
+  producer's (the allocator and, in a replayed graph, the ordering hazards of a foreign-stream launch: see `_flush`);
 * `finish()` makes the compute stream wait for the outstanding reductions (before the optimizer reads the gradients).
 
-Why not torch DDP: its reducer cannot be captured into a hipGraph on this stack (`tools/rccl_capture_probe.py`: plain RCCL
-all-reduce / all-gather capture and replay fine, `DistributedDataParallel`'s backward invalidates the capture), which left
-the N > 1 step on eager launches -- host-limited.  Everything this class issues is a stream operation:
-the whole data-parallel step, collectives included, replays as one graph per batch shape.
+Two transports.  `group=` : torch.distributed (`all_reduce(async_op=True)`, any backend -- what the CPU suite runs on gloo).
+`comm=` : a `comm.StreamComm` -- RCCL's C API inside libavsr_hip.so, the all-reduce forked to a side stream of this object
+behind an event: plain stream operations, so the WHOLE data-parallel step (buckets, cross-rank BatchNorm through a second
+communicator, optimizer) can be captured into a hipGraph and replayed (`bench.py --ddp auto`).  torch DDP's reducer cannot be
+captured on this stack (`tools/rccl_capture_probe.py`), and torch collectives inside a capture leave Work objects whose events
+the process-group watchdog polls.
 """
 import numpy as np
 import torch
