@@ -103,6 +103,36 @@ def _A(t):
     return ops.scale_dropout(t.contiguous(), torch.bfloat16)
 
 
+# hpf mode, front-end trunk: consecutive trunk functions hand their activation over as the bf16 TWIN (the autograd-visible
+# tensor) plus, through this registry, the f32 original for the next function's precise forward.  With f32 outputs autograd
+# itself cast every bf16 data gradient up to the forward dtype and the next function cast it back down -- two passes over the
+# largest activations of the step per trunk function.
+_f32_of = {}
+
+
+def _hand_over(out):
+    """f32 output of a trunk function -> its bf16 twin as the tensor autograd sees (hpf mode, twin available); else `out`."""
+    if not _state["hpf"] or out.dtype != torch.float32:
+        return out
+    ent = _twins.get(out.data_ptr())
+    if ent is None or ent[0].numel() != out.numel():
+        return out
+    tw = ent[1].view(out.shape)
+    if len(_f32_of) > 64:
+        _f32_of.clear()
+    _f32_of[tw.data_ptr()] = out
+    return tw
+
+
+def _f32_in(x):
+    """The f32 original of a handed-over twin (identity for anything else)."""
+    if x.dtype == torch.bfloat16 and _state["hpf"]:
+        o = _f32_of.get(x.data_ptr())
+        if o is not None and o.numel() == x.numel():
+            return o.view(x.shape)
+    return x
+
+
 def is_precise() -> bool:
     return _state["precise"]
 
@@ -624,6 +654,7 @@ def new_step():
     _shared_act.clear()
     _pos_proj.clear()
     _twins.clear()
+    _f32_of.clear()
 
 
 def _zeros(shape, device):
@@ -1847,6 +1878,7 @@ class BasicBlockFn(torch.autograd.Function):
         ph, pw = (KH - 1) // 2, (KW - 1) // 2
         T = act_dtype()
         pr = _state["precise"]
+        x = _f32_in(x)  # hpf: the previous trunk function handed over its bf16 twin; compute on the f32 original
         OH, OW = ops.conv_out(H, KH, stride, ph), ops.conv_out(W, KW, stride, pw)
         rows = N * OH * OW
         bn1 = (g1, b1) + bn1
@@ -1868,7 +1900,7 @@ class BasicBlockFn(torch.autograd.Function):
         ctx.save_for_backward(_A(x), _A(c1), _A(a1), _A(c2), _A(cd), _A(r) if wd is not None else None, w1, w2, wd, g1, b1, g2, b2,
                               gd, bd, m1, i1, n1, m2, i2, n2, md, idd, nd)
         ctx.meta = (dims, stride, training, (OH, OW), bn1[2:], bn2[2:], bnd[2:] if wd is not None else None)
-        return out
+        return _hand_over(out)
 
     @staticmethod
     @_bwd_mode
@@ -1959,7 +1991,10 @@ class StemFn(torch.autograd.Function):
             out = ops.bn_act_fwd(c0, None, m0, i0, g, b, rows, Cout, 1)
         ctx.save_for_backward(x, _A(c0), idx, g, b, m0, i0, n0, _A(xsel))
         ctx.meta = (geom, pool, training, bn_rest, (OH, OW), w.shape, geom_ok and not _bwd_precise())
-        return out
+        if _state["hpf"] and out.dtype == torch.float32 and out.data_ptr() not in _twins and _state.get("tag_ok", True):
+            # (the pooled output has no producer-side twin: make it here -- the first residual block would cast it anyway)
+            _twins[out.data_ptr()] = (out, ops.scale_dropout(out, torch.bfloat16))
+        return _hand_over(out)
 
     @staticmethod
     @_bwd_mode
@@ -2008,7 +2043,7 @@ class AvgPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, groups, win, C):
         ctx.meta = (groups, win, C, x.dtype, x.shape)
-        return ops.avgpool_fwd(x.contiguous(), groups, win, C)
+        return ops.avgpool_fwd(_f32_in(x).contiguous(), groups, win, C)  # (hpf: the trunk hands over its bf16 twin)
 
     @staticmethod
     @_bwd_mode
