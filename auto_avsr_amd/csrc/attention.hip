@@ -592,7 +592,9 @@ struct Attn {
 // The key-tile iteration of the generic kernel is ~1400 VALU/LDS instructions per wave against 26 MFMAs (416 clocks) --
 // at two waves per SIMD the kernel time IS that instruction count.  Same grid, same staging, same
 // arithmetic (online softmax in f32, dropout keep mask by (row, key) index), so the backward kernel pairs with it unchanged.
-template <bool RELPOS>
+// F16 = 1: q / k / v / position band and the probabilities are IEEE half (v_mfma_f32_16x16x32_f16) -- the mixed mode's forward;
+// `out` is then f16 and out2 (optional) its bf16 twin for the backward pass.
+template <bool RELPOS, int F16 = 0>
 struct AttnFwdT {
     static constexpr int KS_E = KT * PITCH, VS_E = KT * PITCH, PB_E = RELPOS ? PB_ROWS * PITCH : 0;
     static constexpr int G_F = RELPOS ? 4 * 16 * G_PITCH : 0;  // f32, per wave [16 q][G_PITCH]
@@ -671,7 +673,7 @@ struct AttnFwdT {
                 st[j] = f32x4{0, 0, 0, 0};
 #pragma unroll
                 for (int ks = 0; ks < 2; ks++)
-                    st[j] = mfma16(ldfrag<1>(Ks, KT * PITCH, PITCH, j * 16 + lc, ks * 32 + 8 * quad).p[0], fq_u[ks], st[j]);
+                    st[j] = mfma16x<F16>(ldfrag<1>(Ks, KT * PITCH, PITCH, j * 16 + lc, ks * 32 + 8 * quad).p[0], fq_u[ks], st[j]);
             }
             if (RELPOS) {
                 // G^T = Pband (q+v)^T: lane holds G[q = lc][band 16t + 4quad .. +3] -> one 16-byte store per band tile
@@ -682,7 +684,7 @@ struct AttnFwdT {
                     f32x4 g = f32x4{0, 0, 0, 0};
 #pragma unroll
                     for (int ks = 0; ks < 2; ks++)
-                        g = mfma16(ldfrag<1>(Pb, PB_ROWS * PITCH, PITCH, sb + t * 16 + lc, ks * 32 + 8 * quad).p[0], fq_v[ks], g);
+                        g = mfma16x<F16>(ldfrag<1>(Pb, PB_ROWS * PITCH, PITCH, sb + t * 16 + lc, ks * 32 + 8 * quad).p[0], fq_v[ks], g);
                     *reinterpret_cast<f32x4*>(Gw + lc * G_PITCH + t * 16 + 4 * quad) = g;
                 }
                 wave_sync();
@@ -743,14 +745,14 @@ struct AttnFwdT {
                 bf16x8 pb;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    pb[r] = (short)f2bf(st[2 * ks][r]);
-                    pb[4 + r] = (short)f2bf(st[2 * ks + 1][r]);
+                    pb[r] = f32_to_raw16<F16>(st[2 * ks][r]);
+                    pb[4 + r] = f32_to_raw16<F16>(st[2 * ks + 1][r]);
                 }
 #pragma unroll
                 for (int n = 0; n < 4; n++) {
                     const bf16_t* p0 = Vs + (ks * 32 + 4 * quad + (lc >> 2)) * PITCH + n * 16 + 4 * (lc & 3);
                     const bf16x4 lo = lds_tr16(p0), hi = lds_tr16(p0 + 16 * PITCH);
-                    acc[n] = mfma16(bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, pb, acc[n]);
+                    acc[n] = mfma16x<F16>(bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}, pb, acc[n]);
                 }
             }
         }
@@ -761,21 +763,27 @@ struct AttnFwdT {
         if (!q_ok) return;
         const float inv = l > 0.f ? 1.f / l : 0.f;
         bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + b * p.sbo + (long)qrow * p.ldo + h * DK;
+        bf16_t* o2 = (F16 && p.out2) ? reinterpret_cast<bf16_t*>(p.out2) + b * p.sbo + (long)qrow * p.ldo + h * DK : nullptr;
 #pragma unroll
         for (int n = 0; n < 4; n++) {
             bf16x4 v4;
 #pragma unroll
-            for (int r = 0; r < 4; r++) v4[r] = (short)f2bf(acc[n][r] * inv);
+            for (int r = 0; r < 4; r++) v4[r] = f32_to_raw16<F16>(acc[n][r] * inv);
             *reinterpret_cast<bf16x4*>(o + n * 16 + 4 * quad) = v4;
+            if (o2) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v4[r] = (short)f2bf(acc[n][r] * inv);
+                *reinterpret_cast<bf16x4*>(o2 + n * 16 + 4 * quad) = v4;
+            }
         }
         if (quad == 0) p.lse[((long)b * p.H + h) * Tq + qrow] = l > 0.f ? (m_run + log2f(l)) * 0.6931471805599453f : 0.f;
     }
 };
 
-template <bool RELPOS>
+template <bool RELPOS, int F16 = 0>
 __global__ __launch_bounds__(256) void attn_fwd_t_kernel(AttnParams p) {
     AVSR_DYN_SMEM(smem);
-    AttnFwdT<RELPOS>::run(p, smem);
+    AttnFwdT<RELPOS, F16>::run(p, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1043,6 +1051,10 @@ int launch_attn(const AttnParams& p, int dtype, int precise, bool relpos, hipStr
             else AVSR_LAUNCH((attn_bwd_t_kernel<false>), grid, block, (AttnBwdT<false>::LDS_BYTES), stream, p);
         } else if (relpos) AVSR_ATTN_GO(bf16_t, 1, true);
         else AVSR_ATTN_GO(bf16_t, 1, false);
+    } else if (dtype == 2) {  // f16 (forward only: the backward pass of the mixed mode runs on the bf16 twins)
+        if (BWD) return -1;
+        if (relpos) AVSR_LAUNCH((attn_fwd_t_kernel<true, 1>), grid, block, (AttnFwdT<true, 1>::LDS_BYTES), stream, p);
+        else AVSR_LAUNCH((attn_fwd_t_kernel<false, 1>), grid, block, (AttnFwdT<false, 1>::LDS_BYTES), stream, p);
     } else {
         if (relpos) AVSR_ATTN_GO(float, 1, true); else AVSR_ATTN_GO(float, 1, false);
     }
@@ -1083,6 +1095,16 @@ extern "C" int avsr_attention_fwd(const void* qu, const void* qv, const void* k,
                                   float scale, float drop_p, uint64_t seed, const uint64_t* seed_dev, hipStream_t stream) {
     return attention_fwd_impl(qu, qv, k, v, pos, dtype, precise, mask, mask_sb, mask_sq, out, nullptr, lse, B, H, Tq, Tk, dk, ldq,
                               ldk, ldv, ldp, ldo, sbq, sbk, sbv, sbo, scale, drop_p, seed, seed_dev, stream);
+}
+
+// f16 forward (q / k / v / pos / out all IEEE half, v_mfma_f32_16x16x32_f16) + the bf16 twin out2 (may be NULL) of its output
+extern "C" int avsr_attention_fwd_h16(const void* qu, const void* qv, const void* k, const void* v, const void* pos,
+                                      const uint8_t* mask, int64_t mask_sb, int64_t mask_sq, void* out, void* out2, float* lse,
+                                      int B, int H, int Tq, int Tk, int dk, int ldq, int ldk, int ldv, int ldp, int ldo,
+                                      int64_t sbq, int64_t sbk, int64_t sbv, int64_t sbo, float scale, float drop_p, uint64_t seed,
+                                      const uint64_t* seed_dev, hipStream_t stream) {
+    return attention_fwd_impl(qu, qv, k, v, pos, 2, 0, mask, mask_sb, mask_sq, out, out2, lse, B, H, Tq, Tk, dk, ldq, ldk, ldv, ldp,
+                              ldo, sbq, sbk, sbv, sbo, scale, drop_p, seed, seed_dev, stream);
 }
 
 // f32 (precise) forward + the bf16 twin of its output (same strides) in one pass

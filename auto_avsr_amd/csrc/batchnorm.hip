@@ -820,6 +820,12 @@ extern "C" int avsr_bn_stats(const void* x, int dtype, float* stats, float* work
                     (const float*)nullptr, workspace, (long)rows, C, CL, rpb, 0);
         AVSR_LAUNCH((bn_partial_sum_kernel<float>), g2, dim3(256), 0, stream, (const float*)workspace, parts, C, stats, 1, (const float*)x,
                     count_out, (float)rows);
+    } else if (dtype == 2) {
+        AVSR_LAUNCH((bn_colreduce_kernel<f16_t, 0>), grid, block, 0, stream, (const f16_t*)x, (const f16_t*)nullptr,
+                    (const f16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                    (const float*)nullptr, workspace, (long)rows, C, CL, rpb, 0);
+        AVSR_LAUNCH((bn_partial_sum_kernel<f16_t>), g2, dim3(256), 0, stream, (const float*)workspace, parts, C, stats, 1, (const f16_t*)x,
+                    count_out, (float)rows);
     } else {
         AVSR_LAUNCH((bn_colreduce_kernel<bf16_t, 0>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)nullptr,
                     (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
@@ -849,6 +855,13 @@ extern "C" int avsr_bn_stats_finalize(const void* x, int dtype, float* workspace
                     (const float*)nullptr, workspace, (long)rows, C, CL, rpb, 0);
         AVSR_LAUNCH((bn_partial_finalize_kernel<float>), g2, dim3(256), 0, stream, (const float*)workspace, parts, C,
                     (const float*)x, (float)rows, eps, momentum, mean, invstd, running_mean, running_var,
+                    num_batches_tracked);
+    } else if (dtype == 2) {
+        AVSR_LAUNCH((bn_colreduce_kernel<f16_t, 0>), grid, block, 0, stream, (const f16_t*)x, (const f16_t*)nullptr,
+                    (const f16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                    (const float*)nullptr, workspace, (long)rows, C, CL, rpb, 0);
+        AVSR_LAUNCH((bn_partial_finalize_kernel<f16_t>), g2, dim3(256), 0, stream, (const float*)workspace, parts, C,
+                    (const f16_t*)x, (float)rows, eps, momentum, mean, invstd, running_mean, running_var,
                     num_batches_tracked);
     } else {
         AVSR_LAUNCH((bn_colreduce_kernel<bf16_t, 0>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)nullptr,
@@ -907,6 +920,18 @@ extern "C" int avsr_bn_act_fwd2(const float* x, const float* add, const float* m
     AVSR_LAUNCH((bn_act_fwd_kernel<float>), grid, block, 0, stream, x, add, mean, invstd, gamma, beta, y, (long)rows, C, act,
                 (bf16_t*)y2);
     AVSR_CHECK_LAUNCH("bn_act_fwd2");
+    return 0;
+}
+
+// f16 in / f16 out + the bf16 twin y2 (may be NULL) of the output in one pass (the "mixed" numerical mode)
+extern "C" int avsr_bn_act_fwd_h16(const void* x, const void* add, const float* mean, const float* invstd, const float* gamma,
+                                   const float* beta, void* y, void* y2, int64_t rows, int C, int act, hipStream_t stream) {
+    AVSR_REQUIRE(C % 8 == 0, "batchnorm: C must be a multiple of 8");
+    if (rows <= 0) return 0;
+    dim3 grid(ew_grid(rows * (C >> 3))), block(BN_THREADS);
+    AVSR_LAUNCH((bn_act_fwd_kernel<f16_t>), grid, block, 0, stream, (const f16_t*)x, (const f16_t*)add, mean, invstd, gamma, beta,
+                (f16_t*)y, (long)rows, C, act, (bf16_t*)y2);
+    AVSR_CHECK_LAUNCH("bn_act_fwd_h16");
     return 0;
 }
 
@@ -1067,6 +1092,18 @@ extern "C" int avsr_bn_small_fwd2(const float* x, int64_t rows, int C, const flo
     AVSR_LAUNCH((bn_small_fwd_kernel<float>), dim3(C / 8), dim3(BNS_THREADS), 0, stream, x, (int)rows, C, gamma, beta, eps, momentum,
                 running_mean, running_var, num_batches_tracked, act, y, mean, invstd, (bf16_t*)y2);
     AVSR_CHECK_LAUNCH("bn_small_fwd2");
+    return 0;
+}
+
+// f16 input / output + the bf16 twin y2 (may be NULL) of the output
+extern "C" int avsr_bn_small_fwd_h16(const void* x, int64_t rows, int C, const float* gamma, const float* beta, float eps,
+                                     float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                     int act, void* y, void* y2, float* mean, float* invstd, hipStream_t stream) {
+    AVSR_REQUIRE(C % 8 == 0, "bn_small: C must be a multiple of 8");
+    AVSR_REQUIRE(rows >= 1 && rows <= BNS_THREADS * BNS_R, "bn_small: rows out of range (avsr_bn_small_max_rows)");
+    AVSR_LAUNCH((bn_small_fwd_kernel<f16_t>), dim3(C / 8), dim3(BNS_THREADS), 0, stream, (const f16_t*)x, (int)rows, C, gamma, beta,
+                eps, momentum, running_mean, running_var, num_batches_tracked, act, (f16_t*)y, mean, invstd, (bf16_t*)y2);
+    AVSR_CHECK_LAUNCH("bn_small_fwd_h16");
     return 0;
 }
 

@@ -13,6 +13,11 @@ constexpr int DW_CH = 64;     // channels per block (one per lane)
 constexpr int DW_TT = 32;     // outputs per block along time (forward / data gradient)
 constexpr int DW_MAXK = 31;
 
+// an intermediate the stand-alone op sequence would have stored in the activation type: bf16 tensors re-round (bit-compatible
+// with that sequence, which the bf16 backward pass recomputes); f32 / f16 (forward-only) tensors keep the f32 value
+template <class T> AVSR_DEV float round_as_stored(float v) { return v; }
+template <> AVSR_DEV float round_as_stored<bf16_t>(float v) { return bf2f(f2bf(v)); }
+
 template <class T>
 AVSR_DEV void stage_time_tile(float* xs, const T* x, int b, int t_first, int nrows, int Tlen, int C, int c0) {
     for (int id = threadIdx.x; id < nrows * (DW_CH / 8); id += 256) {
@@ -44,7 +49,7 @@ AVSR_DEV void stage_time_tile_glu(float* xs, const T* a, int b, int t_first, int
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 v[e] *= avsr_sigmoid(g[e]);
-                if (sizeof(T) == 2) v[e] = bf2f(f2bf(v[e]));
+                v[e] = round_as_stored<T>(v[e]);
             }
         } else {
 #pragma unroll
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
         if (t0 + t < Tlen && c0 + tx < C) {
             const long row = (long)b * Tlen + t0 + t;
             if (glu_a) {
-                if (sizeof(T) == 2) acc = bf2f(f2bf(acc));  // the gradient the stand-alone path stored before its GLU backward
+                acc = round_as_stored<T>(acc);  // the gradient the stand-alone path stored before its GLU backward
                 const float lin = Elem<T>::ld(glu_a + row * 2 * C + c0 + tx), sg = avsr_sigmoid(Elem<T>::ld(glu_a + row * 2 * C + C + c0 + tx));
                 Elem<T>::st(y + row * 2 * C + c0 + tx, acc * sg);
                 Elem<T>::st(y + row * 2 * C + C + c0 + tx, acc * lin * sg * (1.f - sg));
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
                     v[e] *= avsr_sigmoid(g[e]);
-                    if (sizeof(T) == 2) v[e] = bf2f(f2bf(v[e]));  // as the stand-alone GLU kernel would have stored it
+                    v[e] = round_as_stored<T>(v[e]);  // as the stand-alone GLU kernel would have stored it
                 }
             } else {
                 load8(src + ((long)b * Tlen + t) * C + c0, v);
@@ -192,6 +197,19 @@ extern "C" int avsr_dwconv_fwd(const void* x, int dtype, const float* w, const f
         AVSR_LAUNCH((dwconv_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, w, bias, (bf16_t*)y, T, C, K, flip,
                     glu_in, (const bf16_t*)glu_a);
     AVSR_CHECK_LAUNCH("dwconv_fwd");
+    return 0;
+}
+
+// f16 forward (input and output IEEE half) + the bf16 twin y2 (may be NULL) of its output in one pass
+extern "C" int avsr_dwconv_fwd_h16(const void* x, const float* w, const float* bias, void* y, void* y2, int B, int T, int C, int K,
+                                   int glu_in, hipStream_t stream) {
+    AVSR_REQUIRE(K >= 1 && K <= DW_MAXK && (K & 1), "dwconv: K must be odd and <= 31");
+    AVSR_REQUIRE(C % 8 == 0, "dwconv: C must be a multiple of 8");
+    if (B <= 0 || T <= 0) return 0;
+    dim3 grid((C + DW_CH - 1) / DW_CH, (T + DW_TT - 1) / DW_TT, B), block(256);
+    AVSR_LAUNCH((dwconv_kernel<f16_t>), grid, block, 0, stream, (const f16_t*)x, w, bias, (f16_t*)y, T, C, K, 0, glu_in,
+                (const f16_t*)nullptr, (bf16_t*)y2);
+    AVSR_CHECK_LAUNCH("dwconv_fwd_h16");
     return 0;
 }
 

@@ -185,7 +185,11 @@ extern "C" int avsr_scale_dropout(const void* x, int x_dtype, void* out, int out
     AVSR_REQUIRE(add == nullptr || (add_period > 0 && add_period % 8 == 0), "scale_dropout: add_period must be a positive multiple of 8");
     AVSR_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0, "scale_dropout: 16-byte alignment");
     if (x_dtype == 0 && out_dtype == 0) launch_scale_dropout<float, float>(x, out, n, alpha, alpha_dev, drop_p, seed, seed_dev, add, (long)add_period, stream);
-    else if (x_dtype == 0) launch_scale_dropout<float, bf16_t>(x, out, n, alpha, alpha_dev, drop_p, seed, seed_dev, add, (long)add_period, stream);
+    else if (x_dtype == 0 && out_dtype == 1) launch_scale_dropout<float, bf16_t>(x, out, n, alpha, alpha_dev, drop_p, seed, seed_dev, add, (long)add_period, stream);
+    else if (x_dtype == 0 && out_dtype == 2) launch_scale_dropout<float, f16_t>(x, out, n, alpha, alpha_dev, drop_p, seed, seed_dev, add, (long)add_period, stream);
+    else if (x_dtype == 2 && out_dtype == 0) launch_scale_dropout<f16_t, float>(x, out, n, alpha, alpha_dev, drop_p, seed, seed_dev, add, (long)add_period, stream);
+    else if (x_dtype == 2 && out_dtype == 1) launch_scale_dropout<f16_t, bf16_t>(x, out, n, alpha, alpha_dev, drop_p, seed, seed_dev, add, (long)add_period, stream);
+    else if (x_dtype == 2 || out_dtype == 2) { avsr_set_error("scale_dropout: unsupported f16 combination"); return 1; }
     else if (out_dtype == 0) launch_scale_dropout<bf16_t, float>(x, out, n, alpha, alpha_dev, drop_p, seed, seed_dev, add, (long)add_period, stream);
     else launch_scale_dropout<bf16_t, bf16_t>(x, out, n, alpha, alpha_dev, drop_p, seed, seed_dev, add, (long)add_period, stream);
     AVSR_CHECK_LAUNCH("scale_dropout");
@@ -217,6 +221,19 @@ extern "C" int avsr_head_bias_fwd2(const float* x, int64_t ldx, const float* b1,
     AVSR_LAUNCH((head_bias_kernel<float>), grid, block, 0, stream, x, (long)ldx, b1, b2, o1, o2, (long)rows, cols, (bf16_t*)t1,
                 (bf16_t*)t2);
     AVSR_CHECK_LAUNCH("head_bias_fwd2");
+    return 0;
+}
+
+// f16 input / outputs + their bf16 twins (mixed mode: the attention forward reads f16, its backward the twins)
+extern "C" int avsr_head_bias_fwd_h16(const void* x, int64_t ldx, const float* b1, const float* b2, void* o1, void* o2, void* t1,
+                                      void* t2, int64_t rows, int cols, hipStream_t stream) {
+    AVSR_REQUIRE(cols % 8 == 0 && ldx % 8 == 0, "head_bias_fwd: cols/ldx must be multiples of 8");
+    AVSR_REQUIRE((t1 == nullptr) == (t2 == nullptr), "head_bias_fwd_h16: both twins or none");
+    if (rows <= 0) return 0;
+    dim3 grid(ew_grid(rows * (cols >> 3))), block(EW_THREADS);
+    AVSR_LAUNCH((head_bias_kernel<f16_t>), grid, block, 0, stream, (const f16_t*)x, (long)ldx, b1, b2, (f16_t*)o1, (f16_t*)o2,
+                (long)rows, cols, (bf16_t*)t1, (bf16_t*)t2);
+    AVSR_CHECK_LAUNCH("head_bias_fwd_h16");
     return 0;
 }
 

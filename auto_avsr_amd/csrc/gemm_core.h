@@ -45,7 +45,7 @@ struct Params {
     const float* resid;  // v += resid[m,ldr]
     int ldr;
     void* C;
-    void* C2;  // LDS epilogue, non-accumulating f32 outputs: bf16 twin of the stored values (same shape, pitch ldc2) or null
+    void* C2;  // LDS epilogue, non-accumulating f32 / f16 outputs: bf16 twin of the stored values (same shape, pitch ldc2) or null
     int ldc2;
     int c_dtype, ldc;
     int accumulate;  // f32 C only: atomicAdd (needed for split-K; also "+=" semantics)
@@ -315,6 +315,13 @@ AVSR_DEV void epilogue_lds(f32x16 (&acc)[TM][TN], const Params& p, int m0, int n
                 store8(cp, v);
             } else {
                 for (int e = 0; e < nv; e++) cp[e] = v[e];
+            }
+        } else if (p.c_dtype == 2) {  // f16 (forward activations of the mixed mode)
+            f16_t* cp = reinterpret_cast<f16_t*>(p.C) + co;
+            if (full && p.ldc % 8 == 0 && (c_off % 8) == 0) {
+                store8(cp, v);
+            } else {
+                for (int e = 0; e < nv; e++) cp[e] = f2h(v[e]);
             }
         } else {
             bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + co;

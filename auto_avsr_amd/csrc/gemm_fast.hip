@@ -27,15 +27,15 @@ using avsr_gemm_impl::Params;
 
 using avsr_fast::FastKernel;
 
-template <int BM, int BN, int STAGES, int CV, int WGM, int WGN, int ABL, int KS>
+template <int BM, int BN, int STAGES, int CV, int WGM, int WGN, int ABL, int KS, int F16 = 0>
 __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemm_fast_kernel(Params p) {
     AVSR_DYN_SMEM(smem);
-    FastKernel<BM, BN, STAGES, CV, WGM, WGN, ABL, KS>::run(p, smem);
+    FastKernel<BM, BN, STAGES, CV, WGM, WGN, ABL, KS, F16>::run(p, smem);
 }
 
-template <int BM, int BN, int STAGES, int CV = 0, int WGM = 2, int WGN = 2, int ABL = 0, int KS = 1>
+template <int BM, int BN, int STAGES, int CV = 0, int WGM = 2, int WGN = 2, int ABL = 0, int KS = 1, int F16 = 0>
 void launch_fast(Params& p, int split_k, hipStream_t stream) {
-    using K = FastKernel<BM, BN, STAGES, CV, WGM, WGN, ABL, KS>;
+    using K = FastKernel<BM, BN, STAGES, CV, WGM, WGN, ABL, KS, F16>;
     // XCD-aware tile order (knob 1: 0 = automatic, 1 = on, 2 = off).  Automatic: on for the 64x64 GEMM tile -- measured
     // with operands that are NOT cache-resident (tools/microbench_xcd.py: A written by the previous kernel, weights
     // streamed from HBM, as in the training step): every XCD otherwise pulls the whole problem through its own L2
@@ -61,7 +61,7 @@ void launch_fast(Params& p, int split_k, hipStream_t stream) {
         gy = t0;
     }
     dim3 grid((p.N + BN - 1) / BN, gy, split_k), block(K::NTHR);
-    AVSR_LAUNCH((gemm_fast_kernel<BM, BN, STAGES, CV, WGM, WGN, ABL, KS>), grid, block, K::LDS_BYTES, stream, p);
+    AVSR_LAUNCH((gemm_fast_kernel<BM, BN, STAGES, CV, WGM, WGN, ABL, KS, F16>), grid, block, K::LDS_BYTES, stream, p);
 }
 
 // tile codes shared by the GEMM and convolution entry points
@@ -101,17 +101,28 @@ bool launch_tile(int tile, Params& p, int split_k, hipStream_t stream) {
     }
 }
 
+// f16 operands (forward pass of the mixed mode): the three default tile shapes only
+template <int CV>
+bool launch_tile_h16(int tile, Params& p, int split_k, hipStream_t stream) {
+    switch (tile) {
+        case 1: if (CV == 0) { launch_fast<64, 64, 3, 0, 2, 2, 0, 1, 1>(p, split_k, stream); return true; } return false;
+        case 4: launch_fast<128, 128, 2, CV, 2, 2, 0, 1, 1>(p, split_k, stream); return true;
+        case 7: launch_fast<128, 64, 2, CV, 2, 2, 0, 1, 1>(p, split_k, stream); return true;
+        default: return false;
+    }
+}
+
 }  // namespace
 
 int avsr_conv3x3_c64_supported(int H, int W);
 int avsr_conv3x3_c64_launch(int flip, const void* src, const void* wq, const void* resid, void* out, const void* zero_page, int N,
                             int H, int W, hipStream_t stream);
 
-extern "C" int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
-                                 int act, const void* gate, int gate_dtype, int ldg, float gate_scale, float drop_p,
-                                 uint64_t seed, const uint64_t* seed_dev, float alpha, const float* alpha_dev,
-                                 const void* resid, int resid_dtype, int ldr, void* C, int c_dtype, int ldc, int accumulate,
-                                 int split_k, int tile, float* colsum, hipStream_t stream) {
+static int gemm16_nt_impl(int f16, const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
+                          int act, const void* gate, int gate_dtype, int ldg, float gate_scale, float drop_p,
+                          uint64_t seed, const uint64_t* seed_dev, float alpha, const float* alpha_dev,
+                          const void* resid, int resid_dtype, int ldr, void* C, int c_dtype, int ldc, int accumulate,
+                          int split_k, int tile, float* colsum, void* c2, int ldc2, hipStream_t stream) {
     AVSR_REQUIRE(!(colsum && accumulate), "gemm_bf16_nt: colsum needs a non-accumulating output");
     AVSR_REQUIRE(K > 0 && K % 64 == 0, "gemm_bf16_nt: K must be a positive multiple of 64");
     AVSR_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "gemm_bf16_nt: lda/ldb must be multiples of 8 elements");
@@ -129,6 +140,8 @@ extern "C" int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
     p.resid = reinterpret_cast<const float*>(resid); p.resid_dtype = resid_dtype; p.ldr = ldr;
     p.C = C; p.c_dtype = c_dtype; p.ldc = ldc; p.accumulate = accumulate;
     p.colsum = colsum;
+    AVSR_REQUIRE(c2 == nullptr || (!accumulate && c_dtype != 1), "gemm_*_nt: the bf16 twin needs a non-accumulating f32 / f16 output");
+    p.C2 = c2; p.ldc2 = ldc2;
     p.nsplit = 1; p.batch_h = 1; p.nbatch = 1;
     if (split_k < 1) split_k = 1;
     if (tile == 0) {
@@ -139,10 +152,35 @@ extern "C" int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
         // chip, 64x64 with 3 stages (3 blocks per CU) for the skinny M = B*T GEMMs of the transformer layers
         tile = t128 >= 1024 ? 4 : (t12864 >= 400 ? 7 : (g_tune[14] > 0 && (long)((M + 63) / 64) * ((N + 63) / 64) > 256 ? g_tune[14] : 1));  // knob 14: A/B of the tile for grids of 257+ 64x64 tiles
     }
+    if (f16) {
+        if (tile != 1 && tile != 4 && tile != 7) tile = 1;
+        AVSR_REQUIRE(launch_tile_h16<0>(tile, p, split_k, stream), "gemm_h16_nt: unknown tile code");
+        AVSR_CHECK_LAUNCH("gemm_h16_nt");
+        return 0;
+    }
     if (avsr_pair::stash_nt(p, tile, split_k, stream)) return 0;  // launched by avsr_gemm_pair_end (gemm_pair.hip)
     AVSR_REQUIRE(launch_tile<0>(tile, p, split_k, stream), "gemm_bf16_nt: unknown tile code");
     AVSR_CHECK_LAUNCH("gemm_bf16_nt");
     return 0;
+}
+
+extern "C" int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
+                                 int act, const void* gate, int gate_dtype, int ldg, float gate_scale, float drop_p,
+                                 uint64_t seed, const uint64_t* seed_dev, float alpha, const float* alpha_dev,
+                                 const void* resid, int resid_dtype, int ldr, void* C, int c_dtype, int ldc, int accumulate,
+                                 int split_k, int tile, float* colsum, hipStream_t stream) {
+    return gemm16_nt_impl(0, A, lda, B, ldb, M, N, K, bias, act, gate, gate_dtype, ldg, gate_scale, drop_p, seed, seed_dev, alpha,
+                          alpha_dev, resid, resid_dtype, ldr, C, c_dtype, ldc, accumulate, split_k, tile, colsum, nullptr, 0, stream);
+}
+
+// The same contraction on IEEE-half operands (v_mfma_f32_32x32x16_f16): A and B f16 k-contiguous; C f32, bf16 or f16
+// (c_dtype 0 / 1 / 2); c2 (may be NULL): bf16 twin of an f32 / f16 result -- what the backward pass of the mixed mode reads.
+extern "C" int avsr_gemm_h16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
+                                int act, float drop_p, uint64_t seed, const uint64_t* seed_dev, float alpha, const void* resid,
+                                int resid_dtype, int ldr, void* C, int c_dtype, int ldc, int tile, void* c2, int ldc2,
+                                hipStream_t stream) {
+    return gemm16_nt_impl(1, A, lda, B, ldb, M, N, K, bias, act, nullptr, 0, 0, 1.f, drop_p, seed, seed_dev, alpha, nullptr, resid,
+                          resid_dtype, ldr, C, c_dtype, ldc, 0, 1, tile, nullptr, c2, ldc2, stream);
 }
 
 // bf16 implicit-GEMM convolution on the tuned kernel: forward (dgrad = 0: x[N,H,W,Cin] * wp[Cout][KH][KW][Cin] ->
@@ -343,7 +381,7 @@ struct AvsrCastEntry {
     const float* src;
     bf16_t* dst;   // may be null
     bf16_t* dstT;  // may be null
-    int R, C, ldT, blk0, tiles_c, limT, pad1, pad2;  // limT (0 = ldT): rows of dstT that are written (zero tail included)
+    int R, C, ldT, blk0, tiles_c, limT, pad1, pad2;  // limT (0 = ldT): rows of dstT that are written (zero tail included); pad1 = 2: dst is f16, not bf16
 };
 
 namespace {
@@ -374,7 +412,13 @@ __global__ __launch_bounds__(256) void multi_cast_transpose_kernel(const AvsrCas
 #pragma unroll
         for (int k = 0; k < 8; k++) tile[(cc + k) * 72 + r] = f2bf(v[k]);
         if (e.dst && gr < e.R) {
-            if (vec_ok && gc + 8 <= e.C) store8(e.dst + (long)gr * e.C + gc, v);
+            if (e.pad1 == 2) {  // f16 forward copy (mixed mode)
+                f16_t* d16 = reinterpret_cast<f16_t*>(e.dst);
+                if (vec_ok && gc + 8 <= e.C) store8(d16 + (long)gr * e.C + gc, v);
+                else
+                    for (int k = 0; k < 8; k++)
+                        if (gc + k < e.C) d16[(long)gr * e.C + gc + k] = f2h(v[k]);
+            } else if (vec_ok && gc + 8 <= e.C) store8(e.dst + (long)gr * e.C + gc, v);
             else
                 for (int k = 0; k < 8; k++)
                     if (gc + k < e.C) e.dst[(long)gr * e.C + gc + k] = f2bf(v[k]);
@@ -392,7 +436,7 @@ __global__ __launch_bounds__(256) void multi_cast_transpose_kernel(const AvsrCas
 }
 }  // namespace
 
-// table: n entries of 64 bytes {src, dst, dstT, R, C, ldT, blk0, tiles_c, limT, 0, 0}; blk0 = running sum of
+// table: n entries of 64 bytes {src, dst, dstT, R, C, ldT, blk0, tiles_c, limT, dst_dtype (0 / 1 = bf16, 2 = f16), 0}; blk0 = running sum of
 // ceil(max(R, limT ? limT : ldT)/64) * ceil(C/64); total_blocks = the final sum.  limT < ldT lets several transposed
 // copies share one [C][ldT] buffer side by side (concatenated projection weights).
 extern "C" int avsr_multi_cast_transpose(const void* table, int n, int total_blocks, hipStream_t stream) {

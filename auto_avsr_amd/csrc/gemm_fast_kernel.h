@@ -25,7 +25,9 @@ using avsr_gemm_impl::Params;
 // every staged 64-wide k-tile; the partial tiles meet in LDS before the epilogue.  A skinny M = B*T GEMM gives every CU
 // about one block: with 4 waves that is ONE wave per SIMD and nothing to cover the LDS-read -> MFMA latency of the
 // dependent accumulator chain; 8 waves put two on every SIMD without a second pass over the output.
-template <int BM, int BN, int STAGES, int CV = 0, int WGM = 2, int WGN = 2, int ABL = 0, int KS = 1>
+// F16 = 1: both operands are IEEE half instead of bf16 (the forward pass of the "mixed" numerical mode) -- the same bytes, the same
+// staging, the same fragment layout; only the MFMA instruction differs.
+template <int BM, int BN, int STAGES, int CV = 0, int WGM = 2, int WGN = 2, int ABL = 0, int KS = 1, int F16 = 0>
 struct FastKernel {
     static constexpr int BK = 64, NQ = WGM * WGN, NW = NQ * KS, NTHR = 64 * NW;
     static constexpr int KPG = (BK / 16) / KS;  // 16-wide k-steps per wave group and k-tile
@@ -254,7 +256,7 @@ struct FastKernel {
 #pragma unroll
                 for (int i = 0; i < TM; i++)
 #pragma unroll
-                    for (int j = 0; j < TN; j++) acc[i][j] = mfma32(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
+                    for (int j = 0; j < TN; j++) acc[i][j] = mfma32x<F16>(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
                 if (ks + 2 < KPG) load_frags(ks & 1, ks0 + ks + 2);
                 sched_fence();
             }

@@ -272,6 +272,18 @@ extern "C" int avsr_layernorm_fwd2(const float* x, const float* gamma, const flo
     return 0;
 }
 
+// f16 output + its bf16 twin (may be NULL) in one pass (the "mixed" numerical mode: f16 forward operands, bf16 backward)
+extern "C" int avsr_layernorm_fwd_h16(const float* x, const float* gamma, const float* beta, void* y, void* y2, float* mean,
+                                      float* rstd, int rows, int cols, float eps, hipStream_t stream) {
+    AVSR_REQUIRE(cols % 8 == 0 && cols <= 64 * 8 * LN_MAXV, "layernorm: cols must be %8 and <= 2048");
+    if (rows == 0) return 0;
+    dim3 grid((rows + LN_WAVES - 1) / LN_WAVES), block(LN_THREADS);
+    AVSR_LAUNCH((layernorm_fwd_kernel<f16_t>), grid, block, 0, stream, x, gamma, beta, (f16_t*)y, mean, rstd, rows, cols, eps,
+                (bf16_t*)y2);
+    AVSR_CHECK_LAUNCH("layernorm_fwd_h16");
+    return 0;
+}
+
 // dgamma / dbeta (and gsum) are ACCUMULATED into (caller zeroes them or carries grads over).
 // gout (bf16 [rows][cols], may be NULL) = bf16(alpha * dropout(dx)) with the dropout stream of avsr_cast_transpose_colsum
 // (element index row * cols + col); gsum (f32 [cols], may be NULL, needs gout) += column sums of gout.

@@ -53,7 +53,26 @@ AVSR_DEV bf16_t f2bf(float f) {  // round to nearest even, NaN preserved
     return (bf16_t)(u >> 16);
 }
 
-// Storage-type traits: activations live in HBM either as bf16 (bench mode) or
+// IEEE half (1-5-10) as a STORAGE type of forward activations: the "mixed" numerical mode keeps the activations of the
+// Conformer encoder in f16 -- 11 significant bits against the 8 of bf16, the same 2 bytes and the same MFMA rate
+// (v_mfma_f32_*_f16) -- because the north-star bound on the logits (1e-3 relative) is not reachable with 8-bit significands
+// (tools/precision_study.py).  Values are clamped to the finite range on conversion (activations that feed a contraction sit
+// behind a LayerNorm / BatchNorm / softmax: |x| << 65504); gradients never use this type.
+typedef _Float16 f16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+AVSR_DEV float h2f(f16_t h) { return (float)h; }
+AVSR_DEV f16_t f2h(float f) {  // round to nearest even, saturating
+#ifdef AVSR_EMU
+    f = f > 65504.f ? 65504.f : (f < -65504.f ? -65504.f : f);
+#else
+    f = __builtin_amdgcn_fmed3f(f, -65504.f, 65504.f);
+#endif
+    return (f16_t)f;
+}
+AVSR_DEV short f2h_bits(float f) { return __builtin_bit_cast(short, f2h(f)); }
+
+// Storage-type traits: activations live in HBM either as bf16 (bench mode), as f16 (forward pass of the mixed mode) or
 // as f32 (parity mode, where GEMM operands are split into hi+lo bf16 halves).
 template <class T> struct Elem;
 template <> struct Elem<float> {
@@ -64,12 +83,21 @@ template <> struct Elem<bf16_t> {
     static AVSR_DEV float ld(const bf16_t* p) { return bf2f(*p); }
     static AVSR_DEV void st(bf16_t* p, float v) { *p = f2bf(v); }
 };
+template <> struct Elem<f16_t> {
+    static AVSR_DEV float ld(const f16_t* p) { return h2f(*p); }
+    static AVSR_DEV void st(f16_t* p, float v) { *p = f2h(v); }
+};
 
 // 8 consecutive elements -> 8 floats (16-byte / 32-byte vector loads)
 AVSR_DEV void load8(const bf16_t* p, float* out) {
     bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
 #pragma unroll
     for (int i = 0; i < 8; i++) out[i] = bf2f((bf16_t)v[i]);
+}
+AVSR_DEV void load8(const f16_t* p, float* out) {
+    f16x8 v = *reinterpret_cast<const f16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = (float)v[i];
 }
 AVSR_DEV void load8(const float* p, float* out) {
     f32x4 a = *reinterpret_cast<const f32x4*>(p);
@@ -85,6 +113,12 @@ AVSR_DEV void store8(bf16_t* p, const float* v) {
 #pragma unroll
     for (int i = 0; i < 8; i++) o[i] = (short)f2bf(v[i]);
     *reinterpret_cast<bf16x8*>(p) = o;
+}
+AVSR_DEV void store8(f16_t* p, const float* v) {
+    f16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o[i] = f2h(v[i]);
+    *reinterpret_cast<f16x8*>(p) = o;
 }
 AVSR_DEV void store8(float* p, const float* v) {
     f32x4 a, b;
@@ -332,6 +366,62 @@ AVSR_DEV f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a),
                                                    __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+#endif
+}
+
+// The f16 forms of the same two MFMAs (v_mfma_f32_32x32x16_f16 / v_mfma_f32_16x16x32_f16: identical shapes, lane layouts and
+// rate).  Fragments travel as raw 16-bit lanes (bf16x8) through LDS and registers -- staging is a byte copy either way -- so
+// FMT only selects the instruction: 0 = bf16, 1 = f16.
+template <int FMT> AVSR_DEV float raw16_to_f32(short bits) {
+    return FMT == 1 ? (float)__builtin_bit_cast(f16_t, bits) : bf2f((bf16_t)bits);
+}
+template <int FMT> AVSR_DEV short f32_to_raw16(float v) { return FMT == 1 ? f2h_bits(v) : (short)f2bf(v); }
+template <int FMT> AVSR_DEV f32x16 mfma32x(bf16x8 a, bf16x8 b, f32x16 c) {
+    if (FMT == 0) return mfma32(a, b, c);
+#ifdef AVSR_EMU
+    struct P { bf16x8 a, b; } mine{a, b};
+    size_t stride;
+    const unsigned char* all = emu::wave_gather(&mine, sizeof(P), &stride);
+    const int l = emu::lane_id();
+    const int j = l & 31;
+    for (int r = 0; r < 16; r++) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int kb = 0; kb < 2; kb++) {
+            P pa, pb;
+            memcpy(&pa, all + (size_t)(i + 32 * kb) * stride, sizeof(P));
+            memcpy(&pb, all + (size_t)(j + 32 * kb) * stride, sizeof(P));
+            for (int e = 0; e < 8; e++) acc += raw16_to_f32<1>(pa.a[e]) * raw16_to_f32<1>(pb.b[e]);
+        }
+        c[r] = acc;
+    }
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+#endif
+}
+template <int FMT> AVSR_DEV f32x4 mfma16x(bf16x8 a, bf16x8 b, f32x4 c) {
+    if (FMT == 0) return mfma16(a, b, c);
+#ifdef AVSR_EMU
+    struct P { bf16x8 a, b; } mine{a, b};
+    size_t stride;
+    const unsigned char* all = emu::wave_gather(&mine, sizeof(P), &stride);
+    const int l = emu::lane_id();
+    const int j = l & 15;
+    for (int r = 0; r < 4; r++) {
+        const int i = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int kb = 0; kb < 4; kb++) {
+            P pa, pb;
+            memcpy(&pa, all + (size_t)(i + 16 * kb) * stride, sizeof(P));
+            memcpy(&pb, all + (size_t)(j + 16 * kb) * stride, sizeof(P));
+            for (int e = 0; e < 8; e++) acc += raw16_to_f32<1>(pa.a[e]) * raw16_to_f32<1>(pb.b[e]);
+        }
+        c[r] = acc;
+    }
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 #endif
 }
 

@@ -18,30 +18,62 @@ import torch
 from . import ops
 from .ops import NN, NT, TN
 
-_state = {"precise": False, "hpf": False, "seed": 0x5EED, "counter": 0, "seed_dev": None, "bn_sync": None}
+_state = {"precise": False, "hpf": False, "mixed": False, "f16": False, "seed": 0x5EED, "counter": 0, "seed_dev": None,
+          "bn_sync": None}
+
+# "mixed" mode: forward arithmetic per component of the model ("f16": IEEE-half operands, one MFMA per product, bf16 speed;
+# "split": hi + lo bf16 planes, three MFMAs per product; "bf16").  Components not listed run "split".  The default is what
+# tools/precision_study.py (CPU, reference golden of the benchmarked batch) and tools/mixed_sweep.py (MI355X) selected: the
+# twelve Conformer blocks -- 2/3 of the forward contractions of the step outside the front-end -- generate 4.6e-4 of logits
+# error in f16 against 3-6e-3 in bf16, the front-end / heads / decoder stay on split planes.
+MIXED_POLICY = {"encoder": "f16"}
 
 
 def set_precise(flag: bool):
     _state["precise"] = bool(flag)
-    _state["hpf"] = False
+    _state["hpf"] = _state["mixed"] = _state["f16"] = False
+    ops.TWIN = None
 
 
 def set_mode(mode: str):
     """Numerical mode of the hot path:
-      "bf16"    -- bf16 activations / operands, f32 accumulation (the benchmarked mode);
+      "bf16"    -- bf16 activations / operands, f32 accumulation (the fastest mode);
       "precise" -- f32 activations, every contraction on split hi+lo bf16 planes (3 MFMAs per product), forward and backward;
       "hpf"     -- high-precision FORWARD: the forward pass of every autograd function runs exactly as in "precise" (so losses,
                    logits, CTC log-probabilities and decoding meet the 1e-3 parity bound against an fp32 reference), what it saves
                    for the backward pass is stored as bf16, and the backward pass runs exactly as in "bf16" (gradients of bf16
-                   quality at the bf16 cost)."""
-    assert mode in ("bf16", "precise", "hpf"), mode
+                   quality at the bf16 cost);
+      "mixed"   -- "hpf" with the forward arithmetic chosen per component (MIXED_POLICY): the Conformer encoder on IEEE-half
+                   operands (f16 activations between its kernels, v_mfma_f32_*_f16 -- the bf16 kernels' bytes and MFMA rate
+                   with 11 significant bits instead of 8), everything else on split planes; backward as in "bf16".  Meets the
+                   same 1e-3 bound (measured 5-6e-4 on the logits at the benchmarked shape) at a fraction of the hpf cost."""
+    assert mode in ("bf16", "precise", "hpf", "mixed"), mode
     _state["precise"] = mode != "bf16"
-    _state["hpf"] = mode == "hpf"
-    ops.TWIN = _make_twin if mode == "hpf" else None
+    _state["hpf"] = mode in ("hpf", "mixed")
+    _state["mixed"] = mode == "mixed"
+    _state["f16"] = False
+    ops.TWIN = _make_twin if _state["hpf"] else None
 
 
 def mode() -> str:
-    return "hpf" if _state["hpf"] else ("precise" if _state["precise"] else "bf16")
+    return "mixed" if _state["mixed"] else ("hpf" if _state["hpf"] else ("precise" if _state["precise"] else "bf16"))
+
+
+@contextlib.contextmanager
+def component(name):
+    """Scope of one model component (nets.py / frontend.py wrap their forward passes in it): in the "mixed" mode the forward
+    arithmetic inside is MIXED_POLICY[name] (default "split"); a no-op in every other mode and inside backward passes."""
+    if not _state["mixed"] or _state.get("in_bwd", False):
+        yield
+        return
+    fmt = MIXED_POLICY.get(name, "split")
+    assert fmt in ("f16", "split", "bf16"), fmt
+    old = (_state["precise"], _state["f16"])
+    _state["precise"], _state["f16"] = fmt == "split", fmt == "f16"
+    try:
+        yield
+    finally:
+        _state["precise"], _state["f16"] = old
 
 
 def _bwd_precise():
@@ -50,19 +82,19 @@ def _bwd_precise():
 
 
 def _bwd_mode(fn):
-    """Decorator of every autograd backward: in the "hpf" mode the backward pass runs in the bf16 mode."""
+    """Decorator of every autograd backward: in the "hpf" / "mixed" modes the backward pass runs in the bf16 mode."""
     import functools
 
     @functools.wraps(fn)
     def backward(ctx, *grads):
         if not _state["hpf"]:
             return fn(ctx, *grads)
-        old = _state["precise"]
-        _state["precise"] = False
+        old = (_state["precise"], _state["f16"], _state.get("in_bwd", False))
+        _state["precise"], _state["f16"], _state["in_bwd"] = False, False, True
         try:
             return fn(ctx, *grads)
         finally:
-            _state["precise"] = old
+            _state["precise"], _state["f16"], _state["in_bwd"] = old
 
     return backward
 
@@ -79,7 +111,7 @@ _TWIN_MIN = 1 << 15  # elements: below this a cast launch at save time costs not
 def _make_twin(y):
     # only in the forward pass of the hpf mode (the backward pass runs with precise = False), and only when the python-level
     # wrapper that started this sub-layer saw grad mode on (Function.forward itself always runs under no_grad)
-    if not (_state["hpf"] and _state["precise"] and _state.get("tag_ok", False)):
+    if not (_state["hpf"] and (_state["precise"] or _state["f16"]) and _state.get("tag_ok", False)):
         return None
     if y.numel() < _TWIN_MIN or not y.is_contiguous():
         return None
@@ -94,13 +126,28 @@ def _make_twin(y):
 def _A(t):
     """An ACTIVATION-dtype tensor on its way into save_for_backward: in the "hpf" mode (f32 forward, bf16 backward) the
     backward pass gets a bf16 copy; identity in the other modes."""
-    if t is None or not _state["hpf"] or t.dtype != torch.float32:
+    if t is None or not _state["hpf"] or t.dtype not in (torch.float32, torch.float16):
         return t
     ent = _twins.pop(t.data_ptr(), None) if t.is_contiguous() else None
     if ent is not None and ent[0].numel() == t.numel():  # (views of the producer's buffer: same bytes, another shape)
         _twin_stats["used"] += 1
         return ent[1].view(t.shape)
+    _twin_stats["cast"] = _twin_stats.get("cast", 0) + 1
     return ops.scale_dropout(t.contiguous(), torch.bfloat16)
+
+
+def _A_view(t, base):
+    """_A for a strided VIEW `t` of a producer's buffer `base` (a third of the fused Q/K/V projection, a layer's column block of
+    the all-layer position projection): the same view of base's bf16 twin -- no copy, no cast launch.  The twin stays registered
+    (several views of one base are saved)."""
+    if t is None or not _state["hpf"] or t.dtype not in (torch.float32, torch.float16):
+        return t
+    ent = _twins.get(base.data_ptr())
+    if ent is None or ent[0].numel() != base.numel() or t.dtype != base.dtype:
+        return _A(t)
+    off = (t.data_ptr() - base.data_ptr()) // t.element_size()
+    _twin_stats["used"] += 1
+    return ent[1].as_strided(t.shape, t.stride(), ent[1].storage_offset() + off)
 
 
 # hpf mode, front-end trunk: consecutive trunk functions hand their activation over as the bf16 TWIN (the autograd-visible
@@ -137,28 +184,36 @@ def is_precise() -> bool:
     return _state["precise"]
 
 
+def _save_mode():
+    return (_state["precise"], _state["hpf"], _state["mixed"], _state["f16"], ops.TWIN)
+
+
+def _restore_mode(saved):
+    _state["precise"], _state["hpf"], _state["mixed"], _state["f16"], ops.TWIN = saved
+
+
 @contextlib.contextmanager
 def precise(flag=True):
-    old = (_state["precise"], _state["hpf"])
-    _state["precise"], _state["hpf"] = bool(flag), False
+    old = _save_mode()
+    set_precise(flag)
     try:
         yield
     finally:
-        _state["precise"], _state["hpf"] = old
+        _restore_mode(old)
 
 
 @contextlib.contextmanager
 def numerics(mode_name):
-    old = (_state["precise"], _state["hpf"])
+    old = _save_mode()
     set_mode(mode_name)
     try:
         yield
     finally:
-        _state["precise"], _state["hpf"] = old
+        _restore_mode(old)
 
 
 def act_dtype():
-    return torch.float32 if _state["precise"] else torch.bfloat16
+    return torch.float32 if _state["precise"] else (torch.float16 if _state["f16"] else torch.bfloat16)
 
 
 def manual_seed(seed: int):
@@ -218,7 +273,10 @@ _wconv = {}    # (data_ptr, to_dgrad, shape) -> [version, bf16 permuted copy, co
 _wconv_table = {"n": 0, "dev": None, "blocks": 0, "built_for": -1}
 
 
-_wgen = {"cleared": 0, "owner": None, "owner_gen": None, "dirty": 0}
+# "gen": bumped whenever weights change behind the tensor version counter (note_optimizer_step); the side caches that only
+# some numerical modes refresh (split8 planes, f16 copies) remember the generation they were last brought up to date at and
+# re-pack lazily on their next use -- a bf16-mode refresh in between must not make them look fresh (round-3 advisor finding)
+_wgen = {"cleared": 0, "owner": None, "owner_gen": None, "dirty": 0, "gen": 0, "split_gen": 0, "h16_gen": 0}
 
 # ---- pre-split weights of the precise / hpf forward pass (csrc/gemm_split.hip, split8 layout) ---------------------------------
 # The B operand of every forward contraction is a parameter: its hi / lo bf16 planes are formed once per step (ONE multi-tensor
@@ -231,6 +289,7 @@ _wsplit_table = {"n": 0, "dev": None, "blocks": 0, "built_for": -1}
 
 
 def _refresh_split_weights():
+    _wgen["split_gen"] = _wgen["gen"]
     for ent in _wsplit_conv.values():
         ops.conv_weight_permute_split(ent[2], out=ent[1])
         ent[0] = ent[2]._version
@@ -258,6 +317,8 @@ def _w_split(w2d):
         return None
     if _wgen["dirty"]:
         refresh_weight_cache()
+    if _wgen["split_gen"] != _wgen["gen"]:
+        _refresh_split_weights()
     key = (w2d.data_ptr(), tuple(w2d.shape))
     ent = _wsplit.get(key)
     if ent is not None and ent[0] == w2d._version:
@@ -277,6 +338,8 @@ def _w_conv_split(w):
         return None
     if _wgen["dirty"]:
         refresh_weight_cache()
+    if _wgen["split_gen"] != _wgen["gen"]:
+        _refresh_split_weights()
     key = (w.data_ptr(), tuple(w.shape))
     ent = _wsplit_conv.get(key)
     if ent is not None and ent[0] == w._version:
@@ -287,6 +350,73 @@ def _w_conv_split(w):
         ops.conv_weight_permute_split(w, out=ent[1])
     ent[0] = w._version
     return ent[1]
+
+
+# ---- f16 forward copies of Linear-type weights (mixed mode, csrc/gemm_fast.hip with F16 = 1) ---------------------------------------
+# [out][in] IEEE-half copies, refreshed by ONE multi-tensor launch per step (avsr_multi_cast_transpose, dst dtype 2); several
+# weights may be rows of one concatenated buffer (the fused Q/K/V and all-layer position projections).
+_wh16 = {}       # (data_ptr, shape) -> [version, f16 copy (possibly a row slice of a concatenation), weight]
+_wh16_cat = {}   # (data_ptrs...) -> concatenated f16 buffer
+_wh16_table = {"n": 0, "dev": None, "blocks": 0, "built_for": -1}
+
+
+def _refresh_h16_weights():
+    _wgen["h16_gen"] = _wgen["gen"]
+    if not _wh16:
+        return
+    if _wh16_table["built_for"] != len(_wh16):
+        import struct
+
+        blob, blk = b"", 0
+        for (ptr, shape), ent in _wh16.items():
+            R, C = shape
+            tiles_c, tiles_r = (C + 63) // 64, (R + 63) // 64
+            blob += struct.pack("<QQQiiiiiiii", ent[2].data_ptr(), ent[1].data_ptr(), 0, R, C, 0, blk, tiles_c, 0, 2, 0)
+            blk += tiles_r * tiles_c
+        dev = next(iter(_wh16.values()))[2].device
+        host = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+        _wh16_table.update(n=len(_wh16), dev=host.to(dev), blocks=blk, built_for=len(_wh16))
+    ops.multi_cast_transpose(_wh16_table["dev"], _wh16_table["n"], _wh16_table["blocks"])
+    for ent in _wh16.values():
+        ent[0] = ent[2]._version
+
+
+def _w_h16(w2d):
+    """f16 copy of a Linear-type weight [out, in]."""
+    if _wgen["dirty"]:
+        refresh_weight_cache()
+    if _wgen["h16_gen"] != _wgen["gen"]:
+        _refresh_h16_weights()
+    key = (w2d.data_ptr(), tuple(w2d.shape))
+    ent = _wh16.get(key)
+    if ent is not None and ent[0] == w2d._version:
+        return ent[1]
+    if ent is None:
+        ent = _wh16[key] = [-1, torch.empty(w2d.shape, dtype=torch.float16, device=w2d.device), w2d]
+        _wh16_table["built_for"] = -1
+    ops.cast_into(w2d.contiguous(), ent[1])
+    ent[0] = w2d._version
+    return ent[1]
+
+
+def _w_h16_cat(ws):
+    """f16 copy of the row-concatenation of several [out_i, K] weights: [sum out_i, K]; the slices are registered in the f16
+    cache, so the per-step refresh keeps the concatenation current."""
+    key = tuple(w.data_ptr() for w in ws)
+    buf = _wh16_cat.get(key)
+    if buf is None:
+        K = ws[0].shape[1]
+        assert all(w.shape[1] == K and w.dtype == torch.float32 and w.is_contiguous() for w in ws)
+        buf = torch.empty(sum(w.shape[0] for w in ws), K, dtype=torch.float16, device=ws[0].device)
+        off = 0
+        for w in ws:
+            _wh16[(w.data_ptr(), tuple(w.shape))] = [-1, buf[off:off + w.shape[0]], w]
+            off += w.shape[0]
+        _wh16_cat[key] = buf
+        _wh16_table["built_for"] = -1
+    for w in ws:
+        _w_h16(w)  # (re-casts a slice whose weight changed version; everything after an optimizer step)
+    return buf
 
 
 def cached_weight_ptrs():
@@ -300,6 +430,7 @@ def note_optimizer_step(linear_copies_rewritten: bool):
     one at the start of a training step, or the implicit one on the first weight access of a forward pass (eval / decoding
     after native training) -- brings them up to date."""
     _wgen["dirty"] = max(_wgen["dirty"], 1 if linear_copies_rewritten else 2)
+    _wgen["gen"] += 1
 
 
 def _cast_generation():
@@ -339,6 +470,9 @@ def invalidate_weight_cache():
     _wsplit.clear()
     _wsplit_conv.clear()
     _wsplit_table.update(n=0, dev=None, blocks=0, built_for=-1)
+    _wh16.clear()
+    _wh16_cat.clear()
+    _wh16_table.update(n=0, dev=None, blocks=0, built_for=-1)
     _wgen["cleared"] += 1
     _wgen["owner"] = None
     _wgen["dirty"] = 0
@@ -406,8 +540,10 @@ def refresh_weight_cache(force=False):
     load_state_dict -- detected through the tensor version in _w_bf16)."""
     dirty, _wgen["dirty"] = _wgen["dirty"], 0
     _refresh_conv_weights()
-    if _state["precise"] and (_wsplit or _wsplit_conv):
+    if (_state["precise"] or _state["hpf"]) and (_wsplit or _wsplit_conv):
         _refresh_split_weights()
+    if _state["mixed"] and _wh16:
+        _refresh_h16_weights()
     if not _wcache:
         return
     owner = _wgen["owner"]() if _wgen["owner"] is not None else None
@@ -508,7 +644,7 @@ def prepare_pos_proj(pos_emb, weights):
     if D % 64 or any(w.dtype != torch.float32 or not w.is_contiguous() or tuple(w.shape) != (D, D) for w in weights):
         return
     pe = _to_act_shared(pos_emb).reshape(-1, D)
-    if pe.dtype != torch.bfloat16:
+    if pe.dtype not in (torch.bfloat16, torch.float16):
         return
     n, P = len(weights), pe.shape[0]
     if torch.is_grad_enabled() and all(w.requires_grad for w in weights):
@@ -518,8 +654,11 @@ def prepare_pos_proj(pos_emb, weights):
         for i, w in enumerate(weights):
             _pos_proj[(pos_emb.data_ptr(), w.data_ptr())] = (pos_emb, None, out, i, holder)
         return
-    out = torch.empty(P, n * D, dtype=torch.bfloat16, device=pe.device)
-    ops.gemm_bf16_nt(pe, D, _w_bf16_cat(tuple(weights), False), D, P, n * D, D, out, n * D)
+    out = torch.empty(P, n * D, dtype=pe.dtype, device=pe.device)
+    if pe.dtype == torch.float16:
+        ops.gemm_h16_nt(pe, D, _w_h16_cat(tuple(weights)), D, P, n * D, D, out, n * D)
+    else:
+        ops.gemm_bf16_nt(pe, D, _w_bf16_cat(tuple(weights), False), D, P, n * D, D, out, n * D)
     for i, w in enumerate(weights):
         _pos_proj[(pos_emb.data_ptr(), w.data_ptr())] = (pos_emb, out[:, i * D:(i + 1) * D], None, i, None)
 
@@ -547,9 +686,12 @@ class PosProjFn(torch.autograd.Function):
         D = pos_emb.shape[-1]
         pe = _to_act_shared(pos_emb).reshape(-1, D)
         n, P = len(weights), pe.shape[0]
-        out = torch.empty(P, n * D, dtype=torch.bfloat16, device=pe.device)
-        ops.gemm_bf16_nt(pe, D, _w_bf16_cat(tuple(weights), False), D, P, n * D, D, out, n * D)
-        ctx.save_for_backward(pe)
+        out = torch.empty(P, n * D, dtype=pe.dtype, device=pe.device)
+        if pe.dtype == torch.float16:  # mixed mode: f16 projection + its bf16 twin (the layers' backward passes read views of it)
+            ops.gemm_h16_nt(pe, D, _w_h16_cat(tuple(weights)), D, P, n * D, D, out, n * D, twin=True)
+        else:
+            ops.gemm_bf16_nt(pe, D, _w_bf16_cat(tuple(weights), False), D, P, n * D, D, out, n * D)
+        ctx.save_for_backward(_A_shared(pe))
         ctx.holder, ctx.meta = holder, (P, D, n)
         return out
 
@@ -577,6 +719,11 @@ def _gemm_nt(a, w, M, N, K, out, *, lda=None, ldc=None, twin=False, **kw):
     mode the kernel also writes its bf16 copy (picked up by _A)."""
     if _fast_ok(a, K, lda) and w.dim() == 2 and w.dtype == torch.float32 and w.is_contiguous():
         return ops.gemm_bf16_nt(a, lda or K, _w_bf16(w, False), K, M, N, K, out, ldc or N, **kw)
+    if _state["f16"] and a.dtype == torch.float16:
+        # mixed mode, f16 component: the tuned tile kernel on IEEE-half operands (+ the bf16 twin of an activation output)
+        assert K % 64 == 0 and (lda or K) % 8 == 0 and w.dim() == 2 and w.dtype == torch.float32 and w.is_contiguous(), \
+            "f16 forward GEMM: K % 64 == 0 and a dense f32 weight required"
+        return ops.gemm_h16_nt(a, lda or K, _w_h16(w), K, M, N, K, out, ldc or N, twin=twin, **kw)
     if _state["precise"] and ops.SPLIT_FAST and a.dtype == torch.float32 and w.dim() == 2 and w.dtype == torch.float32 \
             and w.is_contiguous() and K % 64 == 0 and (lda or K) % 4 == 0 and a.data_ptr() % 16 == 0:
         # precise / hpf forward: the same split-bf16 arithmetic on the LDS-DMA operand ring (csrc/gemm_split.hip)
@@ -838,7 +985,7 @@ def _to_act_shared(x):
 
 def _A_shared(t):
     """_A for a tensor that several sub-layers of one step save unchanged (encoder memory, position table)."""
-    if t is None or not _state["hpf"] or t.dtype != torch.float32:
+    if t is None or not _state["hpf"] or t.dtype not in (torch.float32, torch.float16):
         return t
     key = (t.data_ptr(), tuple(t.shape), "hpf-save", t._version)
     ent = _shared_act.get(key)
@@ -1257,13 +1404,17 @@ class MhaSublayerFn(torch.autograd.Function):
             Tk = ka.shape[1]
         # self attention in bf16: ONE projection GEMM onto the concatenated [Wq; Wk; Wv] (N = 3D fills the chip where
         # three N = D launches do not); q / k / v are column thirds of its output, read in place by the attention kernel
-        fused = _FUSE_QKV and (not cross) and (not _state["precise"]) and D % 64 == 0 and T == torch.bfloat16 \
+        fused = _FUSE_QKV and (not cross) and (not _state["precise"]) and D % 64 == 0 and T in (torch.bfloat16, torch.float16) \
             and all(w.dtype == torch.float32 and w.is_contiguous() for w in (wq, wk, wv))
         relpos = pos_emb is not None
+        qkv = None
         if fused:
             qkv = torch.empty(B * Tq, 3 * D, dtype=T, device=x.device)
-            ops.gemm_bf16_nt(h, D, _w_bf16_cat((wq, wk, wv), False), D, B * Tq, 3 * D, D, qkv, 3 * D,
-                             bias=_bias3(bq, bk, bv))
+            if T == torch.float16:
+                ops.gemm_h16_nt(h, D, _w_h16_cat((wq, wk, wv)), D, B * Tq, 3 * D, D, qkv, 3 * D, bias=_bias3(bq, bk, bv), twin=True)
+            else:
+                ops.gemm_bf16_nt(h, D, _w_bf16_cat((wq, wk, wv), False), D, B * Tq, 3 * D, D, qkv, 3 * D,
+                                 bias=_bias3(bq, bk, bv))
             q5 = qkv.view(B, Tq, 3, H, dk)
             q, k4, v4 = qkv, q5[:, :, 1], q5[:, :, 2]
             ldq = 3 * D
@@ -1299,11 +1450,16 @@ class MhaSublayerFn(torch.autograd.Function):
         po, so, sdo = _drop_args(p_out, x)
         y = torch.empty_like(x)
         _gemm_nt(ctxv, wo, B * Tq, D, D, y, bias=bo, drop_p=po, seed=so, seed_dev=sdo, resid=x, ldr=D)
+        if fused and qkv.dtype == torch.float16:  # thirds of the fused projection: the same views of its bf16 twin
+            s_qu, s_k, s_v = (_A(qu) if relpos else _A_view(qu, qkv)), _A_view(k4, qkv), _A_view(v4, qkv)
+        else:
+            s_qu, s_k, s_v = _A(qu), _A(k4), _A(v4)
+        s_pp = _A_view(pproj, pp_all) if (pp_all is not None and pproj is not None) else _A(pproj)
         ctx.save_for_backward(x, ln_w, mean, rstd, _A(h), _A_shared(ka) if (cross and not shared_kv) else None, _A_shared(pe), m,
-                              wq, wk, wv, wo, wpos, _A(qu), _A(qv), _A(k4), _A(v4), _A(pproj), _A(ctxv), lse)
+                              wq, wk, wv, wo, wpos, s_qu, _A(qv), s_k, s_v, s_pp, _A(ctxv), lse)
         ctx.meta = (H, pa, sa, sda, po, so, sdo, cross, relpos, fused)
         ctx.kv = (kv_slot, kv_holder, tuple(kv_all.shape)) if shared_kv else None
-        ctx.pp = (pp_slot, pp_holder, tuple(pp_all.shape)) if (relpos and pp_all is not None) else None
+        ctx.pp = (pp_slot, pp_holder, tuple(pp_all.shape), pp_all.dtype) if (relpos and pp_all is not None) else None
         _chain_tag(y, B * Tq, D, 1.0, (po, so, sdo))
         return y
 
@@ -1348,12 +1504,13 @@ class MhaSublayerFn(torch.autograd.Function):
         if ctx.pp is not None:
             # this layer's position gradient accumulates into its column block of ONE zero-filled buffer; the weight
             # gradients of all layers come from it in PosProjFn.backward
-            slot, holder, shape = ctx.pp
+            slot, holder, shape, pp_dtype = ctx.pp
             if holder.get("dpos") is None:
                 holder["dpos"] = _zeros(shape, x.device)
             outs = dict(outs, dpos_out=holder["dpos"][:, slot * D:(slot + 1) * D])
             holder["filled"] = holder.get("filled", 0) + 1
-            dpp_grad = _placeholder_grad(shape, T, x.device) if slot == 0 else None  # the f32 buffer travels in `holder`
+            # the f32 buffer travels in `holder`; the placeholder carries the dtype of the forward output (f16 in the mixed mode)
+            dpp_grad = _placeholder_grad(shape, pp_dtype, x.device) if slot == 0 else None
         du = dv_bias = dwpos = None
         if relpos:
             # the attention backward itself emits dq = dqu + dqv and the two position-bias gradients (their column sums)

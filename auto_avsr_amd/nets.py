@@ -343,17 +343,18 @@ class ConformerEncoder(nn.Module):
             self.after_norm = LayerNorm(attention_dim)
 
     def forward(self, xs, masks):
-        xs = self.embed(xs)
-        if isinstance(xs, tuple):
-            # the position table is batch-shared and identical for every layer: project it for all layers in ONE GEMM
-            # against the concatenated linear_pos weights (attention.py:170 runs linear_pos once per layer)
-            AF.prepare_pos_proj(xs[1], [layer.self_attn.linear_pos.weight for layer in self.encoders
-                                        if hasattr(layer.self_attn, "linear_pos")])
-        xs, masks = self.encoders(xs, masks)
-        if isinstance(xs, tuple):
-            xs = xs[0]
-        if self.normalize_before:
-            xs = self.after_norm(xs)
+        with AF.component("encoder"):  # (mixed numerical mode: the forward arithmetic of this component, AF.MIXED_POLICY)
+            xs = self.embed(xs)
+            if isinstance(xs, tuple):
+                # the position table is batch-shared and identical for every layer: project it for all layers in ONE GEMM
+                # against the concatenated linear_pos weights (attention.py:170 runs linear_pos once per layer)
+                AF.prepare_pos_proj(xs[1], [layer.self_attn.linear_pos.weight for layer in self.encoders
+                                            if hasattr(layer.self_attn, "linear_pos")])
+            xs, masks = self.encoders(xs, masks)
+            if isinstance(xs, tuple):
+                xs = xs[0]
+            if self.normalize_before:
+                xs = self.after_norm(xs)
         return xs, masks
 
     def forward_one_step(self, xs, masks, cache=None):

@@ -7,8 +7,8 @@ import torch
 
 from . import _lib
 
-F32, BF16 = 0, 1
-_DT = {torch.float32: F32, torch.bfloat16: BF16}
+F32, BF16, F16 = 0, 1, 2
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}  # f16: forward activations of the mixed mode only
 NT, NN, TN = 0, 1, 2
 
 
@@ -95,12 +95,13 @@ def paired():
         L.call("avsr_gemm_pair_end")
 
 
-TWIN = None  # functional.py ("hpf" mode): callable(f32 tensor) -> bf16 twin buffer to fill alongside it, or None
+TWIN = None  # functional.py ("hpf" / "mixed" modes): callable(f32 / f16 tensor) -> bf16 twin buffer to fill alongside it, or None
 
 
 def _twin(y):
-    """bf16 twin buffer for an f32 result `y` when the hpf mode wants one (the backward pass reads the twin)."""
-    return TWIN(y) if (TWIN is not None and y.dtype == torch.float32) else None
+    """bf16 twin buffer for an f32 (split-plane forward) or f16 (mixed mode) result `y` when the mode wants one (the bf16
+    backward pass reads the twin)."""
+    return TWIN(y) if (TWIN is not None and y.dtype in (torch.float32, torch.float16)) else None
 
 
 def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-12, twin=False):
@@ -109,6 +110,10 @@ def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-12, twin=False):
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
     y2 = _twin(y) if twin else None
+    if out_dtype == torch.float16:
+        call("avsr_layernorm_fwd_h16", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(y2), _ptr(mean), _ptr(rstd), rows, cols, eps,
+             _stream(x), nbytes=_nb(x, y, y2))
+        return y, mean, rstd
     if y2 is not None:
         call("avsr_layernorm_fwd2", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(y2), _ptr(mean), _ptr(rstd), rows, cols, eps,
              _stream(x), nbytes=_nb(x, y, y2))
@@ -151,6 +156,12 @@ def attention_fwd(qu, qv, k, v, pos, mask, scale, *, precise=False, drop_p=0.0, 
         assert mask.dtype in (torch.uint8, torch.bool) and mask.is_contiguous() and mask.dim() == 3
         msb = mask.shape[1] * mask.shape[2] if mask.shape[0] > 1 else 0  # a batch-1 mask is shared by every sequence
         msq = mask.shape[2] if mask.shape[1] > 1 else 0
+    if qu.dtype == torch.float16:  # mixed mode: f16 operands on the transposed-formulation kernel + bf16 twin of the output
+        out2 = _twin(out)
+        call("avsr_attention_fwd_h16", _ptr(qu), _ptr(qv), _ptr(k), _ptr(v), _ptr(pos), _ptr(mask), msb, msq, _ptr(out), _ptr(out2),
+             _ptr(lse), B, H, Tq, Tk, dk, qu.stride(1), k.stride(1), v.stride(1), pos.stride(0) if pos is not None else 0,
+             out.stride(1), qu.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, drop_p, seed, _ptr(seed_dev), _stream(qu))
+        return out, lse
     out2 = _twin(out) if (precise and out.dtype == torch.float32) else None
     if out2 is not None:  # f32 forward + the bf16 twin of its output in one pass ("hpf" mode)
         call("avsr_attention_fwd2", _ptr(qu), _ptr(qv), _ptr(k), _ptr(v), _ptr(pos), _ptr(mask), msb, msq, _ptr(out), _ptr(out2),
@@ -248,6 +259,9 @@ def head_bias_fwd(x, ldx, rows, cols, b1, b2):
     o2 = torch.empty(rows, cols, dtype=x.dtype, device=x.device)
     t1 = _twin(o1)
     t2 = _twin(o2) if t1 is not None else None
+    if x.dtype == torch.float16:
+        call("avsr_head_bias_fwd_h16", _ptr(x), ldx, _ptr(b1), _ptr(b2), _ptr(o1), _ptr(o2), _ptr(t1), _ptr(t2), rows, cols, _stream(x))
+        return o1, o2
     if t2 is not None:
         call("avsr_head_bias_fwd2", _ptr(x), ldx, _ptr(b1), _ptr(b2), _ptr(o1), _ptr(o2), _ptr(t1), _ptr(t2), rows, cols, _stream(x))
         return o1, o2
@@ -282,6 +296,11 @@ def dwconv(x, w, bias, B, T, C, K, flip=False, glu_in=False, glu_a=None):
     through the GLU backward of glu_a = [a | g] -> returns da [B*T, 2C]."""
     y = torch.empty(B, T, 2 * C if glu_a is not None else C, dtype=x.dtype, device=x.device)
     y2 = _twin(y) if (glu_a is None and not flip) else None
+    if x.dtype == torch.float16:
+        assert glu_a is None and not flip, "f16 depthwise convolution: forward only"
+        call("avsr_dwconv_fwd_h16", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(y2), B, T, C, K, int(glu_in), _stream(x),
+             nbytes=_nb(x, y, y2))
+        return y
     if y2 is not None:  # f32 forward + the bf16 twin of its output ("hpf" mode)
         call("avsr_dwconv_fwd2", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(y2), B, T, C, K, int(glu_in), _stream(x),
              nbytes=_nb(x, y, y2))
@@ -324,6 +343,11 @@ def bn_small_fwd(x, rows, C, gamma, beta, eps, momentum, running_mean, running_v
     invstd = torch.empty(C, dtype=torch.float32, device=x.device)
     y = torch.empty(rows, C, dtype=x.dtype, device=x.device)
     y2 = _twin(y)
+    if x.dtype == torch.float16:
+        call("avsr_bn_small_fwd_h16", _ptr(x), rows, C, _ptr(gamma), _ptr(beta), eps, momentum, _ptr(running_mean),
+             _ptr(running_var), _ptr(num_batches_tracked), act, _ptr(y), _ptr(y2), _ptr(mean), _ptr(invstd), _stream(x),
+             nbytes=2.0 * _nb(x) + _nb(y2))
+        return y, mean, invstd
     if y2 is not None:
         call("avsr_bn_small_fwd2", _ptr(x), rows, C, _ptr(gamma), _ptr(beta), eps, momentum, _ptr(running_mean),
              _ptr(running_var), _ptr(num_batches_tracked), act, _ptr(y), _ptr(y2), _ptr(mean), _ptr(invstd), _stream(x),
@@ -367,6 +391,12 @@ def bn_eval_params(running_mean, running_var, eps):
 
 def bn_act_fwd(x, add, mean, invstd, gamma, beta, rows, C, act):
     y = torch.empty_like(x)
+    if x.dtype == torch.float16:
+        assert add is None or add.dtype == torch.float16
+        y2 = _twin(y)
+        call("avsr_bn_act_fwd_h16", _ptr(x), _ptr(add), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(y2), rows, C,
+             act, _stream(x), nbytes=_nb(x, add, y, y2))
+        return y
     y2 = _twin(y) if (add is None or add.dtype == torch.float32) else None
     if y2 is not None:
         call("avsr_bn_act_fwd2", _ptr(x), _ptr(add), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(y2), rows, C,
@@ -689,6 +719,20 @@ def gemm_f32s_nt(A, lda, B, ldb, M, N, K, C, ldc, *, bias=None, act=0, gate=None
          _ptr(resid), dt(resid) if resid is not None else 0, ldr, _ptr(C), dt(C), ldc, int(accumulate), split_k, tile,
          _ptr(colsum), int(isinstance(B, Split8)), _ptr(c2), ldc, _stream(A), flops=2.0 * M * N * K,
          nbytes=4.0 * (M * K + N * K) + float(M * N * C.element_size()) + (float(M * N * resid.element_size()) if resid is not None else 0.0))
+    return C
+
+
+def gemm_h16_nt(A, lda, B, ldb, M, N, K, C, ldc, *, bias=None, act=0, drop_p=0.0, seed=0, seed_dev=None, alpha=1.0,
+                resid=None, ldr=0, tile=0, twin=False):
+    """Mixed-mode forward NT GEMM (csrc/gemm_fast.hip, F16 = 1): A and B IEEE half, C f32 / bf16 / f16; twin: a dense f16 / f32
+    activation output also leaves as its bf16 twin (same pitch) for the backward pass."""
+    assert A.dtype == torch.float16 and B.dtype == torch.float16
+    c2 = _twin(C) if (twin and C.dtype in (torch.float16, torch.float32) and C.dim() == 2 and C.stride(0) == ldc and C.is_contiguous()) else None
+    call("avsr_gemm_h16_nt", _ptr(A), lda, _ptr(B), ldb, M, N, K, _ptr(bias), act, drop_p, seed, _ptr(seed_dev), alpha,
+         _ptr(resid), dt(resid) if resid is not None else 0, ldr, _ptr(C), dt(C), ldc, tile, _ptr(c2), ldc, _stream(A),
+         flops=2.0 * M * N * K,
+         nbytes=2.0 * (M * K + N * K) + float(M * N * C.element_size()) + (float(M * N * resid.element_size()) if resid is not None else 0.0)
+         + (2.0 * M * N if c2 is not None else 0.0))
     return C
 
 

@@ -8,7 +8,7 @@
  *   - plain pointers + sizes, caller-owned device buffers, no allocation, no
  *     synchronisation; work is enqueued on `stream`;
  *   - return 0 on success, non-zero on error (avsr_last_error() has the text);
- *   - dtype codes: 0 = float32, 1 = bfloat16 (raw 16-bit);
+ *   - dtype codes: 0 = float32, 1 = bfloat16 (raw 16-bit), 2 = IEEE float16 (forward activations of the mixed mode only);
  *   - row-major tensors; "ld" arguments are leading dimensions in elements.
  */
 #ifndef AVSR_HIP_H
@@ -473,6 +473,39 @@ int avsr_audio_transform(const int64_t* wav_ptr, const int32_t* lens, const int3
                          const int32_t* niv, int max_iv, const float* noise, const int64_t* noise_start,
                          const float* snr_db, float eps, float* out, int B, int64_t Lmax, void* workspace,
                          avsr_stream_t stream);
+
+/* ---- "mixed" numerical mode: f16 forward operands of the Conformer encoder -------------------------------------------------
+ * The north star bounds logits / CTC log-probabilities at 1e-3 relative to the fp32 reference; with bf16 operands (8
+ * significant bits) the 12-layer encoder alone generates 3-6e-3, with IEEE half (11 bits, the same 2 bytes and the same MFMA
+ * rate: v_mfma_f32_32x32x16_f16 / v_mfma_f32_16x16x32_f16) 4.6e-4 (tools/precision_study.py).  These entry points are the
+ * forward kernels of the encoder sub-layers on f16 activations; each can write the bf16 twin of its result in the same pass,
+ * which is what the (unchanged, bf16) backward pass reads.  Replaced reference lines as for the bf16 entry points:
+ * layer_norm.py:12-33; positionwise_feed_forward.py:24-30, attention.py:31-34,123, conformer_encoder.py:24,27 (Linear /
+ * pointwise conv forward); attention.py:59-88,153-193 (fused attention forward); attention.py:176-178 (q + pos_bias_u / v);
+ * conformer_encoder.py:25,32,33 (GLU + depthwise conv); conformer_encoder.py:26,33-34 (BatchNorm1d + Swish). */
+int avsr_layernorm_fwd_h16(const float* x, const float* gamma, const float* beta, void* y, void* y2, float* mean, float* rstd,
+                           int rows, int cols, float eps, avsr_stream_t stream);
+/* C[M,N] = epi(A[M,K] . B[N,K]^T), A and B f16 k-contiguous (lda, ldb % 8 == 0), K % 64 == 0; epilogue +bias -> act -> dropout
+ * -> *alpha -> +resid; C f32 / bf16 / f16 (c_dtype 0 / 1 / 2); c2 (may be NULL): bf16 twin of an f32 / f16 C, row pitch ldc2;
+ * tile: 0 auto, 1 = 64x64, 4 = 128x128, 7 = 128x64 */
+int avsr_gemm_h16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias, int act,
+                     float drop_p, uint64_t seed, const uint64_t* seed_dev, float alpha, const void* resid, int resid_dtype,
+                     int ldr, void* C, int c_dtype, int ldc, int tile, void* c2, int ldc2, avsr_stream_t stream);
+int avsr_head_bias_fwd_h16(const void* x, int64_t ldx, const float* b1, const float* b2, void* o1, void* o2, void* t1, void* t2,
+                           int64_t rows, int cols, avsr_stream_t stream);
+/* arguments as avsr_attention_fwd2; q / k / v / pos / out are f16, out2 (may be NULL) the bf16 twin of out */
+int avsr_attention_fwd_h16(const void* qu, const void* qv, const void* k, const void* v, const void* pos, const uint8_t* mask,
+                           int64_t mask_sb, int64_t mask_sq, void* out, void* out2, float* lse, int B, int H, int Tq, int Tk,
+                           int dk, int ldq, int ldk, int ldv, int ldp, int ldo, int64_t sbq, int64_t sbk, int64_t sbv,
+                           int64_t sbo, float scale, float drop_p, uint64_t seed, const uint64_t* seed_dev,
+                           avsr_stream_t stream);
+int avsr_dwconv_fwd_h16(const void* x, const float* w, const float* bias, void* y, void* y2, int B, int T, int C, int K,
+                        int glu_in, avsr_stream_t stream);
+int avsr_bn_act_fwd_h16(const void* x, const void* add, const float* mean, const float* invstd, const float* gamma,
+                        const float* beta, void* y, void* y2, int64_t rows, int C, int act, avsr_stream_t stream);
+int avsr_bn_small_fwd_h16(const void* x, int64_t rows, int C, const float* gamma, const float* beta, float eps, float momentum,
+                          float* running_mean, float* running_var, int64_t* num_batches_tracked, int act, void* y, void* y2,
+                          float* mean, float* invstd, avsr_stream_t stream);
 
 #ifdef __cplusplus
 }

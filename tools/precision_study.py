@@ -1,0 +1,215 @@
+"""CPU study (no GPU): where does the 16-bit forward lose its accuracy, and which operand format buys it back?
+
+Runs the fp32 oracle (oracle/avsr_oracle.py) on the benchmarked batch A with the operands of chosen contraction groups
+rounded to a 16-bit format before every product -- bf16 (8 significant bits, what the bf16 mode feeds the MFMA), f16 (11
+bits) -- and compares decoder logits / CTC log-probabilities / encoder output with the REFERENCE numbers of
+tests/golden/golden_bench_v1.pt exactly as tests/test_bench_parity.py does.  Accumulation stays f32 (as on the MFMA).
+
+    python tools/precision_study.py                # the table of DESIGN.md section 2 (a few minutes on 8 cores)
+    python tools/precision_study.py --config enc_ffn=f16,trunk=bf16
+
+Measurement script: imports oracle/ (allowed for tools, like tools/microbench_augment.py --cpu); never shipped."""
+import argparse
+import os
+import sys
+import time
+import types
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+from oracle import avsr_oracle as O  # noqa: E402
+from bench_common import BATCHES, FIXTURE, ODIM, bench_batch, bench_state_dict, rel  # noqa: E402
+
+GROUPS = ["stem", "trunk", "trunk1", "trunk2", "trunk3", "trunk4", "proj", "enc_ffn", "enc_attn_proj", "enc_attn_core", "enc_conv", "ctc_head", "dec", "dec_out"]
+CFG = {}
+STATS = {}
+
+
+def q(x, fmt, is_w=False):
+    if fmt == "f16a":
+        fmt = None if is_w else "f16"
+    if fmt == "f16w":
+        fmt = "f16" if is_w else None
+    if fmt == "bf16":
+        return x.bfloat16().float()
+    if fmt == "f16":
+        return x.half().float()
+    return x
+
+
+def group_of(pre):
+    if pre.startswith("proj_encoder"):
+        return "proj"
+    if pre.startswith("ctc."):
+        return "ctc_head"
+    if pre.startswith("decoder.output_layer"):
+        return "dec_out"
+    if pre.startswith("decoder."):
+        return "dec"
+    if ".feed_forward" in pre:
+        return "enc_ffn"
+    if ".self_attn." in pre:
+        return "enc_attn_proj"
+    if ".conv_module." in pre:
+        return "enc_conv"
+    return None
+
+
+_scope = [None]
+
+
+def note(group, x):
+    m = float(x.abs().max())
+    STATS[group] = max(STATS.get(group, 0.0), m)
+
+
+def linear(sd, pre, x):
+    g = group_of(pre)
+    fmt = CFG.get(g)
+    note(g, x)
+    return F.linear(q(x, fmt), q(sd[pre + "weight"], fmt, True), sd.get(pre + "bias"))
+
+
+class FShim(types.SimpleNamespace):
+    """torch.nn.functional as seen by the oracle: convolutions and the position projection round their operands."""
+
+    def __getattr__(self, name):
+        return getattr(F, name)
+
+    @staticmethod
+    def _conv(fn, x, w, b=None, **kw):
+        g = _scope[0]
+        fmt = CFG.get(g)
+        note(g, x)
+        return fn(q(x, fmt), q(w, fmt, True), b, **kw)
+
+    def conv1d(self, x, w, b=None, **kw):
+        return self._conv(F.conv1d, x, w, b, **kw)
+
+    def conv2d(self, x, w, b=None, **kw):
+        return self._conv(F.conv2d, x, w, b, **kw)
+
+    def conv3d(self, x, w, b=None, **kw):
+        return self._conv(F.conv3d, x, w, b, **kw)
+
+    def linear(self, x, w, b=None):  # only linear_pos goes through F.linear directly
+        fmt = CFG.get("enc_attn_proj")
+        return F.linear(q(x, fmt), q(w, fmt), b)
+
+
+class TorchShim:
+    def __getattr__(self, name):
+        return getattr(torch, name)
+
+    @staticmethod
+    def matmul(a, b):
+        g = _scope[0]
+        fmt = CFG.get(g)
+        return torch.matmul(q(a, fmt), q(b, fmt))
+
+
+def scoped(fn, group):
+    def wrapper(*a, **kw):
+        old = _scope[0]
+        _scope[0] = group
+        try:
+            return fn(*a, **kw)
+        finally:
+            _scope[0] = old
+    return wrapper
+
+
+def install():
+    O.linear = linear
+    O.F = FShim()
+    O.torch = TorchShim()
+    O.conv_module = scoped(O.conv_module, "enc_conv")
+    O.rel_mha = scoped(O.rel_mha, "enc_attn_core")
+    O.mha = scoped(O.mha, "dec")
+    orig_vf = O.video_frontend
+
+    def video_frontend(sd, pre, x, train_bn=True):
+        B, T = x.shape[0], x.shape[1]
+        _scope[0] = "stem"
+        y = x.transpose(1, 2)
+        y = O.F.conv3d(y, sd[pre + "frontend3D.0.weight"], stride=(1, 2, 2), padding=(2, 3, 3))
+        y = F.silu(O.batch_norm(sd, pre + "frontend3D.1.", y, train_bn))
+        y = F.max_pool3d(y, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+        y = y.transpose(1, 2).reshape(B * T, y.shape[1], y.shape[3], y.shape[4])
+        for li in range(1, 5):
+            _scope[0] = f"trunk{li}" if f"trunk{li}" in CFG else "trunk"
+            for bi in range(2):
+                stride = 2 if (li > 1 and bi == 0) else 1
+                y = O.basic_block(sd, f"{pre}trunk.layer{li}.{bi}.", y, stride, train_bn)
+        _scope[0] = None
+        return y.mean(dim=(2, 3)).view(B, T, -1)
+
+    O.video_frontend = video_frontend
+    del orig_vf
+
+
+def run(case, sd, batch, layer_probe=None):
+    x, lengths, y = batch
+    STATS.clear()
+    with torch.no_grad():
+        (loss, loss_ctc, loss_att, acc), mid = O.e2e_forward(sd, x, lengths, y)
+        ctc = O.linear(sd, "ctc.ctc_lo.", mid["enc"])
+    vcols, tsel = case["vcols"], case["tsel"]
+    out = dict(loss=abs(float(loss) - case["loss"]) / abs(case["loss"]),
+               ctc=abs(float(loss_ctc) - case["loss_ctc"]) / abs(case["loss_ctc"]),
+               att=abs(float(loss_att) - case["loss_att"]) / abs(case["loss_att"]),
+               dec_logits=rel(mid["pred"][:, :, vcols], case["dec_logits"]),
+               ctc_logp=rel(torch.log_softmax(ctc, -1)[:, tsel][:, :, vcols], case["ctc_logp"]),
+               enc=rel(mid["enc"][:, tsel, :32], case["enc"]), acc=acc)
+    return out, mid
+
+
+def parse(spec):
+    cfg = {}
+    for item in spec.split(","):
+        if not item:
+            continue
+        k, v = item.split("=")
+        if k == "all":
+            for g in GROUPS:
+                if not g[-1].isdigit():  # trunk1..4 refine "trunk" only when named explicitly
+                    cfg[g] = v
+        else:
+            assert k in GROUPS, k
+            cfg[k] = v
+    return cfg
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", action="append", default=None)
+    ap.add_argument("--batch", default="A")
+    args = ap.parse_args()
+    torch.set_num_threads(os.cpu_count() or 8)
+    install()
+    fx = torch.load(FIXTURE, weights_only=False)
+    case = fx[args.batch]
+    cfgb = BATCHES[args.batch]
+    sys.path.insert(0, ROOT)
+    from tests.golden.synth import synth_state_dict  # noqa: F401,E402
+    import json
+    tmpl_path = os.path.join(ROOT, "tests", "golden", "golden_v1.pt")
+    # the template state dict (names + shapes) comes from the product's module tree -- no GPU needed to build it
+    from auto_avsr_amd.e2e import E2E
+    m = E2E(ODIM, "video")
+    sd = bench_state_dict(m.state_dict(), cfgb["seed"])
+    batch = bench_batch(cfgb["lengths"], cfgb["L"], cfgb["seed"])
+    specs = args.config or ["", "all=bf16", "all=f16"] + [f"all=bf16,{g}=f32" for g in GROUPS] + \
+        [f"{g}=bf16" for g in GROUPS] + [f"{g}=f16" for g in GROUPS]
+    for spec in specs:
+        CFG.clear()
+        CFG.update(parse(spec))
+        t0 = time.time()
+        out, _ = run(case, sd, batch)
+        print(json.dumps({"config": spec or "f32", **{k: (round(v, 8) if isinstance(v, float) else v) for k, v in out.items()},
+                          "absmax": {k: round(v, 1) for k, v in STATS.items() if k}, "s": round(time.time() - t0, 1)}), flush=True)
