@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void weight_permute_split_kernel(const float* 
 struct AvsrPermEntry {
     const float* w;
     bf16_t* out;
-    int Cout, Cin, taps, to_dgrad, blk0, pad0, pad1, pad2;
+    int Cout, Cin, taps, to_dgrad, blk0, pad0, pad1, pad2;  // pad0 = 2: `out` is IEEE half (mixed mode forward copies), else bf16
 };
 // One block = one (co tile, ci tile) x all taps, transposed through LDS: the source w[co][ci][tap] is read in runs of
 // TCI * taps consecutive floats per co, the output [a][tap][b] is written in runs of 64 consecutive bf16 (128 bytes).
@@ -119,8 +119,12 @@ __global__ __launch_bounds__(256) void multi_weight_permute_kernel(const AvsrPer
         const int b_l = i & 63, t2 = i >> 6;
         const int tap = t2 % e.taps, a_l = t2 / e.taps;
         const int a = (e.to_dgrad ? ci0 : co0) + a_l, b = (e.to_dgrad ? co0 : ci0) + b_l;
-        if (a < (e.to_dgrad ? e.Cin : e.Cout) && b < Bc)
-            e.out[((long)a * e.taps + tap) * Bc + b] = f2bf(lds[tap * PERM_PITCH + a_l * 64 + b_l]);
+        if (a < (e.to_dgrad ? e.Cin : e.Cout) && b < Bc) {
+            const float v = lds[tap * PERM_PITCH + a_l * 64 + b_l];
+            const long o = ((long)a * e.taps + tap) * Bc + b;
+            if (e.pad0 == 2) reinterpret_cast<f16_t*>(e.out)[o] = f2h(v);
+            else e.out[o] = f2bf(v);
+        }
     }
 }
 // dw[co][ci][tap] = dwp[co][tap][ci]
@@ -146,7 +150,9 @@ extern "C" int avsr_conv_weight_permute(const float* w, void* out, int out_dtype
     if (out_dtype == 2) {
         AVSR_REQUIRE(total % 8 == 0 && ld_out == (int64_t)taps * (to_dgrad ? Cout : Cin), "conv_weight_permute: split8 output must be dense");
         AVSR_LAUNCH(weight_permute_split_kernel, grid, block, 0, stream, w, (bf16_t*)out, Cout, Cin, taps, to_dgrad);
-    } else if (out_dtype == 0)
+    } else if (out_dtype == 3)  // IEEE half (dtype code 2 is taken by the split8 layout here)
+        AVSR_LAUNCH((weight_permute_kernel<f16_t>), grid, block, 0, stream, w, (f16_t*)out, Cout, Cin, taps, to_dgrad, (long)ld_out);
+    else if (out_dtype == 0)
         AVSR_LAUNCH((weight_permute_kernel<float>), grid, block, 0, stream, w, (float*)out, Cout, Cin, taps, to_dgrad, (long)ld_out);
     else
         AVSR_LAUNCH((weight_permute_kernel<bf16_t>), grid, block, 0, stream, w, (bf16_t*)out, Cout, Cin, taps, to_dgrad, (long)ld_out);

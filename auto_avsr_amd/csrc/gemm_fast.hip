@@ -256,6 +256,35 @@ extern "C" int avsr_conv2d_bf16(int dgrad, const void* src, const void* wp, cons
     return 0;
 }
 
+// f16 forward convolution of the mixed mode on the same tiled kernel (v_mfma_f32_32x32x16_f16): x [N,H,W,Cin] f16,
+// wp [Cout][KH][KW][Cin] f16 -> y [N,OH,OW,Cout] f16 and (y2 != NULL) its bf16 twin, which the bf16 backward pass reads.
+extern "C" int avsr_conv2d_h16(const void* x, const void* wp, void* y, void* y2, const void* zero_page, int N, int H, int W, int Cin,
+                               int Cout, int KH, int KW, int stride, int pad_h, int pad_w, hipStream_t stream) {
+    const int OH = (H + 2 * pad_h - KH) / stride + 1, OW = (W + 2 * pad_w - KW) / stride + 1;
+    AVSR_REQUIRE(Cin % 64 == 0, "conv2d_h16: input channel count must be a multiple of 64");
+    AVSR_REQUIRE(zero_page != nullptr, "conv2d_h16: zero page required");
+    AVSR_REQUIRE(KH * KW <= 32, "conv2d_h16: at most 32 filter taps");
+    AVSR_REQUIRE(stride == 1 || (stride == 2 && KH <= 8 && KW <= 8), "conv2d_h16: stride must be 1 or 2");
+    AVSR_REQUIRE((long)N * H * W < (1l << 31) && (long)N * OH * OW < (1l << 31), "conv2d_h16: pixel count exceeds int32");
+    if (N <= 0) return 0;
+    Params p{};
+    p.A = x; p.B = wp;
+    p.K = KH * KW * Cin; p.lda = Cin; p.ldb = p.K;
+    p.alpha = 1.f; p.gate_scale = 1.f;
+    p.nsplit = 1; p.batch_h = 1; p.nbatch = 1;
+    p.gate = zero_page;
+    p.c_dtype = 2; p.C = y; p.C2 = y2; p.ldc2 = Cout;
+    p.cN = N;
+    p.cKH = KH; p.cKW = KW; p.cS = stride; p.cPH = pad_h; p.cPW = pad_w; p.cC = Cin; p.cT = 1; p.cKT = 1;
+    p.M = N * OH * OW; p.N = Cout; p.ldc = Cout;
+    p.cH = H; p.cW = W; p.cOH = OH; p.cOW = OW;
+    p.ncls = 1;
+    p.cls_h[0] = OH; p.cls_w[0] = OW; p.cls_nkh[0] = KH; p.cls_nkw[0] = KW;
+    AVSR_REQUIRE(launch_tile_h16<1>(p.N >= 128 ? 4 : 7, p, 1, stream), "conv2d_h16: tile");
+    AVSR_CHECK_LAUNCH("conv2d_h16");
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // dst[c][r] = src[r][c] as bf16, dst row pitch ldd >= R (columns [R, ldd) zero-filled): the k-contiguous copies
 // (W^T for the data gradient, dY^T / x^T for the weight gradient) that bring every contraction into NT form.

@@ -167,6 +167,7 @@ extern "C" int avsr_avgpool_fwd(const void* x, int dtype, float* y, int64_t grou
     AVSR_REQUIRE(C % 8 == 0, "avgpool: C must be a multiple of 8");
     if (groups <= 0) return 0;
     if (dtype == 0) AVSR_LAUNCH((avgpool_fwd_kernel<float>), dim3(grid_for(groups * (C >> 3))), dim3(256), 0, stream, (const float*)x, y, (long)groups, win, C);
+    else if (dtype == 2) AVSR_LAUNCH((avgpool_fwd_kernel<f16_t>), dim3(grid_for(groups * (C >> 3))), dim3(256), 0, stream, (const f16_t*)x, y, (long)groups, win, C);
     else AVSR_LAUNCH((avgpool_fwd_kernel<bf16_t>), dim3(grid_for(groups * (C >> 3))), dim3(256), 0, stream, (const bf16_t*)x, y, (long)groups, win, C);
     AVSR_CHECK_LAUNCH("avgpool_fwd");
     return 0;

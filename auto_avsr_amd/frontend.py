@@ -74,7 +74,10 @@ class ResNet(nn.Module):
         self.avgpool = nn.AdaptiveAvgPool2d(1)
 
     def forward(self, xd):
-        x, (N, H, W, C) = self.layer4(self.layer3(self.layer2(self.layer1(xd))))
+        for i, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
+            with AF.component(f"trunk{i + 1}"):  # (mixed numerical mode: forward arithmetic per stage, AF.MIXED_POLICY)
+                xd = layer(xd)
+        x, (N, H, W, C) = xd
         return AF.avg_pool(x, N, H * W, C)  # AdaptiveAvgPool2d(1) + flatten -> (N, 512) f32
 
 
@@ -103,7 +106,8 @@ class Conv3dResNet(nn.Module):
         assert C1 == 1, "expects (B, T, 1, H, W) grayscale clips"
         conv, bn = self.frontend3D[0], self.frontend3D[1]
         geom = (B, Tn, H, W) + tuple(conv.kernel_size) + (conv.stride[1],) + tuple(conv.padding)
-        x = AF.stem(xs_pad.reshape(B, Tn, H, W).float(), conv, bn, geom, pool=True)  # (B*T, 22, 22, 64)
+        with AF.component("stem"):
+            x = AF.stem(xs_pad.reshape(B, Tn, H, W).float(), conv, bn, geom, pool=True)  # (B*T, 22, 22, 64)
         feats = self.trunk((x, (B * Tn, x.shape[1], x.shape[2], x.shape[3])))
         return feats.view(B, Tn, feats.size(1))
 

@@ -26,7 +26,9 @@ _state = {"precise": False, "hpf": False, "mixed": False, "f16": False, "seed": 
 # tools/precision_study.py (CPU, reference golden of the benchmarked batch) and tools/mixed_sweep.py (MI355X) selected: the
 # twelve Conformer blocks -- 2/3 of the forward contractions of the step outside the front-end -- generate 4.6e-4 of logits
 # error in f16 against 3-6e-3 in bf16, the front-end / heads / decoder stay on split planes.
-MIXED_POLICY = {"encoder": "f16"}
+MIXED_POLICY = {"encoder": "f16", "trunk1": "f16", "trunk2": "f16", "trunk3": "f16", "trunk4": "f16", "decoder": "f16", "dec_out": "f16"}
+if os.environ.get("AVSR_MIXED_POLICY"):  # A/B runs: "encoder=f16,trunk3=f16,decoder=split"
+    MIXED_POLICY = dict(kv.split("=") for kv in os.environ["AVSR_MIXED_POLICY"].split(",") if kv)
 
 
 def set_precise(flag: bool):
@@ -143,8 +145,15 @@ def _A_view(t, base):
     if t is None or not _state["hpf"] or t.dtype not in (torch.float32, torch.float16):
         return t
     ent = _twins.get(base.data_ptr())
-    if ent is None or ent[0].numel() != base.numel() or t.dtype != base.dtype:
+    if t.dtype != base.dtype or not base.is_contiguous():
         return _A(t)
+    if ent is None or ent[0].numel() != base.numel():
+        # no producer-side twin (tensors below _TWIN_MIN, evaluation-mode producers): ONE cast of the base, shared by all of its
+        # views -- the backward kernels address their outputs with the strides of these views, so the layout must be kept
+        if len(_twins) > 256:
+            _twins.clear()
+        _twin_stats["cast"] = _twin_stats.get("cast", 0) + 1
+        ent = _twins[base.data_ptr()] = (base, ops.scale_dropout(base, torch.bfloat16))
     off = (t.data_ptr() - base.data_ptr()) // t.element_size()
     _twin_stats["used"] += 1
     return ent[1].as_strided(t.shape, t.stride(), ent[1].storage_offset() + off)
@@ -159,7 +168,7 @@ _f32_of = {}
 
 def _hand_over(out):
     """f32 output of a trunk function -> its bf16 twin as the tensor autograd sees (hpf mode, twin available); else `out`."""
-    if not _state["hpf"] or out.dtype != torch.float32:
+    if not _state["hpf"] or out.dtype not in (torch.float32, torch.float16):
         return out
     ent = _twins.get(out.data_ptr())
     if ent is None or ent[0].numel() != out.numel():
@@ -172,12 +181,21 @@ def _hand_over(out):
 
 
 def _f32_in(x):
-    """The f32 original of a handed-over twin (identity for anything else)."""
+    """The f32 / f16 original of a handed-over twin (identity for anything else)."""
     if x.dtype == torch.bfloat16 and _state["hpf"]:
         o = _f32_of.get(x.data_ptr())
         if o is not None and o.numel() == x.numel():
             return o.view(x.shape)
     return x
+
+
+def _act_in(x):
+    """Input activation of a trunk function in the dtype its forward pass computes in: the original behind a handed-over twin,
+    converted when the producing component of the mixed mode ran another forward format (one pass over the boundary tensor)."""
+    o = _f32_in(x)
+    if _state["mixed"] and o.dtype != act_dtype() and o.dtype in (torch.float32, torch.float16):
+        return ops.scale_dropout(o.contiguous(), act_dtype())
+    return o
 
 
 def is_precise() -> bool:
@@ -362,6 +380,7 @@ _wh16_table = {"n": 0, "dev": None, "blocks": 0, "built_for": -1}
 
 def _refresh_h16_weights():
     _wgen["h16_gen"] = _wgen["gen"]
+    _refresh_h16_conv_weights()
     if not _wh16:
         return
     if _wh16_table["built_for"] != len(_wh16):
@@ -419,6 +438,50 @@ def _w_h16_cat(ws):
     return buf
 
 
+_wconv16 = {}   # (data_ptr, shape) -> [version, f16 [Cout][taps][Cin] copy, conv weight]
+_wconv16_table = {"n": 0, "dev": None, "blocks": 0, "built_for": -1, "max_taps": 1}
+
+
+def _refresh_h16_conv_weights():
+    if not _wconv16:
+        return
+    if _wconv16_table["built_for"] != len(_wconv16):
+        import struct
+
+        blob, blk, max_taps = b"", 0, 1
+        for (ptr, shape), ent in _wconv16.items():
+            Cout, Cin = shape[0], shape[1]
+            taps = ent[2][0, 0].numel()
+            blob += struct.pack("<QQiiiiiiii", ent[2].data_ptr(), ent[1].data_ptr(), Cout, Cin, taps, 0, blk, 2, 0, 0)
+            blk += ops.weight_permute_blocks(Cout, Cin, False)
+            max_taps = max(max_taps, taps)
+        dev = next(iter(_wconv16.values()))[2].device
+        host = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+        _wconv16_table.update(n=len(_wconv16), dev=host.to(dev), blocks=blk, built_for=len(_wconv16), max_taps=max_taps)
+    ops.multi_weight_permute(_wconv16_table["dev"], _wconv16_table["n"], _wconv16_table["blocks"], _wconv16_table["max_taps"])
+    for ent in _wconv16.values():
+        ent[0] = ent[2]._version
+
+
+def _w_conv_h16(w):
+    """f16 [Cout][taps][Cin] copy of a conv weight (forward operand of an f16 component of the mixed mode)."""
+    if _wgen["dirty"]:
+        refresh_weight_cache()
+    if _wgen["h16_gen"] != _wgen["gen"]:
+        _refresh_h16_weights()
+    key = (w.data_ptr(), tuple(w.shape))
+    ent = _wconv16.get(key)
+    if ent is not None and ent[0] == w._version:
+        return ent[1]
+    if ent is None:
+        ent = _wconv16[key] = [-1, ops.conv_weight_permute(w, torch.float16), w]
+        _wconv16_table["built_for"] = -1
+    else:
+        ent[1].copy_(ops.conv_weight_permute(w, torch.float16))
+    ent[0] = w._version
+    return ent[1]
+
+
 def cached_weight_ptrs():
     """(generation, addresses of every parameter that has a cached bf16 copy: Linear-type, conv-type)."""
     return (_wgen["cleared"], len(_wcache), len(_wconv)), {k[0] for k in _wcache}, {k[0] for k in _wconv}
@@ -473,6 +536,8 @@ def invalidate_weight_cache():
     _wh16.clear()
     _wh16_cat.clear()
     _wh16_table.update(n=0, dev=None, blocks=0, built_for=-1)
+    _wconv16.clear()
+    _wconv16_table.update(n=0, dev=None, blocks=0, built_for=-1, max_taps=1)
     _wgen["cleared"] += 1
     _wgen["owner"] = None
     _wgen["dirty"] = 0
@@ -530,6 +595,9 @@ def _w_conv_fwd(w, x):
         ws = _w_conv_split(w)
         if ws is not None:
             return ws
+    if _state["f16"] and x.dtype == torch.float16:
+        assert w.shape[1] % 64 == 0 and w.dtype == torch.float32 and w.is_contiguous(), "f16 forward convolution: Cin % 64 == 0"
+        return _w_conv_h16(w)
     return _w_conv(w, False)
 
 
@@ -542,7 +610,7 @@ def refresh_weight_cache(force=False):
     _refresh_conv_weights()
     if (_state["precise"] or _state["hpf"]) and (_wsplit or _wsplit_conv):
         _refresh_split_weights()
-    if _state["mixed"] and _wh16:
+    if _state["mixed"] and (_wh16 or _wconv16):
         _refresh_h16_weights()
     if not _wcache:
         return
@@ -719,8 +787,12 @@ def _gemm_nt(a, w, M, N, K, out, *, lda=None, ldc=None, twin=False, **kw):
     mode the kernel also writes its bf16 copy (picked up by _A)."""
     if _fast_ok(a, K, lda) and w.dim() == 2 and w.dtype == torch.float32 and w.is_contiguous():
         return ops.gemm_bf16_nt(a, lda or K, _w_bf16(w, False), K, M, N, K, out, ldc or N, **kw)
-    if _state["f16"] and a.dtype == torch.float16:
-        # mixed mode, f16 component: the tuned tile kernel on IEEE-half operands (+ the bf16 twin of an activation output)
+    if _state["f16"]:
+        # mixed mode, f16 component: the tuned tile kernel on IEEE-half operands (+ the bf16 twin of an activation output); an f32
+        # input (a loss head on the residual stream) is rounded to f16 first -- never silently to bf16
+        if a.dtype != torch.float16:
+            assert lda is None or lda == K
+            a = _to_act(a)
         assert K % 64 == 0 and (lda or K) % 8 == 0 and w.dim() == 2 and w.dtype == torch.float32 and w.is_contiguous(), \
             "f16 forward GEMM: K % 64 == 0 and a dense f32 weight required"
         return ops.gemm_h16_nt(a, lda or K, _w_h16(w), K, M, N, K, out, ldc or N, twin=twin, **kw)
@@ -1420,6 +1492,7 @@ class MhaSublayerFn(torch.autograd.Function):
             ldq = 3 * D
         elif shared_kv:
             q = _proj(h, wq, bq, B * Tq, D, twin=pos_emb is None)
+            assert kv_all.dtype == T, "shared K / V projection and this sub-layer must run the same forward format"
             kv5 = kv_all.view(B, Tk, kv_all.shape[1] // D, H, dk)  # [.., 2 * slot] = K, [.., 2 * slot + 1] = V of this layer
             k4, v4 = kv5[:, :, 2 * kv_slot], kv5[:, :, 2 * kv_slot + 1]
             ldq = D
@@ -1452,13 +1525,15 @@ class MhaSublayerFn(torch.autograd.Function):
         _gemm_nt(ctxv, wo, B * Tq, D, D, y, bias=bo, drop_p=po, seed=so, seed_dev=sdo, resid=x, ldr=D)
         if fused and qkv.dtype == torch.float16:  # thirds of the fused projection: the same views of its bf16 twin
             s_qu, s_k, s_v = (_A(qu) if relpos else _A_view(qu, qkv)), _A_view(k4, qkv), _A_view(v4, qkv)
+        elif shared_kv and kv_all.dtype == torch.float16:
+            s_qu, s_k, s_v = _A(qu), _A_view(k4, kv_all), _A_view(v4, kv_all)
         else:
             s_qu, s_k, s_v = _A(qu), _A(k4), _A(v4)
         s_pp = _A_view(pproj, pp_all) if (pp_all is not None and pproj is not None) else _A(pproj)
         ctx.save_for_backward(x, ln_w, mean, rstd, _A(h), _A_shared(ka) if (cross and not shared_kv) else None, _A_shared(pe), m,
                               wq, wk, wv, wo, wpos, s_qu, _A(qv), s_k, s_v, s_pp, _A(ctxv), lse)
         ctx.meta = (H, pa, sa, sda, po, so, sdo, cross, relpos, fused)
-        ctx.kv = (kv_slot, kv_holder, tuple(kv_all.shape)) if shared_kv else None
+        ctx.kv = (kv_slot, kv_holder, tuple(kv_all.shape), kv_all.dtype) if shared_kv else None
         ctx.pp = (pp_slot, pp_holder, tuple(pp_all.shape), pp_all.dtype) if (relpos and pp_all is not None) else None
         _chain_tag(y, B * Tq, D, 1.0, (po, so, sdo))
         return y
@@ -1493,13 +1568,15 @@ class MhaSublayerFn(torch.autograd.Function):
         if shared_kv:
             # dK / dV go straight into this layer's columns of the shared gradient buffer; the projection's own backward
             # (weight, bias and memory gradients of ALL layers) runs once, in MemoryKVFn.backward
-            slot, holder, shape = ctx.kv
+            slot, holder, shape, kv_dtype = ctx.kv
             if holder.get("dkv") is None:
                 holder["dkv"] = torch.empty(shape, dtype=T, device=x.device)
             g5 = holder["dkv"].view(B, Tk, shape[1] // D, H, dk)
             outs = dict(dk_out=g5[:, :, 2 * slot], dv_out=g5[:, :, 2 * slot + 1])
             holder["filled"] = holder.get("filled", 0) + 1
-            dkv_grad = holder["dkv"] if slot == 0 else None  # ONE consumer hands the buffer to autograd, the others None
+            # ONE consumer hands autograd a gradient (the others None); the real buffer travels in `holder` -- autograd would
+            # convert it to the dtype of the forward output (f16 in the mixed mode)
+            dkv_grad = (holder["dkv"] if kv_dtype == T else _placeholder_grad(shape, kv_dtype, x.device)) if slot == 0 else None
         dpp_grad = None
         if ctx.pp is not None:
             # this layer's position gradient accumulates into its column block of ONE zero-filled buffer; the weight
@@ -1617,9 +1694,12 @@ class MemoryKVFn(torch.autograd.Function):
         ws, bs = wb[0::2], wb[1::2]
         n = len(ws)
         ma = _to_act_shared(memory).reshape(B * Tk, D)
-        kv = torch.empty(B * Tk, n * D, dtype=torch.bfloat16, device=memory.device)
-        ops.gemm_bf16_nt(ma, D, _w_bf16_cat(tuple(ws), False), D, B * Tk, n * D, D, kv, n * D, bias=torch.cat(bs))
-        ctx.save_for_backward(ma, *ws)
+        kv = torch.empty(B * Tk, n * D, dtype=ma.dtype, device=memory.device)
+        if ma.dtype == torch.float16:  # mixed mode: f16 projection + bf16 twin (the source-attention backward passes read views of it)
+            ops.gemm_h16_nt(ma, D, _w_h16_cat(tuple(ws)), D, B * Tk, n * D, D, kv, n * D, bias=torch.cat(bs), twin=True)
+        else:
+            ops.gemm_bf16_nt(ma, D, _w_bf16_cat(tuple(ws), False), D, B * Tk, n * D, D, kv, n * D, bias=torch.cat(bs))
+        ctx.save_for_backward(_A_shared(ma), *ws)
         ctx.holder = holder
         ctx.meta = (B, Tk, D, n)
         return kv
@@ -1630,8 +1710,9 @@ class MemoryKVFn(torch.autograd.Function):
         ma, *ws = ctx.saved_tensors
         B, Tk, D, n = ctx.meta
         holder = ctx.holder
-        assert holder.get("filled", 0) == n // 2 and dkv.data_ptr() == holder["dkv"].data_ptr(), \
+        assert holder.get("filled", 0) == n // 2 and holder.get("dkv") is not None, \
             "MemoryKVFn: every source-attention sub-layer must have written its dK / dV"
+        dkv = holder["dkv"]  # (the autograd-visible gradient is a placeholder of the forward dtype)
         rows = B * Tk
         dbias = _zeros(n * D, dkv.device)
         dmem = torch.empty(B, Tk, D, dtype=torch.float32, device=dkv.device)
@@ -2035,7 +2116,8 @@ class BasicBlockFn(torch.autograd.Function):
         ph, pw = (KH - 1) // 2, (KW - 1) // 2
         T = act_dtype()
         pr = _state["precise"]
-        x = _f32_in(x)  # hpf: the previous trunk function handed over its bf16 twin; compute on the f32 original
+        x_arg = x
+        x = _act_in(x)  # hpf / mixed: the previous trunk function handed over its bf16 twin; compute on the f32 / f16 original
         OH, OW = ops.conv_out(H, KH, stride, ph), ops.conv_out(W, KW, stride, pw)
         rows = N * OH * OW
         bn1 = (g1, b1) + bn1
@@ -2054,7 +2136,8 @@ class BasicBlockFn(torch.autograd.Function):
         else:
             r = x
         out = ops.bn_act_fwd(c2, r, m2, i2, g2, b2, rows, Cout, 1)
-        ctx.save_for_backward(_A(x), _A(c1), _A(a1), _A(c2), _A(cd), _A(r) if wd is not None else None, w1, w2, wd, g1, b1, g2, b2,
+        sx = x_arg if (_state["hpf"] and x_arg.dtype == torch.bfloat16 and x_arg is not x) else _A(x)  # (the handed-over twin itself)
+        ctx.save_for_backward(sx, _A(c1), _A(a1), _A(c2), _A(cd), _A(r) if wd is not None else None, w1, w2, wd, g1, b1, g2, b2,
                               gd, bd, m1, i1, n1, m2, i2, n2, md, idd, nd)
         ctx.meta = (dims, stride, training, (OH, OW), bn1[2:], bn2[2:], bnd[2:] if wd is not None else None)
         return _hand_over(out)

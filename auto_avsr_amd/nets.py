@@ -445,19 +445,21 @@ class TransformerDecoder(BatchScorerInterface, nn.Module):
         return AF.embed(tgt, emb.weight, pe.table(tgt.shape[1], emb.weight.device), pe.xscale, p)
 
     def forward(self, tgt, tgt_mask, memory, memory_mask):
-        x = self._embed(tgt)
-        # the source-attention K / V projections of all layers act on the same memory: one GEMM (functional.MemoryKVFn)
-        shared = AF.memory_kv(memory, [(d.src_attn.linear_k.weight, d.src_attn.linear_k.bias, d.src_attn.linear_v.weight,
-                                        d.src_attn.linear_v.bias) for d in self.decoders])
-        if shared is None:
-            x, tgt_mask, memory, memory_mask = self.decoders(x, tgt_mask, memory, memory_mask)
-        else:
-            for i, layer in enumerate(self.decoders):  # (layer_drop_rate is 0.0 in the reference model: plain loop)
-                x, tgt_mask, memory, memory_mask = layer(x, tgt_mask, memory, memory_mask, kv=(shared[0], i, shared[1]))
-        if self.normalize_before:
-            x = self.after_norm(x)
+        with AF.component("decoder"):  # (mixed numerical mode: forward arithmetic of this component, AF.MIXED_POLICY)
+            x = self._embed(tgt)
+            # the source-attention K / V projections of all layers act on the same memory: one GEMM (functional.MemoryKVFn)
+            shared = AF.memory_kv(memory, [(d.src_attn.linear_k.weight, d.src_attn.linear_k.bias, d.src_attn.linear_v.weight,
+                                            d.src_attn.linear_v.bias) for d in self.decoders])
+            if shared is None:
+                x, tgt_mask, memory, memory_mask = self.decoders(x, tgt_mask, memory, memory_mask)
+            else:
+                for i, layer in enumerate(self.decoders):  # (layer_drop_rate is 0.0 in the reference model: plain loop)
+                    x, tgt_mask, memory, memory_mask = layer(x, tgt_mask, memory, memory_mask, kv=(shared[0], i, shared[1]))
+            if self.normalize_before:
+                x = self.after_norm(x)
         if self.output_layer is not None:
-            x = AF.linear(x, self.output_layer.weight, self.output_layer.bias, out_dtype=torch.float32, pad_out=True)
+            with AF.component("dec_out"):
+                x = AF.linear(x, self.output_layer.weight, self.output_layer.bias, out_dtype=torch.float32, pad_out=True)
         return x, tgt_mask
 
     def forward_one_step(self, tgt, tgt_mask, memory, memory_mask=None, cache=None):

@@ -528,7 +528,9 @@ def conv_weight_permute(w, out_dtype, to_dgrad=False, ld_out=None):
     ld = ld_out or taps * b
     alloc = torch.zeros if ld != taps * b else torch.empty
     out = alloc(a, ld, dtype=out_dtype, device=w.device)
-    call("avsr_conv_weight_permute", _ptr(w), _ptr(out), dt(out), Cout, Cin, taps, int(to_dgrad), ld, _stream(w))
+    # (this entry point's dtype code 2 is the split8 layout; IEEE half is 3)
+    call("avsr_conv_weight_permute", _ptr(w), _ptr(out), 3 if out_dtype == torch.float16 else dt(out), Cout, Cin, taps,
+         int(to_dgrad), ld, _stream(w))
     return out
 
 
@@ -605,6 +607,11 @@ def conv2d_fwd(x, wp, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise):
         call("avsr_conv2d_bf16", 0, _ptr(x), _ptr(wp), None, _ptr(y), _ptr(zero_page(x.device)), N, H, W, Cin, Cout, KH,
              KW, stride, ph, pw, _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin,
              nbytes=_nb(x, wp) + 2.0 * N * OH * OW * Cout)
+        return y
+    if x.dtype == torch.float16:  # mixed mode, f16 component: the tiled kernel on IEEE-half operands + the bf16 twin of the result
+        assert wp.dtype == torch.float16 and Cin % 64 == 0 and stride <= 2 and not precise
+        call("avsr_conv2d_h16", _ptr(x), _ptr(wp), _ptr(y), _ptr(_twin(y)), _ptr(zero_page(x.device)), N, H, W, Cin, Cout, KH, KW,
+             stride, ph, pw, _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin, nbytes=_nb(x, wp) + 4.0 * N * OH * OW * Cout)
         return y
     if precise and SPLIT_FAST and x.dtype == torch.float32 and wp.dtype == torch.float32 and Cin % 64 == 0 and KH * KW <= 32:
         call("avsr_conv2d_f32s", _ptr(x), _ptr(wp), _ptr(y), _ptr(zero_page(x.device)), N, H, W, Cin, Cout, KH, KW, stride,

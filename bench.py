@@ -34,11 +34,17 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--precise", action="store_true", help="parity mode (split-bf16 contractions) instead of bf16")
-    ap.add_argument("--mode", choices=["bf16", "precise", "hpf"], default=None,
-                    help="numerical mode of the timed steps (functional.set_mode): bf16 (default), precise (split-bf16 forward "
-                         "and backward), hpf (precise forward -- logits / losses within the 1e-3 parity bound -- + bf16 backward)")
-    ap.add_argument("--no-precise-leg", action="store_true",
-                    help="skip the extra `precise` object of the JSON line (throughput + parity of the hpf mode, N = 1 video)")
+    ap.add_argument("--mode", choices=["bf16", "precise", "hpf", "mixed"], default=None,
+                    help="numerical mode of the timed steps (functional.set_mode).  mixed (default): the mode that meets the north "
+                         "star's 1e-3 bound on logits / CTC log-probabilities at the lowest cost -- forward contractions on IEEE-half "
+                         "operands (encoder, trunk, decoder) or split bf16 planes (stem, projections, CTC head), bf16 backward; "
+                         "bf16: bf16 operands everywhere (fastest, logits 7e-3 off the fp32 reference); hpf: every forward "
+                         "contraction on split planes; precise: split planes forward and backward")
+    ap.add_argument("--no-precise-leg", "--no-bf16-leg", dest="no_second_leg", action="store_true",
+                    help="skip the extra `bf16` object of the JSON line (throughput + parity of the plain bf16 mode on the same "
+                         "workload, N = 1 video)")
+    ap.add_argument("--hpf-leg", action="store_true",
+                    help="also time the hpf mode (every forward contraction on split planes) -> object `hpf` of the JSON line")
     ap.add_argument("--shapes", type=int, default=8,
                     help="distinct length-bucketed batch shapes cycled through (spread over the bucket list; the longest "
                          "bucket, T = 400, is always one of them)")
@@ -127,7 +133,8 @@ def parity_block(mode):
             "grad_sample_cos_min", "grad_sample_rel_l2_median", "grad_norm_rel_err_median")
     out = {k: (float(f"{r[k]:.3g}") if isinstance(r[k], float) else r[k]) for k in keep}
     out.update(mode={"precise": "precise (split-bf16 forward + backward)", "bf16": "bf16",
-                     "hpf": "hpf (split-bf16 forward, bf16 backward)"}[mode],
+                     "hpf": "hpf (split-bf16 forward, bf16 backward)",
+                     "mixed": "mixed (forward: Conformer encoder on f16 operands, front-end / heads / decoder on split-bf16 planes; bf16 backward)"}[mode],
                batch="A: 4 x 400 frames, 64 labels, reference golden", north_star_tol=1e-3)
     return out
 
@@ -179,7 +186,7 @@ def main():
     odim = selftest["odim"] if selftest else 5049
     torch.manual_seed(0)
     model = E2E(odim, args.modality, **(selftest["model"] if selftest else {})).to(dev).train()
-    mode = args.mode or ("precise" if args.precise else "bf16")
+    mode = args.mode or ("precise" if args.precise else "mixed")
     AF.set_mode(mode)
     AF.manual_seed(1234 + rank)
     seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -405,7 +412,8 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": {"bf16": "bf16", "precise": "f32 (split-bf16 MFMA)", "hpf": "f32 forward (split-bf16 MFMA) / bf16 backward"}[mode],
+        "dtype": {"bf16": "bf16", "precise": "f32 (split-bf16 MFMA)", "hpf": "f32 forward (split-bf16 MFMA) / bf16 backward",
+                  "mixed": "f16 (encoder) + split-bf16 (front-end, heads, decoder) forward / bf16 backward"}[mode],
         "data": "synthetic",
         "config": {"workload": ("configs[1]: modality=video vsr_trlrs3_base" if args.modality == "video" else
                                 "configs[3] single-GPU leg: modality=audio asr_trlrs3_base (a frame = 640 samples)")
@@ -432,11 +440,9 @@ def main():
             out["roofline_hbm"] = hbm
     if rank == 0 and not dp and not args.no_parity and args.modality == "video":
         out["parity"] = parity_block(mode)
-    if rank == 0 and not dp and mode == "bf16" and args.modality == "video" and not args.no_precise_leg \
-            and not args.no_optimizer and not selftest:
-        # The mode that meets the north-star tolerance on logits (1e-3): the SAME workload and step, forward pass on split hi /
-        # lo bf16 planes (three MFMAs per product, f32 activations), backward pass as above.  Fewer steps; same protocol.
-        AF.set_mode("hpf")
+    def second_leg(leg_mode, description):
+        """The SAME workload and step timed in another numerical mode (fewer steps, same protocol) + its parity block."""
+        AF.set_mode(leg_mode)
         AF.invalidate_weight_cache()
         graphs.clear()
         model.zero_grad(set_to_none=True)
@@ -445,16 +451,25 @@ def main():
         dt_p, loss_p = timed_run(n_w, n_w + n_t)
         fr_p = sum(d[3] for d in data[n_w:n_w + n_t])
         lp = float(loss_p.detach())
-        assert lp == lp and abs(lp) < 1e30, f"non-finite loss in the hpf leg: {lp}"
+        assert lp == lp and abs(lp) < 1e30, f"non-finite loss in the {leg_mode} leg: {lp}"
         graphs.clear()
-        out["precise"] = {"mode": "hpf: forward on split hi/lo bf16 planes (3 MFMAs per product, f32 activations -- the arithmetic "
-                                  "that meets the 1e-3 bound), backward + optimizer exactly as the bf16 step on bf16 copies of the "
-                                  "saved activations", "ms_per_step": round(dt_p / n_t * 1e3, 3),
-                          "value": round(fr_p / dt_p, 2), "unit": "video-frames/sec", "steps": n_t, "warmup": n_w,
-                          "vs_bf16_step": round((dt_p / n_t) / (dt / args.steps), 3),
-                          "parity": None if args.no_parity else parity_block("hpf")}
+        res = {"mode": description, "ms_per_step": round(dt_p / n_t * 1e3, 3), "value": round(fr_p / dt_p, 2),
+               "unit": "video-frames/sec", "steps": n_t, "warmup": n_w,
+               "vs_headline_step": round((dt_p / n_t) / (dt / args.steps), 3),
+               "parity": None if args.no_parity else parity_block(leg_mode)}
         AF.set_mode(mode)
         AF.invalidate_weight_cache()
+        return res
+
+    legs_ok = rank == 0 and not dp and args.modality == "video" and not args.no_optimizer and not selftest
+    if legs_ok and mode != "bf16" and not args.no_second_leg:
+        # the fastest arithmetic of this build, for comparison: bf16 operands in every contraction (8 significant bits: decoder
+        # logits 7e-3 / CTC log-probabilities 4e-3 off the fp32 reference -- outside the north star's 1e-3 bound)
+        out["bf16"] = second_leg("bf16", "bf16 operands in every forward and backward contraction (does NOT meet the 1e-3 bound on "
+                                         "logits: see its parity block)")
+    if legs_ok and mode != "hpf" and args.hpf_leg:
+        out["hpf"] = second_leg("hpf", "forward on split hi/lo bf16 planes everywhere (3 MFMAs per product, f32 activations), backward "
+                                       "+ optimizer as the bf16 step")
     if rank == 0 and not dp and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.modality, odim)
     if rank == 0:

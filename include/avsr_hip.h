@@ -491,6 +491,11 @@ int avsr_layernorm_fwd_h16(const float* x, const float* gamma, const float* beta
 int avsr_gemm_h16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias, int act,
                      float drop_p, uint64_t seed, const uint64_t* seed_dev, float alpha, const void* resid, int resid_dtype,
                      int ldr, void* C, int c_dtype, int ldc, int tile, void* c2, int ldc2, avsr_stream_t stream);
+/* f16 forward convolution (resnet.py:10-35 in the mixed mode): x [N,H,W,Cin] f16 * wp [Cout][KH][KW][Cin] f16 -> y f16 (+ bf16 twin y2,
+ * may be NULL); Cin % 64 == 0, stride 1 or 2; wp from avsr_conv_weight_permute (out_dtype 3) / avsr_multi_weight_permute (entry
+ * field pad0 = 2) */
+int avsr_conv2d_h16(const void* x, const void* wp, void* y, void* y2, const void* zero_page, int N, int H, int W, int Cin,
+                    int Cout, int KH, int KW, int stride, int pad_h, int pad_w, avsr_stream_t stream);
 int avsr_head_bias_fwd_h16(const void* x, int64_t ldx, const float* b1, const float* b2, void* o1, void* o2, void* t1, void* t2,
                            int64_t rows, int cols, avsr_stream_t stream);
 /* arguments as avsr_attention_fwd2; q / k / v / pos / out are f16, out2 (may be NULL) the bf16 twin of out */

@@ -1,10 +1,13 @@
 """Parity at the BENCHMARKED shapes: full-size video model on the survey's batch A (4 x 400 frames,
 64 labels) and batch B (16 x 100, 16 labels) against numbers produced by the REFERENCE implementation
-(tests/golden/make_golden_bench.py -> golden_bench_v1.pt), in BOTH numerical modes:
+(tests/golden/make_golden_bench.py -> golden_bench_v1.pt), in ALL FOUR numerical modes:
 
-* precise (split-bf16 contractions): the north-star bound -- losses / logits / CTC log-probs within 1e-3 relative;
-* bf16 (the mode bench.py times): measured and printed; bounds state what bf16 operands (2^-9 relative rounding per
-  contraction input) deliver at this depth, and the same numbers appear in bench.py's `parity` block.
+* precise (split-bf16 contractions forward and backward) and hpf (the same forward, bf16 backward): logits / CTC log-probs at
+  1e-5, far inside the north-star bound of 1e-3 relative;
+* mixed (the mode bench.py times by default: f16 / split-plane forward per component, bf16 backward): logits / CTC log-probs
+  asserted inside 1e-3;
+* bf16 (bench.py's secondary `bf16` object): measured and printed; bounds state what 8-bit significands deliver at this depth,
+  and the same numbers appear in bench.py's `parity` blocks.
 
 Gradients are checked element-wise on 64 sampled entries per tensor (+ cosine, + norm), not by norm alone."""
 import json
@@ -43,28 +46,43 @@ def _model(seed):
 
 
 @pytest.mark.parametrize("tag", ["A", "B"])
-@pytest.mark.parametrize("mode", ["precise", "bf16"])
+@pytest.mark.parametrize("mode", ["precise", "hpf", "mixed", "bf16"])
 def test_bench_shape_parity(gold, tag, mode):
     from auto_avsr_amd import functional as AF
 
     case = gold[tag]
     m = _model(case["seed"])
-    with AF.precise(mode == "precise"):
+    with AF.numerics(mode):
         r = BC.measure(m, case, torch.device("cuda"))
     AF.invalidate_weight_cache()
     print(f"\nPARITY batch {tag} ({len(case['lengths'])} x {max(case['lengths'])}) mode {mode}: " + json.dumps(
         {k: (round(v, 7) if isinstance(v, float) else v) for k, v in r.items()}))
+    # the north-star bound in every mode: the three losses within 1e-3 relative
+    assert r["loss_rel_err"] < 1e-3 and r["ctc_rel_err"] < 1e-3 and r["att_rel_err"] < 1e-3
     if mode == "precise":
-        assert r["loss_rel_err"] < 1e-3 and r["ctc_rel_err"] < 1e-3 and r["att_rel_err"] < 1e-3
         assert r["dec_logits_rel_l2"] < 1e-3 and r["ctc_logp_rel_l2"] < 1e-3 and r["enc_rel_l2"] < 1e-3
         assert r["acc"] == pytest.approx(r["acc_ref"], abs=1e-6) and r["acc_ref"] > 0.1
         assert r["grad_norm_rel_err_max"] < 1e-2 and r["grad_sample_cos_min"] > 0.999
         assert r["grad_sample_rel_l2_max"] < 2e-2, r.get("worst_sample_tensor")
+    elif mode == "hpf":
+        # the precise FORWARD (measured 1e-5 on the logits) with the bf16 backward (gradient samples: cosine 0.998, median
+        # relative L2 7.5e-3 at batch A)
+        assert r["dec_logits_rel_l2"] < 1e-4 and r["ctc_logp_rel_l2"] < 1e-4 and r["enc_rel_l2"] < 1e-3
+        assert r["acc"] == pytest.approx(r["acc_ref"], abs=1e-6)
+        assert r["grad_sample_cos_min"] > 0.99 and r["grad_sample_rel_l2_median"] < 2e-2 and r["grad_norm_rel_err_median"] < 5e-3
+    elif mode == "mixed":
+        # THE BENCHMARKED MODE (bench.py's headline): logits / CTC log-probabilities inside the north star's 1e-3 -- measured
+        # on MI355X with the default policy (f16 encoder + trunk + decoder, split stem / projections / CTC head): 8.0e-4 /
+        # 4.5e-4 at batch A (tools/r4_s2.sh sweep) -- with the bf16 backward
+        assert r["dec_logits_rel_l2"] < 1e-3 and r["ctc_logp_rel_l2"] < 1e-3
+        assert r["enc_rel_l2"] < 1.5e-2  # (a 32-channel slice of the encoder output: ~10x the logits' relative error in every mode)
+        assert r["acc"] == pytest.approx(r["acc_ref"], abs=1e-6)
+        assert r["grad_sample_cos_min"] > 0.99 and r["grad_sample_rel_l2_median"] < 3e-2 and r["grad_norm_rel_err_median"] < 5e-3
     else:
-        # measured on MI355X (round 2): losses 4e-6 .. 5e-5 (inside the north-star's 1e-3), decoder logits 7e-3, CTC
-        # log-probs 4e-3, encoder output 4e-2 (element-wise relative L2 after 12 layers of bf16 activations)
-        assert r["loss_rel_err"] < 1e-3 and r["ctc_rel_err"] < 1e-3 and r["att_rel_err"] < 1e-3
-        assert r["dec_logits_rel_l2"] < 3e-2 and r["ctc_logp_rel_l2"] < 3e-2 and r["enc_rel_l2"] < 8e-2
+        # bf16 operands everywhere (8 significant bits): measured on MI355X decoder logits 7.4e-3, CTC log-probs 4.2e-3, encoder
+        # slice 4e-2 at batch A (batch B within 1.5x) -- 7x / 4x OUTSIDE the north-star bound, which is why it is not the
+        # benchmarked mode; the bounds below would catch a regression of ~1.5x
+        assert r["dec_logits_rel_l2"] < 1.2e-2 and r["ctc_logp_rel_l2"] < 8e-3 and r["enc_rel_l2"] < 8e-2
         assert abs(r["acc"] - r["acc_ref"]) < 0.02
         assert r["grad_sample_cos_min"] > 0.9 and r["grad_sample_cos_mean"] > 0.99
         assert r["grad_norm_rel_err_median"] < 2e-2

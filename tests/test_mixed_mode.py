@@ -1,0 +1,281 @@
+"""The "mixed" numerical mode (functional.set_mode("mixed")): forward kernels on IEEE-half (f16) operands with bf16 twins for the
+backward pass, and the per-component forward policy.
+
+Kernel level: every f16 forward entry point (include/avsr_hip.h, section "mixed") against float64 math on the SAME f16-rounded
+inputs -- exact products, f32 accumulation -- and its bf16 twin against the bf16 rounding of the f16-path result.
+Module level: a small E2E instance against the fp32 oracle (oracle/avsr_oracle.py) for several policies.
+Each test runs on the host emulator build (CPU suite) and on the gfx950 build (-m gpu)."""
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+from auto_avsr_amd import functional as AF
+from auto_avsr_amd import ops
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, HERE)
+
+
+def rel(a, b):
+    a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture
+def twins(monkeypatch):
+    """Switch the producer-side twins on outside an autograd function (what functional.set_mode('mixed') does in a step)."""
+    made = []
+
+    def make(y):
+        t = torch.empty(y.shape, dtype=torch.bfloat16, device=y.device)
+        made.append((y, t))
+        return t
+
+    monkeypatch.setattr(ops, "TWIN", make)
+    return made
+
+
+@pytest.mark.parametrize("tile", [0, 1, 4, 7])
+@pytest.mark.parametrize("shape", [(150, 70, 192), (257, 300, 448), (130, 136, 64)])
+def test_gemm_h16_nt(dev, tile, shape, twins):
+    M, N, K = shape
+    torch.manual_seed(M + tile)
+    A, B = torch.randn(M, K).half(), (0.1 * torch.randn(N, K)).half()
+    ref = A.double() @ B.double().t()
+    C = torch.zeros(M, N + 3, device=dev)
+    ops.gemm_h16_nt(A.to(dev), K, B.to(dev), K, M, N, K, C, N + 3, tile=tile)
+    assert ((C.cpu()[:, :N].double() - ref).abs().max() / ref.abs().max()) < 2e-6  # exact products, f32 accumulation
+    assert C.cpu()[:, N:].abs().max() == 0
+    # epilogue (bias, relu, alpha, f32 residual) + f16 output + its bf16 twin
+    bias, resid = torch.randn(N), torch.randn(M, N)
+    C2 = torch.zeros(M, N, device=dev, dtype=torch.float16)
+    ops.gemm_h16_nt(A.to(dev), K, B.to(dev), K, M, N, K, C2, N, bias=bias.to(dev), act=1, alpha=0.5, resid=resid.to(dev), ldr=N,
+                    tile=tile, twin=(N % 8 == 0))
+    ref2 = torch.relu(ref + bias.double()) * 0.5 + resid.double()
+    assert ((C2.cpu().double() - ref2).abs().max() / ref2.abs().max()) < 1.5e-3  # one f16 rounding (2^-11)
+    if N % 8 == 0:
+        (y, tw), = twins
+        assert y is C2 and rel(tw.float(), ref2) < 4e-3 and (tw.float().cpu() - ref2.float()).abs().max() < 1.2e-2 * ref2.abs().max()
+    # an 11-bit significand is the point: the same contraction on bf16 roundings of the SAME f32 data is ~8x further off
+    Af, Bf = torch.randn(M, K), 0.1 * torch.randn(N, K)
+    exact = Af.double() @ Bf.double().t()
+    Ch = torch.zeros(M, N, device=dev)
+    ops.gemm_h16_nt(Af.half().to(dev), K, Bf.half().to(dev), K, M, N, K, Ch, N, tile=tile)
+    Cb = torch.zeros(M, N, device=dev)
+    ops.gemm_bf16_nt(Af.bfloat16().to(dev), K, Bf.bfloat16().to(dev), K, M, N, K, Cb, N)
+    assert rel(Ch, exact) < 6e-4 and rel(Cb, exact) > 4 * rel(Ch, exact)
+
+
+def test_layernorm_headbias_casts_f16(dev, twins):
+    torch.manual_seed(0)
+    rows, cols = 37, 768
+    x, g, b = torch.randn(rows, cols), torch.randn(cols), torch.randn(cols)
+    ref = torch.nn.functional.layer_norm(x, (cols,), g, b, 1e-12)
+    y, mean, rstd = ops.layernorm_fwd(x.to(dev), g.to(dev), b.to(dev), torch.float16, twin=True)
+    assert y.dtype == torch.float16 and (y.float().cpu() - ref).abs().max() < 4e-3
+    (yy, tw), = twins
+    assert yy is y and (tw.float().cpu() - ref).abs().max() < 3e-2
+    y32, mean32, rstd32 = ops.layernorm_fwd(x.to(dev), g.to(dev), b.to(dev), torch.float32)
+    assert torch.equal(mean, mean32) and torch.equal(rstd, rstd32)
+    twins.clear()
+    # q + pos_bias_u / q + pos_bias_v on an f16 slice of a pitched buffer
+    q = torch.randn(rows, 3 * cols).half()
+    u, v = torch.randn(cols), torch.randn(cols)
+    o1, o2 = ops.head_bias_fwd(q.to(dev), 3 * cols, rows, cols, u.to(dev), v.to(dev))
+    assert o1.dtype == torch.float16
+    assert (o1.float().cpu() - (q[:, :cols].float() + u)).abs().max() < 4e-3
+    assert (o2.float().cpu() - (q[:, :cols].float() + v)).abs().max() < 4e-3
+    assert len(twins) == 2 and (twins[0][1].float().cpu() - (q[:, :cols].float() + u)).abs().max() < 3e-2
+    # casts: f32 -> f16 (round to nearest even, saturating), f16 -> f32 exact, f16 -> bf16
+    z = torch.cat([torch.randn(1000), torch.tensor([1e6, -1e6, 65504.0, 6e-8, 0.0, 1.0 + 2 ** -11, 1.0 + 3 * 2 ** -11])])
+    z = torch.cat([z, torch.zeros((-z.numel()) % 8)])
+    h = ops.scale_dropout(z.to(dev), torch.float16)
+    want = z.clamp(-65504.0, 65504.0).half()
+    assert torch.equal(h.cpu(), want)
+    assert torch.equal(ops.scale_dropout(h, torch.float32).cpu(), want.float())
+    assert torch.equal(ops.scale_dropout(h, torch.bfloat16).cpu(), want.float().bfloat16())
+
+
+@pytest.mark.parametrize("case", [(2, 70, 70, 2, True, "pad"), (1, 130, 130, 1, True, None), (2, 33, 33, 2, False, "causal"),
+                                  (2, 17, 100, 2, False, "pad"), (2, 17, 40, 2, False, "allmasked")])
+def test_attention_fwd_f16(dev, case, twins):
+    """f16 forward on the transposed-formulation kernel: every mask kind, ragged tiles, Tq != Tk; against float64 math on the same
+    f16 inputs.  11-bit operands: an order of magnitude inside the bf16 kernel's tolerance (3e-2 in test_attention.py)."""
+    from test_attention import make_mask, ref_attn
+
+    B, T, Tk, H, relpos, mkind = case
+    torch.manual_seed(5)
+    qu, qv = torch.randn(B, T, H, 64).half(), torch.randn(B, T, H, 64).half()
+    k, v = torch.randn(B, Tk, H, 64).half(), torch.randn(B, Tk, H, 64).half()
+    pos = torch.randn(2 * T - 1, H * 64).half() if relpos else None
+    mask = make_mask(mkind, B, T, Tk)
+    d = lambda t: None if t is None else t.to(dev)
+    ref = ref_attn(qu.double(), qv.double(), k.double(), v.double(), None if pos is None else pos.double(), mask, 0.125)
+    out, lse = ops.attention_fwd(d(qu), d(qv) if relpos else None, d(k), d(v), d(pos), d(mask), 0.125)
+    assert out.dtype == torch.float16
+    assert (out.float().cpu().double() - ref).abs().max() < 4e-3 * max(1.0, float(ref.abs().max()))
+    (o, tw), = twins
+    assert o is out and (tw.float().cpu().double() - ref).abs().max() < 3e-2 * max(1.0, float(ref.abs().max()))
+    # the log-sum-exp the bf16 backward kernel pairs with: equal to the f32 kernel's on the same (f16-exact) inputs
+    out32, lse32 = ops.attention_fwd(d(qu.float()), d(qv.float()) if relpos else None, d(k.float()), d(v.float()),
+                                     d(None if pos is None else pos.float()), d(mask), 0.125, precise=True)
+    assert (lse.cpu() - lse32.cpu()).abs().max() < 2e-3
+
+
+@pytest.mark.gpu
+def test_attention_fwd_f16_bench_geometry(twins):
+    from test_attention import make_mask, ref_attn
+
+    dev = torch.device("cuda")
+    for (B, T, Tk, H, relpos, mkind) in [(2, 400, 400, 3, True, "pad"), (2, 65, 400, 3, False, "pad"), (2, 65, 65, 3, False, "causal")]:
+        torch.manual_seed(6)
+        qu, qv = torch.randn(B, T, H, 64).half(), torch.randn(B, T, H, 64).half()
+        k, v = torch.randn(B, Tk, H, 64).half(), torch.randn(B, Tk, H, 64).half()
+        pos = torch.randn(2 * T - 1, H * 64).half() if relpos else None
+        mask = make_mask(mkind, B, T, Tk)
+        d = lambda t: None if t is None else t.to(dev)
+        ref = ref_attn(qu.double(), qv.double(), k.double(), v.double(), None if pos is None else pos.double(), mask, 0.125)
+        out, _ = ops.attention_fwd(d(qu), d(qv) if relpos else None, d(k), d(v), d(pos), d(mask), 0.125)
+        assert rel(out.float(), ref) < 1.5e-3  # (the bf16 kernel: 1e-2)
+
+
+def test_dwconv_bn_f16(dev, twins):
+    """GLU + depthwise conv and the single-launch BatchNorm1d + Swish of the convolution module on f16 activations."""
+    torch.manual_seed(2)
+    B, T, C, K = 2, 50, 128, 31
+    a = torch.randn(B * T, 2 * C).half()
+    w, bias = 0.2 * torch.randn(C, K), torch.randn(C)
+    glu = a[:, :C].double() * torch.sigmoid(a[:, C:].double())
+    ref = torch.nn.functional.conv1d(glu.view(B, T, C).transpose(1, 2), w.double().unsqueeze(1), bias.double(), padding=15,
+                                     groups=C).transpose(1, 2)
+    y = ops.dwconv(a.to(dev), w.to(dev), bias.to(dev), B, T, C, K, glu_in=True)
+    assert y.dtype == torch.float16 and rel(y.float(), ref) < 6e-4
+    assert rel(twins[0][1].float(), ref) < 4e-3
+    twins.clear()
+    g, b = torch.rand(C) + 0.5, torch.randn(C)
+    rm, rv, nbt = torch.zeros(C), torch.ones(C), torch.zeros((), dtype=torch.int64)
+    x = y.cpu().view(B * T, C)
+    bn = torch.nn.BatchNorm1d(C).double()
+    bn.weight.data, bn.bias.data = g.double(), b.double()
+    refy = torch.nn.functional.silu(bn(x.double()))
+    s, mean, invstd = ops.bn_small_fwd(y, B * T, C, g.to(dev), b.to(dev), 1e-5, 0.1, rm.to(dev), rv.to(dev), nbt.to(dev), 1)
+    assert s.dtype == torch.float16 and rel(s.float(), refy) < 6e-4 and rel(twins[0][1].float(), refy) < 4e-3
+    assert (mean.cpu().double() - x.double().mean(0)).abs().max() < 1e-5
+    # the multi-launch path (what cross-rank BatchNorm runs): statistics + apply on the f16 tensor
+    twins.clear()
+    m2, i2 = ops.bn_stats_finalize(y, B * T, C, 1e-5, 0.1, rm.to(dev), rv.to(dev), None)
+    s2 = ops.bn_act_fwd(y, None, m2, i2, g.to(dev), b.to(dev), B * T, C, 1)
+    assert rel(s2.float(), refy) < 6e-4 and rel(twins[0][1].float(), refy) < 4e-3
+    flat = ops.bn_stats(y, B * T, C, with_count=True)
+    assert float(flat[-1]) == B * T
+
+
+@pytest.mark.parametrize("geom", [(3, 11, 11, 64, 128, 3, 2), (2, 6, 6, 128, 128, 3, 1), (3, 11, 11, 64, 128, 1, 2), (2, 22, 22, 64, 64, 3, 1)])
+def test_conv2d_h16(dev, geom, twins):
+    """Implicit-GEMM convolution on f16 operands (trunk stages of the mixed mode) vs torch on the same f16-rounded data."""
+    N, H, W, Cin, Cout, KH, stride = geom
+    pad = (KH - 1) // 2
+    torch.manual_seed(N + H)
+    x = torch.randn(N, H, W, Cin).half()
+    w = (0.1 * torch.randn(Cout, Cin, KH, KH))
+    wp = ops.conv_weight_permute(w.to(dev), torch.float16)
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.half().double(), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    y = ops.conv2d_fwd(x.to(dev), wp, N, H, W, Cin, Cout, KH, KH, stride, pad, pad, False)
+    assert y.dtype == torch.float16 and rel(y.float(), ref) < 5e-4
+    (yy, tw), = twins
+    assert yy is y and rel(tw.float(), ref) < 4e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------- module level
+POLICIES = {
+    "default": None,
+    "default-casts": None,  # no producer-side twins (what tensors below functional._TWIN_MIN get): save-time casts, same layouts
+    "encoder-only": {"encoder": "f16"},
+    "all-split": {},
+}
+
+
+@pytest.mark.parametrize("policy", list(POLICIES))
+@pytest.mark.parametrize("modality", ["video", "audio"])
+def test_e2e_small_mixed_mode(dev, modality, policy, monkeypatch):
+    """Small E2E instance in the mixed mode against the fp32 oracle: losses inside the north-star bound (1e-3; f16 operands
+    deliver ~1e-4 here), gradients aligned, every saved activation of the f16 components picked up as a producer-side twin, and
+    -- policy {} -- bit-identical to the hpf mode (everything on split planes)."""
+    from oracle import avsr_oracle as O
+    from synth import synth_state_dict
+    from test_modules import no_dropout, synth_batch
+
+    from auto_avsr_amd.e2e import E2E
+
+    if POLICIES[policy] is not None:
+        monkeypatch.setattr(AF, "MIXED_POLICY", POLICIES[policy])
+    torch.manual_seed(0)
+    odim = 72
+    m = no_dropout(E2E(odim, modality, adim=128, aheads=2, eunits=256, elayers=2, dunits=256, dlayers=2, cnn_module_kernel=7))
+    sd = synth_state_dict(m.state_dict(), 13)
+    m.load_state_dict(sd, strict=True)
+    m.to(dev).train()
+    x, lengths, y = synth_batch(modality, 2, 9, 4, odim, seed=8)
+    osd = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running_" not in k else v.clone()) for k, v in sd.items()}
+    (loss_r, ctc_r, att_r, acc_r), _ = O.e2e_forward(osd, x, lengths, y, modality=modality, heads=2)
+    loss_r.backward()
+    AF.invalidate_weight_cache()
+    monkeypatch.setattr(AF, "_TWIN_MIN", (1 << 60) if policy == "default-casts" else 0)
+    AF._twin_stats.update(made=0, used=0, cast=0)
+    with AF.numerics("mixed"):
+        assert AF.mode() == "mixed"
+        loss, loss_ctc, loss_att, acc = m(x.to(dev), lengths.to(dev), y.to(dev))
+        loss.backward()
+    assert AF.mode() == "bf16" and ops.TWIN is None and not AF._state["f16"]
+    assert abs(float(loss_ctc) - float(ctc_r)) < 1e-3 * abs(float(ctc_r))
+    assert abs(float(loss_att) - float(att_r)) < 1e-3 * abs(float(att_r))
+    assert acc == acc_r
+    st = dict(AF._twin_stats)
+    if policy == "default-casts":
+        assert st["made"] == 0 and st["cast"] > 20, st
+    else:
+        assert st["used"] > 20 and st["cast"] <= 8, st
+    cos = []
+    for k, p in m.named_parameters():
+        assert p.grad is not None and p.grad.dtype == torch.float32, k
+        a, b = p.grad.double().flatten().cpu(), osd[k].grad.double().flatten()
+        if b.norm() > 1e-4 * max(1.0, float(osd[k].double().norm())):
+            cos.append((float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)), k))
+    assert min(cos)[0] > 0.9, sorted(cos)[:5]
+    if policy == "all-split":
+        m.load_state_dict(sd, strict=True)
+        AF.invalidate_weight_cache()
+        with AF.numerics("hpf"):
+            ref = [float(v) for v in m(x.to(dev), lengths.to(dev), y.to(dev))[:3]]
+        assert [float(loss), float(loss_ctc), float(loss_att)] == ref
+    AF.invalidate_weight_cache()
+
+
+def test_side_weight_caches_follow_raw_pointer_updates(dev):
+    """Round-3 advisor finding: an optimizer that updates weights through raw pointers (no tensor version bump) followed by a
+    bf16-mode refresh must not leave the split8 / f16 side copies looking fresh."""
+    torch.manual_seed(4)
+    AF.invalidate_weight_cache()
+    lin = torch.nn.Linear(64, 128).to(dev)
+    x = torch.randn(16, 64, device=dev)
+
+    def run(mode):
+        with AF.numerics(mode), torch.no_grad():
+            if mode == "mixed":
+                with AF.component("encoder"):
+                    return AF.linear(x, lin.weight, lin.bias, out_dtype=torch.float32).clone()
+            return AF.linear(x, lin.weight, lin.bias, out_dtype=torch.float32).clone()
+
+    y_split, y_f16 = run("precise"), run("mixed")
+    lin.weight.data.view(-1)[:].mul_(2.0)  # in place through .data: _version unchanged, like the fused optimizer's raw-pointer update
+    AF.note_optimizer_step(False)
+    run("bf16")  # a bf16-mode use in between refreshes the bf16 copies and clears the dirty flag
+    b = lin.bias.detach()
+    for y_old, mode, tol in ((y_split, "precise", 1e-4), (y_f16, "mixed", 2e-3)):
+        y_new = run(mode)
+        assert rel(y_new - b, 2.0 * (y_old - b)) < tol, mode
+    AF.invalidate_weight_cache()
