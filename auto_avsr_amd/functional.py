@@ -171,6 +171,12 @@ def _hand_over(out):
     if not _state["hpf"] or out.dtype not in (torch.float32, torch.float16):
         return out
     ent = _twins.get(out.data_ptr())
+    if (ent is None or ent[0].numel() != out.numel()) and out.dtype == torch.float16 and _state.get("tag_ok", False) \
+            and out.is_contiguous():
+        # an f16 tensor must not be the autograd-visible output: autograd would convert the consumer's bf16 data gradient to f16
+        # (5 exponent bits: gradients below 6e-8 vanish).  No producer-side twin (tensors below _TWIN_MIN): cast one here.
+        _twin_stats["cast"] = _twin_stats.get("cast", 0) + 1
+        ent = _twins[out.data_ptr()] = (out, ops.scale_dropout(out, torch.bfloat16))
     if ent is None or ent[0].numel() != out.numel():
         return out
     tw = ent[1].view(out.shape)
