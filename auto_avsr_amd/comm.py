@@ -52,9 +52,14 @@ class StreamComm:
         return cls(cls.new_unique_id(), 1, 0)
 
     def all_reduce(self, t):
-        assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
-        ops.call("avsr_comm_all_reduce_f32", self.slot, ops._ptr(t), t.numel(), ops._stream(t), nbytes=8.0 * t.numel())
+        assert t.dtype in (torch.float32, torch.bfloat16) and t.is_contiguous() and t.is_cuda
+        ops.call("avsr_comm_all_reduce", self.slot, ops._ptr(t), t.numel(), 0 if t.dtype == torch.float32 else 1, ops._stream(t),
+                 nbytes=2.0 * t.numel() * t.element_size())
         return t
+
+    def ranks(self):
+        """Size of the RCCL communicator as the library reports it (bench.py prints it: config.rccl_ranks)."""
+        return int(_lib.lib().call("avsr_comm_size", self.slot))
 
     def all_gather(self, out, mine):
         assert out.dtype == mine.dtype == torch.float32 and out.is_contiguous() and mine.is_contiguous()
@@ -66,3 +71,40 @@ class StreamComm:
         if StreamComm._live.get(self.slot) is self:
             _lib.lib().call("avsr_comm_destroy", self.slot)
             del StreamComm._live[self.slot]
+
+
+class GroupComm:
+    """The StreamComm interface on a torch.distributed process group of its own (any backend).  The CPU test suite runs the
+    `comm=` control flow of ddp.GradBuckets, the cross-rank BatchNorm and bench.py's data-parallel step on it over gloo (the
+    emulator build has no RCCL); on GPUs it is a transport of last resort (collectives through c10d: not graph-capturable)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+
+        self._dist = dist
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.group = dist.new_group(ranks=list(range(self.world))) if group is None else group  # (collective: every rank calls it)
+
+    @classmethod
+    def from_process_group(cls, group=None):
+        return cls(group)
+
+    def all_reduce(self, t):
+        if t.dtype == torch.bfloat16 and not t.is_cuda:  # (gloo has no bf16 sum: reduce the exact f32 images, round once)
+            f = t.float()
+            self._dist.all_reduce(f, group=self.group)
+            t.copy_(f)
+            return t
+        self._dist.all_reduce(t, group=self.group)
+        return t
+
+    def all_gather(self, out, mine):
+        assert out.numel() == self.world * mine.numel()
+        self._dist.all_gather_into_tensor(out, mine, group=self.group)
+        return out
+
+    def ranks(self):
+        return self.world
+
+    def close(self):
+        pass

@@ -25,7 +25,7 @@ namespace {
 
 struct NcclUniqueId { char internal[128]; };  // rccl.h: NCCL_UNIQUE_ID_BYTES
 typedef void* NcclComm;
-constexpr int kNcclFloat32 = 7, kNcclSum = 0;  // rccl.h: ncclFloat32, ncclSum
+constexpr int kNcclFloat32 = 7, kNcclBfloat16 = 9, kNcclSum = 0;  // rccl.h: ncclFloat32, ncclBfloat16, ncclSum
 
 struct Api {
     void* lib = nullptr;
@@ -118,6 +118,15 @@ extern "C" int avsr_comm_all_reduce_f32(int slot, void* buf, int64_t count, hipS
     return check(g_api.AllReduce(buf, buf, (size_t)count, kNcclFloat32, kNcclSum, g_comm[slot], stream), "ncclAllReduce");
 }
 
+// dtype: 0 = f32, 1 = bf16 (the narrow wire format of the gradient buckets: half the bytes per xGMI link, sums formed in bf16)
+extern "C" int avsr_comm_all_reduce(int slot, void* buf, int64_t count, int dtype, hipStream_t stream) {
+    AVSR_REQUIRE(slot >= 0 && slot < kSlots && g_comm[slot] != nullptr, "comm_all_reduce: no communicator in this slot (avsr_comm_init)");
+    AVSR_REQUIRE(dtype == 0 || dtype == 1, "comm_all_reduce: dtype must be 0 (f32) or 1 (bf16)");
+    if (count <= 0) return 0;
+    return check(g_api.AllReduce(buf, buf, (size_t)count, dtype == 1 ? kNcclBfloat16 : kNcclFloat32, kNcclSum, g_comm[slot], stream),
+                 "ncclAllReduce");
+}
+
 extern "C" int avsr_comm_all_gather_f32(int slot, const void* send, void* recv, int64_t count_per_rank, hipStream_t stream) {
     AVSR_REQUIRE(slot >= 0 && slot < kSlots && g_comm[slot] != nullptr, "comm_all_gather: no communicator in this slot (avsr_comm_init)");
     if (count_per_rank <= 0) return 0;
@@ -131,6 +140,7 @@ extern "C" int avsr_comm_init(int, const void*, int, int) { avsr_set_error("comm
 extern "C" int avsr_comm_destroy(int) { return 0; }
 extern "C" int64_t avsr_comm_size(int) { return 0; }
 extern "C" int avsr_comm_all_reduce_f32(int, void*, int64_t, hipStream_t) { avsr_set_error("comm: not available in the emulator build"); return 1; }
+extern "C" int avsr_comm_all_reduce(int, void*, int64_t, int, hipStream_t) { avsr_set_error("comm: not available in the emulator build"); return 1; }
 extern "C" int avsr_comm_all_gather_f32(int, const void*, void*, int64_t, hipStream_t) { avsr_set_error("comm: not available in the emulator build"); return 1; }
 
 #endif

@@ -39,7 +39,18 @@ class _NullCtx:
 
 
 class GradBuckets:
-    def __init__(self, params, group=None, bucket_mb=64.0, comm=None):
+    def __init__(self, params, group=None, bucket_mb=None, comm=None, wire=None):
+        """bucket_mb: bucket size in MB of f32 gradients (default 64, environment AVSR_BUCKET_MB overrides: sweep hook).
+        wire: "f32" (default) or "bf16" (environment AVSR_GRAD_WIRE): the format the buckets travel in.  bf16 halves the bytes
+        per xGMI link -- the exchange of 1.0 GB of f32 gradients is per-link bound on a ring -- at the
+        price of bf16 sums across the ranks (8 significant bits; the bf16 / mixed modes compute their gradients from bf16
+        operands anyway); the reduced bucket is widened back to f32 for the optimizer on the exchange's own stream."""
+        import os
+
+        if bucket_mb is None:
+            bucket_mb = float(os.environ.get("AVSR_BUCKET_MB", "64"))
+        self.wire = wire or os.environ.get("AVSR_GRAD_WIRE", "f32")
+        assert self.wire in ("f32", "bf16"), self.wire
         self.params = [p for p in params if p.requires_grad]
         assert self.params and all(p.dtype == torch.float32 for p in self.params)
         self.group = group
@@ -65,6 +76,7 @@ class GradBuckets:
         sizes.append(cur_n)
         self.members = members
         self.flat = [torch.zeros(n, dtype=torch.float32, device=self.device) for n in sizes]
+        self.narrow = [torch.zeros(n, dtype=torch.bfloat16, device=self.device) for n in sizes] if self.wire == "bf16" else None
         self.views = {i: self.flat[self.bucket_of[i]][self.offset[i]: self.offset[i] + self.params[i].numel()].view_as(self.params[i])
                       for i in range(len(self.params))}
         self._left = [len(m) for m in members]
@@ -80,7 +92,7 @@ class GradBuckets:
         self._ring_pos = [0] * len(members)
         self.compute_stream = None  # set by begin_step(): the stream the step's kernels are issued on
         self._seen = [dict() for _ in members]  # per bucket: the streams its parameters' hooks ran on in this step
-        self._side = torch.cuda.Stream(device=self.device) if comm is not None else None
+        self._side = torch.cuda.Stream(device=self.device) if (comm is not None and self.device.type == "cuda") else None
         self._side_used = False
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
 
@@ -168,12 +180,24 @@ class GradBuckets:
                 self.params[i].grad = self.views[i]
             if self.comm is not None:
                 # RCCL's C API on the side stream, behind the gather launch; the compute stream goes on with the backward pass
-                self._side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(self._side):
-                    self.comm.all_reduce(self.flat[b])
-                self._side_used = True
+                if self._side is not None:
+                    self._side.wait_stream(torch.cuda.current_stream())
+                with (torch.cuda.stream(self._side) if self._side is not None else _NullCtx()):
+                    self._reduce(b)
+                self._side_used = self._side is not None
             elif self.world > 1 or self.group is not None:
+                if self.wire == "bf16":
+                    raise RuntimeError("GradBuckets: the bf16 wire format needs a stream communicator (comm=)")
                 self._works.append(dist.all_reduce(self.flat[b], group=self.group, async_op=True))
+
+    def _reduce(self, b):
+        """The all-reduce of bucket b on the current stream, in the wire format."""
+        if self.wire == "bf16":
+            ops.cast_into(self.flat[b], self.narrow[b])   # f32 -> bf16 (round to nearest even), 6 B per element
+            self.comm.all_reduce(self.narrow[b])
+            ops.cast_into(self.narrow[b], self.flat[b])   # back to the f32 views the optimizer reads
+        else:
+            self.comm.all_reduce(self.flat[b])
 
     def begin_step(self):
         """Before the forward pass, on the thread / stream that issues the step: remembers the compute stream, so that every

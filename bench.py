@@ -55,14 +55,99 @@ def parse():
                     help="time ONE fixed batch instead of the bucketed workload: the survey's batch A (4 x 400 frames, 64 "
                          "labels) or batch B (16 x 100, 16 labels), SURVEY.md section 8d")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity block (reference goldens at batch A)")
-    ap.add_argument("--ddp", choices=["auto", "torch", "buckets", "buckets-graph"], default="auto",
+    ap.add_argument("--ddp", choices=["auto", "torch", "buckets", "buckets-graph", "buckets-graph1"], default="auto",
                     help="N > 1 gradient exchange.  buckets-graph: this build's bucketed RCCL all-reduce (auto_avsr_amd/ddp.py) with every "
-                         "collective of the step issued through RCCL's C API as a plain stream operation (auto_avsr_amd/comm.py), the "
-                         "WHOLE data-parallel step captured into hipGraphs (one-rank evidence: 20.1 ms / step against 31.2 ms for torch "
-                         "DDP's eager step, profiles/r3_dp1_*.json); buckets: the same exchange on torch.distributed, eager launches; "
-                         "torch: DistributedDataParallel, eager launches.  auto (default) = buckets-graph, falling back to torch if the "
-                         "RCCL binding cannot be set up and to eager launches if a capture fails")
+                         "collective of the step issued through RCCL's C API as a plain stream operation (auto_avsr_amd/comm.py) on two "
+                         "communicators, the WHOLE data-parallel step captured into hipGraphs (one-rank evidence: 20.1 ms / step against "
+                         "31.2 ms for torch DDP's eager step, profiles/r3_dp1_*.json); buckets-graph1: the same on ONE communicator (strict "
+                         "issue order); buckets: the same exchange on torch.distributed, eager launches; torch: DistributedDataParallel, "
+                         "eager launches.  auto (default): buckets-graph -> buckets-graph1 -> torch, each attempt in fresh worker "
+                         "processes under a wall-clock limit (supervise(): a dead-locked collective is a hang, not an exception)")
+    ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)  # a rank process started by supervise()
     return ap.parse_args()
+
+
+DDP_CHAIN = ["buckets-graph", "buckets-graph1", "torch"]
+
+
+def supervise(args):
+    """N > 1 entry.  This process does not touch a GPU: it runs the rank process(es) of the data-parallel bench as children and
+    watches the clock, because the failure mode of a multi-rank collective is a HANG, not an exception -- a communicator whose
+    peers disagree on the order of two collectives spins in a kernel forever, and nothing inside that process can recover.
+
+    * launched by `python -m torch.distributed.run ... bench.py --gpus N` (RANK / WORLD_SIZE in the environment, what the driver
+      does): one child = this rank's worker;  launched as plain `python bench.py --gpus N`: the N workers of one node, started
+      here with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (127.0.0.1) -- no torchrun needed;
+    * attempt k runs the workers in data-parallel mode DDP_CHAIN[k] on its own rendezvous port (MASTER_PORT + 1 + k) with a
+      wall-clock limit; a worker that fails or overruns is killed (whole process group) and the next, more conservative mode is
+      tried: buckets-graph (bucketed exchange + cross-rank BatchNorm on two RCCL communicators through the C API, whole step
+      replayed as hipGraphs) -> buckets-graph1 (the same on ONE communicator: every collective of a rank in one issue order,
+      which is the same program order on every rank -- cannot dead-lock on ordering) -> torch (DistributedDataParallel + c10d
+      collectives, eager launches).  Every supervisor applies the same limits, so the ranks move on together;
+    * rank 0's JSON line (stdout of its worker) is printed once, by this process, after the attempt that succeeded."""
+    import signal
+    import subprocess
+
+    world_env = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if world_env:
+        assert int(os.environ["WORLD_SIZE"]) == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}"
+        ranks = [int(os.environ["RANK"])]
+    else:
+        ranks = list(range(args.gpus))
+    base_port = int(os.environ.get("MASTER_PORT", "29500"))
+    want = os.environ.get("AVSR_DDP") or args.ddp
+    chain = DDP_CHAIN if want == "auto" else [want]
+    limits = [float(x) for x in os.environ.get("AVSR_BENCH_ATTEMPT_TIMEOUT", "600,420,420").split(",")]
+    argv = [a for a in sys.argv[1:] if a != "--worker"]
+    for attempt, mode in enumerate(chain):
+        limit = limits[min(attempt, len(limits) - 1)]
+        procs = []
+        for r in ranks:
+            env = dict(os.environ, AVSR_DDP=mode, AVSR_BENCH_ATTEMPT=str(attempt), MASTER_PORT=str(base_port + 1 + attempt),
+                       MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), WORLD_SIZE=str(args.gpus), RANK=str(r))
+            if not world_env:
+                env["LOCAL_RANK"] = str(r)
+            # (under torchrun the env:// rendezvous would look for the AGENT's store on MASTER_PORT; the workers of an attempt
+            # rendezvous among themselves: rank 0's worker serves the store on this attempt's port)
+            env["TORCHELASTIC_USE_AGENT_STORE"] = "False"
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + ["--worker"], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else None, text=True, start_new_session=True))
+        t0 = time.time()
+        out0, failed = None, None
+        try:
+            for r, pr in zip(ranks, procs):
+                left = max(1.0, limit - (time.time() - t0))
+                o, _ = pr.communicate(timeout=left)
+                if r == 0:
+                    out0 = o
+                if pr.returncode != 0 and failed is None:
+                    failed = f"rank {r} exited with code {pr.returncode}"
+        except subprocess.TimeoutExpired:
+            failed = f"no result within {limit:.0f} s (hang guard)"
+        if failed is not None:
+            for pr in procs:  # the whole process group of every worker: RCCL helper threads / children included
+                if pr.poll() is None:
+                    try:
+                        os.killpg(pr.pid, signal.SIGKILL)
+                    except ProcessLookupError:
+                        pass
+            for pr in procs:
+                try:
+                    pr.wait(timeout=30)
+                except subprocess.TimeoutExpired:
+                    pass
+            nxt = f"; falling back to --ddp {chain[attempt + 1]}" if attempt + 1 < len(chain) else ""
+            print(f"[bench supervisor, ranks {ranks}] attempt {attempt} (--ddp {mode}) failed: {failed}{nxt}", file=sys.stderr, flush=True)
+            continue
+        if out0 is not None:
+            lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+            for ln in out0.splitlines():
+                if not ln.startswith("{"):
+                    print(ln, file=sys.stderr)
+            if lines:
+                print(lines[-1], flush=True)
+        return 0
+    return 1
 
 
 def cpu_baseline(modality, odim):
@@ -141,10 +226,14 @@ def parity_block(mode):
 
 def main():
     args = parse()
+    if args.gpus > 1 and not args.worker:
+        sys.exit(supervise(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    import datetime
+
     import torch.distributed as dist
 
     from auto_avsr_amd import _lib, ops
@@ -178,11 +267,14 @@ def main():
             os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
+        # (the rendezvous waits for ranks whose previous attempt is still running into its wall-clock limit: supervise())
         if selftest:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=900))
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=900))
         AF.set_bn_sync(dist.group.WORLD)
+        if selftest and os.environ.get("AVSR_BENCH_TEST_HANG") == (os.environ.get("AVSR_DDP") or args.ddp) and rank == world - 1:
+            time.sleep(3600)  # test-suite hook: one rank of this mode never arrives (what a dead-locked collective looks like)
     odim = selftest["odim"] if selftest else 5049
     torch.manual_seed(0)
     model = E2E(odim, args.modality, **(selftest["model"] if selftest else {})).to(dev).train()
@@ -216,23 +308,25 @@ def main():
         # bf16 operand copies of the Linear weights, so the next forward pass needs no separate re-cast of 250M weights
         opt = make_optimizer()
     buckets = comm = comm_grads = None
-    if dp and args.ddp == "auto" and os.environ.get("AVSR_DDP") in ("torch", "buckets", "buckets-graph"):
-        args.ddp = os.environ["AVSR_DDP"]  # override without touching the command line (e.g. AVSR_DDP=torch: the conservative path)
+    if dp and os.environ.get("AVSR_DDP") in ("torch", "buckets", "buckets-graph", "buckets-graph1"):
+        args.ddp = os.environ["AVSR_DDP"]  # set by supervise() per attempt (or by hand: AVSR_DDP=torch is the conservative path)
     if dp and args.ddp == "auto":
-        args.ddp = "torch" if selftest else "buckets-graph"
-        if not selftest:
-            try:
-                from auto_avsr_amd.comm import StreamComm
-
-                # two communicators: RCCL runs the operations of ONE communicator in issue order even across streams -- the
-                # small BatchNorm collectives on the compute stream must not queue behind 64 MB bucket all-reduces
-                comm = StreamComm.from_process_group()
-                comm_grads = StreamComm.from_process_group()
-            except Exception as e:  # noqa: BLE001 -- symmetrical across ranks (same library, same call): all ranks fall back
-                print(f"[bench rank {rank}] RCCL C-API communicators unavailable ({type(e).__name__}: {str(e)[:200]}); "
-                      "falling back to --ddp torch", file=sys.stderr, flush=True)
-                comm = comm_grads = None
-                args.ddp = "torch"
+        args.ddp = "buckets-graph"
+    graph_modes = ("buckets-graph", "buckets-graph1")
+    if dp and args.ddp in graph_modes:
+        # every collective of the step straight on RCCL's C API (auto_avsr_amd/comm.py): stream operations only, so the capture
+        # below has no torch Work objects in it (the process group stays for rendezvous, barriers and the timing).
+        # buckets-graph: TWO communicators -- RCCL runs the operations of ONE communicator in issue order even across streams,
+        # and the latency-bound BatchNorm collectives on the compute stream must not queue behind 64 MB bucket all-reduces on
+        # the side stream.  buckets-graph1: ONE communicator for both (strict issue order = program order on every rank).
+        # (CPU self-test: comm.GroupComm, the same interface over gloo, so that this control flow runs in the test suite.)
+        if selftest:
+            from auto_avsr_amd.comm import GroupComm as Comm
+        else:
+            from auto_avsr_amd.comm import StreamComm as Comm
+        comm = Comm.from_process_group()
+        comm_grads = Comm.from_process_group() if args.ddp == "buckets-graph" else comm
+        AF.set_bn_sync(dist.group.WORLD, comm=comm)
     if dp and args.ddp == "torch":
         hot = torch.nn.parallel.DistributedDataParallel(hot, device_ids=None if selftest else [local_rank],
                                                         find_unused_parameters=False, broadcast_buffers=False,
@@ -241,21 +335,13 @@ def main():
         # train.py:37 DDPStrategy(find_unused_parameters=False): bucketed gradient all-reduce over RCCL/xGMI, issued by this
         # build's own exchange (auto_avsr_amd/ddp.py) so that the WHOLE data-parallel step -- collectives included -- can be
         # captured into a hipGraph (torch's DDP reducer cannot: tools/rccl_capture_probe.py).
-        # 64 MB buckets: ring all-reduce over point-to-point xGMI links is per-link bound and wants large messages;
-        # the parameter-poor, compute-rich ResNet trunk runs LAST in the backward pass (~5 ms, 45 MB of gradients),
+        # 64 MB buckets (AVSR_BUCKET_MB): ring all-reduce over point-to-point xGMI links is per-link bound and wants large
+        # messages; the parameter-poor, compute-rich ResNet trunk runs LAST in the backward pass (~5 ms, 45 MB of gradients),
         # so the ~15 encoder/decoder buckets drain underneath it and the exposed tail stays one small bucket.
+        # AVSR_GRAD_WIRE=bf16: the buckets travel as bf16 (half the bytes per link; stated in config.grad_wire).
         from auto_avsr_amd.ddp import GradBuckets
 
-        if args.ddp == "buckets-graph" and not selftest:
-            # every collective of the step straight on RCCL's C API (auto_avsr_amd/comm.py): stream operations only, so the
-            # capture below has no torch Work objects in it (the process group stays for rendezvous, barriers and the timing)
-            if comm is None:
-                from auto_avsr_amd.comm import StreamComm
-
-                comm = StreamComm.from_process_group()
-                comm_grads = StreamComm.from_process_group()
-            AF.set_bn_sync(dist.group.WORLD, comm=comm)
-        buckets = GradBuckets(model.parameters(), group=dist.group.WORLD, bucket_mb=64, comm=comm_grads)
+        buckets = GradBuckets(model.parameters(), group=dist.group.WORLD, comm=comm_grads)
 
     if dp and rank == 0:
         print(f"[bench] data-parallel mode: --ddp {args.ddp}" + (" (RCCL C-API communicators, hipGraph replay)" if comm is not None else ""),
@@ -292,7 +378,7 @@ def main():
         babble = TR.AddNoise(noise=noise.to(dev))
         babble.snr_levels = [0]
         raw = [[0.1 * torch.randn(int(n), generator=g).to(dev) for n in lens.tolist()] for (_, lens, _, _) in pool]
-    use_graph = not args.no_graph and (not dp or args.ddp == "buckets-graph")
+    use_graph = not args.no_graph and (not dp or args.ddp in ("buckets-graph", "buckets-graph1"))
     graphs = {}
     st = {"opt": opt, "graph": use_graph}
     all_params = list(model.parameters())
@@ -423,7 +509,7 @@ def main():
                                + ("" if args.no_optimizer else " + global-norm clip 10 + AdamW(1e-3, .9/.98, wd .03) + warm-up cosine + bf16 weight re-cast")
                                + ((", DDP grad all-reduce + SyncBN over RCCL" if args.ddp == "torch" else
                                    ", bucketed RCCL gradient all-reduce overlapped with backward (auto_avsr_amd.ddp) + SyncBN"
-                                   + (", every collective a stream operation on RCCL's C API (auto_avsr_amd.comm)" if comm is not None else "")) if dp else "")
+                                   + (", every collective a stream operation on RCCL's C API (auto_avsr_amd.comm)" if (comm is not None and not selftest) else "")) if dp else "")
                                + (" [AVSR_BENCH_FORCE_DP: data-parallel machinery on ONE rank]" if dp and world == 1 else "")
                                + (", every step from RAW waveforms: AudioTransform('train') with babble noise at SNR 0 dB + collation "
                                   "on the device inside the timed region" if args.babble else "")
@@ -433,6 +519,12 @@ def main():
                                             int(d[2].shape[2])) for d in data}),
                    "all_hot_path_compute": "libavsr_hip.so (hand-written HIP, gfx950)"},
     }
+    if dp:
+        out["config"].update(ddp_mode=args.ddp, attempt=int(os.environ.get("AVSR_BENCH_ATTEMPT", "0")),
+                             rccl_ranks=(comm.ranks() if comm is not None else dist.get_world_size()),
+                             communicators=(0 if comm is None else (1 if comm_grads is comm else 2)),
+                             grad_wire=(buckets.wire if buckets is not None else "f32"),
+                             bucket_mb=(round(buckets.flat[0].numel() * 4 / 2 ** 20, 1) if buckets is not None else 64))
     if rank == 0 and not dp and not args.no_roofline:
         # (N > 1: an extra rank-0-only step would dead-lock the DDP / BatchNorm collectives; the kernels are the same)
         out["roofline"], hbm = roofline(model, data[args.warmup], ops)
@@ -475,9 +567,8 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dp:
-        for c in (comm, comm_grads):
-            if c is not None:
-                c.close()
+        for c in {id(c): c for c in (comm, comm_grads) if c is not None}.values():
+            c.close()
         dist.destroy_process_group()
 
 

@@ -338,7 +338,9 @@ int avsr_comm_unique_id(void* out128);
 int avsr_comm_init(int slot, const void* id128, int nranks, int rank);
 int avsr_comm_destroy(int slot);
 int64_t avsr_comm_size(int slot); /* 0 without a communicator */
-int avsr_comm_all_reduce_f32(int slot, void* buf, int64_t count, avsr_stream_t stream);                          /* in place, sum */
+int avsr_comm_all_reduce_f32(int slot, void* buf, int64_t count, avsr_stream_t stream);
+/* the same for dtype 0 = f32 / 1 = bf16 (narrow wire format of the gradient buckets: half the bytes per xGMI link) */
+int avsr_comm_all_reduce(int slot, void* buf, int64_t count, int dtype, avsr_stream_t stream);                          /* in place, sum */
 int avsr_comm_all_gather_f32(int slot, const void* send, void* recv, int64_t count_per_rank, avsr_stream_t stream); /* recv: nranks x count */
 /* Tuning knobs of the tuned kernels (process-wide; meant for benchmarks, defaults are the measured best):
  * knob 0 = tile code forced on avsr_conv2d_bf16 (0 = auto), 1 = XCD-aware tile order (0 = automatic: on for the 64x64 GEMM tile, whose

@@ -244,13 +244,19 @@ def test_ddp_bench_configuration(emu_lib_path, tmp_path):
     assert res["ok"] and res["step"] == 2
 
 
-@pytest.mark.parametrize("ddp", ["auto", "buckets"])
-def test_bench_main_two_ranks(emu_lib_path, tmp_path, ddp):
-    """bench.py's own main(), launched exactly as the driver launches it for N = 2 (`python -m torch.distributed.run
-    --nproc-per-node 2 ... bench.py --gpus 2 ...`), on two CPU processes: gloo instead of RCCL, kernels through the host
-    emulator, a small instance of the same model (AVSR_BENCH_SELFTEST, a test-suite-only hook in bench.py).  Executes the
-    whole N > 1 control flow -- process group, cross-rank BatchNorm, DDP buckets, W / sum(B) rescale, barriers,
-    max-over-ranks timing, the rank-0 JSON line -- and checks the contract fields of that line."""
+@pytest.mark.parametrize("launch", ["torchrun-auto", "plain-hang-fallback", "torchrun-buckets"])
+def test_bench_main_two_ranks(emu_lib_path, tmp_path, launch):
+    """bench.py's own main() for N = 2 on two CPU processes: gloo instead of RCCL (comm.GroupComm stands in for the C-API
+    communicators), kernels through the host emulator, a small instance of the same model (AVSR_BENCH_SELFTEST, a
+    test-suite-only hook in bench.py).  Executes the whole N > 1 control flow -- supervisor + worker processes, process group,
+    cross-rank BatchNorm through a communicator, gradient buckets on a second communicator, W / sum(B) rescale, barriers,
+    max-over-ranks timing, the rank-0 JSON line -- and checks the contract fields of that line.
+      torchrun-auto        launched exactly as the driver launches it (`python -m torch.distributed.run --nproc-per-node 2 ...
+                           bench.py --gpus 2 ...`): the default mode, buckets-graph (two communicators);
+      plain-hang-fallback  launched as plain `python bench.py --gpus 2` (bench.py starts its own ranks), and one rank of the
+                           first mode never arrives (AVSR_BENCH_TEST_HANG): the supervisor's wall-clock limit kills the attempt
+                           and the single-communicator mode runs instead;
+      torchrun-buckets     --ddp buckets: the same exchange on torch.distributed collectives."""
     import json
     import subprocess
 
@@ -258,22 +264,31 @@ def test_bench_main_two_ranks(emu_lib_path, tmp_path, ddp):
            "model": dict(adim=128, aheads=2, eunits=128, elayers=1, dunits=128, dlayers=1, cnn_module_kernel=7)}
     env = dict(os.environ, AVSR_BENCH_SELFTEST=json.dumps(cfg), OMP_NUM_THREADS="2")
     port = 35500 + os.getpid() % 2000
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--max-frames", "12", "--shapes", "2"] + ([] if ddp == "auto" else ["--ddp", ddp])  # auto = what the driver runs
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--max-frames", "12", "--shapes", "2"]
+    if launch == "plain-hang-fallback":
+        env.update(AVSR_BENCH_TEST_HANG="buckets-graph", AVSR_BENCH_ATTEMPT_TIMEOUT="45,400,400", MASTER_PORT=str(port))
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + tail + (["--ddp", "buckets"] if launch == "torchrun-buckets" else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout  # rank 0 prints ONE line
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["value"] > 0 and out["ms_per_step"] > 0 and out["higher_is_better"] is True
-    # --ddp torch: DistributedDataParallel (the default); --ddp buckets: auto_avsr_amd.ddp.GradBuckets (one gather launch + one
-    # async all-reduce per bucket, issued from post-accumulate-grad hooks)
-    # (auto: on GPUs the graph-replayed bucket exchange on RCCL's C API; under the CPU self-test hook it resolves to torch DDP)
-    want = "DDP grad all-reduce + SyncBN" if ddp in ("torch", "auto") else "gradient all-reduce overlapped with backward (auto_avsr_amd.ddp) + SyncBN"
-    assert want in out["config"]["workload"] and "eager launches" in out["config"]["workload"]
-    assert out["config"]["final_loss"] == out["config"]["final_loss"]  # finite
+    c = out["config"]
+    assert "gradient all-reduce overlapped with backward (auto_avsr_amd.ddp) + SyncBN" in c["workload"] and "eager launches" in c["workload"]
+    assert c["rccl_ranks"] == 2 and c["grad_wire"] == "f32"
+    if launch == "torchrun-auto":
+        assert c["ddp_mode"] == "buckets-graph" and c["attempt"] == 0 and c["communicators"] == 2
+    elif launch == "plain-hang-fallback":
+        assert c["ddp_mode"] == "buckets-graph1" and c["attempt"] == 1 and c["communicators"] == 1
+        assert "hang guard" in r.stderr and "falling back to --ddp buckets-graph1" in r.stderr
+    else:
+        assert c["ddp_mode"] == "buckets" and c["communicators"] == 0
+    assert c["final_loss"] == c["final_loss"]  # finite
 
 
 def test_bench_main_audio_babble_leg(emu_lib_path):
@@ -295,7 +310,7 @@ def test_bench_main_audio_babble_leg(emu_lib_path):
     assert out["config"]["final_loss"] == out["config"]["final_loss"]
 
 
-def _worker_buckets(rank, world, port, emu_path, out_dir):
+def _worker_buckets(rank, world, port, emu_path, out_dir, transport="group", wire="f32"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -312,8 +327,15 @@ def _worker_buckets(rank, world, port, emu_path, out_dir):
                               torch.nn.Linear(129, 5, bias=False))
     ref.load_state_dict(net.state_dict())
     ddp = torch.nn.parallel.DistributedDataParallel(ref)
-    gb = GradBuckets(net.parameters(), group=dist.group.WORLD, bucket_mb=0.02)  # ~5 k floats per bucket: several buckets
+    if transport == "comm":
+        # the `comm=` control flow (what bench.py's default N > 1 mode runs on RCCL's C API) on the gloo stand-in of StreamComm
+        from auto_avsr_amd.comm import GroupComm
+
+        gb = GradBuckets(net.parameters(), group=dist.group.WORLD, bucket_mb=0.02, comm=GroupComm(), wire=wire)
+    else:
+        gb = GradBuckets(net.parameters(), group=dist.group.WORLD, bucket_mb=0.02)  # ~5 k floats per bucket: several buckets
     assert len(gb.flat) >= 3
+    tol = dict(rtol=1e-6, atol=1e-7) if wire == "f32" else dict(rtol=2e-2, atol=2e-4)  # bf16 wire: 8 significant bits per hop
     g = torch.Generator().manual_seed(100 + rank)  # different data per rank
     for step in range(3):
         x = torch.randn(11 + rank, 37, generator=g)
@@ -322,7 +344,7 @@ def _worker_buckets(rank, world, port, emu_path, out_dir):
         gb.finish()
         for p, q in zip(net.parameters(), ref.parameters()):
             assert p.grad.data_ptr() == gb.views[[id(t) for t in gb.params].index(id(p))].data_ptr(), "grad must be the bucket view"
-            assert torch.allclose(p.grad, q.grad, rtol=1e-6, atol=1e-7), float((p.grad - q.grad).abs().max())
+            assert torch.allclose(p.grad, q.grad, **tol), float((p.grad - q.grad).abs().max())
         for p in list(net.parameters()) + list(ref.parameters()):
             p.grad = None
     # a parameter that gets no gradient is an error at finish(), as with find_unused_parameters=False
@@ -340,12 +362,14 @@ def _worker_buckets(rank, world, port, emu_path, out_dir):
     dist.destroy_process_group()
 
 
-def test_grad_buckets_match_torch_ddp(emu_lib_path, tmp_path):
+@pytest.mark.parametrize("transport,wire", [("group", "f32"), ("comm", "f32"), ("comm", "bf16")])
+def test_grad_buckets_match_torch_ddp(emu_lib_path, tmp_path, transport, wire):
     """auto_avsr_amd.ddp.GradBuckets (flat buckets, one gather launch + one async all-reduce per bucket, issued from
     post-accumulate-grad hooks) gives the gradients torch's DistributedDataParallel gives: two gloo ranks, different data per
-    rank, three steps, several buckets, `.grad` re-pointed at the bucket views."""
-    port = 29500 + (os.getpid() + 7) % 2000
-    mp.spawn(_worker_buckets, args=(2, port, emu_lib_path, str(tmp_path)), nprocs=2, join=True)
+    rank, three steps, several buckets, `.grad` re-pointed at the bucket views.  transport "comm": the stream-communicator
+    control flow of the default N > 1 mode (comm.GroupComm stands in for RCCL's C API); wire "bf16": the narrow wire format."""
+    port = 29500 + (os.getpid() + 7 + 13 * len(transport + wire)) % 2000
+    mp.spawn(_worker_buckets, args=(2, port, emu_lib_path, str(tmp_path), transport, wire), nprocs=2, join=True)
     assert os.path.exists(os.path.join(tmp_path, "ok"))
 
 

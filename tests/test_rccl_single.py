@@ -25,17 +25,20 @@ def test_ddp_syncbn_fused_optimizer_on_single_rank_rccl():
     assert out["losses_bf16_grad_buckets"] == pytest.approx(out["losses_bf16_rccl"], rel=2e-2)
 
 
-def test_data_parallel_step_on_rccl_c_api_captured_into_hipgraph():
+@pytest.mark.parametrize("wire", ["f32", "bf16"])
+def test_data_parallel_step_on_rccl_c_api_captured_into_hipgraph(wire):
     """tools/rccl_capi_world1.py: GradBuckets + cross-rank BatchNorm + batch-size all-gather through this library's own RCCL
     binding (csrc/comm.hip: every collective a stream operation), one rank -- eager losses equal to the plain step, and the
     WHOLE data-parallel step (52 gradient buckets on their side stream, the BatchNorm collectives, the fused optimizer) captured
     into one hipGraph and replayed five times with a falling, finite loss (round 3: the bucket gathers used to be issued on
     the AccumulateGrad streams, which raced with the producers' allocator and showed as NaN gradients in replays)."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_capi_world1.py"), "--small", "--bucket-mb", "0.25"],
-                       capture_output=True, text=True, cwd=ROOT, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+                       capture_output=True, text=True, cwd=ROOT, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", AVSR_GRAD_WIRE=wire))
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-4000:]
     out = json.loads(lines[-1])
+    assert out["grad_wire"] == wire  # bf16: the narrow wire format (cast -> ncclBfloat16 all-reduce -> cast back) inside the graph
     assert out["graph_capture"] == "ok" and out["graph_replay_moved_params"] and out["buckets"] > 10
     assert out["graph_loss"] == out["graph_loss"] and out["graph_loss"] < out["losses_capi"][1]
     assert out["losses_capi"] == pytest.approx(out["losses_plain"], rel=2e-2)

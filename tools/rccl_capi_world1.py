@@ -102,6 +102,7 @@ out["comm_world"] = comm.world
 m1, gb, opt1, step1 = make(comm)
 out["losses_capi"] = eager(step1, m1)
 out["buckets"] = len(gb.flat) if gb is not None else 0
+out["grad_wire"] = gb.wire if gb is not None else None  # AVSR_GRAD_WIRE=bf16: the buckets travel as bf16 (ncclBfloat16 sums)
 assert all(abs(a - b) <= 2e-2 * abs(a) for a, b in zip(out["losses_plain"], out["losses_capi"])), out
 print(json.dumps(dict(out, stage="before-capture")), flush=True)
 AF.refresh_weight_cache()
