@@ -63,27 +63,34 @@ class FusedAdamW:
         index = {p.data_ptr(): i for i, p in enumerate(self.params)}
         covered = np.zeros(len(self.params), dtype=bool)
         tiles, blk = [], 0
+        h16 = AF.h16_copies()  # mixed mode: f16 forward copies, rewritten in the same tile pass
+        h16_keys = []
         for (w, dst, dstT, R, C, ldT, limT) in groups:
             i = index.get(w.data_ptr())
             if i is None or covered[i] or self.params[i].numel() != R * C:
                 continue  # not ours (frozen) -- or an alias we cannot express: the ordinary re-cast must stay
             covered[i] = True
             tiles_c = (C + 63) // 64
+            d16 = 0
+            if w.data_ptr() in h16 and h16[w.data_ptr()][0][1] == (R, C):
+                h16_keys.append(h16[w.data_ptr()][0])
+                d16 = h16[w.data_ptr()][1].data_ptr()
             tiles.append((i, dst.data_ptr() if dst is not None else 0, dstT.data_ptr() if dstT is not None else 0,
-                          R, C, ldT, blk, tiles_c, limT))
+                          R, C, ldT, blk, tiles_c, limT, d16))
             blk += ((max(R, limT) + 63) // 64) * tiles_c
         ours = sum(1 for g in groups if g[0].data_ptr() in index)
         if not tiles or len(tiles) != ours:
             self._cast_plan = (gen, None)
             return self._cast_plan
         trow = np.zeros(len(tiles), dtype=np.dtype([("ptr", "<u8", 6), ("i", "<i4", 8)]))
-        for k, (i, d, dT, R, C, ldT, b0, tc, limT) in enumerate(tiles):
+        for k, (i, d, dT, R, C, ldT, b0, tc, limT, d16) in enumerate(tiles):
             trow["ptr"][k] = (self._rows[i, 0], 0, self._rows[i, 2], self._rows[i, 3], d, dT)
             trow["i"][k] = (R, C, ldT, b0, tc, limT, 0, 0)
+            trow["i"][k].view(np.uint32)[6:8] = (d16 & 0xFFFFFFFF, d16 >> 32)  # the two spare words hold the f16 copy's address
         lin = self._rows[~covered].copy()
         nb = (lin[:, 4].astype(np.int64) + _CHUNK - 1) // _CHUNK
         lin[:, 5] = (np.cumsum(nb) - nb).astype(np.uint64)
-        self._cast_plan = (gen, covered, lin, int(nb.sum()), trow, blk, np.array([t[0] for t in tiles]))
+        self._cast_plan = (gen, covered, lin, int(nb.sum()), trow, blk, np.array([t[0] for t in tiles]), h16_keys)
         return self._cast_plan
 
     def _table(self, grads, plan=None):
@@ -104,7 +111,7 @@ class FusedAdamW:
             blk = self._blocks
             blob = rows.reshape(-1).view(np.uint8)
             if plan is not None:
-                _, covered, lin, lin_blk, trow, tile_blk, tidx = plan
+                _, covered, lin, lin_blk, trow, tile_blk, tidx, _ = plan
                 lin = lin.copy()
                 lin[:, 1] = rows[~covered, 1]
                 trow = trow.copy()
@@ -145,7 +152,7 @@ class FusedAdamW:
             self._note_stale(AF, False)  # parameters changed behind `_version`: their cached bf16 copies are stale
             return
 
-        gen, _, lin, lin_blk, trow, tile_blk, _ = plan
+        gen, _, lin, lin_blk, trow, tile_blk, _, h16_keys = plan
         base = table.data_ptr()
         lin_ptr, tile_ptr = base + 48 * n, base + 48 * n + 48 * len(lin)
         ops.call("avsr_adamw_cast_step", base, n, blk, lin_ptr, len(lin), lin_blk, tile_ptr, len(trow), tile_blk,
@@ -153,6 +160,7 @@ class FusedAdamW:
                  self.weight_decay, self.max_grad_norm, self.warmup_steps, self.total_steps, ops._stream(table),
                  nbytes=self._algo_bytes(True))
         AF.claim_weight_casts(self, gen)  # refresh_weight_cache() now has nothing to do for the Linear copies
+        AF.claim_h16_copies(h16_keys)     # ... nor for the f16 forward copies this pass rewrote (mixed mode)
         self._note_stale(AF, True)        # ... but the conv-weight permutes are stale until it runs
 
     def _algo_bytes(self, cast):

@@ -445,7 +445,8 @@ int avsr_multi_copy_scale(const void* table, int n, int total_blocks, float scal
  *   table / n / total_blocks          every parameter (48-byte entries as above) -- gradient norm only
  *   lin_table / lin_n / lin_blocks    parameters updated by the linear kernel (same format, own blk0 numbering)
  *   tile_table / tile_n / tile_blocks 80-byte entries {float* p, const float* g, float* m, float* v, bf16* dst,
- *       bf16* dstT (either may be 0), int R, C, ldT, blk0, tiles_c, limT, 0, 0}: weight [R][C] updated in 64x64 tiles,
+ *       bf16* dstT (either may be 0), int R, C, ldT, blk0, tiles_c, limT, f16* dst16 (may be 0: IEEE-half [R][C] copy, the
+ *       forward operand of the mixed mode's f16 components)}: weight [R][C] updated in 64x64 tiles,
  *       dst = bf16 [R][C], dstT = bf16 [C][ldT] (rows [R, limT) zero; limT 0 = ldT), blk0 = running sum of
  *       ceil(max(R, limT ? limT : ldT)/64) * ceil(C/64)
  * Every parameter must appear in exactly one of lin_table / tile_table. */

@@ -113,6 +113,44 @@ def test_fused_adamw_cast_weights(dev):
     AF.invalidate_weight_cache()
 
 
+def test_fused_adamw_writes_f16_forward_copies(dev):
+    """Mixed mode: the f16 forward copies (functional._w_h16 / _w_h16_cat: dense weights and row slices of a fused Q/K/V buffer)
+    of weights the tile pass updates are rewritten in that pass; the per-step refresh then only re-casts f16 copies the optimizer
+    does not cover (a weight without any bf16 copy, e.g. linear_pos: updated by the linear kernel)."""
+    from auto_avsr_amd import functional as AF
+
+    torch.manual_seed(6)
+    AF.invalidate_weight_cache()
+    shapes = [(128, 64), (64, 64), (64, 64), (64, 64), (64, 128), (64,)]
+    ps = [torch.nn.Parameter(torch.randn(s).to(dev)) for s in shapes]
+    opt = FusedAdamW(ps, lr=1e-2, weight_decay=0.03, max_grad_norm=1.0, cast_weights=True)
+    for w in (ps[0], ps[1], ps[2], ps[3]):
+        AF._w_bf16(w, True)               # (the data-gradient copies every Linear of the model has)
+    h0 = AF._w_h16(ps[0])
+    hcat = AF._w_h16_cat((ps[1], ps[2], ps[3]))
+    h4 = AF._w_h16(ps[4])                 # no bf16 copy registered: not in the tile plan
+    for it in range(2):
+        for q in ps:
+            q.grad = torch.randn_like(q)
+        opt.step()
+        assert torch.equal(h0.cpu(), ps[0].detach().cpu().half())
+        assert torch.equal(hcat.cpu(), torch.cat([ps[1], ps[2], ps[3]]).detach().cpu().half())
+        assert AF._wh16_owned == {(w.data_ptr(), tuple(w.shape)) for w in ps[:4]}
+        assert not torch.equal(h4.cpu(), ps[4].detach().cpu().half())  # stale until the refresh
+        calls = []
+        orig = AF.ops.multi_cast_transpose
+        AF.ops.multi_cast_transpose = lambda t, n, b: (calls.append(n), orig(t, n, b))
+        try:
+            with AF.numerics("mixed"):
+                AF.refresh_weight_cache()
+        finally:
+            AF.ops.multi_cast_transpose = orig
+        assert calls == [1], calls        # ONE table entry: the uncovered weight
+        assert torch.equal(h4.cpu(), ps[4].detach().cpu().half())
+        assert AF._w_h16(ps[0]) is h0 and AF._w_h16(ps[4]) is h4
+    AF.invalidate_weight_cache()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("cast", [False, True], ids=["plain", "cast_weights"])
 def test_fused_adamw_under_hipgraph(cast):
