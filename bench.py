@@ -583,11 +583,11 @@ KERNELS_OF = {"avsr_gemm_bf16_nt": r"^gemm_fast_kernel<\d+, \d+, \d+, 0,", "avsr
 def counter_traffic(pattern):
     """HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, calibrated) of the kernels matching `pattern`, from the committed
     summary of the two rocprofv3 --pmc passes over one eager step of this workload (tools/pmc_step.py, tools/pmc_report.py ->
-    profiles/r3_hbm_traffic.json; tools/r3_pmc.sh is the recipe).  PMC counters cannot be read from inside this process; the
+    profiles/r4_hbm_traffic.json; tools/r4_pmc.sh is the recipe).  PMC counters cannot be read from inside this process; the
     passes are separate runs, as the profiling guide prescribes.  None when the summary is absent."""
     import re
 
-    path = os.path.join(ROOT, "profiles", "r3_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r4_hbm_traffic.json")
     if not os.path.exists(path):
         return None, None
     tr = json.load(open(path))
@@ -599,7 +599,7 @@ def counter_traffic(pattern):
             wr += k["wr_bytes"]
     if n == 0:
         return None, None
-    return round((rd + wr) / n), f"profiles/r3_hbm_traffic.json ({tr.get('shape', '')}): {int(n)} launches, read {rd / 1e6:.0f} MB + written {wr / 1e6:.0f} MB"
+    return round((rd + wr) / n), f"profiles/r4_hbm_traffic.json ({tr.get('shape', '')}): {int(n)} launches, read {rd / 1e6:.0f} MB + written {wr / 1e6:.0f} MB"
 
 
 def roofline(model, batch, ops):

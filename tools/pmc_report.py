@@ -17,6 +17,9 @@ import re
 import sqlite3
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kname import clean  # noqa: E402
+
 
 def load(path, counter):
     if os.path.isdir(path):
@@ -39,25 +42,26 @@ def load(path, counter):
     for name, st, en, ev, gx, gy, gz in cur.execute(
             f"select s.{name_col}, d.start, d.end, d.event_id, d.grid_size_x, d.grid_size_y, d.grid_size_z from {kd} d "
             f"join {ks} s on d.kernel_id = s.id order by d.start"):
-        name = name.replace("(anonymous namespace)::", "").replace("avsr_gemm_impl::", "")
-        name = re.sub(r"^void ", "", re.sub(r"\((?!.*<).*$", "", name))
+        name = clean(name)
         rows.append((name, (en - st) * 1e-3, vals.get(ev, 0.0), gx * gy * gz))
     return rows
 
 
 # kernel families: (label, regex over rocprofv3 kernel names, C-ABI entry points whose launches they are)
 FAMILIES = [
-    ("transformer GEMMs (Linear fwd / dgrad NT, wgrad TN, paired launches)", r"^(gemm_fast_kernel<\d+, \d+, \d+, 0,|gemm_pair_kernel|gemm_tn_fast_kernel<3, 0>)",
-     ("avsr_gemm_bf16_nt", "avsr_gemm_bf16_tn")),
-    ("ResNet conv fwd / dgrad (implicit GEMM + the patch-staged 64-channel kernel)", r"^(gemm_fast_kernel<\d+, \d+, \d+, [12],|conv3x3_c64_kernel)", ("avsr_conv2d_bf16",)),
+    ("transformer GEMMs (Linear fwd NT on f16 / bf16 / split planes, dgrad NT, wgrad TN, paired launches)",
+     r"^(gemm_fast_kernel<\d+, \d+, \d+, 0,|gemm_pair_kernel|gemm_tn_fast_kernel<3, 0>|gemm_split_kernel<\d+, \d+, \d+, 0,)",
+     ("avsr_gemm_bf16_nt", "avsr_gemm_bf16_tn", "avsr_gemm_h16_nt", "avsr_gemm_f32s_nt")),
+    ("ResNet conv fwd / dgrad (implicit GEMM on f16 / bf16 / split planes + the patch-staged 64-channel kernel)",
+     r"^(gemm_fast_kernel<\d+, \d+, \d+, [12],|conv3x3_c64_kernel|gemm_split_kernel<\d+, \d+, \d+, 1,)", ("avsr_conv2d_bf16", "avsr_conv2d_h16", "avsr_conv2d_f32s")),
     ("ResNet 3x3 conv wgrad", r"^(conv3x3_wgrad_kernel|wgrad_reduce_kernel)", ("avsr_conv3x3_wgrad_bf16",)),
     ("BatchNorm passes", r"^bn_", ("avsr_bn_stats", "avsr_bn_stats_finalize", "avsr_bn_act_fwd", "avsr_bn_bwd_reduce", "avsr_bn_bwd_apply",
                                   "avsr_bn_act_pool_fwd", "avsr_bn_pool_bwd_reduce", "avsr_bn_pool_bwd_apply", "avsr_bn_small_fwd",
-                                  "avsr_bn_small_bwd")),
-    ("LayerNorm fwd / bwd", r"^layernorm_", ("avsr_layernorm_fwd", "avsr_layernorm_bwd")),
+                                  "avsr_bn_small_bwd", "avsr_bn_act_fwd2", "avsr_bn_act_fwd_h16", "avsr_bn_small_fwd2", "avsr_bn_small_fwd_h16")),
+    ("LayerNorm fwd / bwd", r"^layernorm_", ("avsr_layernorm_fwd", "avsr_layernorm_bwd", "avsr_layernorm_fwd2", "avsr_layernorm_fwd_h16")),
     ("optimizer (clip + AdamW + bf16 weight copies)", r"^(multi_adamw|multi_sumsq|clip_coef)", ("avsr_adamw_step", "avsr_adamw_cast_step")),
-    ("video stem conv fwd / wgrad", r"^stem_", ("avsr_stem357_fwd", "avsr_stem357_wgrad")),
-    ("depthwise conv fwd / dgrad / wgrad", r"^dwconv_", ("avsr_dwconv_fwd", "avsr_dwconv_wgrad")),
+    ("video stem conv fwd / wgrad", r"^stem_", ("avsr_stem357_fwd", "avsr_stem357_wgrad", "avsr_stem357_fwd_f32s")),
+    ("depthwise conv fwd / dgrad / wgrad", r"^dwconv_", ("avsr_dwconv_fwd", "avsr_dwconv_wgrad", "avsr_dwconv_fwd2", "avsr_dwconv_fwd_h16")),
     ("max-pool fwd / bwd", r"^maxpool_", ("avsr_maxpool2d_fwd", "avsr_maxpool2d_bwd")),
 ]
 

@@ -26,7 +26,8 @@ dev = torch.device("cuda:0")
 ops.apply_env_tuning()
 torch.manual_seed(0)
 model = E2E(5049, "video").to(dev).train()
-AF.set_precise(False)
+MODE = os.environ.get("AVSR_PMC_MODE", "mixed")  # the numerical mode bench.py times by default
+AF.set_mode(MODE)
 AF.manual_seed(1234)
 seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
 AF.set_seed_tensor(seed_dev)
@@ -85,7 +86,7 @@ ops.sum_scale(mark, 1.0)
 torch.cuda.synchronize()
 info = {"B": int(x.shape[0]), "T": int(x.shape[1]), "L": int(y.shape[2]), "real_frames": int(frames),
         "loss": float(loss.detach()),
-        "shape": f"video, B={int(x.shape[0])} T={int(x.shape[1])} L={int(y.shape[2])}, {int(frames)} real frames, bf16 mode, "
+        "shape": f"video, B={int(x.shape[0])} T={int(x.shape[1])} L={int(y.shape[2])}, {int(frames)} real frames, {MODE} mode, "
                  "full training step (fwd + bwd + clip + AdamW), eager launches",
         "entries": {k: {"calls": v[0], "flops": v[1], "bytes": v[2]} for k, v in per_entry.items()}}
 os.makedirs("gpurun_out", exist_ok=True)

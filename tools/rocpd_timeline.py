@@ -3,9 +3,13 @@ optimizer updates, with its start offset, duration, the idle gap since the previ
 Usage: python tools/rocpd_timeline.py <results.db> <out.txt> [steps_back]
 The summary at the top gives launches, busy time, idle time and the per-kernel totals of that single step -- the place to
 see what a graph replay really executes (framework kernels included) and where the device waits."""
+import os
 import re
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kname import clean  # noqa: E402
 
 
 def main():
@@ -31,9 +35,7 @@ def main():
     busy = gaps = 0.0
     prev_end = None
     for i, (name, st, en, g, w) in enumerate(step):
-        name = name.replace("(anonymous namespace)::", "").replace("avsr_gemm_impl::", "").replace("void ", "")
-        name = re.sub(r"\((?!.*<).*$", "", name)
-        name = re.sub(r"at::native::", "", name)
+        name = re.sub(r"at::native::", "", clean(name))
         dur = (en - st) * 1e-3
         gap = (st - prev_end) * 1e-3 if prev_end is not None else 0.0
         prev_end = max(en, prev_end or en)
