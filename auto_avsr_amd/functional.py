@@ -1170,6 +1170,7 @@ class LayerNormFn(torch.autograd.Function):
 
 
 def layer_norm(x, gamma, beta, eps=1e-12, out_dtype=torch.float32):
+    _state["tag_ok"] = torch.is_grad_enabled()
     return LayerNormFn.apply(_to_f32(x), gamma, beta, eps, out_dtype)
 
 
@@ -1229,6 +1230,7 @@ class LinearFn(torch.autograd.Function):
 
 
 def linear(x, w, b=None, out_dtype=None, pad_out=False):
+    _state["tag_ok"] = torch.is_grad_enabled()
     return LinearFn.apply(x, w, b, out_dtype or act_dtype(), pad_out)
 
 
@@ -1329,6 +1331,12 @@ class FfnFn(torch.autograd.Function):
         return dx, dw1, db1, dw2, db2, None
 
 
+def ffn(x, w1, b1, w2, b2, p):
+    """Stand-alone PositionwiseFeedForward.forward (positionwise_feed_forward.py:28-30)."""
+    _state["tag_ok"] = torch.is_grad_enabled()
+    return FfnFn.apply(x, w1, b1, w2, b2, float(p))
+
+
 class MlpFn(torch.autograd.Function):
     """Two-layer perceptron with its own input / hidden / output widths: W2 relu(W1 x + b1) + b2  (f32 out).
     The fusion head of the audio-visual model (e2e_av.py); same kernels and backward structure as FfnFn."""
@@ -1366,6 +1374,7 @@ class MlpFn(torch.autograd.Function):
 
 
 def mlp(x, w1, b1, w2, b2):
+    _state["tag_ok"] = torch.is_grad_enabled()
     return MlpFn.apply(x, w1, b1, w2, b2)
 
 
@@ -1484,6 +1493,7 @@ class AttentionCoreFn(torch.autograd.Function):
 
 
 def attention_core(q_in, kv_in, pos_emb, mask, wq, bq, wk, bk, wv, bv, wo, bo, wpos, bias_u, bias_v, H, p_attn):
+    _state["tag_ok"] = torch.is_grad_enabled()
     same = kv_in is q_in
     return AttentionCoreFn.apply(q_in, q_in if same else kv_in, pos_emb, mask, wq, bq, wk, bk, wv, bv, wo, bo, wpos,
                                  bias_u, bias_v, H, float(p_attn), same)
@@ -2329,4 +2339,5 @@ class AvgPoolFn(torch.autograd.Function):
 
 
 def avg_pool(x, groups, win, C):
+    _state["tag_ok"] = torch.is_grad_enabled()
     return AvgPoolFn.apply(x, groups, win, C)

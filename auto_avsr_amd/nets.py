@@ -42,7 +42,7 @@ class PositionwiseFeedForward(nn.Module):
 
     def forward(self, x):
         p = self.dropout.p if self.training else 0.0
-        return AF.FfnFn.apply(x, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias, p)
+        return AF.ffn(x, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias, p)
 
 
 class MultiHeadedAttention(nn.Module):

@@ -83,7 +83,24 @@ def validate(model, batches, world):
 
 def fit(model, args, dev, rank=0, world=1, backend="nccl", log=print):
     """The training loop proper, on an already constructed `E2E`-like model (tests run it on a small instance over
-    gloo + the emulator).  Returns the list of per-step losses of this rank."""
+    gloo + the emulator).  Returns the list of per-step losses of this rank.  Whatever the loop attached to the model or the
+    process -- gradient-bucket hooks on the parameters, RCCL communicators, the cross-rank BatchNorm switch -- is released on
+    the way out, also when a step raises: a second fit() on the same model (fine-tuning after pre-training in one process)
+    starts clean instead of running two hook sets on stale communicators."""
+    from . import functional as AF
+
+    held = {"buckets": None, "comms": []}
+    try:
+        return _fit(model, args, dev, rank, world, backend, log, held)
+    finally:
+        if held["buckets"] is not None:
+            held["buckets"].remove()
+        for c in held["comms"]:
+            c.close()
+        AF.set_bn_sync(None)
+
+
+def _fit(model, args, dev, rank, world, backend, log, held):
     from . import functional as AF
     from .optim import FusedAdamW
     from .synthetic import bucket_batches, make_batch, rank_batches, utterance_lengths
@@ -107,8 +124,9 @@ def fit(model, args, dev, rank=0, world=1, backend="nccl", log=print):
                 from .comm import StreamComm
 
                 comm_bn, comm_grads = StreamComm.from_process_group(), StreamComm.from_process_group()
+                held["comms"] += [comm_bn, comm_grads]
                 AF.set_bn_sync(dist.group.WORLD, comm=comm_bn)
-            buckets = GradBuckets(model.parameters(), group=dist.group.WORLD, bucket_mb=64, comm=comm_grads)
+            buckets = held["buckets"] = GradBuckets(model.parameters(), group=dist.group.WORLD, comm=comm_grads)
         else:
             hot = torch.nn.parallel.DistributedDataParallel(
                 hot, device_ids=[dev.index] if dev.type == "cuda" else None, find_unused_parameters=False,
@@ -190,7 +208,6 @@ def fit(model, args, dev, rank=0, world=1, backend="nccl", log=print):
             from average_checkpoints import ensemble
 
             log(f"averaged checkpoint: {ensemble(args)}")
-    AF.set_bn_sync(None)
     return losses
 
 

@@ -169,7 +169,7 @@ def cpu_baseline(modality, odim):
     sd = synth_state_dict(tmpl.state_dict(), 0)
     del tmpl
     sd = {k: (v.requires_grad_() if v.is_floating_point() and "running_" not in k else v) for k, v in sd.items()}
-    lengths = [200, 190]  # half of the survey's batch A per utterance pair: 400 padded / 390 real frames per iteration
+    lengths = [400, 380]  # the first two utterances of the survey's batch A at its full length T = 400: 780 real frames per iteration
     x, lens, y, frames = make_batch(lengths, [0, 1], modality, odim, seed=1)
     times = []
     for it in range(4):
@@ -186,8 +186,8 @@ def cpu_baseline(modality, odim):
             "value_best": round(frames / min(times), 2),
             "sample": f"fwd+bwd of the fp32 oracle (oracle/avsr_oracle.py, a CPU restatement pinned against the reference: "
                       f"/root/reference does not exist on the GPU box, so the reference E2E itself cannot be timed here) on "
-                      f"{cores} threads, B=2 T=200 ({frames} real frames per iteration; half of SURVEY batch A per utterance "
-                      f"pair), 1 warm-up + 3 timed iterations: median {med:.2f}s, min {min(times):.2f}s",
+                      f"{cores} threads, B=2 T=400 ({frames} real frames per iteration: the first two utterances of SURVEY batch A at "
+                      f"full length), 1 warm-up + 3 timed iterations: median {med:.2f}s, min {min(times):.2f}s",
             "reference_itself": {"value": 85.5, "unit": "video-frames/sec", "cores": 8,
                                  "note": "the reference's own E2E fwd+bwd on batch A, measured in the survey container "
                                          "(BASELINE.md section 3); not re-measurable on the GPU box"}}

@@ -43,9 +43,14 @@ class DeviceBatches:
 
     def __init__(self, loader, dataset, device, single=False):
         self.loader, self.ds, self.device, self.single = loader, dataset, torch.device(device), single
+        self.epoch = 0
 
     def __len__(self):
         return len(self.loader)
+
+    @property
+    def sampler(self):  # (what a trainer looks at to find a DistributedSampler)
+        return getattr(self.loader, "sampler", None)
 
     def _inputs(self, raws):
         from auto_avsr_amd import transforms as TR
@@ -57,6 +62,13 @@ class DeviceBatches:
         return TR.audio_batch(xs, at.subset, at.add_noise)
 
     def __iter__(self):
+        # This wrapper is not a DataLoader, so a trainer that injects a DistributedSampler into DataLoaders (Lightning) cannot
+        # shard it: DataModule builds the sampler itself when a process group is up, and every pass over the loader is an epoch
+        # (DistributedSampler.set_epoch: a fresh, rank-consistent shuffle per epoch).
+        smp = self.sampler
+        if hasattr(smp, "set_epoch"):
+            smp.set_epoch(self.epoch)
+        self.epoch += 1
         for item in self.loader:
             if self.single:
                 x, _ = self._inputs([item["input"]])
@@ -130,19 +142,33 @@ class DataModule(_DMBase):
     def _workers(self):
         return 0 if getattr(self.args, "synthetic_utterances", 0) else self.num_workers
 
+    @staticmethod
+    def _dist_sampler(ds, shuffle):
+        """One process per GPU (train.py:30-42): every rank must see its own share of the pre-formed batches.  The reference
+        leaves that to Lightning, which swaps a DistributedSampler into plain DataLoaders; the loaders of this build may be
+        wrapped (DeviceBatches), so the sampler is built here whenever a process group exists -- a trainer that finds a
+        DistributedSampler already in place keeps it and only calls set_epoch()."""
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return None
+        return torch.utils.data.distributed.DistributedSampler(ds, shuffle=shuffle, seed=0, drop_last=False)
+
     def train_dataloader(self):
         base = self._dataset("train", self.args.train_file)
         ds = CustomBucketDataset(base, base.input_lengths, self.args.max_frames, self.train_num_buckets,
                                  batch_size=self.batch_size)
         raw = getattr(base, "raw", False)
-        return self._finish(torch.utils.data.DataLoader(ds, num_workers=self._workers(), batch_size=None, shuffle=self.train_shuffle,
+        smp = self._dist_sampler(ds, self.train_shuffle)
+        return self._finish(torch.utils.data.DataLoader(ds, num_workers=self._workers(), batch_size=None,
+                                                        shuffle=self.train_shuffle and smp is None, sampler=smp,
                                                         collate_fn=_identity if raw else collate_pad), base)
 
     def val_dataloader(self):
         base = self._dataset("val", self.args.val_file)
         ds = CustomBucketDataset(base, base.input_lengths, 1000, 1, batch_size=self.batch_size)
         raw = getattr(base, "raw", False)
-        return self._finish(torch.utils.data.DataLoader(ds, batch_size=None, num_workers=self._workers(),
+        return self._finish(torch.utils.data.DataLoader(ds, batch_size=None, num_workers=self._workers(), sampler=self._dist_sampler(ds, False),
                                                         collate_fn=_identity if raw else collate_pad), base)
 
     def test_dataloader(self):

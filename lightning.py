@@ -103,6 +103,9 @@ class ModelModule(_Base):
         return loss
 
     def training_step(self, batch, batch_idx):
+        from auto_avsr_amd import functional as AF
+
+        AF.new_step()  # per-step registries of the kernels' autograd glue (zero-scratch arena, twin / hand-over tables)
         loss = self._step(batch, batch_idx, "train")
         if HAVE_LIGHTNING:
             sizes = self.all_gather(batch["inputs"].size(0))

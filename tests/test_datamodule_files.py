@@ -80,3 +80,39 @@ def test_datamodule_file_backed_loaders(dev, tmp_path, monkeypatch, modality):
         want = TR.VideoTransform("test")(clips[rel].permute(0, 3, 1, 2).to(dev))
     assert torch.equal(tests[0]["input"].cpu(), want.cpu())
     assert tests[0]["target"].tolist() == [int(v) for v in rows[0].split(",")[3].split()]
+
+
+def test_datamodule_shards_wrapped_loaders_across_ranks(dev, tmp_path, monkeypatch):
+    """Round-3 advisor finding: the file-backed loaders are DeviceBatches wrappers, which a trainer cannot give a
+    DistributedSampler -- every rank would train on every batch.  With a process group up the DataModule shards them itself:
+    the ranks' batches are disjoint, cover the epoch, and the shuffle changes per epoch (set_epoch) consistently across ranks."""
+    import torch.distributed as dist
+
+    from datamodule.data_module import DataModule
+
+    root = str(tmp_path)
+    _write_tree(root, 23, "audio")
+    monkeypatch.setattr(TR, "load_default_noise", lambda: torch.randn(1, 40000, generator=torch.Generator().manual_seed(3)))
+    args = types.SimpleNamespace(root_dir=root, modality="audio", train_file="train.csv", val_file="val.csv", test_file="test.csv",
+                                 max_frames=30, synthetic_utterances=0)
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 2)
+    seen = {}
+    for rank in (0, 1):
+        monkeypatch.setattr(dist, "get_rank", lambda group=None, r=rank: r)
+        dm = DataModule(args, num_workers=0, device=str(dev))
+        loader = dm.train_dataloader()
+        assert isinstance(loader.sampler, torch.utils.data.distributed.DistributedSampler)
+        epochs = []
+        for _ in range(2):  # two passes = two epochs
+            epochs.append([tuple(b["input_lengths"].tolist()) + tuple(b["targets"].flatten().tolist()) for b in loader])
+        seen[rank] = epochs
+        val = dm.val_dataloader()
+        assert isinstance(val.sampler, torch.utils.data.distributed.DistributedSampler) and not val.sampler.shuffle
+    nb = len(dm.train_dataloader().loader.dataset)
+    for e in (0, 1):
+        a, b = seen[0][e], seen[1][e]
+        assert len(a) == len(b) == (nb + 1) // 2
+        assert len(set(a) | set(b)) == nb          # the two ranks cover every batch of the epoch ...
+        assert len(set(a) & set(b)) == 2 * len(a) - nb  # ... sharing only the DistributedSampler's padding batch (odd counts)
+    assert seen[0][0] != seen[0][1]                # a fresh shuffle per epoch
