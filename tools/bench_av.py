@@ -21,12 +21,13 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--mode", choices=["bf16", "mixed", "hpf"], default="mixed", help="numerical mode (functional.set_mode), as bench.py")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     odim = 5049
     model = E2EAV(odim).to(dev).train()
-    AF.set_precise(False)
+    AF.set_mode(args.mode)
     AF.manual_seed(1)
     seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
     AF.set_seed_tensor(seed_dev)
@@ -74,7 +75,9 @@ def main():
 
     print(json.dumps({"metric": "AV-fusion frames/sec (parallel audio + video encoders, shared decoder), full training step",
                       "value": round(B * T / dt, 1), "unit": "video-frames/sec", "n_gpus": 1, "steps": args.steps,
-                      "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 2), "dtype": "bf16", "data": "synthetic",
+                      "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 2),
+                      "dtype": {"bf16": "bf16", "mixed": "f16 / split-bf16 forward per component, bf16 backward", "hpf": "split-bf16 forward, bf16 backward"}[args.mode],
+                      "data": "synthetic",
                       "config": {"workload": f"configs[4] single-GPU leg: E2EAV {n / 1e6:.0f} M parameters, max-frames {args.frames} "
                                              f"=> batch ({B}, {T}, {label.shape[2]}), " + ("eager launches" if args.no_graph else "hipGraph replay"),
                                  "parity": "n/a (no AV model in the reference snapshot, SURVEY F4)"}}))
