@@ -8,6 +8,15 @@ mode, where every contraction runs on split hi/lo bf16 planes (about 1e-5 relati
 Sub-layer functions (``ffn_sublayer``, ``relpos_mha_sublayer``, ``conv_sublayer``, ``mha_sublayer``) implement
 one pre-LN residual branch each, ``x + scale * dropout(f(LN(x)))``, forward and backward, so that the residual
 add, the dropout masks, bias / activation and the LayerNorm gradient are all fused into kernel epilogues.
+
+Layout (round 4: one module per sub-layer family instead of one 2 400-line file).  THIS module: the numerical modes and
+the per-component forward policy, the twin / hand-over registries, the weight caches (bf16, split8, f16 copies), the
+shared GEMM / prologue / weight-gradient helpers, LayerNorm, Linear and the FFN functions.  ``functional_attention``:
+position projection, attention cores, MHA sub-layer, shared K / V projection.  ``functional_convmod``: BatchNorm
+plumbing + the convolution-module sub-layer.  ``functional_heads``: embedding, scale / dropout, CTC and
+label-smoothing losses.  ``functional_frontend``: ResNet block, stem, average pool.  Everything they define is
+re-exported here (bottom of the file), so callers keep saying ``functional.<name>``; run-time switches and registries
+(``_FUSE_QKV``, ``MIXED_POLICY``, ``_state`` ...) live here only and the family modules read them through this module.
 """
 import contextlib
 import os
@@ -733,86 +742,7 @@ def _bias3(bq, bk, bv):
     return torch.cat([bq, bk, bv])
 
 
-_pos_proj = {}
-
-
-def prepare_pos_proj(pos_emb, weights):
-    """bf16 mode: pos_emb [1, P, D] @ [W_0; W_1; ...]^T -> [P, n*D] in one launch; layer l's relative-position attention then
-    reads its D-column block in place (row pitch n*D) instead of running its own P x D x D projection.  The weight gradients
-    stay per layer (dW_l = dpos_l^T pe).  No-op in precise mode / for shapes the tuned kernel does not take -- the layers
-    then project on their own.  Entries are dropped by new_step()."""
-    _pos_proj.clear()
-    if _state["precise"] or len(weights) < 2 or pos_emb is None:
-        return
-    D = pos_emb.shape[-1]
-    if D % 64 or any(w.dtype != torch.float32 or not w.is_contiguous() or tuple(w.shape) != (D, D) for w in weights):
-        return
-    pe = _to_act_shared(pos_emb).reshape(-1, D)
-    if pe.dtype not in (torch.bfloat16, torch.float16):
-        return
-    n, P = len(weights), pe.shape[0]
-    if torch.is_grad_enabled() and all(w.requires_grad for w in weights):
-        # training: the projection is an autograd node of its own, so that the n weight gradients are ONE contraction too
-        holder = {}
-        out = PosProjFn.apply(pos_emb, holder, *weights)
-        for i, w in enumerate(weights):
-            _pos_proj[(pos_emb.data_ptr(), w.data_ptr())] = (pos_emb, None, out, i, holder)
-        return
-    out = torch.empty(P, n * D, dtype=pe.dtype, device=pe.device)
-    if pe.dtype == torch.float16:
-        ops.gemm_h16_nt(pe, D, _w_h16_cat(tuple(weights)), D, P, n * D, D, out, n * D)
-    else:
-        ops.gemm_bf16_nt(pe, D, _w_bf16_cat(tuple(weights), False), D, P, n * D, D, out, n * D)
-    for i, w in enumerate(weights):
-        _pos_proj[(pos_emb.data_ptr(), w.data_ptr())] = (pos_emb, out[:, i * D:(i + 1) * D], None, i, None)
-
-
-_placeholders = {}
-
-
-def _placeholder_grad(shape, dtype, device):
-    """A zero 'gradient' of the right shape / dtype that costs no launch and no memory (an expanded scalar): tells autograd
-    that the producer's backward may run, while the real gradient sits in a side buffer."""
-    z = _placeholders.get((dtype, device))
-    if z is None:
-        z = _placeholders[(dtype, device)] = torch.zeros((), dtype=dtype, device=device)
-    return z.expand(shape)
-
-
-class PosProjFn(torch.autograd.Function):
-    """linear_pos of every encoder layer applied to the (batch-shared, layer-independent) position table
-    (attention.py:170): forward one [P, D] x [D, n*D] GEMM; backward one [n*D, D] = dpos_all^T pe contraction over the
-    buffer whose column blocks the layers' attention backward accumulated into (MhaSublayerFn, ctx.pp) -- instead of n
-    zero-fills and n 144-tile GEMMs that each leave half of the chip idle."""
-
-    @staticmethod
-    def forward(ctx, pos_emb, holder, *weights):
-        D = pos_emb.shape[-1]
-        pe = _to_act_shared(pos_emb).reshape(-1, D)
-        n, P = len(weights), pe.shape[0]
-        out = torch.empty(P, n * D, dtype=pe.dtype, device=pe.device)
-        if pe.dtype == torch.float16:  # mixed mode: f16 projection + its bf16 twin (the layers' backward passes read views of it)
-            ops.gemm_h16_nt(pe, D, _w_h16_cat(tuple(weights)), D, P, n * D, D, out, n * D, twin=True)
-        else:
-            ops.gemm_bf16_nt(pe, D, _w_bf16_cat(tuple(weights), False), D, P, n * D, D, out, n * D)
-        ctx.save_for_backward(_A_shared(pe))
-        ctx.holder, ctx.meta = holder, (P, D, n)
-        return out
-
-    @staticmethod
-    @_bwd_mode
-    def backward(ctx, dout):
-        (pe,) = ctx.saved_tensors
-        P, D, n = ctx.meta
-        holder = ctx.holder
-        assert holder.get("filled", 0) == n and holder.get("dpos") is not None, \
-            "PosProjFn: every encoder layer must have accumulated its position gradient"
-        # (`dout` is a placeholder: autograd would round a real f32 gradient to the bf16 of the forward output)
-        dW = _wgrad(holder["dpos"], pe, P, n * D, D)
-        holder["dpos"] = None
-        holder["filled"] = 0
-        return (None, None) + tuple(dW[i * D:(i + 1) * D] for i in range(n))
-
+_pos_proj = {}  # (pos_emb address, linear_pos weight address) -> shared projection of the step (functional_attention.prepare_pos_proj)
 
 def _fast_ok(a, K, lda):
     return (not _state["precise"]) and a.dtype == torch.bfloat16 and K % 64 == 0 and (lda or K) % 8 == 0
@@ -1378,966 +1308,15 @@ def mlp(x, w1, b1, w2, b2):
     return MlpFn.apply(x, w1, b1, w2, b2)
 
 
-# ------------------------------------------------------------------------------------------------ attention cores
-def _proj(h, w, b, rows, D, twin=True):
-    out = torch.empty(rows, w.shape[0], dtype=act_dtype(), device=h.device)
-    _gemm_nt(h, w, rows, w.shape[0], D, out, bias=b, twin=twin)
-    return out
-
-
-class AttentionCoreFn(torch.autograd.Function):
-    """Projections + fused attention + output projection of attention.py:90-104 / 153-193, *without* residual:
-    returns linear_out(softmax(...) v) as f32.  q_in / kv_in are activation-dtype or f32 (rows x D) inputs."""
-
-    @staticmethod
-    def forward(ctx, q_in, kv_in, pos_emb, mask, wq, bq, wk, bk, wv, bv, wo, bo, wpos, bias_u, bias_v, H, p_attn,
-                same_kv):
-        B, Tq, D = q_in.shape
-        Tk = kv_in.shape[1]
-        dk = D // H
-        T = act_dtype()
-        qa = _to_act(q_in)
-        ka = qa if same_kv else _to_act(kv_in)
-        q = _proj(qa, wq, bq, B * Tq, D, twin=pos_emb is None)
-        k = _proj(ka, wk, bk, B * Tk, D)
-        v = _proj(ka, wv, bv, B * Tk, D)
-        relpos = pos_emb is not None
-        pe = pproj = qv = None
-        if relpos:
-            pe = _to_act(pos_emb.reshape(-1, D))
-            pproj = torch.empty(pe.shape[0], D, dtype=T, device=q.device)
-            _gemm_nt(pe, wpos, pe.shape[0], D, D, pproj)
-            qu, qv = ops.head_bias_fwd(q, D, B * Tq, D, bias_u.reshape(-1), bias_v.reshape(-1))
-        else:
-            qu = q
-        pa, sa, sda = _drop_args(p_attn, q_in)
-        m = _mask_arg(mask)
-        ctxv, lse = ops.attention_fwd(qu.view(B, Tq, H, dk), qv.view(B, Tq, H, dk) if relpos else None,
-                                      k.view(B, Tk, H, dk), v.view(B, Tk, H, dk), pproj, m, 1.0 / math.sqrt(dk),
-                                      precise=_state["precise"], drop_p=pa, seed=sa, seed_dev=sda)
-        y = torch.empty(B, Tq, D, dtype=torch.float32, device=q.device)
-        _gemm_nt(ctxv, wo, B * Tq, D, D, y, bias=bo)
-        qa_s = _A(qa)
-        ctx.save_for_backward(qa_s, qa_s if ka is qa else _A(ka), _A(pe), m, wq, wk, wv, wo, wpos, _A(qu), _A(qv), _A(k), _A(v),
-                              _A(pproj), _A(ctxv), lse)
-        ctx.meta = (H, pa, sa, sda, same_kv, relpos, bq is not None)
-        return y
-
-    @staticmethod
-    @_bwd_mode
-    def backward(ctx, dy):
-        qa, ka, pe, m, wq, wk, wv, wo, wpos, qu, qv, k, v, pproj, ctxv, lse = ctx.saved_tensors
-        H, pa, sa, sda, same_kv, relpos, has_b = ctx.meta
-        B, Tq, D = qa.shape
-        Tk = ka.shape[1]
-        dk = D // H
-        T = act_dtype()
-        g = _to_act(dy)
-        dbo = _bgrad(g, B * Tq, D)
-        dctx = torch.empty(B, Tq, D, dtype=T, device=g.device)
-        with ops.paired():
-            dwo = _wgrad(g, ctxv, B * Tq, D, D)
-            _gemm_nn(g, wo, B * Tq, D, D, dctx)
-        dqu, dqv, dk_, dv_, dpos = ops.attention_bwd(
-            qu.view(B, Tq, H, dk), qv.view(B, Tq, H, dk) if relpos else None, k.view(B, Tk, H, dk),
-            v.view(B, Tk, H, dk), pproj, m, ctxv, lse, dctx, 1.0 / math.sqrt(dk), precise=_state["precise"],
-            drop_p=pa, seed=sa, seed_dev=sda)
-        du = dv_bias = dwpos = None
-        if relpos:
-            dq = torch.empty(B * Tq, D, dtype=T, device=g.device)
-            du = torch.zeros(D, dtype=torch.float32, device=g.device)
-            dv_bias = torch.zeros(D, dtype=torch.float32, device=g.device)
-            ops.head_bias_bwd(dqu, dqv, dq, D, du, dv_bias, B * Tq, D)
-            du, dv_bias = du.view(H, dk), dv_bias.view(H, dk)
-            dwpos = _wgrad(dpos, pe, pe.shape[0], D, D)
-        else:
-            dq = dqu.view(B * Tq, D)
-        dk2, dv2 = dk_.view(B * Tk, D), dv_.view(B * Tk, D)
-        dbq = dbk = dbv = None
-        if has_b:
-            dbq, dbk, dbv = _bgrad(dq, B * Tq, D), _bgrad(dk2, B * Tk, D), _bgrad(dv2, B * Tk, D)
-        dq_in = dkv_in = None
-        # each projection: weight gradient + data gradient as one launch (the data gradients chain through `resid`)
-        if same_kv:
-            t1 = torch.empty(B * Tq, D, dtype=torch.float32, device=g.device)
-            with ops.paired():
-                dwq = _wgrad(dq, qa, B * Tq, D, D)
-                _gemm_nn(dq, wq, B * Tq, D, D, t1)
-            t2 = torch.empty_like(t1)
-            with ops.paired():
-                dwk = _wgrad(dk2, ka, B * Tk, D, D)
-                _gemm_nn(dk2, wk, B * Tk, D, D, t2, resid=t1, ldr=D)
-            dq_in = torch.empty(B, Tq, D, dtype=torch.float32, device=g.device)
-            with ops.paired():
-                dwv = _wgrad(dv2, ka, B * Tk, D, D)
-                _gemm_nn(dv2, wv, B * Tk, D, D, dq_in, resid=t2, ldr=D)
-        else:
-            with ops.paired():
-                dwq = _wgrad(dq, qa, B * Tq, D, D)
-                if ctx.needs_input_grad[0]:
-                    dq_in = torch.empty(B, Tq, D, dtype=torch.float32, device=g.device)
-                    _gemm_nn(dq, wq, B * Tq, D, D, dq_in)
-            need_kv = ctx.needs_input_grad[1]
-            t2 = torch.empty(B * Tk, D, dtype=torch.float32, device=g.device) if need_kv else None
-            with ops.paired():
-                dwk = _wgrad(dk2, ka, B * Tk, D, D)
-                if need_kv:
-                    _gemm_nn(dk2, wk, B * Tk, D, D, t2)
-            with ops.paired():
-                dwv = _wgrad(dv2, ka, B * Tk, D, D)
-                if need_kv:
-                    dkv_in = torch.empty(B, Tk, D, dtype=torch.float32, device=g.device)
-                    _gemm_nn(dv2, wv, B * Tk, D, D, dkv_in, resid=t2, ldr=D)
-        return (dq_in, dkv_in, None, None, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dwpos, du, dv_bias, None, None,
-                None)
-
-
-def attention_core(q_in, kv_in, pos_emb, mask, wq, bq, wk, bk, wv, bv, wo, bo, wpos, bias_u, bias_v, H, p_attn):
-    _state["tag_ok"] = torch.is_grad_enabled()
-    same = kv_in is q_in
-    return AttentionCoreFn.apply(q_in, q_in if same else kv_in, pos_emb, mask, wq, bq, wk, bk, wv, bv, wo, bo, wpos,
-                                 bias_u, bias_v, H, float(p_attn), same)
-
-
-class MhaSublayerFn(torch.autograd.Function):
-    """x + dropout(MHA(LN(x), kv, kv)):  conformer_encoder.py:119-142 (rel-pos self attention, kv = LN(x)) and
-    transformer_decoder.py:65-118 (self attention with kv = LN(x); source attention with kv = memory)."""
-
-    @staticmethod
-    def forward(ctx, x, memory, pos_emb, mask, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, wpos, bias_u, bias_v, H,
-                p_attn, p_out, eps, kv_all=None, kv_slot=0, kv_holder=None, pp_all=None, pp_slot=0, pp_holder=None):
-        x = x.contiguous()
-        ctx.chain = _chain_take(x)
-        B, Tq, D = x.shape
-        dk = D // H
-        T = act_dtype()
-        h, mean, rstd = ops.layernorm_fwd(x, ln_w, ln_b, T, eps, twin=True)
-        shared_kv = kv_all is not None  # source attention on the all-layer K/V projection of the memory (MemoryKVFn)
-        cross = memory is not None or shared_kv
-        if shared_kv:
-            ka = None
-            Tk = kv_all.shape[0] // B
-        else:
-            ka = _to_act_shared(memory) if cross else h
-            Tk = ka.shape[1]
-        # self attention in bf16: ONE projection GEMM onto the concatenated [Wq; Wk; Wv] (N = 3D fills the chip where
-        # three N = D launches do not); q / k / v are column thirds of its output, read in place by the attention kernel
-        fused = _FUSE_QKV and (not cross) and (not _state["precise"]) and D % 64 == 0 and T in (torch.bfloat16, torch.float16) \
-            and all(w.dtype == torch.float32 and w.is_contiguous() for w in (wq, wk, wv))
-        relpos = pos_emb is not None
-        qkv = None
-        if fused:
-            qkv = torch.empty(B * Tq, 3 * D, dtype=T, device=x.device)
-            if T == torch.float16:
-                ops.gemm_h16_nt(h, D, _w_h16_cat((wq, wk, wv)), D, B * Tq, 3 * D, D, qkv, 3 * D, bias=_bias3(bq, bk, bv), twin=True)
-            else:
-                ops.gemm_bf16_nt(h, D, _w_bf16_cat((wq, wk, wv), False), D, B * Tq, 3 * D, D, qkv, 3 * D,
-                                 bias=_bias3(bq, bk, bv))
-            q5 = qkv.view(B, Tq, 3, H, dk)
-            q, k4, v4 = qkv, q5[:, :, 1], q5[:, :, 2]
-            ldq = 3 * D
-        elif shared_kv:
-            q = _proj(h, wq, bq, B * Tq, D, twin=pos_emb is None)
-            assert kv_all.dtype == T, "shared K / V projection and this sub-layer must run the same forward format"
-            kv5 = kv_all.view(B, Tk, kv_all.shape[1] // D, H, dk)  # [.., 2 * slot] = K, [.., 2 * slot + 1] = V of this layer
-            k4, v4 = kv5[:, :, 2 * kv_slot], kv5[:, :, 2 * kv_slot + 1]
-            ldq = D
-        else:
-            q = _proj(h, wq, bq, B * Tq, D, twin=pos_emb is None)
-            k4 = _proj(ka, wk, bk, B * Tk, D).view(B, Tk, H, dk)
-            v4 = _proj(ka, wv, bv, B * Tk, D).view(B, Tk, H, dk)
-            ldq = D
-        pe = pproj = qv = None
-        if relpos:
-            pe = _to_act_shared(pos_emb).reshape(-1, D)
-            pre = _pos_proj.get((pos_emb.data_ptr(), wpos.data_ptr())) if pp_all is None else None
-            if pp_all is not None:
-                pproj = pp_all[:, pp_slot * D:(pp_slot + 1) * D]  # column block of the all-layer projection (PosProjFn)
-            elif pre is not None and pre[1] is not None and pre[1].dtype == T:
-                pproj = pre[1]  # the same, without autograd (prepare_pos_proj under no_grad), row pitch n_layers * D
-            else:
-                pproj = torch.empty(pe.shape[0], D, dtype=T, device=x.device)
-                _gemm_nt(pe, wpos, pe.shape[0], D, D, pproj)
-            qu, qv = ops.head_bias_fwd(q, ldq, B * Tq, D, bias_u.reshape(-1), bias_v.reshape(-1))
-            qu, qv = qu.view(B, Tq, H, dk), qv.view(B, Tq, H, dk)
-        else:
-            qu = q5[:, :, 0] if fused else q.view(B, Tq, H, dk)
-        pa, sa, sda = _drop_args(p_attn, x)
-        m = _mask_arg(mask)
-        ctxv, lse = ops.attention_fwd(qu, qv, k4, v4, pproj, m, 1.0 / math.sqrt(dk),
-                                      precise=_state["precise"], drop_p=pa, seed=sa, seed_dev=sda)
-        po, so, sdo = _drop_args(p_out, x)
-        y = torch.empty_like(x)
-        _gemm_nt(ctxv, wo, B * Tq, D, D, y, bias=bo, drop_p=po, seed=so, seed_dev=sdo, resid=x, ldr=D)
-        if fused and qkv.dtype == torch.float16:  # thirds of the fused projection: the same views of its bf16 twin
-            s_qu, s_k, s_v = (_A(qu) if relpos else _A_view(qu, qkv)), _A_view(k4, qkv), _A_view(v4, qkv)
-        elif shared_kv and kv_all.dtype == torch.float16:
-            s_qu, s_k, s_v = _A(qu), _A_view(k4, kv_all), _A_view(v4, kv_all)
-        else:
-            s_qu, s_k, s_v = _A(qu), _A(k4), _A(v4)
-        s_pp = _A_view(pproj, pp_all) if (pp_all is not None and pproj is not None) else _A(pproj)
-        ctx.save_for_backward(x, ln_w, mean, rstd, _A(h), _A_shared(ka) if (cross and not shared_kv) else None, _A_shared(pe), m,
-                              wq, wk, wv, wo, wpos, s_qu, _A(qv), s_k, s_v, s_pp, _A(ctxv), lse)
-        ctx.meta = (H, pa, sa, sda, po, so, sdo, cross, relpos, fused)
-        ctx.kv = (kv_slot, kv_holder, tuple(kv_all.shape), kv_all.dtype) if shared_kv else None
-        ctx.pp = (pp_slot, pp_holder, tuple(pp_all.shape), pp_all.dtype) if (relpos and pp_all is not None) else None
-        _chain_tag(y, B * Tq, D, 1.0, (po, so, sdo))
-        return y
-
-    @staticmethod
-    @_bwd_mode
-    def backward(ctx, dy):
-        (x, ln_w, mean, rstd, h, ka, pe, m, wq, wk, wv, wo, wpos, qu, qv, k4, v4, pproj, ctxv, lse) = ctx.saved_tensors
-        H, pa, sa, sda, po, so, sdo, cross, relpos, fused = ctx.meta
-        dy = dy.contiguous()
-        B, Tq, D = x.shape
-        shared_kv = ctx.kv is not None
-        if not cross:
-            ka = h
-        Tk = k4.shape[1]
-        dk = D // H
-        T = act_dtype()
-        g, gT, _ = _prologue(dy, B * Tq, D, drop=(po, so, sdo), want_bias=False)
-        dbo = _zeros(D, x.device)
-        dctx = torch.empty(B, Tq, D, dtype=T, device=x.device)
-        with ops.paired():
-            dwo = _wgrad(g, ctxv, B * Tq, D, D, bias_out=dbo)
-            _gemm_nn(g, wo, B * Tq, D, D, dctx)
-        outs = {}
-        if fused:  # dq | dk | dv land side by side: one bias-gradient pass, one weight-gradient GEMM, one data-gradient GEMM
-            dqkv = torch.empty(B * Tq, 3 * D, dtype=T, device=x.device)
-            d5 = dqkv.view(B, Tq, 3, H, dk)
-            outs = dict(dk_out=d5[:, :, 1], dv_out=d5[:, :, 2])
-            if not relpos:
-                outs["dqu_out"] = d5[:, :, 0]
-        dkv_grad = None
-        if shared_kv:
-            # dK / dV go straight into this layer's columns of the shared gradient buffer; the projection's own backward
-            # (weight, bias and memory gradients of ALL layers) runs once, in MemoryKVFn.backward
-            slot, holder, shape, kv_dtype = ctx.kv
-            if holder.get("dkv") is None:
-                holder["dkv"] = torch.empty(shape, dtype=T, device=x.device)
-            g5 = holder["dkv"].view(B, Tk, shape[1] // D, H, dk)
-            outs = dict(dk_out=g5[:, :, 2 * slot], dv_out=g5[:, :, 2 * slot + 1])
-            holder["filled"] = holder.get("filled", 0) + 1
-            # ONE consumer hands autograd a gradient (the others None); the real buffer travels in `holder` -- autograd would
-            # convert it to the dtype of the forward output (f16 in the mixed mode)
-            dkv_grad = (holder["dkv"] if kv_dtype == T else _placeholder_grad(shape, kv_dtype, x.device)) if slot == 0 else None
-        dpp_grad = None
-        if ctx.pp is not None:
-            # this layer's position gradient accumulates into its column block of ONE zero-filled buffer; the weight
-            # gradients of all layers come from it in PosProjFn.backward
-            slot, holder, shape, pp_dtype = ctx.pp
-            if holder.get("dpos") is None:
-                holder["dpos"] = _zeros(shape, x.device)
-            outs = dict(outs, dpos_out=holder["dpos"][:, slot * D:(slot + 1) * D])
-            holder["filled"] = holder.get("filled", 0) + 1
-            # the f32 buffer travels in `holder`; the placeholder carries the dtype of the forward output (f16 in the mixed mode)
-            dpp_grad = _placeholder_grad(shape, pp_dtype, x.device) if slot == 0 else None
-        du = dv_bias = dwpos = None
-        if relpos:
-            # the attention backward itself emits dq = dqu + dqv and the two position-bias gradients (their column sums)
-            dq = dqkv if fused else torch.empty(B * Tq, D, dtype=T, device=x.device)
-            du = _zeros(D, x.device)
-            dv_bias = _zeros(D, x.device)
-            outs = dict(outs, dq_sum=d5[:, :, 0] if fused else dq.view(B, Tq, H, dk), du=du, dv_bias=dv_bias)
-        dqu, dqv, dk_, dv_, dpos = ops.attention_bwd(
-            qu, qv, k4, v4, pproj, m, ctxv, lse, dctx, 1.0 / math.sqrt(dk), precise=_state["precise"],
-            drop_p=pa, seed=sa, seed_dev=sda, **outs)
-        if relpos:
-            du, dv_bias = du.view(H, dk), dv_bias.view(H, dk)
-            dwpos = _wgrad(dpos, pe, pe.shape[0], D, D) if ctx.pp is None else None
-        elif not fused:
-            dq = dqu.view(B * Tq, D)
-        dmem = None
-        if fused:
-            dbc = _zeros(3 * D, x.device)
-            dh = torch.empty(B * Tq, D, dtype=torch.float32, device=x.device)
-            wcT = _w_bf16_cat((wq, wk, wv), True)
-            with ops.paired():
-                dwc = _wgrad(dqkv, h, B * Tq, 3 * D, D, bias_out=dbc)
-                ops.gemm_bf16_nt(dqkv, 3 * D, wcT, 3 * D, B * Tq, D, 3 * D, dh, D)
-            dwq, dwk, dwv = dwc[:D], dwc[D:2 * D], dwc[2 * D:]
-            dbq, dbk, dbv = dbc[:D], dbc[D:2 * D], dbc[2 * D:]
-        else:
-            if not shared_kv:
-                dk2, dv2 = dk_.view(B * Tk, D), dv_.view(B * Tk, D)
-            dbq, dbk, dbv = _zeros(D, x.device), _zeros(D, x.device), _zeros(D, x.device)
-            # each projection: weight gradient + data gradient as one launch (data gradients chain through `resid`)
-            if shared_kv:
-                dh = torch.empty(B * Tq, D, dtype=T, device=x.device)
-                with ops.paired():
-                    dwq = _wgrad(dq, h, B * Tq, D, D, bias_out=dbq)
-                    _gemm_nn(dq, wq, B * Tq, D, D, dh)
-                dwk = dwv = dbk = dbv = None
-            elif cross:
-                dh = torch.empty(B * Tq, D, dtype=T, device=x.device)
-                with ops.paired():
-                    dwq = _wgrad(dq, h, B * Tq, D, D, bias_out=dbq)
-                    _gemm_nn(dq, wq, B * Tq, D, D, dh)
-                need_mem = ctx.needs_input_grad[1]
-                t2 = torch.empty(B * Tk, D, dtype=torch.float32, device=x.device) if need_mem else None
-                with ops.paired():
-                    dwk = _wgrad(dk2, ka, B * Tk, D, D, bias_out=dbk)
-                    if need_mem:
-                        _gemm_nn(dk2, wk, B * Tk, D, D, t2)
-                with ops.paired():
-                    dwv = _wgrad(dv2, ka, B * Tk, D, D, bias_out=dbv)
-                    if need_mem:
-                        dmem = torch.empty(B, Tk, D, dtype=torch.float32, device=x.device)
-                        _gemm_nn(dv2, wv, B * Tk, D, D, dmem, resid=t2, ldr=D)
-            else:
-                t1 = torch.empty(B * Tq, D, dtype=torch.float32, device=x.device)
-                with ops.paired():
-                    dwq = _wgrad(dq, h, B * Tq, D, D, bias_out=dbq)
-                    _gemm_nn(dq, wq, B * Tq, D, D, t1)
-                t2 = torch.empty_like(t1)
-                with ops.paired():
-                    dwk = _wgrad(dk2, ka, B * Tk, D, D, bias_out=dbk)
-                    _gemm_nn(dk2, wk, B * Tq, D, D, t2, resid=t1, ldr=D)
-                dh = torch.empty_like(t1)
-                with ops.paired():
-                    dwv = _wgrad(dv2, ka, B * Tk, D, D, bias_out=dbv)
-                    _gemm_nn(dv2, wv, B * Tq, D, D, dh, resid=t2, ldr=D)
-        dg = _zeros(D, x.device)
-        dbt = _zeros(D, x.device)
-        dx = _ln_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dy, ctx.chain)
-        return (dx, dmem, None, None, dg, dbt, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dwpos, du, dv_bias, None, None,
-                None, None, dkv_grad, None, None, dpp_grad, None, None)
-
-
-def mha_sublayer(x, memory, pos_emb, mask, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, wpos, bias_u, bias_v, H, p_attn,
-                 p_out, eps=1e-12, kv=None):
-    """kv = (kv_all, slot, holder) from memory_kv(): source attention reads its K / V from the all-layer projection."""
-    _state["tag_ok"] = torch.is_grad_enabled()
-    if kv is not None:
-        return MhaSublayerFn.apply(_to_f32(x), None, pos_emb, mask, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, wpos,
-                                   bias_u, bias_v, H, float(p_attn), float(p_out), eps, kv[0], kv[1], kv[2])
-    if pos_emb is not None and wpos is not None:
-        pre = _pos_proj.get((pos_emb.data_ptr(), wpos.data_ptr()))
-        if pre is not None and pre[2] is not None and torch.is_grad_enabled():
-            return MhaSublayerFn.apply(_to_f32(x), memory, pos_emb, mask, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, wpos,
-                                       bias_u, bias_v, H, float(p_attn), float(p_out), eps, None, 0, None, pre[2], pre[3],
-                                       pre[4])
-    return MhaSublayerFn.apply(_to_f32(x), memory, pos_emb, mask, ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo, wpos,
-                               bias_u, bias_v, H, float(p_attn), float(p_out), eps)
-
-
-class MemoryKVFn(torch.autograd.Function):
-    """K and V projections of the encoder memory for ALL decoder layers at once (transformer_decoder.py:100-108 runs
-    linear_k / linear_v of every layer's src_attn on the same memory, attention.py:50-52):
-        forward : kv_all [B*Tk, 2*n*D] = memory @ [Wk_0; Wv_0; Wk_1; ...]^T + [bk_0 | bv_0 | ...]   -- ONE GEMM instead of 2n;
-        backward: the n source-attention sub-layers write dK_l / dV_l into their columns of one shared buffer
-                  (MhaSublayerFn, shared_kv); when all of them have run, ONE paired launch gives the weight gradients of
-                  all 2n projections (+ bias gradients) and the memory gradient sum_l (dK_l Wk_l + dV_l Wv_l) -- instead of
-                  2n paired launches chained through `resid` and n - 1 autograd additions of [B, Tk, D] tensors.
-    The contraction of the memory gradient runs over K = 2*n*D = 9216 in one launch: long k loops are where the tile kernel
-    is efficient."""
-
-    @staticmethod
-    def forward(ctx, memory, holder, *wb):
-        B, Tk, D = memory.shape
-        ws, bs = wb[0::2], wb[1::2]
-        n = len(ws)
-        ma = _to_act_shared(memory).reshape(B * Tk, D)
-        kv = torch.empty(B * Tk, n * D, dtype=ma.dtype, device=memory.device)
-        if ma.dtype == torch.float16:  # mixed mode: f16 projection + bf16 twin (the source-attention backward passes read views of it)
-            ops.gemm_h16_nt(ma, D, _w_h16_cat(tuple(ws)), D, B * Tk, n * D, D, kv, n * D, bias=torch.cat(bs), twin=True)
-        else:
-            ops.gemm_bf16_nt(ma, D, _w_bf16_cat(tuple(ws), False), D, B * Tk, n * D, D, kv, n * D, bias=torch.cat(bs))
-        ctx.save_for_backward(_A_shared(ma), *ws)
-        ctx.holder = holder
-        ctx.meta = (B, Tk, D, n)
-        return kv
-
-    @staticmethod
-    @_bwd_mode
-    def backward(ctx, dkv):
-        ma, *ws = ctx.saved_tensors
-        B, Tk, D, n = ctx.meta
-        holder = ctx.holder
-        assert holder.get("filled", 0) == n // 2 and holder.get("dkv") is not None, \
-            "MemoryKVFn: every source-attention sub-layer must have written its dK / dV"
-        dkv = holder["dkv"]  # (the autograd-visible gradient is a placeholder of the forward dtype)
-        rows = B * Tk
-        dbias = _zeros(n * D, dkv.device)
-        dmem = torch.empty(B, Tk, D, dtype=torch.float32, device=dkv.device)
-        wcT = _w_bf16_cat(tuple(ws), True)
-        with ops.paired():
-            dW = _wgrad(dkv, ma, rows, n * D, D, bias_out=dbias)
-            ops.gemm_bf16_nt(dkv, n * D, wcT, n * D, rows, D, n * D, dmem.view(rows, D), D)
-        holder["dkv"] = None
-        holder["filled"] = 0
-        grads = [dmem, None]
-        for i in range(n):
-            grads += [dW[i * D:(i + 1) * D], dbias[i * D:(i + 1) * D]]
-        return tuple(grads)
-
-
-def memory_kv(memory, layers_kv):
-    """layers_kv: [(Wk, bk, Wv, bv)] per decoder layer.  Returns (kv_all, holder) for mha_sublayer(kv=(kv_all, l, holder)),
-    or None when the shared projection does not apply (precise mode, shapes the tuned kernel does not take)."""
-    if _state["precise"] or not _FUSE_QKV or len(layers_kv) < 2 or not torch.is_grad_enabled():
-        return None
-    D = memory.shape[-1]
-    flat = []
-    for (wk, bk, wv, bv) in layers_kv:
-        flat += [wk, bk, wv, bv]
-    if D % 64 or any(w.dtype != torch.float32 or not w.is_contiguous() or tuple(w.shape) != (D, D) for w in flat[0::2]) \
-            or any(b is None for b in flat[1::2]) or not memory.requires_grad:
-        return None
-    holder = {}
-    return MemoryKVFn.apply(memory, holder, *flat), holder
-
-
-# ------------------------------------------------------------------------------------------------ BatchNorm plumbing
-_const_cache = {}
-
-
-def _const1(value, device):
-    """A resident 1-element f32 constant (BatchNorm row counts): one fill per distinct value instead of one per
-    BatchNorm per step.  Never created under hipGraph capture (its fill would only run at replay)."""
-    if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
-        t = _const_cache.get((device, value))
-        return t if t is not None else torch.full((1,), value, dtype=torch.float32, device=device)
-    key = (device, value)
-    t = _const_cache.get(key)
-    if t is None:
-        if len(_const_cache) > 4096:
-            _const_cache.clear()
-        t = _const_cache[key] = torch.full((1,), value, dtype=torch.float32, device=device)
-    return t
-
-
-def _bn_train_stats(c2, rows, C, eps, momentum, running_mean, running_var, nbt=None):
-    """Batch statistics (+ running-stat update, + num_batches_tracked count) of a [rows, C] activation; merged across
-    ranks when set_bn_sync()."""
-    group = _state["bn_sync"]
-    if group is not None:
-        import torch.distributed as dist
-
-        # one all-gather of {shifted statistics, row count} per BatchNorm (ranks hold different row counts); the
-        # payload is written by the statistics kernel and read in place (strided) by the merge kernel, which also
-        # leaves the global row count on the device for the backward pass -- no glue launches around the collective
-        comm = _state.get("bn_comm")
-        W = comm.world if comm is not None else dist.get_world_size(group)
-        mine = ops.bn_stats(c2, rows, C, with_count=True)
-        flat = torch.empty(W * mine.numel(), dtype=torch.float32, device=c2.device)
-        if comm is not None:
-            comm.all_gather(flat, mine)
-        else:
-            dist.all_gather_into_tensor(flat, mine, group=group)
-        n_total = torch.empty(1, dtype=torch.float32, device=c2.device)
-        mean, invstd = ops.bn_finalize(flat, flat.data_ptr() + 12 * C, W, C, eps, momentum, running_mean, running_var,
-                                       nbt, stats_stride=3 * C + 1, counts_stride=3 * C + 1, n_total=n_total)
-        return mean, invstd, n_total
-    mean, invstd = ops.bn_stats_finalize(c2, rows, C, eps, momentum, running_mean, running_var, nbt)
-    return mean, invstd, None
-
-
-def _bn_bwd_sums(sums, counts, rows):
-    """All-reduce the backward sums across the sync group; returns (sums_for_dx, inv_n, n_dev).  `counts` is what
-    _bn_train_stats returned: under synchronisation the global row count, resident on the device."""
-    group = _state["bn_sync"]
-    if group is None:
-        return sums, 1.0 / rows, None
-    import torch.distributed as dist
-
-    tot = sums.clone()
-    if _state.get("bn_comm") is not None:
-        _state["bn_comm"].all_reduce(tot)
-    else:
-        dist.all_reduce(tot, group=group)
-    return tot, 0.0, counts  # global row count stays on the device (no host sync)
-
-
-class ConvSublayerFn(torch.autograd.Function):
-    """x + dropout(ConvolutionModule(LN(x))):  conformer_encoder.py:145-151,30-35.
-    pointwise(D->2D) -> GLU -> depthwise(K) -> BatchNorm1d (batch stats over every frame) -> SiLU -> pointwise."""
-
-    @staticmethod
-    def forward(ctx, x, ln_w, ln_b, w_pw1, b_pw1, w_dw, b_dw, bn_w, bn_b, bn_rm, bn_rv, bn_nbt, w_pw2, b_pw2, training,
-                momentum, bn_eps, p_out, eps):
-        x = x.contiguous()
-        B, Tn, D = x.shape
-        rows = B * Tn
-        K = w_dw.shape[-1]
-        T = act_dtype()
-        fused = ln_w is not None  # False: bare ConvolutionModule.forward (no LayerNorm, no residual)
-        ctx.chain = _chain_take(x) if fused else None
-        if fused:
-            h, mean, rstd = ops.layernorm_fwd(x, ln_w, ln_b, T, eps, twin=True)
-        else:
-            h, mean, rstd = _to_act(x), None, None
-        a = torch.empty(rows, 2 * D, dtype=T, device=x.device)
-        _gemm_nt(h, w_pw1.view(2 * D, D), rows, 2 * D, D, a, bias=b_pw1, twin=True)
-        # GLU (conformer_encoder.py:32) is folded into the depthwise convolution: its window staging forms
-        # a[:, :D] * sigmoid(a[:, D:]) on the fly, the GLU output is never written
-        gl = None
-        wdw = w_dw.view(D, K)
-        c = ops.dwconv(a, wdw, b_dw, B, Tn, D, K, glu_in=True)
-        one_launch = training and _BN_SMALL and _state["bn_sync"] is None and rows <= ops.BN_SMALL_MAX_ROWS
-        if one_launch:  # statistics + running stats + normalise + Swish in one pass (no cross-rank merge to wait for)
-            s, bmean, binv = ops.bn_small_fwd(c, rows, D, bn_w, bn_b, bn_eps, momentum, bn_rm, bn_rv, bn_nbt, 1)
-            counts = None
-        else:
-            if training:
-                bmean, binv, counts = _bn_train_stats(c, rows, D, bn_eps, momentum, bn_rm, bn_rv, bn_nbt)
-            else:
-                bmean, binv = ops.bn_eval_params(bn_rm, bn_rv, bn_eps)
-                counts = None
-            s = ops.bn_act_fwd(c, None, bmean, binv, bn_w, bn_b, rows, D, 1)
-        po, so, sdo = _drop_args(p_out, x)
-        y = torch.empty_like(x)
-        _gemm_nt(s, w_pw2.view(D, D), rows, D, D, y, bias=b_pw2, drop_p=po, seed=so, seed_dev=sdo,
-                 resid=x if fused else None, ldr=D)
-        ctx.save_for_backward(x, ln_w, mean, rstd, _A(h), _A(a), gl, _A(c), bmean, binv, bn_w, bn_b, _A(s), w_pw1, wdw, w_pw2, counts)
-        ctx.meta = (training, po, so, sdo, K, fused)
-        if fused:
-            _chain_tag(y, rows, D, 1.0, (po, so, sdo))
-        return y
-
-    @staticmethod
-    @_bwd_mode
-    def backward(ctx, dy):
-        (x, ln_w, mean, rstd, h, a, gl, c, bmean, binv, bn_w, bn_b, s, w_pw1, wdw, w_pw2, counts) = ctx.saved_tensors
-        training, po, so, sdo, K, fused = ctx.meta
-        dy = dy.contiguous()
-        B, Tn, D = x.shape
-        rows = B * Tn
-        T = act_dtype()
-        g, gT, _ = _prologue(dy, rows, D, drop=(po, so, sdo), want_bias=False)
-        db2 = _zeros(D, x.device)
-        ds = torch.empty(rows, D, dtype=T, device=x.device)
-        with ops.paired():
-            dw2 = _wgrad(g, s, rows, D, D, bias_out=db2).view(D, D, 1)
-            _gemm_nn(g, w_pw2.view(D, D), rows, D, D, ds)
-        if training and _BN_SMALL and _state["bn_sync"] is None and rows <= ops.BN_SMALL_MAX_ROWS:
-            dc, dbn_w, dbn_b = ops.bn_small_bwd(c, ds, rows, D, bmean, binv, bn_w, bn_b, 1)
-        else:
-            sums = ops.bn_bwd_reduce(c, ds, None, bmean, binv, bn_w, bn_b, rows, D, 1)
-            dbn_w, dbn_b = sums[1], sums[0]
-            if training:
-                sums_dx, inv_n, n_dev = _bn_bwd_sums(sums, counts, rows)
-            else:
-                sums_dx, inv_n, n_dev = torch.zeros_like(sums), 0.0, None
-            dc, _ = ops.bn_bwd_apply(c, ds, None, bmean, binv, bn_w, bn_b, sums_dx, inv_n, rows, D, 1, False, n_dev=n_dev)
-        dwdw = _zeros((D, K), x.device)
-        dbdw = _zeros(D, x.device)
-        ops.dwconv_wgrad(a, dc, dwdw, dbdw, B, Tn, D, K, glu_in=True)
-        # data gradient of the depthwise convolution with the GLU backward as its epilogue: d glu never reaches HBM
-        da = ops.dwconv(dc, wdw, None, B, Tn, D, K, flip=True, glu_a=a).view(rows, 2 * D)
-        db1 = _zeros(2 * D, x.device)
-        if fused:
-            dh = torch.empty(rows, D, dtype=T, device=x.device)
-            with ops.paired():
-                dw1 = _wgrad(da, h, rows, 2 * D, D, bias_out=db1).view(2 * D, D, 1)
-                _gemm_nn(da, w_pw1.view(2 * D, D), rows, D, 2 * D, dh)
-            dg = _zeros(D, x.device)
-            dbt = _zeros(D, x.device)
-            dx = _ln_bwd(dh, x, ln_w, mean, rstd, dg, dbt, dy, ctx.chain)
-        else:
-            dg = dbt = None
-            dx = torch.empty(B, Tn, D, dtype=torch.float32, device=x.device)
-            with ops.paired():
-                dw1 = _wgrad(da, h, rows, 2 * D, D, bias_out=db1).view(2 * D, D, 1)
-                _gemm_nn(da, w_pw1.view(2 * D, D), rows, D, 2 * D, dx)
-        return (dx, dg, dbt, dw1, db1, dwdw.view(D, 1, K), dbdw, dbn_w, dbn_b, None, None, None, dw2, db2, None, None,
-                None, None, None)
-
-
-def conv_sublayer(x, ln_w, ln_b, w_pw1, b_pw1, w_dw, b_dw, bn, w_pw2, b_pw2, p_out, eps=1e-12):
-    """bn: the torch.nn.BatchNorm1d module holding weight / bias / running stats (updated in place in training).
-    ln_w = ln_b = None gives the bare module (no LayerNorm, no residual, no output dropout)."""
-    training = bn.training
-    _state["tag_ok"] = torch.is_grad_enabled()
-    momentum = bn.momentum if bn.momentum is not None else 0.1
-    # the batch counter of the BatchNorm is incremented by its statistics kernel (bn_finalize)
-    return ConvSublayerFn.apply(_to_f32(x), ln_w, ln_b, w_pw1, b_pw1, w_dw, b_dw, bn.weight, bn.bias, bn.running_mean,
-                                bn.running_var, bn.num_batches_tracked if training else None, w_pw2, b_pw2, training,
-                                float(momentum), float(bn.eps), float(p_out), eps)
-
-
-# ------------------------------------------------------------------------------------------------ misc
-class ScaleDropoutFn(torch.autograd.Function):
-    """alpha * dropout(x) -> f32   (embedding.py:179-184: x*sqrt(d) then dropout; ctc.py:54 dropout)."""
-
-    @staticmethod
-    def forward(ctx, x, alpha, p, out_dtype):
-        pp, s, sd = _drop_args(p, x)
-        ctx.meta = (alpha, pp, s, sd, x.dtype)
-        return ops.scale_dropout(x.contiguous(), out_dtype, alpha=alpha, drop_p=pp, seed=s, seed_dev=sd)
-
-    @staticmethod
-    @_bwd_mode
-    def backward(ctx, dy):
-        alpha, pp, s, sd, in_dtype = ctx.meta
-        out = torch.float32 if in_dtype == torch.float32 else act_dtype()
-        return ops.scale_dropout(dy.contiguous(), out, alpha=alpha, drop_p=pp, seed=s, seed_dev=sd), None, None, None
-
-
-def scale_dropout(x, alpha=1.0, p=0.0, out_dtype=torch.float32):
-    return ScaleDropoutFn.apply(x, float(alpha), float(p), out_dtype)
-
-
-class EmbedFn(torch.autograd.Function):
-    """dropout(table[ids]*sqrt(d) + pe[pos])   transformer_decoder.py:186-189 + embedding.py:78-87."""
-
-    @staticmethod
-    def forward(ctx, ids, table, pe, scale, p):
-        L = ids.shape[-1]
-        pp, s, sd = _drop_args(p, table)
-        ids = ids.contiguous()
-        ctx.save_for_backward(ids)
-        ctx.meta = (scale, pp, s, sd, table.shape)
-        return ops.embed_fwd(ids, table, pe[:L].contiguous(), L, scale, pp, s, sd)
-
-    @staticmethod
-    @_bwd_mode
-    def backward(ctx, dy):
-        (ids,) = ctx.saved_tensors
-        scale, pp, s, sd, tshape = ctx.meta
-        dt = torch.zeros(tshape, dtype=torch.float32, device=dy.device)
-        ops.embed_bwd(ids, _to_f32(dy), dt, scale, pp, s, sd)
-        return None, dt, None, None, None
-
-
-def embed(ids, table, pe, scale, p):
-    return EmbedFn.apply(ids, table, pe, float(scale), float(p))
-
-
-# ------------------------------------------------------------------------------------------------ loss heads
-class CtcLossFn(torch.autograd.Function):
-    """ctc.py:32-38: log_softmax + CTCLoss(sum, zero_infinity) / B on f32 logits [B,T,V] (possibly a [..., :V]
-    view of a pitch-padded buffer).  The gradient is produced by the forward kernels."""
-
-    @staticmethod
-    def forward(ctx, logits, labels, in_lens, ignore_id):
-        B, Tn, V = logits.shape
-        pit = _pitched_2d(logits, B * Tn, V)
-        if pit is None or logits.dtype != torch.float32:
-            ld = padded_cols(V)
-            buf = torch.zeros(B * Tn, ld, dtype=torch.float32, device=logits.device)
-            buf[:, :V].copy_(logits.reshape(B * Tn, V))
-            pit = (buf, ld)
-        l2, ld = pit
-        lab = labels.reshape(B, -1).contiguous()
-        nll, grad = ops.ctc_loss(l2, ld, lab, in_lens.to(torch.int64).contiguous(), B, Tn, V,
-                                 want_grad=True, ignore_id=ignore_id)
-        loss = ops.sum_finite_scale(nll, 1.0 / B)
-        ctx.save_for_backward(grad)
-        ctx.meta = (B, Tn, V, ld)
-        return loss.view(())
-
-    @staticmethod
-    @_bwd_mode
-    def backward(ctx, g):
-        (grad,) = ctx.saved_tensors
-        B, Tn, V, ld = ctx.meta
-        d = ops.scale_dropout(grad, torch.float32, alpha=1.0 / B, alpha_dev=g.reshape(1).to(torch.float32).contiguous())
-        return d.view(B, Tn, ld)[..., :V], None, None, None
-
-
-def ctc_loss(logits, labels, in_lens, ignore_id=-1):
-    return CtcLossFn.apply(logits, labels, in_lens, ignore_id)
-
-
-class CeSmoothFn(torch.autograd.Function):
-    """label_smoothing_loss.py:41-63 (sum over tokens / B) + nets_utils.py:272-292 accuracy, on f32 logits
-    [B,L,V].  Returns (loss, n_hits, n_valid) as device scalars."""
-
-    @staticmethod
-    def forward(ctx, logits, target, smoothing, ignore_id, denom):
-        V = logits.shape[-1]
-        rows = logits.numel() // V
-        pit = _pitched_2d(logits, rows, V)
-        if pit is None or logits.dtype != torch.float32:
-            ld = padded_cols(V)
-            buf = torch.zeros(rows, ld, dtype=torch.float32, device=logits.device)
-            buf[:, :V].copy_(logits.reshape(rows, V))
-            pit = (buf, ld)
-        l2, ld = pit
-        tgt = target.reshape(-1).to(torch.int64).contiguous()
-        row_loss, row_hit, grad = ops.ce_smooth(l2, ld, tgt, V, smoothing, want_grad=True, ignore_id=ignore_id)
-        loss = ops.sum_scale(row_loss, 1.0 / denom)
-        hits = ops.sum_scale(row_hit, 1.0)
-        ctx.save_for_backward(grad)
-        ctx.meta = (logits.shape, ld, denom)
-        ctx.mark_non_differentiable(hits)
-        return loss.view(()), hits.view(())
-
-    @staticmethod
-    @_bwd_mode
-    def backward(ctx, g, _gh):
-        (grad,) = ctx.saved_tensors
-        shape, ld, denom = ctx.meta
-        d = ops.scale_dropout(grad, torch.float32, alpha=1.0 / denom,
-                              alpha_dev=g.reshape(1).to(torch.float32).contiguous())
-        return d.view(shape[:-1] + (ld,))[..., : shape[-1]], None, None, None, None
-
-
-def ce_smooth(logits, target, smoothing, ignore_id, denom):
-    return CeSmoothFn.apply(logits, target, float(smoothing), int(ignore_id), float(denom))
-
-
-class AddRowsFn(torch.autograd.Function):
-    """dropout(x*scale + table[t])  for x (B, n, D), table (n, D) -- embedding.py:78-87 as a stand-alone module."""
-
-    @staticmethod
-    def forward(ctx, x, table, scale, p):
-        pp, s, sd = _drop_args(p, x)
-        ctx.meta = (scale, pp, s, sd)
-        return ops.scale_dropout(x.contiguous(), torch.float32, alpha=scale, drop_p=pp, seed=s, seed_dev=sd,
-                                 add=table, add_period=table.numel())
-
-    @staticmethod
-    @_bwd_mode
-    def backward(ctx, dy):
-        scale, pp, s, sd = ctx.meta
-        return ops.scale_dropout(dy.contiguous(), torch.float32, alpha=scale, drop_p=pp, seed=s, seed_dev=sd), None, None, None
-
-
-def add(a, b):
-    """a + b (f32 result; inference-time glue of the incremental decoder, no autograd)."""
-    bb = _to_f32(b)
-    return ops.scale_dropout(a.contiguous(), torch.float32, add=bb, add_period=bb.numel())
-
-
-def log_softmax(logits):
-    """Row-wise log-softmax of f32 logits [..., V] (possibly a [..., :V] view of a pitch-padded buffer); inference
-    helper of ctc.py:76-83 and transformer_decoder.py:288."""
-    V = logits.shape[-1]
-    rows = logits.numel() // V
-    pit = _pitched_2d(logits, rows, V)
-    if pit is None or logits.dtype != torch.float32:
-        ld = padded_cols(V)
-        buf = torch.zeros(rows, ld, dtype=torch.float32, device=logits.device)
-        buf[:, :V].copy_(logits.reshape(rows, V))
-        pit = (buf, ld)
-    l2, ld = pit
-    out = ops.log_softmax(l2, ld, rows, V)
-    return out.view(logits.shape[:-1] + (ld,))[..., :V]
-
-
-# ================================================================================================ front-ends
-def _bn_fwd_params(c2, rows, C, bn, training):
-    """(mean, invstd, counts) of a BatchNorm over the rows of c2; bn = (weight, bias, running_mean, running_var,
-    eps, momentum).  Training: batch statistics (cross-rank when set_bn_sync) + running-stat update."""
-    if training:
-        return _bn_train_stats(c2, rows, C, bn[4], bn[5], bn[2], bn[3], bn[6] if len(bn) > 6 else None)
-    mean, invstd = ops.bn_eval_params(bn[2], bn[3], bn[4])
-    return mean, invstd, None
-
-
-def _bn_bwd(c, dy, add, mean, invstd, bn, counts, rows, C, act, want_dadd, training):
-    """Backward of y = act(bn(c) + add): returns (dc, dadd, dgamma, dbeta)."""
-    sums = ops.bn_bwd_reduce(c, dy, add, mean, invstd, bn[0], bn[1], rows, C, act)
-    dgamma, dbeta = sums[1], sums[0]  # views of a fresh tensor
-    if training:
-        sums_dx, inv_n, n_dev = _bn_bwd_sums(sums, counts, rows)
-    else:
-        sums_dx, inv_n, n_dev = torch.zeros_like(sums), 0.0, None
-    dc, dadd = ops.bn_bwd_apply(c, dy, add, mean, invstd, bn[0], bn[1], sums_dx, inv_n, rows, C, act, want_dadd,
-                                n_dev=n_dev)
-    return dc, dadd, dgamma, dbeta
-
-
-def bn_tuple(m):
-    """Pack a torch BatchNorm module for the front-end functions.  In training the batch counter is incremented by
-    the statistics kernel (bn_finalize) -- one launch less per BatchNorm than `num_batches_tracked.add_(1)`."""
-    return (m.weight, m.bias, m.running_mean, m.running_var, float(m.eps), float(m.momentum if m.momentum is not None else 0.1),
-            m.num_batches_tracked if m.training else None)
-
-
-class BasicBlockFn(torch.autograd.Function):
-    """frontend/resnet.py:82-98 (and resnet1d.py:83-99 with H = 1) on a channels-last activation:
-    conv3x3(stride) -> BN -> SiLU -> conv3x3 -> BN -> (+ identity | + BN(conv1x1(stride))) -> SiLU,
-    forward and backward, every convolution an implicit MFMA GEMM, BatchNorm in batch-statistics mode."""
-
-    @staticmethod
-    def forward(ctx, x, dims, stride, training, w1, g1, b1, w2, g2, b2, wd, gd, bd, bn1, bn2, bnd):
-        N, H, W, Cin = dims
-        Cout = w1.shape[0]
-        KH, KW = w1.shape[2], w1.shape[3]
-        ph, pw = (KH - 1) // 2, (KW - 1) // 2
-        T = act_dtype()
-        pr = _state["precise"]
-        x_arg = x
-        x = _act_in(x)  # hpf / mixed: the previous trunk function handed over its bf16 twin; compute on the f32 / f16 original
-        OH, OW = ops.conv_out(H, KH, stride, ph), ops.conv_out(W, KW, stride, pw)
-        rows = N * OH * OW
-        bn1 = (g1, b1) + bn1
-        bn2 = (g2, b2) + bn2
-        c1 = ops.conv2d_fwd(x, _w_conv_fwd(w1, x), N, H, W, Cin, Cout, KH, KW, stride, ph, pw, pr)
-        m1, i1, n1 = _bn_fwd_params(c1, rows, Cout, bn1, training)
-        a1 = ops.bn_act_fwd(c1, None, m1, i1, g1, b1, rows, Cout, 1)
-        c2 = ops.conv2d_fwd(a1, _w_conv_fwd(w2, a1), N, OH, OW, Cout, Cout, KH, KW, 1, ph, pw, pr)
-        m2, i2, n2 = _bn_fwd_params(c2, rows, Cout, bn2, training)
-        cd = md = idd = nd = None
-        if wd is not None:
-            bnd = (gd, bd) + bnd
-            cd = ops.conv2d_fwd(x, _w_conv_fwd(wd, x), N, H, W, Cin, Cout, 1, 1, stride, 0, 0, pr)
-            md, idd, nd = _bn_fwd_params(cd, rows, Cout, bnd, training)
-            r = ops.bn_act_fwd(cd, None, md, idd, gd, bd, rows, Cout, 0)
-        else:
-            r = x
-        out = ops.bn_act_fwd(c2, r, m2, i2, g2, b2, rows, Cout, 1)
-        sx = x_arg if (_state["hpf"] and x_arg.dtype == torch.bfloat16 and x_arg is not x) else _A(x)  # (the handed-over twin itself)
-        ctx.save_for_backward(sx, _A(c1), _A(a1), _A(c2), _A(cd), _A(r) if wd is not None else None, w1, w2, wd, g1, b1, g2, b2,
-                              gd, bd, m1, i1, n1, m2, i2, n2, md, idd, nd)
-        ctx.meta = (dims, stride, training, (OH, OW), bn1[2:], bn2[2:], bnd[2:] if wd is not None else None)
-        return _hand_over(out)
-
-    @staticmethod
-    @_bwd_mode
-    def backward(ctx, dout):
-        (x, c1, a1, c2, cd, r, w1, w2, wd, g1, b1, g2, b2, gd, bd, m1, i1, n1, m2, i2, n2, md, idd, nd) = ctx.saved_tensors
-        dims, stride, training, (OH, OW), r1, r2, rd = ctx.meta
-        N, H, W, Cin = dims
-        Cout = w1.shape[0]
-        KH, KW = w1.shape[2], w1.shape[3]
-        ph, pw = (KH - 1) // 2, (KW - 1) // 2
-        T = act_dtype()
-        pr = _state["precise"]
-        rows = N * OH * OW
-        dout = _to_act(dout)
-        if wd is None:
-            r = x
-        dc2, dr, dg2, db2 = _bn_bwd(c2, dout, r, m2, i2, (g2, b2) + r2, n2, rows, Cout, 1, True, training)
-        dw2 = ops.conv2d_wgrad(dc2, a1, N, OH, OW, Cout, Cout, KH, KW, 1, ph, pw, pr, torch_layout=True)
-        da1 = ops.conv2d_dgrad(dc2, _w_conv(w2, True), None, N, OH, OW, Cout, Cout, KH, KW, 1,
-                               ph, pw, pr)
-        dc1, _, dg1, db1 = _bn_bwd(c1, da1, None, m1, i1, (g1, b1) + r1, n1, rows, Cout, 1, False, training)
-        dw1 = ops.conv2d_wgrad(dc1, x, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, pr, torch_layout=True)
-        dwd = dgd = dbd = None
-        if wd is not None:
-            dcd, _, dgd, dbd = _bn_bwd(cd, dr, None, md, idd, (gd, bd) + rd, nd, rows, Cout, 0, False, training)
-            dwd = ops.conv2d_wgrad(dcd, x, N, H, W, Cin, Cout, 1, 1, stride, 0, 0, pr, torch_layout=True)
-            skip = ops.conv2d_dgrad(dcd, _w_conv(wd, True), None, N, H, W, Cin, Cout, 1, 1,
-                                    stride, 0, 0, pr)
-        else:
-            skip = dr
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = ops.conv2d_dgrad(dc1, _w_conv(w1, True), skip, N, H, W, Cin, Cout, KH, KW,
-                                  stride, ph, pw, pr)
-        return (dx, None, None, None, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None)
-
-
-def basic_block(x, dims, stride, training, conv1, bn1, conv2, bn2, down):
-    """x: channels-last [N,H,W,Cin] activation-dtype tensor; modules supply the parameters."""
-    _state["tag_ok"] = torch.is_grad_enabled()
-    t1, t2 = bn_tuple(bn1), bn_tuple(bn2)
-    if down is not None:
-        td = bn_tuple(down[1])
-        return BasicBlockFn.apply(x, dims, stride, training, conv1.weight, t1[0], t1[1], conv2.weight, t2[0], t2[1],
-                                  down[0].weight, td[0], td[1], t1[2:], t2[2:], td[2:])
-    return BasicBlockFn.apply(x, dims, stride, training, conv1.weight, t1[0], t1[1], conv2.weight, t2[0], t2[1], None, None,
-                              None, t1[2:], t2[2:], None)
-
-
-class StemFn(torch.autograd.Function):
-    """Single-input-channel stem: conv (temporal x spatial taps) -> BN -> SiLU -> optional 3x3/s2 max-pool.
-    Video: frontend/resnet.py:203-219 (Conv3d(1,64,(5,7,7),s(1,2,2)) + BatchNorm3d + SiLU + MaxPool3d).
-    Audio: frontend/resnet1d.py:124-139,190-192 (Conv1d(1,64,80,s4) + BatchNorm1d + SiLU; no pooling)."""
-
-    @staticmethod
-    def forward(ctx, x, w, g, b, bn_rest, geom, pool, training):
-        B, Tn, H, W, KT, KH, KW, stride, pt, ph, pw = geom
-        Cout = w.shape[0]
-        T = act_dtype()
-        pr = _state["precise"]
-        x = x.contiguous()
-        taps = KT * KH * KW
-        ldw = padded_cols(taps)
-        geom_ok = (KT, KH, KW, stride, pt, ph, pw, Cout) == (5, 7, 7, 2, 2, 3, 3, 64) and W % 4 == 0 and W <= 96 \
-            and (W - 1) // 2 + 1 <= 64
-        dedicated = geom_ok and not pr
-        if dedicated:  # csrc/stem.hip: input rows staged once in LDS
-            c0 = ops.stem357_fwd(x, w, B, Tn, H, W)
-        elif geom_ok and pr and ops.SPLIT_FAST and x.dtype == torch.float32 and w.dtype == torch.float32:
-            c0 = ops.stem357_fwd_f32s(x, w.contiguous(), B, Tn, H, W)  # the same kernel on split hi / lo planes, f32 result
-        else:
-            wp = ops.conv_weight_permute(w, T, ld_out=ldw)
-            c0 = ops.conv_stem_fwd(x, wp, ldw, T, B, Tn, H, W, Cout, KT, KH, KW, stride, pt, ph, pw, pr)
-        OH, OW = c0.shape[1], c0.shape[2]
-        rows = B * Tn * OH * OW
-        bn = (g, b) + bn_rest
-        m0, i0, n0 = _bn_fwd_params(c0, rows, Cout, bn, training)
-        idx = xsel = None
-        if pool and _FUSE_STEM_POOL:
-            # BN + SiLU + max-pool in one pass: the full-resolution activation (396 MB per 1600 video frames) is never
-            # written (the backward pass recomputes it from c0 anyway)
-            # xsel: the raw conv output at every arg-max -- all the backward reduce pass needs of c0
-            out, idx, xsel = ops.bn_act_pool_fwd(c0, m0, i0, g, b, B * Tn, OH, OW, Cout, 3, 2, 1, 1, want_xsel=True)
-        elif pool:
-            a0 = ops.bn_act_fwd(c0, None, m0, i0, g, b, rows, Cout, 1)
-            out, idx = ops.maxpool2d_fwd(a0, B * Tn, OH, OW, Cout, 3, 2, 1)
-        else:
-            out = ops.bn_act_fwd(c0, None, m0, i0, g, b, rows, Cout, 1)
-        ctx.save_for_backward(x, _A(c0), idx, g, b, m0, i0, n0, _A(xsel))
-        ctx.meta = (geom, pool, training, bn_rest, (OH, OW), w.shape, geom_ok and not _bwd_precise())
-        if _state["hpf"] and out.dtype == torch.float32 and out.data_ptr() not in _twins and _state.get("tag_ok", True):
-            # (the pooled output has no producer-side twin: make it here -- the first residual block would cast it anyway)
-            _twins[out.data_ptr()] = (out, ops.scale_dropout(out, torch.bfloat16))
-        return _hand_over(out)
-
-    @staticmethod
-    @_bwd_mode
-    def backward(ctx, dout):
-        x, c0, idx, g, b, m0, i0, n0, xsel = ctx.saved_tensors
-        geom, pool, training, bn_rest, (OH, OW), wshape, dedicated = ctx.meta
-        B, Tn, H, W, KT, KH, KW, stride, pt, ph, pw = geom
-        Cout = wshape[0]
-        rows = B * Tn * OH * OW
-        dout = _to_act(dout)
-        if pool and _FUSE_STEM_POOL:
-            # the activation gradient is gathered from the pooled gradient inside both BatchNorm backward passes: the
-            # full-resolution gradient (396 MB per 1600 video frames) is neither written nor read back
-            dp = _to_act(dout)
-            # sum over pixels of dz == sum over pooled outputs of dpool * act'(z(arg-max pixel)): the reduce pass runs on
-            # the pooled tensors (a quarter of the pixels) and never reads c0
-            POH, POW = ops.conv_out(OH, 3, 2, 1), ops.conv_out(OW, 3, 2, 1)
-            sums = ops.bn_bwd_reduce(xsel, dp, None, m0, i0, g, b, B * Tn * POH * POW, Cout, 1)
-            dg, db = sums[1], sums[0]
-            if training:
-                sums_dx, inv_n, n_dev = _bn_bwd_sums(sums, n0, rows)
-            else:
-                sums_dx, inv_n, n_dev = torch.zeros_like(sums), 0.0, None
-            dc0 = ops.bn_pool_bwd_apply(c0, dp, idx, m0, i0, g, b, sums_dx, inv_n, B * Tn, OH, OW, Cout, 3, 2, 1, 1,
-                                        n_dev=n_dev)
-        else:
-            da0 = ops.maxpool2d_bwd(idx, dout, B * Tn, OH, OW, Cout, 3, 2, 1) if pool else dout
-            dc0, _, dg, db = _bn_bwd(c0, da0, None, m0, i0, (g, b) + bn_rest, n0, rows, Cout, 1, False, training)
-        if dedicated:
-            dw = ops.stem357_wgrad(dc0, x, B, Tn, H, W)
-        else:
-            dw = ops.conv_stem_wgrad(dc0, x, B, Tn, H, W, Cout, KT, KH, KW, stride, pt, ph, pw, _state["precise"])
-        return None, dw.view(wshape), dg, db, None, None, None, None
-
-
-def stem(x, conv, bn, geom, pool):
-    _state["tag_ok"] = torch.is_grad_enabled()
-    t = bn_tuple(bn)
-    return StemFn.apply(x, conv.weight, t[0], t[1], t[2:], geom, pool, bn.training)
-
-
-class AvgPoolFn(torch.autograd.Function):
-    """Mean over groups of `win` consecutive pixels of a channels-last tensor -> f32 [groups, C]
-    (AdaptiveAvgPool2d(1), resnet.py:117,164; AvgPool1d(20), resnet1d.py:143-146)."""
-
-    @staticmethod
-    def forward(ctx, x, groups, win, C):
-        ctx.meta = (groups, win, C, x.dtype, x.shape)
-        return ops.avgpool_fwd(_f32_in(x).contiguous(), groups, win, C)  # (hpf: the trunk hands over its bf16 twin)
-
-    @staticmethod
-    @_bwd_mode
-    def backward(ctx, dy):
-        groups, win, C, dtype, shape = ctx.meta
-        return ops.avgpool_bwd(_to_f32(dy), dtype, groups, win, C).view(shape), None, None, None
-
-
-def avg_pool(x, groups, win, C):
-    _state["tag_ok"] = torch.is_grad_enabled()
-    return AvgPoolFn.apply(x, groups, win, C)
+# ---- the sub-layer families live in modules of their own (round 4); everything they define is part of this module's surface
+# (nets.py / frontend.py / tests address it as functional.<name>)
+from .functional_convmod import (  # noqa: E402,F401
+    _const_cache, _const1, _bn_train_stats, _bn_bwd_sums, ConvSublayerFn, conv_sublayer)
+from .functional_attention import (  # noqa: E402,F401
+    prepare_pos_proj, _placeholders, _placeholder_grad, PosProjFn, _proj, AttentionCoreFn, attention_core,
+    MhaSublayerFn, mha_sublayer, MemoryKVFn, memory_kv)
+from .functional_heads import (  # noqa: E402,F401
+    ScaleDropoutFn, scale_dropout, EmbedFn, embed, CtcLossFn, ctc_loss, CeSmoothFn, ce_smooth, AddRowsFn, add,
+    log_softmax)
+from .functional_frontend import (  # noqa: E402,F401
+    _bn_fwd_params, _bn_bwd, bn_tuple, BasicBlockFn, basic_block, StemFn, stem, AvgPoolFn, avg_pool)

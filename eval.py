@@ -23,7 +23,7 @@ def parse_args(argv=None):
     p.add_argument("--synthetic-utterances", type=int, default=0,
                    help="decode this many synthetic utterances instead of a dataset (default when --root-dir is absent: 4)")
     p.add_argument("--max-test-frames", type=int, default=100, help="length cap of the synthetic utterances")
-    p.add_argument("--numerics", choices=["precise", "bf16"], default="precise",
+    p.add_argument("--numerics", choices=["precise", "mixed", "bf16"], default="precise",
                    help="arithmetic of the decoding forward pass: precise (split hi / lo bf16 planes -- hypotheses equal an fp32 run "
                         "of the reference; the default) or bf16 (faster on long utterances)")
     return p.parse_args(argv)

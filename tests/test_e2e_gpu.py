@@ -74,10 +74,22 @@ def test_full_e2e_bf16_vs_oracle():
     assert min(cos) > 0.9 and sum(cos) / len(cos) > 0.99, (min(cos), sum(cos) / len(cos))
 
 
-def test_hipgraph_replay_matches_eager():
+@pytest.fixture
+def numerics_mode(request):
+    from auto_avsr_amd import functional as AF
+
+    AF.set_mode(request.param)
+    yield request.param
+    AF.set_mode("bf16")
+    AF.invalidate_weight_cache()
+
+
+@pytest.mark.parametrize("numerics_mode", ["bf16", "mixed"], indirect=True)
+def test_hipgraph_replay_matches_eager(numerics_mode):
     """The bench path: a training step captured into a hipGraph (per batch shape) must reproduce the eager
-    gradients on EVERY replay -- zero-initialised accumulators re-zeroed, fresh cast of the weights, no buffer of the
-    capture freed or reused afterwards (two shapes are captured before either graph is replayed)."""
+    gradients on EVERY replay -- zero-initialised accumulators re-zeroed, fresh cast of the weights (mixed mode: also the f16 /
+    split-plane copies), no buffer of the capture freed or reused afterwards (two shapes are captured before either graph is
+    replayed).  Both the bf16 mode and the mixed mode bench.py times."""
     from auto_avsr_amd import functional as AF
 
     m, _ = _model("video", 9)
@@ -132,7 +144,7 @@ def test_hipgraph_replay_matches_eager():
     AF.invalidate_weight_cache()
 
 
-@pytest.mark.parametrize("mode", ["precise", "bf16"])
+@pytest.mark.parametrize("mode", ["precise", "mixed", "bf16"])
 def test_full_e2e_beam_search_vs_reference(mode):
     """Evaluation path at full size (eval mode): front-end -> encoder -> hybrid CTC/attention beam search as
     lightning.ModelModule.forward wires it; hypotheses equal the reference's (tests/golden/make_golden_decode.py) -- in the
@@ -148,7 +160,10 @@ def test_full_e2e_beam_search_vs_reference(mode):
     bs = lightning.get_beam_search_decoder(m, [str(i) for i in range(5049)], beam_size=c["beam"])
     AF.set_mode(mode)
     AF.invalidate_weight_cache()
-    tol = 1e-3 if mode == "precise" else 2e-2
+    # (mixed: the encoder on f16 operands, the incremental decoder steps / CTC scorer on split planes: the n-best list of the
+    # reference token for token, scores within 5e-3; the encoder sample within 1e-2 of its maximum)
+    tol = {"precise": 1e-3, "mixed": 1e-2, "bf16": 2e-2}[mode]
+    stol = {"precise": 1e-3, "mixed": 5e-3, "bf16": 2e-2}[mode]
     try:
         with torch.no_grad():
             feats = m.proj_encoder(m.frontend(x.cuda()))
@@ -164,4 +179,4 @@ def test_full_e2e_beam_search_vs_reference(mode):
         d = got.asdict()
         if mode == "precise" or i == 0:
             assert d["yseq"] == ref["yseq"], (mode, i)
-            assert abs(d["score"] - ref["score"]) < tol * max(1.0, abs(ref["score"])), (mode, i, d["score"], ref["score"])
+            assert abs(d["score"] - ref["score"]) < stol * max(1.0, abs(ref["score"])), (mode, i, d["score"], ref["score"])
