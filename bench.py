@@ -661,7 +661,7 @@ def roofline(model, batch, ops):
             "traffic_unit": "HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, calibrated)", "traffic_source": src,
             "algorithmic_bytes_per_launch": round(algo),
             "avg_us_event_bracketed": round(t_ev / n * 1e6, 2),
-            "step_kernel_time_ms": round(tot * 1e3, 3),
+            "event_bracketed_sum_ms": round(tot * 1e3, 3),  # (sum over launches INCLUDING ~3 us of event-pair overhead each: not kernel time)
             "share_of_kernel_time": round(t_ev / tot, 3),
             "families_ms": {k: round(v[0] * 1e3, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:8]}}
     bn = [c for c in rec2 if c[0] in BN_FAMILY]

@@ -12,7 +12,9 @@ FIXTURE = os.path.join(HERE, "golden_bench_v1.pt")
 FAV = 17
 ODIM = 5049
 NSAMP = 64
-BATCHES = {"A": dict(lengths=[400, 380, 360, 340], L=64, seed=21), "B": dict(lengths=[100] * 16, L=16, seed=22)}
+BATCHES = {"A": dict(lengths=[400, 380, 360, 340], L=64, seed=21), "B": dict(lengths=[100] * 16, L=16, seed=22),
+           # round 4: the audio model (BASELINE configs[3]: asr_trlrs3_base) at batch A's geometry -- 640 samples per frame
+           "AA": dict(lengths=[400, 380, 360, 340], L=64, seed=23, modality="audio")}
 
 
 def sample_index(name, numel, seed=0):
@@ -26,19 +28,23 @@ def bench_state_dict(template, seed):
     return sd
 
 
-def bench_batch(lengths, L, seed):
-    """x (B, Tmax, 1, 88, 88) zero-padded, lengths, y (B, 1, L) with label length round(T / 6.25) capped at L, pad -1."""
+def bench_batch(lengths, L, seed, modality="video"):
+    """x (B, Tmax, 1, 88, 88) [audio: (B, 640 Tmax, 1)] zero-padded, lengths in frames [audio: in samples], y (B, 1, L) with
+    label length round(T / 6.25) capped at L, pad -1."""
     g = torch.Generator().manual_seed(5000 + seed)
     B, T = len(lengths), max(lengths)
-    x = torch.zeros(B, T, 1, 88, 88)
+    x = torch.zeros(B, T, 1, 88, 88) if modality == "video" else torch.zeros(B, 640 * T, 1)
     y = torch.full((B, 1, L), -1, dtype=torch.int64)
     for b, t in enumerate(lengths):
-        x[b, :t] = torch.randn(t, 1, 88, 88, generator=g)
+        if modality == "video":
+            x[b, :t] = torch.randn(t, 1, 88, 88, generator=g)
+        else:
+            x[b, : 640 * t] = torch.randn(640 * t, 1, generator=g)
         n = min(L, max(1, round(t / 6.25)))
         lab = torch.randint(1, ODIM - 1, (n,), generator=g)
         lab[::5] = FAV
         y[b, 0, :n] = lab
-    return x, torch.tensor(lengths, dtype=torch.int64), y
+    return x, torch.tensor(lengths, dtype=torch.int64) * (1 if modality == "video" else 640), y
 
 
 def rel(a, b):
@@ -55,7 +61,7 @@ def measure(model, case, device):
     are skipped)."""
     import statistics
 
-    x, lengths, y = bench_batch(case["lengths"], case["L"], case["seed"])
+    x, lengths, y = bench_batch(case["lengths"], case["L"], case["seed"], case.get("modality", "video"))
     grab = {}
     hooks = [model.encoder.register_forward_hook(lambda m, i, o: grab.__setitem__("enc", o[0].detach())),
              model.decoder.register_forward_hook(lambda m, i, o: grab.__setitem__("dec", o[0].detach())),

@@ -29,7 +29,7 @@ def gold():
     return torch.load(BC.FIXTURE, weights_only=False)
 
 
-def _model(seed):
+def _model(seed, modality="video"):
     from auto_avsr_amd import _lib
     from auto_avsr_amd import functional as AF
     from auto_avsr_amd.e2e import E2E
@@ -37,7 +37,7 @@ def _model(seed):
     _lib._lib = None
     assert not _lib.lib().is_emulator
     AF.invalidate_weight_cache()
-    m = E2E(BC.ODIM, "video")
+    m = E2E(BC.ODIM, modality)
     for mod in m.modules():
         if isinstance(mod, torch.nn.Dropout):
             mod.p = 0.0
@@ -45,13 +45,13 @@ def _model(seed):
     return m.cuda().train()
 
 
-@pytest.mark.parametrize("tag", ["A", "B"])
+@pytest.mark.parametrize("tag", ["A", "B", "AA"])  # AA (round 4): the AUDIO model (BASELINE configs[3]) at batch A's geometry
 @pytest.mark.parametrize("mode", ["precise", "hpf", "mixed", "bf16"])
 def test_bench_shape_parity(gold, tag, mode):
     from auto_avsr_amd import functional as AF
 
     case = gold[tag]
-    m = _model(case["seed"])
+    m = _model(case["seed"], case.get("modality", "video"))
     with AF.numerics(mode):
         r = BC.measure(m, case, torch.device("cuda"))
     AF.invalidate_weight_cache()

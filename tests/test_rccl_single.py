@@ -42,3 +42,21 @@ def test_data_parallel_step_on_rccl_c_api_captured_into_hipgraph(wire):
     assert out["graph_capture"] == "ok" and out["graph_replay_moved_params"] and out["buckets"] > 10
     assert out["graph_loss"] == out["graph_loss"] and out["graph_loss"] < out["losses_capi"][1]
     assert out["losses_capi"] == pytest.approx(out["losses_plain"], rel=2e-2)
+    # ... and against the ORACLE, not only against the same kernels without a communicator: the first step's loss (before any
+    # update) of the data-parallel path equals the fp32 restatement of the reference on the same weights and batch, rescaled
+    # W / sum(B) as lightning.py:88-90 does (bf16 mode: 3e-2)
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from synth import synth_batch, synth_state_dict
+
+    from auto_avsr_amd.e2e import E2E
+    from oracle import avsr_oracle as O
+
+    torch.manual_seed(0)
+    tmpl = E2E(41, "video", adim=128, aheads=2, eunits=256, elayers=2, dunits=256, dlayers=2, cnn_module_kernel=7)
+    sd = synth_state_dict(tmpl.state_dict(), 31)
+    x, lens, y = synth_batch("video", 3, 8, 3, 41, seed=12, lengths=[8, 6, 5])
+    with torch.no_grad():
+        (loss_r, *_), _ = O.e2e_forward(sd, x, lens, y, modality="video", heads=2)
+    assert out["losses_capi"][0] == pytest.approx(float(loss_r) / 3.0, rel=3e-2)
