@@ -100,6 +100,12 @@ class GroupComm:
 
     def all_gather(self, out, mine):
         assert out.numel() == self.world * mine.numel()
+        if out.is_cuda and self._dist.get_backend(self.group) == "gloo":
+            # (gloo has no all-gather on device tensors: sum of one-hot placements)
+            out.zero_()
+            out.view(self.world, -1)[self.rank].copy_(mine.reshape(-1))
+            self._dist.all_reduce(out, group=self.group)
+            return out
         self._dist.all_gather_into_tensor(out, mine, group=self.group)
         return out
 
