@@ -306,24 +306,34 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_pool3_fwd_kernel(
         load8(invstd + c, is);
         load8(gamma + c, ga);
         load8(beta + c, be);
+        // max over the window of act(bn(x)) needs TWO activations, not nine: bn is affine in x (monotone either way) and every
+        // activation here (identity, ReLU, SiLU) is monotone or falls-then-rises, so the maximum over a set of inputs is attained
+        // at the set's largest or smallest x.  The SiLU evaluations (v_exp + v_rcp: ~12 VALU each) were what bound this kernel
+        // -- 9 per pooled output, 2x its byte time; compares are one instruction.  Ties keep the first tap in window order.
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-            m[e] = -INFINITY;
-            am[e] = 0;
-            xs[e] = 0.f;
-        }
+            float xM = -INFINITY, xm = INFINITY;
+            int tM = 0, tm = 0;
 #pragma unroll
-        for (int t = 0; t < 9; t++) {
-            const bool in = (ok >> t) & 1u;
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                float a = act_fwd((v[t][e] - mu[e]) * is[e] * ga[e] + be[e], act);
-                if (sizeof(T) == 2) a = bf2f(f2bf(a));  // the value the unfused path would have stored
-                const bool take = in && a > m[e];
-                m[e] = take ? a : m[e];
-                am[e] = take ? t : am[e];
-                xs[e] = take ? v[t][e] : xs[e];
+            for (int t = 0; t < 9; t++) {
+                const bool in = (ok >> t) & 1u;
+                const float xv = v[t][e];
+                const bool up = in && xv > xM, dn = in && xv < xm;
+                xM = up ? xv : xM;
+                tM = up ? t : tM;
+                xm = dn ? xv : xm;
+                tm = dn ? t : tm;
             }
+            float aM = act_fwd((xM - mu[e]) * is[e] * ga[e] + be[e], act);
+            float am_ = act_fwd((xm - mu[e]) * is[e] * ga[e] + be[e], act);
+            if (sizeof(T) == 2) {  // the values the unfused path would have stored
+                aM = bf2f(f2bf(aM));
+                am_ = bf2f(f2bf(am_));
+            }
+            const bool lo = am_ > aM || (am_ == aM && tm < tM);
+            m[e] = lo ? am_ : aM;
+            am[e] = lo ? tm : tM;
+            xs[e] = lo ? xm : xM;
         }
         store8(y + i * 8, m);
         if (xsel) store8(xsel + i * 8, xs);

@@ -240,7 +240,10 @@ def test_bn_pool_bwd_fused_matches_three_pass(dev, dtype):
     dx1 = ops.bn_pool_bwd_apply(x, dpool, idx, mean, invstd, gamma, beta, sums1, 1.0 / rows, N, H, W, C, 3, 2, 1, 1)
     # the product path: the reduce pass on the pooled tensors alone, through xsel (raw x at every arg-max)
     y2, idx2, xsel = ops.bn_act_pool_fwd(x, mean, invstd, gamma, beta, N, H, W, C, 3, 2, 1, 1, want_xsel=True)
-    assert torch.equal(idx2, idx)
+    # (the fused kernel finds the maximum from the window's largest and smallest INPUT -- two activations instead of nine; where
+    # several taps round to the same bf16 activation it may name another of the tied taps than the first in window order)
+    assert torch.equal(y2, y)
+    assert torch.equal(idx2, idx) if dtype == torch.float32 else (idx2 == idx).float().mean() > 0.99
     sums2 = ops.bn_bwd_reduce(xsel.view(-1, C), dpool.view(-1, C), None, mean, invstd, gamma, beta, dpool.numel() // C, C, 1)
     # the three-pass path rounds the gathered gradient to the storage type before the BatchNorm passes; the fused one does not
     tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
