@@ -180,8 +180,13 @@ class ResNet1D(nn.Module):
         B, S = x.shape
         k, st, pd = self.conv1.kernel_size[0], self.conv1.stride[0], self.conv1.padding[0]
         geom = (B, 1, 1, S, 1, 1, k, st, 0, 0, pd)
-        h = AF.stem(x, self.conv1, self.bn1, geom, pool=False)  # (B, 1, S/4, 64)
-        h, (N, H, W, C) = self.layer4(self.layer3(self.layer2(self.layer1((h, (B, 1, h.shape[2], h.shape[3]))))))
+        with AF.component("astem"):
+            h = AF.stem(x, self.conv1, self.bn1, geom, pool=False)  # (B, 1, S/4, 64)
+        xd = (h, (B, 1, h.shape[2], h.shape[3]))
+        for i, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
+            with AF.component(f"atrunk{i + 1}"):  # (mixed numerical mode: forward arithmetic per stage, AF.MIXED_POLICY)
+                xd = layer(xd)
+        h, (N, H, W, C) = xd
         win = self.avgpool.kernel_size[0] if isinstance(self.avgpool.kernel_size, tuple) else self.avgpool.kernel_size
         groups = B * (W // win)
         if W % win:

@@ -31,8 +31,8 @@ _state = {"precise": False, "hpf": False, "mixed": False, "f16": False, "seed": 
           "bn_sync": None}
 
 # "mixed" mode: forward arithmetic per component of the model ("f16": IEEE-half operands, one MFMA per product, bf16 speed;
-# "split": hi + lo bf16 planes, three MFMAs per product; "bf16").  Components: stem, trunk1..trunk4 (ResNet stages), encoder,
-# decoder, dec_out (the vocabulary projection); what is not listed (and the projections / CTC head outside any component)
+# "split": hi + lo bf16 planes, three MFMAs per product; "bf16").  Components: stem, trunk1..trunk4 (ResNet stages), astem,
+# atrunk1..atrunk4 (the audio front-end), encoder, decoder, dec_out (the vocabulary projection); what is not listed (and the projections / CTC head outside any component)
 # runs "split".  The default was chosen from measurements on the MI355X against the reference goldens of BOTH benchmarked
 # batches (tools/mixed_sweep.py -> profiles/r4_mixed_policy_sweep.txt; the CPU study tools/precision_study.py predicted the
 # encoder-only figure to 3 %): decoder-logit error / step time at batch A --
@@ -42,7 +42,9 @@ _state = {"precise": False, "hpf": False, "mixed": False, "f16": False, "seed": 
 # The early ResNet stages are where f16 hurts most per millisecond saved (stage 1 alone: B 6.0e-4 -> 8.3e-4), and the
 # sensitivity moves by +-40 % with the weights (batch A / B use different synthetic weights): the default keeps >= 25 % of the
 # 1e-3 bound in hand on both fixtures.
-MIXED_POLICY = {"encoder": "f16", "decoder": "f16", "trunk3": "f16", "trunk4": "f16"}
+# (atrunkN / astem: the stages of the 1-D audio ResNet, measured on the audio fixture "AA": encoder + decoder 6.6e-4, + atrunk3, 4
+# 6.8e-4 / -0.7 ms per step, + atrunk2 7.1e-4, + atrunk1 9.2e-4 -- profiles/r4_mixed_policy_sweep.txt)
+MIXED_POLICY = {"encoder": "f16", "decoder": "f16", "trunk3": "f16", "trunk4": "f16", "atrunk3": "f16", "atrunk4": "f16"}
 if os.environ.get("AVSR_MIXED_POLICY"):  # A/B runs: "encoder=f16,trunk3=f16,decoder=split"
     MIXED_POLICY = dict(kv.split("=") for kv in os.environ["AVSR_MIXED_POLICY"].split(",") if kv)
 

@@ -19,12 +19,15 @@ T4 = "trunk1=f16,trunk2=f16,trunk3=f16,trunk4=f16"
 DEFAULT = ["encoder=f16", f"encoder=f16,{T4}", f"encoder=f16,{T4},decoder=f16", f"encoder=f16,{T4},decoder=f16,dec_out=f16",
            "encoder=f16,trunk2=f16,trunk3=f16,trunk4=f16,decoder=f16,dec_out=f16", "encoder=f16,decoder=f16,dec_out=f16",
            f"encoder=f16,{T4},dec_out=f16"]
+tags = ("A", "B")
+if len(sys.argv) > 1 and sys.argv[1].startswith("--tags="):  # e.g. --tags=AA (the audio model at batch A's geometry)
+    tags = tuple(sys.argv.pop(1)[7:].split(","))
 policies = sys.argv[1:] or DEFAULT
 gold = torch.load(BC.FIXTURE, weights_only=False)
-for tag in ("A", "B"):
+for tag in tags:
     case = gold[tag]
     AF.invalidate_weight_cache()
-    m = E2E(BC.ODIM, "video")
+    m = E2E(BC.ODIM, case.get("modality", "video"))
     for mod in m.modules():
         if isinstance(mod, torch.nn.Dropout):
             mod.p = 0.0
