@@ -99,6 +99,20 @@ def supervise(args):
     chain = DDP_CHAIN if want == "auto" else [want]
     limits = [float(x) for x in os.environ.get("AVSR_BENCH_ATTEMPT_TIMEOUT", "600,420,420").split(",")]
     argv = [a for a in sys.argv[1:] if a != "--worker"]
+    live = []
+
+    def reap(signum=None, frame=None):  # the launcher (torchrun, the driver) is taking this supervisor down: take the workers along
+        for pr in live:
+            if pr.poll() is None:
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+        if signum is not None:
+            sys.exit(128 + signum)
+
+    signal.signal(signal.SIGTERM, reap)
+    signal.signal(signal.SIGINT, reap)
     for attempt, mode in enumerate(chain):
         limit = limits[min(attempt, len(limits) - 1)]
         procs = []
@@ -111,7 +125,8 @@ def supervise(args):
             # rendezvous among themselves: rank 0's worker serves the store on this attempt's port)
             env["TORCHELASTIC_USE_AGENT_STORE"] = "False"
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + ["--worker"], env=env,
-                                          stdout=subprocess.PIPE if r == 0 else None, text=True, start_new_session=True))
+                                          stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True, start_new_session=True))
+        live[:] = procs  # (only rank 0's JSON line reaches this process's stdout; everything else any worker prints goes to stderr)
         t0 = time.time()
         out0, failed = None, None
         try:
