@@ -587,8 +587,12 @@ def main():
         dist.destroy_process_group()
 
 
+# entry points that launch the SAME kernel template on another operand format are one roofline family: the LDS-DMA NT tile kernel
+# (csrc/gemm_fast_kernel.h) runs bf16 operands behind avsr_gemm_bf16_nt and f16 operands behind avsr_gemm_h16_nt (mixed mode forward)
+SAME_KERNEL = {"avsr_gemm_h16_nt": "avsr_gemm_bf16_nt", "avsr_conv2d_h16": "avsr_conv2d_bf16"}
 BN_FAMILY = ("avsr_bn_stats", "avsr_bn_stats_finalize", "avsr_bn_act_fwd", "avsr_bn_bwd_reduce", "avsr_bn_bwd_apply",
-             "avsr_bn_act_pool_fwd", "avsr_bn_pool_bwd_reduce", "avsr_bn_pool_bwd_apply", "avsr_bn_small_fwd", "avsr_bn_small_bwd")
+             "avsr_bn_act_pool_fwd", "avsr_bn_pool_bwd_reduce", "avsr_bn_pool_bwd_apply", "avsr_bn_small_fwd", "avsr_bn_small_bwd",
+             "avsr_bn_act_fwd2", "avsr_bn_act_fwd_h16", "avsr_bn_small_fwd2", "avsr_bn_small_fwd_h16")
 # C-ABI entry point -> the kernel names it launches, as rocprofv3 prints them (profiles/*_hbm_traffic.json keys)
 KERNELS_OF = {"avsr_gemm_bf16_nt": r"^gemm_fast_kernel<\d+, \d+, \d+, 0,", "avsr_conv2d_bf16": r"^(gemm_fast_kernel<\d+, \d+, \d+, [12],|conv3x3_c64_kernel)",
               "avsr_conv3x3_wgrad_bf16": r"^(conv3x3_wgrad_kernel|wgrad_reduce_kernel)", "avsr_gemm_bf16_tn": r"^gemm_tn_fast_kernel",
@@ -635,6 +639,7 @@ def roofline(model, batch, ops):
     model.zero_grad(set_to_none=True)
     fam = {}
     for name, e0, e1, flops, nbytes in rec:
+        name = SAME_KERNEL.get(name, name)
         t = e0.elapsed_time(e1) * 1e-3
         f = fam.setdefault(name, [0.0, 0.0, 0])
         f[0] += t
@@ -645,7 +650,8 @@ def roofline(model, batch, ops):
     t_ev, _, n = fam[name]
     # pass 2: the same launches, back to back (buffers of the recorded step may have been recycled by the allocator --
     # irrelevant for timing, and nothing of the model is used afterwards)
-    ops.RECORD = ((name,) + BN_FAMILY, [])
+    members = tuple(k for k, v in SAME_KERNEL.items() if v == name) + (name,)
+    ops.RECORD = (members + BN_FAMILY, [])
     loss, *_ = model.forward_tensors(x, lens, y)
     loss.backward()
     torch.cuda.synchronize()
@@ -664,14 +670,14 @@ def roofline(model, batch, ops):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / reps
 
-    calls = [c for c in rec2 if c[0] == name]
+    calls = [c for c in rec2 if c[0] in members]
     t = replay(calls)
     fl = sum(c[2] for c in calls)
     peak = 2500.0
     ach = fl / t / 1e12 if t > 0 else 0.0
-    traffic, src = counter_traffic(KERNELS_OF.get(name, "^$"))
+    traffic, src = counter_traffic(KERNELS_OF.get(name, "^$"))  # (the pattern of the bf16 entry point matches the f16 instantiations too)
     algo = sum(c[3] for c in calls) / max(len(calls), 1)
-    main = {"bound": "mfma", "kernel": name, "launches": len(calls), "avg_us": round(t / max(len(calls), 1) * 1e6, 2),
+    main = {"bound": "mfma", "kernel": " + ".join(reversed(members)), "launches": len(calls), "avg_us": round(t / max(len(calls), 1) * 1e6, 2),
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
             "traffic_unit": "HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, calibrated)", "traffic_source": src,
             "algorithmic_bytes_per_launch": round(algo),
