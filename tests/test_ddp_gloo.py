@@ -266,7 +266,7 @@ def test_bench_main_two_ranks(emu_lib_path, tmp_path, launch):
     port = 35500 + os.getpid() % 2000
     tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--max-frames", "12", "--shapes", "2"]
     if launch == "plain-hang-fallback":
-        env.update(AVSR_BENCH_TEST_HANG="buckets-graph", AVSR_BENCH_ATTEMPT_TIMEOUT="45,400,400", MASTER_PORT=str(port))
+        env.update(AVSR_BENCH_TEST_HANG="buckets-graph", AVSR_BENCH_ATTEMPT_TIMEOUT="30,400,400", MASTER_PORT=str(port))
         cmd = [sys.executable] + tail
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
