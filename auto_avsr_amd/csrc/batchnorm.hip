@@ -280,7 +280,8 @@ template <class T>
 __global__ __launch_bounds__(BN_THREADS) void bn_act_pool3_fwd_kernel(
     const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y, uint8_t* __restrict__ idx,
-    T* __restrict__ xsel, long N, int H, int W, int C, int OH, int OW, int act) {
+    T* __restrict__ xsel, long N, int H, int W, int C, int OH, int OW, int act, bf16_t* __restrict__ y2 = nullptr,
+    bf16_t* __restrict__ xsel2 = nullptr) {
     const int cv = C >> 3;
     const long total = N * OH * OW * cv;
     for (long i = (long)blockIdx.x * BN_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * BN_THREADS) {
@@ -336,7 +337,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_pool3_fwd_kernel(
             xs[e] = lo ? xm : xM;
         }
         store8(y + i * 8, m);
+        if (y2) store8(y2 + i * 8, m);            // bf16 twin of an f32 result (hpf / mixed modes: what the backward pass reads)
         if (xsel) store8(xsel + i * 8, xs);
+        if (xsel2) store8(xsel2 + i * 8, xs);     // ... and the arg-max inputs straight in bf16 (only the backward pass reads them)
         uint64_t pk = 0;
 #pragma unroll
         for (int e = 0; e < 8; e++) pk |= (uint64_t)am[e] << (8 * e);
@@ -972,6 +975,22 @@ extern "C" int avsr_bn_act_pool_fwd(const void* x, int dtype, const float* mean,
         AVSR_LAUNCH((bn_act_pool_fwd_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, mean, invstd, gamma, beta,
                     (bf16_t*)y, idx, (long)N, H, W, C, OH, OW, K, S, P, act);
     AVSR_CHECK_LAUNCH("bn_act_pool_fwd");
+    return 0;
+}
+
+// f32 input / output of the 3x3 / stride 2 / pad 1 case + the bf16 twin y2 of the pooled output and xsel2, the arg-max inputs in bf16
+// (either may be NULL), in the same pass -- the hpf / mixed modes' stem: no cast launches over the pooled tensors afterwards
+extern "C" int avsr_bn_act_pool3_fwd2(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                      float* y, void* y2, uint8_t* idx, void* xsel2, int64_t N, int H, int W, int C, int act,
+                                      hipStream_t stream) {
+    AVSR_REQUIRE(C % 8 == 0, "batchnorm: C must be a multiple of 8");
+    AVSR_REQUIRE(idx != nullptr, "bn_act_pool3_fwd2: idx required");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    if (N <= 0) return 0;
+    dim3 grid(ew_grid((long)N * OH * OW * (C >> 3))), block(BN_THREADS);
+    AVSR_LAUNCH((bn_act_pool3_fwd_kernel<float>), grid, block, 0, stream, x, mean, invstd, gamma, beta, y, idx, (float*)nullptr, (long)N,
+                H, W, C, OH, OW, act, (bf16_t*)y2, (bf16_t*)xsel2);
+    AVSR_CHECK_LAUNCH("bn_act_pool3_fwd2");
     return 0;
 }
 

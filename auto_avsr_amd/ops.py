@@ -413,6 +413,13 @@ def bn_act_pool_fwd(x, mean, invstd, gamma, beta, N, H, W, C, K, S, P, act, want
     OH, OW = conv_out(H, K, S, P), conv_out(W, K, S, P)
     y = torch.empty(N, OH, OW, C, dtype=x.dtype, device=x.device)
     idx = torch.empty(N, OH, OW, C, dtype=torch.uint8, device=x.device)
+    if x.dtype == torch.float32 and (K, S, P) == (3, 2, 1) and want_xsel:
+        y2 = _twin(y)
+        if y2 is not None:  # hpf / mixed modes: the pooled output's bf16 twin and the arg-max inputs in bf16, from the same pass
+            xsel = torch.empty(N, OH, OW, C, dtype=torch.bfloat16, device=x.device)
+            call("avsr_bn_act_pool3_fwd2", _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(y2), _ptr(idx),
+                 _ptr(xsel), N, H, W, C, act, _stream(x), nbytes=_nb(x, y, y2, idx, xsel))
+            return y, idx, xsel
     xsel = torch.empty_like(y) if want_xsel else None
     call("avsr_bn_act_pool_fwd", _ptr(x), dt(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(idx),
          _ptr(xsel), N, H, W, C, K, S, P, act, _stream(x), nbytes=_nb(x, y, idx, xsel))

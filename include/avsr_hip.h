@@ -197,6 +197,10 @@ int avsr_bn_act_pool_fwd(const void* x, int dtype, const float* mean, const floa
                                        with it the backward reduce pass is avsr_bn_bwd_reduce(xsel, dpool) on the pooled
                                        tensors alone (sum over pooled outputs == sum over pixels) */,
                          int64_t N, int H, int W, int C, int K, int S, int P, int act, avsr_stream_t stream);
+/* the 3x3 / stride 2 / pad 1 case on an f32 input with the bf16 twin y2 of the pooled f32 output and the arg-max inputs xsel2 in
+ * bf16 written in the same pass (either may be NULL): the video stem of the hpf / mixed modes */
+int avsr_bn_act_pool3_fwd2(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, float* y,
+                           void* y2, uint8_t* idx, void* xsel2, int64_t N, int H, int W, int C, int act, avsr_stream_t stream);
 /* backward of avsr_bn_act_pool_fwd in the two BatchNorm backward passes, the activation gradient gathered from the pooled
  * gradient dpool [N][OH][OW][C] through idx (no full-resolution gradient tensor): sums [2][C] = (sum dz, sum dz*xhat),
  * then dx [N][H][W][C] from the (all-reduced) sums; workspace / inv_n / n_dev as avsr_bn_bwd_reduce / _apply */

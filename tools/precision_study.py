@@ -25,7 +25,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 from oracle import avsr_oracle as O  # noqa: E402
 from bench_common import BATCHES, FIXTURE, ODIM, bench_batch, bench_state_dict, rel  # noqa: E402
 
-GROUPS = ["stem", "trunk", "trunk1", "trunk2", "trunk3", "trunk4", "proj", "enc_ffn", "enc_attn_proj", "enc_attn_core", "enc_conv", "ctc_head", "dec", "dec_out"]
+GROUPS = ["stem", "trunk", "trunk1", "trunk2", "trunk3", "trunk4", "proj", "enc_ffn", "enc_attn_proj", "enc_attn_q", "enc_attn_k", "enc_attn_v",
+          "enc_attn_out", "enc_attn_pos", "enc_attn_core", "enc_conv", "ctc_head", "dec", "dec_out"]
 CFG = {}
 STATS = {}
 
@@ -54,7 +55,8 @@ def group_of(pre):
     if ".feed_forward" in pre:
         return "enc_ffn"
     if ".self_attn." in pre:
-        return "enc_attn_proj"
+        fine = "enc_attn_" + pre.rstrip(".").rsplit("linear_", 1)[-1]  # q / k / v / out refine "enc_attn_proj" when named explicitly
+        return fine if fine in CFG else "enc_attn_proj"
     if ".conv_module." in pre:
         return "enc_conv"
     return None
@@ -98,7 +100,7 @@ class FShim(types.SimpleNamespace):
         return self._conv(F.conv3d, x, w, b, **kw)
 
     def linear(self, x, w, b=None):  # only linear_pos goes through F.linear directly
-        fmt = CFG.get("enc_attn_proj")
+        fmt = CFG.get("enc_attn_pos", CFG.get("enc_attn_proj"))
         return F.linear(q(x, fmt), q(w, fmt), b)
 
 
@@ -177,7 +179,7 @@ def parse(spec):
         k, v = item.split("=")
         if k == "all":
             for g in GROUPS:
-                if not g[-1].isdigit():  # trunk1..4 refine "trunk" only when named explicitly
+                if not g[-1].isdigit() and g not in ("enc_attn_q", "enc_attn_k", "enc_attn_v", "enc_attn_out", "enc_attn_pos"):  # refinements: only when named explicitly
                     cfg[g] = v
         else:
             assert k in GROUPS, k
