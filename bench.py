@@ -514,7 +514,8 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": {"bf16": "bf16", "precise": "f32 (split-bf16 MFMA)", "hpf": "f32 forward (split-bf16 MFMA) / bf16 backward",
-                  "mixed": "f16 (encoder) + split-bf16 (front-end, heads, decoder) forward / bf16 backward"}[mode],
+                  "mixed": "f16 (" + ", ".join(k for k, v in sorted(AF.MIXED_POLICY.items()) if v == "f16")
+                           + ") + split-bf16 (everything else) forward / bf16 backward"}[mode],
         "data": "synthetic",
         "config": {"workload": ("configs[1]: modality=video vsr_trlrs3_base" if args.modality == "video" else
                                 "configs[3] single-GPU leg: modality=audio asr_trlrs3_base (a frame = 640 samples)")
