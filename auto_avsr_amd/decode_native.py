@@ -1,0 +1,206 @@
+"""Host side of csrc/decode.hip: the hybrid CTC / attention beam search with ONE library call per decoding step.
+
+`NativeBeam.search` is what `decoding.BatchBeamSearch.forward` runs when the scorers are the ones the reference wires
+(lightning.py:126-158: this build's TransformerDecoder, CTCPrefixScorer, optionally LengthBonus, pre-beam on the decoder
+scores): same search (batch_beam_search.py:208-349 over beam_search.py:330-457), same hypotheses, with the per-step work --
+decoder pass on the new position over cached K / V, pre-beam, CTC prefix scores, top-k, beam re-ordering -- issued from C++
+(`avsr_beam_step`) instead of ~120 python-issued launches.  The python loop here only looks at the 1 KB the step copies
+back (tokens, parents, scores), collects ended hypotheses and applies the end-detection rule.  Any other scorer
+configuration keeps the python step of decoding.py."""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+MAX_BEAM = 128
+
+
+def _f32(t):
+    t = t.detach()
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+class NativeBeam:
+    """One session object per BatchBeamSearch: weights are re-bound when any decoder parameter changes."""
+
+    def __init__(self, bs):
+        self.bs = bs
+        self.handle = 0
+        self.key = None
+        self.keep_alive = []
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.lib().call("avsr_beam_destroy", self.handle)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------------ eligibility
+    @staticmethod
+    def supported(bs):
+        from .decoding import CTCPrefixScorer, LengthBonus
+        from .nets import TransformerDecoder
+
+        full, part = bs.full_scorers, bs.part_scorers
+        if set(part) != {"ctc"} or not isinstance(part["ctc"], CTCPrefixScorer):
+            return False
+        if "decoder" not in full or not isinstance(full["decoder"], TransformerDecoder):
+            return False
+        if set(full) - {"decoder", "length_bonus"}:
+            return False
+        if "length_bonus" in full and not isinstance(full["length_bonus"], LengthBonus):
+            return False
+        if not bs.do_pre_beam or bs.pre_beam_score_key not in ("decoder", "full") or bs.weights["decoder"] <= 0:
+            return False
+        dec = full["decoder"]
+        lay = dec.decoders[0]
+        D, H = lay.size, lay.self_attn.h
+        FF = lay.feed_forward.w_1.out_features
+        if dec.output_layer is None or not dec.normalize_before or D != 64 * H or FF % 64:
+            return False
+        beam, S = bs.beam_size, bs.pre_beam_size
+        return 2 <= beam <= MAX_BEAM and beam <= S - 1 and beam * (S + 1) <= 8192
+
+    # ------------------------------------------------------------------------------------------------ weights
+    def _bind(self, dev, min_pos):
+        bs = self.bs
+        dec = bs.full_scorers["decoder"]
+        params = list(dec.parameters())
+        pos = dec.embed[1]
+        pe = _f32(pos.table(max(pos.pe.size(1), min_pos), dev))
+        key = (str(dev), pe.data_ptr(), pe.shape[0]) + tuple((p.data_ptr(), p._version) for p in params)
+        if key == self.key:
+            return
+        L = _lib.lib()
+        if self.handle:
+            L.call("avsr_beam_destroy", self.handle)
+            self.handle = 0
+        lay0 = dec.decoders[0]
+        D, H, FF = lay0.size, lay0.self_attn.h, lay0.feed_forward.w_1.out_features
+        emb = dec.embed[0]
+        V = dec.output_layer.out_features
+        keep = [_f32(emb.weight), pe]
+        for d in dec.decoders:
+            sa, ca, ff = d.self_attn, d.src_attn, d.feed_forward
+            keep += [_f32(d.norm1.weight), _f32(d.norm1.bias),
+                     torch.cat([_f32(sa.linear_q.weight), _f32(sa.linear_k.weight), _f32(sa.linear_v.weight)], 0).contiguous(),
+                     torch.cat([_f32(sa.linear_q.bias), _f32(sa.linear_k.bias), _f32(sa.linear_v.bias)], 0).contiguous(),
+                     _f32(sa.linear_out.weight), _f32(sa.linear_out.bias),
+                     _f32(d.norm2.weight), _f32(d.norm2.bias), _f32(ca.linear_q.weight), _f32(ca.linear_q.bias),
+                     torch.cat([_f32(ca.linear_k.weight), _f32(ca.linear_v.weight)], 0).contiguous(),
+                     torch.cat([_f32(ca.linear_k.bias), _f32(ca.linear_v.bias)], 0).contiguous(),
+                     _f32(ca.linear_out.weight), _f32(ca.linear_out.bias),
+                     _f32(d.norm3.weight), _f32(d.norm3.bias), _f32(ff.w_1.weight), _f32(ff.w_1.bias), _f32(ff.w_2.weight),
+                     _f32(ff.w_2.bias)]
+        keep += [_f32(dec.after_norm.weight), _f32(dec.after_norm.bias), _f32(dec.output_layer.weight), _f32(dec.output_layer.bias)]
+        assert all(t.device == keep[0].device for t in keep)
+        has_len = int("length_bonus" in bs.full_scorers)
+        cfg = (ctypes.c_int32 * 12)(D, H, FF, V, len(dec.decoders), bs.beam_size, bs.pre_beam_size, bs.sos, bs.eos,
+                                    bs.part_scorers["ctc"].blank, has_len, pe.shape[0])
+        fcfg = (ctypes.c_float * 5)(bs.weights["decoder"], bs.weights["ctc"], bs.weights.get("length_bonus", 0.0) if has_len else 0.0,
+                                    pos.xscale, dec.decoders[0].norm1.eps)
+        ptrs = (ctypes.c_void_p * len(keep))(*[t.data_ptr() for t in keep])
+        h = L.call("avsr_beam_create", ctypes.cast(cfg, ctypes.c_void_p), ctypes.cast(fcfg, ctypes.c_void_p),
+                   ctypes.cast(ptrs, ctypes.c_void_p), len(keep))
+        if not h:
+            raise _lib.AvsrLibraryError("avsr_beam_create: " + L.cdll.avsr_last_error().decode())
+        self.handle, self.key, self.keep_alive = h, key, keep
+        self.V, self.pe_rows = V, pe.shape[0]
+        pin = dev.type == "cuda"
+        self.host = torch.empty(MAX_BEAM * 8, dtype=torch.float32, pin_memory=pin)
+        self.host_np = self.host.numpy().reshape(MAX_BEAM, 8)
+        self.yseq_host = None
+
+    # ------------------------------------------------------------------------------------------------ the search
+    @torch.no_grad()
+    def search(self, x, maxlenratio=0.0, minlenratio=0.0):
+        from .decoding import Hypothesis
+
+        bs = self.bs
+        if maxlenratio == 0:
+            maxlen = x.shape[0]
+        elif maxlenratio < 0:
+            maxlen = -1 * int(maxlenratio)
+        else:
+            maxlen = max(1, int(maxlenratio * x.size(0)))
+        dev = x.device
+        dec, ctc = bs.full_scorers["decoder"], bs.part_scorers["ctc"]
+        self._bind(dev, maxlen + 2)
+        L = _lib.lib()
+        r0, _ = ctc.batch_init_state(x)  # also computes ctc.logp [T][ld]
+        T = x.shape[0]
+        logp = ctc.logp
+        memory = _f32(x)
+        r_init = r0.reshape(T, 2).contiguous()
+        nws = L.call("avsr_beam_workspace_bytes", self.handle, T, maxlen)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        stream = ops._stream(memory)
+        L.call("avsr_beam_begin", self.handle, memory.data_ptr(), T, logp.data_ptr(), logp.stride(0), r_init.data_ptr(), ws.data_ptr(),
+               nws, maxlen, stream)
+        n_out = ctypes.c_int(0)
+        host_ptr, n_ptr = self.host.data_ptr(), ctypes.cast(ctypes.pointer(n_out), ctypes.c_void_p)
+        names = ["decoder"] + (["length_bonus"] if "length_bonus" in bs.full_scorers else []) + ["ctc"]
+        col = {"decoder": 3, "ctc": 4, "length_bonus": 5}
+        eos = bs.eos
+        ended, best, best_len = [], -math.inf, {}
+
+        def fetch():
+            yseq_host = self.yseq_host
+            if yseq_host is None or yseq_host.shape[0] < bs.beam_size * (maxlen + 2):
+                yseq_host = self.yseq_host = torch.empty(bs.beam_size * (maxlen + 2), dtype=torch.int64, pin_memory=dev.type == "cuda")
+            ldy, Lc = ctypes.c_int(0), ctypes.c_int(0)
+            L.call("avsr_beam_fetch_yseq", self.handle, yseq_host.data_ptr(), ctypes.cast(ctypes.pointer(ldy), ctypes.c_void_p),
+                   ctypes.cast(ctypes.pointer(Lc), ctypes.c_void_p), stream)
+            return yseq_host.numpy(), ldy.value, Lc.value
+
+        def end(row, ys, forced):
+            nonlocal best
+            ys = list(ys) + ([eos] if forced else [])
+            sc = float(row[2])
+            ended.append(Hypothesis(yseq=torch.tensor(ys, dtype=torch.int64), score=sc, scores={k: float(row[col[k]]) for k in names},
+                                    states={}))
+            best = max(best, sc)
+            best_len[len(ys)] = max(best_len.get(len(ys), -math.inf), sc)
+
+        for i in range(maxlen):
+            L.call("avsr_beam_step", self.handle, host_ptr, n_ptr, stream)
+            K = n_out.value
+            out = self.host_np[:K]
+            tok = out[:, 0].astype(np.int64)
+            if i == maxlen - 1:  # force an end so that at least one hypothesis finishes (beam_search.py:430-436)
+                ys, ldy, Lc = fetch()
+                for b in range(K):
+                    end(out[b], ys[b * ldy: b * ldy + Lc], True)
+                n_alive = 0
+            else:
+                is_eos = tok == eos
+                n_alive = K
+                if is_eos.any():
+                    ys, ldy, Lc = fetch()
+                    for b in np.nonzero(is_eos)[0].tolist():
+                        end(out[b], ys[b * ldy: b * ldy + Lc], False)
+                    keep = np.nonzero(~is_eos)[0].astype(np.int32)
+                    n_alive = int(keep.shape[0])
+                    L.call("avsr_beam_keep", self.handle, keep.ctypes.data, n_alive, stream)
+            if maxlenratio == 0.0 and ended and self._end_detect(best, best_len, i):
+                break
+            if n_alive == 0:
+                break
+        nbest = sorted(ended, key=lambda h: float(h.score), reverse=True)
+        if not nbest:
+            return [] if minlenratio < 0.1 else self.search(x, maxlenratio, max(0.0, minlenratio - 0.1))
+        return nbest
+
+    @staticmethod
+    def _end_detect(best, best_len, i, M=3, D_end=math.log(1 * math.exp(-10))):
+        """decoding.end_detect (e2e_asr_common.py:17-47) on the running maxima instead of the list of dicts."""
+        count = 0
+        for m in range(M):
+            s = best_len.get(i - m)
+            if s is not None and s - best < D_end:
+                count += 1
+        return count == M

@@ -13,6 +13,7 @@ CTC prefix-score kernel (csrc/ctc_prefix.hip: the reference loops over the T fra
 step), one top-k over beam x vocabulary, and index_select gathers.  Nothing is unbatched into per-hypothesis python
 objects until hypotheses end."""
 import math
+import os
 from typing import Any, Dict, List, NamedTuple, Optional
 
 import torch
@@ -22,6 +23,9 @@ from .ctc_prefix_score import CTCPrefixScore, CTCPrefixScoreTH
 from .scorer_interface import BatchPartialScorerInterface, BatchScorerInterface
 
 LOGZERO = -10000000000.0
+# A/B switch: 0 keeps the python-issued decoding step below for every scorer configuration (default: the reference's scorer set
+# runs the one-call-per-step search of decode_native.py / csrc/decode.hip)
+NATIVE_BEAM = os.environ.get("AVSR_NATIVE_BEAM", "1") != "0"
 
 
 class Hypothesis(NamedTuple):
@@ -182,6 +186,7 @@ class BatchBeamSearch(torch.nn.Module):
         self.pre_beam_score_key = pre_beam_score_key
         self.do_pre_beam = (pre_beam_score_key is not None and self.pre_beam_size < self.n_vocab
                             and len(self.part_scorers) > 0)
+        self._native = None  # decode_native.NativeBeam, False = this scorer set stays on the python step
 
     # ---------------------------------------------------------------------------------------------- one step
     def _step(self, beam, x):
@@ -237,6 +242,13 @@ class BatchBeamSearch(torch.nn.Module):
     @torch.no_grad()
     def forward(self, x: torch.Tensor, maxlenratio: float = 0.0, minlenratio: float = 0.0) -> List[Hypothesis]:
         """x: encoder output of one utterance (T, D).  Returns the ended hypotheses, best first (beam_search.py:330-406)."""
+        if NATIVE_BEAM and self._native is not False:
+            if self._native is None:
+                from .decode_native import NativeBeam
+
+                self._native = NativeBeam(self) if NativeBeam.supported(self) else False
+            if self._native:
+                return self._native.search(x, maxlenratio, minlenratio)
         if maxlenratio == 0:
             maxlen = x.shape[0]
         elif maxlenratio < 0:

@@ -430,6 +430,32 @@ int avsr_ctc_prefix_score(const float* logp, int T, int V, int ldv, const float*
                           const int64_t* cand, int NH, int S, int out_len, int blank, float* r_new, float* psi,
                           float* psi_eos, avsr_stream_t stream);
 
+/* ---- beam search, one decoding step per host call (decode.hip) ------------------------------------------------------
+ * One iteration of BatchBeamSearch.search (espnet/nets/batch_beam_search.py:208-349 over beam_search.py:330-406) with the
+ * reference's scorer wiring (lightning.py:126-158): TransformerDecoder.batch_score (decoder/transformer_decoder.py:226-258,
+ * 301-334), CTCPrefixScorer.batch_score_partial (scorers/ctc.py:101-126), LengthBonus, pre-beam on the decoder scores, top-k
+ * over beam x vocabulary, state selection -- issued from C++ (~75 launches, one device-to-host copy, one stream sync) on
+ * [position][slot] K / V caches with per-hypothesis ancestry instead of re-projecting every previous position.
+ * cfg: D, H, FF, V, n_layers, beam, S (pre-beam size), sos, eos, blank, has_length_bonus, rows of the position table.
+ * fcfg: w_decoder, w_ctc, w_length_bonus, embedding scale, LayerNorm eps.
+ * w: embed [V][D], position table [rows][D], per layer {norm1 g, b, W_qkv [3D][D], b_qkv, W_o, b_o, norm2 g, b, src W_q, b_q,
+ * src W_kv [2D][D], b_kv, src W_o, b_o, norm3 g, b, W_1 [FF][D], b_1, W_2 [D][FF], b_2}, after_norm g, b, output W [V][D], b;
+ * all f32 device pointers that outlive the session.  Returns an opaque handle, 0 on an unsupported configuration. */
+int64_t avsr_beam_create(const int32_t* cfg, const float* fcfg, const void* const* w, int n_w);
+int avsr_beam_destroy(int64_t handle);
+int64_t avsr_beam_workspace_bytes(int64_t handle, int T, int Lmax);
+/* new utterance: memory [T][D] f32 encoder output, ctc_logp [T][ld_ctc] f32 log-softmax of the CTC head, r_init [T][2] CTC
+ * state of the empty prefix (ctc_prefix_score.py:60-66), workspace of avsr_beam_workspace_bytes(handle, T, Lmax) */
+int avsr_beam_begin(int64_t handle, const float* memory, int T, const float* ctc_logp, int ld_ctc, const float* r_init,
+                    void* workspace, int64_t workspace_bytes, int Lmax, avsr_stream_t stream);
+/* one step for all running hypotheses; host_out [K][8] f32 = {token, parent, total, decoder sum, ctc sum, length sum, 0, 0},
+ * valid on return (synchronises the stream); K through n_out */
+int avsr_beam_step(int64_t handle, float* host_out, int* n_out, avsr_stream_t stream);
+/* drop the hypotheses not listed (ended ones, batch_beam_search.py:178-206); keep: ascending indices into the current beam */
+int avsr_beam_keep(int64_t handle, const int32_t* keep, int n_keep, avsr_stream_t stream);
+/* token sequences of the current beam into host_yseq [n][*ldy_out] (first *L_out entries of a row valid); synchronises */
+int avsr_beam_fetch_yseq(int64_t handle, int64_t* host_yseq, int* ldy_out, int* L_out, avsr_stream_t stream);
+
 /* ---- optimizer step (optim.hip): global-norm clip + AdamW + warm-up cosine schedule, all parameters in 3 launches ---
  * Replaces torch.nn.utils.clip_grad_norm_(params, max_grad_norm) + torch.optim.AdamW(...).step() +
  * WarmupCosineScheduler.step() (reference lightning.py:48-52, train.py:41, cosine.py:6-25).

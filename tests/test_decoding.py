@@ -51,27 +51,40 @@ def test_ctc_prefix_scores_vs_reference(dev, case):
     assert bool((r1[~live] < LOGZERO / 2).all())
 
 
-@pytest.mark.parametrize("case", GOLD["beam"], ids=lambda c: f"seed{c['seed']}")
-def test_beam_search_vs_reference(dev, case):
-    """Same weights, same encoder output: the n-best token sequences equal the reference's, scores within 1e-3."""
+def _search(dev, case, native, maxlenratio=0.0, beam=None, linear_units=256):
+    from auto_avsr_amd import decoding
+
     odim, T, D = case["odim"], case["T"], case["D"]
+    torch.manual_seed(0)
+    dec = nets.TransformerDecoder(odim, attention_dim=D, attention_heads=2, linear_units=linear_units, num_blocks=2).eval()
+    ctc = nets.CTC(odim, D, 0.1, reduce=True).eval()
+    dec.load_state_dict(synth_state_dict(dec.state_dict(), case["seed"]))
+    ctc.load_state_dict(synth_state_dict(ctc.state_dict(), case["seed"] + 1))
+    dec, ctc = dec.to(dev), ctc.to(dev)
+    g = torch.Generator().manual_seed(500 + case["seed"])
+    enc = (torch.randn(T, D, generator=g) * 1.5).to(dev)
+    scorers = {"decoder": dec, "ctc": CTCPrefixScorer(ctc, odim - 1), "lm": None, "length_bonus": LengthBonus(odim)}
+    weights = {"decoder": 1.0 - case["ctc_weight"], "ctc": case["ctc_weight"], "lm": 0.0, "length_bonus": case["penalty"]}
+    bs = BatchBeamSearch(beam_size=beam or case["beam"], vocab_size=odim, weights=weights, scorers=scorers, sos=odim - 1,
+                         eos=odim - 1, token_list=[str(i) for i in range(odim)], pre_beam_score_key="decoder")
+    was = decoding.NATIVE_BEAM
+    decoding.NATIVE_BEAM = native
     AF.set_precise(True)
     try:
-        torch.manual_seed(0)
-        dec = nets.TransformerDecoder(odim, attention_dim=D, attention_heads=2, linear_units=256, num_blocks=2).eval()
-        ctc = nets.CTC(odim, D, 0.1, reduce=True).eval()
-        dec.load_state_dict(synth_state_dict(dec.state_dict(), case["seed"]))
-        ctc.load_state_dict(synth_state_dict(ctc.state_dict(), case["seed"] + 1))
-        dec, ctc = dec.to(dev), ctc.to(dev)
-        g = torch.Generator().manual_seed(500 + case["seed"])
-        enc = (torch.randn(T, D, generator=g) * 1.5).to(dev)
-        scorers = {"decoder": dec, "ctc": CTCPrefixScorer(ctc, odim - 1), "lm": None, "length_bonus": LengthBonus(odim)}
-        weights = {"decoder": 1.0 - case["ctc_weight"], "ctc": case["ctc_weight"], "lm": 0.0, "length_bonus": case["penalty"]}
-        bs = BatchBeamSearch(beam_size=case["beam"], vocab_size=odim, weights=weights, scorers=scorers, sos=odim - 1,
-                             eos=odim - 1, token_list=[str(i) for i in range(odim)], pre_beam_score_key="decoder")
-        nbest = bs(enc)
+        nbest = bs(enc, maxlenratio=maxlenratio)
     finally:
         AF.set_precise(False)
+        decoding.NATIVE_BEAM = was
+    assert bool(bs._native) == native  # the path asked for is the one that ran
+    return nbest
+
+
+@pytest.mark.parametrize("native", [True, False], ids=["native", "python"])
+@pytest.mark.parametrize("case", GOLD["beam"], ids=lambda c: f"seed{c['seed']}")
+def test_beam_search_vs_reference(dev, case, native):
+    """Same weights, same encoder output: the n-best token sequences equal the reference's, scores within 1e-3 -- for the
+    one-call-per-step search (csrc/decode.hip through decode_native.py, the default) and for the python-issued step."""
+    nbest = _search(dev, case, native)
     assert len(nbest) == case["n_ended"]
     for got, ref in zip(nbest, case["hyps"]):
         d = got.asdict()
@@ -79,6 +92,66 @@ def test_beam_search_vs_reference(dev, case):
         assert abs(d["score"] - ref["score"]) < 1e-3 * max(1.0, abs(ref["score"]))
         for k, v in ref["scores"].items():
             assert abs(d["scores"][k] - v) < 2e-3 * max(1.0, abs(v)), k
+
+
+@pytest.mark.parametrize("maxlenratio", [0.0, -4, 0.5])
+def test_native_beam_search_equals_python_step(dev, maxlenratio):
+    """Every ended hypothesis (not only the reference's recorded n-best), every per-scorer score, with a search that runs
+    into the forced end (maxlenratio = -4: four steps, beam_search.py:430-436) and one stopped by the end-detection rule.
+    Hypotheses the CTC scorer rules out (LOGZERO = -1e10 in the score: more labels than frames) tie at ~-1e9 and are ordered
+    arbitrarily by any top-k -- excluded from the comparison."""
+    case = GOLD["beam"][3]
+    a, b = _search(dev, case, True, maxlenratio), _search(dev, case, False, maxlenratio)
+    assert len(a) == len(b) and len(a) >= 1
+    live = 0
+    for x, y in zip(a, b):
+        x, y = x.asdict(), y.asdict()
+        if y["score"] < -1e8:
+            assert x["score"] < -1e8
+            continue
+        live += 1
+        assert x["yseq"] == y["yseq"]
+        assert abs(x["score"] - y["score"]) < 1e-3 * max(1.0, abs(y["score"]))
+        assert set(x["scores"]) == set(y["scores"])
+        for k, v in y["scores"].items():
+            assert abs(x["scores"][k] - v) < 1e-3 * max(1.0, abs(v)), k
+    assert live >= 3
+
+
+def test_native_beam_search_long_ffn(dev):
+    """linear_units = 2048 (the reference model's decoder width): the FFN's second contraction runs as K slices across blocks +
+    the row-sum kernel (csrc/decode.hip skinny()), which the 256-unit golden cases never reach."""
+    case = GOLD["beam"][0]
+    a, b = _search(dev, case, True, linear_units=2048), _search(dev, case, False, linear_units=2048)
+    assert len(a) == len(b) and len(a) >= 1
+    for x, y in zip(a, b):
+        x, y = x.asdict(), y.asdict()
+        if y["score"] < -1e8:
+            continue
+        assert x["yseq"] == y["yseq"]
+        assert abs(x["score"] - y["score"]) < 1e-3 * max(1.0, abs(y["score"]))
+
+
+def test_native_beam_refuses_what_it_cannot_score(dev):
+    """Scorer sets outside the reference's wiring stay on the python step: a vocabulary smaller than the pre-beam (no pre-beam,
+    beam_search.py:85-90) and a foreign full scorer."""
+    from auto_avsr_amd.decode_native import NativeBeam
+
+    case = dict(GOLD["beam"][0])
+    nb = _search(dev, case, False, beam=30)  # pre-beam 45 >= vocabulary 40: do_pre_beam is False
+    assert len(nb) >= 1
+    dec = nets.TransformerDecoder(40, attention_dim=128, attention_heads=2, linear_units=256, num_blocks=1).eval()
+    ctc = nets.CTC(40, 128, 0.1, reduce=True).eval()
+
+    class Other(LengthBonus):
+        pass
+
+    mk = lambda sc, beam: BatchBeamSearch(beam_size=beam, vocab_size=40, weights={k: 0.5 for k in sc}, scorers=sc, sos=39, eos=39,  # noqa: E731
+                                          token_list=None, pre_beam_score_key="decoder")
+    assert NativeBeam.supported(mk({"decoder": dec, "ctc": CTCPrefixScorer(ctc, 39), "length_bonus": LengthBonus(40)}, 5))
+    assert not NativeBeam.supported(mk({"decoder": dec, "ctc": CTCPrefixScorer(ctc, 39), "lm": Other(40)}, 5))
+    assert not NativeBeam.supported(mk({"decoder": dec, "ctc": CTCPrefixScorer(ctc, 39)}, 30))
+    assert not NativeBeam.supported(mk({"decoder": dec, "length_bonus": LengthBonus(40)}, 5))
 
 
 def test_end_detect_rule():

@@ -33,9 +33,13 @@ def main():
     m = m.to(dev).eval()
     bs = lightning.get_beam_search_decoder(m, [str(i) for i in range(5049)], beam_size=args.beam)
     rows = []
-    for mode in ("bf16", "precise"):
+    from auto_avsr_amd import decoding
+
+    for mode, native in (("mixed", True), ("bf16", True), ("precise", True), ("bf16", False), ("precise", False)):
         AF.set_mode(mode)
         AF.invalidate_weight_cache()
+        decoding.NATIVE_BEAM = native  # True: one library call per step (csrc/decode.hip); False: the python-issued step
+        bs._native = None
         for T in (100, 400):
             x, _, _ = synth_batch("video", 1, T, 3, 5049, seed=T, lengths=[T])
             x = x.to(dev)
@@ -56,11 +60,14 @@ def main():
                     t_dec.append(t2 - t1)
                 steps = max(len(h.asdict()["yseq"]) for h in nbest) - 1 if nbest else 0
             enc_ms, dec_ms = min(t_enc) * 1e3, min(t_dec) * 1e3
-            rows.append({"mode": mode, "T_frames": T, "beam": args.beam, "encoder_ms": round(enc_ms, 2), "beam_search_ms": round(dec_ms, 2),
+            assert bool(bs._native) == native
+            rows.append({"mode": mode, "step": "native (avsr_beam_step)" if native else "python-issued", "T_frames": T, "beam": args.beam, "encoder_ms": round(enc_ms, 2), "beam_search_ms": round(dec_ms, 2),
                          "longest_hypothesis_tokens": steps, "ms_per_token": round(dec_ms / max(steps, 1), 3),
                          "utterances_per_sec": round(1e3 / (enc_ms + dec_ms), 3)})
+            rows[-1]["best_yseq_head"] = nbest[0].asdict()["yseq"][:12] if nbest else []
             print(json.dumps(rows[-1]), file=sys.stderr, flush=True)
     AF.set_mode("bf16")
+    decoding.NATIVE_BEAM = True
     print(json.dumps({"metric": "decode throughput, video E2E 250M, hybrid CTC/attention beam search (lightning.py:54-64,126-158)",
                       "reference_cpu": "2.12 s per 4 s utterance (T = 100), 8 host cores, BASELINE.md section 2",
                       "data": "synthetic input, synthetic (tests/golden/synth.py) weights", "rows": rows}))
