@@ -157,13 +157,19 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
 // The linear layers of a decoding step (transformer_decoder.py:84-126 on ONE position per hypothesis): C[M][N] =
 // act(LN?(A)[M][K] . W[N][K]^T + bias) + resid with M <= beam rows.  On the tiled GEMM (64 x 64 tile, 12 - 48 sequential
 // k-tiles behind a two-stage ring) such a launch takes 25 us whatever M is: with 12 - 48 blocks on 256 CUs it is a chain of
-// dependent HBM round trips.  Here a block owns 32 weight rows and ALL of K, its KW waves split K between them (192 - 384
-// columns each), every lane streams its own weight row and activation rows from global memory straight into MFMA fragments
-// (no LDS ring: nothing is reused inside a wave), the split hi / lo bf16 planes are formed in registers (three MFMAs per
-// product: the precise mode's arithmetic), and the KW partial tiles meet in LDS.  The LayerNorm in front of a sub-layer's
-// first projection (pre-norm blocks) is applied to the A fragments as they are loaded -- every block sees whole rows of A,
-// so the row statistics cost one pass over 40 x 768 values per block and the 19 stand-alone LayerNorm launches of a
-// step disappear.
+// dependent HBM round trips.  Here a block owns 32 weight rows and 64 NW columns of K (all of K = 768: NW = 12 waves), wave w
+// its own 64 columns, in two phases of 32:
+//  * operands travel global -> LDS by LDS-DMA, 8 lanes per 128-byte row piece (first version: every lane streamed its own
+//    row straight into MFMA fragments -- 32 distinct cache lines per wave-instruction, and the CU's address path, one line
+//    per cycle, was the bound: 10 us per launch, 19 us with the LayerNorm statistics re-reading A);
+//  * the region a wave stages into is its own (no block barrier between the phases), 16-byte chunks XOR-swizzled by the
+//    row so that the fragment reads (lane = row) spread over the banks;
+//  * split hi / lo bf16 planes formed in registers, three MFMAs per product (the precise mode's arithmetic);
+//  * the NW partial tiles meet in LDS (each wave parks its accumulators in its own staging region).
+// LayerNorm in front of a sub-layer's first projection (pre-norm blocks) is applied to the A fragments as they are read; the
+// row statistics it needs were left behind by whatever produced the rows (st_out below: per-row sum and sum of squares of
+// every block's 32 columns, summed by the consumer) -- the 19 stand-alone LayerNorm launches of a step disappear and no
+// kernel reads its input twice.
 struct SkinnyArgs {
     const float* A;
     long lda;
@@ -171,13 +177,17 @@ struct SkinnyArgs {
     long ldw;
     const float *bias, *ln_g, *ln_b;
     float eps;
+    const float* st_in;  // LN: [M][st_in_nt][2] partial (sum, sum of squares) of every row of A
+    int st_in_nt;
     const float* resid;
     long ldr;
     float* C;
     long ldc;
+    float* st_out;  // [M][gridDim.x][2] or NULL: the same statistics of the rows written here
     int M, N, K, act;
     int Z;           // K slices (blockIdx.z); Z > 1: raw partial sums to partial[z][M][N], finished by rowsum_kernel
     float* partial;
+    int r8, reg_bytes;  // rows of A staged per block (multiple of 8, <= 48) and bytes of a wave's LDS region
 };
 
 AVSR_DEV void split8(const float* x, bf16x8& hi, bf16x8& lo) {
@@ -189,159 +199,234 @@ AVSR_DEV void split8(const float* x, bf16x8& hi, bf16x8& lo) {
     }
 }
 
-// NW waves split K: wave w owns columns [w * K / NW, (w + 1) * K / NW) in batches of BS k-steps of 16 whose operands are all
-// requested before any is used (the launch is latency-bound: the loads must overlap, not queue behind a k loop).  LN: K = 64 NW
-// -- a wave sees its 64 columns of every row.
-template <int NW, int BS, bool LN>
+// The lanes of a wave run in lock step on the GPU; the host emulator runs them as fibers that only meet at wave collectives, so
+// wave-private LDS traffic (DMA by all lanes, then reads of what OTHER lanes staged) needs a meeting point there.
+AVSR_DEV void wave_converge() {
+#ifdef AVSR_EMU
+    (void)__shfl_xor(0, 1);
+#endif
+}
+
+constexpr int SK_ROWS = 48;  // rows of A per block (LDS: 12 waves x (32 + 48) x 128 bytes)
+
+template <int NW>
 __global__ __launch_bounds__(64 * NW) void skinny_gemm_kernel(SkinnyArgs a) {
     AVSR_DYN_SMEM(smem);
-    constexpr int RP = 33;
-    float* red = reinterpret_cast<float*>(smem);  // [NW][64][RP]
-    __shared__ float part[2][NW][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 64;
-    const int rows = min(64, a.M - m0);
-    const int Kw = a.K / (NW * a.Z), kbeg = (blockIdx.z * NW + wave) * Kw;
+    __shared__ float s_mean[64], s_rstd[64];
+    constexpr int NT = 64 * NW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * SK_ROWS;
+    const int rows = min(SK_ROWS, a.M - m0);
     const int half = lane >> 5, li = lane & 31;
-    const bool nv = n0 + li < a.N;
-    const float* wrow = a.W + (size_t)(nv ? n0 + li : 0) * a.ldw + 8 * half;
-    const bool av[2] = {li < rows, li + 32 < rows};
-    const float* arow[2] = {a.A + (size_t)(m0 + (av[0] ? li : 0)) * a.lda + 8 * half,
-                            a.A + (size_t)(m0 + (av[1] ? li + 32 : 0)) * a.lda + 8 * half};
+    char* reg = smem + (size_t)wave * a.reg_bytes;  // [4 groups of 8 weight rows][1 KiB] then [r8 / 8 groups of 8 rows of A][1 KiB]
+    char* areg = reg + 4096;
+    if (a.ln_g) {  // row statistics from the producer's partial sums: 16 lanes per row
+        const int sub = tid & 15;
+        for (int r0 = 0; r0 < rows; r0 += NT >> 4) {
+            const int r = r0 + (tid >> 4);
+            float s1 = 0.f, s2 = 0.f;
+            if (r < rows)
+                for (int j = sub; j < a.st_in_nt; j += 16) {
+                    const float* q = a.st_in + ((size_t)(m0 + r) * a.st_in_nt + j) * 2;
+                    s1 += q[0];
+                    s2 += q[1];
+                }
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) {
+                s1 += __shfl_xor(s1, m);
+                s2 += __shfl_xor(s2, m);
+            }
+            if (r < rows && sub == 0) {
+                const float mean = s1 / (float)a.K;
+                s_mean[r] = mean;
+                s_rstd[r] = 1.0f / sqrtf(fmaxf(s2 / (float)a.K - mean * mean, 0.f) + a.eps);
+            }
+        }
+        __syncthreads();
+    }
+    float mean[2] = {0.f, 0.f}, rstd[2] = {1.f, 1.f};
+    if (a.ln_g) {
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+            if (li + 32 * t < rows) {
+                mean[t] = s_mean[li + 32 * t];
+                rstd[t] = s_rstd[li + 32 * t];
+            }
+    }
     f32x16 acc[2];
 #pragma unroll
     for (int t = 0; t < 2; t++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
-    float mean[2] = {0.f, 0.f}, rstd[2] = {1.f, 1.f};
-    float wall[LN ? 4 : 1][8];  // LN: this wave's four weight fragments, requested BEFORE the statistics (they do not depend on them)
-    if (LN) {
+    const int kb = (blockIdx.z * NW + wave) * 64;  // this wave's 64 columns of K
+    const int g8 = lane >> 3, pc = lane & 7;       // staging: row inside a group of 8, physical 16-byte chunk
+#pragma unroll 1
+    for (int ph = 0; ph < 2; ph++) {
+        const int col0 = kb + 32 * ph;
 #pragma unroll
-        for (int s = 0; s < 4; s++) load8(wrow + kbeg + 16 * s, wall[s]);
-        // row statistics from this wave's 64 columns of every row, shifted by the row's first element (one pass, no cancellation:
-        // the shift is a sample of the row), met in LDS; the fragments are read again below (L2 hits) instead of being kept:
-        // 64 more live registers would spill at 12 waves per block
-        float sh[2], s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+        for (int gi = 0; gi < 4; gi++) {
+            const int r = 8 * gi + g8;
+            const int n = min(n0 + r, a.N - 1);
+            glds16(a.W + (size_t)n * a.ldw + col0 + 4 * (pc ^ (r & 7)), reg + gi * 1024);
+        }
+        for (int gi = 0; gi < a.r8 / 8; gi++) {
+            const int r = 8 * gi + g8;
+            const int m = m0 + min(r, rows - 1);
+            glds16(a.A + (size_t)m * a.lda + col0 + 4 * (pc ^ (r & 7)), areg + gi * 1024);
+        }
+        wait_vmcnt<0>();
+        wave_converge();
+        sched_fence();
 #pragma unroll
-        for (int t = 0; t < 2; t++) sh[t] = arow[t][-8 * half];
+        for (int s = 0; s < 2; s++) {
+            const int c0 = 4 * s + 2 * half;  // this lane's two logical chunks of the 32 columns: c0, c0 + 1
+            float w8[8];
+            {
+                const char* row = reg + (li >> 3) * 1024 + (li & 7) * 128;
+                const f32x4 lo4 = *reinterpret_cast<const f32x4*>(row + ((c0 ^ (li & 7)) << 4));
+                const f32x4 hi4 = *reinterpret_cast<const f32x4*>(row + (((c0 + 1) ^ (li & 7)) << 4));
 #pragma unroll
-        for (int s = 0; s < 4; s++)  // (K = 64 NW: four k-steps per wave)
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                float x8[8];
-                load8(arow[t] + kbeg + 16 * s, x8);
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const float d = x8[e] - sh[t];
-                    s1[t] += d;
-                    s2[t] += d * d;
+                for (int e = 0; e < 4; e++) {
+                    w8[e] = lo4[e];
+                    w8[4 + e] = hi4[e];
                 }
-            }
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-            s1[t] += __shfl_xor(s1[t], 32);
-            s2[t] += __shfl_xor(s2[t], 32);
-            if (half == 0) {
-                part[0][wave][li + 32 * t] = s1[t];
-                part[1][wave][li + 32 * t] = s2[t];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-            float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; w++) {
-                a1 += part[0][w][li + 32 * t];
-                a2 += part[1][w][li + 32 * t];
-            }
-            const float m = a1 / (float)a.K;
-            mean[t] = sh[t] + m;
-            rstd[t] = 1.0f / sqrtf(fmaxf(a2 / (float)a.K - m * m, 0.f) + a.eps);
-        }
-    }
-    for (int k0 = kbeg; k0 < kbeg + Kw; k0 += 16 * BS) {
-        float w8[BS][8], x8[2][BS][8];
-#pragma unroll
-        for (int s = 0; s < BS; s++) {
-            if (LN) {
-#pragma unroll
-                for (int e = 0; e < 8; e++) w8[s][e] = wall[(k0 - kbeg) / 16 + s][e];
-            } else {
-                load8(wrow + k0 + 16 * s, w8[s]);
-            }
-#pragma unroll
-            for (int t = 0; t < 2; t++) load8(arow[t] + k0 + 16 * s, x8[t][s]);
-        }
-        if (LN) {
-#pragma unroll
-            for (int s = 0; s < BS; s++) {
-                float g8[8], b8[8];
-                load8(a.ln_g + k0 + 16 * s + 8 * half, g8);
-                load8(a.ln_b + k0 + 16 * s + 8 * half, b8);
-#pragma unroll
-                for (int t = 0; t < 2; t++)
-#pragma unroll
-                    for (int e = 0; e < 8; e++) x8[t][s][e] = (x8[t][s][e] - mean[t]) * rstd[t] * g8[e] + b8[e];
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < BS; s++) {
-            if (!nv) {
-#pragma unroll
-                for (int e = 0; e < 8; e++) w8[s][e] = 0.f;
             }
             bf16x8 whi, wlo;
-            split8(w8[s], whi, wlo);
+            split8(w8, whi, wlo);
+            float g8v[8], b8v[8];
+            if (a.ln_g) {
+                load8(a.ln_g + col0 + 16 * s + 8 * half, g8v);
+                load8(a.ln_b + col0 + 16 * s + 8 * half, b8v);
+            }
 #pragma unroll
             for (int t = 0; t < 2; t++) {
-                if (!av[t]) {
+                const int r = li + 32 * t;
+                float x8[8];
+                if (r < a.r8) {
+                    const char* row = areg + (r >> 3) * 1024 + (r & 7) * 128;
+                    const f32x4 lo4 = *reinterpret_cast<const f32x4*>(row + ((c0 ^ (r & 7)) << 4));
+                    const f32x4 hi4 = *reinterpret_cast<const f32x4*>(row + (((c0 + 1) ^ (r & 7)) << 4));
 #pragma unroll
-                    for (int e = 0; e < 8; e++) x8[t][s][e] = 0.f;
+                    for (int e = 0; e < 4; e++) {
+                        x8[e] = lo4[e];
+                        x8[4 + e] = hi4[e];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) x8[e] = 0.f;
+                }
+                if (a.ln_g) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) x8[e] = (x8[e] - mean[t]) * rstd[t] * g8v[e] + b8v[e];
                 }
                 bf16x8 ahi, alo;
-                split8(x8[t][s], ahi, alo);
+                split8(x8, ahi, alo);
                 acc[t] = mfma32(alo, whi, acc[t]);
                 acc[t] = mfma32(ahi, wlo, acc[t]);
                 acc[t] = mfma32(ahi, whi, acc[t]);
             }
         }
+        sched_fence();  // (the fragment reads above are complete -- their values were consumed -- before the next phase's DMA lands)
+        wave_converge();
     }
+    // the wave's partial tile -> its own region (reads of the staged operands are done), [64][33] f32
+    constexpr int RP = 33;
+    float* mine = reinterpret_cast<float*>(reg);
 #pragma unroll
     for (int t = 0; t < 2; t++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
-            red[((size_t)wave * 64 + row) * RP + li] = acc[t][r];
+            mine[row * RP + li] = acc[t][r];
         }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < 64 * 32; idx += 64 * NW) {
+    for (int idx = tid; idx < 64 * 32; idx += NT) {  // (trip count is wave-uniform: 2048 and NT are multiples of 64)
         const int row = idx >> 5, col = idx & 31;
-        if (row >= rows || n0 + col >= a.N) continue;
+        const bool ok = row < rows && n0 + col < a.N;
         float v = 0.f;
+        if (ok) {
 #pragma unroll
-        for (int w = 0; w < NW; w++) v += red[((size_t)w * 64 + row) * RP + col];
-        if (a.Z > 1) {
-            a.partial[((size_t)blockIdx.z * a.M + m0 + row) * a.N + n0 + col] = v;
-            continue;
+            for (int w = 0; w < NW; w++) v += reinterpret_cast<const float*>(smem + (size_t)w * a.reg_bytes)[row * RP + col];
+            if (a.Z > 1) {
+                a.partial[((size_t)blockIdx.z * a.M + m0 + row) * a.N + n0 + col] = v;
+            } else {
+                if (a.bias) v += a.bias[n0 + col];
+                if (a.act == 1) v = fmaxf(v, 0.f);
+                if (a.resid) v += a.resid[(size_t)(m0 + row) * a.ldr + n0 + col];
+                a.C[(size_t)(m0 + row) * a.ldc + n0 + col] = v;
+            }
         }
-        if (a.bias) v += a.bias[n0 + col];
-        if (a.act == 1) v = fmaxf(v, 0.f);
-        if (a.resid) v += a.resid[(size_t)(m0 + row) * a.ldr + n0 + col];
-        a.C[(size_t)(m0 + row) * a.ldc + n0 + col] = v;
+        if (a.st_out) {  // (never with Z > 1)
+            float s1 = v, s2 = v * v;
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1) {
+                s1 += __shfl_xor(s1, m);
+                s2 += __shfl_xor(s2, m);
+            }
+            if (col == 0 && row < rows) {
+                float* q = a.st_out + ((size_t)(m0 + row) * gridDim.x + blockIdx.x) * 2;
+                q[0] = s1;
+                q[1] = s2;
+            }
+        }
     }
 }
 
-// C[m][n] = sum_z partial[z][m][n] + bias[n] + resid[m][n]: the K slices of a split contraction, summed in slice order
+// C[m][n] = sum_z partial[z][m][n] + bias[n] + resid[m][n]: the K slices of a split contraction, summed in slice order; block =
+// row; st_out [M][1][2]: the row's (sum, sum of squares) for the LayerNorm that follows
 __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ partial, int Z, int M, int N, const float* __restrict__ bias,
-                                                     const float* __restrict__ resid, long ldr, float* __restrict__ C, long ldc) {
-    const int m = blockIdx.x;
+                                                     const float* __restrict__ resid, long ldr, float* __restrict__ C, long ldc,
+                                                     float* __restrict__ st_out) {
+    __shared__ float red[2][4];
+    const int m = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float s1 = 0.f, s2 = 0.f;
     for (int n = threadIdx.x; n < N; n += 256) {
         float v = 0.f;
         for (int z = 0; z < Z; z++) v += partial[((size_t)z * M + m) * N + n];
         if (bias) v += bias[n];
         if (resid) v += resid[(size_t)m * ldr + n];
         C[(size_t)m * ldc + n] = v;
+        s1 += v;
+        s2 += v * v;
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+        red[0][wave] = s1;
+        red[1][wave] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && st_out) {
+        st_out[2 * m] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        st_out[2 * m + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+// x[r] = embed[last[r]] * scale + pe  (transformer_decoder.py:186-189, embedding.py:78-87; one position for every hypothesis) and
+// the row's LayerNorm statistics; block = row
+__global__ __launch_bounds__(256) void dec_embed_kernel(const int64_t* __restrict__ last, const float* __restrict__ table,
+                                                        const float* __restrict__ pe, float scale, int D, float* __restrict__ x,
+                                                        float* __restrict__ st_out) {
+    __shared__ float red[2][4];
+    const int m = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* row = table + (size_t)last[m] * D;
+    float s1 = 0.f, s2 = 0.f;
+    for (int n = threadIdx.x; n < D; n += 256) {
+        const float v = row[n] * scale + pe[n];
+        x[(size_t)m * D + n] = v;
+        s1 += v;
+        s2 += v * v;
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+        red[0][wave] = s1;
+        red[1][wave] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        st_out[2 * m] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        st_out[2 * m + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     }
 }
 
@@ -664,7 +749,7 @@ struct Session {
     BeamBuf st[2];
     std::vector<float*> cache;   // per layer [Lmax][beam][3 D]: q | k | v of the position's row
     std::vector<float*> memkv;   // per layer [T][2 D]
-    float *x, *x1, *x2, *h, *att, *q2, *ff, *part, *mean, *rstd, *logits, *logp, *lse, *psi, *psi_eos, *r_new, *selv, *host_dev;
+    float *x, *x1, *x2, *h, *att, *q2, *ff, *part, *stx, *st1, *st2, *mean, *rstd, *logits, *logp, *lse, *psi, *psi_eos, *r_new, *selv, *host_dev;
     int64_t* cand;
     int* sel;
 };
@@ -705,7 +790,10 @@ void carve(Session& s, Carver& c, int T, int Lmax) {
     s.att = c.take<float>(beam * D);
     s.q2 = c.take<float>(beam * D);
     s.ff = c.take<float>(beam * (size_t)s.FF);
-    s.part = c.take<float>((size_t)8 * beam * D);  // K slices of the FFN's second contraction (at most 8)
+    s.part = c.take<float>((size_t)8 * beam * D);
+    s.stx = c.take<float>(beam * (D / 32) * 2);
+    s.st1 = c.take<float>(beam * (D / 32) * 2);
+    s.st2 = c.take<float>(beam * (D / 32) * 2);  // K slices of the FFN's second contraction (at most 8)
     s.mean = c.take<float>(beam);
     s.rstd = c.take<float>(beam);
     s.logits = c.take<float>(beam * (size_t)ldv);
@@ -726,40 +814,50 @@ int gemm(const float* A, int lda, const float* B, int M, int N, int K, const flo
                              0, 1, 0, nullptr, 0, nullptr, 0, stream);
 }
 
-// C = act(LN?(A) W^T + bias) + resid for the <= beam rows of a decoding step (skinny_gemm_kernel); ln_g == NULL: no LayerNorm
+// per-row (sum, sum of squares) partials left by the producer of a [M][D] activation for the LayerNorm that consumes it
+struct RowStats {
+    float* buf;  // [M][nt][2]
+    int nt;
+};
+
+// C = act(LN?(A) W^T + bias) + resid for the <= beam rows of a decoding step (skinny_gemm_kernel).  ln_g == NULL: no LayerNorm;
+// otherwise `in` holds the statistics of A's rows.  out (may be NULL): receives the statistics of C's rows.
 int skinny(const float* A, int lda, const float* W, int M, int N, int K, const float* bias, const float* ln_g, const float* ln_b, float eps,
-           int act, const float* resid, int ldr, float* C, int ldc, float* partial, hipStream_t stream) {
-    // K slices across blocks for the long contraction (the FFN's second: K = 2048 / 3072, N = D gives only D / 32 blocks, each
-    // streaming 0.9 MB through one CU): 768 or 512 columns per block, partial sums finished by rowsum_kernel
+           const RowStats* in, int act, const float* resid, int ldr, float* C, int ldc, RowStats* out, float* partial, hipStream_t stream) {
+    // K slices across blocks when K exceeds the 16 waves x 64 columns of a block (the FFN's second contraction: K = 2048 /
+    // 3072): partial sums, finished by rowsum_kernel
+    auto ok_nw = [](int nw) { return nw >= 1 && nw <= 12 && (nw <= 4 || nw % 2 == 0); };  // the instantiated block sizes
     int Z = 1;
-    if (!ln_g && act == 0 && partial && K >= 2048) Z = K % 768 == 0 ? K / 768 : (K % 512 == 0 ? K / 512 : 1);
-    if (Z > 8) Z = 1;  // (the partial buffer holds 8 slices)
-    SkinnyArgs a{A, lda, W, K, bias, ln_g, ln_b, eps, resid, ldr, C, ldc, M, N, K, act, Z, partial};
-    const dim3 grid((N + 31) / 32, (M + 63) / 64, Z);
-    const int Kb = K / Z;
-#define SKINNY_CASE(NW, BS, LNF)                                                                                         \
-    AVSR_LAUNCH((skinny_gemm_kernel<NW, BS, LNF>), grid, dim3(64 * NW), (size_t)NW * 64 * 33 * sizeof(float), stream, a)
-    if (ln_g) {  // K = 64 NW exactly: four k-steps per wave, two batches of two
-        switch (K) {
-            case 128: SKINNY_CASE(2, 2, true); break;
-            case 256: SKINNY_CASE(4, 2, true); break;
-            case 512: SKINNY_CASE(8, 2, true); break;
-            case 768: SKINNY_CASE(12, 2, true); break;
-            case 1024: SKINNY_CASE(16, 2, true); break;
-            default: avsr_set_error("beam_step: attention dimension must be 128, 256, 512, 768 or 1024"); return 1;
-        }
-    } else if (Kb % 1024 == 0) SKINNY_CASE(16, 2, false);
-    else if (Kb % 768 == 0) SKINNY_CASE(12, 4, false);
-    else if (Kb % 512 == 0) SKINNY_CASE(8, 4, false);
-    else if (Kb % 256 == 0) SKINNY_CASE(4, 4, false);
-    else if (Kb % 128 == 0) SKINNY_CASE(2, 4, false);
-    else if (Kb % 64 == 0) SKINNY_CASE(1, 4, false);
-    else {
-        avsr_set_error("beam_step: K must be a multiple of 64");
+    while (Z <= 8 && !(K % (64 * Z) == 0 && ok_nw(K / (64 * Z)))) Z++;
+    if (Z > 8 || (Z > 1 && (ln_g || act != 0 || !partial))) {
+        avsr_set_error("beam_step: unsupported contraction length");
         return 1;
     }
+    const int nw = K / (64 * Z);
+    const int r8 = ((M < SK_ROWS ? M : SK_ROWS) + 7) / 8 * 8;
+    int reg = (32 + r8) * 128;
+    if (reg < 64 * 33 * 4) reg = 64 * 33 * 4;
+    reg = (reg + 1023) / 1024 * 1024;
+    const dim3 grid((N + 31) / 32, (M + SK_ROWS - 1) / SK_ROWS, Z);
+    SkinnyArgs a{A, lda, W, K, bias, ln_g, ln_b, eps, in ? in->buf : nullptr, in ? in->nt : 0, resid, ldr, C, ldc,
+                 (out && Z == 1) ? out->buf : nullptr, M, N, K, act, Z, partial, r8, reg};
+    if (out) out->nt = Z == 1 ? (int)grid.x : 1;
+#define SKINNY_CASE(NW) AVSR_LAUNCH((skinny_gemm_kernel<NW>), grid, dim3(64 * NW), (size_t)NW * reg, stream, a)
+    switch (nw) {
+        case 1: SKINNY_CASE(1); break;
+        case 2: SKINNY_CASE(2); break;
+        case 3: SKINNY_CASE(3); break;
+        case 4: SKINNY_CASE(4); break;
+        case 6: SKINNY_CASE(6); break;
+        case 8: SKINNY_CASE(8); break;
+        case 10: SKINNY_CASE(10); break;
+        case 12: SKINNY_CASE(12); break;
+        default: avsr_set_error("beam_step: unsupported contraction length"); return 1;
+    }
 #undef SKINNY_CASE
-    if (Z > 1) AVSR_LAUNCH(rowsum_kernel, dim3(M), dim3(256), 0, stream, (const float*)partial, Z, M, N, bias, resid, (long)ldr, C, (long)ldc);
+    if (Z > 1)
+        AVSR_LAUNCH(rowsum_kernel, dim3(M), dim3(256), 0, stream, (const float*)partial, Z, M, N, bias, resid, (long)ldr, C, (long)ldc,
+                    out ? out->buf : (float*)nullptr);
     return 0;
 }
 
@@ -770,6 +868,22 @@ int skinny(const float* A, int lda, const float* W, int M, int N, int K, const f
         const int rc__ = (call);  \
         if (rc__ != 0) return rc__; \
     } while (0)
+
+// The linear layer of a decoding step on its own (tests, microbenchmarks): C = act(LN?(A) W^T + bias) + resid, M <= 128 rows.
+// st_in [M][st_in_nt][2]: per-row (sum, sum of squares) partials of A (LN only); st_out [M][ceil(N / 32)][2] or NULL: the same
+// for the rows of C; partial: >= 8 * M * N floats, needed when K > 768 (K slices).  Returns the number of partials per row of
+// st_out through st_out_nt (may be NULL).
+extern "C" int avsr_decode_linear(const float* A, int lda, const float* W, int M, int N, int K, const float* bias, const float* ln_g,
+                                  const float* ln_b, float eps, const float* st_in, int st_in_nt, int act, const float* resid, int ldr,
+                                  float* C, int ldc, float* st_out, int* st_out_nt, float* partial, hipStream_t stream) {
+    RowStats in{const_cast<float*>(st_in), st_in_nt}, out{st_out, 0};
+    const int rc = skinny(A, lda, W, M, N, K, bias, ln_g, ln_b, eps, ln_g ? &in : nullptr, act, resid, ldr, C, ldc, st_out ? &out : nullptr,
+                          partial, stream);
+    if (rc != 0) return rc;
+    AVSR_CHECK_LAUNCH("decode_linear");
+    if (st_out_nt) *st_out_nt = out.nt;
+    return 0;
+}
 
 // cfg: D, H, FF, V, n_layers, beam, S (pre-beam size), sos, eos, blank, has_length_bonus, pe_rows
 // fcfg: w_decoder, w_ctc, w_length_bonus, embedding scale (sqrt(D), embedding.py:84), LayerNorm eps
@@ -845,24 +959,26 @@ extern "C" int avsr_beam_step(int64_t h, float* host_out, int* n_out, hipStream_
     BeamBuf& st = s.st[s.cur];
     BeamBuf& nx = s.st[s.cur ^ 1];
     const float scale = 1.0f / sqrtf(64.f);
-    // embedding of the last token at position L - 1 (transformer_decoder.py:186-189, embedding.py:78-87)
-    DEC_TRY(avsr_embed_fwd(st.last, s.embed, s.pe + (size_t)(L - 1) * D, s.x, n, 1, D, s.emb_scale, 0.f, 0, nullptr, stream));
+    // embedding of the last token at position L - 1 (transformer_decoder.py:186-189, embedding.py:78-87) + its row statistics
+    RowStats sx{s.stx, 1}, s1{s.st1, 0}, s2{s.st2, 0};
+    AVSR_LAUNCH(dec_embed_kernel, dim3(n), dim3(256), 0, stream, (const int64_t*)st.last, s.embed, s.pe + (size_t)(L - 1) * D, s.emb_scale, D,
+                s.x, sx.buf);
     float* x = s.x;
     for (int l = 0; l < s.nl; l++) {
         const Layer& w = s.layers[l];
         float* row = s.cache[l] + (size_t)(L - 1) * beam * 3 * D;  // this position's q | k | v rows, slot b = hypothesis b
-        DEC_TRY(skinny(x, D, w.wqkv, n, 3 * D, D, w.bqkv, w.n1g, w.n1b, s.eps, 0, nullptr, 0, row, 3 * D, nullptr, stream));
+        DEC_TRY(skinny(x, D, w.wqkv, n, 3 * D, D, w.bqkv, w.n1g, w.n1b, s.eps, &sx, 0, nullptr, 0, row, 3 * D, nullptr, nullptr, stream));
         AVSR_LAUNCH(dec_attn_kernel, dim3(n, s.H), dim3(256), (size_t)L * sizeof(float), stream, (const float*)row, (long)3 * D,
                     (const float*)s.cache[l], (long)beam * 3 * D, (long)3 * D, D, 2 * D, (const int*)st.anc, s.ldy, L, scale, s.att, (long)D);
-        DEC_TRY(skinny(s.att, D, w.wo, n, D, D, w.bo, nullptr, nullptr, 0.f, 0, x, D, s.x1, D, nullptr, stream));
-        DEC_TRY(skinny(s.x1, D, w.wq2, n, D, D, w.bq2, w.n2g, w.n2b, s.eps, 0, nullptr, 0, s.q2, D, nullptr, stream));
+        DEC_TRY(skinny(s.att, D, w.wo, n, D, D, w.bo, nullptr, nullptr, 0.f, nullptr, 0, x, D, s.x1, D, &s1, nullptr, stream));
+        DEC_TRY(skinny(s.x1, D, w.wq2, n, D, D, w.bq2, w.n2g, w.n2b, s.eps, &s1, 0, nullptr, 0, s.q2, D, nullptr, nullptr, stream));
         AVSR_LAUNCH(dec_attn_kernel, dim3(n, s.H), dim3(256), (size_t)s.T * sizeof(float), stream, (const float*)s.q2, (long)D,
                     (const float*)s.memkv[l], (long)2 * D, 0L, 0, D, (const int*)nullptr, 0, s.T, scale, s.att, (long)D);
-        DEC_TRY(skinny(s.att, D, w.wo2, n, D, D, w.bo2, nullptr, nullptr, 0.f, 0, s.x1, D, s.x2, D, nullptr, stream));
-        DEC_TRY(skinny(s.x2, D, w.w1, n, s.FF, D, w.b1, w.n3g, w.n3b, s.eps, 1, nullptr, 0, s.ff, s.FF, nullptr, stream));
-        DEC_TRY(skinny(s.ff, s.FF, w.w2, n, D, s.FF, w.b2, nullptr, nullptr, 0.f, 0, s.x2, D, s.x, D, s.part, stream));
+        DEC_TRY(skinny(s.att, D, w.wo2, n, D, D, w.bo2, nullptr, nullptr, 0.f, nullptr, 0, s.x1, D, s.x2, D, &s2, nullptr, stream));
+        DEC_TRY(skinny(s.x2, D, w.w1, n, s.FF, D, w.b1, w.n3g, w.n3b, s.eps, &s2, 1, nullptr, 0, s.ff, s.FF, nullptr, nullptr, stream));
+        DEC_TRY(skinny(s.ff, s.FF, w.w2, n, D, s.FF, w.b2, nullptr, nullptr, 0.f, nullptr, 0, s.x2, D, s.x, D, &sx, s.part, stream));
     }
-    DEC_TRY(skinny(x, D, s.wout, n, s.V, D, s.bout, s.ang, s.anb, s.eps, 0, nullptr, 0, s.logits, s.ldv, nullptr, stream));
+    DEC_TRY(skinny(x, D, s.wout, n, s.V, D, s.bout, s.ang, s.anb, s.eps, &sx, 0, nullptr, 0, s.logits, s.ldv, nullptr, nullptr, stream));
     DEC_TRY(avsr_log_softmax(s.logits, s.ldv, s.lse, s.logp, n, s.V, stream));
     AVSR_LAUNCH(prebeam_select_kernel, dim3(n), dim3(256), (size_t)(s.V + s.S) * sizeof(unsigned), stream, (const float*)s.logp, (long)s.ldv,
                 s.V, s.S, s.cand);

@@ -62,6 +62,12 @@ class NativeBeam:
         FF = lay.feed_forward.w_1.out_features
         if dec.output_layer is None or not dec.normalize_before or D != 64 * H or FF % 64:
             return False
+
+        def block_ok(nw):  # the block sizes csrc/decode.hip instantiates (waves of 64 columns of K)
+            return 1 <= nw <= 12 and (nw <= 4 or nw % 2 == 0)
+
+        if not block_ok(D // 64) or not any(FF % (64 * z) == 0 and block_ok(FF // (64 * z)) for z in range(1, 9)):
+            return False
         beam, S = bs.beam_size, bs.pre_beam_size
         return 2 <= beam <= MAX_BEAM and beam <= S - 1 and beam * (S + 1) <= 8192
 

@@ -444,6 +444,13 @@ int avsr_ctc_prefix_score(const float* logp, int T, int V, int ldv, const float*
 int64_t avsr_beam_create(const int32_t* cfg, const float* fcfg, const void* const* w, int n_w);
 int avsr_beam_destroy(int64_t handle);
 int64_t avsr_beam_workspace_bytes(int64_t handle, int T, int Lmax);
+/* the linear layer of a decoding step on its own: C = act(LN?(A) W^T + bias) + resid for M <= 128 rows (transformer_decoder.py:84-126
+ * on one position per hypothesis); st_in [M][st_in_nt][2] per-row (sum, sum of squares) partials of A when ln_g != NULL;
+ * st_out [M][ceil(N/32)][2] (may be NULL) the same for the rows of C, partial count per row through st_out_nt; partial: scratch of
+ * 8 * M * N floats, used when K > 768 */
+int avsr_decode_linear(const float* A, int lda, const float* W, int M, int N, int K, const float* bias, const float* ln_g,
+                       const float* ln_b, float eps, const float* st_in, int st_in_nt, int act, const float* resid, int ldr,
+                       float* C, int ldc, float* st_out, int* st_out_nt, float* partial, avsr_stream_t stream);
 /* new utterance: memory [T][D] f32 encoder output, ctc_logp [T][ld_ctc] f32 log-softmax of the CTC head, r_init [T][2] CTC
  * state of the empty prefix (ctc_prefix_score.py:60-66), workspace of avsr_beam_workspace_bytes(handle, T, Lmax) */
 int avsr_beam_begin(int64_t handle, const float* memory, int T, const float* ctc_logp, int ld_ctc, const float* r_init,

@@ -118,6 +118,44 @@ def test_native_beam_search_equals_python_step(dev, maxlenratio):
     assert live >= 3
 
 
+@pytest.mark.parametrize("M,N,K,ln,act,res", [(5, 64, 128, False, 0, False), (5, 64, 128, True, 0, False), (40, 96, 128, True, 1, True),
+                                              (40, 50, 256, False, 0, True), (33, 128, 768, True, 0, True), (7, 128, 2048, False, 0, True),
+                                              (50, 64, 128, True, 0, True), (1, 5049, 128, True, 0, False)])
+def test_decode_linear(dev, M, N, K, ln, act, res):
+    """The linear layer of a decoding step (csrc/decode.hip skinny_gemm_kernel: LDS-DMA staging, split-plane MFMAs, LayerNorm
+    from the producer's row statistics, K slices + row-sum for long contractions) against float64, and the row statistics it
+    leaves for the next LayerNorm."""
+    import ctypes
+
+    from auto_avsr_amd import _lib, ops
+
+    L = _lib.lib()
+    g0 = torch.Generator().manual_seed(M * 1000 + N + K)
+    rnd = lambda *sh: torch.randn(*sh, generator=g0)  # noqa: E731
+    A, W, b = (rnd(M, K) * 2 + 0.5).to(dev), (rnd(N, K) / K ** 0.5).to(dev), rnd(N).to(dev)
+    g, be, R = (torch.rand(K, generator=g0) + 0.5).to(dev), (rnd(K) * 0.1).to(dev), rnd(M, N).to(dev)
+    C = torch.zeros(M, N, device=dev)
+    nt_max = (N + 31) // 32
+    st = torch.zeros(M * nt_max * 2, device=dev)
+    part = torch.zeros(8 * M * N, device=dev)
+    st_in = torch.stack([A.sum(1), (A * A).sum(1)], 1).contiguous()
+    n = ctypes.c_int(0)
+    L.call("avsr_decode_linear", A.data_ptr(), K, W.data_ptr(), M, N, K, b.data_ptr(), g.data_ptr() if ln else None,
+           be.data_ptr() if ln else None, 1e-12, st_in.data_ptr() if ln else None, 1, act, R.data_ptr() if res else None, N, C.data_ptr(), N,
+           st.data_ptr(), ctypes.cast(ctypes.pointer(n), ctypes.c_void_p), part.data_ptr(), ops._stream(A))
+    X = torch.nn.functional.layer_norm(A.double(), (K,), g.double(), be.double(), 1e-12) if ln else A.double()
+    ref = X @ W.double().T + b.double()
+    if act:
+        ref = ref.relu()
+    if res:
+        ref = ref + R.double()
+    assert float((C.double() - ref).abs().max() / ref.abs().max()) < 2e-5
+    assert n.value == (1 if K > 768 else nt_max)
+    stv = st[: M * n.value * 2].view(M, n.value, 2).double()
+    assert float((stv[:, :, 0].sum(1) - ref.sum(1)).abs().max()) < 1e-3 * float(ref.abs().sum(1).max())
+    assert float((stv[:, :, 1].sum(1) - (ref * ref).sum(1)).abs().max()) < 1e-4 * float((ref * ref).sum(1).max())
+
+
 def test_native_beam_search_long_ffn(dev):
     """linear_units = 2048 (the reference model's decoder width): the FFN's second contraction runs as K slices across blocks +
     the row-sum kernel (csrc/decode.hip skinny()), which the 256-unit golden cases never reach."""
