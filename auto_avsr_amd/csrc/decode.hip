@@ -548,17 +548,36 @@ AVSR_DEV void radix_compact(const unsigned* keys, int n, unsigned thr, int n_gt,
 }
 
 // Pre-beam (beam_search.py:240-262 with pre_beam_score_key = "decoder" / "full"): the S best tokens of every row of the
-// decoder's log-probabilities, as a SET.
-__global__ __launch_bounds__(256) void prebeam_select_kernel(const float* __restrict__ logp, long ld, int V, int S,
-                                                             int64_t* __restrict__ cand) {
+// decoder's scores, as a SET -- fused with the log-softmax that produces those scores (transformer_decoder.py:256:
+// logp = logits - logsumexp(logits), written for the selection kernel; the order of a row is that of its logits).
+__global__ __launch_bounds__(256) void logsoftmax_prebeam_kernel(const float* __restrict__ logits, float* __restrict__ logp, long ld, int V,
+                                                                 int S, int64_t* __restrict__ cand) {
     AVSR_DYN_SMEM(smem);
     unsigned* keys = reinterpret_cast<unsigned*>(smem);  // [V]
     int* picked = reinterpret_cast<int*>(keys + V);      // [S]
     __shared__ RadixScratch sc;
-    const int row = blockIdx.x, tid = threadIdx.x;
-    const float* x = logp + (size_t)row * ld;
-    for (int i = tid; i < V; i += 256) keys[i] = f2key(x[i]);
+    __shared__ float redf[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* x = logits + (size_t)row * ld;
+    float m = -INFINITY;
+    for (int i = tid; i < V; i += 256) {
+        const float v = x[i];
+        keys[i] = f2key(v);
+        m = fmaxf(m, v);
+    }
+    m = wave_max(m);
+    if (lane == 0) redf[wave] = m;
     __syncthreads();
+    m = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    __syncthreads();
+    float l = 0.f;
+    for (int i = tid; i < V; i += 256) l += expf(x[i] - m);
+    l = wave_sum(l);
+    if (lane == 0) redf[wave] = l;
+    __syncthreads();
+    const float lse = m + logf((redf[0] + redf[1]) + (redf[2] + redf[3]));
+    float* y = logp + (size_t)row * ld;
+    for (int i = tid; i < V; i += 256) y[i] = x[i] - lse;
     unsigned thr;
     int n_gt, eq_take;
     radix_select(keys, V, S, sc, thr, n_gt, eq_take);
@@ -979,9 +998,8 @@ extern "C" int avsr_beam_step(int64_t h, float* host_out, int* n_out, hipStream_
         DEC_TRY(skinny(s.ff, s.FF, w.w2, n, D, s.FF, w.b2, nullptr, nullptr, 0.f, nullptr, 0, s.x2, D, s.x, D, &sx, s.part, stream));
     }
     DEC_TRY(skinny(x, D, s.wout, n, s.V, D, s.bout, s.ang, s.anb, s.eps, &sx, 0, nullptr, 0, s.logits, s.ldv, nullptr, nullptr, stream));
-    DEC_TRY(avsr_log_softmax(s.logits, s.ldv, s.lse, s.logp, n, s.V, stream));
-    AVSR_LAUNCH(prebeam_select_kernel, dim3(n), dim3(256), (size_t)(s.V + s.S) * sizeof(unsigned), stream, (const float*)s.logp, (long)s.ldv,
-                s.V, s.S, s.cand);
+    AVSR_LAUNCH(logsoftmax_prebeam_kernel, dim3(n), dim3(256), (size_t)(s.V + s.S) * sizeof(unsigned), stream, (const float*)s.logits, s.logp,
+                (long)s.ldv, s.V, s.S, s.cand);
     DEC_TRY(avsr_ctc_prefix_score(s.ctc_logp, s.T, s.V, s.ld_ctc, st.r, st.last, s.cand, n, s.S, L - 1, s.blank, s.r_new, s.psi,
                                   s.psi_eos, stream));
     const int NE = n * (s.S + 1);
