@@ -71,13 +71,14 @@ AVSR_DEV float wave_max(float v) {
 // -- self-attention: the [position][slot] cache, the hypothesis' own ancestry; source attention: the utterance's memory
 // projection, shared by every hypothesis.  16 lanes share a key (one float4 of the 64 dimensions each), a block of four
 // waves takes 16 keys per iteration; scores are parked in LDS, softmax in f32 with expf.
-__global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__ q, long ldq, const float* __restrict__ kv, long step_j,
+__global__ __launch_bounds__(1024) void dec_attn_kernel(const float* __restrict__ q, long ldq, const float* __restrict__ kv, long step_j,
                                                        long step_slot, int koff, int voff, const int* __restrict__ anc, int ld_anc,
                                                        int len, float scale, float* __restrict__ out, long ldo) {
     AVSR_DYN_SMEM(smem);
+    const int nwv = blockDim.x >> 6;             // 4, 8 or 16 waves: 16 keys per wave and chunk
     float* sc = reinterpret_cast<float*>(smem);  // [len] scores, then probabilities
-    __shared__ float red[4];
-    __shared__ float part[4][64];
+    float* part = sc + len;                      // [nwv][64]
+    __shared__ float red[16];
     const int b = blockIdx.x, h = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
@@ -88,16 +89,16 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
     };
     // four keys per lane and pass: the loads of a chunk of 64 keys are requested together (a loop of one key per iteration is a
     // chain of exposed L2 round trips: 8 us for 100 keys)
-    for (int j0 = 0; j0 < len; j0 += 64) {
+    for (int j0 = 0; j0 < len; j0 += 16 * nwv) {
         f32x4 k4[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int j = j0 + 16 * u + 4 * wave + g;
+            const int j = j0 + 4 * nwv * u + 4 * wave + g;
             k4[u] = j < len ? *reinterpret_cast<const f32x4*>(row_of(j) + koff) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int j = j0 + 16 * u + 4 * wave + g;
+            const int j = j0 + 4 * nwv * u + 4 * wave + g;
             float s = q4[0] * k4[u][0] + q4[1] * k4[u][1] + q4[2] * k4[u][2] + q4[3] * k4[u][3];
 #pragma unroll
             for (int m = 8; m >= 1; m >>= 1) s += __shfl_xor(s, m);
@@ -106,14 +107,15 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
     }
     __syncthreads();
     float m = -INFINITY;
-    for (int j = threadIdx.x; j < len; j += 256) m = fmaxf(m, sc[j]);
+    for (int j = threadIdx.x; j < len; j += blockDim.x) m = fmaxf(m, sc[j]);
     m = wave_max(m);
     if (lane == 0) red[wave] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    m = red[0];
+    for (int w = 1; w < nwv; w++) m = fmaxf(m, red[w]);
     __syncthreads();
     float l = 0.f;
-    for (int j = threadIdx.x; j < len; j += 256) {
+    for (int j = threadIdx.x; j < len; j += blockDim.x) {
         const float p = expf(sc[j] - m);
         sc[j] = p;
         l += p;
@@ -121,14 +123,15 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
     l = wave_sum(l);
     if (lane == 0) red[wave] = l;
     __syncthreads();
-    l = (red[0] + red[1]) + (red[2] + red[3]);
+    l = 0.f;
+    for (int w = 0; w < nwv; w++) l += red[w];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int j0 = 0; j0 < len; j0 += 64) {
+    for (int j0 = 0; j0 < len; j0 += 16 * nwv) {
         f32x4 v4[4];
         float p[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int j = j0 + 16 * u + 4 * wave + g;
+            const int j = j0 + 4 * nwv * u + 4 * wave + g;
             v4[u] = j < len ? *reinterpret_cast<const f32x4*>(row_of(j) + voff) : f32x4{0.f, 0.f, 0.f, 0.f};
             p[u] = j < len ? sc[j] : 0.f;
         }
@@ -144,12 +147,115 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
     }
     if (g == 0) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) part[wave][4 * c + e] = acc[e];
+        for (int e = 0; e < 4; e++) part[wave * 64 + 4 * c + e] = acc[e];
     }
     __syncthreads();
     if (threadIdx.x < 64) {
-        const float v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        float v = 0.f;
+        for (int w = 0; w < nwv; w++) v += part[w * 64 + threadIdx.x];
         out[(size_t)b * ldo + h * 64 + threadIdx.x] = v / l;
+    }
+}
+
+// Source attention of a decoding step (transformer_decoder.py:109-117): every hypothesis attends to the SAME projected memory,
+// so a block takes HB hypotheses of one head and reads each key / value row once for all of them (with one hypothesis per
+// block the 480 blocks of a beam-40 step pull 98 MB through the L2s at T = 400: 35 us per launch).  Layout as dec_attn_kernel:
+// 16 lanes per key, 16 keys per block iteration, four iterations' loads in flight; wave w owns the softmax of hypothesis w.
+constexpr int SRC_HB = 4;
+__global__ __launch_bounds__(1024) void dec_src_attn_kernel(const float* __restrict__ q, long ldq, const float* __restrict__ kv, long step_j,
+                                                           int voff, int n, int len, float scale, float* __restrict__ out, long ldo) {
+    AVSR_DYN_SMEM(smem);
+    const int nwv = blockDim.x >> 6;             // 4, 8 or 16 waves
+    float* sc = reinterpret_cast<float*>(smem);  // [SRC_HB][len]
+    float* part = sc + SRC_HB * len;             // [nwv][SRC_HB][64]
+    __shared__ float s_l[SRC_HB];
+    const int b0 = blockIdx.x * SRC_HB, h = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    f32x4 q4[SRC_HB];
+#pragma unroll
+    for (int i = 0; i < SRC_HB; i++)
+        q4[i] = b0 + i < n ? *reinterpret_cast<const f32x4*>(q + (size_t)(b0 + i) * ldq + h * 64 + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* base = kv + h * 64 + 4 * c;
+    for (int j0 = 0; j0 < len; j0 += 16 * nwv) {
+        f32x4 k4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + 4 * nwv * u + 4 * wave + g;
+            k4[u] = j < len ? *reinterpret_cast<const f32x4*>(base + (size_t)j * step_j) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + 4 * nwv * u + 4 * wave + g;
+#pragma unroll
+            for (int i = 0; i < SRC_HB; i++) {
+                float s = q4[i][0] * k4[u][0] + q4[i][1] * k4[u][1] + q4[i][2] * k4[u][2] + q4[i][3] * k4[u][3];
+#pragma unroll
+                for (int m = 8; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+                if (c == 0 && j < len) sc[i * len + j] = s * scale;
+            }
+        }
+    }
+    __syncthreads();
+    if (wave < SRC_HB) {  // softmax of hypothesis `wave`
+        float* row = sc + wave * len;
+        float m = -INFINITY;
+        for (int j = lane; j < len; j += 64) m = fmaxf(m, row[j]);
+        m = wave_max(m);
+        float l = 0.f;
+        for (int j = lane; j < len; j += 64) {
+            const float p = expf(row[j] - m);
+            row[j] = p;
+            l += p;
+        }
+        l = wave_sum(l);
+        if (lane == 0) s_l[wave] = l;
+    }
+    __syncthreads();
+    f32x4 acc[SRC_HB];
+#pragma unroll
+    for (int i = 0; i < SRC_HB; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j0 = 0; j0 < len; j0 += 16 * nwv) {
+        f32x4 v4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + 4 * nwv * u + 4 * wave + g;
+            v4[u] = j < len ? *reinterpret_cast<const f32x4*>(base + (size_t)j * step_j + voff) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + 4 * nwv * u + 4 * wave + g;
+            if (j < len) {
+#pragma unroll
+                for (int i = 0; i < SRC_HB; i++) {
+                    const float p = sc[i * len + j];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc[i][e] += p * v4[u][e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < SRC_HB; i++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            acc[i][e] += __shfl_xor(acc[i][e], 16);
+            acc[i][e] += __shfl_xor(acc[i][e], 32);
+        }
+    if (g == 0) {
+#pragma unroll
+        for (int i = 0; i < SRC_HB; i++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) part[(wave * SRC_HB + i) * 64 + 4 * c + e] = acc[i][e];
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 * SRC_HB) {
+        const int i = threadIdx.x >> 6, d = threadIdx.x & 63;
+        if (b0 + i < n) {
+            float v = 0.f;
+            for (int w = 0; w < nwv; w++) v += part[(w * SRC_HB + i) * 64 + d];
+            out[(size_t)(b0 + i) * ldo + h * 64 + d] = v / s_l[i];
+        }
     }
 }
 
@@ -987,12 +1093,13 @@ extern "C" int avsr_beam_step(int64_t h, float* host_out, int* n_out, hipStream_
         const Layer& w = s.layers[l];
         float* row = s.cache[l] + (size_t)(L - 1) * beam * 3 * D;  // this position's q | k | v rows, slot b = hypothesis b
         DEC_TRY(skinny(x, D, w.wqkv, n, 3 * D, D, w.bqkv, w.n1g, w.n1b, s.eps, &sx, 0, nullptr, 0, row, 3 * D, nullptr, nullptr, stream));
-        AVSR_LAUNCH(dec_attn_kernel, dim3(n, s.H), dim3(256), (size_t)L * sizeof(float), stream, (const float*)row, (long)3 * D,
+        const int wv_self = L <= 64 ? 4 : (L <= 256 ? 8 : 16), wv_src = s.T <= 64 ? 4 : (s.T <= 256 ? 8 : 16);  // waves per attention block
+        AVSR_LAUNCH(dec_attn_kernel, dim3(n, s.H), dim3(64 * wv_self), (size_t)(L + 64 * wv_self) * sizeof(float), stream, (const float*)row, (long)3 * D,
                     (const float*)s.cache[l], (long)beam * 3 * D, (long)3 * D, D, 2 * D, (const int*)st.anc, s.ldy, L, scale, s.att, (long)D);
         DEC_TRY(skinny(s.att, D, w.wo, n, D, D, w.bo, nullptr, nullptr, 0.f, nullptr, 0, x, D, s.x1, D, &s1, nullptr, stream));
         DEC_TRY(skinny(s.x1, D, w.wq2, n, D, D, w.bq2, w.n2g, w.n2b, s.eps, &s1, 0, nullptr, 0, s.q2, D, nullptr, nullptr, stream));
-        AVSR_LAUNCH(dec_attn_kernel, dim3(n, s.H), dim3(256), (size_t)s.T * sizeof(float), stream, (const float*)s.q2, (long)D,
-                    (const float*)s.memkv[l], (long)2 * D, 0L, 0, D, (const int*)nullptr, 0, s.T, scale, s.att, (long)D);
+        AVSR_LAUNCH(dec_src_attn_kernel, dim3((n + SRC_HB - 1) / SRC_HB, s.H), dim3(64 * wv_src), (size_t)SRC_HB * (s.T + 64 * wv_src) * sizeof(float), stream,
+                    (const float*)s.q2, (long)D, (const float*)s.memkv[l], (long)2 * D, D, n, s.T, scale, s.att, (long)D);
         DEC_TRY(skinny(s.att, D, w.wo2, n, D, D, w.bo2, nullptr, nullptr, 0.f, nullptr, 0, s.x1, D, s.x2, D, &s2, nullptr, stream));
         DEC_TRY(skinny(s.x2, D, w.w1, n, s.FF, D, w.b1, w.n3g, w.n3b, s.eps, &s2, 1, nullptr, 0, s.ff, s.FF, nullptr, nullptr, stream));
         DEC_TRY(skinny(s.ff, s.FF, w.w2, n, D, s.FF, w.b2, nullptr, nullptr, 0.f, nullptr, 0, s.x2, D, s.x, D, &sx, s.part, stream));

@@ -156,6 +156,20 @@ def test_decode_linear(dev, M, N, K, ln, act, res):
     assert float((stv[:, :, 1].sum(1) - (ref * ref).sum(1)).abs().max()) < 1e-4 * float((ref * ref).sum(1).max())
 
 
+@pytest.mark.parametrize("T", [80, 300])
+def test_native_beam_search_long_memory(dev, T):
+    """Encoder memories longer than one attention chunk: the source-attention blocks run with 8 (T <= 256) and 16 waves."""
+    case = dict(GOLD["beam"][0], T=T)
+    a, b = _search(dev, case, True, maxlenratio=-5), _search(dev, case, False, maxlenratio=-5)
+    assert len(a) == len(b) and len(a) >= 1
+    for x, y in zip(a, b):
+        x, y = x.asdict(), y.asdict()
+        if y["score"] < -1e8:
+            continue
+        assert x["yseq"] == y["yseq"]
+        assert abs(x["score"] - y["score"]) < 1e-3 * max(1.0, abs(y["score"]))
+
+
 def test_native_beam_search_long_ffn(dev):
     """linear_units = 2048 (the reference model's decoder width): the FFN's second contraction runs as K slices across blocks +
     the row-sum kernel (csrc/decode.hip skinny()), which the 256-unit golden cases never reach."""

@@ -188,3 +188,40 @@ def test_full_e2e_beam_search_vs_reference(mode):
         if mode == "precise" or i == 0:
             assert d["yseq"] == ref["yseq"], (mode, i)
             assert abs(d["score"] - ref["score"]) < stol * max(1.0, abs(ref["score"])), (mode, i, d["score"], ref["score"])
+
+
+def test_native_beam_search_equals_python_step_full_size():
+    """Full-size model, T = 100 frames, beam 40, the search running to the length limit (prefixes of 100 tokens: self-attention
+    blocks with 4, then 8 waves over the ancestry-indexed cache): the one-call-per-step search and the python-issued step end
+    with the same hypotheses."""
+    import lightning
+    from auto_avsr_amd import decoding
+    from auto_avsr_amd import functional as AF
+
+    m, _ = _model("video", 3)
+    m.eval()
+    x, _, _ = synth_batch("video", 1, 100, 3, 5049, seed=100, lengths=[100])
+    bs = lightning.get_beam_search_decoder(m, [str(i) for i in range(5049)], beam_size=40)
+    AF.set_mode("precise")
+    AF.invalidate_weight_cache()
+    was = decoding.NATIVE_BEAM
+    try:
+        with torch.no_grad():
+            feats = m.proj_encoder(m.frontend(x.cuda()))
+            enc, _ = m.encoder(feats, None)
+            e = enc.squeeze(0).float()
+            res = {}
+            for native in (True, False):
+                decoding.NATIVE_BEAM = native
+                bs._native = None
+                res[native] = [h.asdict() for h in bs(e)]
+                assert bool(bs._native) == native
+    finally:
+        decoding.NATIVE_BEAM = was
+        AF.set_mode("bf16")
+        AF.invalidate_weight_cache()
+    a, b = res[True], res[False]
+    assert len(a) == len(b) and len(a) >= 10
+    for x_, y_ in list(zip(a, b))[:10]:
+        assert x_["yseq"] == y_["yseq"] and len(y_["yseq"]) > 50
+        assert abs(x_["score"] - y_["score"]) < 1e-3 * abs(y_["score"])
