@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const int64_t* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Top-S selection by radix select on the order-preserving integer image of the floats (256 threads, keys in LDS).  The
+// Top-S selection by radix select on the order-preserving integer image of the floats (keys in LDS).  The
 // digits are taken from key - min(key), most significant byte of the SPAN first: log-probabilities share sign and exponent,
 // so the top byte of the raw key is the same for nearly every element -- a histogram pass on it is thousands of LDS atomics
 // on one address (measured: 57 us for 5 049 values); relative to the span the first digit already spreads.
@@ -556,20 +556,23 @@ AVSR_DEV int wave_incl_scan(int v, int lane) {
     return v;
 }
 
+constexpr int SEL_NT = 1024;  // threads of the selection kernels (the per-element passes are latency chains: more lanes, fewer trips)
+
 struct RadixScratch {
     int hist[256];
-    unsigned wmin[4], wmax[4];
+    unsigned wmin[SEL_NT / 64], wmax[SEL_NT / 64];
     unsigned prefix, mask;
     int remaining;
-    int wtot[2][4];
+    int wtot[2][SEL_NT / 64];
 };
 
 // keys[0 .. n): finds the S-th largest key `thr`; returns the number of keys above it, `eq_take` = how many keys equal to it
-// belong to the selection (taken in index order).  S <= n.  All 256 threads call it.
+// belong to the selection (taken in index order).  S <= n.  All SEL_NT threads call it.
 AVSR_DEV void radix_select(const unsigned* keys, int n, int S, RadixScratch& sc, unsigned& thr, int& n_gt, int& eq_take) {
+    constexpr int NWV = SEL_NT / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned lo = 0xffffffffu, hi = 0u;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += SEL_NT) {
         lo = umin(lo, keys[i]);
         hi = umax(hi, keys[i]);
     }
@@ -588,26 +591,31 @@ AVSR_DEV void radix_select(const unsigned* keys, int n, int S, RadixScratch& sc,
         sc.remaining = S;
     }
     __syncthreads();
-    const unsigned kmin = umin(umin(sc.wmin[0], sc.wmin[1]), umin(sc.wmin[2], sc.wmin[3]));
-    const unsigned span = umax(umax(sc.wmax[0], sc.wmax[1]), umax(sc.wmax[2], sc.wmax[3])) - kmin;
+    unsigned kmin = sc.wmin[0], kmax = sc.wmax[0];
+#pragma unroll
+    for (int w = 1; w < NWV; w++) {
+        kmin = umin(kmin, sc.wmin[w]);
+        kmax = umax(kmax, sc.wmax[w]);
+    }
+    const unsigned span = kmax - kmin;
     int bits = 0;
     while (bits < 32 && (span >> bits) != 0u) bits++;
     const int npass = (bits + 7) / 8;
     for (int pass = npass - 1; pass >= 0; pass--) {
-        sc.hist[tid] = 0;
+        if (tid < 256) sc.hist[tid] = 0;
         __syncthreads();
         const unsigned prefix = sc.prefix, mask = sc.mask;
-        for (int i = tid; i < n; i += 256) {
+        for (int i = tid; i < n; i += SEL_NT) {
             const unsigned k = keys[i] - kmin;
             if ((k & mask) == prefix) atomicAdd(&sc.hist[(k >> (8 * pass)) & 255u], 1);
         }
         __syncthreads();
-        {
-            // digit d with  #(digits > d) < remaining <= #(digits >= d):  thread t looks at digit 255 - t; inclusive scan from the top
-            const int rem = sc.remaining, own = sc.hist[255 - tid];
-            int incl = wave_incl_scan(own, lane);
-            if (lane == 63) sc.wtot[0][wave] = incl;
-            __syncthreads();
+        // digit d with  #(digits > d) < remaining <= #(digits >= d):  thread t < 256 looks at digit 255 - t; inclusive scan from the top
+        const int rem = sc.remaining, own = tid < 256 ? sc.hist[255 - tid] : 0;
+        int incl = tid < 256 ? wave_incl_scan(own, lane) : 0;  // (waves 0 - 3 whole: wave-uniform)
+        if (tid < 256 && lane == 63) sc.wtot[0][wave] = incl;
+        __syncthreads();
+        if (tid < 256) {
             for (int w = 0; w < wave; w++) incl += sc.wtot[0][w];
             if (incl >= rem && incl - own < rem) {  // exactly one thread
                 sc.remaining = rem - (incl - own);  // entries still to take among the keys that share the prefix extended by this digit
@@ -625,7 +633,7 @@ AVSR_DEV void radix_select(const unsigned* keys, int n, int S, RadixScratch& sc,
 // the selected keys' indices in index order (greater-than-threshold ones first, then the ties): out[0 .. S)
 AVSR_DEV void radix_compact(const unsigned* keys, int n, unsigned thr, int n_gt, int eq_take, RadixScratch& sc, int* out) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per = (n + 255) / 256;
+    const int per = (n + SEL_NT - 1) / SEL_NT;
     const int lo = min(n, tid * per), hi = min(n, lo + per);
     int ngt = 0, neq = 0;
     for (int i = lo; i < hi; i++) {
@@ -656,17 +664,17 @@ AVSR_DEV void radix_compact(const unsigned* keys, int n, unsigned thr, int n_gt,
 // Pre-beam (beam_search.py:240-262 with pre_beam_score_key = "decoder" / "full"): the S best tokens of every row of the
 // decoder's scores, as a SET -- fused with the log-softmax that produces those scores (transformer_decoder.py:256:
 // logp = logits - logsumexp(logits), written for the selection kernel; the order of a row is that of its logits).
-__global__ __launch_bounds__(256) void logsoftmax_prebeam_kernel(const float* __restrict__ logits, float* __restrict__ logp, long ld, int V,
+__global__ __launch_bounds__(SEL_NT) void logsoftmax_prebeam_kernel(const float* __restrict__ logits, float* __restrict__ logp, long ld, int V,
                                                                  int S, int64_t* __restrict__ cand) {
     AVSR_DYN_SMEM(smem);
     unsigned* keys = reinterpret_cast<unsigned*>(smem);  // [V]
     int* picked = reinterpret_cast<int*>(keys + V);      // [S]
     __shared__ RadixScratch sc;
-    __shared__ float redf[4];
+    __shared__ float redf[SEL_NT / 64];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* x = logits + (size_t)row * ld;
     float m = -INFINITY;
-    for (int i = tid; i < V; i += 256) {
+    for (int i = tid; i < V; i += SEL_NT) {
         const float v = x[i];
         keys[i] = f2key(v);
         m = fmaxf(m, v);
@@ -674,22 +682,25 @@ __global__ __launch_bounds__(256) void logsoftmax_prebeam_kernel(const float* __
     m = wave_max(m);
     if (lane == 0) redf[wave] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    m = redf[0];
+    for (int w = 1; w < SEL_NT / 64; w++) m = fmaxf(m, redf[w]);
     __syncthreads();
     float l = 0.f;
-    for (int i = tid; i < V; i += 256) l += expf(x[i] - m);
+    for (int i = tid; i < V; i += SEL_NT) l += expf(x[i] - m);
     l = wave_sum(l);
     if (lane == 0) redf[wave] = l;
     __syncthreads();
-    const float lse = m + logf((redf[0] + redf[1]) + (redf[2] + redf[3]));
+    float lsum = 0.f;
+    for (int w = 0; w < SEL_NT / 64; w++) lsum += redf[w];
+    const float lse = m + logf(lsum);
     float* y = logp + (size_t)row * ld;
-    for (int i = tid; i < V; i += 256) y[i] = x[i] - lse;
+    for (int i = tid; i < V; i += SEL_NT) y[i] = x[i] - lse;
     unsigned thr;
     int n_gt, eq_take;
     radix_select(keys, V, S, sc, thr, n_gt, eq_take);
     radix_compact(keys, V, thr, n_gt, eq_take, sc, picked);
     __syncthreads();
-    for (int i = tid; i < S; i += 256) cand[(size_t)row * S + i] = picked[i];
+    for (int i = tid; i < S; i += SEL_NT) cand[(size_t)row * S + i] = picked[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -697,7 +708,7 @@ __global__ __launch_bounds__(256) void logsoftmax_prebeam_kernel(const float* __
 // extended by one of its S candidates or by <eos> (scorers/ctc.py gives <eos> its complete-sequence probability whether
 // or not the pre-beam kept it; every other token outside the candidates carries the CTC scorer's LOGZERO and cannot
 // reach a beam of K <= n * (S - 1) -- the host refuses configurations where it could).  Arithmetic order as the python
-// form: ((w_dec * logp + w_len) + w_ctc * (log_psi - s_prev)) + score, f32.  ONE block of 256 threads: radix select of the
+// form: ((w_dec * logp + w_len) + w_ctc * (log_psi - s_prev)) + score, f32.  ONE block: radix select of the
 // K best values, then a rank sort of those K (value descending, entry ascending).
 struct SelectArgs {
     const float* logp;  // [n][ld] decoder log-probabilities
@@ -711,7 +722,7 @@ struct SelectArgs {
     float* selv;  // [K][4]: total, decoder term logp, ctc term (log_psi - s_prev), ctc log_psi
 };
 
-__global__ __launch_bounds__(256) void beam_select_kernel(SelectArgs a) {
+__global__ __launch_bounds__(SEL_NT) void beam_select_kernel(SelectArgs a) {
     AVSR_DYN_SMEM(smem);
     const int NE = a.n * (a.S + 1);
     float* val = reinterpret_cast<float*>(smem);            // [NE]
@@ -721,9 +732,9 @@ __global__ __launch_bounds__(256) void beam_select_kernel(SelectArgs a) {
     int* has_eos = cnd + a.n * a.S;                          // [n] <eos> is among the candidates of hypothesis b
     __shared__ RadixScratch sc;
     const int tid = threadIdx.x;
-    for (int i = tid; i < a.n; i += 256) has_eos[i] = 0;
+    for (int i = tid; i < a.n; i += SEL_NT) has_eos[i] = 0;
     __syncthreads();
-    for (int i = tid; i < a.n * a.S; i += 256) {
+    for (int i = tid; i < a.n * a.S; i += SEL_NT) {
         const int t = (int)a.cand[i];
         cnd[i] = t;
         if (t == a.eos) has_eos[i / a.S] = 1;
@@ -744,7 +755,7 @@ __global__ __launch_bounds__(256) void beam_select_kernel(SelectArgs a) {
         dec = a.logp[(size_t)b * a.ld + tok];
         return valid;
     };
-    for (int e = tid; e < NE; e += 256) {
+    for (int e = tid; e < NE; e += SEL_NT) {
         int b, c, tok;
         float dec, ctc_rel, log_psi, v = -INFINITY;
         if (decode(e, b, c, tok, dec, ctc_rel, log_psi)) {
@@ -763,7 +774,7 @@ __global__ __launch_bounds__(256) void beam_select_kernel(SelectArgs a) {
     radix_select(keys, NE, a.K, sc, thr, n_gt, eq_take);
     radix_compact(keys, NE, thr, n_gt, eq_take, sc, picked);
     __syncthreads();
-    for (int r = tid; r < a.K; r += 256) {
+    for (int r = tid; r < a.K; r += SEL_NT) {
         const int e = picked[r];
         const float v = val[e];
         int rank = 0;
@@ -1105,7 +1116,7 @@ extern "C" int avsr_beam_step(int64_t h, float* host_out, int* n_out, hipStream_
         DEC_TRY(skinny(s.ff, s.FF, w.w2, n, D, s.FF, w.b2, nullptr, nullptr, 0.f, nullptr, 0, s.x2, D, s.x, D, &sx, s.part, stream));
     }
     DEC_TRY(skinny(x, D, s.wout, n, s.V, D, s.bout, s.ang, s.anb, s.eps, &sx, 0, nullptr, 0, s.logits, s.ldv, nullptr, nullptr, stream));
-    AVSR_LAUNCH(logsoftmax_prebeam_kernel, dim3(n), dim3(256), (size_t)(s.V + s.S) * sizeof(unsigned), stream, (const float*)s.logits, s.logp,
+    AVSR_LAUNCH(logsoftmax_prebeam_kernel, dim3(n), dim3(SEL_NT), (size_t)(s.V + s.S) * sizeof(unsigned), stream, (const float*)s.logits, s.logp,
                 (long)s.ldv, s.V, s.S, s.cand);
     DEC_TRY(avsr_ctc_prefix_score(s.ctc_logp, s.T, s.V, s.ld_ctc, st.r, st.last, s.cand, n, s.S, L - 1, s.blank, s.r_new, s.psi,
                                   s.psi_eos, stream));
@@ -1113,7 +1124,7 @@ extern "C" int avsr_beam_step(int64_t h, float* host_out, int* n_out, hipStream_
     const int K = beam;  // n * V >= beam always; the viable entries n * (S - 1) >= beam by the create-time check
     SelectArgs a{s.logp, (long)s.ldv, s.cand, s.psi, s.psi_eos, st.sc + 4 * beam, st.sc, n, s.S, K, s.eos, s.blank, s.has_len,
                  s.w_dec, s.w_ctc, s.w_len, s.sel, s.selv};
-    AVSR_LAUNCH(beam_select_kernel, dim3(1), dim3(256), (size_t)(2 * NE + K + n * s.S + n) * 4, stream, a);
+    AVSR_LAUNCH(beam_select_kernel, dim3(1), dim3(SEL_NT), (size_t)(2 * NE + K + n * s.S + n) * 4, stream, a);
     AVSR_LAUNCH(beam_update_kernel, dim3(K), dim3(256), 0, stream, st, nx, s.ldy, beam, L, n, K, s.T, s.S, (const int*)s.sel,
                 (const float*)s.selv, (const float*)s.r_new, s.host_dev);
     AVSR_CHECK_LAUNCH("beam_step");
