@@ -73,7 +73,7 @@ def test_bench_shape_parity(gold, tag, mode):
     elif mode == "mixed":
         # THE BENCHMARKED MODE (bench.py's headline): logits / CTC log-probabilities inside the north star's 1e-3 -- measured
         # on MI355X with the default policy (f16 encoder + trunk + decoder, split stem / projections / CTC head): 8.0e-4 /
-        # 4.5e-4 at batch A (tools/r4_s2.sh sweep) -- with the bf16 backward
+        # 4.5e-4 at batch A (tools/r4_policy_sweep.sh sweep) -- with the bf16 backward
         assert r["dec_logits_rel_l2"] < 1e-3 and r["ctc_logp_rel_l2"] < 1e-3
         assert r["enc_rel_l2"] < 1.5e-2  # (a 32-channel slice of the encoder output: ~10x the logits' relative error in every mode)
         assert r["acc"] == pytest.approx(r["acc_ref"], abs=1e-6)
