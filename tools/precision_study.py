@@ -7,6 +7,8 @@ tests/golden/golden_bench_v1.pt exactly as tests/test_bench_parity.py does.  Acc
 
     python tools/precision_study.py                # the table of DESIGN.md section 2 (a few minutes on 8 cores)
     python tools/precision_study.py --config enc_ffn=f16,trunk=bf16
+    python tools/precision_study.py --layers      # error GROWTH along the network: relative L2 of every block's output against the
+                                                  # f32 oracle for bf16 / f16 / the default mixed policy (profiles/r4_layer_error_growth.txt)
 
 Measurement script: imports oracle/ (allowed for tools, like tools/microbench_augment.py --cpu); never shipped."""
 import argparse
@@ -155,6 +157,23 @@ def install():
     del orig_vf
 
 
+TRACE = None  # --layers: [(name, tensor)] outputs of the blocks, in execution order
+
+
+def install_trace():
+    def rec(fn, name_of):
+        def wrapper(*a, **kw):
+            y = fn(*a, **kw)
+            if TRACE is not None:
+                TRACE.append((name_of(a), y.detach().clone()))
+            return y
+        return wrapper
+
+    O.basic_block = rec(O.basic_block, lambda a: "trunk " + a[1].split("trunk.")[1].rstrip("."))
+    O.encoder_layer = rec(O.encoder_layer, lambda a: "encoder layer " + a[1].rstrip(".").rsplit(".", 1)[1])
+    O.decoder_layer = rec(O.decoder_layer, lambda a: "decoder layer " + a[1].rstrip(".").rsplit(".", 1)[1])
+
+
 def run(case, sd, batch, layer_probe=None):
     x, lengths, y = batch
     STATS.clear()
@@ -191,8 +210,11 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", action="append", default=None)
     ap.add_argument("--batch", default="A")
+    ap.add_argument("--layers", action="store_true")
     args = ap.parse_args()
     torch.set_num_threads(os.cpu_count() or 8)
+    if args.layers:
+        install_trace()  # (innermost: the recorded outputs are those of the quantised blocks)
     install()
     fx = torch.load(FIXTURE, weights_only=False)
     case = fx[args.batch]
@@ -206,6 +228,24 @@ if __name__ == "__main__":
     m = E2E(ODIM, "video")
     sd = bench_state_dict(m.state_dict(), cfgb["seed"])
     batch = bench_batch(cfgb["lengths"], cfgb["L"], cfgb["seed"])
+    if args.layers:
+        MIXED = "trunk3=f16,trunk4=f16,enc_ffn=f16,enc_attn_proj=f16,enc_attn_core=f16,enc_conv=f16,dec=f16"  # functional.MIXED_POLICY
+        cols = {}
+        for name, spec in (("f32", ""), ("bf16", "all=bf16"), ("f16", "all=f16"), ("mixed", MIXED)):
+            CFG.clear()
+            CFG.update(parse(spec))
+            TRACE = []
+            out, mid = run(case, sd, batch)
+            TRACE += [("encoder output (after_norm)", mid["enc"]), ("decoder logits", mid["pred"])]
+            cols[name] = TRACE
+            print(f"# {name}: logits vs REFERENCE golden {out['dec_logits']:.3e}", flush=True)
+            TRACE = None
+        print(f"# relative L2 error of every block's output against the f32 oracle, batch {args.batch} (tools/precision_study.py --layers)")
+        print(f"{'block output':34s} {'bf16':>10s} {'f16':>10s} {'mixed':>10s}")
+        for i, (nm, ref) in enumerate(cols["f32"]):
+            e = [float((cols[k][i][1] - ref).norm() / ref.norm()) for k in ("bf16", "f16", "mixed")]
+            print(f"{nm:34s} {e[0]:10.2e} {e[1]:10.2e} {e[2]:10.2e}")
+        sys.exit(0)
     specs = args.config or ["", "all=bf16", "all=f16"] + [f"all=bf16,{g}=f32" for g in GROUPS] + \
         [f"{g}=bf16" for g in GROUPS] + [f"{g}=f16" for g in GROUPS]
     for spec in specs:
