@@ -263,19 +263,19 @@ __global__ __launch_bounds__(1024) void dec_src_attn_kernel(const float* __restr
 // The linear layers of a decoding step (transformer_decoder.py:84-126 on ONE position per hypothesis): C[M][N] =
 // act(LN?(A)[M][K] . W[N][K]^T + bias) + resid with M <= beam rows.  On the tiled GEMM (64 x 64 tile, 12 - 48 sequential
 // k-tiles behind a two-stage ring) such a launch takes 25 us whatever M is: with 12 - 48 blocks on 256 CUs it is a chain of
-// dependent HBM round trips.  Here a block owns 32 weight rows and 64 NW columns of K (all of K = 768: NW = 12 waves), wave w
-// its own 64 columns, in two phases of 32:
-//  * operands travel global -> LDS by LDS-DMA, 8 lanes per 128-byte row piece (first version: every lane streamed its own
-//    row straight into MFMA fragments -- 32 distinct cache lines per wave-instruction, and the CU's address path, one line
-//    per cycle, was the bound: 10 us per launch, 19 us with the LayerNorm statistics re-reading A);
-//  * the region a wave stages into is its own (no block barrier between the phases), 16-byte chunks XOR-swizzled by the
-//    row so that the fragment reads (lane = row) spread over the banks;
-//  * split hi / lo bf16 planes formed in registers, three MFMAs per product (the precise mode's arithmetic);
-//  * the NW partial tiles meet in LDS (each wave parks its accumulators in its own staging region).
-// LayerNorm in front of a sub-layer's first projection (pre-norm blocks) is applied to the A fragments as they are read; the
-// row statistics it needs were left behind by whatever produced the rows (st_out below: per-row sum and sum of squares of
-// every block's 32 columns, summed by the consumer) -- the 19 stand-alone LayerNorm launches of a step disappear and no
-// kernel reads its input twice.
+// dependent HBM round trips.  Here a block owns 16 weight rows and 64 NW columns of K (all of K = 768: NW = 12 waves), wave w
+// its own 64 columns; split hi / lo bf16 planes are formed in registers, three MFMAs per product (the precise mode's
+// arithmetic); the NW partial tiles meet in LDS.
+// LayerNorm in front of a sub-layer's first projection (pre-norm blocks) is applied to the A fragments; the row statistics it
+// needs were left behind by whatever produced the rows (st_out below: per-row sum and sum of squares of every block's 16
+// columns, summed by the consumer) -- the 19 stand-alone LayerNorm launches of a step disappear and no kernel reads its input
+// twice.
+// History of the kernel (MI355X, per launch at M = 40, K = 768): 32-row MFMA fragments streamed by every lane from its own row:
+// 43 us -- 32 distinct cache lines per wave-instruction, the CU's address path (one line per cycle) was the bound -- and 19 us
+// more when the LayerNorm statistics re-read A; the same tile staged by LDS-DMA (8 lanes per 128-byte row piece, XOR-swizzled
+// wave-private regions, two phases): 9.4 us; the 16-row form below (whole cache lines per four lanes, no staging, one round
+// trip): 9.5 us.  The last two differ in everything but the result: what remains is the price of ANY dependent launch that
+// touches fresh HBM lines here (a 40-block row-sum of 120 KB takes 6 us), not of the data path.
 struct SkinnyArgs {
     const float* A;
     long lda;
@@ -293,7 +293,6 @@ struct SkinnyArgs {
     int M, N, K, act;
     int Z;           // K slices (blockIdx.z); Z > 1: raw partial sums to partial[z][M][N], finished by rowsum_kernel
     float* partial;
-    int r8, reg_bytes;  // rows of A staged per block (multiple of 8, <= 48) and bytes of a wave's LDS region
 };
 
 AVSR_DEV void split8(const float* x, bf16x8& hi, bf16x8& lo) {
@@ -305,27 +304,38 @@ AVSR_DEV void split8(const float* x, bf16x8& hi, bf16x8& lo) {
     }
 }
 
-// The lanes of a wave run in lock step on the GPU; the host emulator runs them as fibers that only meet at wave collectives, so
-// wave-private LDS traffic (DMA by all lanes, then reads of what OTHER lanes staged) needs a meeting point there.
-AVSR_DEV void wave_converge() {
-#ifdef AVSR_EMU
-    (void)__shfl_xor(0, 1);
-#endif
-}
-
-constexpr int SK_ROWS = 48;  // rows of A per block (LDS: 12 waves x (32 + 48) x 128 bytes)
+// v_mfma_f32_16x16x32, no staging.  In the 16-row fragment layout a lane holds 8 consecutive k of row (lane & 15) and the four lanes lane, lane + 16, +32, +48 hold the
+// next 8 each: a wave-instruction reads 16 rows x 128 contiguous bytes -- whole cache lines, four lanes per line -- so the
+// fragments can come straight from global memory without the one-line-per-lane address traffic that sank the first 32-row
+// version.  A block owns 16 weight rows (twice the blocks of the staged kernel: 48 - 316 of them), wave w its 64 columns of K
+// = two MFMA steps; every operand of a wave is requested up front (4 + 12 16-byte loads per lane) and arrives in ONE round trip
+// instead of the staged kernel's two DMA phases.
+constexpr int SK16_ROWS = 48;  // three 16-row tiles per block
 
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void skinny_gemm_kernel(SkinnyArgs a) {
+__global__ __launch_bounds__(64 * NW) void skinny16_kernel(SkinnyArgs a) {
     AVSR_DYN_SMEM(smem);
-    __shared__ float s_mean[64], s_rstd[64];
-    constexpr int NT = 64 * NW;
+    float* red = reinterpret_cast<float*>(smem);  // [NW][48][17]
+    __shared__ float s_mean[SK16_ROWS], s_rstd[SK16_ROWS];
+    constexpr int NT = 64 * NW, RP = 17;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * SK_ROWS;
-    const int rows = min(SK_ROWS, a.M - m0);
-    const int half = lane >> 5, li = lane & 31;
-    char* reg = smem + (size_t)wave * a.reg_bytes;  // [4 groups of 8 weight rows][1 KiB] then [r8 / 8 groups of 8 rows of A][1 KiB]
-    char* areg = reg + 4096;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * SK16_ROWS;
+    const int rows = min(SK16_ROWS, a.M - m0);
+    const int li = lane & 15, kq = lane >> 4;
+    const int kb = (blockIdx.z * NW + wave) * 64 + 8 * kq;  // this lane's first column
+    // every operand of this wave, requested before anything else (LayerNorm statistics below overlap the round trip)
+    const bool nv = n0 + li < a.N;
+    const float* wrow = a.W + (size_t)(nv ? n0 + li : 0) * a.ldw + kb;
+    float w8[2][8], x8[3][2][8];
+#pragma unroll
+    for (int s = 0; s < 2; s++) load8(wrow + 32 * s, w8[s]);
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        const int r = li + 16 * t;
+        const float* arow = a.A + (size_t)(m0 + min(r, rows - 1)) * a.lda + kb;
+#pragma unroll
+        for (int s = 0; s < 2; s++) load8(arow + 32 * s, x8[t][s]);
+    }
     if (a.ln_g) {  // row statistics from the producer's partial sums: 16 lanes per row
         const int sub = tid & 15;
         for (int r0 = 0; r0 < rows; r0 += NT >> 4) {
@@ -350,109 +360,50 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_kernel(SkinnyArgs a) {
         }
         __syncthreads();
     }
-    float mean[2] = {0.f, 0.f}, rstd[2] = {1.f, 1.f};
-    if (a.ln_g) {
+    f32x4 acc[3];
 #pragma unroll
-        for (int t = 0; t < 2; t++)
-            if (li + 32 * t < rows) {
-                mean[t] = s_mean[li + 32 * t];
-                rstd[t] = s_rstd[li + 32 * t];
-            }
-    }
-    f32x16 acc[2];
+    for (int t = 0; t < 3; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 2; t++)
+    for (int s = 0; s < 2; s++) {
+        if (!nv) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
-    const int kb = (blockIdx.z * NW + wave) * 64;  // this wave's 64 columns of K
-    const int g8 = lane >> 3, pc = lane & 7;       // staging: row inside a group of 8, physical 16-byte chunk
-#pragma unroll 1
-    for (int ph = 0; ph < 2; ph++) {
-        const int col0 = kb + 32 * ph;
-#pragma unroll
-        for (int gi = 0; gi < 4; gi++) {
-            const int r = 8 * gi + g8;
-            const int n = min(n0 + r, a.N - 1);
-            glds16(a.W + (size_t)n * a.ldw + col0 + 4 * (pc ^ (r & 7)), reg + gi * 1024);
+            for (int e = 0; e < 8; e++) w8[s][e] = 0.f;
         }
-        for (int gi = 0; gi < a.r8 / 8; gi++) {
-            const int r = 8 * gi + g8;
-            const int m = m0 + min(r, rows - 1);
-            glds16(a.A + (size_t)m * a.lda + col0 + 4 * (pc ^ (r & 7)), areg + gi * 1024);
+        bf16x8 whi, wlo;
+        split8(w8[s], whi, wlo);
+        float g8v[8], b8v[8];
+        if (a.ln_g) {
+            load8(a.ln_g + kb + 32 * s, g8v);
+            load8(a.ln_b + kb + 32 * s, b8v);
         }
-        wait_vmcnt<0>();
-        wave_converge();
-        sched_fence();
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
-            const int c0 = 4 * s + 2 * half;  // this lane's two logical chunks of the 32 columns: c0, c0 + 1
-            float w8[8];
-            {
-                const char* row = reg + (li >> 3) * 1024 + (li & 7) * 128;
-                const f32x4 lo4 = *reinterpret_cast<const f32x4*>(row + ((c0 ^ (li & 7)) << 4));
-                const f32x4 hi4 = *reinterpret_cast<const f32x4*>(row + (((c0 + 1) ^ (li & 7)) << 4));
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    w8[e] = lo4[e];
-                    w8[4 + e] = hi4[e];
-                }
-            }
-            bf16x8 whi, wlo;
-            split8(w8, whi, wlo);
-            float g8v[8], b8v[8];
+        for (int t = 0; t < 3; t++) {
+            const int r = li + 16 * t;
             if (a.ln_g) {
-                load8(a.ln_g + col0 + 16 * s + 8 * half, g8v);
-                load8(a.ln_b + col0 + 16 * s + 8 * half, b8v);
+                const float mean = r < rows ? s_mean[r] : 0.f, rstd = r < rows ? s_rstd[r] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; e++) x8[t][s][e] = (x8[t][s][e] - mean) * rstd * g8v[e] + b8v[e];
             }
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const int r = li + 32 * t;
-                float x8[8];
-                if (r < a.r8) {
-                    const char* row = areg + (r >> 3) * 1024 + (r & 7) * 128;
-                    const f32x4 lo4 = *reinterpret_cast<const f32x4*>(row + ((c0 ^ (r & 7)) << 4));
-                    const f32x4 hi4 = *reinterpret_cast<const f32x4*>(row + (((c0 + 1) ^ (r & 7)) << 4));
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        x8[e] = lo4[e];
-                        x8[4 + e] = hi4[e];
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; e++) x8[e] = 0.f;
-                }
-                if (a.ln_g) {
-#pragma unroll
-                    for (int e = 0; e < 8; e++) x8[e] = (x8[e] - mean[t]) * rstd[t] * g8v[e] + b8v[e];
-                }
-                bf16x8 ahi, alo;
-                split8(x8, ahi, alo);
-                acc[t] = mfma32(alo, whi, acc[t]);
-                acc[t] = mfma32(ahi, wlo, acc[t]);
-                acc[t] = mfma32(ahi, whi, acc[t]);
-            }
+            bf16x8 ahi, alo;
+            split8(x8[t][s], ahi, alo);
+            acc[t] = mfma16(alo, whi, acc[t]);
+            acc[t] = mfma16(ahi, wlo, acc[t]);
+            acc[t] = mfma16(ahi, whi, acc[t]);
         }
-        sched_fence();  // (the fragment reads above are complete -- their values were consumed -- before the next phase's DMA lands)
-        wave_converge();
     }
-    // the wave's partial tile -> its own region (reads of the staged operands are done), [64][33] f32
-    constexpr int RP = 33;
-    float* mine = reinterpret_cast<float*>(reg);
+    float* mine = red + (size_t)wave * SK16_ROWS * RP;
 #pragma unroll
-    for (int t = 0; t < 2; t++)
+    for (int t = 0; t < 3; t++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
-            mine[row * RP + li] = acc[t][r];
-        }
+        for (int r = 0; r < 4; r++) mine[(16 * t + 4 * kq + r) * RP + li] = acc[t][r];
     __syncthreads();
-    for (int idx = tid; idx < 64 * 32; idx += NT) {  // (trip count is wave-uniform: 2048 and NT are multiples of 64)
-        const int row = idx >> 5, col = idx & 31;
+    for (int idx = tid; idx < SK16_ROWS * 16; idx += NT) {  // (wave-uniform trip count: 768 and NT are multiples of 64)
+        const int row = idx >> 4, col = idx & 15;
         const bool ok = row < rows && n0 + col < a.N;
         float v = 0.f;
         if (ok) {
 #pragma unroll
-            for (int w = 0; w < NW; w++) v += reinterpret_cast<const float*>(smem + (size_t)w * a.reg_bytes)[row * RP + col];
+            for (int w = 0; w < NW; w++) v += red[((size_t)w * SK16_ROWS + row) * RP + col];
             if (a.Z > 1) {
                 a.partial[((size_t)blockIdx.z * a.M + m0 + row) * a.N + n0 + col] = v;
             } else {
@@ -465,7 +416,7 @@ __global__ __launch_bounds__(64 * NW) void skinny_gemm_kernel(SkinnyArgs a) {
         if (a.st_out) {  // (never with Z > 1)
             float s1 = v, s2 = v * v;
 #pragma unroll
-            for (int m = 16; m >= 1; m >>= 1) {
+            for (int m = 8; m >= 1; m >>= 1) {
                 s1 += __shfl_xor(s1, m);
                 s2 += __shfl_xor(s2, m);
             }
@@ -927,9 +878,9 @@ void carve(Session& s, Carver& c, int T, int Lmax) {
     s.q2 = c.take<float>(beam * D);
     s.ff = c.take<float>(beam * (size_t)s.FF);
     s.part = c.take<float>((size_t)8 * beam * D);
-    s.stx = c.take<float>(beam * (D / 32) * 2);
-    s.st1 = c.take<float>(beam * (D / 32) * 2);
-    s.st2 = c.take<float>(beam * (D / 32) * 2);  // K slices of the FFN's second contraction (at most 8)
+    s.stx = c.take<float>(beam * (D / 16) * 2);
+    s.st1 = c.take<float>(beam * (D / 16) * 2);
+    s.st2 = c.take<float>(beam * (D / 16) * 2);  // K slices of the FFN's second contraction (at most 8)
     s.mean = c.take<float>(beam);
     s.rstd = c.take<float>(beam);
     s.logits = c.take<float>(beam * (size_t)ldv);
@@ -956,7 +907,7 @@ struct RowStats {
     int nt;
 };
 
-// C = act(LN?(A) W^T + bias) + resid for the <= beam rows of a decoding step (skinny_gemm_kernel).  ln_g == NULL: no LayerNorm;
+// C = act(LN?(A) W^T + bias) + resid for the <= beam rows of a decoding step (skinny16_kernel).  ln_g == NULL: no LayerNorm;
 // otherwise `in` holds the statistics of A's rows.  out (may be NULL): receives the statistics of C's rows.
 int skinny(const float* A, int lda, const float* W, int M, int N, int K, const float* bias, const float* ln_g, const float* ln_b, float eps,
            const RowStats* in, int act, const float* resid, int ldr, float* C, int ldc, RowStats* out, float* partial, hipStream_t stream) {
@@ -970,15 +921,11 @@ int skinny(const float* A, int lda, const float* W, int M, int N, int K, const f
         return 1;
     }
     const int nw = K / (64 * Z);
-    const int r8 = ((M < SK_ROWS ? M : SK_ROWS) + 7) / 8 * 8;
-    int reg = (32 + r8) * 128;
-    if (reg < 64 * 33 * 4) reg = 64 * 33 * 4;
-    reg = (reg + 1023) / 1024 * 1024;
-    const dim3 grid((N + 31) / 32, (M + SK_ROWS - 1) / SK_ROWS, Z);
+    const dim3 grid((N + 15) / 16, (M + SK16_ROWS - 1) / SK16_ROWS, Z);
     SkinnyArgs a{A, lda, W, K, bias, ln_g, ln_b, eps, in ? in->buf : nullptr, in ? in->nt : 0, resid, ldr, C, ldc,
-                 (out && Z == 1) ? out->buf : nullptr, M, N, K, act, Z, partial, r8, reg};
+                 (out && Z == 1) ? out->buf : nullptr, M, N, K, act, Z, partial};
     if (out) out->nt = Z == 1 ? (int)grid.x : 1;
-#define SKINNY_CASE(NW) AVSR_LAUNCH((skinny_gemm_kernel<NW>), grid, dim3(64 * NW), (size_t)NW * reg, stream, a)
+#define SKINNY_CASE(NW) AVSR_LAUNCH((skinny16_kernel<NW>), grid, dim3(64 * NW), (size_t)NW * SK16_ROWS * 17 * sizeof(float), stream, a)
     switch (nw) {
         case 1: SKINNY_CASE(1); break;
         case 2: SKINNY_CASE(2); break;

@@ -446,7 +446,7 @@ int avsr_beam_destroy(int64_t handle);
 int64_t avsr_beam_workspace_bytes(int64_t handle, int T, int Lmax);
 /* the linear layer of a decoding step on its own: C = act(LN?(A) W^T + bias) + resid for M <= 128 rows (transformer_decoder.py:84-126
  * on one position per hypothesis); st_in [M][st_in_nt][2] per-row (sum, sum of squares) partials of A when ln_g != NULL;
- * st_out [M][ceil(N/32)][2] (may be NULL) the same for the rows of C, partial count per row through st_out_nt; partial: scratch of
+ * st_out [M][ceil(N/16)][2] (may be NULL) the same for the rows of C, partial count per row through st_out_nt; partial: scratch of
  * 8 * M * N floats, used when K > 768 */
 int avsr_decode_linear(const float* A, int lda, const float* W, int M, int N, int K, const float* bias, const float* ln_g,
                        const float* ln_b, float eps, const float* st_in, int st_in_nt, int act, const float* resid, int ldr,

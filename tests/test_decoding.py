@@ -122,9 +122,9 @@ def test_native_beam_search_equals_python_step(dev, maxlenratio):
                                               (40, 50, 256, False, 0, True), (33, 128, 768, True, 0, True), (7, 128, 2048, False, 0, True),
                                               (50, 64, 128, True, 0, True), (1, 5049, 128, True, 0, False)])
 def test_decode_linear(dev, M, N, K, ln, act, res):
-    """The linear layer of a decoding step (csrc/decode.hip skinny_gemm_kernel: LDS-DMA staging, split-plane MFMAs, LayerNorm
-    from the producer's row statistics, K slices + row-sum for long contractions) against float64, and the row statistics it
-    leaves for the next LayerNorm."""
+    """The linear layer of a decoding step (csrc/decode.hip skinny16_kernel: MFMA fragments straight from global memory, split-plane
+    MFMAs, LayerNorm from the producer's row statistics, K slices + row-sum for long contractions) against float64, and the row
+    statistics it leaves for the next LayerNorm."""
     import ctypes
 
     from auto_avsr_amd import _lib, ops
@@ -135,14 +135,14 @@ def test_decode_linear(dev, M, N, K, ln, act, res):
     A, W, b = (rnd(M, K) * 2 + 0.5).to(dev), (rnd(N, K) / K ** 0.5).to(dev), rnd(N).to(dev)
     g, be, R = (torch.rand(K, generator=g0) + 0.5).to(dev), (rnd(K) * 0.1).to(dev), rnd(M, N).to(dev)
     C = torch.zeros(M, N, device=dev)
-    nt_max = (N + 31) // 32
+    nt_max = (N + 15) // 16
     st = torch.zeros(M * nt_max * 2, device=dev)
     part = torch.zeros(8 * M * N, device=dev)
     st_in = torch.stack([A.sum(1), (A * A).sum(1)], 1).contiguous()
     n = ctypes.c_int(0)
     L.call("avsr_decode_linear", A.data_ptr(), K, W.data_ptr(), M, N, K, b.data_ptr(), g.data_ptr() if ln else None,
-           be.data_ptr() if ln else None, 1e-12, st_in.data_ptr() if ln else None, 1, act, R.data_ptr() if res else None, N, C.data_ptr(), N,
-           st.data_ptr(), ctypes.cast(ctypes.pointer(n), ctypes.c_void_p), part.data_ptr(), ops._stream(A))
+           be.data_ptr() if ln else None, 1e-12, st_in.data_ptr() if ln else None, 1, act, R.data_ptr() if res else None, N,
+           C.data_ptr(), N, st.data_ptr(), ctypes.cast(ctypes.pointer(n), ctypes.c_void_p), part.data_ptr(), ops._stream(A))
     X = torch.nn.functional.layer_norm(A.double(), (K,), g.double(), be.double(), 1e-12) if ln else A.double()
     ref = X @ W.double().T + b.double()
     if act:

@@ -21,6 +21,9 @@ def main():
     from auto_avsr_amd.e2e import E2E
 
     decoding.NATIVE_BEAM = native
+    from auto_avsr_amd import ops
+
+    ops.apply_env_tuning()  # AVSR_TUNE="17=1": the LDS-staged linear-layer kernel of the decoding step
     dev = torch.device("cuda:0")
     m = E2E(5049, "video")
     m.load_state_dict(synth_state_dict(m.state_dict(), 3))
