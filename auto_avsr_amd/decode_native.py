@@ -7,8 +7,10 @@ decoder pass on the new position over cached K / V, pre-beam, CTC prefix scores,
 (`avsr_beam_step`) instead of ~120 python-issued launches.  The python loop here only looks at the 1 KB the step copies
 back (tokens, parents, scores), collects ended hypotheses and applies the end-detection rule.  Any other scorer
 configuration keeps the python step of decoding.py."""
+import contextlib
 import ctypes
 import math
+import threading
 
 import numpy as np
 import torch
@@ -89,20 +91,25 @@ class NativeBeam:
         D, H, FF = lay0.size, lay0.self_attn.h, lay0.feed_forward.w_1.out_features
         emb = dec.embed[0]
         V = dec.output_layer.out_features
-        keep = [_f32(emb.weight), pe]
-        for d in dec.decoders:
-            sa, ca, ff = d.self_attn, d.src_attn, d.feed_forward
-            keep += [_f32(d.norm1.weight), _f32(d.norm1.bias),
-                     torch.cat([_f32(sa.linear_q.weight), _f32(sa.linear_k.weight), _f32(sa.linear_v.weight)], 0).contiguous(),
-                     torch.cat([_f32(sa.linear_q.bias), _f32(sa.linear_k.bias), _f32(sa.linear_v.bias)], 0).contiguous(),
-                     _f32(sa.linear_out.weight), _f32(sa.linear_out.bias),
-                     _f32(d.norm2.weight), _f32(d.norm2.bias), _f32(ca.linear_q.weight), _f32(ca.linear_q.bias),
-                     torch.cat([_f32(ca.linear_k.weight), _f32(ca.linear_v.weight)], 0).contiguous(),
-                     torch.cat([_f32(ca.linear_k.bias), _f32(ca.linear_v.bias)], 0).contiguous(),
-                     _f32(ca.linear_out.weight), _f32(ca.linear_out.bias),
-                     _f32(d.norm3.weight), _f32(d.norm3.bias), _f32(ff.w_1.weight), _f32(ff.w_1.bias), _f32(ff.w_2.weight),
-                     _f32(ff.w_2.bias)]
-        keep += [_f32(dec.after_norm.weight), _f32(dec.after_norm.bias), _f32(dec.output_layer.weight), _f32(dec.output_layer.bias)]
+        shared = getattr(bs, "_native_weights", None)  # the stacked / f32 weight tensors: one set for all sessions of this search
+        if shared is not None and shared[0] == key:
+            keep = shared[1]
+        else:
+            keep = [_f32(emb.weight), pe]
+            for d in dec.decoders:
+                sa, ca, ff = d.self_attn, d.src_attn, d.feed_forward
+                keep += [_f32(d.norm1.weight), _f32(d.norm1.bias),
+                         torch.cat([_f32(sa.linear_q.weight), _f32(sa.linear_k.weight), _f32(sa.linear_v.weight)], 0).contiguous(),
+                         torch.cat([_f32(sa.linear_q.bias), _f32(sa.linear_k.bias), _f32(sa.linear_v.bias)], 0).contiguous(),
+                         _f32(sa.linear_out.weight), _f32(sa.linear_out.bias),
+                         _f32(d.norm2.weight), _f32(d.norm2.bias), _f32(ca.linear_q.weight), _f32(ca.linear_q.bias),
+                         torch.cat([_f32(ca.linear_k.weight), _f32(ca.linear_v.weight)], 0).contiguous(),
+                         torch.cat([_f32(ca.linear_k.bias), _f32(ca.linear_v.bias)], 0).contiguous(),
+                         _f32(ca.linear_out.weight), _f32(ca.linear_out.bias),
+                         _f32(d.norm3.weight), _f32(d.norm3.bias), _f32(ff.w_1.weight), _f32(ff.w_1.bias), _f32(ff.w_2.weight),
+                         _f32(ff.w_2.bias)]
+            keep += [_f32(dec.after_norm.weight), _f32(dec.after_norm.bias), _f32(dec.output_layer.weight), _f32(dec.output_layer.bias)]
+            bs._native_weights = (key, keep)
         assert all(t.device == keep[0].device for t in keep)
         has_len = int("length_bonus" in bs.full_scorers)
         cfg = (ctypes.c_int32 * 12)(D, H, FF, V, len(dec.decoders), bs.beam_size, bs.pre_beam_size, bs.sos, bs.eos,
@@ -123,7 +130,8 @@ class NativeBeam:
 
     # ------------------------------------------------------------------------------------------------ the search
     @torch.no_grad()
-    def search(self, x, maxlenratio=0.0, minlenratio=0.0):
+    def search(self, x, maxlenratio=0.0, minlenratio=0.0, ctc_state=None):
+        """ctc_state: (log-posteriors [T][ld], empty-prefix state [T][2]) from `prepare_ctc` when the caller computed them (search_many)."""
         from .decoding import Hypothesis
 
         bs = self.bs
@@ -137,11 +145,9 @@ class NativeBeam:
         dec, ctc = bs.full_scorers["decoder"], bs.part_scorers["ctc"]
         self._bind(dev, maxlen + 2)
         L = _lib.lib()
-        r0, _ = ctc.batch_init_state(x)  # also computes ctc.logp [T][ld]
         T = x.shape[0]
-        logp = ctc.logp
+        logp, r_init = ctc_state if ctc_state is not None else prepare_ctc(ctc, x)
         memory = _f32(x)
-        r_init = r0.reshape(T, 2).contiguous()
         nws = L.call("avsr_beam_workspace_bytes", self.handle, T, maxlen)
         ws = torch.empty(nws, dtype=torch.uint8, device=dev)
         stream = ops._stream(memory)
@@ -198,7 +204,7 @@ class NativeBeam:
                 break
         nbest = sorted(ended, key=lambda h: float(h.score), reverse=True)
         if not nbest:
-            return [] if minlenratio < 0.1 else self.search(x, maxlenratio, max(0.0, minlenratio - 0.1))
+            return [] if minlenratio < 0.1 else self.search(x, maxlenratio, max(0.0, minlenratio - 0.1), ctc_state=(logp, r_init))
         return nbest
 
     @staticmethod
@@ -210,3 +216,62 @@ class NativeBeam:
             if s is not None and s - best < D_end:
                 count += 1
         return count == M
+
+
+def prepare_ctc(ctc_scorer, x):
+    """CTC log-posteriors [T][ld] of one utterance and the state of the empty prefix [T][2] (scorers/ctc.py:87-99)."""
+    r0, _ = ctc_scorer.batch_init_state(x)
+    return ctc_scorer.logp, r0.reshape(x.shape[0], 2).contiguous()
+
+
+def search_many(bs, xs, workers=4, maxlenratio=0.0, minlenratio=0.0):
+    """Beam searches of several utterances AT ONCE: `workers` host threads, each with its own session (beam state, workspace,
+    pinned result buffer) and its own stream.  A decoding step is 52 dependent launches of 24 - 316 blocks that are bound by
+    launch / memory latency, not by the machine: steps of different utterances overlap on the GPU, and the library call
+    releases the GIL while it issues the launches and waits for the step's result.  Results are those of `bs(x)` per utterance
+    (each search is the same sequence of launches on its own state).  The CTC posteriors are computed here, on the caller's
+    thread: the kernels' python glue (functional.py mode state, weight caches) is not re-entrant."""
+    if not xs:
+        return []
+    dev = xs[0].device
+    cuda = dev.type == "cuda"
+    ctc = bs.part_scorers["ctc"]
+    pre = [prepare_ctc(ctc, x) for x in xs]
+    maxpos = max((x.shape[0] if maxlenratio == 0 else (-int(maxlenratio) if maxlenratio < 0 else max(1, int(maxlenratio * x.shape[0]))))
+                 for x in xs) + 2
+    workers = max(1, min(workers, len(xs)))
+    pool = getattr(bs, "_native_pool", None)
+    if pool is None or len(pool) < workers:
+        pool = bs._native_pool = (pool or []) + [NativeBeam(bs) for _ in range(workers - len(pool or []))]
+    for sess in pool[:workers]:
+        sess._bind(dev, maxpos)  # (on this thread: binding extends the decoder's position table)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(workers)] if cuda else [None] * workers
+    if cuda:
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream(dev))  # encoder outputs / posteriors were produced on the caller's stream
+    results, errors, it, lock = [None] * len(xs), [], iter(range(len(xs))), threading.Lock()
+
+    def work(w):
+        ctx = torch.cuda.stream(streams[w]) if cuda else contextlib.nullcontext()
+        try:
+            with ctx, torch.no_grad():
+                while True:
+                    with lock:
+                        i = next(it, None)
+                    if i is None or errors:
+                        break
+                    results[i] = pool[w].search(xs[i], maxlenratio, minlenratio, ctc_state=pre[i])
+        except BaseException as e:  # noqa: BLE001 -- re-raised on the caller's thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(w,), daemon=True) for w in range(workers)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if cuda:
+        for st in streams:
+            torch.cuda.current_stream(dev).wait_stream(st)
+    if errors:
+        raise errors[0]
+    return results

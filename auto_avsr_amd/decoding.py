@@ -285,6 +285,21 @@ class BatchBeamSearch(torch.nn.Module):
             return [] if minlenratio < 0.1 else self.forward(x, maxlenratio, max(0.0, minlenratio - 0.1))
         return nbest
 
+    def forward_many(self, xs, workers: int = 4, maxlenratio: float = 0.0, minlenratio: float = 0.0):
+        """Not in the reference: the searches of several utterances (encoder outputs (T_i, D)) run concurrently -- one host thread,
+        one stream and one session of csrc/decode.hip per worker (decode_native.search_many).  Returns [self(x) for x in xs];
+        scorer sets the library does not cover are searched one after the other by the python step."""
+        if NATIVE_BEAM and self._native is not False:
+            if self._native is None:
+                from .decode_native import NativeBeam
+
+                self._native = NativeBeam(self) if NativeBeam.supported(self) else False
+            if self._native:
+                from .decode_native import search_many
+
+                return search_many(self, list(xs), workers, maxlenratio, minlenratio)
+        return [self(x, maxlenratio, minlenratio) for x in xs]
+
     def _keep_state(self, k, st, keep):
         if st is None:
             return None

@@ -26,20 +26,47 @@ def parse_args(argv=None):
     p.add_argument("--numerics", choices=["precise", "mixed", "bf16"], default="precise",
                    help="arithmetic of the decoding forward pass: precise (split hi / lo bf16 planes -- hypotheses equal an fp32 run "
                         "of the reference; the default) or bf16 (faster on long utterances)")
+    p.add_argument("--decode-workers", type=int, default=1,
+                   help="beam searches in flight at once (host threads + streams, one decoding session each); 1 = the reference's "
+                        "one-utterance-at-a-time loop")
     return p.parse_args(argv)
 
 
-def run_test_loop(module, loader, device, log=None):
-    """Trainer.test without Lightning: the module's own hooks over the loader (lightning.py:69-84,116-123)."""
+def run_test_loop(module, loader, device, log=None, decode_workers=1):
+    """Trainer.test without Lightning: the module's own hooks over the loader (lightning.py:69-84,116-123).  decode_workers > 1:
+    utterances are taken in groups whose beam searches run concurrently (ModelModule.decode_many); same transcripts, same WER."""
     import torch
+
+    from lightning import compute_word_level_distance
 
     module.on_test_epoch_start()
     with torch.no_grad():
-        for i, sample in enumerate(loader):
-            sample = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in sample.items()}
-            module.test_step(sample, i)
-            if log is not None:
-                log(i, module.total_edit_distance, module.total_length)
+        if decode_workers <= 1:
+            for i, sample in enumerate(loader):
+                sample = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in sample.items()}
+                module.test_step(sample, i)
+                if log is not None:
+                    log(i, module.total_edit_distance, module.total_length)
+        else:
+            group, done = [], 0
+
+            def flush():
+                nonlocal done
+                for s, predicted in zip(group, module.decode_many([s["input"] for s in group], workers=decode_workers)):
+                    actual = module.text_transform.post_process(s["target"])
+                    module.total_edit_distance += compute_word_level_distance(actual, predicted)
+                    module.total_length += len(actual.split())
+                    if log is not None:
+                        log(done, module.total_edit_distance, module.total_length)
+                    done += 1
+                group.clear()
+
+            for sample in loader:
+                group.append({k: (v.to(device) if torch.is_tensor(v) else v) for k, v in sample.items()})
+                if len(group) == 4 * decode_workers:
+                    flush()
+            if group:
+                flush()
     return module.on_test_epoch_end()
 
 
@@ -76,7 +103,7 @@ def cli_main(argv=None):
             SyntheticAVDataset(len(lens), args.modality, odim=module.model.odim, seed=2, lengths=lens), batch_size=None)
     else:
         loader = datamodule.test_dataloader()
-    wer = run_test_loop(module, loader, torch.device("cuda"),
+    wer = run_test_loop(module, loader, torch.device("cuda"), decode_workers=args.decode_workers,
                         log=lambda i, d, n: logging.info(f"utt {i}: running WER {d / max(n, 1):.4f} ({d}/{n} words)"))
     print(f"WER {wer:.4f} over {module.total_length} reference words")
     return wer

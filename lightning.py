@@ -127,6 +127,21 @@ class ModelModule(_Base):
         predicted_token_id = torch.tensor(list(map(int, nbest_hyps[0]["yseq"][1:])))
         return self.text_transform.post_process(predicted_token_id).replace("<eos>", "")
 
+    def decode_many(self, samples, workers=4):
+        """Not in the reference: the transcripts of several utterances, their beam searches running concurrently (one host
+        thread + stream + decoding session per worker, BatchBeamSearch.forward_many); front-end / encoder one utterance at a
+        time as in `_decode`."""
+        encs = []
+        for sample in samples:
+            x = self.model.proj_encoder(self.model.frontend(sample.unsqueeze(0)))
+            enc_feat, _ = self.model.encoder(x, None)
+            encs.append(enc_feat.squeeze(0))
+        out = []
+        for nbest in self.beam_search.forward_many(encs, workers=workers):
+            ids = torch.tensor(list(map(int, nbest[0].asdict()["yseq"][1:])))
+            out.append(self.text_transform.post_process(ids).replace("<eos>", ""))
+        return out
+
     def forward(self, sample):
         self.beam_search = get_beam_search_decoder(self.model, self.token_list)
         return self._decode(sample)

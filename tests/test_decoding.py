@@ -184,6 +184,40 @@ def test_native_beam_search_long_ffn(dev):
         assert abs(x["score"] - y["score"]) < 1e-3 * max(1.0, abs(y["score"]))
 
 
+def test_forward_many_equals_one_at_a_time(dev):
+    """BatchBeamSearch.forward_many: five utterances of different lengths through three concurrent sessions (host threads + streams)
+    give the hypotheses of five separate calls."""
+    case = GOLD["beam"][1]
+    odim, D = case["odim"], case["D"]
+    torch.manual_seed(0)
+    dec = nets.TransformerDecoder(odim, attention_dim=D, attention_heads=2, linear_units=256, num_blocks=2).eval()
+    ctc = nets.CTC(odim, D, 0.1, reduce=True).eval()
+    dec.load_state_dict(synth_state_dict(dec.state_dict(), case["seed"]))
+    ctc.load_state_dict(synth_state_dict(ctc.state_dict(), case["seed"] + 1))
+    dec, ctc = dec.to(dev), ctc.to(dev)
+    g = torch.Generator().manual_seed(77)
+    xs = [(torch.randn(T, D, generator=g) * 1.5).to(dev) for T in (9, 17, 12, 23, 15)]
+    scorers = {"decoder": dec, "ctc": CTCPrefixScorer(ctc, odim - 1), "lm": None, "length_bonus": LengthBonus(odim)}
+    weights = {"decoder": 0.7, "ctc": 0.3, "lm": 0.0, "length_bonus": 0.5}
+    bs = BatchBeamSearch(beam_size=6, vocab_size=odim, weights=weights, scorers=scorers, sos=odim - 1, eos=odim - 1,
+                         token_list=None, pre_beam_score_key="decoder")
+    AF.set_precise(True)
+    try:
+        many = bs.forward_many(xs, workers=3)
+        assert bs._native and len(bs._native_pool) == 3
+        single = [bs(x) for x in xs]
+    finally:
+        AF.set_precise(False)
+    assert len(many) == len(single) == 5
+    for a, b in zip(many, single):
+        assert len(a) == len(b) and len(a) >= 1
+        for x, y in zip(a, b):
+            x, y = x.asdict(), y.asdict()
+            if y["score"] < -1e8:
+                continue
+            assert x["yseq"] == y["yseq"] and abs(x["score"] - y["score"]) < 1e-4 * max(1.0, abs(y["score"]))
+
+
 def test_native_beam_refuses_what_it_cannot_score(dev):
     """Scorer sets outside the reference's wiring stay on the python step: a vocabulary smaller than the pre-beam (no pre-beam,
     beam_search.py:85-90) and a foreign full scorer."""

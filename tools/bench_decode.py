@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--beam", type=int, default=40)
+    ap.add_argument("--many", type=int, default=16, help="utterances of the concurrent-decoding rows (BatchBeamSearch.forward_many)")
     args = ap.parse_args()
     import lightning
     from synth import synth_batch, synth_state_dict
@@ -65,6 +66,33 @@ def main():
                          "longest_hypothesis_tokens": steps, "ms_per_token": round(dec_ms / max(steps, 1), 3),
                          "utterances_per_sec": round(1e3 / (enc_ms + dec_ms), 3)})
             rows[-1]["best_yseq_head"] = nbest[0].asdict()["yseq"][:12] if nbest else []
+            print(json.dumps(rows[-1]), file=sys.stderr, flush=True)
+    # several utterances in flight: forward_many with 1, 2, 4, 8 workers over `--many` utterances of T = 100 (encoder outputs ready)
+    AF.set_mode("mixed")
+    AF.invalidate_weight_cache()
+    decoding.NATIVE_BEAM = True
+    bs._native = None
+    encs = []
+    with torch.no_grad():
+        for i in range(args.many):
+            x, _, _ = synth_batch("video", 1, 100, 3, 5049, seed=1000 + i, lengths=[100])
+            feats = m.proj_encoder(m.frontend(x.to(dev)))
+            encs.append(m.encoder(feats, None)[0].squeeze(0).float())
+        ref = None
+        for workers in (1, 2, 4, 8):
+            best = None
+            for rep in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                res = bs.forward_many(encs, workers=workers)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                best = dt if best is None or dt < best else best
+            ys = [r[0].asdict()["yseq"] for r in res]
+            ref = ys if ref is None else ref
+            rows.append({"mode": "mixed", "step": f"native, {workers} searches in flight (forward_many)", "T_frames": 100, "beam": args.beam,
+                         "utterances": args.many, "beam_search_ms_total": round(best * 1e3, 1),
+                         "utterances_per_sec_search_only": round(args.many / best, 2), "same_best_hypotheses_as_1_worker": ys == ref})
             print(json.dumps(rows[-1]), file=sys.stderr, flush=True)
     AF.set_mode("bf16")
     decoding.NATIVE_BEAM = True
