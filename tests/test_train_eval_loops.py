@@ -117,10 +117,14 @@ def test_eval_wer_loop(dev):
         loader = torch.utils.data.DataLoader(ds, batch_size=None)
         seen = []
         wer = EV.run_test_loop(mod, loader, dev, log=lambda i, d, n: seen.append((i, d, n)))
+        # --decode-workers 2: the same utterances with two beam searches in flight -> the same running totals
+        seen2 = []
+        wer2 = EV.run_test_loop(mod, loader, dev, log=lambda i, d, n: seen2.append((i, d, n)), decode_workers=2)
     finally:
         LM.TextTransform = LM_TextTransform
     assert len(seen) == 3 and seen[-1][2] == mod.total_length == sum(max(1, round(t / 6.5)) for t in (6, 8, 7))
     assert 0.0 <= wer and wer == mod.total_edit_distance / mod.total_length
+    assert seen2 == seen and wer2 == wer
     assert LM.compute_word_level_distance("a b c", "a x c d") == 2
 
 
