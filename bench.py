@@ -97,7 +97,7 @@ def supervise(args):
     base_port = int(os.environ.get("MASTER_PORT", "29500"))
     want = os.environ.get("AVSR_DDP") or args.ddp
     chain = DDP_CHAIN if want == "auto" else [want]
-    limits = [float(x) for x in os.environ.get("AVSR_BENCH_ATTEMPT_TIMEOUT", "600,420,420").split(",")]
+    limits = [float(x) for x in os.environ.get("AVSR_BENCH_ATTEMPT_TIMEOUT", "420,300,300").split(",")]
     argv = [a for a in sys.argv[1:] if a != "--worker"]
     live = []
 
