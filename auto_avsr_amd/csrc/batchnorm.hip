@@ -888,6 +888,64 @@ extern "C" int avsr_bn_stats_finalize(const void* x, int dtype, float* workspace
     return 0;
 }
 
+// Statistics left behind by a producer's epilogue (avsr_conv2d_f32s_stats): part [ntiles][2][C] UNSHIFTED column sums / sums of
+// squares of 128-row tiles.  First 256 blocks fold the tiles into ws [256][2][C] (block j: tiles j, j + 256, ...; plain stores),
+// then the shared finalize kernels run on those 256 partials with a zero shift row (zeros: >= C zero floats).
+// _finalize_parts: single rank, (mean, invstd) + running statistics; _stats_parts: the [3][C] (+ count) payload of the
+// cross-rank merge (avsr_bn_finalize).
+constexpr int BN_PART_SLOTS = 256;
+__global__ __launch_bounds__(256) void bn_parts_fold_kernel(const float* __restrict__ part, int ntiles, int C2, float* __restrict__ ws) {
+    __shared__ float red[256];
+    const int lanes_per = 256 / C2 > 0 ? 256 / C2 : 1;  // row lanes when 2 C < 256
+    const int col = threadIdx.x % C2, rl = threadIdx.x / C2;
+    for (int c0 = 0; c0 < C2; c0 += 256) {  // (2 C <= 256: one trip)
+        const int c = c0 + col;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c < C2 && rl < lanes_per) {
+            int t = blockIdx.x + BN_PART_SLOTS * rl;
+            const int step = BN_PART_SLOTS * lanes_per;
+            for (; t + 3 * step < ntiles; t += 4 * step) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = part[(size_t)(t + u * step) * C2 + c];
+#pragma unroll
+                for (int u = 0; u < 4; u++) a[u] += v[u];
+            }
+            for (; t < ntiles; t += step) a[0] += part[(size_t)t * C2 + c];
+        }
+        red[threadIdx.x] = (a[0] + a[1]) + (a[2] + a[3]);
+        __syncthreads();
+        if (rl == 0 && c < C2) {
+            float v = 0.f;
+            for (int q = 0; q < lanes_per; q++) v += red[q * C2 + col];
+            ws[(size_t)blockIdx.x * C2 + c] = v;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int avsr_bn_finalize_parts(const float* part, int ntiles, int C, const float* zeros, float* ws, int64_t rows, float eps,
+                                      float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
+                                      int64_t* num_batches_tracked, hipStream_t stream) {
+    AVSR_REQUIRE(ntiles >= 1 && C >= 1 && rows >= 1 && zeros != nullptr && ws != nullptr, "bn_finalize_parts: bad arguments");
+    AVSR_LAUNCH(bn_parts_fold_kernel, dim3(BN_PART_SLOTS), dim3(256), 0, stream, part, ntiles, 2 * C, ws);
+    dim3 g2((C + 15) / 16);
+    AVSR_LAUNCH((bn_partial_finalize_kernel<float>), g2, dim3(256), 0, stream, (const float*)ws, BN_PART_SLOTS, C, zeros, (float)rows, eps,
+                momentum, mean, invstd, running_mean, running_var, num_batches_tracked);
+    AVSR_CHECK_LAUNCH("bn_finalize_parts");
+    return 0;
+}
+extern "C" int avsr_bn_stats_parts(const float* part, int ntiles, int C, const float* zeros, float* ws, float* stats, float* count_out,
+                                   int64_t rows, hipStream_t stream) {
+    AVSR_REQUIRE(ntiles >= 1 && C >= 1 && rows >= 1 && zeros != nullptr && ws != nullptr, "bn_stats_parts: bad arguments");
+    AVSR_LAUNCH(bn_parts_fold_kernel, dim3(BN_PART_SLOTS), dim3(256), 0, stream, part, ntiles, 2 * C, ws);
+    dim3 g2((2 * C + 15) / 16);
+    AVSR_LAUNCH((bn_partial_sum_kernel<float>), g2, dim3(256), 0, stream, (const float*)ws, BN_PART_SLOTS, C, stats, 1, zeros, count_out,
+                (float)rows);
+    AVSR_CHECK_LAUNCH("bn_stats_parts");
+    return 0;
+}
+
 extern "C" int avsr_bn_finalize(const float* stats, const float* counts, int world, int C, int64_t stats_stride,
                                 int64_t counts_stride, float eps, float momentum, float* mean, float* invstd,
                                 float* running_mean, float* running_var, int64_t* num_batches_tracked,

@@ -70,6 +70,11 @@ struct Params {
     // gradient is split into (row grid cls_h x cls_w starting at pixel (cls_y0, cls_x0) with step cS; taps
     // kh = cls_py + cS*i, kw = cls_px + cS*j; m-tiles [cls_tile0[c], cls_tile0[c+1]))
     float* colsum;  // LDS epilogue, non-accumulating outputs: colsum[n] += sum_m of the stored value (bias gradients)
+    // LDS epilogue, non-accumulating outputs: BatchNorm statistics of the stored values without a pass over them --
+    // colstat [M tiles][2][N] (need not be initialised): row (m0 / BM) receives the tile's column sums and sums of squares by plain
+    // stores (a first version accumulated into 64 slots with float atomics: 774 k L2 atomics per first-stage convolution cost
+    // what the removed statistics pass had cost)
+    float* colstat;
     float* colsum_a;  // TN tile kernel only: colsum_a[m] += sum_k A[k][m] -- the bias gradient of the Linear whose weight
                       // gradient this contraction is (A = its output gradient), taken from the staged A tiles
     int cN, xcd_order, ncls;
@@ -222,9 +227,9 @@ AVSR_DEV void epilogue_lds(f32x16 (&acc)[TM][TN], const Params& p, int m0, int n
     }
     constexpr int CPR = BN / 8;  // chunks per row
     static_assert(NTHR % CPR == 0 && 64 % CPR == 0, "a thread keeps one column chunk for all of its rows");
-    float cs[8];  // this thread's share of the column sums (its chunk, its rows)
+    float cs[8], cq[8];  // this thread's share of the column sums / sums of squares (its chunk, its rows)
 #pragma unroll
-    for (int e = 0; e < 8; e++) cs[e] = 0.f;
+    for (int e = 0; e < 8; e++) cs[e] = cq[e] = 0.f;
     for (int id = threadIdx.x; id < BM * CPR; id += NTHR) {
         const int r = id / CPR, c = (id % CPR) * 8;
         const int row = rowmap ? rowmap[r] : m0 + r, col = n0 + c;
@@ -294,9 +299,13 @@ AVSR_DEV void epilogue_lds(f32x16 (&acc)[TM][TN], const Params& p, int m0, int n
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] += rr[e];
         }
-        if (p.colsum) {
+        if (p.colsum || p.colstat) {
 #pragma unroll
             for (int e = 0; e < 8; e++) cs[e] += e < nv ? v[e] : 0.f;
+        }
+        if (p.colstat) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) cq[e] += e < nv ? v[e] * v[e] : 0.f;
         }
         const size_t co = c_off + (size_t)row * p.ldc + col;
         if (p.C2) {
@@ -332,17 +341,44 @@ AVSR_DEV void epilogue_lds(f32x16 (&acc)[TM][TN], const Params& p, int m0, int n
             }
         }
     }
-    if (p.colsum) {
+    if (p.colsum || p.colstat) {
         // lanes l, l + CPR, l + 2 CPR, ... of a wave hold the same column chunk: butterfly over those lane bits, then one
         // atomic per column from lanes 0 .. CPR-1 (a Linear's bias gradient without a second pass over its output gradient)
 #pragma unroll
         for (int m = 32; m >= CPR; m >>= 1)
 #pragma unroll
             for (int e = 0; e < 8; e++) cs[e] += __shfl_xor(cs[e], m);
-        if (lane < CPR)
+        if (p.colsum && lane < CPR)
 #pragma unroll
             for (int e = 0; e < 8; e++)
                 if (n0 + lane * 8 + e < p.N) atomicAdd(p.colsum + n0 + lane * 8 + e, cs[e]);
+    }
+    if (p.colstat) {
+#pragma unroll
+        for (int m = 32; m >= CPR; m >>= 1)
+#pragma unroll
+            for (int e = 0; e < 8; e++) cq[e] += __shfl_xor(cq[e], m);
+        // the NTHR / 64 waves of the block hold different rows of the same column chunks: meet in LDS (the tile image is dead by now)
+        __syncthreads();
+        float* meet = tile;  // [NTHR / 64][2][BN]
+        const int wv = threadIdx.x >> 6;
+        if (lane < CPR)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                meet[(wv * 2 + 0) * BN + lane * 8 + e] = cs[e];
+                meet[(wv * 2 + 1) * BN + lane * 8 + e] = cq[e];
+            }
+        __syncthreads();
+        float* row = p.colstat + (size_t)(m0 / BM) * 2 * p.N;
+        for (int i = threadIdx.x; i < 2 * BN; i += NTHR) {
+            const int j = i / BN, c = i - j * BN;
+            if (n0 + c < p.N) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < NTHR / 64; w++) v += meet[(w * 2 + j) * BN + c];
+                row[(size_t)j * p.N + n0 + c] = v;
+            }
+        }
     }
 }
 

@@ -381,14 +381,15 @@ extern "C" int avsr_gemm_f32s_nt(const float* A, int lda, const float* B, int ld
 
 // f32 implicit-GEMM convolution forward on split hi / lo bf16 planes: x[N,H,W,Cin] * wp[Cout][KH][KW][Cin] -> y[N,OH,OW,Cout]
 // (all f32, channels-last; Cin % 64 == 0; zero_page: >= 16 zero bytes in device memory)
-extern "C" int avsr_conv2d_f32s(const float* x, const float* wp, float* y, const void* zero_page, int N, int H, int W, int Cin,
-                                int Cout, int KH, int KW, int stride, int pad_h, int pad_w, int tile, int w_split, void* y2,
-                                hipStream_t stream) {
+static int conv2d_f32s_impl(const float* x, const float* wp, float* y, const void* zero_page, int N, int H, int W, int Cin, int Cout, int KH,
+                            int KW, int stride, int pad_h, int pad_w, int tile, int w_split, void* y2, float* stats_part, int stats_tiles,
+                            hipStream_t stream) {
     const int OH = (H + 2 * pad_h - KH) / stride + 1, OW = (W + 2 * pad_w - KW) / stride + 1;
     AVSR_REQUIRE(Cin % 64 == 0, "conv2d_f32s: input channel count must be a multiple of 64");
     AVSR_REQUIRE(zero_page != nullptr, "conv2d_f32s: zero page required");
     AVSR_REQUIRE(KH * KW <= 32, "conv2d_f32s: at most 32 filter taps");
     AVSR_REQUIRE((long)N * H * W < (1l << 31) && (long)N * OH * OW < (1l << 31), "conv2d_f32s: pixel count exceeds int32");
+    AVSR_REQUIRE(stats_part == nullptr || (long)stats_tiles * 128 >= (long)N * OH * OW, "conv2d_f32s: statistics buffer too small");
     if (N <= 0) return 0;
     Params p{};
     p.A = x; p.B = wp;
@@ -402,11 +403,30 @@ extern "C" int avsr_conv2d_f32s(const float* x, const float* wp, float* y, const
     p.cKH = KH; p.cKW = KW; p.cS = stride; p.cPH = pad_h; p.cPW = pad_w; p.cC = Cin;
     p.M = N * OH * OW; p.N = Cout; p.ldc = Cout;
     p.cH = H; p.cW = W; p.cOH = OH; p.cOW = OW;
+    p.colstat = stats_part;
     if (tile == 0) tile = Cout >= 128 ? 14 : 13;
+    AVSR_REQUIRE(stats_part == nullptr || tile == 13 || tile == 14, "conv2d_f32s: statistics need a 128-row tile");
     const bool ok = w_split ? launch_tile<1, true>(tile, p, 1, stream) : launch_tile<1, false>(tile, p, 1, stream);
     AVSR_REQUIRE(ok, "conv2d_f32s: unknown tile code");
     AVSR_CHECK_LAUNCH("conv2d_f32s");
     return 0;
+}
+
+extern "C" int avsr_conv2d_f32s(const float* x, const float* wp, float* y, const void* zero_page, int N, int H, int W, int Cin,
+                                int Cout, int KH, int KW, int stride, int pad_h, int pad_w, int tile, int w_split, void* y2,
+                                hipStream_t stream) {
+    return conv2d_f32s_impl(x, wp, y, zero_page, N, H, W, Cin, Cout, KH, KW, stride, pad_h, pad_w, tile, w_split, y2, nullptr, 0, stream);
+}
+
+// the same convolution leaving the BatchNorm statistics of its output behind: row t of stats_part [stats_tiles >= ceil(rows / 128)]
+// [2][Cout] = per-column sums / sums of squares of the stored f32 values of output rows [128 t, 128 t + 128), from the epilogue
+// (frontend/resnet.py:82-98: every trunk convolution feeds a BatchNorm in batch-statistics mode); finish with
+// avsr_bn_finalize_parts / avsr_bn_stats_parts
+extern "C" int avsr_conv2d_f32s_stats(const float* x, const float* wp, float* y, const void* zero_page, int N, int H, int W, int Cin,
+                                      int Cout, int KH, int KW, int stride, int pad_h, int pad_w, int tile, int w_split, void* y2,
+                                      float* stats_part, int stats_tiles, hipStream_t stream) {
+    AVSR_REQUIRE(stats_part != nullptr, "conv2d_f32s_stats: statistics buffer required");
+    return conv2d_f32s_impl(x, wp, y, zero_page, N, H, W, Cin, Cout, KH, KW, stride, pad_h, pad_w, tile, w_split, y2, stats_part, stats_tiles, stream);
 }
 
 // dst (split8 layout, n * 4 bytes) <- src (f32, n elements, n % 8 == 0): every group of 8 consecutive elements becomes its

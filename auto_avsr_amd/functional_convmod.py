@@ -29,9 +29,10 @@ def _const1(value, device):
     return t
 
 
-def _bn_train_stats(c2, rows, C, eps, momentum, running_mean, running_var, nbt=None):
+def _bn_train_stats(c2, rows, C, eps, momentum, running_mean, running_var, nbt=None, parts=None):
     """Batch statistics (+ running-stat update, + num_batches_tracked count) of a [rows, C] activation; merged across
-    ranks when set_bn_sync()."""
+    ranks when set_bn_sync().  parts: the partial statistics the producing convolution's epilogue left behind
+    (ops.conv2d_fwd(stats=...)) -- no pass over c2 then."""
     group = _state["bn_sync"]
     if group is not None:
         import torch.distributed as dist
@@ -41,7 +42,7 @@ def _bn_train_stats(c2, rows, C, eps, momentum, running_mean, running_var, nbt=N
         # leaves the global row count on the device for the backward pass -- no glue launches around the collective
         comm = _state.get("bn_comm")
         W = comm.world if comm is not None else dist.get_world_size(group)
-        mine = ops.bn_stats(c2, rows, C, with_count=True)
+        mine = ops.bn_stats_parts(parts, rows, C) if parts is not None else ops.bn_stats(c2, rows, C, with_count=True)
         flat = torch.empty(W * mine.numel(), dtype=torch.float32, device=c2.device)
         if comm is not None:
             comm.all_gather(flat, mine)
@@ -51,7 +52,10 @@ def _bn_train_stats(c2, rows, C, eps, momentum, running_mean, running_var, nbt=N
         mean, invstd = ops.bn_finalize(flat, flat.data_ptr() + 12 * C, W, C, eps, momentum, running_mean, running_var,
                                        nbt, stats_stride=3 * C + 1, counts_stride=3 * C + 1, n_total=n_total)
         return mean, invstd, n_total
-    mean, invstd = ops.bn_stats_finalize(c2, rows, C, eps, momentum, running_mean, running_var, nbt)
+    if parts is not None:
+        mean, invstd = ops.bn_finalize_parts(parts, rows, C, eps, momentum, running_mean, running_var, nbt)
+    else:
+        mean, invstd = ops.bn_stats_finalize(c2, rows, C, eps, momentum, running_mean, running_var, nbt)
     return mean, invstd, None
 
 

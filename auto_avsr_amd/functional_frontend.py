@@ -1,6 +1,8 @@
 """Autograd glue of the front-ends (split out of functional.py in round 4): BasicBlockFn (ResNet block), StemFn (Conv3d /
 Conv1d stem + BatchNorm + SiLU (+ max-pool)), AvgPoolFn.  Re-exported by functional.py."""
 
+import os
+
 import torch
 
 from . import functional as AF
@@ -13,13 +15,28 @@ from .functional_convmod import (  # noqa: F401
 
 
 # ================================================================================================ front-ends
-def _bn_fwd_params(c2, rows, C, bn, training):
+def _bn_fwd_params(c2, rows, C, bn, training, parts=None):
     """(mean, invstd, counts) of a BatchNorm over the rows of c2; bn = (weight, bias, running_mean, running_var,
-    eps, momentum).  Training: batch statistics (cross-rank when set_bn_sync) + running-stat update."""
+    eps, momentum).  Training: batch statistics (cross-rank when set_bn_sync) + running-stat update; parts: partial statistics
+    from the producing convolution's epilogue (_conv_bn_stats)."""
     if training:
-        return _bn_train_stats(c2, rows, C, bn[4], bn[5], bn[2], bn[3], bn[6] if len(bn) > 6 else None)
+        return _bn_train_stats(c2, rows, C, bn[4], bn[5], bn[2], bn[3], bn[6] if len(bn) > 6 else None, parts=parts)
     mean, invstd = ops.bn_eval_params(bn[2], bn[3], bn[4])
     return mean, invstd, None
+
+
+# A/B switch: 0 keeps the stand-alone statistics pass over every convolution output
+_FUSE_BN_STATS = os.environ.get("AVSR_FUSE_BN_STATS", "1") != "0"
+
+
+def _conv_bn_stats(x, wp, Cin, Cout, KH, KW, rows, training):
+    """Mixed mode, split-plane components: a partial-statistics buffer for ops.conv2d_fwd(stats=...) -- the convolution's epilogue
+    leaves per-column sums / sums of squares of every 128-row output tile, and the BatchNorm that follows is finished from those
+    (one 44 us pass over a 200 MB f32 activation less per BatchNorm).  None: the convolution runs on a kernel without that
+    epilogue, or the mode asks for the shifted two-level statistics of the stand-alone pass (precise / hpf parity at 1e-5)."""
+    if not (training and _FUSE_BN_STATS and _state["mixed"] and ops.conv2d_takes_stats(x, wp, Cin, KH, KW, _state["precise"])):
+        return None
+    return torch.empty(ops.bn_stat_tiles(rows), 2, Cout, dtype=torch.float32, device=x.device)
 
 
 def _bn_bwd(c, dy, add, mean, invstd, bn, counts, rows, C, act, want_dadd, training):
@@ -61,16 +78,22 @@ class BasicBlockFn(torch.autograd.Function):
         rows = N * OH * OW
         bn1 = (g1, b1) + bn1
         bn2 = (g2, b2) + bn2
-        c1 = ops.conv2d_fwd(x, _w_conv_fwd(w1, x), N, H, W, Cin, Cout, KH, KW, stride, ph, pw, pr)
-        m1, i1, n1 = _bn_fwd_params(c1, rows, Cout, bn1, training)
+        wp1 = _w_conv_fwd(w1, x)
+        st1 = _conv_bn_stats(x, wp1, Cin, Cout, KH, KW, rows, training)
+        c1 = ops.conv2d_fwd(x, wp1, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, pr, stats=st1)
+        m1, i1, n1 = _bn_fwd_params(c1, rows, Cout, bn1, training, parts=st1)
         a1 = ops.bn_act_fwd(c1, None, m1, i1, g1, b1, rows, Cout, 1)
-        c2 = ops.conv2d_fwd(a1, _w_conv_fwd(w2, a1), N, OH, OW, Cout, Cout, KH, KW, 1, ph, pw, pr)
-        m2, i2, n2 = _bn_fwd_params(c2, rows, Cout, bn2, training)
+        wp2 = _w_conv_fwd(w2, a1)
+        st2 = _conv_bn_stats(a1, wp2, Cout, Cout, KH, KW, rows, training)
+        c2 = ops.conv2d_fwd(a1, wp2, N, OH, OW, Cout, Cout, KH, KW, 1, ph, pw, pr, stats=st2)
+        m2, i2, n2 = _bn_fwd_params(c2, rows, Cout, bn2, training, parts=st2)
         cd = md = idd = nd = None
         if wd is not None:
             bnd = (gd, bd) + bnd
-            cd = ops.conv2d_fwd(x, _w_conv_fwd(wd, x), N, H, W, Cin, Cout, 1, 1, stride, 0, 0, pr)
-            md, idd, nd = _bn_fwd_params(cd, rows, Cout, bnd, training)
+            wpd = _w_conv_fwd(wd, x)
+            std = _conv_bn_stats(x, wpd, Cin, Cout, 1, 1, rows, training)
+            cd = ops.conv2d_fwd(x, wpd, N, H, W, Cin, Cout, 1, 1, stride, 0, 0, pr, stats=std)
+            md, idd, nd = _bn_fwd_params(cd, rows, Cout, bnd, training, parts=std)
             r = ops.bn_act_fwd(cd, None, md, idd, gd, bd, rows, Cout, 0)
         else:
             r = x

@@ -334,6 +334,25 @@ def bn_stats_finalize(x, rows, C, eps, momentum, running_mean, running_var, num_
     return mean, invstd
 
 
+def bn_finalize_parts(part, rows, C, eps, momentum, running_mean, running_var, num_batches_tracked=None):
+    """(mean, invstd) + running-stat update from the partial statistics a convolution epilogue left (conv2d_fwd(stats=part))."""
+    mean = torch.empty(C, dtype=torch.float32, device=part.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=part.device)
+    ws = torch.empty(512 * C, dtype=torch.float32, device=part.device)
+    call("avsr_bn_finalize_parts", _ptr(part), part.shape[0], C, _ptr(zero_page(part.device)), _ptr(ws), rows, eps, momentum, _ptr(mean),
+         _ptr(invstd), _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _stream(part), nbytes=_nb(part))
+    return mean, invstd
+
+
+def bn_stats_parts(part, rows, C):
+    """The flat [3 * C + 1] payload {shift = 0, sums, sums of squares, row count} of the cross-rank merge from partial statistics."""
+    flat = torch.empty(3 * C + 1, dtype=torch.float32, device=part.device)
+    ws = torch.empty(512 * C, dtype=torch.float32, device=part.device)
+    call("avsr_bn_stats_parts", _ptr(part), part.shape[0], C, _ptr(zero_page(part.device)), _ptr(ws), _ptr(flat),
+         flat.data_ptr() + 12 * C, rows, _stream(part), nbytes=_nb(part))
+    return flat
+
+
 BN_SMALL_MAX_ROWS = 2048  # avsr_bn_small_max_rows()
 
 
@@ -590,7 +609,7 @@ _zero_pages = {}
 def zero_page(device):
     z = _zero_pages.get(device)
     if z is None:
-        z = _zero_pages[device] = torch.zeros(64, dtype=torch.float32, device=device)
+        z = _zero_pages[device] = torch.zeros(1024, dtype=torch.float32, device=device)  # (>= the widest BatchNorm: its zero shift row)
     return z
 
 
@@ -607,9 +626,22 @@ def tune(knob, value):
     call("avsr_tune", int(knob), int(value))
 
 
-def conv2d_fwd(x, wp, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise):
+def bn_stat_tiles(rows):
+    """Rows of the partial-statistics buffer of avsr_conv2d_f32s_stats: one per 128-row output tile."""
+    return (rows + 127) // 128
+
+
+def conv2d_takes_stats(x, wp, Cin, KH, KW, precise):
+    """Will conv2d_fwd run on the split-plane kernel, whose epilogue can leave the BatchNorm statistics of the output behind?"""
+    return bool(precise and SPLIT_FAST and x.dtype == torch.float32 and wp.dtype == torch.float32 and Cin % 64 == 0 and KH * KW <= 32)
+
+
+def conv2d_fwd(x, wp, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise, stats=None):
+    """stats (conv2d_takes_stats only): [bn_stat_tiles(rows)][2][Cout] f32 (uninitialised) -- receives per 128-row tile the
+    per-column sums / sums of squares of y."""
     OH, OW = conv_out(H, KH, stride, ph), conv_out(W, KW, stride, pw)
     y = torch.empty(N, OH, OW, Cout, dtype=x.dtype, device=x.device)
+    assert stats is None or conv2d_takes_stats(x, wp, Cin, KH, KW, precise)
     if not precise and x.dtype == torch.bfloat16 and wp.dtype == torch.bfloat16 and Cin % 64 == 0 and stride <= 2:
         call("avsr_conv2d_bf16", 0, _ptr(x), _ptr(wp), None, _ptr(y), _ptr(zero_page(x.device)), N, H, W, Cin, Cout, KH,
              KW, stride, ph, pw, _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin,
@@ -621,6 +653,11 @@ def conv2d_fwd(x, wp, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise):
              stride, ph, pw, _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin, nbytes=_nb(x, wp) + 4.0 * N * OH * OW * Cout)
         return y
     if precise and SPLIT_FAST and x.dtype == torch.float32 and wp.dtype == torch.float32 and Cin % 64 == 0 and KH * KW <= 32:
+        if stats is not None:
+            call("avsr_conv2d_f32s_stats", _ptr(x), _ptr(wp), _ptr(y), _ptr(zero_page(x.device)), N, H, W, Cin, Cout, KH, KW, stride,
+                 ph, pw, 0, int(isinstance(wp, Split8)), _ptr(_twin(y)), _ptr(stats), stats.shape[0], _stream(x),
+                 flops=2.0 * N * OH * OW * Cout * KH * KW * Cin, nbytes=_nb(x, wp, y))
+            return y
         call("avsr_conv2d_f32s", _ptr(x), _ptr(wp), _ptr(y), _ptr(zero_page(x.device)), N, H, W, Cin, Cout, KH, KW, stride,
              ph, pw, 0, int(isinstance(wp, Split8)), _ptr(_twin(y)), _stream(x),
              flops=2.0 * N * OH * OW * Cout * KH * KW * Cin, nbytes=_nb(x, wp, y))

@@ -332,6 +332,19 @@ int avsr_multi_split_pack(const void* table, int n, int total_blocks, avsr_strea
 int avsr_conv2d_f32s(const float* x, const float* wp, float* y, const void* zero_page, int N, int H, int W, int Cin, int Cout,
                      int KH, int KW, int stride, int pad_h, int pad_w, int tile, int w_split /* 1: wp in the split8 layout */,
                      void* y2 /* may be NULL: bf16 twin of y */, avsr_stream_t stream);
+/* the same convolution leaving the BatchNorm statistics of its output behind (frontend/resnet.py:82-98: every trunk convolution
+ * feeds a BatchNorm in batch-statistics mode): row t of stats_part [stats_tiles >= ceil(rows / 128)][2][Cout] (need not be
+ * initialised) = column sums / sums of squares of the stored values of output rows [128 t, 128 t + 128), from the epilogue -- no
+ * statistics pass over y; finish with avsr_bn_finalize_parts (one rank) or avsr_bn_stats_parts + avsr_bn_finalize (cross-rank);
+ * ws: 512 * C floats of scratch, zeros: >= C zero floats */
+int avsr_conv2d_f32s_stats(const float* x, const float* wp, float* y, const void* zero_page, int N, int H, int W, int Cin,
+                           int Cout, int KH, int KW, int stride, int pad_h, int pad_w, int tile, int w_split, void* y2,
+                           float* stats_part, int stats_tiles, avsr_stream_t stream);
+int avsr_bn_finalize_parts(const float* part, int ntiles, int C, const float* zeros, float* ws, int64_t rows, float eps, float momentum,
+                           float* mean, float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                           avsr_stream_t stream);
+int avsr_bn_stats_parts(const float* part, int ntiles, int C, const float* zeros, float* ws, float* stats, float* count_out, int64_t rows,
+                        avsr_stream_t stream);
 /* ---- collectives of the data-parallel step straight on RCCL (csrc/comm.hip; RCCL is bound with dlopen at the first call).
  * Replaces, for graph-captured steps, the torch.distributed calls of train.py:30-42 (DDP gradient all-reduce, SyncBatchNorm
  * statistics) and lightning.py:88-90 (batch-size all-gather): every call is ONE stream operation on `stream`, nothing else.

@@ -190,6 +190,37 @@ def test_conv2d_h16(dev, geom, twins):
     assert yy is y and rel(tw.float(), ref) < 4e-3
 
 
+@pytest.mark.parametrize("geom", [(3, 11, 11, 64, 128, 3, 2), (5, 22, 22, 64, 64, 3, 1), (3, 11, 11, 64, 128, 1, 2)])
+def test_conv_epilogue_leaves_batchnorm_statistics(dev, geom):
+    """avsr_conv2d_f32s_stats: the split-plane convolution's epilogue leaves per-column sums / sums of squares of every 128-row
+    tile of its output; avsr_bn_finalize_parts turns them into (mean, invstd) + running statistics, avsr_bn_stats_parts into the
+    cross-rank payload -- against the stand-alone statistics pass over the same output and torch's batch_norm."""
+    N, H, W, Cin, Cout, KH, stride = geom
+    pad = (KH - 1) // 2
+    torch.manual_seed(N * H)
+    x = (torch.randn(N, H, W, Cin) + 0.3).to(dev)
+    w = (0.1 * torch.randn(Cout, Cin, KH, KH)).to(dev)
+    wp = ops.conv_weight_permute(w, torch.float32)
+    OH = (H + 2 * pad - KH) // stride + 1
+    part = torch.full((ops.bn_stat_tiles(N * OH * OH), 2, Cout), float("nan"), device=dev)  # (every row must be written)
+    assert ops.conv2d_takes_stats(x, wp, Cin, KH, KH, True)
+    y = ops.conv2d_fwd(x, wp, N, H, W, Cin, Cout, KH, KH, stride, pad, pad, True, stats=part)
+    y0 = ops.conv2d_fwd(x, wp, N, H, W, Cin, Cout, KH, KH, stride, pad, pad, True)
+    assert torch.equal(y, y0)
+    rows = y.numel() // Cout
+    y2 = y.view(rows, Cout).double()
+    assert rel(part[:, 0].sum(0).double(), y2.sum(0)) < 1e-5 and rel(part[:, 1].sum(0).double(), (y2 * y2).sum(0)) < 1e-5
+    rm, rv = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+    rm0, rv0 = rm.clone(), rv.clone()
+    nbt = torch.zeros((), dtype=torch.int64, device=dev)
+    mean, invstd = ops.bn_finalize_parts(part, rows, Cout, 1e-5, 0.1, rm, rv, nbt)
+    mean0, invstd0 = ops.bn_stats_finalize(y.view(rows, Cout), rows, Cout, 1e-5, 0.1, rm0, rv0)
+    assert rel(mean, mean0) < 1e-5 and rel(invstd, invstd0) < 1e-5 and rel(rm, rm0) < 1e-5 and rel(rv, rv0) < 1e-5 and int(nbt) == 1
+    flat = ops.bn_stats_parts(part, rows, Cout)
+    assert float(flat[3 * Cout]) == rows and float(flat[:Cout].abs().max()) == 0.0
+    assert rel(flat[Cout: 2 * Cout].double(), y2.sum(0)) < 1e-5
+
+
 # ---------------------------------------------------------------------------------------------------------------- module level
 POLICIES = {
     "default": None,
@@ -213,6 +244,12 @@ def test_e2e_small_mixed_mode(dev, modality, policy, monkeypatch):
 
     if POLICIES[policy] is not None:
         monkeypatch.setattr(AF, "MIXED_POLICY", POLICIES[policy])
+    from auto_avsr_amd import functional_frontend as FF
+
+    if policy == "all-split":  # bit-identity with hpf below: BatchNorm statistics from the stand-alone pass, as hpf takes them
+        monkeypatch.setattr(FF, "_FUSE_BN_STATS", False)
+    trace = []
+    monkeypatch.setattr(ops, "TRACE", trace)
     torch.manual_seed(0)
     odim = 72
     m = no_dropout(E2E(odim, modality, adim=128, aheads=2, eunits=256, elayers=2, dunits=256, dlayers=2, cnn_module_kernel=7))
@@ -234,6 +271,12 @@ def test_e2e_small_mixed_mode(dev, modality, policy, monkeypatch):
     assert abs(float(loss_ctc) - float(ctc_r)) < 1e-3 * abs(float(ctc_r))
     assert abs(float(loss_att) - float(att_r)) < 1e-3 * abs(float(att_r))
     assert acc == acc_r
+    names = [t[0] for t in trace]
+    if policy != "all-split":  # split-plane trunk stages 1 - 2 (2-D and 1-D ResNet alike): statistics come out of the convolution epilogue
+        assert names.count("avsr_conv2d_f32s_stats") == 9 and names.count("avsr_bn_finalize_parts") == 9, \
+            (names.count("avsr_conv2d_f32s_stats"), names.count("avsr_bn_finalize_parts"))
+    else:
+        assert "avsr_conv2d_f32s_stats" not in names
     st = dict(AF._twin_stats)
     if policy == "default-casts":
         assert st["made"] == 0 and st["cast"] > 20, st
