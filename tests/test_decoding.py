@@ -184,6 +184,22 @@ def test_native_beam_search_long_ffn(dev):
         assert abs(x["score"] - y["score"]) < 1e-3 * max(1.0, abs(y["score"]))
 
 
+@pytest.mark.parametrize("beam,T,maxlenratio", [(2, 9, 0.0), (5, 1, 0.0), (5, 9, -1), (4, 2, 0.0)])
+def test_native_beam_search_edge_cases(dev, beam, T, maxlenratio):
+    """The smallest beam the library takes (2: pre-beam 3), a one-frame utterance, a one-step search (forced end at the first
+    step), a two-frame utterance: same ended hypotheses as the python-issued step."""
+    case = dict(GOLD["beam"][2], T=T)
+    a, b = _search(dev, case, True, maxlenratio, beam=beam), _search(dev, case, False, maxlenratio, beam=beam)
+    assert len(a) == len(b) and len(a) >= 1
+    for x, y in zip(a, b):
+        x, y = x.asdict(), y.asdict()
+        if y["score"] < -1e8:
+            assert x["score"] < -1e8
+            continue
+        assert x["yseq"] == y["yseq"]
+        assert abs(x["score"] - y["score"]) < 1e-3 * max(1.0, abs(y["score"]))
+
+
 def test_forward_many_equals_one_at_a_time(dev):
     """BatchBeamSearch.forward_many: five utterances of different lengths through three concurrent sessions (host threads + streams)
     give the hypotheses of five separate calls."""
