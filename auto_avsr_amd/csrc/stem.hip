@@ -108,7 +108,8 @@ constexpr int OP = 72;       // pitch (bf16) of the LDS output row [pixel][64 ch
 template <int NS, class TO>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wp,
                                                        TO* __restrict__ y, int T, int H, int W, int OH, int OW,
-                                                       long total_rows, bf16_t* __restrict__ y2 = nullptr) {
+                                                       long total_rows, bf16_t* __restrict__ y2 = nullptr,
+                                                       float* __restrict__ stats_part = nullptr) {
     constexpr int OPT = sizeof(TO) == 2 ? OP : 68;  // pitch of the LDS output row in elements (16-byte multiple, bank-skewed)
     __shared__ __attribute__((aligned(16))) bf16_t patch[NS * 36 * LP];
     __shared__ __attribute__((aligned(16))) TO orow[64 * OPT];
@@ -126,6 +127,9 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
     patch_init<NS>(patch, W);
     f32x4 q[PATCH_V];
     patch_load(q, x, (long)blockIdx.x * FWD_ROWS, OH, T, H, W);
+    // BatchNorm statistics of the block's output (stats_part, f32 output only): in the copy-out below a thread always handles the
+    // same four channels (256 threads, 16 chunks per pixel), so it sums them and their squares over all pixels of all rows
+    f32x4 st1 = f32x4{0.f, 0.f, 0.f, 0.f}, st2 = f32x4{0.f, 0.f, 0.f, 0.f};
     for (long row = (long)blockIdx.x * FWD_ROWS; row < row_end; row++) {
         __syncthreads();  // the previous row's patch and output row are no longer read
         patch_store<NS>(patch, q, W);
@@ -160,9 +164,33 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
             const int pix = i / CPP, c = (i % CPP) * EPC;
             const f32x4 v = *reinterpret_cast<const f32x4*>(orow + pix * OPT + c);
             *reinterpret_cast<f32x4*>(dst + pix * CO + c) = v;
+            if (sizeof(TO) == 4 && stats_part) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    st1[e] += v[e];
+                    st2[e] += v[e] * v[e];
+                }
+            }
             if (sizeof(TO) == 4 && y2)  // bf16 twin of the f32 result (hpf mode)
                 *reinterpret_cast<bf16x4*>(y2 + (row * OW + pix) * CO + c) =
                     bf16x4{(short)f2bf(v[0]), (short)f2bf(v[1]), (short)f2bf(v[2]), (short)f2bf(v[3])};
+        }
+    }
+    if (sizeof(TO) == 4 && stats_part) {  // 16 threads per 4-channel chunk meet in LDS: row blockIdx.x of [blocks][2][64]
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(orow);  // [16 thread groups][2][64]
+        const int grp = threadIdx.x >> 4, c = (threadIdx.x & 15) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            red[(grp * 2 + 0) * CO + c + e] = st1[e];
+            red[(grp * 2 + 1) * CO + c + e] = st2[e];
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * CO) {
+            float v = 0.f;
+#pragma unroll
+            for (int g2 = 0; g2 < 16; g2++) v += red[g2 * 2 * CO + threadIdx.x];
+            stats_part[(size_t)blockIdx.x * 2 * CO + threadIdx.x] = v;
         }
     }
 }
@@ -353,8 +381,8 @@ extern "C" int avsr_stem357_fwd(const float* x, const float* w, void* y, void* w
 
 // The same convolution for the precise / hpf modes: y (f32) from split hi + lo bf16 planes of x and w (three MFMAs per
 // product, ~2^-16 relative error -- the arithmetic of avsr_conv_stem_fwd with precise = 1).  Same workspace.
-extern "C" int avsr_stem357_fwd_f32s(const float* x, const float* w, float* y, void* y2, void* workspace, int B, int T, int H,
-                                     int W, hipStream_t stream) {
+static int stem357_fwd_f32s_impl(const float* x, const float* w, float* y, void* y2, void* workspace, int B, int T, int H, int W,
+                                 float* stats_part, int stats_rows, hipStream_t stream) {
     AVSR_REQUIRE(W % 4 == 0 && W <= 96 && H >= 1, "stem357: W must be a multiple of 4 and <= 96");
     if (B <= 0 || T <= 0) return 0;
     const int OH = (H + 6 - KH) / 2 + 1, OW = (W + 6 - KW) / 2 + 1;
@@ -362,10 +390,31 @@ extern "C" int avsr_stem357_fwd_f32s(const float* x, const float* w, float* y, v
     AVSR_LAUNCH(stem_weight_kernel<2>, dim3((CO * KP + 255) / 256), dim3(256), 0, stream, w, wp);
     const long rows = (long)B * T * OH;
     AVSR_REQUIRE(OW <= 64, "stem357: at most 64 output columns");
-    AVSR_LAUNCH((stem_fwd_kernel<2, float>), dim3((unsigned)((rows + FWD_ROWS - 1) / FWD_ROWS)), dim3(256), 0, stream, x,
-                (const bf16_t*)wp, y, T, H, W, OH, OW, rows, (bf16_t*)y2);
+    const long blocks = (rows + FWD_ROWS - 1) / FWD_ROWS;
+    AVSR_REQUIRE(stats_part == nullptr || stats_rows >= blocks, "stem357: statistics buffer too small");
+    AVSR_LAUNCH((stem_fwd_kernel<2, float>), dim3((unsigned)blocks), dim3(256), 0, stream, x, (const bf16_t*)wp, y, T, H, W, OH, OW, rows,
+                (bf16_t*)y2, stats_part);
     AVSR_CHECK_LAUNCH("stem357_fwd_f32s");
     return 0;
+}
+
+// The same convolution for the precise / hpf modes: y (f32) from split hi + lo bf16 planes of x and w (three MFMAs per
+// product, ~2^-16 relative error -- the arithmetic of avsr_conv_stem_fwd with precise = 1).  Same workspace.
+extern "C" int avsr_stem357_fwd_f32s(const float* x, const float* w, float* y, void* y2, void* workspace, int B, int T, int H,
+                                     int W, hipStream_t stream) {
+    return stem357_fwd_f32s_impl(x, w, y, y2, workspace, B, T, H, W, nullptr, 0, stream);
+}
+// ... leaving the BatchNorm statistics of its output behind (frontend/resnet.py:203-219: Conv3d -> BatchNorm3d in batch-statistics
+// mode): row j of stats_part [stats_rows >= avsr_stem357_stat_rows(B, T, H)][2][64] = per-channel sums / sums of squares of the
+// output rows block j wrote; finish with avsr_bn_finalize_parts / avsr_bn_stats_parts
+extern "C" int64_t avsr_stem357_stat_rows(int B, int T, int H) {
+    const int OH = (H + 6 - KH) / 2 + 1;
+    return ((int64_t)B * T * OH + FWD_ROWS - 1) / FWD_ROWS;
+}
+extern "C" int avsr_stem357_fwd_f32s_stats(const float* x, const float* w, float* y, void* y2, void* workspace, int B, int T, int H,
+                                           int W, float* stats_part, int stats_rows, hipStream_t stream) {
+    AVSR_REQUIRE(stats_part != nullptr, "stem357_fwd_f32s_stats: statistics buffer required");
+    return stem357_fwd_f32s_impl(x, w, y, y2, workspace, B, T, H, W, stats_part, stats_rows, stream);
 }
 
 // dw[64,1,5,7,7] (f32, overwritten) = weight gradient for dy[B*T, OH, OW, 64] (bf16)

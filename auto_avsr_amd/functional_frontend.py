@@ -164,6 +164,7 @@ class StemFn(torch.autograd.Function):
         T = act_dtype()
         pr = _state["precise"]
         x = x.contiguous()
+        st0 = None
         taps = KT * KH * KW
         ldw = padded_cols(taps)
         geom_ok = (KT, KH, KW, stride, pt, ph, pw, Cout) == (5, 7, 7, 2, 2, 3, 3, 64) and W % 4 == 0 and W <= 96 \
@@ -172,14 +173,19 @@ class StemFn(torch.autograd.Function):
         if dedicated:  # csrc/stem.hip: input rows staged once in LDS
             c0 = ops.stem357_fwd(x, w, B, Tn, H, W)
         elif geom_ok and pr and ops.SPLIT_FAST and x.dtype == torch.float32 and w.dtype == torch.float32:
-            c0 = ops.stem357_fwd_f32s(x, w.contiguous(), B, Tn, H, W)  # the same kernel on split hi / lo planes, f32 result
+            # the same kernel on split hi / lo planes, f32 result; mixed mode: it leaves the BatchNorm statistics of its output
+            # behind (the stand-alone pass over this 790 MB activation took 175 us)
+            if training and _FUSE_BN_STATS and _state["mixed"]:
+                c0, st0 = ops.stem357_fwd_f32s(x, w.contiguous(), B, Tn, H, W, want_stats=True)
+            else:
+                c0 = ops.stem357_fwd_f32s(x, w.contiguous(), B, Tn, H, W)
         else:
             wp = ops.conv_weight_permute(w, T, ld_out=ldw)
             c0 = ops.conv_stem_fwd(x, wp, ldw, T, B, Tn, H, W, Cout, KT, KH, KW, stride, pt, ph, pw, pr)
         OH, OW = c0.shape[1], c0.shape[2]
         rows = B * Tn * OH * OW
         bn = (g, b) + bn_rest
-        m0, i0, n0 = _bn_fwd_params(c0, rows, Cout, bn, training)
+        m0, i0, n0 = _bn_fwd_params(c0, rows, Cout, bn, training, parts=st0)
         idx = xsel = None
         if pool and AF._FUSE_STEM_POOL:
             # BN + SiLU + max-pool in one pass: the full-resolution activation (396 MB per 1600 video frames) is never

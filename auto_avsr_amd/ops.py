@@ -838,11 +838,17 @@ def stem357_fwd(x, w, B, T, H, W):
     return y
 
 
-def stem357_fwd_f32s(x, w, B, T, H, W):
-    """Precise-mode video stem forward (f32 result, split hi / lo bf16 planes, csrc/stem.hip)."""
+def stem357_fwd_f32s(x, w, B, T, H, W, want_stats=False):
+    """Precise-mode video stem forward (f32 result, split hi / lo bf16 planes, csrc/stem.hip).  want_stats: also returns the
+    per-block partial BatchNorm statistics [blocks][2][64] the kernel leaves behind (bn_finalize_parts / bn_stats_parts)."""
     OH, OW = conv_out(H, 7, 2, 3), conv_out(W, 7, 2, 3)
     y = torch.empty(B * T, OH, OW, 64, dtype=torch.float32, device=x.device)
     ws = torch.empty(call("avsr_stem357_workspace_bytes") // 4 + 16, dtype=torch.float32, device=x.device)
+    if want_stats:
+        part = torch.empty(call("avsr_stem357_stat_rows", B, T, H), 2, 64, dtype=torch.float32, device=x.device)
+        call("avsr_stem357_fwd_f32s_stats", _ptr(x), _ptr(w), _ptr(y), _ptr(_twin(y)), _ptr(ws), B, T, H, W, _ptr(part), part.shape[0],
+             _stream(x), flops=2.0 * B * T * OH * OW * 64 * 245, nbytes=_nb(x, y))
+        return y, part
     call("avsr_stem357_fwd_f32s", _ptr(x), _ptr(w), _ptr(y), _ptr(_twin(y)), _ptr(ws), B, T, H, W, _stream(x),
          flops=2.0 * B * T * OH * OW * 64 * 245, nbytes=_nb(x, y))
     return y

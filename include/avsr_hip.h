@@ -408,6 +408,12 @@ int avsr_stem357_wgrad(const void* dy, const float* x, float* dw, void* workspac
 /* precise / hpf modes: the same convolution with an f32 result from split hi + lo bf16 planes (three MFMAs per product) */
 int avsr_stem357_fwd_f32s(const float* x, const float* w, float* y, void* y2 /* may be NULL: bf16 twin of y */, void* workspace,
                           int B, int T, int H, int W, avsr_stream_t stream);
+/* ... leaving the BatchNorm statistics of its output behind (frontend/resnet.py:203-219: Conv3d -> BatchNorm3d in batch-statistics
+ * mode): row j of stats_part [stats_rows >= avsr_stem357_stat_rows(B, T, H)][2][64] = per-channel sums / sums of squares of the
+ * output rows block j wrote; finish with avsr_bn_finalize_parts / avsr_bn_stats_parts */
+int64_t avsr_stem357_stat_rows(int B, int T, int H);
+int avsr_stem357_fwd_f32s_stats(const float* x, const float* w, float* y, void* y2, void* workspace, int B, int T, int H, int W,
+                                float* stats_part, int stats_rows, avsr_stream_t stream);
 
 /* bf16 weight-gradient contraction without transposed copies (gemm_tn_fast.hip: LDS-DMA k-major tiles +
  * ds_read_b64_tr_b16): C[M][N] (f32, ldc) (+)= sum_k A[k][m] B[k][n]; A [K][lda], B [K][ldb] bf16.

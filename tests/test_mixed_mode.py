@@ -221,6 +221,24 @@ def test_conv_epilogue_leaves_batchnorm_statistics(dev, geom):
     assert rel(flat[Cout: 2 * Cout].double(), y2.sum(0)) < 1e-5
 
 
+def test_stem_leaves_batchnorm_statistics(dev):
+    """avsr_stem357_fwd_f32s_stats: per-block partial sums of the video stem's output -> the same (mean, invstd) as the stand-alone pass."""
+    B, T, H, W = 2, 5, 24, 24
+    torch.manual_seed(3)
+    x = torch.randn(B, T, H, W).to(dev)
+    w = (0.1 * torch.randn(64, 1, 5, 7, 7)).to(dev)
+    y0 = ops.stem357_fwd_f32s(x, w, B, T, H, W)
+    y, part = ops.stem357_fwd_f32s(x, w, B, T, H, W, want_stats=True)
+    assert torch.equal(y, y0) and torch.isfinite(part).all()
+    rows = y.numel() // 64
+    y2 = y.view(rows, 64).double()
+    assert rel(part[:, 0].sum(0).double(), y2.sum(0)) < 1e-5 and rel(part[:, 1].sum(0).double(), (y2 * y2).sum(0)) < 1e-5
+    rm, rv = torch.zeros(64, device=dev), torch.ones(64, device=dev)
+    mean, invstd = ops.bn_finalize_parts(part, rows, 64, 1e-5, 0.1, rm, rv)
+    mean0, invstd0 = ops.bn_stats_finalize(y.view(rows, 64), rows, 64, 1e-5, 0.1, torch.zeros(64, device=dev), torch.ones(64, device=dev))
+    assert rel(mean, mean0) < 1e-5 and rel(invstd, invstd0) < 1e-5
+
+
 # ---------------------------------------------------------------------------------------------------------------- module level
 POLICIES = {
     "default": None,
@@ -273,7 +291,9 @@ def test_e2e_small_mixed_mode(dev, modality, policy, monkeypatch):
     assert acc == acc_r
     names = [t[0] for t in trace]
     if policy != "all-split":  # split-plane trunk stages 1 - 2 (2-D and 1-D ResNet alike): statistics come out of the convolution epilogue
-        assert names.count("avsr_conv2d_f32s_stats") == 9 and names.count("avsr_bn_finalize_parts") == 9, \
+        n_stem = int(modality == "video")  # (the video stem kernel leaves its statistics too; the audio stem is a tiled conv1d)
+        assert names.count("avsr_conv2d_f32s_stats") == 9 and names.count("avsr_stem357_fwd_f32s_stats") == n_stem \
+            and names.count("avsr_bn_finalize_parts") == 9 + n_stem, \
             (names.count("avsr_conv2d_f32s_stats"), names.count("avsr_bn_finalize_parts"))
     else:
         assert "avsr_conv2d_f32s_stats" not in names
