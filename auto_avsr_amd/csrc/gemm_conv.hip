@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void weight_permute_split_kernel(const float* 
 struct AvsrPermEntry {
     const float* w;
     bf16_t* out;
-    int Cout, Cin, taps, to_dgrad, blk0, pad0, pad1, pad2;  // pad0 = 2: `out` is IEEE half (mixed mode forward copies), else bf16
+    int Cout, Cin, taps, to_dgrad, blk0, pad0, pad1, pad2;  // pad0 = 2: `out` is the two-plane IEEE-half image [Cout][2][taps][Cin] (mixed mode forward copies), else bf16
 };
 // One block = one (co tile, ci tile) x all taps, transposed through LDS: the source w[co][ci][tap] is read in runs of
 // TCI * taps consecutive floats per co, the output [a][tap][b] is written in runs of 64 consecutive bf16 (128 bytes).
@@ -122,8 +122,11 @@ __global__ __launch_bounds__(256) void multi_weight_permute_kernel(const AvsrPer
         if (a < (e.to_dgrad ? e.Cin : e.Cout) && b < Bc) {
             const float v = lds[tap * PERM_PITCH + a_l * 64 + b_l];
             const long o = ((long)a * e.taps + tap) * Bc + b;
-            if (e.pad0 == 2) reinterpret_cast<f16_t*>(e.out)[o] = f2h(v);
-            else e.out[o] = f2bf(v);
+            if (e.pad0 == 2) {  // two-plane f16 image [a][2][taps][b] (prims.h f2h_lo)
+                f16_t* o16 = reinterpret_cast<f16_t*>(e.out) + ((long)(2 * a) * e.taps + tap) * Bc + b;
+                o16[0] = f2h(v);
+                o16[(long)e.taps * Bc] = f2h_lo(v);
+            } else e.out[o] = f2bf(v);
         }
     }
 }

@@ -28,6 +28,7 @@ namespace avsr_gemm_impl {
 struct Params {
     const void* A;
     const void* B;
+    const void* B2;  // tuned NT kernel with two f16 weight planes (gemm_fast_kernel.h WP = 2): the scaled lo plane, pitch ldb; else unused
     int lda, ldb;
     int M, N, K;
     int k_chunk;  // K range handled per blockIdx.z (split-K); == K when not split

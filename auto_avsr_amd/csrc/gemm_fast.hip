@@ -27,15 +27,15 @@ using avsr_gemm_impl::Params;
 
 using avsr_fast::FastKernel;
 
-template <int BM, int BN, int STAGES, int CV, int WGM, int WGN, int ABL, int KS, int F16 = 0>
+template <int BM, int BN, int STAGES, int CV, int WGM, int WGN, int ABL, int KS, int F16 = 0, int WP = 1>
 __global__ __launch_bounds__(64 * WGM * WGN * KS) void gemm_fast_kernel(Params p) {
     AVSR_DYN_SMEM(smem);
-    FastKernel<BM, BN, STAGES, CV, WGM, WGN, ABL, KS, F16>::run(p, smem);
+    FastKernel<BM, BN, STAGES, CV, WGM, WGN, ABL, KS, F16, WP>::run(p, smem);
 }
 
-template <int BM, int BN, int STAGES, int CV = 0, int WGM = 2, int WGN = 2, int ABL = 0, int KS = 1, int F16 = 0>
+template <int BM, int BN, int STAGES, int CV = 0, int WGM = 2, int WGN = 2, int ABL = 0, int KS = 1, int F16 = 0, int WP = 1>
 void launch_fast(Params& p, int split_k, hipStream_t stream) {
-    using K = FastKernel<BM, BN, STAGES, CV, WGM, WGN, ABL, KS, F16>;
+    using K = FastKernel<BM, BN, STAGES, CV, WGM, WGN, ABL, KS, F16, WP>;
     // XCD-aware tile order (knob 1: 0 = automatic, 1 = on, 2 = off).  Automatic: on for the 64x64 GEMM tile -- measured
     // with operands that are NOT cache-resident (tools/microbench_xcd.py: A written by the previous kernel, weights
     // streamed from HBM, as in the training step): every XCD otherwise pulls the whole problem through its own L2
@@ -61,7 +61,7 @@ void launch_fast(Params& p, int split_k, hipStream_t stream) {
         gy = t0;
     }
     dim3 grid((p.N + BN - 1) / BN, gy, split_k), block(K::NTHR);
-    AVSR_LAUNCH((gemm_fast_kernel<BM, BN, STAGES, CV, WGM, WGN, ABL, KS, F16>), grid, block, K::LDS_BYTES, stream, p);
+    AVSR_LAUNCH((gemm_fast_kernel<BM, BN, STAGES, CV, WGM, WGN, ABL, KS, F16, WP>), grid, block, K::LDS_BYTES, stream, p);
 }
 
 // tile codes shared by the GEMM and convolution entry points
@@ -112,13 +112,28 @@ bool launch_tile_h16(int tile, Params& p, int split_k, hipStream_t stream) {
     }
 }
 
+// f16 operands with two weight planes (Params::B2).  LDS per block: 64x64 / 3 stages 72 KB (2 blocks per CU) or 2 stages 48 KB
+// (3 per CU, code 21); 128x64 / 2 stages 64 KB (2 per CU): the A tile is shared by both planes, so the 128-row tile moves as
+// many operand bytes per output as the one-plane 64x64 tile; 128x128 / 2 stages 96 KB (1 per CU, code 4)
+template <int CV>
+bool launch_tile_h16x2(int tile, Params& p, int split_k, hipStream_t stream) {
+    switch (tile) {
+        case 1: if (CV == 0) { launch_fast<64, 64, 3, 0, 2, 2, 0, 1, 1, 2>(p, split_k, stream); return true; } return false;
+        case 21: if (CV == 0) { launch_fast<64, 64, 2, 0, 2, 2, 0, 1, 1, 2>(p, split_k, stream); return true; } return false;
+        case 4: launch_fast<128, 128, 2, CV, 2, 2, 0, 1, 1, 2>(p, split_k, stream); return true;
+        case 7: launch_fast<128, 64, 2, CV, 2, 2, 0, 1, 1, 2>(p, split_k, stream); return true;
+        case 2: launch_fast<128, 64, 3, CV, 2, 2, 0, 1, 1, 2>(p, split_k, stream); return true;
+        default: return false;
+    }
+}
+
 }  // namespace
 
 int avsr_conv3x3_c64_supported(int H, int W);
 int avsr_conv3x3_c64_launch(int flip, const void* src, const void* wq, const void* resid, void* out, const void* zero_page, int N,
                             int H, int W, hipStream_t stream);
 
-static int gemm16_nt_impl(int f16, const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
+static int gemm16_nt_impl(int f16, const void* A, int lda, const void* B, const void* B_lo, int ldb, int M, int N, int K, const float* bias,
                           int act, const void* gate, int gate_dtype, int ldg, float gate_scale, float drop_p,
                           uint64_t seed, const uint64_t* seed_dev, float alpha, const float* alpha_dev,
                           const void* resid, int resid_dtype, int ldr, void* C, int c_dtype, int ldc, int accumulate,
@@ -131,7 +146,7 @@ static int gemm16_nt_impl(int f16, const void* A, int lda, const void* B, int ld
     AVSR_REQUIRE(!(split_k > 1 && !accumulate), "gemm_bf16_nt: split-K needs accumulate=1");
     if (M <= 0 || N <= 0) return 0;
     Params p{};
-    p.A = A; p.B = B; p.lda = lda; p.ldb = ldb;
+    p.A = A; p.B = B; p.B2 = B_lo; p.lda = lda; p.ldb = ldb;
     p.M = M; p.N = N; p.K = K;
     p.bias = bias; p.act = act;
     p.gate = gate; p.gate_dtype = gate_dtype; p.ldg = ldg; p.gate_scale = gate_scale;
@@ -144,6 +159,7 @@ static int gemm16_nt_impl(int f16, const void* A, int lda, const void* B, int ld
     p.C2 = c2; p.ldc2 = ldc2;
     p.nsplit = 1; p.batch_h = 1; p.nbatch = 1;
     if (split_k < 1) split_k = 1;
+    const bool auto_tile = tile == 0;
     if (tile == 0) {
         const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
         const long t12864 = (long)((M + 127) / 128) * ((N + 63) / 64);
@@ -151,6 +167,17 @@ static int gemm16_nt_impl(int f16, const void* A, int lda, const void* B, int ld
         // deeper ring at every size -- 128x128 / 128x64 with a 2-stage ring (2 / 3 blocks per CU) once the grid fills the
         // chip, 64x64 with 3 stages (3 blocks per CU) for the skinny M = B*T GEMMs of the transformer layers
         tile = t128 >= 1024 ? 4 : (t12864 >= 400 ? 7 : (g_tune[14] > 0 && (long)((M + 63) / 64) * ((N + 63) / 64) > 256 ? g_tune[14] : 1));  // knob 14: A/B of the tile for grids of 257+ 64x64 tiles
+    }
+    if (f16 && B_lo) {
+        AVSR_REQUIRE(((uintptr_t)B_lo % 16) == 0, "gemm_h16_nt: the lo plane must be 16-byte aligned");
+        if (auto_tile) {
+            // the A tile serves both planes: a 128-row tile once the grid fills the chip with them, else 64x64 (knob 17: A/B)
+            const long t12864 = (long)((M + 127) / 128) * ((N + 63) / 64);
+            tile = g_tune[17] > 0 ? g_tune[17] : (t12864 >= 256 ? 7 : 1);
+        }
+        AVSR_REQUIRE(launch_tile_h16x2<0>(tile, p, split_k, stream), "gemm_h16_nt: unknown tile code (two weight planes)");
+        AVSR_CHECK_LAUNCH("gemm_h16_nt");
+        return 0;
     }
     if (f16) {
         if (tile != 1 && tile != 4 && tile != 7) tile = 1;
@@ -169,17 +196,18 @@ extern "C" int avsr_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb,
                                  uint64_t seed, const uint64_t* seed_dev, float alpha, const float* alpha_dev,
                                  const void* resid, int resid_dtype, int ldr, void* C, int c_dtype, int ldc, int accumulate,
                                  int split_k, int tile, float* colsum, hipStream_t stream) {
-    return gemm16_nt_impl(0, A, lda, B, ldb, M, N, K, bias, act, gate, gate_dtype, ldg, gate_scale, drop_p, seed, seed_dev, alpha,
+    return gemm16_nt_impl(0, A, lda, B, nullptr, ldb, M, N, K, bias, act, gate, gate_dtype, ldg, gate_scale, drop_p, seed, seed_dev, alpha,
                           alpha_dev, resid, resid_dtype, ldr, C, c_dtype, ldc, accumulate, split_k, tile, colsum, nullptr, 0, stream);
 }
 
 // The same contraction on IEEE-half operands (v_mfma_f32_32x32x16_f16): A and B f16 k-contiguous; C f32, bf16 or f16
 // (c_dtype 0 / 1 / 2); c2 (may be NULL): bf16 twin of an f32 / f16 result -- what the backward pass of the mixed mode reads.
-extern "C" int avsr_gemm_h16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
+// B_lo (may be NULL): the scaled lo plane of the weight, f16((w - B) * 2^11), same pitch -- two MFMAs per product, weight exact.
+extern "C" int avsr_gemm_h16_nt(const void* A, int lda, const void* B, const void* B_lo, int ldb, int M, int N, int K, const float* bias,
                                 int act, float drop_p, uint64_t seed, const uint64_t* seed_dev, float alpha, const void* resid,
                                 int resid_dtype, int ldr, void* C, int c_dtype, int ldc, int tile, void* c2, int ldc2,
                                 hipStream_t stream) {
-    return gemm16_nt_impl(1, A, lda, B, ldb, M, N, K, bias, act, nullptr, 0, 0, 1.f, drop_p, seed, seed_dev, alpha, nullptr, resid,
+    return gemm16_nt_impl(1, A, lda, B, B_lo, ldb, M, N, K, bias, act, nullptr, 0, 0, 1.f, drop_p, seed, seed_dev, alpha, nullptr, resid,
                           resid_dtype, ldr, C, c_dtype, ldc, 0, 1, tile, nullptr, c2, ldc2, stream);
 }
 
@@ -258,7 +286,8 @@ extern "C" int avsr_conv2d_bf16(int dgrad, const void* src, const void* wp, cons
 
 // f16 forward convolution of the mixed mode on the same tiled kernel (v_mfma_f32_32x32x16_f16): x [N,H,W,Cin] f16,
 // wp [Cout][KH][KW][Cin] f16 -> y [N,OH,OW,Cout] f16 and (y2 != NULL) its bf16 twin, which the bf16 backward pass reads.
-extern "C" int avsr_conv2d_h16(const void* x, const void* wp, void* y, void* y2, const void* zero_page, int N, int H, int W, int Cin,
+// ldw: row pitch of wp in elements (0 = KH * KW * Cin); wp_lo (may be NULL): scaled lo plane of the filter, same pitch.
+extern "C" int avsr_conv2d_h16(const void* x, const void* wp, const void* wp_lo, int ldw, void* y, void* y2, const void* zero_page, int N, int H, int W, int Cin,
                                int Cout, int KH, int KW, int stride, int pad_h, int pad_w, hipStream_t stream) {
     const int OH = (H + 2 * pad_h - KH) / stride + 1, OW = (W + 2 * pad_w - KW) / stride + 1;
     AVSR_REQUIRE(Cin % 64 == 0, "conv2d_h16: input channel count must be a multiple of 64");
@@ -268,8 +297,9 @@ extern "C" int avsr_conv2d_h16(const void* x, const void* wp, void* y, void* y2,
     AVSR_REQUIRE((long)N * H * W < (1l << 31) && (long)N * OH * OW < (1l << 31), "conv2d_h16: pixel count exceeds int32");
     if (N <= 0) return 0;
     Params p{};
-    p.A = x; p.B = wp;
-    p.K = KH * KW * Cin; p.lda = Cin; p.ldb = p.K;
+    p.A = x; p.B = wp; p.B2 = wp_lo;
+    p.K = KH * KW * Cin; p.lda = Cin; p.ldb = ldw ? ldw : p.K;
+    AVSR_REQUIRE(p.ldb >= p.K && p.ldb % 8 == 0, "conv2d_h16: bad filter pitch");
     p.alpha = 1.f; p.gate_scale = 1.f;
     p.nsplit = 1; p.batch_h = 1; p.nbatch = 1;
     p.gate = zero_page;
@@ -280,7 +310,12 @@ extern "C" int avsr_conv2d_h16(const void* x, const void* wp, void* y, void* y2,
     p.cH = H; p.cW = W; p.cOH = OH; p.cOW = OW;
     p.ncls = 1;
     p.cls_h[0] = OH; p.cls_w[0] = OW; p.cls_nkh[0] = KH; p.cls_nkw[0] = KW;
-    AVSR_REQUIRE(launch_tile_h16<1>(p.N >= 128 ? 4 : 7, p, 1, stream), "conv2d_h16: tile");
+    if (wp_lo) {
+        // two filter planes: 128x64 tiles keep two blocks per CU (64 KB each); knob 18: A/B against 128x128 (one block per CU)
+        const int tile = g_tune[18] > 0 ? g_tune[18] : 7;
+        AVSR_REQUIRE(launch_tile_h16x2<1>(tile, p, 1, stream), "conv2d_h16: tile (two filter planes)");
+    } else
+        AVSR_REQUIRE(launch_tile_h16<1>(p.N >= 128 ? 4 : 7, p, 1, stream), "conv2d_h16: tile");
     AVSR_CHECK_LAUNCH("conv2d_h16");
     return 0;
 }
@@ -441,12 +476,17 @@ __global__ __launch_bounds__(256) void multi_cast_transpose_kernel(const AvsrCas
 #pragma unroll
         for (int k = 0; k < 8; k++) tile[(cc + k) * 72 + r] = f2bf(v[k]);
         if (e.dst && gr < e.R) {
-            if (e.pad1 == 2) {  // f16 forward copy (mixed mode)
-                f16_t* d16 = reinterpret_cast<f16_t*>(e.dst);
-                if (vec_ok && gc + 8 <= e.C) store8(d16 + (long)gr * e.C + gc, v);
-                else
+            if (e.pad1 == 2) {  // f16 forward copy (mixed mode), [R][2][C]: hi row, scaled lo row (prims.h f2h_lo)
+                f16_t* d16 = reinterpret_cast<f16_t*>(e.dst) + (long)gr * 2 * e.C + gc;
+                if (vec_ok && gc + 8 <= e.C) {
+                    store8(d16, v);
+                    store8_lo(d16 + e.C, v);
+                } else
                     for (int k = 0; k < 8; k++)
-                        if (gc + k < e.C) d16[(long)gr * e.C + gc + k] = f2h(v[k]);
+                        if (gc + k < e.C) {
+                            d16[k] = f2h(v[k]);
+                            d16[e.C + k] = f2h_lo(v[k]);
+                        }
             } else if (vec_ok && gc + 8 <= e.C) store8(e.dst + (long)gr * e.C + gc, v);
             else
                 for (int k = 0; k < 8; k++)
@@ -465,7 +505,7 @@ __global__ __launch_bounds__(256) void multi_cast_transpose_kernel(const AvsrCas
 }
 }  // namespace
 
-// table: n entries of 64 bytes {src, dst, dstT, R, C, ldT, blk0, tiles_c, limT, dst_dtype (0 / 1 = bf16, 2 = f16), 0}; blk0 = running sum of
+// table: n entries of 64 bytes {src, dst, dstT, R, C, ldT, blk0, tiles_c, limT, dst_dtype (0 / 1 = bf16, 2 = two-plane f16 [R][2][C]), 0}; blk0 = running sum of
 // ceil(max(R, limT ? limT : ldT)/64) * ceil(C/64); total_blocks = the final sum.  limT < ldT lets several transposed
 // copies share one [C][ldT] buffer side by side (concatenated projection weights).
 extern "C" int avsr_multi_cast_transpose(const void* table, int n, int total_blocks, hipStream_t stream) {

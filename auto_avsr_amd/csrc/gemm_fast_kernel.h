@@ -27,15 +27,23 @@ using avsr_gemm_impl::Params;
 // dependent accumulator chain; 8 waves put two on every SIMD without a second pass over the output.
 // F16 = 1: both operands are IEEE half instead of bf16 (the forward pass of the "mixed" numerical mode) -- the same bytes, the same
 // staging, the same fragment layout; only the MFMA instruction differs.
-template <int BM, int BN, int STAGES, int CV = 0, int WGM = 2, int WGN = 2, int ABL = 0, int KS = 1, int F16 = 0>
+// WP = 2 (round 5, F16 only): the B operand (a weight) arrives as TWO f16 planes -- hi = f16(w) and lo = f16((w - hi) * 2^11),
+// Params::B and Params::B2, same pitch -- and every product is formed twice: acc += a * hi, acc_lo += a * lo, result =
+// acc + acc_lo * 2^-11.  The weight is then exact to ~2^-22 and the only operand rounding left is the activation's 2^-12:
+// the parity study (tools/precision_study.py, "f16a") puts the decoder-logit error of the mixed mode at 0.65x of the
+// single-plane figure.  The lo plane is SCALED so that it stays in the normal f16 range (|w - hi| <= 2^-12 |w| would be
+// subnormal for every weight below 0.25) and needs its own accumulators for that.  Cost: the B stream and the MFMA count double,
+// the A stream does not.
+template <int BM, int BN, int STAGES, int CV = 0, int WGM = 2, int WGN = 2, int ABL = 0, int KS = 1, int F16 = 0, int WP = 1>
 struct FastKernel {
+    static_assert(WP == 1 || (WP == 2 && F16 == 1 && KS == 1), "two weight planes: f16 operands only");
     static constexpr int BK = 64, NQ = WGM * WGN, NW = NQ * KS, NTHR = 64 * NW;
     static constexpr int KPG = (BK / 16) / KS;  // 16-wide k-steps per wave group and k-tile
     static_assert(KS == 1 || KS == 2 || KS == 4, "k-split of the 64-wide tile");
     static constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
-    static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
-    static constexpr int A_LOADS = BM / (8 * NW), B_LOADS = BN / (8 * NW);  // wave-instructions per wave per stage
-    static constexpr int LPT = A_LOADS + B_LOADS;                           // LDS-DMA ops per thread per tile
+    static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + WP * B_BYTES;
+    static constexpr int A_LOADS = BM / (8 * NW), B_LOADS = BN / (8 * NW);  // wave-instructions per wave per stage (and plane)
+    static constexpr int LPT = A_LOADS + WP * B_LOADS;                      // LDS-DMA ops per thread per tile
     static constexpr size_t RING_BYTES = (size_t)STAGES * STAGE_BYTES, EPI_BYTES = (size_t)BM * (BN + 4) * 4;
     static constexpr size_t MAP_OFF = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
     static constexpr size_t LDS_BYTES = MAP_OFF + (CV == 2 ? BM * 4 : 0);
@@ -139,6 +147,11 @@ struct FastKernel {
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; i++) glds16(ri.b[i] + db, stage + A_BYTES + (wave * B_LOADS + i) * 1024);
+        if (WP == 2) {
+            const long lo = reinterpret_cast<const bf16_t*>(p.B2) - reinterpret_cast<const bf16_t*>(p.B);  // (elements; same pitch)
+#pragma unroll
+            for (int i = 0; i < B_LOADS; i++) glds16(ri.b[i] + db + lo, stage + A_BYTES + B_BYTES + (wave * B_LOADS + i) * 1024);
+        }
     }
 
     static AVSR_DEV bf16x8 frag(const char* base, int r, int chunk) {
@@ -195,12 +208,16 @@ struct FastKernel {
         }
 
         f32x16 acc[TM][TN];
+        f32x16 acc_lo[WP == 2 ? TM : 1][WP == 2 ? TN : 1];  // products with the scaled lo plane of the weight
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
             for (int j = 0; j < TN; j++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 16; r++) {
+                    acc[i][j][r] = 0.f;
+                    if (WP == 2) acc_lo[i][j][r] = 0.f;
+                }
 
         const Rows ri = decode_rows(p, A, B, m0, n0, cls, tp, wave, lane);
         // blocks walk k in lockstep: with a row pitch that is a multiple of the channel interleave, every block's loads of
@@ -232,7 +249,7 @@ struct FastKernel {
             // of the address arithmetic of the next operand loads (which hides their LDS latency); k-step ks+2 is
             // requested as soon as the MFMAs of k-step ks have been issued.  The scheduling fences keep that order.
             // (The compiler makes the first LDS wait after an LDS-DMA instruction a full one; placed here it is free.)
-            bf16x8 fa[2][TM], fb[2][TN];
+            bf16x8 fa[2][TM], fb[2][TN], fl[2][WP == 2 ? TN : 1];
             const int arow = wm * WM + (lane & 31), brow = wn * WN + (lane & 31);
             auto load_frags = [&](int set, int ks) {
                 const int chunk = ks * 2 + (lane >> 5);
@@ -240,6 +257,10 @@ struct FastKernel {
                 for (int i = 0; i < TM; i++) fa[set][i] = frag(As, arow + i * 32, chunk);
 #pragma unroll
                 for (int j = 0; j < TN; j++) fb[set][j] = frag(Bs, brow + j * 32, chunk);
+                if (WP == 2) {
+#pragma unroll
+                    for (int j = 0; j < TN; j++) fl[set][j] = frag(Bs + B_BYTES, brow + j * 32, chunk);
+                }
             };
             const int ks0 = kg * KPG;
             if (ABL != 1) {
@@ -256,7 +277,10 @@ struct FastKernel {
 #pragma unroll
                 for (int i = 0; i < TM; i++)
 #pragma unroll
-                    for (int j = 0; j < TN; j++) acc[i][j] = mfma32x<F16>(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
+                    for (int j = 0; j < TN; j++) {
+                        acc[i][j] = mfma32x<F16>(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
+                        if (WP == 2) acc_lo[i][j] = mfma32x<F16>(fa[ks & 1][i], fl[ks & 1][j], acc_lo[i][j]);
+                    }
                 if (ks + 2 < KPG) load_frags(ks & 1, ks0 + ks + 2);
                 sched_fence();
             }
@@ -264,6 +288,14 @@ struct FastKernel {
         int t = 0;
         for (; t + STAGES - 1 < nt; t++) step(t, std::true_type{});
         for (; t < nt; t++) step(t, std::false_type{});
+        if (WP == 2) {
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[i][j][r] += acc_lo[i][j][r] * (1.0f / AVSR_H16_LO_SCALE);
+        }
         if (CV != 0) {
             Params q = p;
             q.gate = nullptr;  // in conv mode the field carries the zero page, not an activation gate

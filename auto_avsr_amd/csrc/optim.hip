@@ -198,7 +198,7 @@ struct OptTileEntry {  // 80 bytes
     bf16_t* dst;   // may be null
     bf16_t* dstT;  // may be null
     int R, C, ldT, blk0, tiles_c, limT;
-    f16_t* dst16;  // may be null: IEEE-half [R][C] copy (forward operand of the mixed mode's f16 components)
+    f16_t* dst16;  // may be null: two-plane IEEE-half [R][2][C] copy (forward operand of the mixed mode's f16 components)
 };
 static_assert(sizeof(OptTileEntry) == 80, "tile table rows are 80 bytes (auto_avsr_amd/optim.py)");
 
@@ -252,14 +252,20 @@ __global__ __launch_bounds__(256) void multi_adamw_cast_kernel(const OptTileEntr
             store8(e.m + off, m);
             store8(e.v + off, v);
             if (e.dst) store8(e.dst + off, p);
-            if (e.dst16) store8(e.dst16 + off, p);
+            if (e.dst16) {  // two-plane f16 image [R][2][C] (prims.h f2h_lo)
+                store8(e.dst16 + off + (long)gr * e.C, p);
+                store8_lo(e.dst16 + off + (long)(gr + 1) * e.C, p);
+            }
         } else {
             for (int k = 0; k < cnt; k++) {
                 e.p[off + k] = p[k];
                 e.m[off + k] = m[k];
                 e.v[off + k] = v[k];
                 if (e.dst) e.dst[off + k] = f2bf(p[k]);
-                if (e.dst16) e.dst16[off + k] = f2h(p[k]);
+                if (e.dst16) {
+                    e.dst16[off + (long)gr * e.C + k] = f2h(p[k]);
+                    e.dst16[off + (long)(gr + 1) * e.C + k] = f2h_lo(p[k]);
+                }
             }
         }
 #pragma unroll

@@ -71,6 +71,12 @@ AVSR_DEV f16_t f2h(float f) {  // round to nearest even, saturating
     return (f16_t)f;
 }
 AVSR_DEV short f2h_bits(float f) { return __builtin_bit_cast(short, f2h(f)); }
+// Two-plane f16 image of a WEIGHT (round 5): hi = f16(w), lo = f16((w - hi) * 2^11).  The scale keeps the lo plane in the normal
+// f16 range; consumers accumulate a * lo separately and fold it in as acc_lo * 2^-11 (gemm_fast_kernel.h, WP = 2).  Every f16
+// forward copy of a weight is stored row-interleaved, [rows][2][K]: the hi row r at element 2 r K, its lo row K further on, so any
+// row slice of a (concatenated) copy carries both planes and a one-plane consumer simply reads hi with pitch 2 K.
+#define AVSR_H16_LO_SCALE 2048.0f
+AVSR_DEV f16_t f2h_lo(float w) { return f2h((w - h2f(f2h(w))) * AVSR_H16_LO_SCALE); }
 
 // Storage-type traits: activations live in HBM either as bf16 (bench mode), as f16 (forward pass of the mixed mode) or
 // as f32 (parity mode, where GEMM operands are split into hi+lo bf16 halves).
@@ -119,6 +125,12 @@ AVSR_DEV void store8(f16_t* p, const float* v) {
 #pragma unroll
     for (int i = 0; i < 8; i++) o[i] = f2h(v[i]);
     *reinterpret_cast<f16x8*>(p) = o;
+}
+AVSR_DEV void store8_lo(f16_t* p, const float* v) {  // the scaled lo plane of 8 weights
+    float l[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) l[i] = (v[i] - h2f(f2h(v[i]))) * AVSR_H16_LO_SCALE;
+    store8(p, l);
 }
 AVSR_DEV void store8(float* p, const float* v) {
     f32x4 a, b;

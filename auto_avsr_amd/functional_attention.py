@@ -10,7 +10,7 @@ from . import functional as AF
 from . import ops
 from .functional import (  # noqa: F401
     _A, _A_shared, _A_view, _bgrad, _bias3, _bwd_mode, _chain_tag, _chain_take, _drop_args, _gemm_nn, _gemm_nt,
-    _ln_bwd, _mask_arg, _pos_proj, _prologue, _state, _to_act, _to_act_shared, _to_f32, _w_bf16_cat, _w_h16_cat,
+    _ln_bwd, _mask_arg, _pos_proj, _prologue, _state, _to_act, _to_act_shared, _to_f32, _w_bf16_cat, _w_h16_cat, _h16_nt,
     _wgrad, _zeros, act_dtype)
 
 
@@ -38,7 +38,7 @@ def prepare_pos_proj(pos_emb, weights):
         return
     out = torch.empty(P, n * D, dtype=pe.dtype, device=pe.device)
     if pe.dtype == torch.float16:
-        ops.gemm_h16_nt(pe, D, _w_h16_cat(tuple(weights)), D, P, n * D, D, out, n * D)
+        _h16_nt(pe, D, _w_h16_cat(tuple(weights)), P, n * D, D, out, n * D, planes=1)  # (one plane: see PosProjFn)
     else:
         ops.gemm_bf16_nt(pe, D, _w_bf16_cat(tuple(weights), False), D, P, n * D, D, out, n * D)
     for i, w in enumerate(weights):
@@ -70,7 +70,9 @@ class PosProjFn(torch.autograd.Function):
         n, P = len(weights), pe.shape[0]
         out = torch.empty(P, n * D, dtype=pe.dtype, device=pe.device)
         if pe.dtype == torch.float16:  # mixed mode: f16 projection + its bf16 twin (the layers' backward passes read views of it)
-            ops.gemm_h16_nt(pe, D, _w_h16_cat(tuple(weights)), D, P, n * D, D, out, n * D, twin=True)
+            # the hi plane of linear_pos alone: the position term sits behind the softmax, where operand rounding averages out
+            # (tools/precision_study.py: q / k / pos projections on one plane leave the logits error unchanged)
+            _h16_nt(pe, D, _w_h16_cat(tuple(weights)), P, n * D, D, out, n * D, planes=1, twin=True)
         else:
             ops.gemm_bf16_nt(pe, D, _w_bf16_cat(tuple(weights), False), D, P, n * D, D, out, n * D)
         ctx.save_for_backward(_A_shared(pe))
@@ -244,7 +246,7 @@ class MhaSublayerFn(torch.autograd.Function):
         if fused:
             qkv = torch.empty(B * Tq, 3 * D, dtype=T, device=x.device)
             if T == torch.float16:
-                ops.gemm_h16_nt(h, D, _w_h16_cat((wq, wk, wv)), D, B * Tq, 3 * D, D, qkv, 3 * D, bias=_bias3(bq, bk, bv), twin=True)
+                _h16_nt(h, D, _w_h16_cat((wq, wk, wv)), B * Tq, 3 * D, D, qkv, 3 * D, bias=_bias3(bq, bk, bv), twin=True)
             else:
                 ops.gemm_bf16_nt(h, D, _w_bf16_cat((wq, wk, wv), False), D, B * Tq, 3 * D, D, qkv, 3 * D,
                                  bias=_bias3(bq, bk, bv))
@@ -457,7 +459,7 @@ class MemoryKVFn(torch.autograd.Function):
         ma = _to_act_shared(memory).reshape(B * Tk, D)
         kv = torch.empty(B * Tk, n * D, dtype=ma.dtype, device=memory.device)
         if ma.dtype == torch.float16:  # mixed mode: f16 projection + bf16 twin (the source-attention backward passes read views of it)
-            ops.gemm_h16_nt(ma, D, _w_h16_cat(tuple(ws)), D, B * Tk, n * D, D, kv, n * D, bias=torch.cat(bs), twin=True)
+            _h16_nt(ma, D, _w_h16_cat(tuple(ws)), B * Tk, n * D, D, kv, n * D, bias=torch.cat(bs), twin=True)
         else:
             ops.gemm_bf16_nt(ma, D, _w_bf16_cat(tuple(ws), False), D, B * Tk, n * D, D, kv, n * D, bias=torch.cat(bs))
         ctx.save_for_backward(_A_shared(ma), *ws)

@@ -72,6 +72,7 @@ class BasicBlockFn(torch.autograd.Function):
         ph, pw = (KH - 1) // 2, (KW - 1) // 2
         T = act_dtype()
         pr = _state["precise"]
+        wpl = 2 if _state["wp2"] else 1  # mixed mode, "f16x2" component: both planes of the f16 filter copies
         x_arg = x
         x = _act_in(x)  # hpf / mixed: the previous trunk function handed over its bf16 twin; compute on the f32 / f16 original
         OH, OW = ops.conv_out(H, KH, stride, ph), ops.conv_out(W, KW, stride, pw)
@@ -80,19 +81,19 @@ class BasicBlockFn(torch.autograd.Function):
         bn2 = (g2, b2) + bn2
         wp1 = _w_conv_fwd(w1, x)
         st1 = _conv_bn_stats(x, wp1, Cin, Cout, KH, KW, rows, training)
-        c1 = ops.conv2d_fwd(x, wp1, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, pr, stats=st1)
+        c1 = ops.conv2d_fwd(x, wp1, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, pr, stats=st1, wp_planes=wpl)
         m1, i1, n1 = _bn_fwd_params(c1, rows, Cout, bn1, training, parts=st1)
         a1 = ops.bn_act_fwd(c1, None, m1, i1, g1, b1, rows, Cout, 1)
         wp2 = _w_conv_fwd(w2, a1)
         st2 = _conv_bn_stats(a1, wp2, Cout, Cout, KH, KW, rows, training)
-        c2 = ops.conv2d_fwd(a1, wp2, N, OH, OW, Cout, Cout, KH, KW, 1, ph, pw, pr, stats=st2)
+        c2 = ops.conv2d_fwd(a1, wp2, N, OH, OW, Cout, Cout, KH, KW, 1, ph, pw, pr, stats=st2, wp_planes=wpl)
         m2, i2, n2 = _bn_fwd_params(c2, rows, Cout, bn2, training, parts=st2)
         cd = md = idd = nd = None
         if wd is not None:
             bnd = (gd, bd) + bnd
             wpd = _w_conv_fwd(wd, x)
             std = _conv_bn_stats(x, wpd, Cin, Cout, 1, 1, rows, training)
-            cd = ops.conv2d_fwd(x, wpd, N, H, W, Cin, Cout, 1, 1, stride, 0, 0, pr, stats=std)
+            cd = ops.conv2d_fwd(x, wpd, N, H, W, Cin, Cout, 1, 1, stride, 0, 0, pr, stats=std, wp_planes=wpl)
             md, idd, nd = _bn_fwd_params(cd, rows, Cout, bnd, training, parts=std)
             r = ops.bn_act_fwd(cd, None, md, idd, gd, bd, rows, Cout, 0)
         else:

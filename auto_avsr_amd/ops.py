@@ -636,7 +636,7 @@ def conv2d_takes_stats(x, wp, Cin, KH, KW, precise):
     return bool(precise and SPLIT_FAST and x.dtype == torch.float32 and wp.dtype == torch.float32 and Cin % 64 == 0 and KH * KW <= 32)
 
 
-def conv2d_fwd(x, wp, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise, stats=None):
+def conv2d_fwd(x, wp, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise, stats=None, wp_planes=1):
     """stats (conv2d_takes_stats only): [bn_stat_tiles(rows)][2][Cout] f32 (uninitialised) -- receives per 128-row tile the
     per-column sums / sums of squares of y."""
     OH, OW = conv_out(H, KH, stride, ph), conv_out(W, KW, stride, pw)
@@ -649,8 +649,13 @@ def conv2d_fwd(x, wp, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise, stats
         return y
     if x.dtype == torch.float16:  # mixed mode, f16 component: the tiled kernel on IEEE-half operands + the bf16 twin of the result
         assert wp.dtype == torch.float16 and Cin % 64 == 0 and stride <= 2 and not precise
-        call("avsr_conv2d_h16", _ptr(x), _ptr(wp), _ptr(y), _ptr(_twin(y)), _ptr(zero_page(x.device)), N, H, W, Cin, Cout, KH, KW,
-             stride, ph, pw, _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin, nbytes=_nb(x, wp) + 4.0 * N * OH * OW * Cout)
+        # wp: dense [Cout][taps*Cin], or the two-plane image [Cout][2][taps*Cin] (functional._w_conv_h16) with wp_lo = its lo rows
+        # when the component asks for exact weights ("f16x2")
+        two = wp.dim() == 3
+        hi, lo = (wp[:, 0], wp[:, 1] if wp_planes == 2 else None) if two else (wp, None)
+        call("avsr_conv2d_h16", _ptr(x), _ptr(hi), _ptr(lo), hi.stride(0) if two else 0, _ptr(y), _ptr(_twin(y)), _ptr(zero_page(x.device)),
+             N, H, W, Cin, Cout, KH, KW, stride, ph, pw, _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin,
+             nbytes=_nb(x) + (2.0 if lo is not None else 1.0) * 2.0 * Cout * KH * KW * Cin + 4.0 * N * OH * OW * Cout)
         return y
     if precise and SPLIT_FAST and x.dtype == torch.float32 and wp.dtype == torch.float32 and Cin % 64 == 0 and KH * KW <= 32:
         if stats is not None:
@@ -774,16 +779,17 @@ def gemm_f32s_nt(A, lda, B, ldb, M, N, K, C, ldc, *, bias=None, act=0, gate=None
 
 
 def gemm_h16_nt(A, lda, B, ldb, M, N, K, C, ldc, *, bias=None, act=0, drop_p=0.0, seed=0, seed_dev=None, alpha=1.0,
-                resid=None, ldr=0, tile=0, twin=False):
+                resid=None, ldr=0, tile=0, twin=False, B_lo=None):
     """Mixed-mode forward NT GEMM (csrc/gemm_fast.hip, F16 = 1): A and B IEEE half, C f32 / bf16 / f16; twin: a dense f16 / f32
-    activation output also leaves as its bf16 twin (same pitch) for the backward pass."""
-    assert A.dtype == torch.float16 and B.dtype == torch.float16
+    activation output also leaves as its bf16 twin (same pitch) for the backward pass.  B_lo: the scaled lo plane of the weight
+    (same pitch) -- two MFMAs per product, exact weights."""
+    assert A.dtype == torch.float16 and B.dtype == torch.float16 and (B_lo is None or B_lo.dtype == torch.float16)
     c2 = _twin(C) if (twin and C.dtype in (torch.float16, torch.float32) and C.dim() == 2 and C.stride(0) == ldc and C.is_contiguous()) else None
-    call("avsr_gemm_h16_nt", _ptr(A), lda, _ptr(B), ldb, M, N, K, _ptr(bias), act, drop_p, seed, _ptr(seed_dev), alpha,
+    call("avsr_gemm_h16_nt", _ptr(A), lda, _ptr(B), _ptr(B_lo), ldb, M, N, K, _ptr(bias), act, drop_p, seed, _ptr(seed_dev), alpha,
          _ptr(resid), dt(resid) if resid is not None else 0, ldr, _ptr(C), dt(C), ldc, tile, _ptr(c2), ldc, _stream(A),
          flops=2.0 * M * N * K,
-         nbytes=2.0 * (M * K + N * K) + float(M * N * C.element_size()) + (float(M * N * resid.element_size()) if resid is not None else 0.0)
-         + (2.0 * M * N if c2 is not None else 0.0))
+         nbytes=2.0 * (M * K + (2 if B_lo is not None else 1) * N * K) + float(M * N * C.element_size())
+         + (float(M * N * resid.element_size()) if resid is not None else 0.0) + (2.0 * M * N if c2 is not None else 0.0))
     return C
 
 

@@ -210,32 +210,42 @@ def cpu_baseline(modality, odim):
 
 def parity_block(mode):
     """Measured error of THIS run's numerical mode against the reference at the survey's batch A (full-size video model,
-    4 x 400 frames): the numbers tests/test_bench_parity.py asserts on, read from the committed reference golden
-    (tests/golden/golden_bench_v1.pt, generated by tests/golden/make_golden_bench.py from /root/reference)."""
+    4 x 400 frames) and batch B (16 x 100): the numbers tests/test_bench_parity.py asserts on, read from the committed reference
+    goldens (tests/golden/golden_bench_v1.pt + golden_bench_full_v1.pt, generated by tests/golden/make_golden_bench*.py from
+    /root/reference).  `dec_logits_full_rel_l2` is the relative L2 error over the WHOLE decoder-logit tensor pred_pad (B, L+1, 5049)
+    -- the figure the north star's 1e-3 applies to; `ctc_logits_raw_rel_l2` / `enc_full_rel_l2` are the raw CTC-head logits and the
+    encoder output at 8 frames per utterance, all channels, unflattered by any offset (`dec_logits_rel_l2` / `ctc_logp_rel_l2` are
+    round 4's 32-column / log-probability figures, kept for continuity: they read 1.5 - 8x lower)."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import bench_common as BC
 
     from auto_avsr_amd import functional as AF
     from auto_avsr_amd.e2e import E2E
 
-    case = torch.load(BC.FIXTURE, weights_only=False)["A"]
-    AF.invalidate_weight_cache()
-    m = E2E(BC.ODIM, "video")
-    for mod in m.modules():
-        if isinstance(mod, torch.nn.Dropout):
-            mod.p = 0.0
-    m.load_state_dict(BC.bench_state_dict(m.state_dict(), case["seed"]))
-    m = m.cuda().train()
-    with AF.numerics(mode):
-        r = BC.measure(m, case, torch.device("cuda"))
-    AF.invalidate_weight_cache()
-    keep = ("loss_rel_err", "ctc_rel_err", "att_rel_err", "dec_logits_rel_l2", "ctc_logp_rel_l2", "acc", "acc_ref",
-            "grad_sample_cos_min", "grad_sample_rel_l2_median", "grad_norm_rel_err_median")
-    out = {k: (float(f"{r[k]:.3g}") if isinstance(r[k], float) else r[k]) for k in keep}
+    gold = torch.load(BC.FIXTURE, weights_only=False)
+    keep = ("loss_rel_err", "ctc_rel_err", "att_rel_err", "dec_logits_full_rel_l2", "ctc_logits_raw_rel_l2", "enc_full_rel_l2",
+            "dec_logits_rel_l2", "ctc_logp_rel_l2", "acc", "acc_ref", "grad_sample_cos_min", "grad_sample_rel_l2_median",
+            "grad_norm_rel_err_median")
+    out = {}
+    for tag in ("A", "B"):
+        case = gold[tag]
+        AF.invalidate_weight_cache()
+        m = E2E(BC.ODIM, "video")
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        m.load_state_dict(BC.bench_state_dict(m.state_dict(), case["seed"]))
+        m = m.cuda().train()
+        with AF.numerics(mode):
+            r = BC.measure(m, case, torch.device("cuda"))
+        AF.invalidate_weight_cache()
+        del m
+        out[tag] = {k: (float(f"{r[k]:.3g}") if isinstance(r[k], float) else r[k]) for k in keep if k in r}
     out.update(mode={"precise": "precise (split-bf16 forward + backward)", "bf16": "bf16",
                      "hpf": "hpf (split-bf16 forward, bf16 backward)",
-                     "mixed": "mixed (forward: Conformer encoder on f16 operands, front-end / heads / decoder on split-bf16 planes; bf16 backward)"}[mode],
-               batch="A: 4 x 400 frames, 64 labels, reference golden", north_star_tol=1e-3)
+                     "mixed": "mixed (forward: encoder / decoder / ResNet stages 3-4 on f16 activations x two-plane f16 weights, "
+                              "stem / stages 1-2 / projections / heads on split-bf16 planes; bf16 backward)"}[mode],
+               batches="A: 4 x 400 frames, 64 labels; B: 16 x 100 frames, 16 labels; reference goldens", north_star_tol=1e-3)
     return out
 
 

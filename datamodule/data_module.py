@@ -41,9 +41,10 @@ class DeviceBatches:
     reference's per-sample transform chain + padding collation as one device launch per batch (transforms.video_batch /
     audio_batch).  `single` = the test loader (one utterance per item, no padding)."""
 
-    def __init__(self, loader, dataset, device, single=False):
+    def __init__(self, loader, dataset, device, single=False, epoch=0):
         self.loader, self.ds, self.device, self.single = loader, dataset, torch.device(device), single
-        self.epoch = 0
+        self.epoch = epoch  # first epoch this object serves (DataModule counts its train_dataloader() calls)
+        self._seen = getattr(getattr(loader, "sampler", None), "epoch", None)
 
     def __len__(self):
         return len(self.loader)
@@ -67,7 +68,11 @@ class DeviceBatches:
         # (DistributedSampler.set_epoch: a fresh, rank-consistent shuffle per epoch).
         smp = self.sampler
         if hasattr(smp, "set_epoch"):
-            smp.set_epoch(self.epoch)
+            # a trainer that found the sampler (Lightning, through `.sampler`) has already called set_epoch(current_epoch):
+            # never override an epoch set from outside
+            if smp.epoch == self._seen:
+                smp.set_epoch(self.epoch)
+            self._seen = smp.epoch
         self.epoch += 1
         for item in self.loader:
             if self.single:
@@ -136,8 +141,18 @@ class DataModule(_DMBase):
         return AVDataset(root_dir=self.args.root_dir, label_path=os.path.join(self.args.root_dir, "labels", label_file),
                          subset=subset, modality=self.args.modality, audio_transform=at, video_transform=vt)
 
-    def _finish(self, loader, dataset, single=False):
-        return DeviceBatches(loader, dataset, self.device, single) if getattr(dataset, "raw", False) else loader
+    def _finish(self, loader, dataset, single=False, epoch=0):
+        return DeviceBatches(loader, dataset, self.device, single, epoch) if getattr(dataset, "raw", False) else loader
+
+    def _train_epoch(self):
+        """Epoch the next train loader starts at.  train.py reloads the loaders every epoch, so a per-loader counter would
+        restart at 0 and every epoch would replay the same shuffle: the trainer's epoch when one is attached, else the number
+        of loaders handed out so far (the same on every rank)."""
+        tr = getattr(self, "trainer", None)
+        ep = getattr(tr, "current_epoch", None)
+        if ep is None:
+            ep = self._train_loaders = getattr(self, "_train_loaders", -1) + 1
+        return int(ep)
 
     def _workers(self):
         return 0 if getattr(self.args, "synthetic_utterances", 0) else self.num_workers
@@ -162,7 +177,8 @@ class DataModule(_DMBase):
         smp = self._dist_sampler(ds, self.train_shuffle)
         return self._finish(torch.utils.data.DataLoader(ds, num_workers=self._workers(), batch_size=None,
                                                         shuffle=self.train_shuffle and smp is None, sampler=smp,
-                                                        collate_fn=_identity if raw else collate_pad), base)
+                                                        collate_fn=_identity if raw else collate_pad), base,
+                            epoch=self._train_epoch())
 
     def val_dataloader(self):
         base = self._dataset("val", self.args.val_file)

@@ -546,14 +546,19 @@ int avsr_layernorm_fwd_h16(const float* x, const float* gamma, const float* beta
                            int rows, int cols, float eps, avsr_stream_t stream);
 /* C[M,N] = epi(A[M,K] . B[N,K]^T), A and B f16 k-contiguous (lda, ldb % 8 == 0), K % 64 == 0; epilogue +bias -> act -> dropout
  * -> *alpha -> +resid; C f32 / bf16 / f16 (c_dtype 0 / 1 / 2); c2 (may be NULL): bf16 twin of an f32 / f16 C, row pitch ldc2;
- * tile: 0 auto, 1 = 64x64, 4 = 128x128, 7 = 128x64 */
-int avsr_gemm_h16_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias, int act,
+ * tile: 0 auto, 1 = 64x64, 4 = 128x128, 7 = 128x64.
+ * B_lo (round 5; may be NULL): second plane of the WEIGHT, f16((w - B) * 2^11), same pitch ldb -- every product is formed with
+ * both planes (two MFMAs), so the weight enters with ~22 significant bits and only the activation's f16 rounding is left
+ * (decoder-logit error of the mixed mode 0.65x of the one-plane figure).  The forward copies this build keeps are
+ * row-interleaved [N][2][K] (hi row, lo row): B = copy, B_lo = copy + K, ldb = 2 K. */
+int avsr_gemm_h16_nt(const void* A, int lda, const void* B, const void* B_lo, int ldb, int M, int N, int K, const float* bias, int act,
                      float drop_p, uint64_t seed, const uint64_t* seed_dev, float alpha, const void* resid, int resid_dtype,
                      int ldr, void* C, int c_dtype, int ldc, int tile, void* c2, int ldc2, avsr_stream_t stream);
 /* f16 forward convolution (resnet.py:10-35 in the mixed mode): x [N,H,W,Cin] f16 * wp [Cout][KH][KW][Cin] f16 -> y f16 (+ bf16 twin y2,
- * may be NULL); Cin % 64 == 0, stride 1 or 2; wp from avsr_conv_weight_permute (out_dtype 3) / avsr_multi_weight_permute (entry
- * field pad0 = 2) */
-int avsr_conv2d_h16(const void* x, const void* wp, void* y, void* y2, const void* zero_page, int N, int H, int W, int Cin,
+ * may be NULL); Cin % 64 == 0, stride 1 or 2; wp from avsr_conv_weight_permute (out_dtype 3; dense, ldw = 0) or from
+ * avsr_multi_weight_permute (entry field pad0 = 2: the two-plane image [Cout][2][KH][KW][Cin] -> wp = image, wp_lo = image +
+ * KH KW Cin, ldw = 2 KH KW Cin); wp_lo (may be NULL): scaled lo plane of the filter as in avsr_gemm_h16_nt */
+int avsr_conv2d_h16(const void* x, const void* wp, const void* wp_lo, int ldw, void* y, void* y2, const void* zero_page, int N, int H, int W, int Cin,
                     int Cout, int KH, int KW, int stride, int pad_h, int pad_w, avsr_stream_t stream);
 int avsr_head_bias_fwd_h16(const void* x, int64_t ldx, const float* b1, const float* b2, void* o1, void* o2, void* t1, void* t2,
                            int64_t rows, int cols, avsr_stream_t stream);

@@ -45,6 +45,17 @@ def load_pretrained(model, args):
         model.load_state_dict(ckpt)
 
 
+def steps_per_epoch(loader, world):
+    """Optimizer steps per epoch and rank.  The reference divides the length of the UNSHARDED loader by the world size
+    (lightning.py:49); this build's DataModule installs a DistributedSampler itself once a process group is up, and such a
+    loader already reports the per-rank count -- dividing it again would end the cosine schedule after 1 / world of training."""
+    from torch.utils.data.distributed import DistributedSampler
+
+    if isinstance(getattr(loader, "sampler", None), DistributedSampler):
+        return len(loader)
+    return len(loader) / world
+
+
 class ModelModule(_Base):
     def __init__(self, args):
         super().__init__()
@@ -83,7 +94,7 @@ class ModelModule(_Base):
         return opt, sched
 
     def configure_optimizers(self):
-        n = len(self.trainer.datamodule.train_dataloader()) / self.trainer.num_devices / self.trainer.num_nodes
+        n = steps_per_epoch(self.trainer.datamodule.train_dataloader(), self.trainer.num_devices * self.trainer.num_nodes)
         opt, sched = self.make_optimizer(n)
         return [opt], [{"scheduler": sched, "interval": "step"}]
 

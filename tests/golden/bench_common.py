@@ -9,6 +9,7 @@ from synth import _gen, synth_state_dict
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 FIXTURE = os.path.join(HERE, "golden_bench_v1.pt")
+FIXTURE_FULL = os.path.join(HERE, "golden_bench_full_v1.pt")  # round 5: whole tensors (make_golden_bench_full.py)
 FAV = 17
 ODIM = 5049
 NSAMP = 64
@@ -45,6 +46,27 @@ def bench_batch(lengths, L, seed, modality="video"):
         lab[::5] = FAV
         y[b, 0, :n] = lab
     return x, torch.tensor(lengths, dtype=torch.int64) * (1 if modality == "video" else 640), y
+
+
+def raw_frames(nfr):
+    """Frames at which the whole-tensor fixture keeps the raw CTC logits / the encoder output of every utterance."""
+    return torch.linspace(0, nfr - 1, 8).round().long()
+
+
+def load_full(tag):
+    """The whole-tensor reference outputs of case `tag` (None when the fixture is absent)."""
+    if not os.path.exists(FIXTURE_FULL):
+        return None
+    return torch.load(FIXTURE_FULL, weights_only=False)[tag]
+
+
+def full_errors(full, dec, ctc, enc):
+    """Unflattered forward errors: relative L2 over the WHOLE decoder-logit tensor `pred_pad` (B, L+1, V), over the RAW CTC
+    logits and over the encoder output at the fixture's frames.  `dec` (B, L+1, >=V), `ctc` (B, T, >=V), `enc` (B, T, D)."""
+    ts = full["tsel_raw"]
+    return {"dec_logits_full_rel_l2": rel(dec.float().cpu()[..., :ODIM], full["pred_pad"]),
+            "ctc_logits_raw_rel_l2": rel(ctc.float().cpu()[:, ts][..., :ODIM], full["ys_hat"]),
+            "enc_full_rel_l2": rel(enc.float().cpu()[:, ts], full["enc"])}
 
 
 def rel(a, b):
@@ -86,6 +108,9 @@ def measure(model, case, device):
     ctc_logp = torch.log_softmax(ctc, -1)[:, tsel][:, :, vcols]
     out["ctc_logp_rel_l2"] = rel(ctc_logp, case["ctc_logp"])
     out["enc_rel_l2"] = rel(grab["enc"].float().cpu()[:, tsel, :32], case["enc"])
+    full = load_full(case["tag"])
+    if full is not None:
+        out.update(full_errors(full, grab["dec"], grab["ctc"], grab["enc"]))
     gmax = max(case["grad_norms"].values())
     norm_err, cos, samp = [], [], []
     worst = {}

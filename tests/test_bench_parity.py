@@ -59,6 +59,20 @@ def test_bench_shape_parity(gold, tag, mode):
         {k: (round(v, 7) if isinstance(v, float) else v) for k, v in r.items()}))
     # the north-star bound in every mode: the three losses within 1e-3 relative
     assert r["loss_rel_err"] < 1e-3 and r["ctc_rel_err"] < 1e-3 and r["att_rel_err"] < 1e-3
+    # round 5: WHOLE tensors (golden_bench_full_v1.pt: the reference's pred_pad (B, L+1, 5049), its raw CTC logits and encoder
+    # output at 8 frames per utterance) -- plain relative L2, no selected columns, no log-softmax offset
+    full, raw, enc = r["dec_logits_full_rel_l2"], r["ctc_logits_raw_rel_l2"], r["enc_full_rel_l2"]
+    if mode in ("precise", "hpf"):
+        assert full < 1e-4 and raw < 1e-4 and enc < 1e-4
+    elif mode == "mixed":
+        # THE BENCHMARKED MODE: the whole decoder-logit tensor inside the north star's 1e-3 with >= 20 % in hand at every
+        # benchmarked shape (CPU model of the policy, tools/precision_study.py "mixed=f16a": 5.4e-4 / 6.3e-4 at A / B).  The
+        # raw CTC logits and the encoder output carry the encoder's accumulated f16 activation rounding (~2e-3; the CTC LOSS,
+        # which the bound names, is at 1e-5): bounded here so that a regression shows
+        assert full < 8e-4, full
+        assert raw < 3e-3 and enc < 3e-3
+    else:
+        assert full < 1.5e-2 and raw < 4e-2 and enc < 4e-2
     if mode == "precise":
         assert r["dec_logits_rel_l2"] < 1e-3 and r["ctc_logp_rel_l2"] < 1e-3 and r["enc_rel_l2"] < 1e-3
         assert r["acc"] == pytest.approx(r["acc_ref"], abs=1e-6) and r["acc_ref"] > 0.1

@@ -116,3 +116,45 @@ def test_datamodule_shards_wrapped_loaders_across_ranks(dev, tmp_path, monkeypat
         assert len(set(a) | set(b)) == nb          # the two ranks cover every batch of the epoch ...
         assert len(set(a) & set(b)) == 2 * len(a) - nb  # ... sharing only the DistributedSampler's padding batch (odd counts)
     assert seen[0][0] != seen[0][1]                # a fresh shuffle per epoch
+
+
+def test_reloaded_train_loaders_reshuffle_and_schedule_length(dev, tmp_path, monkeypatch):
+    """Round-4 advisor findings.  (1) train.py reloads the loaders every epoch: each fresh DeviceBatches must start at the
+    DataModule's epoch, not at 0 (the same batch order every epoch), and must not override an epoch a trainer set through
+    `.sampler`.  (2) a loader that carries its own DistributedSampler already reports the PER-RANK batch count:
+    lightning.steps_per_epoch must not divide it by the world size again (the cosine schedule would end after 1 / world)."""
+    import torch.distributed as dist
+
+    import lightning as LM
+    from datamodule.data_module import DataModule
+
+    root = str(tmp_path)
+    _write_tree(root, 23, "audio")
+    monkeypatch.setattr(TR, "load_default_noise", lambda: torch.randn(1, 40000, generator=torch.Generator().manual_seed(3)))
+    args = types.SimpleNamespace(root_dir=root, modality="audio", train_file="train.csv", val_file="val.csv", test_file="test.csv",
+                                 max_frames=30, synthetic_utterances=0)
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 2)
+    monkeypatch.setattr(dist, "get_rank", lambda group=None: 0)
+    dm = DataModule(args, num_workers=0, device=str(dev))
+    key = lambda loader: [tuple(b["input_lengths"].tolist()) + tuple(b["targets"].flatten().tolist()) for b in loader]  # noqa: E731
+    first, second = key(dm.train_dataloader()), key(dm.train_dataloader())  # one fresh loader per epoch, as train.py asks for
+    assert first != second and sorted(first) != [] and len(first) == len(second)
+    # a trainer's set_epoch wins: two loaders given the same epoch from outside replay the same order
+    la, lb = dm.train_dataloader(), dm.train_dataloader()
+    la.sampler.set_epoch(7)
+    lb.sampler.set_epoch(7)
+    ka = key(la)
+    assert ka == key(lb)
+    # with a trainer attached the epoch comes from it
+    dm.trainer = types.SimpleNamespace(current_epoch=7)
+    assert key(dm.train_dataloader()) == ka
+    del dm.trainer
+    # schedule length: per-rank count taken as it is when the loader is sharded, divided when it is not
+    loader = dm.train_dataloader()
+    nb = len(loader.loader.dataset)
+    assert len(loader) == (nb + 1) // 2
+    assert LM.steps_per_epoch(loader, 2) == (nb + 1) // 2
+    monkeypatch.setattr(dist, "is_initialized", lambda: False)
+    plain = DataModule(args, num_workers=0, device=str(dev)).train_dataloader()
+    assert len(plain) == nb and LM.steps_per_epoch(plain, 2) == nb / 2

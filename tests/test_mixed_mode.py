@@ -174,6 +174,78 @@ def test_dwconv_bn_f16(dev, twins):
     assert float(flat[-1]) == B * T
 
 
+def _planes(w):
+    """hi / scaled-lo f16 planes of an f32 weight as the kernels define them (csrc/prims.h f2h_lo)."""
+    hi = w.half()
+    return hi, ((w - hi.float()) * 2048.0).half()
+
+
+@pytest.mark.parametrize("tile", [0, 1, 21, 7, 2, 4])
+@pytest.mark.parametrize("shape", [(150, 70, 192), (257, 300, 448), (130, 136, 64)])
+def test_gemm_h16x2_nt(dev, tile, shape, twins):
+    """Two weight planes (round 5): products with the EXACT f32 weight up to ~2^-22, f16 activations.  Against float64 math on
+    the f16-rounded activations and the unrounded weight; the one-plane kernel on the same data is >= 20x further off.  The planes
+    come from the multi-tensor cast the training step uses (functional._w_h16) and, for the pitch / slice handling, from torch."""
+    M, N, K = shape
+    torch.manual_seed(M + tile)
+    A, W = torch.randn(M, K).half(), 0.1 * torch.randn(N, K)
+    W[0, :8] = torch.tensor([0.0, 1e-7, -3e-6, 6.1e-5, 0.25, -0.2500001, 1.0, 3.7e-3])  # zeros, sub-f16-normal values, binade edges
+    ref = A.double() @ W.double().t()
+    AF.invalidate_weight_cache()
+    Wd = W.to(dev)
+    buf = AF._w_h16(Wd)
+    hi, lo = _planes(W)
+    assert buf.shape == (N, 2, K) and torch.equal(buf[:, 0].cpu(), hi) and torch.equal(buf[:, 1].cpu(), lo)
+    C = torch.zeros(M, N + 3, device=dev)
+    ops.gemm_h16_nt(A.to(dev), K, buf[:, 0], 2 * K, M, N, K, C, N + 3, tile=tile, B_lo=buf[:, 1])
+    e2 = float((C.cpu()[:, :N].double() - ref).abs().max() / ref.abs().max())
+    assert e2 < 3e-6 and C.cpu()[:, N:].abs().max() == 0, e2
+    C1 = torch.zeros(M, N, device=dev)
+    ops.gemm_h16_nt(A.to(dev), K, buf[:, 0], 2 * K, M, N, K, C1, N, tile=1 if tile == 21 else tile)
+    assert rel(C1, ref) > 20 * rel(C[:, :N], ref)
+    # epilogue + f16 output + twin, through the host helper the sub-layers call
+    bias, resid = torch.randn(N), torch.randn(M, N)
+    C2 = torch.zeros(M, N, device=dev, dtype=torch.float16)
+    AF._h16_nt(A.to(dev), K, buf, M, N, K, C2, N, planes=2, bias=bias.to(dev), act=1, alpha=0.5, resid=resid.to(dev), ldr=N, tile=tile,
+               twin=(N % 8 == 0))
+    ref2 = torch.relu(ref + bias.double()) * 0.5 + resid.double()
+    assert ((C2.cpu().double() - ref2).abs().max() / ref2.abs().max()) < 1.5e-3  # one f16 rounding of the result
+    if N % 8 == 0:
+        (y, tw), = twins
+        assert y is C2 and rel(tw.float(), ref2) < 4e-3
+    AF.invalidate_weight_cache()
+
+
+@pytest.mark.parametrize("geom", [(3, 11, 11, 64, 128, 3, 2), (2, 6, 6, 128, 128, 3, 1), (3, 11, 11, 64, 128, 1, 2), (2, 22, 22, 64, 64, 3, 1)])
+@pytest.mark.parametrize("tile", [0, 4])
+def test_conv2d_h16x2(dev, geom, tile, twins):
+    """Implicit-GEMM convolution with two filter planes: exact filter, f16 activations (float64 math on the same data)."""
+    N, H, W, Cin, Cout, KH, stride = geom
+    pad = (KH - 1) // 2
+    torch.manual_seed(N + H)
+    x = torch.randn(N, H, W, Cin).half()
+    w = (0.1 * torch.randn(Cout, Cin, KH, KH))
+    AF.invalidate_weight_cache()
+    wd = w.to(dev)
+    buf = AF._w_conv_h16(wd)
+    wperm = w.permute(0, 2, 3, 1).reshape(Cout, -1)
+    hi, lo = _planes(wperm)
+    assert buf.shape == (Cout, 2, KH * KH * Cin) and torch.equal(buf[:, 0].cpu(), hi) and torch.equal(buf[:, 1].cpu(), lo)
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double(), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    ops.tune(18, tile)
+    try:
+        y = ops.conv2d_fwd(x.to(dev), buf, N, H, W, Cin, Cout, KH, KH, stride, pad, pad, False, wp_planes=2)
+    finally:
+        ops.tune(18, 0)
+    assert y.dtype == torch.float16 and rel(y.float(), ref) < 2.5e-4  # (the f16 rounding of the OUTPUT: 2^-12 rms)
+    (yy, tw), = twins
+    assert yy is y and rel(tw.float(), ref) < 4e-3
+    y1 = ops.conv2d_fwd(x.to(dev), buf, N, H, W, Cin, Cout, KH, KH, stride, pad, pad, False, wp_planes=1)
+    ref1 = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.half().double(), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    assert rel(y1.float(), ref1) < 2.5e-4  # one plane = the hi rows of the same image
+    AF.invalidate_weight_cache()
+
+
 @pytest.mark.parametrize("geom", [(3, 11, 11, 64, 128, 3, 2), (2, 6, 6, 128, 128, 3, 1), (3, 11, 11, 64, 128, 1, 2), (2, 22, 22, 64, 64, 3, 1)])
 def test_conv2d_h16(dev, geom, twins):
     """Implicit-GEMM convolution on f16 operands (trunk stages of the mixed mode) vs torch on the same f16-rounded data."""
@@ -244,11 +316,12 @@ POLICIES = {
     "default": None,
     "default-casts": None,  # no producer-side twins (what tensors below functional._TWIN_MIN get): save-time casts, same layouts
     "encoder-only": {"encoder": "f16"},
+    "one-plane": {"encoder": "f16", "decoder": "f16", "trunk3": "f16", "trunk4": "f16", "atrunk3": "f16", "atrunk4": "f16"},  # round 4's default
     "all-split": {},
 }
 
 
-@pytest.mark.parametrize("modality,policy", [("video", "default"), ("video", "default-casts"), ("video", "all-split"),
+@pytest.mark.parametrize("modality,policy", [("video", "default"), ("video", "default-casts"), ("video", "all-split"), ("video", "one-plane"),
                                              ("audio", "default")])
 def test_e2e_small_mixed_mode(dev, modality, policy, monkeypatch):
     """Small E2E instance in the mixed mode against the fp32 oracle: losses inside the north-star bound (1e-3; f16 operands

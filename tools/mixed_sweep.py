@@ -1,6 +1,6 @@
 """Forward-format policy sweep of the mixed numerical mode on the MI355X: parity of the full-size video model against the
 reference goldens at the survey's batch A and batch B (tests/golden/golden_bench_v1.pt) for a list of policies
-(functional.MIXED_POLICY: component -> "f16" | "split").  One model per batch, re-used by every policy.
+(functional.MIXED_POLICY: component -> "f16" | "f16x2" | "split"); round 5: whole-tensor errors first.  One model per batch, re-used by every policy.
     python tools/mixed_sweep.py [policy ...]          # policy = "encoder=f16,trunk1=f16,..." ("" = everything on split planes)"""
 import json
 import os
@@ -41,4 +41,5 @@ for tag in tags:
         with AF.numerics("mixed"):
             r = BC.measure(m, case, torch.device("cuda"))
         print(json.dumps({"batch": tag, "policy": pol, **{k: float(f"{r[k]:.3g}") for k in (
-            "dec_logits_rel_l2", "ctc_logp_rel_l2", "loss_rel_err", "grad_sample_cos_min", "grad_sample_rel_l2_median")}}), flush=True)
+            "dec_logits_full_rel_l2", "ctc_logits_raw_rel_l2", "enc_full_rel_l2", "dec_logits_rel_l2", "ctc_logp_rel_l2", "loss_rel_err",
+            "grad_sample_cos_min", "grad_sample_rel_l2_median") if k in r}}), flush=True)

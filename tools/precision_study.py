@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 from oracle import avsr_oracle as O  # noqa: E402
-from bench_common import BATCHES, FIXTURE, ODIM, bench_batch, bench_state_dict, rel  # noqa: E402
+from bench_common import BATCHES, FIXTURE, ODIM, bench_batch, bench_state_dict, full_errors, load_full, rel  # noqa: E402
 
 GROUPS = ["stem", "trunk", "trunk1", "trunk2", "trunk3", "trunk4", "proj", "enc_ffn", "enc_attn_proj", "enc_attn_q", "enc_attn_k", "enc_attn_v",
           "enc_attn_out", "enc_attn_pos", "enc_attn_core", "enc_conv", "ctc_head", "dec", "dec_out"]
@@ -33,7 +33,12 @@ CFG = {}
 STATS = {}
 
 
+_exact_layer = [False]  # inside an encoder layer that `enc_exact_layers=N` keeps on exact (split-plane) arithmetic
+
+
 def q(x, fmt, is_w=False):
+    if _exact_layer[0]:
+        return x
     if fmt == "f16a":
         fmt = None if is_w else "f16"
     if fmt == "f16w":
@@ -155,6 +160,17 @@ def install():
 
     O.video_frontend = video_frontend
     del orig_vf
+    orig_layer = O.encoder_layer
+
+    def encoder_layer(sd, pre, *a, **kw):
+        n = int(pre.rstrip(".").rsplit(".", 1)[1])
+        _exact_layer[0] = n < int(CFG.get("enc_exact_layers", 0)) or n >= 12 - int(CFG.get("enc_exact_last", 0))
+        try:
+            return orig_layer(sd, pre, *a, **kw)
+        finally:
+            _exact_layer[0] = False
+
+    O.encoder_layer = encoder_layer
 
 
 TRACE = None  # --layers: [(name, tensor)] outputs of the blocks, in execution order
@@ -187,6 +203,10 @@ def run(case, sd, batch, layer_probe=None):
                dec_logits=rel(mid["pred"][:, :, vcols], case["dec_logits"]),
                ctc_logp=rel(torch.log_softmax(ctc, -1)[:, tsel][:, :, vcols], case["ctc_logp"]),
                enc=rel(mid["enc"][:, tsel, :32], case["enc"]), acc=acc)
+    full = load_full(case["tag"])
+    if full is not None:  # round 5: whole-tensor errors (decoder logits, RAW CTC logits, encoder output)
+        fe = full_errors(full, mid["pred"], ctc, mid["enc"])
+        out.update(dec_full=fe["dec_logits_full_rel_l2"], ctc_raw=fe["ctc_logits_raw_rel_l2"], enc_full=fe["enc_full_rel_l2"])
     return out, mid
 
 
@@ -200,6 +220,14 @@ def parse(spec):
             for g in GROUPS:
                 if not g[-1].isdigit() and g not in ("enc_attn_q", "enc_attn_k", "enc_attn_v", "enc_attn_out", "enc_attn_pos"):  # refinements: only when named explicitly
                     cfg[g] = v
+        elif k == "mixed":  # the round-4 default policy with format v
+            for g in ("trunk3", "trunk4", "enc_ffn", "enc_attn_proj", "enc_attn_core", "enc_conv", "dec"):
+                cfg[g] = v
+        elif k == "enc":
+            for g in ("enc_ffn", "enc_attn_proj", "enc_attn_core", "enc_conv"):
+                cfg[g] = v
+        elif k in ("enc_exact_layers", "enc_exact_last"):
+            cfg[k] = v
         else:
             assert k in GROUPS, k
             cfg[k] = v
@@ -228,6 +256,7 @@ if __name__ == "__main__":
     m = E2E(ODIM, "video")
     sd = bench_state_dict(m.state_dict(), cfgb["seed"])
     batch = bench_batch(cfgb["lengths"], cfgb["L"], cfgb["seed"])
+    assert cfgb.get("modality", "video") == "video", "the study wraps the video front-end only"
     if args.layers:
         MIXED = "trunk3=f16,trunk4=f16,enc_ffn=f16,enc_attn_proj=f16,enc_attn_core=f16,enc_conv=f16,dec=f16"  # functional.MIXED_POLICY
         cols = {}
