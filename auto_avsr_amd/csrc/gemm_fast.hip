@@ -173,7 +173,9 @@ static int gemm16_nt_impl(int f16, const void* A, int lda, const void* B, const 
         if (auto_tile) {
             // the A tile serves both planes: a 128-row tile once the grid fills the chip with them, else 64x64 (knob 17: A/B)
             const long t12864 = (long)((M + 127) / 128) * ((N + 63) / 64);
-            tile = g_tune[17] > 0 ? g_tune[17] : (t12864 >= 256 ? 7 : 1);
+            // measured (tools/microbench_h16x2.py, us): 1600x768x768 11.5 (64x64) / 12.9 (128x64); 1600x3072x768 35.2 / 28.2;
+            // 1600x768x3072 35.4 / 32.2 with the 3-stage 128x64 ring (a long k loop amortises the fewer, fatter blocks)
+            tile = g_tune[17] > 0 ? g_tune[17] : (t12864 >= 256 ? 7 : (K >= 2048 && t12864 >= 128 ? 2 : 1));
         }
         AVSR_REQUIRE(launch_tile_h16x2<0>(tile, p, split_k, stream), "gemm_h16_nt: unknown tile code (two weight planes)");
         AVSR_CHECK_LAUNCH("gemm_h16_nt");

@@ -39,7 +39,7 @@ class _NullCtx:
 
 
 class GradBuckets:
-    def __init__(self, params, group=None, bucket_mb=None, comm=None, wire=None):
+    def __init__(self, params, group=None, bucket_mb=None, comm=None, wire=None, spare=72):
         """bucket_mb: bucket size in MB of f32 gradients (default 64, environment AVSR_BUCKET_MB overrides: sweep hook).
         wire: "f32" (default) or "bf16" (environment AVSR_GRAD_WIRE): the format the buckets travel in.  bf16 halves the bytes
         per xGMI link -- the exchange of 1.0 GB of f32 gradients is per-link bound on a ring -- at the
@@ -49,8 +49,11 @@ class GradBuckets:
 
         if bucket_mb is None:
             bucket_mb = float(os.environ.get("AVSR_BUCKET_MB", "64"))
-        self.wire = wire or os.environ.get("AVSR_GRAD_WIRE", "f32")
+        self.wire = os.environ.get("AVSR_GRAD_WIRE") or wire or "f32"  # (the environment wins: sweep hook)
         assert self.wire in ("f32", "bf16"), self.wire
+        if self.wire == "bf16" and comm is None:
+            self.wire = "f32"  # the narrow format needs a stream communicator; torch.distributed groups travel as f32
+        self.timing = None  # set by time_next_step(): per-bucket events of ONE eager step (diagnostics)
         self.params = [p for p in params if p.requires_grad]
         assert self.params and all(p.dtype == torch.float32 for p in self.params)
         self.group = group
@@ -87,7 +90,7 @@ class GradBuckets:
         # rewritten only after the asynchronous copy that last read them has completed.  Everything pinned is allocated HERE
         # (hipHostMalloc is not allowed under stream capture).
         self._captured = {}  # (bucket, gradient addresses) -> (host rows, device table, blocks)
-        self._spare = [[self._new_slot(len(m)) for _ in range(24)] for m in members]  # for captured steps (one per batch shape)
+        self._spare = [[self._new_slot(len(m)) for _ in range(spare)] for m in members]  # for captured steps (one per batch shape)
         self._ring = [[self._new_slot(len(m)) for _ in range(4)] for m in members]    # for eager steps
         self._ring_pos = [0] * len(members)
         self.compute_stream = None  # set by begin_step(): the stream the step's kernels are issued on
@@ -138,7 +141,7 @@ class GradBuckets:
             ent = self._captured.get((b,) + ptrs)
             if ent is None:
                 if not self._spare[b]:
-                    raise RuntimeError("GradBuckets: out of pre-pinned table buffers under hipGraph capture (24 captured step shapes per bucket)")
+                    raise RuntimeError("GradBuckets: out of pre-pinned table buffers under hipGraph capture (`spare` captured step shapes per bucket)")
                 host, dev, _ = self._spare[b].pop()
                 fill(host)
                 ent = self._captured[(b,) + ptrs] = (host, dev, blocks)
@@ -183,11 +186,16 @@ class GradBuckets:
                 if self._side is not None:
                     self._side.wait_stream(torch.cuda.current_stream())
                 with (torch.cuda.stream(self._side) if self._side is not None else _NullCtx()):
-                    self._reduce(b)
+                    if self.timing is not None and self._side is not None:
+                        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                        ev[0].record()
+                        self._reduce(b)
+                        ev[1].record()
+                        self.timing["buckets"].append((b, ev))
+                    else:
+                        self._reduce(b)
                 self._side_used = self._side is not None
             elif self.world > 1 or self.group is not None:
-                if self.wire == "bf16":
-                    raise RuntimeError("GradBuckets: the bf16 wire format needs a stream communicator (comm=)")
                 self._works.append(dist.all_reduce(self.flat[b], group=self.group, async_op=True))
 
     def _reduce(self, b):
@@ -215,9 +223,38 @@ class GradBuckets:
             w.wait()
         self._works.clear()
         if self._side_used:
+            if self.timing is not None:
+                self.timing["bwd_end"] = torch.cuda.Event(enable_timing=True)
+                self.timing["bwd_end"].record()
             torch.cuda.current_stream().wait_stream(self._side)
+            if self.timing is not None:
+                self.timing["joined"] = torch.cuda.Event(enable_timing=True)
+                self.timing["joined"].record()
             self._side_used = False
         self._left = [len(m) for m in self.members]
+
+    def time_next_step(self):
+        """Diagnostics: the next EAGER step records an event pair around every bucket's exchange on the side stream and around
+        the join at the end of the backward pass.  Stream communicators on a GPU only."""
+        self.timing = {"buckets": [], "t0": None}
+        if self.device.type == "cuda":
+            self.timing["t0"] = torch.cuda.Event(enable_timing=True)
+            self.timing["t0"].record()
+
+    def timing_report(self):
+        """After time_next_step() + one eager step + a device synchronisation: per bucket (in flush order) its size, when its
+        exchange started and ended relative to the start of the step, and how long the compute stream stood waiting at the
+        join -- the part of the gradient exchange that the backward pass did NOT hide."""
+        t, self.timing = self.timing, None
+        if not t or t.get("t0") is None or "joined" not in t:
+            return None
+        t0 = t["t0"]
+        rows = [{"bucket": b, "mb": round(self.flat[b].numel() * (2 if self.wire == "bf16" else 4) / 2 ** 20, 1),
+                 "start_ms": round(t0.elapsed_time(ev[0]), 3), "end_ms": round(t0.elapsed_time(ev[1]), 3)} for b, ev in t["buckets"]]
+        return {"wire": self.wire, "buckets": rows, "backward_done_ms": round(t0.elapsed_time(t["bwd_end"]), 3),
+                "exchange_done_ms": round(t0.elapsed_time(t["joined"]), 3),
+                "exposed_ms": round(t["bwd_end"].elapsed_time(t["joined"]), 3),
+                "sum_exchange_ms": round(sum(r["end_ms"] - r["start_ms"] for r in rows), 3)}
 
     def remove(self):
         for h in self._hooks:

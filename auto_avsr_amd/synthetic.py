@@ -35,10 +35,14 @@ def bucket_batches(lengths, max_frames=1600, num_buckets=400):
     return batches
 
 
-def make_batch(lengths, idxs, modality="video", odim=5049, seed=0, device="cpu"):
+def make_batch(lengths, idxs, modality="video", odim=5049, seed=0, device="cpu", on_device=False):
     """One collated batch: inputs (B,T,1,88,88) [audio: (B,640T,1)] zero-padded, input_lengths (B,),
-    targets (B,1,L) padded with -1; L_i = max(1, round(T_i/6.5)) ids uniform in [1, odim-2]."""
+    targets (B,1,L) padded with -1; L_i = max(1, round(T_i/6.5)) ids uniform in [1, odim-2].
+    on_device: draw the input samples with the DEVICE's generator (a training loop that makes a fresh batch per step cannot wait
+    80 ms for 12 M host-side normal deviates + a 50 MB upload in front of a 22 ms step); labels / lengths as always."""
     g = torch.Generator().manual_seed(10007 * seed + 17)
+    if on_device and torch.device(device).type != "cpu":
+        return _make_batch_on_device(lengths, idxs, modality, odim, seed, torch.device(device), g)
     ts = [int(lengths[i]) for i in idxs]
     B, T = len(ts), max(ts)
     ls = [max(1, int(round(t / 6.5))) for t in ts]
@@ -58,6 +62,31 @@ def make_batch(lengths, idxs, modality="video", odim=5049, seed=0, device="cpu")
             x[b, : t * 640, 0] = (w - w.mean()) / w.std()
         lens = torch.tensor(ts, dtype=torch.int64) * 640
     return x.to(device), lens.to(device), y.to(device), sum(ts)
+
+
+def _make_batch_on_device(lengths, idxs, modality, odim, seed, dev, g):
+    gd = torch.Generator(device=dev).manual_seed(10007 * seed + 17)
+    ts = [int(lengths[i]) for i in idxs]
+    B, T = len(ts), max(ts)
+    ls = [max(1, int(round(t / 6.5))) for t in ts]
+    y = torch.full((B, 1, max(ls)), -1, dtype=torch.int64)
+    for b, n in enumerate(ls):
+        y[b, 0, :n] = torch.randint(1, odim - 1, (n,), generator=g)
+    tl = torch.tensor(ts, dtype=torch.int64)
+    if modality == "video":
+        x = torch.randn(B, T, 1, 88, 88, device=dev, generator=gd)
+        x *= (torch.arange(T, device=dev)[None, :] < tl.to(dev)[:, None]).view(B, T, 1, 1, 1)  # zero padding
+        lens = tl
+    else:
+        x = torch.randn(B, T * 640, device=dev, generator=gd)
+        valid = torch.arange(T * 640, device=dev)[None, :] < (tl.to(dev) * 640)[:, None]
+        x = x * valid
+        n = (tl.to(dev) * 640).float()[:, None]
+        mean = x.sum(1, keepdim=True) / n
+        var = (((x - mean) * valid) ** 2).sum(1, keepdim=True) / (n - 1)
+        x = (((x - mean) / var.sqrt()) * valid).unsqueeze(-1)
+        lens = tl * 640
+    return x, lens.to(dev), y.to(dev), sum(ts)
 
 
 def rank_batches(batches, rank, world, seed=0):

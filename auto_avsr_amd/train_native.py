@@ -81,6 +81,67 @@ def validate(model, batches, world):
             "decoder_acc_val": float(tot[3]) / n}
 
 
+class _SyntheticSource:
+    """The synthetic LRS3-shaped corpus: length-bucketed batches, a fresh seeded order per epoch and rank."""
+
+    def __init__(self, args, model, dev, rank, world):
+        from .synthetic import bucket_batches, utterance_lengths
+
+        self.args, self.odim, self.dev, self.rank, self.world = args, model.odim, dev, rank, world
+        self.lengths = utterance_lengths(getattr(args, "synthetic_utterances", 0) or 20000)
+        self.all_batches = bucket_batches(self.lengths, args.max_frames, args.train_num_buckets)
+        self.steps_per_epoch = (len(self.all_batches) + world - 1) // world
+
+    def epoch(self, epoch, global_step):
+        from .synthetic import make_batch, rank_batches
+
+        batches = rank_batches(self.all_batches, self.rank, self.world, seed=epoch)
+        assert len(batches) == self.steps_per_epoch
+        for i, idxs in enumerate(batches):
+            x, lens, y, _ = make_batch(self.lengths, idxs, self.args.modality, self.odim, seed=global_step + i, device=self.dev,
+                                       on_device=True)
+            yield x, lens, y
+
+    def val_batches(self, n):
+        from .synthetic import bucket_batches, make_batch, rank_batches, utterance_lengths
+
+        val_lengths = utterance_lengths(2000, seed=43)
+        val_all = bucket_batches(val_lengths, 1000, 1)  # val_dataloader: max_frames 1000, one bucket (data_module.py:156-158)
+        return [make_batch(val_lengths, b, self.args.modality, self.odim, seed=10_000 + i, device=self.dev)
+                for i, b in enumerate(rank_batches(val_all, self.rank, self.world, seed=1)[:n])]
+
+
+class _FileSource:
+    """File-backed data through the reference's DataModule surface (datamodule/data_module.py: AVDataset + CustomBucketDataset +
+    the device-side transform / collation of DeviceBatches), sharded across ranks by the DistributedSampler DataModule installs."""
+
+    def __init__(self, args, model, dev, rank, world):
+        from datamodule.data_module import DataModule
+
+        self.dm = DataModule(args, train_num_buckets=args.train_num_buckets, device=str(dev))
+        self.dev = dev
+        self.steps_per_epoch = len(self.dm.train_dataloader())
+
+    def _triples(self, loader):
+        for b in loader:
+            yield b["inputs"].to(self.dev), b["input_lengths"].to(self.dev), b["targets"].to(self.dev)
+
+    def epoch(self, epoch, global_step):
+        self.dm._train_loaders = epoch - 1  # (DataModule._train_epoch: the loader handed out next serves this epoch)
+        return self._triples(self.dm.train_dataloader())
+
+    def val_batches(self, n):
+        import itertools
+
+        return [(x, l, y, None) for x, l, y in itertools.islice(self._triples(self.dm.val_dataloader()), n)] if n else []
+
+
+def _batch_source(args, model, dev, rank, world):
+    if getattr(args, "synthetic", False) or not getattr(args, "train_file", None):
+        return _SyntheticSource(args, model, dev, rank, world)
+    return _FileSource(args, model, dev, rank, world)
+
+
 def fit(model, args, dev, rank=0, world=1, backend="nccl", log=print):
     """The training loop proper, on an already constructed `E2E`-like model (tests run it on a small instance over
     gloo + the emulator).  Returns the list of per-step losses of this rank.  Whatever the loop attached to the model or the
@@ -89,10 +150,13 @@ def fit(model, args, dev, rank=0, world=1, backend="nccl", log=print):
     starts clean instead of running two hook sets on stale communicators."""
     from . import functional as AF
 
-    held = {"buckets": None, "comms": []}
+    held = {"buckets": None, "comms": [], "stepper": None}
+    old_mode = AF._save_mode()
     try:
         return _fit(model, args, dev, rank, world, backend, log, held)
     finally:
+        AF._restore_mode(old_mode)
+        fit.last_stats = dict(held["stepper"].stats, tail_ms=held.get("tail_ms")) if held["stepper"] is not None else None
         if held["buckets"] is not None:
             held["buckets"].remove()
         for c in held["comms"]:
@@ -103,8 +167,6 @@ def fit(model, args, dev, rank=0, world=1, backend="nccl", log=print):
 def _fit(model, args, dev, rank, world, backend, log, held):
     from . import functional as AF
     from .optim import FusedAdamW
-    from .synthetic import bucket_batches, make_batch, rank_batches, utterance_lengths
-
     AF.manual_seed(42 + rank)
     seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
     AF.set_seed_tensor(seed_dev)
@@ -126,16 +188,16 @@ def _fit(model, args, dev, rank, world, backend, log, held):
                 comm_bn, comm_grads = StreamComm.from_process_group(), StreamComm.from_process_group()
                 held["comms"] += [comm_bn, comm_grads]
                 AF.set_bn_sync(dist.group.WORLD, comm=comm_bn)
-            buckets = held["buckets"] = GradBuckets(model.parameters(), group=dist.group.WORLD, comm=comm_grads)
+            wire = "f32" if (getattr(args, "numerics", None) or AF.mode()) == "precise" else "bf16"  # (bf16 backward: bf16 wire)
+            buckets = held["buckets"] = GradBuckets(model.parameters(), group=dist.group.WORLD, comm=comm_grads, wire=wire)
         else:
             hot = torch.nn.parallel.DistributedDataParallel(
                 hot, device_ids=[dev.index] if dev.type == "cuda" else None, find_unused_parameters=False,
                 broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=64)
-    lengths = utterance_lengths(getattr(args, "synthetic_utterances", 0) or 20000)
-    all_batches = bucket_batches(lengths, args.max_frames, args.train_num_buckets)
+    source = _batch_source(args, model, dev, rank, world)
     # every rank sees the same number of batches per epoch (DistributedSampler pads): the schedule lengths below and the
     # number of collectives per epoch are identical on all ranks
-    steps_per_epoch = (len(all_batches) + world - 1) // world
+    steps_per_epoch = source.steps_per_epoch
     # lightning.py:48-52 + train.py:41 + cosine.py as one fused multi-tensor step (optim.py): AdamW(.9/.98), clip 10,
     # per-step warm-up cosine; step count / lr / gradient norm stay on the device
     opt = FusedAdamW(model.parameters(), lr=args.lr, betas=(0.9, 0.98), weight_decay=args.weight_decay, max_grad_norm=10.0,
@@ -146,42 +208,67 @@ def _fit(model, args, dev, rank, world, backend, log, held):
     if getattr(args, "ckpt_path", None):
         start_epoch, global_step = load_checkpoint(args.ckpt_path, model, opt)
         seed_dev.add_(global_step)  # dropout masks are a function of (rank, global step, site): a resumed run continues them
-    n_val = getattr(args, "val_batches", 0) or 0
-    val_lengths = utterance_lengths(2000, seed=43)
-    val_all = bucket_batches(val_lengths, 1000, 1)  # val_dataloader: max_frames 1000, one bucket (data_module.py:156-158)
-    val = [make_batch(val_lengths, b, args.modality, model.odim, seed=10_000 + i, device=dev)
-           for i, b in enumerate(rank_batches(val_all, rank, world, seed=1)[:n_val])]
+    val = source.val_batches(getattr(args, "val_batches", 0) or 0)
     max_steps = getattr(args, "steps", None)
     losses = []
     t0 = time.time()
     done = False
+    params = list(model.parameters())
+    mode = getattr(args, "numerics", None)  # train.py: --numerics, default "mixed" (what bench.py times); None: the caller's mode
+
+    def full_step(x, lens, y):
+        """ONE training step, start to end, with no host decision that depends on the batch's values: what runs eagerly the
+        first time a batch shape shows up and what a hipGraph of that shape replays afterwards (graph_step.StepGraphs)."""
+        for p in params:  # (gradients of a replayed step live in the graph's pool: never accumulate into them)
+            p.grad = None
+        seed_dev.add_(1)
+        AF.manual_seed(42 + rank)  # restart the per-site counter: mask = f(rank, site index, seed_dev = global step)
+        if buckets is not None:
+            buckets.begin_step()
+        AF.new_step()
+        AF.refresh_weight_cache()  # conv-weight permutes; the Linear copies were rewritten by the optimizer step itself
+        loss, loss_ctc, loss_att, hits, ntok = hot(x, lens, y)
+        if world > 1:
+            bs = torch.full((1,), float(x.shape[0]), device=dev)
+            allb = torch.empty(world, device=dev)
+            if buckets is not None and buckets.comm is not None:
+                AF._state["bn_comm"].all_gather(allb, bs)
+            else:
+                dist.all_gather_into_tensor(allb, bs)
+            loss = loss * (world / allb.sum())  # lightning.py:88-90
+        loss.backward()
+        if buckets is not None:
+            buckets.finish()
+        opt.step()
+        return loss.detach(), loss_ctc.detach(), loss_att.detach(), hits, ntok
+
+    # hipGraph replay per batch shape (what bench.py times): single-rank runs, and data-parallel runs whose collectives are all
+    # stream operations on RCCL's C API (AVSR_DDP=buckets on GPUs); torch's DDP reducer cannot be captured
+    from .graph_step import StepGraphs
+
+    graph_ok = dev.type == "cuda" and not getattr(args, "no_graph", False) and \
+        (world == 1 or (buckets is not None and buckets.comm is not None))
+    stepper = StepGraphs(full_step, enabled=graph_ok, capture_after=1, thread_local=world > 1,
+                         max_graphs=int(os.environ.get("AVSR_MAX_GRAPHS", "64")),
+                         on_fail=lambda e: log(f"[rank {rank}] hipGraph capture failed ({type(e).__name__}: {str(e)[:160]}); eager from here on"))
+    held["stepper"] = stepper
+    tail, t_tail = int(getattr(args, "time_last", 0) or 0), None
+    if mode is not None:
+        AF.set_mode(mode)
     for epoch in range(start_epoch, args.max_epochs):
         # reload_dataloaders_every_n_epochs=1 + shuffle=True (train.py:39, data_module.py:140): a new order every epoch
-        batches = rank_batches(all_batches, rank, world, seed=epoch)
-        assert len(batches) == steps_per_epoch
-        for bi, idxs in enumerate(batches):
-            x, lens, y, frames = make_batch(lengths, idxs, args.modality, model.odim, seed=global_step, device=dev)
-            seed_dev.add_(1)
-            AF.manual_seed(42 + rank)  # restart the per-site counter: mask = f(rank, site index, seed_dev = global step)
-            if buckets is not None:
-                buckets.begin_step()
-            AF.new_step()
-            AF.refresh_weight_cache()  # conv-weight permutes; the Linear copies were rewritten by the optimizer step itself
-            loss, loss_ctc, loss_att, hits, ntok = hot(x, lens, y)
-            if world > 1:
-                bs = torch.full((1,), float(x.shape[0]), device=dev)
-                allb = torch.empty(world, device=dev)
-                if buckets is not None and buckets.comm is not None:
-                    AF._state["bn_comm"].all_gather(allb, bs)
-                else:
-                    dist.all_gather_into_tensor(allb, bs)
-                loss = loss * (world / allb.sum())  # lightning.py:88-90
-            loss.backward()
-            if buckets is not None:
-                buckets.finish()
-            opt.step()
-            opt.zero_grad(set_to_none=True)
+        nb = 0
+        for bi, (x, lens, y) in enumerate(source.epoch(epoch, global_step)):
+            nb += 1
+            if tail and max_steps and global_step == max_steps - tail:  # --time-last N: wall clock of the last N steps
+                torch.cuda.synchronize() if dev.type == "cuda" else None
+                t_tail = time.perf_counter()
+            loss, loss_ctc, loss_att, hits, ntok = stepper(x, lens, y)
             global_step += 1
+            if t_tail is not None and global_step == max_steps:
+                torch.cuda.synchronize() if dev.type == "cuda" else None
+                held["tail_ms"] = (time.perf_counter() - t_tail) / tail * 1e3
+                log(f"last {tail} steps: {held['tail_ms']:.2f} ms / step ({stepper.stats})")
             every = getattr(args, "log_every", 10)
             if every and ((global_step - 1) % every == 0 or global_step == max_steps):
                 losses.append(float(loss.detach()))
@@ -192,7 +279,7 @@ def _fit(model, args, dev, rank, world, backend, log, held):
             if max_steps and global_step >= max_steps:
                 done = True
                 break
-        if done and bi + 1 < len(batches):
+        if done and nb < steps_per_epoch:
             break  # stopped inside an epoch (--steps): no end-of-epoch work
         metrics = validate(model, val, world)
         if rank == 0 and metrics:

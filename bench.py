@@ -67,7 +67,9 @@ def parse():
     return ap.parse_args()
 
 
-DDP_CHAIN = ["buckets-graph", "buckets-graph1", "torch"]
+# round 5: the chain STARTS at the order-safe single-communicator mode (the first N > 1 execution of this code is the driver's: a
+# hang in the two-communicator mode would burn its limit before anything is measured); `--ddp buckets-graph` / AVSR_DDP opt in
+DDP_CHAIN = ["buckets-graph1", "buckets", "torch"]
 
 
 def supervise(args):
@@ -80,10 +82,12 @@ def supervise(args):
       here with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (127.0.0.1) -- no torchrun needed;
     * attempt k runs the workers in data-parallel mode DDP_CHAIN[k] on its own rendezvous port (MASTER_PORT + 1 + k) with a
       wall-clock limit; a worker that fails or overruns is killed (whole process group) and the next, more conservative mode is
-      tried: buckets-graph (bucketed exchange + cross-rank BatchNorm on two RCCL communicators through the C API, whole step
-      replayed as hipGraphs) -> buckets-graph1 (the same on ONE communicator: every collective of a rank in one issue order,
-      which is the same program order on every rank -- cannot dead-lock on ordering) -> torch (DistributedDataParallel + c10d
-      collectives, eager launches).  Every supervisor applies the same limits, so the ranks move on together;
+      tried: buckets-graph1 (bucketed exchange + cross-rank BatchNorm on ONE RCCL communicator through the C API, whole step
+      replayed as hipGraphs: every collective of a rank in one issue order, which is the same program order on every rank --
+      cannot dead-lock on ordering) -> buckets (the same exchange over torch.distributed, eager launches) -> torch
+      (DistributedDataParallel + c10d collectives, eager launches).  `--ddp buckets-graph` (two communicators, so that the
+      latency-bound BatchNorm collectives do not queue behind 64 MB buckets) is opt-in: it needs two collective kernels
+      co-resident, which no hardware run has confirmed.  Every supervisor applies the same limits, so the ranks move on together;
     * rank 0's JSON line (stdout of its worker) is printed once, by this process, after the attempt that succeeded."""
     import signal
     import subprocess
@@ -97,7 +101,7 @@ def supervise(args):
     base_port = int(os.environ.get("MASTER_PORT", "29500"))
     want = os.environ.get("AVSR_DDP") or args.ddp
     chain = DDP_CHAIN if want == "auto" else [want]
-    limits = [float(x) for x in os.environ.get("AVSR_BENCH_ATTEMPT_TIMEOUT", "420,300,300").split(",")]
+    limits = [float(x) for x in os.environ.get("AVSR_BENCH_ATTEMPT_TIMEOUT", "300,240,240").split(",")]
     argv = [a for a in sys.argv[1:] if a != "--worker"]
     live = []
 
@@ -366,7 +370,9 @@ def main():
         # AVSR_GRAD_WIRE=bf16: the buckets travel as bf16 (half the bytes per link; stated in config.grad_wire).
         from auto_avsr_amd.ddp import GradBuckets
 
-        buckets = GradBuckets(model.parameters(), group=dist.group.WORLD, comm=comm_grads)
+        # wire format: bf16 whenever the backward pass computes its gradients from bf16 operands anyway (every mode but
+        # "precise") and a stream communicator carries the buckets -- half the bytes per xGMI link; AVSR_GRAD_WIRE overrides
+        buckets = GradBuckets(model.parameters(), group=dist.group.WORLD, comm=comm_grads, wire="f32" if mode == "precise" else "bf16")
 
     if dp and rank == 0:
         print(f"[bench] data-parallel mode: --ddp {args.ddp}" + (" (RCCL C-API communicators, hipGraph replay)" if comm is not None else ""),
@@ -404,8 +410,7 @@ def main():
         babble.snr_levels = [0]
         raw = [[0.1 * torch.randn(int(n), generator=g).to(dev) for n in lens.tolist()] for (_, lens, _, _) in pool]
     use_graph = not args.no_graph and (not dp or args.ddp in ("buckets-graph", "buckets-graph1"))
-    graphs = {}
-    st = {"opt": opt, "graph": use_graph}
+    st = {"opt": opt}
     all_params = list(model.parameters())
 
     def clear_grads():  # Module.zero_grad walks the module tree (2 ms of host time per step); this is the same effect
@@ -413,6 +418,7 @@ def main():
             p.grad = None
 
     def eager_step(x, lens, y):
+        clear_grads()  # (the gradients of a replayed step live in the graph's memory pool: never accumulate into them)
         if buckets is not None:
             buckets.begin_step()  # the bucket gathers are issued on THIS stream (ddp.py: no foreign-stream launches)
         AF.new_step()
@@ -433,57 +439,46 @@ def main():
             buckets.finish()  # the compute stream waits for the bucket all-reduces issued during the backward pass
         if st["opt"] is not None:
             st["opt"].step()
-        return loss
+        return (loss,)
+
+    # One hipGraph per batch shape (auto_avsr_amd/graph_step.py -- the same class train.py's native driver steps through): the
+    # ~850 kernel launches of a step (N > 1: + the RCCL collectives) are replayed by the GPU front-end instead of being issued one
+    # by one from Python (HIP graphs, not a tracing compiler).  The benchmark captures a shape on first sight, after one eager
+    # warm-up step on a side stream (set-up, outside the timed region).
+    from auto_avsr_amd.graph_step import StepGraphs
+
+    def warm(x, lens, y):
+        eager_step(x, lens, y)
+        clear_grads()
+        AF.refresh_weight_cache()  # builds the multi-tensor cast table (H2D copy) outside the capture
+
+    def capture_failed(e):
+        print(f"[bench rank {rank}] hipGraph capture of the data-parallel step failed ({type(e).__name__}: "
+              f"{str(e)[:200]}); continuing with eager launches", file=sys.stderr, flush=True)
+        clear_grads()
+        if buckets is not None:
+            buckets._works.clear()
+            buckets._left = [len(m) for m in buckets.members]
+
+    # (N > 1: the process group's watchdog thread queries events while this thread captures -> thread-local capture mode; a
+    # failed capture is fatal at N = 1 and a fall-back to eager launches at N > 1)
+    stepper = StepGraphs(eager_step, enabled=use_graph, capture_after=0, warm=warm, thread_local=dp,
+                         on_fail=capture_failed if dp else None, max_graphs=max(64, nshape))
 
     def step(i):
         x, lens, y, _ = data[i]
         if raw is not None:
             # inside the timed step: per-utterance mask / noise-offset draws on the host, ONE device launch for the batch; the
-            # result overwrites the step's (graph-static) input tensor
+            # result overwrites the step's input tensor
             xb, _ = TR.audio_batch(raw[i % nshape], "train", babble)
             x.copy_(xb)
-        if st["graph"]:
-            # one hipGraph per batch shape: the ~830 kernel launches of a step (N > 1: + the RCCL collectives) are replayed by
-            # the GPU front-end instead of being issued one by one from Python (HIP graphs, not a tracing compiler)
-            key = i % nshape
-            if key not in graphs:
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    eager_step(x, lens, y)
-                    model.zero_grad(set_to_none=True)
-                torch.cuda.current_stream().wait_stream(side)
-                AF.refresh_weight_cache()  # builds the multi-tensor cast table (H2D copy) outside the capture
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                try:
-                    # (N > 1: the process group's watchdog thread queries events while this thread captures)
-                    with torch.cuda.graph(g, **({"capture_error_mode": "thread_local"} if dp else {})):
-                        captured_loss = eager_step(x, lens, y)
-                except Exception as e:  # noqa: BLE001 -- capture is an optimisation: the eager step below is always valid
-                    if not dp:
-                        raise
-                    print(f"[bench rank {rank}] hipGraph capture of the data-parallel step failed ({type(e).__name__}: "
-                          f"{str(e)[:200]}); continuing with eager launches", file=sys.stderr, flush=True)
-                    st["graph"] = False
-                    torch.cuda.synchronize()
-                    model.zero_grad(set_to_none=True)
-                    if buckets is not None:
-                        buckets._works.clear()
-                        buckets._left = [len(m) for m in buckets.members]
-                    return step(i)
-                graphs[key] = (g, captured_loss.detach())  # the loss lives in the graph's static memory: re-written by every replay
-            graphs[key][0].replay()
-            return graphs[key][1]
-        loss = eager_step(x, lens, y)
-        clear_grads()
-        return loss
+        return stepper(x, lens, y)[0]
 
     sync = (lambda: None) if selftest else torch.cuda.synchronize
 
     def timed_run(n_warm, n_end):
         """Captures (set-up, not steps), n_warm untimed steps, then steps [n_warm, n_end) between barrier + synchronize."""
-        if st["graph"]:
+        if stepper.enabled:
             for j in range(nshape):
                 step(j)
         for i in range(n_warm):
@@ -524,8 +519,10 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": {"bf16": "bf16", "precise": "f32 (split-bf16 MFMA)", "hpf": "f32 forward (split-bf16 MFMA) / bf16 backward",
-                  "mixed": "f16 (" + ", ".join(k for k, v in sorted(AF.MIXED_POLICY.items()) if v == "f16")
-                           + ") + split-bf16 (everything else) forward / bf16 backward"}[mode],
+                  "mixed": "f16 activations x " + ", ".join(
+                      f"{fmt} weights ({', '.join(k for k, v in sorted(AF.MIXED_POLICY.items()) if v == fmt)})"
+                      for fmt in ("f16x2", "f16") if fmt in AF.MIXED_POLICY.values())
+                           + " + split-bf16 (everything else) forward / bf16 backward"}[mode],
         "data": "synthetic",
         "config": {"workload": ("configs[1]: modality=video vsr_trlrs3_base" if args.modality == "video" else
                                 "configs[3] single-GPU leg: modality=audio asr_trlrs3_base (a frame = 640 samples)")
@@ -539,7 +536,7 @@ def main():
                                + (" [AVSR_BENCH_FORCE_DP: data-parallel machinery on ONE rank]" if dp and world == 1 else "")
                                + (", every step from RAW waveforms: AudioTransform('train') with babble noise at SNR 0 dB + collation "
                                   "on the device inside the timed region" if args.babble else "")
-                               + (f", hipGraph replay, {nshape} batch shapes cycled" if st["graph"] else f", eager launches, {nshape} batch shapes cycled"),
+                               + (f", hipGraph replay, {nshape} batch shapes cycled" if stepper.enabled else f", eager launches, {nshape} batch shapes cycled"),
                    "padded_frames_per_sec": round(float(ftot[1]) / dt, 2), "final_loss": round(final_loss, 4),
                    "batch_shapes": sorted({(int(d[0].shape[0]), int(d[0].shape[1]) // (640 if args.modality == "audio" else 1),
                                             int(d[2].shape[2])) for d in data}),
@@ -551,6 +548,17 @@ def main():
                              communicators=(0 if comm is None else (1 if comm_grads is comm else 2)),
                              grad_wire=(buckets.wire if buckets is not None else "f32"),
                              bucket_mb=(round(buckets.flat[0].numel() * 4 / 2 ** 20, 1) if buckets is not None else 64))
+    if dp and buckets is not None and buckets.comm is not None and not selftest:
+        # one more step, eager, with an event pair around every bucket's exchange (EVERY rank runs it: the collectives need their
+        # peers): when does each bucket leave, how long does it travel, and how long does the compute stream stand at the join
+        # after the backward pass -- the part of the gradient exchange the backward pass did not hide
+        torch.cuda.synchronize()
+        buckets.time_next_step()
+        eager_step(*data[args.warmup][:3])
+        torch.cuda.synchronize()
+        rep = buckets.timing_report()
+        if rep is not None:
+            out["config"]["bucket_overlap"] = rep
     if rank == 0 and not dp and not args.no_roofline:
         # (N > 1: an extra rank-0-only step would dead-lock the DDP / BatchNorm collectives; the kernels are the same)
         out["roofline"], hbm = roofline(model, data[args.warmup], ops)

@@ -252,10 +252,11 @@ def test_bench_main_two_ranks(emu_lib_path, tmp_path, launch):
     cross-rank BatchNorm through a communicator, gradient buckets on a second communicator, W / sum(B) rescale, barriers,
     max-over-ranks timing, the rank-0 JSON line -- and checks the contract fields of that line.
       torchrun-auto        launched exactly as the driver launches it (`python -m torch.distributed.run --nproc-per-node 2 ...
-                           bench.py --gpus 2 ...`): the default mode, buckets-graph (two communicators);
+                           bench.py --gpus 2 ...`): the default mode -- since round 5 buckets-graph1 (ONE communicator: the
+                           order-safe mode), gradient buckets travelling as bf16;
       plain-hang-fallback  launched as plain `python bench.py --gpus 2` (bench.py starts its own ranks), and one rank of the
                            first mode never arrives (AVSR_BENCH_TEST_HANG): the supervisor's wall-clock limit kills the attempt
-                           and the single-communicator mode runs instead;
+                           and the next mode of the chain (buckets: torch.distributed collectives, eager) runs instead;
       torchrun-buckets     --ddp buckets: the same exchange on torch.distributed collectives."""
     import json
     import subprocess
@@ -266,7 +267,7 @@ def test_bench_main_two_ranks(emu_lib_path, tmp_path, launch):
     port = 35500 + os.getpid() % 2000
     tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--max-frames", "12", "--shapes", "2"]
     if launch == "plain-hang-fallback":
-        env.update(AVSR_BENCH_TEST_HANG="buckets-graph", AVSR_BENCH_ATTEMPT_TIMEOUT="30,400,400", MASTER_PORT=str(port))
+        env.update(AVSR_BENCH_TEST_HANG="buckets-graph1", AVSR_BENCH_ATTEMPT_TIMEOUT="30,400,400", MASTER_PORT=str(port))
         cmd = [sys.executable] + tail
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -280,12 +281,12 @@ def test_bench_main_two_ranks(emu_lib_path, tmp_path, launch):
     assert out["value"] > 0 and out["ms_per_step"] > 0 and out["higher_is_better"] is True
     c = out["config"]
     assert "gradient all-reduce overlapped with backward (auto_avsr_amd.ddp) + SyncBN" in c["workload"] and "eager launches" in c["workload"]
-    assert c["rccl_ranks"] == 2 and c["grad_wire"] == "f32"
+    assert c["rccl_ranks"] == 2
     if launch == "torchrun-auto":
-        assert c["ddp_mode"] == "buckets-graph" and c["attempt"] == 0 and c["communicators"] == 2
+        assert c["ddp_mode"] == "buckets-graph1" and c["attempt"] == 0 and c["communicators"] == 1 and c["grad_wire"] == "bf16"
     elif launch == "plain-hang-fallback":
-        assert c["ddp_mode"] == "buckets-graph1" and c["attempt"] == 1 and c["communicators"] == 1
-        assert "hang guard" in r.stderr and "falling back to --ddp buckets-graph1" in r.stderr
+        assert c["ddp_mode"] == "buckets" and c["attempt"] == 1 and c["communicators"] == 0 and c["grad_wire"] == "f32"
+        assert "hang guard" in r.stderr and "falling back to --ddp buckets" in r.stderr
     else:
         assert c["ddp_mode"] == "buckets" and c["communicators"] == 0
     assert c["final_loss"] == c["final_loss"]  # finite

@@ -133,10 +133,16 @@ def test_fused_adamw_writes_f16_forward_copies(dev):
         for q in ps:
             q.grad = torch.randn_like(q)
         opt.step()
-        assert torch.equal(h0.cpu(), ps[0].detach().cpu().half())
-        assert torch.equal(hcat.cpu(), torch.cat([ps[1], ps[2], ps[3]]).detach().cpu().half())
+        # two-plane images [out][2][in]: hi = f16(w), lo = f16((w - hi) * 2^11) (csrc/prims.h f2h_lo)
+        def planes(w):
+            w = w.detach().cpu()
+            hi = w.half()
+            return torch.stack([hi, ((w - hi.float()) * 2048.0).half()], 1)
+
+        assert torch.equal(h0.cpu(), planes(ps[0]))
+        assert torch.equal(hcat.cpu(), planes(torch.cat([ps[1], ps[2], ps[3]])))
         assert AF._wh16_owned == {(w.data_ptr(), tuple(w.shape)) for w in ps[:4]}
-        assert not torch.equal(h4.cpu(), ps[4].detach().cpu().half())  # stale until the refresh
+        assert not torch.equal(h4.cpu(), planes(ps[4]))  # stale until the refresh
         calls = []
         orig = AF.ops.multi_cast_transpose
         AF.ops.multi_cast_transpose = lambda t, n, b: (calls.append(n), orig(t, n, b))
@@ -146,7 +152,7 @@ def test_fused_adamw_writes_f16_forward_copies(dev):
         finally:
             AF.ops.multi_cast_transpose = orig
         assert calls == [1], calls        # ONE table entry: the uncovered weight
-        assert torch.equal(h4.cpu(), ps[4].detach().cpu().half())
+        assert torch.equal(h4.cpu(), planes(ps[4]))
         assert AF._w_h16(ps[0]) is h0 and AF._w_h16(ps[4]) is h4
     AF.invalidate_weight_cache()
 

@@ -162,3 +162,41 @@ def test_optimizer_step_marks_weight_copies_stale(dev):
         assert (c1 - c0).abs().max() > 0.1, f"stale conv copy (cast_weights={cast})"
         y0, c0 = y1, c1
     AF.invalidate_weight_cache()
+
+
+@pytest.mark.gpu
+def test_native_fit_graph_replay_equals_eager(tmp_path, monkeypatch):
+    """train.py's native loop steps through graph_step.StepGraphs: a batch shape runs eagerly the first time it shows up and as
+    a replayed hipGraph from its second visit on -- with NEW data in every step.  Same seeds, same corpus: the losses of the
+    replaying run equal those of the eager run (--no-graph) step for step, in the mode train.py defaults to (mixed), over
+    three epochs of a corpus whose shapes repeat every epoch."""
+    import auto_avsr_amd.synthetic as S
+    from auto_avsr_amd import functional as AF
+    from auto_avsr_amd import train_native as TN
+
+    dev = torch.device("cuda")
+    monkeypatch.setattr(S, "utterance_lengths", lambda n=6, seed=42, lo=12, hi=400: torch.tensor([12, 14, 20, 22, 30, 33, 12, 21]).numpy())
+    runs = {}
+    for tag, no_graph in (("eager", True), ("graph", False)):
+        AF.invalidate_weight_cache()
+        m = small_e2e().to(dev).train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.1  # (dropout ON: the masks are a function of the device-side step counter, which replays advance too)
+        args = _args(tmp_path / tag, max_frames=48, train_num_buckets=3, max_epochs=3, synthetic_utterances=8, numerics="mixed",
+                     no_graph=no_graph, val_batches=0, exp_dir=None)
+        runs[tag] = (TN.fit(m, args, dev, log=lambda s: None), TN.fit.last_stats,
+                     {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items() if v.is_floating_point()})
+    (le, se, we), (lg, sg, wg) = runs["eager"], runs["graph"]
+    assert se["replayed"] == 0 and sg["captured"] >= 2 and sg["replayed"] >= 2 * sg["captured"], (se, sg)
+    assert len(le) == len(lg) >= 6
+    print("losses eager", le, "graph", lg)
+    # (not bitwise: split-K / statistics atomics commit in a run-dependent order, and Adam's normalisation turns the rounding
+    # noise of near-zero gradients into weight differences of a fraction of lr; replaying STALE inputs would be off by > 10 %)
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 5e-3 * abs(a), (le, lg)
+    num = sum(float((we[k] - wg[k]).norm() ** 2) for k in we) ** 0.5
+    den = sum(float(we[k].norm() ** 2) for k in we) ** 0.5
+    assert num <= 2e-3 * den, num / den
+    assert AF.mode() == "bf16"
+    AF.invalidate_weight_cache()

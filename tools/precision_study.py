@@ -28,7 +28,7 @@ from oracle import avsr_oracle as O  # noqa: E402
 from bench_common import BATCHES, FIXTURE, ODIM, bench_batch, bench_state_dict, full_errors, load_full, rel  # noqa: E402
 
 GROUPS = ["stem", "trunk", "trunk1", "trunk2", "trunk3", "trunk4", "proj", "enc_ffn", "enc_attn_proj", "enc_attn_q", "enc_attn_k", "enc_attn_v",
-          "enc_attn_out", "enc_attn_pos", "enc_attn_core", "enc_conv", "ctc_head", "dec", "dec_out"]
+          "enc_attn_out", "enc_attn_pos", "enc_attn_core", "enc_conv", "enc_conv_pw1", "enc_conv_dw", "enc_conv_pw2", "ctc_head", "dec", "dec_out"]
 CFG = {}
 STATS = {}
 
@@ -98,6 +98,11 @@ class FShim(types.SimpleNamespace):
         return fn(q(x, fmt), q(w, fmt, True), b, **kw)
 
     def conv1d(self, x, w, b=None, **kw):
+        if _scope[0] == "enc_conv":  # refinements of the convolution module: pointwise 1 / depthwise / pointwise 2, when named
+            sub = "enc_conv_dw" if kw.get("groups", 1) > 1 else ("enc_conv_pw1" if w.shape[0] == 2 * w.shape[1] else "enc_conv_pw2")
+            if sub in CFG:
+                note(sub, x)
+                return F.conv1d(q(x, CFG[sub]), q(w, CFG[sub], True), b, **kw)
         return self._conv(F.conv1d, x, w, b, **kw)
 
     def conv2d(self, x, w, b=None, **kw):
@@ -218,7 +223,7 @@ def parse(spec):
         k, v = item.split("=")
         if k == "all":
             for g in GROUPS:
-                if not g[-1].isdigit() and g not in ("enc_attn_q", "enc_attn_k", "enc_attn_v", "enc_attn_out", "enc_attn_pos"):  # refinements: only when named explicitly
+                if not g[-1].isdigit() and g not in ("enc_attn_q", "enc_attn_k", "enc_attn_v", "enc_attn_out", "enc_attn_pos", "enc_conv_dw"):  # refinements: only when named explicitly
                     cfg[g] = v
         elif k == "mixed":  # the round-4 default policy with format v
             for g in ("trunk3", "trunk4", "enc_ffn", "enc_attn_proj", "enc_attn_core", "enc_conv", "dec"):

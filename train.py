@@ -36,6 +36,12 @@ def parse_args(argv=None):
     p.add_argument("--steps", default=None, type=int, help="stop after this many optimizer steps")
     p.add_argument("--val-batches", default=8, type=int, help="synthetic validation batches per rank and epoch")
     p.add_argument("--synthetic-utterances", default=0, type=int, help="size of the synthetic corpus (default 20000)")
+    p.add_argument("--numerics", default="mixed", choices=["mixed", "hpf", "precise", "bf16"],
+                   help="numerical mode of the hot path (auto_avsr_amd.functional.set_mode); default: the mode bench.py times, "
+                        "the cheapest one whose logits stay within 1e-3 of the fp32 reference")
+    p.add_argument("--no-graph", action="store_true", help="eager launches instead of one replayed hipGraph per batch shape")
+    p.add_argument("--log-every", default=10, type=int)
+    p.add_argument("--time-last", default=0, type=int, help="report the wall clock per step of the last N of --steps steps")
     return p.parse_args(argv)
 
 
