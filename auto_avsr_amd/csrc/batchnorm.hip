@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void bn_partial_finalize_kernel(
     }
     const double nn = (double)n;
     const double mean = (double)Elem<T>::ld(x0 + c) + s1 / nn;
-    const double m2 = s2 - s1 * s1 / nn;
+    const double m2 = fmax(s2 - s1 * s1 / nn, 0.0);  // (f32 partials of a channel with |mean| >> std may cancel below zero)
     const double var = m2 / nn;
     mean_out[c] = (float)mean;
     invstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -226,7 +226,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, const float*
         if (n <= 0.0) continue;
         const double s1 = stats[w * ss + C + c], s2 = stats[w * ss + 2 * C + c];
         const double mw = (double)stats[w * ss + c] + s1 / n;
-        m2 += (s2 - s1 * s1 / n) + n * (mw - mean) * (mw - mean);
+        m2 += fmax(s2 - s1 * s1 / n, 0.0) + n * (mw - mean) * (mw - mean);
     }
     const double var = m2 / n_tot;
     mean_out[c] = (float)mean;
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(BNS_THREADS) void bn_small_fwd_kernel(
         }
         const double nn = (double)rows;
         const double mean = (double)Elem<T>::ld(x + c) + s1 / nn;
-        const double m2 = s2 - s1 * s1 / nn;
+        const double m2 = fmax(s2 - s1 * s1 / nn, 0.0);  // (f32 partials of a channel with |mean| >> std may cancel below zero)
         const double var = m2 / nn;
         const float mf = (float)mean, isf = (float)(1.0 / sqrt(var + (double)eps));
         mean_out[c] = mf;

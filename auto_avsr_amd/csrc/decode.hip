@@ -953,7 +953,7 @@ int skinny(const float* A, int lda, const float* W, int M, int N, int K, const f
     } while (0)
 
 // The linear layer of a decoding step on its own (tests, microbenchmarks): C = act(LN?(A) W^T + bias) + resid, M <= 128 rows.
-// st_in [M][st_in_nt][2]: per-row (sum, sum of squares) partials of A (LN only); st_out [M][ceil(N / 32)][2] or NULL: the same
+// st_in [M][st_in_nt][2]: per-row (sum, sum of squares) partials of A (LN only); st_out [M][ceil(N / 16)][2] or NULL (one partial per 16-column block: size it from out->nt): the same
 // for the rows of C; partial: >= 8 * M * N floats, needed when K > 768 (K slices).  Returns the number of partials per row of
 // st_out through st_out_nt (may be NULL).
 extern "C" int avsr_decode_linear(const float* A, int lda, const float* W, int M, int N, int K, const float* bias, const float* ln_g,

@@ -80,7 +80,11 @@ class NativeBeam:
         params = list(dec.parameters())
         pos = dec.embed[1]
         pe = _f32(pos.table(max(pos.pe.size(1), min_pos), dev))
-        key = (str(dev), pe.data_ptr(), pe.shape[0]) + tuple((p.data_ptr(), p._version) for p in params)
+        # (FusedAdamW updates parameters through raw pointers without bumping `_version`: the optimizer-step generation of the
+        # weight caches is part of the key, so the stacked copies below are rebuilt after native training steps too)
+        from . import functional as AF
+
+        key = (str(dev), pe.data_ptr(), pe.shape[0], AF._wgen["gen"]) + tuple((p.data_ptr(), p._version) for p in params)
         if key == self.key:
             return
         L = _lib.lib()
