@@ -462,11 +462,11 @@ AVSR_DEV void bns_block_sum16(float (&a)[8], float (&b)[8], float* red /* [8 wav
     __syncthreads();
 }
 
-template <class T>
+template <class T, class TO = T>
 __global__ __launch_bounds__(BNS_THREADS) void bn_small_fwd_kernel(
     const T* __restrict__ x, int rows, int C, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
-    int64_t* __restrict__ num_batches_tracked, int act, T* __restrict__ y, float* __restrict__ mean_out,
+    int64_t* __restrict__ num_batches_tracked, int act, TO* __restrict__ y, float* __restrict__ mean_out,
     float* __restrict__ invstd_out, bf16_t* __restrict__ y2 = nullptr) {
     __shared__ float red[8 * 16];
     __shared__ float mu_s[8], is_s[8];
@@ -1170,14 +1170,21 @@ extern "C" int avsr_bn_small_fwd(const void* x, int dtype, int64_t rows, int C, 
     return 0;
 }
 
-// f32 input / output + the bf16 twin y2 of the output in one pass
+// f32 input, f32 (y_dtype 0) or f16 (y_dtype 2) output + the bf16 twin y2 of the output in one pass.  f16 output: the mixed mode
+// keeps the convolution module's element-wise chain (pointwise-1 output -> GLU -> depthwise conv -> BatchNorm) in f32 and rounds
+// to f16 only here, where the next consumer is an MFMA operand.
 extern "C" int avsr_bn_small_fwd2(const float* x, int64_t rows, int C, const float* gamma, const float* beta, float eps,
                                   float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                                  int act, float* y, void* y2, float* mean, float* invstd, hipStream_t stream) {
+                                  int act, void* y, int y_dtype, void* y2, float* mean, float* invstd, hipStream_t stream) {
     AVSR_REQUIRE(C % 8 == 0, "bn_small: C must be a multiple of 8");
     AVSR_REQUIRE(rows >= 1 && rows <= BNS_THREADS * BNS_R, "bn_small: rows out of range (avsr_bn_small_max_rows)");
-    AVSR_LAUNCH((bn_small_fwd_kernel<float>), dim3(C / 8), dim3(BNS_THREADS), 0, stream, x, (int)rows, C, gamma, beta, eps, momentum,
-                running_mean, running_var, num_batches_tracked, act, y, mean, invstd, (bf16_t*)y2);
+    AVSR_REQUIRE(y_dtype == 0 || y_dtype == 2, "bn_small_fwd2: output f32 (0) or f16 (2)");
+    if (y_dtype == 2)
+        AVSR_LAUNCH((bn_small_fwd_kernel<float, f16_t>), dim3(C / 8), dim3(BNS_THREADS), 0, stream, x, (int)rows, C, gamma, beta, eps,
+                    momentum, running_mean, running_var, num_batches_tracked, act, (f16_t*)y, mean, invstd, (bf16_t*)y2);
+    else
+        AVSR_LAUNCH((bn_small_fwd_kernel<float>), dim3(C / 8), dim3(BNS_THREADS), 0, stream, x, (int)rows, C, gamma, beta, eps, momentum,
+                    running_mean, running_var, num_batches_tracked, act, (float*)y, mean, invstd, (bf16_t*)y2);
     AVSR_CHECK_LAUNCH("bn_small_fwd2");
     return 0;
 }

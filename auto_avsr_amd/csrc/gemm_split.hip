@@ -37,9 +37,11 @@ namespace {
 
 using avsr_gemm_impl::Params;
 
-// BSP: B is in the split8 layout.  ACV: the staged A tile is converted to split8 in place, once per stage, by all threads.
+// BSP: B is in the split8 layout.  ACV = 1: the staged A tile is converted to split8 in place, once per stage, by all threads;
+// ACV = 2 (round 5): A ARRIVES in the split8 layout -- its producer (a BatchNorm + activation pass) wrote it that way, the same
+// bytes as the f32 tensor -- so the stage needs no conversion pass and no second barrier.
 // WGM x WGN: wave grid (4 waves).
-template <int BM, int BN, int STAGES, int CV, bool BSP = false, int WGM = 2, int WGN = 2, bool ACV = false>
+template <int BM, int BN, int STAGES, int CV, bool BSP = false, int WGM = 2, int WGN = 2, int ACV = 0>
 struct SplitKernel {
     static constexpr int BK = 32, NW = 4, NTHR = 256;
     static_assert(WGM * WGN == NW, "four waves");
@@ -199,7 +201,7 @@ struct SplitKernel {
             block_barrier_raw();  // tile t is in LDS for every wave; everyone is done reading tile t-1's buffer
             char* As = smem + (t % STAGES) * STAGE_BYTES;
             const char* Bs = As + A_BYTES;
-            if (ACV) {
+            if (ACV == 1) {
                 convert_a(As);
                 lds_wait<0>();        // this wave's LDS writes have landed (LDS-DMA of later tiles stays in flight: no vmcnt wait)
                 sched_fence();
@@ -249,13 +251,13 @@ struct SplitKernel {
     }
 };
 
-template <int BM, int BN, int STAGES, int CV, bool BSP, int WGM, int WGN, bool ACV>
+template <int BM, int BN, int STAGES, int CV, bool BSP, int WGM, int WGN, int ACV>
 __global__ __launch_bounds__(256) void gemm_split_kernel(Params p) {
     AVSR_DYN_SMEM(smem);
     SplitKernel<BM, BN, STAGES, CV, BSP, WGM, WGN, ACV>::run(p, smem);
 }
 
-template <int BM, int BN, int STAGES, int CV, bool BSP, int WGM = 2, int WGN = 2, bool ACV = false>
+template <int BM, int BN, int STAGES, int CV, bool BSP, int WGM = 2, int WGN = 2, int ACV = 0>
 void launch_split(Params& p, int split_k, hipStream_t stream) {
     using K = SplitKernel<BM, BN, STAGES, CV, BSP, WGM, WGN, ACV>;
     if (CV == 0) {
@@ -277,12 +279,17 @@ void launch_split(Params& p, int split_k, hipStream_t stream) {
 template <int CV, bool BSP>
 bool launch_tile(int tile, Params& p, int split_k, hipStream_t stream) {
     switch (tile) {
-        case 11: launch_split<64, 64, 3, CV, BSP, 2, 2, true>(p, split_k, stream); return true;
-        case 12: launch_split<64, 64, 2, CV, BSP, 2, 2, true>(p, split_k, stream); return true;
-        case 13: launch_split<128, 64, 2, CV, BSP, 2, 2, true>(p, split_k, stream); return true;
-        case 14: launch_split<128, 128, 2, CV, BSP, 2, 2, true>(p, split_k, stream); return true;
-        case 15: launch_split<128, 64, 3, CV, BSP, 2, 2, true>(p, split_k, stream); return true;
-        case 16: launch_split<128, 128, 3, CV, BSP, 2, 2, true>(p, split_k, stream); return true;
+        case 11: launch_split<64, 64, 3, CV, BSP, 2, 2, 1>(p, split_k, stream); return true;
+        case 12: launch_split<64, 64, 2, CV, BSP, 2, 2, 1>(p, split_k, stream); return true;
+        case 13: launch_split<128, 64, 2, CV, BSP, 2, 2, 1>(p, split_k, stream); return true;
+        case 14: launch_split<128, 128, 2, CV, BSP, 2, 2, 1>(p, split_k, stream); return true;
+        case 15: launch_split<128, 64, 3, CV, BSP, 2, 2, 1>(p, split_k, stream); return true;
+        case 16: launch_split<128, 128, 3, CV, BSP, 2, 2, 1>(p, split_k, stream); return true;
+        // 23 .. 26: A pre-split in HBM (ACV = 2): 128x64 / 2, 128x128 / 2, 128x64 / 3, 128x128 / 3 stages
+        case 23: if constexpr (BSP) { launch_split<128, 64, 2, CV, BSP, 2, 2, 2>(p, split_k, stream); return true; } return false;
+        case 24: if constexpr (BSP) { launch_split<128, 128, 2, CV, BSP, 2, 2, 2>(p, split_k, stream); return true; } return false;
+        case 25: if constexpr (BSP) { launch_split<128, 64, 3, CV, BSP, 2, 2, 2>(p, split_k, stream); return true; } return false;
+        case 26: if constexpr (BSP) { launch_split<128, 128, 3, CV, BSP, 2, 2, 2>(p, split_k, stream); return true; } return false;
         case 1: launch_split<64, 64, 3, CV, BSP>(p, split_k, stream); return true;
         case 2: launch_split<64, 64, 2, CV, BSP>(p, split_k, stream); return true;
         case 3: launch_split<128, 64, 2, CV, BSP>(p, split_k, stream); return true;
@@ -405,7 +412,7 @@ static int conv2d_f32s_impl(const float* x, const float* wp, float* y, const voi
     p.cH = H; p.cW = W; p.cOH = OH; p.cOW = OW;
     p.colstat = stats_part;
     if (tile == 0) tile = Cout >= 128 ? 14 : 13;
-    AVSR_REQUIRE(stats_part == nullptr || tile == 13 || tile == 14, "conv2d_f32s: statistics need a 128-row tile");
+    AVSR_REQUIRE(stats_part == nullptr || tile == 13 || tile == 14 || (tile >= 23 && tile <= 26), "conv2d_f32s: statistics need a 128-row tile");
     const bool ok = w_split ? launch_tile<1, true>(tile, p, 1, stream) : launch_tile<1, false>(tile, p, 1, stream);
     AVSR_REQUIRE(ok, "conv2d_f32s: unknown tile code");
     AVSR_CHECK_LAUNCH("conv2d_f32s");

@@ -93,7 +93,13 @@ class ConvSublayerFn(torch.autograd.Function):
             h, mean, rstd = ops.layernorm_fwd(x, ln_w, ln_b, T, eps, twin=True)
         else:
             h, mean, rstd = _to_act(x), None, None
-        a = torch.empty(rows, 2 * D, dtype=T, device=x.device)
+        # Mixed mode, f16 component (round 5): what only ELEMENT-WISE kernels read -- the pointwise-1 output (GLU + depthwise
+        # convolution) and the depthwise output (BatchNorm + Swish) -- stays f32; the chain is rounded to f16 once, by the
+        # BatchNorm kernel, where the next consumer (pointwise 2) is an MFMA operand.  Two f16 roundings per layer fewer on the
+        # residual branch the parity study found most sensitive (tools/precision_study.py "enc_conv"); the backward pass reads
+        # the bf16 twins the producers write either way.
+        Tc = torch.float32 if _state["f16"] else T
+        a = torch.empty(rows, 2 * D, dtype=Tc, device=x.device)
         _gemm_nt(h, w_pw1.view(2 * D, D), rows, 2 * D, D, a, bias=b_pw1, twin=True)
         # GLU (conformer_encoder.py:32) is folded into the depthwise convolution: its window staging forms
         # a[:, :D] * sigmoid(a[:, D:]) on the fly, the GLU output is never written
@@ -102,7 +108,8 @@ class ConvSublayerFn(torch.autograd.Function):
         c = ops.dwconv(a, wdw, b_dw, B, Tn, D, K, glu_in=True)
         one_launch = training and AF._BN_SMALL and _state["bn_sync"] is None and rows <= ops.BN_SMALL_MAX_ROWS
         if one_launch:  # statistics + running stats + normalise + Swish in one pass (no cross-rank merge to wait for)
-            s, bmean, binv = ops.bn_small_fwd(c, rows, D, bn_w, bn_b, bn_eps, momentum, bn_rm, bn_rv, bn_nbt, 1)
+            s, bmean, binv = ops.bn_small_fwd(c, rows, D, bn_w, bn_b, bn_eps, momentum, bn_rm, bn_rv, bn_nbt, 1,
+                                              out_dtype=T if Tc != T else None)
             counts = None
         else:
             if training:
@@ -111,6 +118,8 @@ class ConvSublayerFn(torch.autograd.Function):
                 bmean, binv = ops.bn_eval_params(bn_rm, bn_rv, bn_eps)
                 counts = None
             s = ops.bn_act_fwd(c, None, bmean, binv, bn_w, bn_b, rows, D, 1)
+            if s.dtype != T:  # (f32 chain of the mixed mode on the cross-rank / evaluation path: one cast launch)
+                s = _to_act(s)
         po, so, sdo = _drop_args(p_out, x)
         y = torch.empty_like(x)
         _gemm_nt(s, w_pw2.view(D, D), rows, D, D, y, bias=b_pw2, drop_p=po, seed=so, seed_dev=sdo,

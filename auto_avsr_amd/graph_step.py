@@ -37,6 +37,13 @@ class StepGraphs:
         self.pool = None
         self.stats = {"eager": 0, "captured": 0, "replayed": 0, "evicted": 0}
 
+    def reset(self):
+        """Drop every captured graph (a change of numerical mode, of the optimizer, of the model).  The shared memory pool goes
+        with them: a pool handle whose last graph is gone must not be handed to a new capture."""
+        self.graphs.clear()
+        self.seen.clear()
+        self.pool = None
+
     @staticmethod
     def key(x, lens, y):
         return (tuple(x.shape), tuple(lens.shape), tuple(y.shape), x.dtype, y.dtype)
@@ -60,7 +67,7 @@ class StepGraphs:
         self.graphs[key] = (g, sx, sl, sy, outs)
         self.stats["captured"] += 1
         while len(self.graphs) > self.max_graphs:
-            self.graphs.popitem(last=False)
+            self.graphs.popitem(last=False)  # (never the one just captured: max_graphs >= 1)
             self.stats["evicted"] += 1
 
     def __call__(self, x, lens, y):

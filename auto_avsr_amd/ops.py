@@ -356,12 +356,19 @@ def bn_stats_parts(part, rows, C):
 BN_SMALL_MAX_ROWS = 2048  # avsr_bn_small_max_rows()
 
 
-def bn_small_fwd(x, rows, C, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, act):
-    """Single-rank BatchNorm + activation of a small [rows, C] activation in ONE launch: (y, mean, invstd)."""
+def bn_small_fwd(x, rows, C, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, act, out_dtype=None):
+    """Single-rank BatchNorm + activation of a small [rows, C] activation in ONE launch: (y, mean, invstd).  out_dtype (f32 input
+    only): torch.float16 -- the normalised output leaves as f16 (+ its bf16 twin): the next consumer is an MFMA operand."""
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
     invstd = torch.empty(C, dtype=torch.float32, device=x.device)
-    y = torch.empty(rows, C, dtype=x.dtype, device=x.device)
+    y = torch.empty(rows, C, dtype=out_dtype or x.dtype, device=x.device)
     y2 = _twin(y)
+    if x.dtype == torch.float32 and y.dtype == torch.float16:
+        call("avsr_bn_small_fwd2", _ptr(x), rows, C, _ptr(gamma), _ptr(beta), eps, momentum, _ptr(running_mean),
+             _ptr(running_var), _ptr(num_batches_tracked), act, _ptr(y), 2, _ptr(y2), _ptr(mean), _ptr(invstd), _stream(x),
+             nbytes=_nb(x) + _nb(y) + _nb(y2))
+        return y, mean, invstd
+    assert y.dtype == x.dtype
     if x.dtype == torch.float16:
         call("avsr_bn_small_fwd_h16", _ptr(x), rows, C, _ptr(gamma), _ptr(beta), eps, momentum, _ptr(running_mean),
              _ptr(running_var), _ptr(num_batches_tracked), act, _ptr(y), _ptr(y2), _ptr(mean), _ptr(invstd), _stream(x),
@@ -369,7 +376,7 @@ def bn_small_fwd(x, rows, C, gamma, beta, eps, momentum, running_mean, running_v
         return y, mean, invstd
     if y2 is not None:
         call("avsr_bn_small_fwd2", _ptr(x), rows, C, _ptr(gamma), _ptr(beta), eps, momentum, _ptr(running_mean),
-             _ptr(running_var), _ptr(num_batches_tracked), act, _ptr(y), _ptr(y2), _ptr(mean), _ptr(invstd), _stream(x),
+             _ptr(running_var), _ptr(num_batches_tracked), act, _ptr(y), 0, _ptr(y2), _ptr(mean), _ptr(invstd), _stream(x),
              nbytes=2.0 * _nb(x) + _nb(y2))
         return y, mean, invstd
     call("avsr_bn_small_fwd", _ptr(x), dt(x), rows, C, _ptr(gamma), _ptr(beta), eps, momentum, _ptr(running_mean),

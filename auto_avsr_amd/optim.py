@@ -17,7 +17,7 @@ _CHUNK = 4096
 
 class FusedAdamW:
     def __init__(self, params, lr, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0, max_grad_norm=0.0, warmup_steps=0,
-                 total_steps=0, cast_weights=False):
+                 total_steps=0, cast_weights=False, graph_shapes=64):
         self.params = [p for p in params if p.requires_grad]
         assert self.params, "no trainable parameters"
         assert all(p.dtype == torch.float32 and p.is_contiguous() for p in self.params), "f32 contiguous master weights"
@@ -45,7 +45,9 @@ class FusedAdamW:
         self._rows[:, 4] = numel.astype(np.uint64)
         self._rows[:, 5] = (np.cumsum(blocks) - blocks).astype(np.uint64)
         self._blocks = int(blocks.sum())
-        self._free_host = [self._new_host() for _ in range(24)]  # every captured step shape holds one for good
+        # pinned table buffers: every captured step shape holds one for good (hipHostMalloc is not allowed under capture, so they
+        # are all allocated here), eager steps rotate through up to 16 more (gradient addresses change from step to step)
+        self._free_host = [self._new_host() for _ in range(graph_shapes + 24)]
 
     def _new_host(self):
         t = torch.empty(self._table_bytes, dtype=torch.uint8)

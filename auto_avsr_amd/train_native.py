@@ -152,8 +152,19 @@ def fit(model, args, dev, rank=0, world=1, backend="nccl", log=print):
 
     held = {"buckets": None, "comms": [], "stepper": None}
     old_mode = AF._save_mode()
+    # The whole loop runs on a stream of its own, never on the legacy default stream: gradient-accumulation nodes remember the
+    # stream they were created on, and a hipGraph capture must not meet work bound to the default stream (it would have to
+    # synchronise with it, which is illegal under capture) -- the same rule bench.py's warm-up steps follow.
+    work = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+    if work is not None:
+        work.wait_stream(torch.cuda.current_stream(dev))
     try:
-        return _fit(model, args, dev, rank, world, backend, log, held)
+        if work is None:
+            return _fit(model, args, dev, rank, world, backend, log, held)
+        with torch.cuda.stream(work):
+            out = _fit(model, args, dev, rank, world, backend, log, held)
+        torch.cuda.current_stream(dev).wait_stream(work)
+        return out
     finally:
         AF._restore_mode(old_mode)
         fit.last_stats = dict(held["stepper"].stats, tail_ms=held.get("tail_ms")) if held["stepper"] is not None else None
@@ -202,7 +213,7 @@ def _fit(model, args, dev, rank, world, backend, log, held):
     # per-step warm-up cosine; step count / lr / gradient norm stay on the device
     opt = FusedAdamW(model.parameters(), lr=args.lr, betas=(0.9, 0.98), weight_decay=args.weight_decay, max_grad_norm=10.0,
                      warmup_steps=args.warmup_epochs * steps_per_epoch, total_steps=args.max_epochs * steps_per_epoch,
-                     cast_weights=dev.type == "cuda")
+                     cast_weights=dev.type == "cuda", graph_shapes=int(os.environ.get("AVSR_MAX_GRAPHS", "64")))
     folder = os.path.join(args.exp_dir, args.exp_name) if getattr(args, "exp_dir", None) else None
     start_epoch, global_step = 0, 0
     if getattr(args, "ckpt_path", None):

@@ -188,10 +188,10 @@ def cpu_baseline(modality, odim):
     sd = synth_state_dict(tmpl.state_dict(), 0)
     del tmpl
     sd = {k: (v.requires_grad_() if v.is_floating_point() and "running_" not in k else v) for k, v in sd.items()}
-    lengths = [400, 380]  # the first two utterances of the survey's batch A at its full length T = 400: 780 real frames per iteration
-    x, lens, y, frames = make_batch(lengths, [0, 1], modality, odim, seed=1)
+    lengths = [400, 380, 360, 340]  # the survey's batch A, all four utterances (round 4 timed the first two): 1480 real frames per iteration
+    x, lens, y, frames = make_batch(lengths, [0, 1, 2, 3], modality, odim, seed=1)
     times = []
-    for it in range(4):
+    for it in range(3):
         for v in sd.values():
             if v.is_floating_point():
                 v.grad = None
@@ -205,8 +205,8 @@ def cpu_baseline(modality, odim):
             "value_best": round(frames / min(times), 2),
             "sample": f"fwd+bwd of the fp32 oracle (oracle/avsr_oracle.py, a CPU restatement pinned against the reference: "
                       f"/root/reference does not exist on the GPU box, so the reference E2E itself cannot be timed here) on "
-                      f"{cores} threads, B=2 T=400 ({frames} real frames per iteration: the first two utterances of SURVEY batch A at "
-                      f"full length), 1 warm-up + 3 timed iterations: median {med:.2f}s, min {min(times):.2f}s",
+                      f"{cores} threads, SURVEY batch A (B=4 T=400, {frames} real frames per iteration), 1 warm-up + 2 timed "
+                      f"iterations: median {med:.2f}s, min {min(times):.2f}s",
             "reference_itself": {"value": 85.5, "unit": "video-frames/sec", "cores": 8,
                                  "note": "the reference's own E2E fwd+bwd on batch A, measured in the survey container "
                                          "(BASELINE.md section 3); not re-measurable on the GPU box"}}
@@ -570,7 +570,7 @@ def main():
         """The SAME workload and step timed in another numerical mode (fewer steps, same protocol) + its parity block."""
         AF.set_mode(leg_mode)
         AF.invalidate_weight_cache()
-        graphs.clear()
+        stepper.reset()
         model.zero_grad(set_to_none=True)
         st["opt"] = make_optimizer()
         n_w, n_t = min(args.warmup, 2), min(args.steps, 8)
@@ -578,7 +578,7 @@ def main():
         fr_p = sum(d[3] for d in data[n_w:n_w + n_t])
         lp = float(loss_p.detach())
         assert lp == lp and abs(lp) < 1e30, f"non-finite loss in the {leg_mode} leg: {lp}"
-        graphs.clear()
+        stepper.reset()
         res = {"mode": description, "ms_per_step": round(dt_p / n_t * 1e3, 3), "value": round(fr_p / dt_p, 2),
                "unit": "video-frames/sec", "steps": n_t, "warmup": n_w,
                "vs_headline_step": round((dt_p / n_t) / (dt / args.steps), 3),
@@ -621,11 +621,13 @@ KERNELS_OF = {"avsr_gemm_bf16_nt": r"^gemm_fast_kernel<\d+, \d+, \d+, 0,", "avsr
 def counter_traffic(pattern):
     """HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, calibrated) of the kernels matching `pattern`, from the committed
     summary of the two rocprofv3 --pmc passes over one eager step of this workload (tools/pmc_step.py, tools/pmc_report.py ->
-    profiles/r4_hbm_traffic.json; tools/r4_pmc.sh is the recipe).  PMC counters cannot be read from inside this process; the
+    profiles/r5_hbm_traffic.json, taken on the SAME batch shape the roofline legs re-issue their launches on; tools/r5_pmc.sh is the recipe; the round-4 summary is the fall-back).  PMC counters cannot be read from inside this process; the
     passes are separate runs, as the profiling guide prescribes.  None when the summary is absent."""
     import re
 
-    path = os.path.join(ROOT, "profiles", "r4_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r5_hbm_traffic.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r4_hbm_traffic.json")
     if not os.path.exists(path):
         return None, None
     tr = json.load(open(path))
@@ -637,7 +639,7 @@ def counter_traffic(pattern):
             wr += k["wr_bytes"]
     if n == 0:
         return None, None
-    return round((rd + wr) / n), f"profiles/r4_hbm_traffic.json ({tr.get('shape', '')}): {int(n)} launches, read {rd / 1e6:.0f} MB + written {wr / 1e6:.0f} MB"
+    return round((rd + wr) / n), f"profiles/{os.path.basename(path)} ({tr.get('shape', '')}): {int(n)} launches, read {rd / 1e6:.0f} MB + written {wr / 1e6:.0f} MB"
 
 
 def roofline(model, batch, ops):

@@ -174,10 +174,11 @@ int avsr_bn_small_max_rows(void);
 int avsr_bn_small_fwd(const void* x, int dtype, int64_t rows, int C, const float* gamma, const float* beta, float eps,
                       float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, int act, void* y,
                       float* mean, float* invstd, avsr_stream_t stream);
-/* f32 in / out + the bf16 twin y2 of the output (the "hpf" numerical mode) */
+/* f32 in, f32 (y_dtype 0: the "hpf" numerical mode) or f16 (y_dtype 2: the mixed mode's convolution module, whose element-wise
+ * chain stays f32 up to this point) out + the bf16 twin y2 of the output */
 int avsr_bn_small_fwd2(const float* x, int64_t rows, int C, const float* gamma, const float* beta, float eps, float momentum,
-                       float* running_mean, float* running_var, int64_t* num_batches_tracked, int act, float* y, void* y2,
-                       float* mean, float* invstd, avsr_stream_t stream);
+                       float* running_mean, float* running_var, int64_t* num_batches_tracked, int act, void* y, int y_dtype,
+                       void* y2, float* mean, float* invstd, avsr_stream_t stream);
 int avsr_bn_small_bwd(const void* x, const void* dy, int dtype, int64_t rows, int C, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, int act, void* dx, float* dgamma, float* dbeta,
                       avsr_stream_t stream);
