@@ -246,12 +246,14 @@ __global__ void bn_eval_params_kernel(const float* __restrict__ running_mean, co
     invstd_out[c] = 1.0f / sqrtf(running_var[c] + eps);
 }
 
-template <class T>
-__global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(const T* __restrict__ x, const T* __restrict__ add,
+// TA / TY: storage types of the residual input and of the output (sp8_t: the split8 layout the split-plane convolution reads
+// without a conversion pass -- prims.h)
+template <class T, class TA = T, class TY = T>
+__global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(const T* __restrict__ x, const TA* __restrict__ add,
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma,
-                                                                const float* __restrict__ beta, T* __restrict__ y,
+                                                                const float* __restrict__ beta, TY* __restrict__ y,
                                                                 long rows, int C, int act, bf16_t* __restrict__ y2 = nullptr) {
     const int cv = C >> 3;
     const long nvec = rows * cv;
@@ -276,10 +278,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_fwd_kernel(const T* __restr
 // instead of one load per loop trip.  (A 2 x 2-windows-per-thread variant -- 25 taps for four outputs -- was measured 2.5x
 // SLOWER: 96 accumulator registers per thread on top of the taps.)  Also records xsel = the RAW input at the arg-max: the backward reduce pass then
 // runs on the pooled tensors alone (sum over pooled outputs of dpool * act'(z(xsel)) == sum over pixels of dz).
-template <class T>
+template <class T, class TY = T>
 __global__ __launch_bounds__(BN_THREADS) void bn_act_pool3_fwd_kernel(
     const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y, uint8_t* __restrict__ idx,
+    const float* __restrict__ gamma, const float* __restrict__ beta, TY* __restrict__ y, uint8_t* __restrict__ idx,
     T* __restrict__ xsel, long N, int H, int W, int C, int OH, int OW, int act, bf16_t* __restrict__ y2 = nullptr,
     bf16_t* __restrict__ xsel2 = nullptr) {
     const int cv = C >> 3;
@@ -982,14 +984,27 @@ extern "C" int avsr_bn_act_fwd(const void* x, const void* add, int dtype, const 
     return 0;
 }
 
-// f32 in / f32 out + the bf16 twin of the output in one pass (the "hpf" numerical mode)
-extern "C" int avsr_bn_act_fwd2(const float* x, const float* add, const float* mean, const float* invstd, const float* gamma,
-                                const float* beta, float* y, void* y2, int64_t rows, int C, int act, hipStream_t stream) {
+// f32 in / f32 out + the bf16 twin of the output in one pass (the "hpf" numerical mode).  layout (round 5): bit 0 -- y is written
+// in the split8 layout (prims.h sp8_t: what avsr_conv2d_f32s* reads as a pre-split A operand, tile codes 23 - 26); bit 1 -- `add`
+// is stored in the split8 layout.
+extern "C" int avsr_bn_act_fwd2(const float* x, const void* add, const float* mean, const float* invstd, const float* gamma,
+                                const float* beta, void* y, void* y2, int64_t rows, int C, int act, int layout, hipStream_t stream) {
     AVSR_REQUIRE(C % 8 == 0, "batchnorm: C must be a multiple of 8");
     if (rows <= 0) return 0;
     dim3 grid(ew_grid(rows * (C >> 3))), block(BN_THREADS);
-    AVSR_LAUNCH((bn_act_fwd_kernel<float>), grid, block, 0, stream, x, add, mean, invstd, gamma, beta, y, (long)rows, C, act,
-                (bf16_t*)y2);
+    const bool ys = layout & 1, as = (layout & 2) && add;
+    if (ys && as)
+        AVSR_LAUNCH((bn_act_fwd_kernel<float, sp8_t, sp8_t>), grid, block, 0, stream, x, (const sp8_t*)add, mean, invstd, gamma, beta,
+                    (sp8_t*)y, (long)rows, C, act, (bf16_t*)y2);
+    else if (ys)
+        AVSR_LAUNCH((bn_act_fwd_kernel<float, float, sp8_t>), grid, block, 0, stream, x, (const float*)add, mean, invstd, gamma, beta,
+                    (sp8_t*)y, (long)rows, C, act, (bf16_t*)y2);
+    else if (as)
+        AVSR_LAUNCH((bn_act_fwd_kernel<float, sp8_t, float>), grid, block, 0, stream, x, (const sp8_t*)add, mean, invstd, gamma, beta,
+                    (float*)y, (long)rows, C, act, (bf16_t*)y2);
+    else
+        AVSR_LAUNCH((bn_act_fwd_kernel<float>), grid, block, 0, stream, x, (const float*)add, mean, invstd, gamma, beta, (float*)y,
+                    (long)rows, C, act, (bf16_t*)y2);
     AVSR_CHECK_LAUNCH("bn_act_fwd2");
     return 0;
 }
@@ -1038,16 +1053,21 @@ extern "C" int avsr_bn_act_pool_fwd(const void* x, int dtype, const float* mean,
 
 // f32 input / output of the 3x3 / stride 2 / pad 1 case + the bf16 twin y2 of the pooled output and xsel2, the arg-max inputs in bf16
 // (either may be NULL), in the same pass -- the hpf / mixed modes' stem: no cast launches over the pooled tensors afterwards
+// y_split8: the pooled output is written in the split8 layout (prims.h sp8_t) for a split-plane consumer
 extern "C" int avsr_bn_act_pool3_fwd2(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                      float* y, void* y2, uint8_t* idx, void* xsel2, int64_t N, int H, int W, int C, int act,
-                                      hipStream_t stream) {
+                                      void* y, void* y2, uint8_t* idx, void* xsel2, int64_t N, int H, int W, int C, int act,
+                                      int y_split8, hipStream_t stream) {
     AVSR_REQUIRE(C % 8 == 0, "batchnorm: C must be a multiple of 8");
     AVSR_REQUIRE(idx != nullptr, "bn_act_pool3_fwd2: idx required");
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     if (N <= 0) return 0;
     dim3 grid(ew_grid((long)N * OH * OW * (C >> 3))), block(BN_THREADS);
-    AVSR_LAUNCH((bn_act_pool3_fwd_kernel<float>), grid, block, 0, stream, x, mean, invstd, gamma, beta, y, idx, (float*)nullptr, (long)N,
-                H, W, C, OH, OW, act, (bf16_t*)y2, (bf16_t*)xsel2);
+    if (y_split8)
+        AVSR_LAUNCH((bn_act_pool3_fwd_kernel<float, sp8_t>), grid, block, 0, stream, x, mean, invstd, gamma, beta, (sp8_t*)y, idx,
+                    (float*)nullptr, (long)N, H, W, C, OH, OW, act, (bf16_t*)y2, (bf16_t*)xsel2);
+    else
+        AVSR_LAUNCH((bn_act_pool3_fwd_kernel<float>), grid, block, 0, stream, x, mean, invstd, gamma, beta, (float*)y, idx,
+                    (float*)nullptr, (long)N, H, W, C, OH, OW, act, (bf16_t*)y2, (bf16_t*)xsel2);
     AVSR_CHECK_LAUNCH("bn_act_pool3_fwd2");
     return 0;
 }

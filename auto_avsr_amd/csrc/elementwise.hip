@@ -187,6 +187,11 @@ extern "C" int avsr_scale_dropout(const void* x, int x_dtype, void* out, int out
     if (x_dtype == 0 && out_dtype == 0) launch_scale_dropout<float, float>(x, out, n, alpha, alpha_dev, drop_p, seed, seed_dev, add, (long)add_period, stream);
     else if (x_dtype == 0 && out_dtype == 1) launch_scale_dropout<float, bf16_t>(x, out, n, alpha, alpha_dev, drop_p, seed, seed_dev, add, (long)add_period, stream);
     else if (x_dtype == 0 && out_dtype == 2) launch_scale_dropout<float, f16_t>(x, out, n, alpha, alpha_dev, drop_p, seed, seed_dev, add, (long)add_period, stream);
+    // x_dtype 3: the split8 storage layout of an f32-sized activation (prims.h sp8_t; n % 8 == 0)
+    else if (x_dtype == 3 && n % 8 != 0) { avsr_set_error("scale_dropout: a split8 source needs n % 8 == 0"); return 1; }
+    else if (x_dtype == 3 && out_dtype == 0) launch_scale_dropout<sp8_t, float>(x, out, n, alpha, alpha_dev, drop_p, seed, seed_dev, add, (long)add_period, stream);
+    else if (x_dtype == 3 && out_dtype == 1) launch_scale_dropout<sp8_t, bf16_t>(x, out, n, alpha, alpha_dev, drop_p, seed, seed_dev, add, (long)add_period, stream);
+    else if (x_dtype == 3 && out_dtype == 2) launch_scale_dropout<sp8_t, f16_t>(x, out, n, alpha, alpha_dev, drop_p, seed, seed_dev, add, (long)add_period, stream);
     else if (x_dtype == 2 && out_dtype == 0) launch_scale_dropout<f16_t, float>(x, out, n, alpha, alpha_dev, drop_p, seed, seed_dev, add, (long)add_period, stream);
     else if (x_dtype == 2 && out_dtype == 1) launch_scale_dropout<f16_t, bf16_t>(x, out, n, alpha, alpha_dev, drop_p, seed, seed_dev, add, (long)add_period, stream);
     else if (x_dtype == 2 || out_dtype == 2) { avsr_set_error("scale_dropout: unsupported f16 combination"); return 1; }

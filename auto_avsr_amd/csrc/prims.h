@@ -466,6 +466,35 @@ template <int NS> AVSR_DEV void split_bf16(float x, bf16_t* out) {
     if (NS == 2) out[NS - 1] = f2bf(x - bf2f(h));
 }
 
+// "split8" as a STORAGE type of an activation (round 5): an f32-sized tensor whose every group of 8 consecutive elements holds
+// the 8 hi bf16 followed by the 8 lo bf16 of the values it stands for (the layout csrc/gemm_split.hip consumes without a
+// conversion pass: tiles with ACV = 2).  The producers are element-wise passes (BatchNorm + activation), the other consumers read
+// it back as hi + lo (16 significant bits: what the split-plane contraction uses of the value anyway).  sizeof == 4, so pointer
+// arithmetic in elements is that of the f32 tensor; only whole groups of 8 are addressable.
+struct sp8_t { float raw; };
+AVSR_DEV void load8(const sp8_t* p, float* out) {
+    const bf16x8 hi = *reinterpret_cast<const bf16x8*>(p);
+    const bf16x8 lo = *(reinterpret_cast<const bf16x8*>(p) + 1);
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = bf2f((bf16_t)hi[i]) + bf2f((bf16_t)lo[i]);
+}
+AVSR_DEV void store8(sp8_t* p, const float* v) {
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        bf16_t pl[2];
+        split_bf16<2>(v[i], pl);
+        hi[i] = (short)pl[0];
+        lo[i] = (short)pl[1];
+    }
+    *reinterpret_cast<bf16x8*>(p) = hi;
+    *(reinterpret_cast<bf16x8*>(p) + 1) = lo;
+}
+template <> struct Elem<sp8_t> {  // (single elements of a split8 tensor are not addressable: callers keep counts multiples of 8)
+    static AVSR_DEV float ld(const sp8_t*) { return 0.f; }
+    static AVSR_DEV void st(sp8_t*, float) {}
+};
+
 // ---------------------------------------------------------------- stateless dropout RNG
 // keep-mask for element `idx` of a tensor under (seed, p): a 32-bit mix of the 64-bit (seed, idx) counter; forward and
 // backward recompute the same bits.

@@ -59,6 +59,16 @@ def bn_tuple(m):
             m.num_batches_tracked if m.training else None)
 
 
+_PRESPLIT = os.environ.get("AVSR_PRESPLIT", "1") != "0"  # A/B switch: split8 activations between the split-plane trunk stages
+
+
+def _presplit_ok():
+    """Is the running component one whose activations may leave in the split8 layout?  Mixed mode, split-plane arithmetic, forward
+    pass, producer-side twins on (the backward pass reads the bf16 twin, never the split8 tensor)."""
+    return bool(_PRESPLIT and _state["mixed"] and _state["precise"] and ops.SPLIT_FAST and ops.TWIN is not None
+                and not _state.get("in_bwd", False))
+
+
 class BasicBlockFn(torch.autograd.Function):
     """frontend/resnet.py:82-98 (and resnet1d.py:83-99 with H = 1) on a channels-last activation:
     conv3x3(stride) -> BN -> SiLU -> conv3x3 -> BN -> (+ identity | + BN(conv1x1(stride))) -> SiLU,
@@ -80,25 +90,31 @@ class BasicBlockFn(torch.autograd.Function):
         bn1 = (g1, b1) + bn1
         bn2 = (g2, b2) + bn2
         wp1 = _w_conv_fwd(w1, x)
+        wpd = _w_conv_fwd(wd, x) if wd is not None else None
+        # Mixed mode, split-plane component (round 5): activations that only a split-plane convolution and element-wise passes read
+        # travel in the split8 layout -- written that way by the BatchNorm + activation pass, staged by the convolution without its
+        # in-LDS conversion pass (csrc/gemm_split.hip, ACV = 2: stage-1 convolution 392 -> 294 us, tools/microbench_presplit.py).
+        ps = _presplit_ok()
+        if isinstance(x, ops.Split8) and not (pr and isinstance(wp1, ops.Split8) and (wd is None or isinstance(wpd, ops.Split8))):
+            x = ops.scale_dropout(x, torch.float32)  # (a consumer that cannot read the layout: one pass back to plain f32)
         st1 = _conv_bn_stats(x, wp1, Cin, Cout, KH, KW, rows, training)
         c1 = ops.conv2d_fwd(x, wp1, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, pr, stats=st1, wp_planes=wpl)
         m1, i1, n1 = _bn_fwd_params(c1, rows, Cout, bn1, training, parts=st1)
-        a1 = ops.bn_act_fwd(c1, None, m1, i1, g1, b1, rows, Cout, 1)
-        wp2 = _w_conv_fwd(w2, a1)
+        wp2 = _w_conv_fwd(w2, c1)
+        a1 = ops.bn_act_fwd(c1, None, m1, i1, g1, b1, rows, Cout, 1, out_split8=ps and isinstance(wp2, ops.Split8))
         st2 = _conv_bn_stats(a1, wp2, Cout, Cout, KH, KW, rows, training)
         c2 = ops.conv2d_fwd(a1, wp2, N, OH, OW, Cout, Cout, KH, KW, 1, ph, pw, pr, stats=st2, wp_planes=wpl)
         m2, i2, n2 = _bn_fwd_params(c2, rows, Cout, bn2, training, parts=st2)
         cd = md = idd = nd = None
         if wd is not None:
             bnd = (gd, bd) + bnd
-            wpd = _w_conv_fwd(wd, x)
             std = _conv_bn_stats(x, wpd, Cin, Cout, 1, 1, rows, training)
             cd = ops.conv2d_fwd(x, wpd, N, H, W, Cin, Cout, 1, 1, stride, 0, 0, pr, stats=std, wp_planes=wpl)
             md, idd, nd = _bn_fwd_params(cd, rows, Cout, bnd, training, parts=std)
             r = ops.bn_act_fwd(cd, None, md, idd, gd, bd, rows, Cout, 0)
         else:
             r = x
-        out = ops.bn_act_fwd(c2, r, m2, i2, g2, b2, rows, Cout, 1)
+        out = ops.bn_act_fwd(c2, r, m2, i2, g2, b2, rows, Cout, 1, out_split8=ps and Cout % 64 == 0)
         sx = x_arg if (_state["hpf"] and x_arg.dtype == torch.bfloat16 and x_arg is not x) else _A(x)  # (the handed-over twin itself)
         ctx.save_for_backward(sx, _A(c1), _A(a1), _A(c2), _A(cd), _A(r) if wd is not None else None, w1, w2, wd, g1, b1, g2, b2,
                               gd, bd, m1, i1, n1, m2, i2, n2, md, idd, nd)
@@ -192,7 +208,9 @@ class StemFn(torch.autograd.Function):
             # BN + SiLU + max-pool in one pass: the full-resolution activation (396 MB per 1600 video frames) is never
             # written (the backward pass recomputes it from c0 anyway)
             # xsel: the raw conv output at every arg-max -- all the backward reduce pass needs of c0
-            out, idx, xsel = ops.bn_act_pool_fwd(c0, m0, i0, g, b, B * Tn, OH, OW, Cout, 3, 2, 1, 1, want_xsel=True)
+            out, idx, xsel = ops.bn_act_pool_fwd(c0, m0, i0, g, b, B * Tn, OH, OW, Cout, 3, 2, 1, 1, want_xsel=True,
+                                                 out_split8=_presplit_ok() and c0.dtype == torch.float32 and Cout % 64 == 0
+                                                 and AF.MIXED_POLICY.get("trunk1", "split") == "split")
         elif pool:
             a0 = ops.bn_act_fwd(c0, None, m0, i0, g, b, rows, Cout, 1)
             out, idx = ops.maxpool2d_fwd(a0, B * Tn, OH, OW, Cout, 3, 2, 1)
@@ -252,7 +270,10 @@ class AvgPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, groups, win, C):
         ctx.meta = (groups, win, C, x.dtype, x.shape)
-        return ops.avgpool_fwd(_f32_in(x).contiguous(), groups, win, C)  # (hpf: the trunk hands over its bf16 twin)
+        xi = _f32_in(x)  # (hpf: the trunk hands over its bf16 twin)
+        if isinstance(xi, ops.Split8):
+            xi = ops.scale_dropout(xi, torch.float32)
+        return ops.avgpool_fwd(xi.contiguous(), groups, win, C)
 
     @staticmethod
     @_bwd_mode

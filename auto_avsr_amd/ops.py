@@ -12,7 +12,14 @@ _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}  # f16: for
 NT, NN, TN = 0, 1, 2
 
 
-def dt(t):
+def dt(t, split8_ok=False):
+    """dtype code of the C ABI: 0 f32, 1 bf16, 2 f16; 3 = an f32-sized activation stored in the split8 layout (Split8 below).
+    Only avsr_scale_dropout reads that layout through a dtype code; any other binding that asks for the code of a Split8 tensor
+    fails here, loudly, instead of handing its bytes to a kernel as f32."""
+    if isinstance(t, Split8):
+        if not split8_ok:
+            raise TypeError("a split8-layout activation reached an entry point that cannot read it")
+        return 3
     return _DT[t.dtype]
 
 
@@ -249,7 +256,7 @@ def attention_bwd(qu, qv, k, v, pos, mask, out, lse, dout, scale, *, precise=Fal
 def scale_dropout(x, out_dtype, alpha=1.0, drop_p=0.0, seed=0, alpha_dev=None, seed_dev=None, add=None,
                   add_period=0):
     out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
-    call("avsr_scale_dropout", _ptr(x), dt(x), _ptr(out), dt(out), x.numel(), alpha, _ptr(alpha_dev), drop_p, seed,
+    call("avsr_scale_dropout", _ptr(x), dt(x, split8_ok=True), _ptr(out), dt(out), x.numel(), alpha, _ptr(alpha_dev), drop_p, seed,
          _ptr(seed_dev), _ptr(add), add_period, _stream(x))
     return out
 
@@ -415,8 +422,14 @@ def bn_eval_params(running_mean, running_var, eps):
     return mean, invstd
 
 
-def bn_act_fwd(x, add, mean, invstd, gamma, beta, rows, C, act):
+def bn_act_fwd(x, add, mean, invstd, gamma, beta, rows, C, act, out_split8=False):
+    """out_split8 (f32 input only): the output leaves in the split8 layout (a Split8-tagged f32-sized tensor) -- what the
+    split-plane convolution stages without a conversion pass; `add` may be Split8-tagged itself."""
     y = torch.empty_like(x)
+    if isinstance(y, Split8):
+        y = y.as_subclass(torch.Tensor)
+    add_s8 = isinstance(add, Split8)
+    assert not (out_split8 or add_s8) or (x.dtype == torch.float32 and not isinstance(x, Split8))
     if x.dtype == torch.float16:
         assert add is None or add.dtype == torch.float16
         y2 = _twin(y)
@@ -424,16 +437,16 @@ def bn_act_fwd(x, add, mean, invstd, gamma, beta, rows, C, act):
              act, _stream(x), nbytes=_nb(x, add, y, y2))
         return y
     y2 = _twin(y) if (add is None or add.dtype == torch.float32) else None
-    if y2 is not None:
+    if y2 is not None or out_split8 or add_s8:
         call("avsr_bn_act_fwd2", _ptr(x), _ptr(add), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(y2), rows, C,
-             act, _stream(x), nbytes=_nb(x, add, y, y2))
-        return y
+             act, int(out_split8) | (2 if add_s8 else 0), _stream(x), nbytes=_nb(x, add, y, y2))
+        return y.as_subclass(Split8) if out_split8 else y
     call("avsr_bn_act_fwd", _ptr(x), _ptr(add), dt(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y),
          rows, C, act, _stream(x), nbytes=_nb(x, add, y))
     return y
 
 
-def bn_act_pool_fwd(x, mean, invstd, gamma, beta, N, H, W, C, K, S, P, act, want_xsel=False):
+def bn_act_pool_fwd(x, mean, invstd, gamma, beta, N, H, W, C, K, S, P, act, want_xsel=False, out_split8=False):
     """maxpool(act(bn(x))) without the full-resolution activation; returns (y, idx) like maxpool2d_fwd -- and with
     want_xsel (3x3 / stride 2 / pad 1 only) also xsel, the raw x at every arg-max."""
     OH, OW = conv_out(H, K, S, P), conv_out(W, K, S, P)
@@ -441,11 +454,12 @@ def bn_act_pool_fwd(x, mean, invstd, gamma, beta, N, H, W, C, K, S, P, act, want
     idx = torch.empty(N, OH, OW, C, dtype=torch.uint8, device=x.device)
     if x.dtype == torch.float32 and (K, S, P) == (3, 2, 1) and want_xsel:
         y2 = _twin(y)
-        if y2 is not None:  # hpf / mixed modes: the pooled output's bf16 twin and the arg-max inputs in bf16, from the same pass
+        if y2 is not None or out_split8:  # hpf / mixed modes: the pooled output's bf16 twin and the arg-max inputs in bf16, from the same pass
             xsel = torch.empty(N, OH, OW, C, dtype=torch.bfloat16, device=x.device)
             call("avsr_bn_act_pool3_fwd2", _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(y2), _ptr(idx),
-                 _ptr(xsel), N, H, W, C, act, _stream(x), nbytes=_nb(x, y, y2, idx, xsel))
-            return y, idx, xsel
+                 _ptr(xsel), N, H, W, C, act, int(out_split8), _stream(x), nbytes=_nb(x, y, y2, idx, xsel))
+            return (y.as_subclass(Split8) if out_split8 else y), idx, xsel
+    assert not out_split8, "split8 output: the fused 3x3 / stride-2 stem pass with a producer-side twin only"
     xsel = torch.empty_like(y) if want_xsel else None
     call("avsr_bn_act_pool_fwd", _ptr(x), dt(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(idx),
          _ptr(xsel), N, H, W, C, K, S, P, act, _stream(x), nbytes=_nb(x, y, idx, xsel))
@@ -665,15 +679,21 @@ def conv2d_fwd(x, wp, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise, stats
              nbytes=_nb(x) + (2.0 if lo is not None else 1.0) * 2.0 * Cout * KH * KW * Cin + 4.0 * N * OH * OW * Cout)
         return y
     if precise and SPLIT_FAST and x.dtype == torch.float32 and wp.dtype == torch.float32 and Cin % 64 == 0 and KH * KW <= 32:
+        # x in the split8 layout (its producer wrote it that way): the kernel variants that stage A without a conversion pass
+        tile = 0
+        if isinstance(x, Split8):
+            assert isinstance(wp, Split8), "a pre-split activation needs the pre-split filter"
+            tile = 24 if Cout >= 128 else 23
         if stats is not None:
             call("avsr_conv2d_f32s_stats", _ptr(x), _ptr(wp), _ptr(y), _ptr(zero_page(x.device)), N, H, W, Cin, Cout, KH, KW, stride,
-                 ph, pw, 0, int(isinstance(wp, Split8)), _ptr(_twin(y)), _ptr(stats), stats.shape[0], _stream(x),
+                 ph, pw, tile, int(isinstance(wp, Split8)), _ptr(_twin(y)), _ptr(stats), stats.shape[0], _stream(x),
                  flops=2.0 * N * OH * OW * Cout * KH * KW * Cin, nbytes=_nb(x, wp, y))
             return y
         call("avsr_conv2d_f32s", _ptr(x), _ptr(wp), _ptr(y), _ptr(zero_page(x.device)), N, H, W, Cin, Cout, KH, KW, stride,
-             ph, pw, 0, int(isinstance(wp, Split8)), _ptr(_twin(y)), _stream(x),
+             ph, pw, tile, int(isinstance(wp, Split8)), _ptr(_twin(y)), _stream(x),
              flops=2.0 * N * OH * OW * Cout * KH * KW * Cin, nbytes=_nb(x, wp, y))
         return y
+    assert not isinstance(x, Split8), "a pre-split activation reached a convolution path that cannot read it"
     call("avsr_conv2d_fwd", _ptr(x), dt(x), _ptr(wp), dt(wp), _ptr(y), N, H, W, Cin, Cout, KH, KW, stride, ph, pw,
          int(precise), _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin)
     return y

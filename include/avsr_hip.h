@@ -186,9 +186,11 @@ int avsr_bn_small_bwd(const void* x, const void* dy, int dtype, int64_t rows, in
 int avsr_bn_act_fwd(const void* x, const void* add, int dtype, const float* mean, const float* invstd,
                     const float* gamma, const float* beta, void* y, int64_t rows, int C, int act,
                     avsr_stream_t stream);
-/* f32 in / f32 out + the bf16 twin y2 of the output */
-int avsr_bn_act_fwd2(const float* x, const float* add, const float* mean, const float* invstd, const float* gamma,
-                     const float* beta, float* y, void* y2, int64_t rows, int C, int act, avsr_stream_t stream);
+/* f32 in / f32 out + the bf16 twin y2 of the output.  layout (round 5): bit 0 -- y is written in the "split8" layout (every group
+ * of 8 consecutive values as its 8 hi bf16 + 8 lo bf16: the bytes of the f32 tensor, and what avsr_conv2d_f32s* consumes as a
+ * pre-split A operand -- tile codes 23 - 26 -- without a conversion pass); bit 1 -- `add` is stored in that layout */
+int avsr_bn_act_fwd2(const float* x, const void* add, const float* mean, const float* invstd, const float* gamma,
+                     const float* beta, void* y, void* y2, int64_t rows, int C, int act, int layout, avsr_stream_t stream);
 /* maxpool(act(bn(x))) in one pass: y [N][OH][OW][C] + argmax idx (uint8, kh*K+kw of the first maximum) from
  * x [N][H][W][C]; replaces BatchNorm3d + SiLU + MaxPool3d((1,3,3),(1,2,2),(0,1,1)) of the video stem
  * (frontend/resnet.py:212-218) without materialising the full-resolution activation */
@@ -200,8 +202,9 @@ int avsr_bn_act_pool_fwd(const void* x, int dtype, const float* mean, const floa
                          int64_t N, int H, int W, int C, int K, int S, int P, int act, avsr_stream_t stream);
 /* the 3x3 / stride 2 / pad 1 case on an f32 input with the bf16 twin y2 of the pooled f32 output and the arg-max inputs xsel2 in
  * bf16 written in the same pass (either may be NULL): the video stem of the hpf / mixed modes */
-int avsr_bn_act_pool3_fwd2(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, float* y,
-                           void* y2, uint8_t* idx, void* xsel2, int64_t N, int H, int W, int C, int act, avsr_stream_t stream);
+int avsr_bn_act_pool3_fwd2(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, void* y,
+                           void* y2, uint8_t* idx, void* xsel2, int64_t N, int H, int W, int C, int act, int y_split8,
+                           avsr_stream_t stream);
 /* backward of avsr_bn_act_pool_fwd in the two BatchNorm backward passes, the activation gradient gathered from the pooled
  * gradient dpool [N][OH][OW][C] through idx (no full-resolution gradient tensor): sums [2][C] = (sum dz, sum dz*xhat),
  * then dx [N][H][W][C] from the (all-reduced) sums; workspace / inv_n / n_dev as avsr_bn_bwd_reduce / _apply */

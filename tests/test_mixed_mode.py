@@ -311,6 +311,55 @@ def test_stem_leaves_batchnorm_statistics(dev):
     assert rel(mean, mean0) < 1e-5 and rel(invstd, invstd0) < 1e-5
 
 
+def test_split8_activations(dev, twins):
+    """Round 5: activations between the split-plane trunk stages travel in the split8 layout (8 hi bf16 + 8 lo bf16 per group of
+    8 values, the bytes of the f32 tensor).  The BatchNorm + activation pass writes it (and reads a split8 residual), the
+    split-plane convolution stages it without its in-LDS conversion pass -- bit-identical to the conversion it replaces -- and
+    the cast kernel reads it back (component boundaries)."""
+    torch.manual_seed(3)
+    N, H, W, C, Cout = 3, 11, 11, 64, 128
+    rows = N * H * W
+    c = torch.randn(rows, C)
+    res = torch.randn(rows, C)
+    mean, invstd, g, b = 0.1 * torch.randn(C), 1.0 + 0.1 * torch.rand(C), 1.0 + 0.1 * torch.randn(C), 0.1 * torch.randn(C)
+    z = (c - mean) * invstd * g + b
+
+    def sp(v):  # what the layout keeps of a value: hi + lo bf16
+        hi = v.bfloat16().float()
+        return hi + (v - hi).bfloat16().float()
+
+    a = ops.bn_act_fwd(c.to(dev), None, mean.to(dev), invstd.to(dev), g.to(dev), b.to(dev), rows, C, 1, out_split8=True)
+    assert isinstance(a, ops.Split8) and a.dtype == torch.float32 and ops.dt(a, split8_ok=True) == 3
+    want = torch.nn.functional.silu(z)
+    back = ops.scale_dropout(a, torch.float32).cpu()
+    assert torch.allclose(back, sp(want), rtol=2e-5, atol=2e-6) and rel(back, want) < 1e-5  # (16 significant bits)
+    assert torch.equal(back, sp(back))  # what comes back is exactly representable as hi + lo
+    (y, tw), = twins
+    assert y.data_ptr() == a.data_ptr() and rel(tw.float(), want) < 4e-3
+    assert rel(ops.scale_dropout(a, torch.float16).float(), want) < 5e-4  # (boundary to an f16 component)
+    # a split8 residual + split8 output
+    twins.clear()
+    o = ops.bn_act_fwd(c.to(dev), a, mean.to(dev), invstd.to(dev), g.to(dev), b.to(dev), rows, C, 1, out_split8=True)
+    want2 = torch.nn.functional.silu(z + back)
+    assert rel(ops.scale_dropout(o, torch.float32), want2) < 1e-5
+    # the convolution on the pre-split operand == the convolution that converts the f32 tile in LDS (up to the f32 rounding of
+    # hi + lo when the pair is summed back for the comparison: 2^-24)
+    w = 0.1 * torch.randn(Cout, C, 3, 3)
+    wp = ops.conv_weight_permute_split(w.to(dev))
+    x32 = back.view(N, H, W, C).to(dev)  # (values that are exactly representable in the layout)
+    y_conv = ops.conv2d_fwd(x32, wp, N, H, W, C, Cout, 3, 3, 2, 1, 1, True)
+    y_pre = ops.conv2d_fwd(a.view(N, H, W, C), wp, N, H, W, C, Cout, 3, 3, 2, 1, 1, True)
+    assert rel(y_pre, y_conv) < 1e-6
+    st = torch.empty(ops.bn_stat_tiles(N * 6 * 6), 2, Cout, device=dev)
+    y_pre2 = ops.conv2d_fwd(a.view(N, H, W, C), wp, N, H, W, C, Cout, 3, 3, 2, 1, 1, True, stats=st)
+    assert torch.equal(y_pre.cpu(), y_pre2.cpu())
+    ref = torch.nn.functional.conv2d(back.view(N, H, W, C).double().permute(0, 3, 1, 2), w.double(), stride=2, padding=1).permute(0, 2, 3, 1)
+    assert rel(y_pre, ref) < 3e-5
+    # a consumer that cannot read the layout fails loudly
+    with pytest.raises(TypeError):
+        ops.bn_stats(a, rows, C)
+
+
 # ---------------------------------------------------------------------------------------------------------------- module level
 POLICIES = {
     "default": None,
@@ -339,6 +388,7 @@ def test_e2e_small_mixed_mode(dev, modality, policy, monkeypatch):
 
     if policy == "all-split":  # bit-identity with hpf below: BatchNorm statistics from the stand-alone pass, as hpf takes them
         monkeypatch.setattr(FF, "_FUSE_BN_STATS", False)
+        monkeypatch.setattr(FF, "_PRESPLIT", False)  # (and plain f32 activations between the trunk stages, as in hpf)
     trace = []
     monkeypatch.setattr(ops, "TRACE", trace)
     torch.manual_seed(0)
