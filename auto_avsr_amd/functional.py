@@ -454,6 +454,22 @@ def _refresh_h16_weights(everything=False):
         ent[0] = ent[2]._version
 
 
+def _cast_h16_entries(ents):
+    """(Re)write the two-plane copies of the given cache entries with one multi-tensor launch over a table built on the spot."""
+    import struct
+
+    blob, blk = b"", 0
+    for ent in ents:
+        R, C = ent[2].shape
+        tiles_c, tiles_r = (C + 63) // 64, (R + 63) // 64
+        blob += struct.pack("<QQQiiiiiiii", ent[2].data_ptr(), ent[1].data_ptr(), 0, R, C, 0, blk, tiles_c, 0, 2, 0)
+        blk += tiles_r * tiles_c
+    table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(ents[0][2].device)
+    ops.multi_cast_transpose(table, len(ents), blk)
+    for ent in ents:
+        ent[0] = ent[2]._version
+
+
 def _w_h16(w2d):
     """Two-plane f16 copy [out, 2, in] of a Linear-type weight [out, in]."""
     if _wgen["dirty"]:
@@ -468,7 +484,7 @@ def _w_h16(w2d):
     if ent is None:
         ent = _wh16[key] = [-1, torch.empty(w2d.shape[0], 2, w2d.shape[1], dtype=torch.float16, device=w2d.device), w2d]
         _wh16_table["built_for"] = -1
-    _refresh_h16_weights(everything=True)  # (one multi-tensor launch brings every registered copy up to date)
+    _cast_h16_entries([ent])  # (this copy alone: a one-entry table -- registration happens once per weight, outside any capture)
     return ent[1]
 
 

@@ -340,7 +340,7 @@ def main():
     if dp and os.environ.get("AVSR_DDP") in ("torch", "buckets", "buckets-graph", "buckets-graph1"):
         args.ddp = os.environ["AVSR_DDP"]  # set by supervise() per attempt (or by hand: AVSR_DDP=torch is the conservative path)
     if dp and args.ddp == "auto":
-        args.ddp = "buckets-graph"
+        args.ddp = DDP_CHAIN[0]  # (a worker started without the supervisor: the head of the chain, the single-communicator mode)
     graph_modes = ("buckets-graph", "buckets-graph1")
     if dp and args.ddp in graph_modes:
         # every collective of the step straight on RCCL's C API (auto_avsr_amd/comm.py): stream operations only, so the capture
