@@ -111,7 +111,8 @@ int avsr_gemm_tn_batched(const void* A, int a_dtype, int lda, int64_t sAb, int64
 
 /* ---- elementwise glue (elementwise.hip) --------------------------------------------------- */
 /* out = dropout(alpha*x + add[i % add_period])   (add may be NULL; embedding.py:78-87,179-184; the dropout
- * branches of conformer_encoder.py:114-157 on the backward side; ctc.py:54) */
+ * branches of conformer_encoder.py:114-157 on the backward side; ctc.py:54).  x_dtype 3 (round 5): x is an f32-sized activation
+ * stored in the split8 layout (n % 8 == 0) -- the cast at the boundary between a split-plane and an f16 component */
 int avsr_scale_dropout(const void* x, int x_dtype, void* out, int out_dtype, int64_t n, float alpha,
                        const float* alpha_dev, float drop_p, uint64_t seed, const uint64_t* seed_dev,
                        const float* add, int64_t add_period, avsr_stream_t stream);
@@ -332,7 +333,10 @@ int avsr_gemm_f32s_nt(const float* A, int lda, const float* B, int ldb, int M, i
 int avsr_split_pack(const float* src, void* dst, int64_t n, avsr_stream_t stream);
 int avsr_multi_split_pack(const void* table, int n, int total_blocks, avsr_stream_t stream);
 /* f32 convolution forward on the same kernel (implicit GEMM, channels-last, Cin % 64 == 0; frontend/resnet.py:10-35):
- * x[N,H,W,Cin] * wp[Cout][KH][KW][Cin] -> y[N,OH,OW,Cout], all f32; zero_page: >= 16 zero bytes of device memory */
+ * x[N,H,W,Cin] * wp[Cout][KH][KW][Cin] -> y[N,OH,OW,Cout], all f32; zero_page: >= 16 zero bytes of device memory.
+ * tile: 0 = automatic (128 x 128 for Cout >= 128, else 128 x 64; the staged A tile converted to split8 in LDS once per stage);
+ * 23 / 24 (25 / 26 with a 3-stage ring) = 128 x 64 / 128 x 128 on an x that ARRIVES in the split8 layout (w_split = 1 required:
+ * avsr_bn_act_fwd2 layout bit 0 / avsr_bn_act_pool3_fwd2 y_split8 write it) -- no conversion pass, one barrier per k-tile */
 int avsr_conv2d_f32s(const float* x, const float* wp, float* y, const void* zero_page, int N, int H, int W, int Cin, int Cout,
                      int KH, int KW, int stride, int pad_h, int pad_w, int tile, int w_split /* 1: wp in the split8 layout */,
                      void* y2 /* may be NULL: bf16 twin of y */, avsr_stream_t stream);
