@@ -55,8 +55,10 @@ AVSR_DEV void adam_update(float& p, float g, float& m, float& v, const AdamScala
     p -= s.step_size * (m / denom);
 }
 
-// dst_i[0 .. numel_i) = scale * src_i[...] for every table entry {p = dst, g = src, numel, blk0} (m / v unused): the
-// gradients of one data-parallel bucket gathered into the bucket's flat buffer (and pre-divided by the world size) in ONE launch.
+// dst_i[0 .. numel_i) = scale * src_i[...] for every table entry {p = dst, g = src, m = optional bf16 dst, numel, blk0} (v unused):
+// the gradients of one data-parallel bucket gathered into the bucket's flat buffer (and pre-divided by the world size) in ONE launch.
+// m != NULL (round 5, the bf16 wire format): the scaled gradient goes to the bf16 buffer m INSTEAD of p -- the bucket travels as
+// bf16 and is widened into p after the all-reduce, so the f32 image of the local gradients and the cast pass over it are skipped.
 // Gradients may be dword-aligned only (views into other buffers): scalar accesses at the ragged ends.
 __global__ __launch_bounds__(256) void multi_copy_scale_kernel(const OptEntry* __restrict__ table, int n, float scale) {
     const OptEntry e = find_entry(table, n, blockIdx.x);
@@ -66,13 +68,24 @@ __global__ __launch_bounds__(256) void multi_copy_scale_kernel(const OptEntry* _
     for (int j = 0; j < 4; j++) {
         const long i = base + (threadIdx.x + 256 * j) * 4;
         if (i >= e.numel) break;
+        bf16_t* nb = reinterpret_cast<bf16_t*>(e.m);
         if (vec && i + 4 <= e.numel) {
             f32x4 v = *reinterpret_cast<const f32x4*>(e.g + i);
 #pragma unroll
             for (int k = 0; k < 4; k++) v[k] *= scale;
-            *reinterpret_cast<f32x4*>(e.p + i) = v;
+            if (nb) {
+                bf16x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; k++) o[k] = (short)f2bf(v[k]);
+                *reinterpret_cast<bf16x4*>(nb + i) = o;  // (bucket slices start 16-byte aligned in f32: 8-byte aligned here)
+            } else {
+                *reinterpret_cast<f32x4*>(e.p + i) = v;
+            }
         } else {
-            for (int k = 0; k < 4 && i + k < e.numel; k++) e.p[i + k] = scale * e.g[i + k];
+            for (int k = 0; k < 4 && i + k < e.numel; k++) {
+                if (nb) nb[i + k] = f2bf(scale * e.g[i + k]);
+                else e.p[i + k] = scale * e.g[i + k];
+            }
         }
     }
 }

@@ -131,6 +131,10 @@ class GradBuckets:
             rows = np.zeros((len(idx), 6), dtype=np.uint64)
             rows[:, 0] = [self.views[i].data_ptr() for i in idx]
             rows[:, 1] = ptrs
+            if self.narrow is not None and self.comm is not None:
+                # bf16 wire: the gather writes the scaled gradients straight into the bf16 bucket (csrc/optim.hip
+                # multi_copy_scale_kernel, entry field m); the f32 views are filled by the widening pass after the all-reduce
+                rows[:, 2] = [self.narrow[b].data_ptr() + 2 * self.offset[i] for i in idx]
             rows[:, 4] = numel.astype(np.uint64)
             rows[:, 5] = (np.cumsum(nblk) - nblk).astype(np.uint64)
             host.numpy()[:] = rows.reshape(-1).view(np.uint8)
@@ -201,7 +205,7 @@ class GradBuckets:
     def _reduce(self, b):
         """The all-reduce of bucket b on the current stream, in the wire format."""
         if self.wire == "bf16":
-            ops.cast_into(self.flat[b], self.narrow[b])   # f32 -> bf16 (round to nearest even), 6 B per element
+            # (the bucket is already bf16: the gather launch wrote it -- no pass over an f32 image of the local gradients)
             self.comm.all_reduce(self.narrow[b])
             ops.cast_into(self.narrow[b], self.flat[b])   # back to the f32 views the optimizer reads
         else:
