@@ -62,13 +62,25 @@ class GradBuckets:
         self.comm = comm
         self.world = comm.world if comm is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.device = self.params[0].device
-        cap = max(1, int(bucket_mb * (1 << 20) / 4))
-        # buckets over the parameters in reverse order; every slice starts 16-byte aligned
+        self._cap = max(1, int(bucket_mb * (1 << 20) / 4))
+        self._n_spare = spare
+        # first assignment: the parameters in reverse registration order (roughly the order their gradients become ready); the
+        # first step records the REAL arrival order and rebuild_by_arrival() re-buckets by it (see there)
+        self._arrival = []
+        self.rebuilt = False
+        self._assign(list(reversed(range(len(self.params)))))
+        self.compute_stream = None  # set by begin_step(): the stream the step's kernels are issued on
+        self._side = torch.cuda.Stream(device=self.device) if (comm is not None and self.device.type == "cuda") else None
+        self._side_used = False
+        self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
+
+    def _assign(self, order):
+        """Buckets of at most `_cap` f32 elements over the parameters in `order`; every slice starts 16-byte aligned."""
         self.bucket_of, self.offset, sizes, members = {}, {}, [], []
         cur, cur_n = [], 0
-        for i in reversed(range(len(self.params))):
+        for i in order:
             n = (self.params[i].numel() + 3) // 4 * 4
-            if cur and cur_n + n > cap:
+            if cur and cur_n + n > self._cap:
                 members.append(cur)
                 sizes.append(cur_n)
                 cur, cur_n = [], 0
@@ -90,14 +102,34 @@ class GradBuckets:
         # rewritten only after the asynchronous copy that last read them has completed.  Everything pinned is allocated HERE
         # (hipHostMalloc is not allowed under stream capture).
         self._captured = {}  # (bucket, gradient addresses) -> (host rows, device table, blocks)
-        self._spare = [[self._new_slot(len(m)) for _ in range(spare)] for m in members]  # for captured steps (one per batch shape)
+        self._spare = [[self._new_slot(len(m)) for _ in range(self._n_spare)] for m in members]  # for captured steps (one per batch shape)
         self._ring = [[self._new_slot(len(m)) for _ in range(4)] for m in members]    # for eager steps
         self._ring_pos = [0] * len(members)
-        self.compute_stream = None  # set by begin_step(): the stream the step's kernels are issued on
         self._seen = [dict() for _ in members]  # per bucket: the streams its parameters' hooks ran on in this step
-        self._side = torch.cuda.Stream(device=self.device) if (comm is not None and self.device.type == "cuda") else None
-        self._side_used = False
-        self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
+
+    def rebuild_by_arrival(self):
+        """Re-bucket the parameters in the order their gradients ARRIVED during the first step (what torch DDP does after its
+        first iteration).  Registration order is a poor predictor here: one autograd node produces the `linear_pos` weight
+        gradients of ALL twelve encoder layers at the very end of the encoder's backward pass, so under the first assignment
+        every encoder bucket holds one late member and all of them flush together, ten buckets at once with only the trunk's
+        backward left to hide under (round 5, `config.bucket_overlap` of a one-rank run: encoder buckets at 35.3 - 36.6 ms of
+        a step whose decoder buckets left at 22.5 ms).  In arrival order the late gradients share the LAST bucket and every
+        other bucket leaves as soon as its layers are done.  Call once, after the first (eager) step, with the gradients
+        cleared, before any hipGraph capture; every rank must call it (rank 0's order is broadcast: one order for all)."""
+        assert not self._captured and all(n == len(m) for n, m in zip(self._left, self.members)), "rebuild between steps, before captures"
+        order = list(self._arrival)
+        self._arrival = None
+        self.rebuilt = True
+        if sorted(order) != list(range(len(self.params))):
+            return False  # (a step that did not touch every parameter exactly once: keep the first assignment)
+        if self.world > 1 and self.group is not None and dist.is_initialized():
+            t = torch.tensor(order, dtype=torch.int64, device=self.device if dist.get_backend(self.group) != "gloo" else "cpu")
+            dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not dist.group.WORLD else 0, group=self.group)
+            order = t.tolist()
+        for p in self.params:
+            assert p.grad is None, "rebuild_by_arrival: clear the gradients first (they are views of the old buckets)"
+        self._assign(order)
+        return True
 
     def _new_slot(self, n):
         host = torch.empty(48 * n, dtype=torch.uint8)
@@ -108,6 +140,8 @@ class GradBuckets:
     def _make_hook(self, i):
         def hook(param):
             b = self.bucket_of[i]
+            if self._arrival is not None:
+                self._arrival.append(i)
             if self.device.type == "cuda":
                 # a post-accumulate hook runs on the stream of its parameter's AccumulateGrad node -- not necessarily the
                 # same stream for every parameter of the bucket (nodes that survived from an earlier iteration keep theirs)
@@ -236,6 +270,8 @@ class GradBuckets:
                 self.timing["joined"].record()
             self._side_used = False
         self._left = [len(m) for m in self.members]
+        if self._arrival is not None and len(self._arrival) > len(self.params):
+            self._arrival = None  # (more than one step went by without a rebuild: the record is of no use any more)
 
     def time_next_step(self):
         """Diagnostics: the next EAGER step records an event pair around every bucket's exchange on the side stream and around

@@ -251,6 +251,10 @@ def _fit(model, args, dev, rank, world, backend, log, held):
         if buckets is not None:
             buckets.finish()
         opt.step()
+        if buckets is not None and not buckets.rebuilt and not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            for p in params:  # (after the first step: buckets in the order the gradients arrived -- ddp.GradBuckets.rebuild_by_arrival)
+                p.grad = None
+            buckets.rebuild_by_arrival()
         return loss.detach(), loss_ctc.detach(), loss_att.detach(), hits, ntok
 
     # hipGraph replay per batch shape (what bench.py times): single-rank runs, and data-parallel runs whose collectives are all

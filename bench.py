@@ -439,6 +439,11 @@ def main():
             buckets.finish()  # the compute stream waits for the bucket all-reduces issued during the backward pass
         if st["opt"] is not None:
             st["opt"].step()
+        if buckets is not None and not buckets.rebuilt and not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            # after the FIRST step (always an eager one): re-bucket the parameters in the order their gradients arrived, so that
+            # every bucket leaves as soon as its layers are done (ddp.GradBuckets.rebuild_by_arrival; every rank, same order)
+            clear_grads()
+            buckets.rebuild_by_arrival()
         return (loss,)
 
     # One hipGraph per batch shape (auto_avsr_amd/graph_step.py -- the same class train.py's native driver steps through): the

@@ -348,6 +348,14 @@ def _worker_buckets(rank, world, port, emu_path, out_dir, transport="group", wir
             assert torch.allclose(p.grad, q.grad, **tol), float((p.grad - q.grad).abs().max())
         for p in list(net.parameters()) + list(ref.parameters()):
             p.grad = None
+        if step == 0:
+            # round 5: after the first step the buckets are rebuilt in the order the gradients ARRIVED (rank 0's order, broadcast);
+            # the following steps must give the same averaged gradients through the new assignment
+            before = [list(m) for m in gb.members]
+            assert gb.rebuild_by_arrival() and gb.rebuilt
+            flat_order = [i for m in gb.members for i in m]
+            assert sorted(flat_order) == list(range(len(gb.params))) and flat_order[0] == len(gb.params) - 1  # last layer's weight first
+            assert [i for m in before for i in m] != [] and len(gb.flat) >= 3
     # a parameter that gets no gradient is an error at finish(), as with find_unused_parameters=False
     x = torch.randn(4, 37)
     net[0](x).sum().backward()
