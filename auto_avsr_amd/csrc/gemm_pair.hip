@@ -22,6 +22,7 @@ namespace {
 using avsr_gemm_impl::Params;
 using avsr_fast::FastKernel;
 using Tn = avsr_tn::TnKernel<3, 0>;
+using Tn128 = avsr_tn::TnKernel<2, 0, 2, 2>;  // 128 x 128 weight-gradient tiles (gemm_tn_kernel.h): the large dW of FFN / fused Q / K / V
 
 struct PairState {
     bool active = false, have_nt = false, have_tn = false;
@@ -29,11 +30,12 @@ struct PairState {
     int nt_tile = 0;
     int gxa = 0, gya = 0;            // NT grid
     int gxb = 0, gyb = 0, gzb = 0;   // TN grid (z = k-split)
+    int tn_big = 0;                  // 1: 128 x 128 TN tiles
     hipStream_t stream = nullptr;
 };
 thread_local PairState g_pair;
 
-template <class KA>
+template <class KA, class KB>
 __global__ __launch_bounds__(256) void gemm_pair_kernel(Params pa, Params pb, int na, int gxa, int gya, int gxb, int gyb) {
     AVSR_DYN_SMEM(smem);
     int b = blockIdx.x;
@@ -43,16 +45,16 @@ __global__ __launch_bounds__(256) void gemm_pair_kernel(Params pa, Params pb, in
     } else {
         b -= na;
         const int r = b / gxb;
-        Tn::run_at(pb, smem, b - r * gxb, r % gyb, r / gyb);
+        KB::run_at(pb, smem, b - r * gxb, r % gyb, r / gyb);
     }
 }
 
-template <class KA>
+template <class KA, class KB>
 void launch_pair(const PairState& s) {
     const int na = s.have_nt ? s.gxa * s.gya : 0;
     const int nb = s.have_tn ? s.gxb * s.gyb * s.gzb : 0;
-    const size_t lds = KA::LDS_BYTES > Tn::LDS_BYTES ? KA::LDS_BYTES : Tn::LDS_BYTES;
-    AVSR_LAUNCH((gemm_pair_kernel<KA>), dim3(na + nb), dim3(256), lds, s.stream, s.nt, s.tn, na, s.gxa > 0 ? s.gxa : 1,
+    const size_t lds = KA::LDS_BYTES > KB::LDS_BYTES ? KA::LDS_BYTES : KB::LDS_BYTES;
+    AVSR_LAUNCH((gemm_pair_kernel<KA, KB>), dim3(na + nb), dim3(256), lds, s.stream, s.nt, s.tn, na, s.gxa > 0 ? s.gxa : 1,
                 s.gya > 0 ? s.gya : 1, s.gxb > 0 ? s.gxb : 1, s.gyb > 0 ? s.gyb : 1);
 }
 
@@ -85,9 +87,20 @@ bool stash_tn(const Params& p, int split_k, hipStream_t stream) {
     kc = ((kc + 63) / 64) * 64;
     split_k = (p.K + kc - 1) / kc;
     s.tn = p;
+    // 128 x 128 tiles for the weight gradient (half the operand bytes per output, half the transpose reads per MFMA) -- MEASURED
+    // SLOWER on the MI355X (round 5, fixed batch A: 23.85 ms with 64 x 64 tiles everywhere, 24.1 - 24.2 with 128 x 128 for the FFN /
+    // fused Q / K / V weight gradients, 24.8 with 128 x 128 everywhere; the FFN pair 50.8 -> 60.3 us): the TN tile is bound by the
+    // latency of its transpose-read -> MFMA chain at one wave per SIMD, not by the operand stream, and four times fewer blocks
+    // leave less to overlap it with.  Kept behind knob 19 = 2 (tests/test_kernels_basic.py) as the record of the experiment.
+    s.tn_big = avsr_tune_knobs[19] == 2 && p.M >= 128 && p.N >= 128;
+    if (s.tn_big) {
+        split_k = 1;  // (the data-gradient tiles of the pair fill the chip; no atomics, no zeroed output needed -- but honour accumulate)
+        kc = ((p.K + 63) / 64) * 64;
+    }
+    const int tb = s.tn_big ? 128 : 64;
     s.tn.k_chunk = kc;
-    s.gxb = (p.N + 63) / 64;
-    s.gyb = (p.M + 63) / 64;
+    s.gxb = (p.N + tb - 1) / tb;
+    s.gyb = (p.M + tb - 1) / tb;
     s.gzb = split_k;
     s.stream = stream;
     s.have_tn = true;
@@ -108,8 +121,11 @@ extern "C" int avsr_gemm_pair_end(void) {
     g_pair = PairState{};
     AVSR_REQUIRE(s.active, "gemm_pair_end: no open pair on this thread");
     if (!s.have_nt && !s.have_tn) return 0;
-    if (s.have_nt && s.nt_tile == 7) launch_pair<FastKernel<128, 64, 2, 0>>(s);
-    else launch_pair<FastKernel<64, 64, 3, 0>>(s);
+    if (s.tn_big) {
+        if (s.have_nt && s.nt_tile == 7) launch_pair<FastKernel<128, 64, 2, 0>, Tn128>(s);
+        else launch_pair<FastKernel<64, 64, 3, 0>, Tn128>(s);
+    } else if (s.have_nt && s.nt_tile == 7) launch_pair<FastKernel<128, 64, 2, 0>, Tn>(s);
+    else launch_pair<FastKernel<64, 64, 3, 0>, Tn>(s);
     AVSR_CHECK_LAUNCH("gemm_pair");
     return 0;
 }

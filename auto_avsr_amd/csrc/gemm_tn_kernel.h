@@ -7,13 +7,19 @@ namespace avsr_tn {
 
 using avsr_gemm_impl::Params;
 
-template <int STAGES, int CV>
+// TMS x TNS (round 5): 64-column sub-tiles per operand -- the block computes a (64 TMS) x (64 TNS) output tile, each of its 2 x 2
+// waves a (32 TMS) x (32 TNS) grid of 32 x 32 accumulators.  1 x 1 is the original kernel.  2 x 2 (128 x 128) halves the operand
+// bytes per output and the transpose reads per MFMA (8 reads feed 4 MFMAs instead of 4 feeding 1): for the weight gradients with
+// >= 400 64 x 64 tiles (FFN, fused Q / K / V), whose launches are bound by the L2 -> LDS operand stream.
+template <int STAGES, int CV, int TMS = 1, int TNS = 1>
 struct TnKernel {
-    static constexpr int BM = 64, BN = 64, BK = 64;
-    static constexpr int OP_BYTES = BK * 128;          // one operand stage: 64 k-rows x 64 columns bf16
-    static constexpr int STAGE_BYTES = 2 * OP_BYTES;
-    static constexpr int LPT = 4;                      // LDS-DMA ops per thread per tile (2 for A, 2 for B)
-    static constexpr size_t LDS_BYTES = (size_t)STAGES * STAGE_BYTES;
+    static_assert(CV == 0 || (TMS == 1 && TNS == 1), "gathered B operand: 64 x 64 tiles only");
+    static constexpr int BM = 64 * TMS, BN = 64 * TNS, BK = 64;
+    static constexpr int OP_BYTES = BK * 128;          // one 64-column sub-tile of an operand stage: 64 k-rows x 64 columns bf16
+    static constexpr int A_BYTES = TMS * OP_BYTES, STAGE_BYTES = (TMS + TNS) * OP_BYTES;
+    static constexpr int LPT = 2 * (TMS + TNS);        // LDS-DMA ops per thread per tile
+    static constexpr size_t RING_BYTES = (size_t)STAGES * STAGE_BYTES, EPI_BYTES = (size_t)BM * (BN + 4) * 4;
+    static constexpr size_t LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
 
     static AVSR_DEV void issue(const Params& p, const bf16_t* A, const bf16_t* B, int m0, int n0, int k0, int kend,
                                char* stage, int wave, int lane) {
@@ -31,24 +37,32 @@ struct TnKernel {
             const int kr = (wave * 2 + i) * 8 + ksub;  // k-row inside the tile
             const int k = k0 + kr;
             const bool kin = k < kend;
-            const bf16_t* sa = (kin && m0 + chunk < p.M) ? A + (size_t)k * p.lda + m0 + chunk : zero;
-            glds16(sa, stage + (wave * 2 + i) * 1024);
-            const bf16_t* sb = zero;
-            if (CV == 0) {
-                if (kin && n0 + chunk < p.N) sb = B + (size_t)k * p.ldb + n0 + chunk;
-            } else if (kin) {
-                const int pix = p.cOH * p.cOW;
-                const int n = k / pix, r = k - n * pix;
-                const int oh = r / p.cOW, ow = r - oh * p.cOW;
-                const int ih = oh * p.cS + kh - p.cPH, iw = ow * p.cS + kw - p.cPW;
-                if (ih >= 0 && ih < p.cH && iw >= 0 && iw < p.cW)
-                    sb = B + (((size_t)n * p.cH + ih) * p.cW + iw) * p.cC + cbase + chunk;
+#pragma unroll
+            for (int s = 0; s < TMS; s++) {
+                const int mc = m0 + s * 64 + chunk;
+                const bf16_t* sa = (kin && mc < p.M) ? A + (size_t)k * p.lda + mc : zero;
+                glds16(sa, stage + s * OP_BYTES + (wave * 2 + i) * 1024);
             }
-            glds16(sb, stage + OP_BYTES + (wave * 2 + i) * 1024);
+#pragma unroll
+            for (int s = 0; s < TNS; s++) {
+                const bf16_t* sb = zero;
+                if (CV == 0) {
+                    const int nc = n0 + s * 64 + chunk;
+                    if (kin && nc < p.N) sb = B + (size_t)k * p.ldb + nc;
+                } else if (kin) {
+                    const int pix = p.cOH * p.cOW;
+                    const int n = k / pix, r = k - n * pix;
+                    const int oh = r / p.cOW, ow = r - oh * p.cOW;
+                    const int ih = oh * p.cS + kh - p.cPH, iw = ow * p.cS + kw - p.cPW;
+                    if (ih >= 0 && ih < p.cH && iw >= 0 && iw < p.cW)
+                        sb = B + (((size_t)n * p.cH + ih) * p.cW + iw) * p.cC + cbase + chunk;
+                }
+                glds16(sb, stage + A_BYTES + s * OP_BYTES + (wave * 2 + i) * 1024);
+            }
         }
     }
 
-    // 32 (m or n) x 16 (k) MFMA fragment of the k-major tile at `base`: columns c0..c0+31, k-step ks, as two
+    // 32 (m or n) x 16 (k) MFMA fragment of the k-major 64-column sub-tile at `base`: columns c0..c0+31, k-step ks, as two
     // transpose reads.  Issued in the asm form (prims.h lds_tr16_async): the compiler would otherwise park every
     // transpose read behind a vmcnt(0) -- i.e. behind the LDS-DMA of the NEXT tiles -- and serialise the ring.
     static AVSR_DEV void frag_async(const char* base, int c0, int ks, int lane, bf16x4& lo, bf16x4& hi) {
@@ -72,18 +86,26 @@ struct TnKernel {
         const int kbeg = zs * p.k_chunk;
         const int kend = min(p.K, kbeg + p.k_chunk);
         const int nt = (kend - kbeg + BK - 1) / BK;
-        f32x16 acc[1][1];
+        f32x16 acc[TMS][TNS];
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[0][0][r] = 0.f;
+        for (int i = 0; i < TMS; i++)
+#pragma unroll
+            for (int j = 0; j < TNS; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
         // Bias gradient on the side: the blocks of the first n-tile column also sum the A tiles they stage over k (each wave
         // 16 of the 64 k-rows, lane = column).  A is the output gradient of the Linear, so this IS colsum(dY) -- no separate
         // pass over dY.  Read through a generic pointer: an LDS-address-space load would be ordered behind the LDS-DMA of the
         // tiles still in flight (prims.h).
         const bool do_cs = CV == 0 && p.colsum_a != nullptr && bx == 0;
-        float cs = 0.f;
+        float cs[TMS];
+#pragma unroll
+        for (int s = 0; s < TMS; s++) cs[s] = 0.f;
 #pragma unroll
         for (int s = 0; s < STAGES - 1; s++)
             if (s < nt) issue(p, A, B, m0, n0, kbeg + s * BK, kend, smem + s * STAGE_BYTES, wave, lane);
+        // this wave's fragments: m block i covers tile columns wm * 32 TMS + 32 i (sub-tile = that / 64), n block j likewise
+        constexpr int NF = 2 * (TMS + TNS);  // transpose reads per k-step
         for (int t = 0; t < nt; t++) {
             const int later = min(STAGES - 2, nt - 1 - t);
             if (later >= 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
@@ -92,37 +114,68 @@ struct TnKernel {
                 issue(p, A, B, m0, n0, kbeg + (t + STAGES - 1) * BK, kend, smem + ((t + STAGES - 1) % STAGES) * STAGE_BYTES,
                       wave, lane);
             const char* As = smem + (t % STAGES) * STAGE_BYTES;
-            const char* Bs = As + OP_BYTES;
+            const char* Bs = As + A_BYTES;
             if (do_cs) {
-                const bf16_t* col = reinterpret_cast<const bf16_t*>(As) + (wave * 16) * 64 + lane;
 #pragma unroll
-                for (int r = 0; r < 16; r++) cs += bf2f(col[r * 64]);
+                for (int s = 0; s < TMS; s++) {
+                    const bf16_t* col = reinterpret_cast<const bf16_t*>(As + s * OP_BYTES) + (wave * 16) * 64 + lane;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) cs[s] += bf2f(col[r * 64]);
+                }
             }
-            bf16x4 f[2][4];  // two register sets: k-step ks+1 is requested before the MFMA of k-step ks
-            frag_async(As, wm * 32, 0, lane, f[0][0], f[0][1]);
-            frag_async(Bs, wn * 32, 0, lane, f[0][2], f[0][3]);
+            bf16x4 fa[2][TMS][2], fb[2][TNS][2];  // two register sets: k-step ks+1 is requested before the MFMAs of k-step ks
+            auto request = [&](int set, int ks) {
+#pragma unroll
+                for (int i = 0; i < TMS; i++) {
+                    const int col = wm * 32 * TMS + 32 * i;
+                    frag_async(As + (col >> 6) * OP_BYTES, col & 63, ks, lane, fa[set][i][0], fa[set][i][1]);
+                }
+#pragma unroll
+                for (int j = 0; j < TNS; j++) {
+                    const int col = wn * 32 * TNS + 32 * j;
+                    frag_async(Bs + (col >> 6) * OP_BYTES, col & 63, ks, lane, fb[set][j][0], fb[set][j][1]);
+                }
+            };
+            request(0, 0);
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ks++) {
                 const int c = ks & 1;
                 if (ks + 1 < BK / 16) {
-                    frag_async(As, wm * 32, ks + 1, lane, f[c ^ 1][0], f[c ^ 1][1]);
-                    frag_async(Bs, wn * 32, ks + 1, lane, f[c ^ 1][2], f[c ^ 1][3]);
-                    lds_wait<4>();  // the four reads just issued may stay in flight
+                    request(c ^ 1, ks + 1);
+                    lds_wait<NF>();  // the reads just issued may stay in flight
                 } else {
                     lds_wait<0>();
                 }
+                bf16x8 a[TMS], b[TNS];
 #pragma unroll
-                for (int q = 0; q < 4; q++) lds_tie(f[c][q]);
-                const bf16x8 a{f[c][0][0], f[c][0][1], f[c][0][2], f[c][0][3], f[c][1][0], f[c][1][1], f[c][1][2], f[c][1][3]};
-                const bf16x8 b{f[c][2][0], f[c][2][1], f[c][2][2], f[c][2][3], f[c][3][0], f[c][3][1], f[c][3][2], f[c][3][3]};
-                acc[0][0] = mfma32(a, b, acc[0][0]);
+                for (int i = 0; i < TMS; i++) {
+                    lds_tie(fa[c][i][0]);
+                    lds_tie(fa[c][i][1]);
+                    a[i] = bf16x8{fa[c][i][0][0], fa[c][i][0][1], fa[c][i][0][2], fa[c][i][0][3],
+                                  fa[c][i][1][0], fa[c][i][1][1], fa[c][i][1][2], fa[c][i][1][3]};
+                }
+#pragma unroll
+                for (int j = 0; j < TNS; j++) {
+                    lds_tie(fb[c][j][0]);
+                    lds_tie(fb[c][j][1]);
+                    b[j] = bf16x8{fb[c][j][0][0], fb[c][j][0][1], fb[c][j][0][2], fb[c][j][0][3],
+                                  fb[c][j][1][0], fb[c][j][1][1], fb[c][j][1][2], fb[c][j][1][3]};
+                }
+#pragma unroll
+                for (int i = 0; i < TMS; i++)
+#pragma unroll
+                    for (int j = 0; j < TNS; j++) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
                 sched_fence();
             }
         }
-        if (do_cs && m0 + lane < p.M) atomicAdd(p.colsum_a + m0 + lane, cs);
+        if (do_cs) {
+#pragma unroll
+            for (int s = 0; s < TMS; s++)
+                if (m0 + s * 64 + lane < p.M) atomicAdd(p.colsum_a + m0 + s * 64 + lane, cs[s]);
+        }
         Params q = p;
         q.gate = nullptr;  // the field carries the zero page
-        avsr_gemm_impl::epilogue_lds<64, 64, 1, 1>(acc, q, m0, n0, wm * 32, wn * 32, zs, 0, smem);
+        avsr_gemm_impl::epilogue_lds<BM, BN, TMS, TNS>(acc, q, m0, n0, wm * 32 * TMS, wn * 32 * TNS, zs, 0, smem);
     }
 };
 

@@ -988,6 +988,9 @@ def _prologue(src, rows, n, *, alpha=1.0, drop=(0.0, 0, None), want_dst=True, wa
     return g, None, db
 
 
+_TN_SPLIT_TILES = int(os.environ.get("AVSR_TN_SPLIT_MAX_TILES", "300"))
+
+
 def _wgrad(dy, x, rows, n_out, n_in, lda=None, ldb=None, bias_out=None):
     """dW[n_out, n_in] = dy[rows, n_out]^T x[rows, n_in] (f32).  Small outputs are split along the token
     dimension so that the launch still fills the 256 CUs.
@@ -1001,7 +1004,10 @@ def _wgrad(dy, x, rows, n_out, n_in, lda=None, ldb=None, bias_out=None):
         if m_pad != n_out and (lda or n_out) < m_pad:
             m_pad = None
         if m_pad is not None:
-            split = 2 if (tiles < 300 and rows >= 512) else 1
+            # knob (A/B): AVSR_TN_SPLIT_MAX_TILES -- weight gradients with fewer 64 x 64 output tiles than this are split in two
+            # along the token dimension (atomics onto a zeroed output); inside a paired launch the data-gradient tiles fill the
+            # chip anyway, so the threshold that suited the stand-alone kernel need not suit the pair
+            split = 2 if (tiles < _TN_SPLIT_TILES and rows >= 512) else 1
             alloc = _zeros if split > 1 else (lambda shp, dev: torch.empty(shp, dtype=torch.float32, device=dev))
             dw = alloc((m_pad, n_in), dy.device)
             ops.gemm_bf16_tn(dy, lda or n_out, x, ldb or n_in, m_pad, n_in, rows, dw, n_in, accumulate=split > 1,

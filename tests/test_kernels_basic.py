@@ -282,3 +282,38 @@ def test_gemm_pair_nt_tn(dev, tile, split):
         assert ((c.cpu().double() - want_cs).abs().max() / want_cs.abs().max().clamp_min(1.0)) < 1e-5
     ref_dx = dy.cpu().double() @ wT.cpu().double().t()
     assert ((dx3.cpu().double() - ref_dx).abs().max() / ref_dx.abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("shape", [(200, 136, 192), (333, 256, 320), (130, 128, 128)])
+def test_gemm_pair_tn_128_tiles(dev, shape):
+    """Round 5: the weight-gradient half of a paired launch on 128 x 128 tiles (gemm_tn_kernel.h TMS = TNS = 2; measured slower
+    than the 64 x 64 tiles on the MI355X and therefore behind tuning knob 19 = 2): ragged M / N / K edges, the bias-gradient column sums of both 64-column sub-tiles,
+    results against float64 and against the 64 x 64 tiles."""
+    rows, n_out, n_in = shape
+    torch.manual_seed(rows)
+    Kp = (n_out + 63) // 64 * 64
+    dy = torch.zeros(rows, Kp)
+    dy[:, :n_out] = torch.randn(rows, n_out)
+    dy = dy.bfloat16().to(dev)
+    wT = torch.randn(n_in, Kp).bfloat16().to(dev)
+    x = torch.randn(rows, n_in).bfloat16().to(dev)
+    ref_dw = dy.cpu().double()[:, :n_out].t() @ x.cpu().double()
+    ref_dx = dy.cpu().double() @ wT.cpu().double().t()
+    want_cs = dy.cpu().double()[:, :n_out].sum(0)
+    res = {}
+    for knob in (0, 2):  # 64 x 64 tiles (the default), 128 x 128 tiles
+        ops.tune(19, knob)
+        try:
+            dx = torch.zeros(rows, n_in, device=dev, dtype=torch.bfloat16)
+            dw = torch.full((n_out, n_in), 7.0, device=dev)  # (overwritten, not accumulated into)
+            cs = torch.zeros(n_out, device=dev)
+            with ops.paired():
+                ops.gemm_bf16_tn(dy, Kp, x, n_in, n_out, n_in, rows, dw, n_in, accumulate=False, split_k=1, colsum_a=cs)
+                ops.gemm_bf16_nt(dy, Kp, wT, Kp, rows, n_in, Kp, dx, n_in, tile=1)
+        finally:
+            ops.tune(19, 0)
+        assert ((dw.cpu().double() - ref_dw).abs().max() / ref_dw.abs().max()) < 2e-6, knob
+        assert ((dx.cpu().double() - ref_dx).abs().max() / ref_dx.abs().max()) < 1e-2, knob
+        assert ((cs.cpu().double() - want_cs).abs().max() / want_cs.abs().max().clamp_min(1.0)) < 1e-5, knob
+        res[knob] = dw.cpu()
+    assert (res[0] - res[2]).abs().max() <= 1e-5 * res[0].abs().max()  # (same products, f32 sums in another order)
