@@ -22,6 +22,7 @@ namespace {
 using avsr_gemm_impl::Params;
 using avsr_fast::FastKernel;
 using Tn = avsr_tn::TnKernel<3, 0>;
+using Tn4 = avsr_tn::TnKernel<3, 0, 1, 1, 4>;  // all four k-steps' transpose reads of a tile in flight together (knob 20 = 1)
 using Tn128 = avsr_tn::TnKernel<2, 0, 2, 2>;  // 128 x 128 weight-gradient tiles (gemm_tn_kernel.h): the large dW of FFN / fused Q / K / V
 
 struct PairState {
@@ -124,6 +125,9 @@ extern "C" int avsr_gemm_pair_end(void) {
     if (s.tn_big) {
         if (s.have_nt && s.nt_tile == 7) launch_pair<FastKernel<128, 64, 2, 0>, Tn128>(s);
         else launch_pair<FastKernel<64, 64, 3, 0>, Tn128>(s);
+    } else if (avsr_tune_knobs[20] == 1) {
+        if (s.have_nt && s.nt_tile == 7) launch_pair<FastKernel<128, 64, 2, 0>, Tn4>(s);
+        else launch_pair<FastKernel<64, 64, 3, 0>, Tn4>(s);
     } else if (s.have_nt && s.nt_tile == 7) launch_pair<FastKernel<128, 64, 2, 0>, Tn>(s);
     else launch_pair<FastKernel<64, 64, 3, 0>, Tn>(s);
     AVSR_CHECK_LAUNCH("gemm_pair");

@@ -11,8 +11,12 @@ using avsr_gemm_impl::Params;
 // waves a (32 TMS) x (32 TNS) grid of 32 x 32 accumulators.  1 x 1 is the original kernel.  2 x 2 (128 x 128) halves the operand
 // bytes per output and the transpose reads per MFMA (8 reads feed 4 MFMAs instead of 4 feeding 1): for the weight gradients with
 // >= 400 64 x 64 tiles (FFN, fused Q / K / V), whose launches are bound by the L2 -> LDS operand stream.
-template <int STAGES, int CV, int TMS = 1, int TNS = 1>
+// DEPTH: fragment register sets = k-steps whose transpose reads are in flight together (2: k-step ks+1 requested before the MFMAs
+// of ks; 4: all four k-steps of a staged tile requested up front, 16 reads per wait chain -- the LDS reaches its rate only
+// with >= 16 DS operations in flight per wave, MI355X_MICROARCH.md "LDS").
+template <int STAGES, int CV, int TMS = 1, int TNS = 1, int DEPTH = 2>
 struct TnKernel {
+    static_assert(DEPTH == 2 || DEPTH == 4, "fragment pipeline depth");
     static_assert(CV == 0 || (TMS == 1 && TNS == 1), "gathered B operand: 64 x 64 tiles only");
     static constexpr int BM = 64 * TMS, BN = 64 * TNS, BK = 64;
     static constexpr int OP_BYTES = BK * 128;          // one 64-column sub-tile of an operand stage: 64 k-rows x 64 columns bf16
@@ -123,7 +127,7 @@ struct TnKernel {
                     for (int r = 0; r < 16; r++) cs[s] += bf2f(col[r * 64]);
                 }
             }
-            bf16x4 fa[2][TMS][2], fb[2][TNS][2];  // two register sets: k-step ks+1 is requested before the MFMAs of k-step ks
+            bf16x4 fa[DEPTH][TMS][2], fb[DEPTH][TNS][2];  // DEPTH register sets (see the template comment)
             auto request = [&](int set, int ks) {
 #pragma unroll
                 for (int i = 0; i < TMS; i++) {
@@ -137,10 +141,21 @@ struct TnKernel {
                 }
             };
             request(0, 0);
+            if (DEPTH == 4) {
+#pragma unroll
+                for (int ks = 1; ks < BK / 16; ks++) request(ks, ks);
+            }
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ks++) {
-                const int c = ks & 1;
-                if (ks + 1 < BK / 16) {
+                const int c = DEPTH == 4 ? ks : (ks & 1);
+                if (DEPTH == 4) {
+                    switch (ks) {  // (immediates; the reads of the later k-steps stay in flight)
+                        case 0: lds_wait<3 * NF>(); break;
+                        case 1: lds_wait<2 * NF>(); break;
+                        case 2: lds_wait<NF>(); break;
+                        default: lds_wait<0>(); break;
+                    }
+                } else if (ks + 1 < BK / 16) {
                     request(c ^ 1, ks + 1);
                     lds_wait<NF>();  // the reads just issued may stay in flight
                 } else {

@@ -317,3 +317,28 @@ def test_gemm_pair_tn_128_tiles(dev, shape):
         assert ((cs.cpu().double() - want_cs).abs().max() / want_cs.abs().max().clamp_min(1.0)) < 1e-5, knob
         res[knob] = dw.cpu()
     assert (res[0] - res[2]).abs().max() <= 1e-5 * res[0].abs().max()  # (same products, f32 sums in another order)
+
+
+def test_gemm_pair_tn_deep_fragment_pipeline(dev):
+    """Tuning knob 20 = 1: the weight-gradient tile requests the transpose reads of all four k-steps of a staged tile up front
+    (gemm_tn_kernel.h DEPTH = 4).  Same products in the same order: results equal the default's bit for bit."""
+    torch.manual_seed(5)
+    rows, n_out, n_in = 333, 192, 256
+    dy = torch.randn(rows, n_out).bfloat16().to(dev)
+    wT = torch.randn(n_in, n_out).bfloat16().to(dev)
+    x = torch.randn(rows, n_in).bfloat16().to(dev)
+    out = {}
+    for knob in (0, 1):
+        ops.tune(20, knob)
+        try:
+            dx = torch.zeros(rows, n_in, device=dev, dtype=torch.bfloat16)
+            dw = torch.zeros(n_out, n_in, device=dev)
+            with ops.paired():
+                ops.gemm_bf16_tn(dy, n_out, x, n_in, n_out, n_in, rows, dw, n_in, accumulate=True, split_k=2)
+                ops.gemm_bf16_nt(dy, n_out, wT, n_out, rows, n_in, n_out, dx, n_in, tile=1)
+        finally:
+            ops.tune(20, 0)
+        out[knob] = (dx.cpu(), dw.cpu())
+    ref = dy.cpu().double().t() @ x.cpu().double()
+    assert ((out[1][1].double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    assert torch.equal(out[0][0], out[1][0]) and (out[0][1] - out[1][1]).abs().max() <= 1e-5 * out[0][1].abs().max()
