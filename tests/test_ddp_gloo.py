@@ -395,3 +395,55 @@ def test_stream_comm_needs_the_gpu_library(emu_lib_path):
         assert StreamComm._live == {}
     finally:
         _lib._lib = None
+
+
+def _worker_fit(rank, world, port, emu_path, out_dir, ddp_mode):
+    """train.py's native loop (auto_avsr_amd.train_native.fit) on two gloo ranks."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["AVSR_DDP"] = ddp_mode
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import types
+
+    import numpy as np
+
+    import auto_avsr_amd.synthetic as S
+    from auto_avsr_amd import _lib
+    from auto_avsr_amd import functional as AF
+    from auto_avsr_amd import train_native as TN
+    from auto_avsr_amd.e2e import E2E
+
+    _lib._install_for_tests(emu_path)
+    S.utterance_lengths = lambda n=6, seed=42, lo=12, hi=400: np.array([3, 4, 5, 3, 4, 6][:n])
+    torch.manual_seed(0)  # identical replicas
+    m = E2E(30, "video", adim=128, aheads=2, eunits=64, elayers=1, dunits=64, dlayers=1, cnn_module_kernel=7).train()
+    args = types.SimpleNamespace(modality="video", max_frames=8, train_num_buckets=3, lr=1e-3, weight_decay=0.03, warmup_epochs=0,
+                                 max_epochs=1, exp_dir=None, exp_name="run", ckpt_path=None, steps=None, val_batches=1,
+                                 synthetic_utterances=6, log_every=1, numerics="precise", synthetic=True)
+    logs = []
+    losses = TN.fit(m, args, torch.device("cpu"), rank=rank, world=world, backend="gloo", log=logs.append)
+    assert len(losses) >= 2 and all(v == v and abs(v) < 1e6 for v in losses)
+    assert AF._state["bn_sync"] is None and AF.mode() == "bf16"  # (released on the way out; the caller's mode restored)
+    # replicas stay identical: same averaged gradients, same update, on every rank
+    flat = torch.cat([p.detach().flatten() for p in m.parameters()] + [b.detach().float().flatten() for b in m.buffers()])
+    other = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(other, flat)
+    assert torch.isfinite(flat).all() and torch.equal(other[0], other[1])
+    if rank == 0:
+        torch.save({"losses": losses, "val": [s for s in logs if "validation" in s]}, os.path.join(out_dir, f"fit_{ddp_mode}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ddp_mode", ["torch", "buckets"])
+def test_native_fit_two_ranks(emu_lib_path, tmp_path, ddp_mode):
+    """train.py's native driver on two ranks (gloo; kernels through the emulator): per-rank shards of the length-bucketed
+    batches, cross-rank BatchNorm, the W / sum(B) rescale, the gradient exchange -- torch DDP (`AVSR_DDP=torch`, the driver's
+    default) or this build's buckets incl. their rebuild in gradient-arrival order after the first step (`AVSR_DDP=buckets`) --
+    the fused optimizer and the validation pass; both ranks end with bit-identical replicas (parameters AND BatchNorm buffers)."""
+    port = 37500 + (os.getpid() + len(ddp_mode)) % 2000
+    mp.spawn(_worker_fit, args=(2, port, emu_lib_path, str(tmp_path), ddp_mode), nprocs=2, join=True)
+    res = torch.load(os.path.join(tmp_path, f"fit_{ddp_mode}.pt"))
+    assert len(res["losses"]) >= 2 and len(res["val"]) == 1
