@@ -24,6 +24,10 @@ class FusedAdamW:
         self.device = self.params[0].device
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), tuple(betas), float(eps), float(weight_decay)
         self.max_grad_norm, self.warmup_steps, self.total_steps = float(max_grad_norm), int(warmup_steps), int(total_steps)
+        if self.total_steps > 0 and self.total_steps <= self.warmup_steps:
+            # (the reference's scheduler divides by total - warm-up steps, cosine.py:23: a ZeroDivisionError there -- here the
+            # device-side schedule would turn the learning rate, and with it every weight, into NaN without a word)
+            raise ValueError(f"FusedAdamW: total_steps ({self.total_steps}) must exceed warmup_steps ({self.warmup_steps})")
         self.exp_avg = [torch.zeros_like(p) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
         self.state = torch.zeros(4, dtype=torch.float32, device=self.device)  # step, lr, grad norm, clip coefficient
