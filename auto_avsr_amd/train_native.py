@@ -118,7 +118,8 @@ class _FileSource:
     def __init__(self, args, model, dev, rank, world):
         from datamodule.data_module import DataModule
 
-        self.dm = DataModule(args, train_num_buckets=args.train_num_buckets, device=str(dev))
+        self.dm = DataModule(args, train_num_buckets=args.train_num_buckets, device=str(dev),
+                             num_workers=int(getattr(args, "num_workers", 10)))
         self.dev = dev
         self.steps_per_epoch = len(self.dm.train_dataloader())
 
@@ -289,7 +290,7 @@ def _fit(model, args, dev, rank, world, backend, log, held):
                 losses.append(float(loss.detach()))
                 if rank == 0:
                     log(f"epoch {epoch} step {global_step} loss {losses[-1]:.4f} ctc {float(loss_ctc.detach()):.4f} att "
-                        f"{float(loss_att.detach()):.4f} acc {float(hits) / max(float(ntok), 1):.4f} lr {opt.last_lr:.2e} gnorm "
+                        f"{float(loss_att.detach()):.4f} acc {float(hits.detach()) / max(float(ntok.detach()), 1):.4f} lr {opt.last_lr:.2e} gnorm "
                         f"{opt.last_grad_norm:.2f} ({time.time() - t0:.1f}s)")
             if max_steps and global_step >= max_steps:
                 done = True

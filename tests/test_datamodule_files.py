@@ -158,3 +158,33 @@ def test_reloaded_train_loaders_reshuffle_and_schedule_length(dev, tmp_path, mon
     monkeypatch.setattr(dist, "is_initialized", lambda: False)
     plain = DataModule(args, num_workers=0, device=str(dev)).train_dataloader()
     assert len(plain) == nb and LM.steps_per_epoch(plain, 2) == nb / 2
+
+
+def test_native_fit_on_file_backed_data(dev, tmp_path, monkeypatch):
+    """train.py's native loop over FILES: `train_native.fit` with `--train-file` set draws its batches from
+    DataModule.train_dataloader() -- AVDataset reading wav files, CustomBucketDataset's length-bucketed batches, the reference's
+    training transform (time masking + babble noise) and padding collation as one device launch per batch -- instead of the
+    synthetic corpus; a validation pass over val_dataloader() closes each epoch."""
+    from auto_avsr_amd import functional as AF
+    from auto_avsr_amd import train_native as TN
+    from auto_avsr_amd.e2e import E2E
+
+    root = str(tmp_path)
+    _write_tree(root, 9, "audio")
+    monkeypatch.setattr(TR, "load_default_noise", lambda: torch.randn(1, 40000, generator=torch.Generator().manual_seed(3)))
+    torch.manual_seed(0)
+    AF.invalidate_weight_cache()
+    m = E2E(31, "audio", adim=128, aheads=2, eunits=64, elayers=1, dunits=64, dlayers=1, cnn_module_kernel=7).to(dev).train()
+    before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    args = types.SimpleNamespace(root_dir=root, modality="audio", train_file="train.csv", val_file="val.csv", test_file="test.csv",
+                                 max_frames=30, train_num_buckets=3, lr=1e-3, weight_decay=0.03, warmup_epochs=0, max_epochs=2,
+                                 exp_dir=None, exp_name="run", ckpt_path=None, steps=None, val_batches=1, synthetic=False,
+                                 synthetic_utterances=0, log_every=1, numerics="precise" if dev.type == "cpu" else "mixed", num_workers=0)
+    logs = []
+    losses = TN.fit(m, args, dev, log=logs.append)
+    assert isinstance(TN._batch_source(args, m, dev, 0, 1), TN._FileSource)
+    assert len(losses) >= 4 and all(v == v and abs(v) < 1e6 for v in losses)
+    assert sum("validation" in s for s in logs) == 2
+    moved = sum(float((v.float() - before[k].float()).abs().sum()) for k, v in m.state_dict().items() if v.is_floating_point())
+    assert moved > 0 and all(torch.isfinite(v).all() for v in m.state_dict().values() if v.is_floating_point())
+    AF.invalidate_weight_cache()
