@@ -59,6 +59,36 @@ def _bn_train_stats(c2, rows, C, eps, momentum, running_mean, running_var, nbt=N
     return mean, invstd, None
 
 
+def _bn_train_stats_pair(ca, cb, rows, C, bn_a, bn_b, parts_a=None, parts_b=None):
+    """Cross-rank batch statistics of TWO independent BatchNorms over activations of the same shape -- the main path's first
+    BatchNorm and the down-sampling path's of a residual block (resnet.py:82-98, resnet1d.py:83-99: both convolutions read the
+    block input) -- through ONE all-gather: the two {statistics, row count} payloads travel side by side and each merge kernel reads
+    its half of the gathered buffer strided.  One latency-bound collective less per down-sampling block and step (train.py:31
+    `sync_batchnorm=True` costs 64 of them).  bn_x = (eps, momentum, running_mean, running_var, num_batches_tracked)."""
+    import torch.distributed as dist
+
+    group = _state["bn_sync"]
+    assert group is not None
+    comm = _state.get("bn_comm")
+    W = comm.world if comm is not None else dist.get_world_size(group)
+    mine = torch.cat([ops.bn_stats_parts(p, rows, C) if p is not None else ops.bn_stats(c, rows, C, with_count=True)
+                      for c, p in ((ca, parts_a), (cb, parts_b))])
+    P = 3 * C + 1
+    flat = torch.empty(W * 2 * P, dtype=torch.float32, device=ca.device)
+    if comm is not None:
+        comm.all_gather(flat, mine)
+    else:
+        dist.all_gather_into_tensor(flat, mine, group=group)
+    out = []
+    for k, (eps, momentum, rm, rv, nbt) in enumerate((bn_a, bn_b)):
+        half = flat[k * P:]
+        n_total = torch.empty(1, dtype=torch.float32, device=ca.device)
+        mean, invstd = ops.bn_finalize(half, half.data_ptr() + 12 * C, W, C, eps, momentum, rm, rv, nbt,
+                                       stats_stride=2 * P, counts_stride=2 * P, n_total=n_total)
+        out.append((mean, invstd, n_total))
+    return out
+
+
 def _bn_bwd_sums(sums, counts, rows):
     """All-reduce the backward sums across the sync group; returns (sums_for_dx, inv_n, n_dev).  `counts` is what
     _bn_train_stats returned: under synchronisation the global row count, resident on the device."""

@@ -10,6 +10,7 @@ from . import ops
 from .functional import (  # noqa: F401
     _A, _act_in, _bwd_mode, _bwd_precise, _f32_in, _hand_over, _state, _to_act, _to_f32, _twins, _w_conv,
     _w_conv_fwd, act_dtype, padded_cols)
+from .functional_convmod import _bn_train_stats_pair  # noqa: F401
 from .functional_convmod import (  # noqa: F401
     _bn_bwd_sums, _bn_train_stats)
 
@@ -99,18 +100,30 @@ class BasicBlockFn(torch.autograd.Function):
             x = ops.scale_dropout(x, torch.float32)  # (a consumer that cannot read the layout: one pass back to plain f32)
         st1 = _conv_bn_stats(x, wp1, Cin, Cout, KH, KW, rows, training)
         c1 = ops.conv2d_fwd(x, wp1, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, pr, stats=st1, wp_planes=wpl)
-        m1, i1, n1 = _bn_fwd_params(c1, rows, Cout, bn1, training, parts=st1)
+        cd = md = idd = nd = None
+        pair = wd is not None and training and _state["bn_sync"] is not None
+        if pair:
+            # cross-rank BatchNorm, down-sampling block: both convolutions read x, their two BatchNorms' statistics cross the
+            # ranks in ONE all-gather (functional_convmod._bn_train_stats_pair)
+            bnd = (gd, bd) + bnd
+            std = _conv_bn_stats(x, wpd, Cin, Cout, 1, 1, rows, training)
+            cd = ops.conv2d_fwd(x, wpd, N, H, W, Cin, Cout, 1, 1, stride, 0, 0, pr, stats=std, wp_planes=wpl)
+            (m1, i1, n1), (md, idd, nd) = _bn_train_stats_pair(
+                c1, cd, rows, Cout, (bn1[4], bn1[5], bn1[2], bn1[3], bn1[6] if len(bn1) > 6 else None),
+                (bnd[4], bnd[5], bnd[2], bnd[3], bnd[6] if len(bnd) > 6 else None), parts_a=st1, parts_b=std)
+        else:
+            m1, i1, n1 = _bn_fwd_params(c1, rows, Cout, bn1, training, parts=st1)
         wp2 = _w_conv_fwd(w2, c1)
         a1 = ops.bn_act_fwd(c1, None, m1, i1, g1, b1, rows, Cout, 1, out_split8=ps and isinstance(wp2, ops.Split8))
         st2 = _conv_bn_stats(a1, wp2, Cout, Cout, KH, KW, rows, training)
         c2 = ops.conv2d_fwd(a1, wp2, N, OH, OW, Cout, Cout, KH, KW, 1, ph, pw, pr, stats=st2, wp_planes=wpl)
         m2, i2, n2 = _bn_fwd_params(c2, rows, Cout, bn2, training, parts=st2)
-        cd = md = idd = nd = None
         if wd is not None:
-            bnd = (gd, bd) + bnd
-            std = _conv_bn_stats(x, wpd, Cin, Cout, 1, 1, rows, training)
-            cd = ops.conv2d_fwd(x, wpd, N, H, W, Cin, Cout, 1, 1, stride, 0, 0, pr, stats=std, wp_planes=wpl)
-            md, idd, nd = _bn_fwd_params(cd, rows, Cout, bnd, training, parts=std)
+            if not pair:
+                bnd = (gd, bd) + bnd
+                std = _conv_bn_stats(x, wpd, Cin, Cout, 1, 1, rows, training)
+                cd = ops.conv2d_fwd(x, wpd, N, H, W, Cin, Cout, 1, 1, stride, 0, 0, pr, stats=std, wp_planes=wpl)
+                md, idd, nd = _bn_fwd_params(cd, rows, Cout, bnd, training, parts=std)
             r = ops.bn_act_fwd(cd, None, md, idd, gd, bd, rows, Cout, 0)
         else:
             r = x

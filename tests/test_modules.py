@@ -484,3 +484,55 @@ def test_encoder_shared_position_projection_equivalence(dev):
         assert rel(g1[k], g0[k]) < tol or float(g0[k].abs().max()) < 1e-7, (k, rel(g1[k], g0[k]))
         seen += "linear_pos" in k
     assert seen == 3
+
+
+def test_downsampling_blocks_share_their_batchnorm_all_gather(dev):
+    """Cross-rank BatchNorm (train.py:31): in a down-sampling residual block the statistics of the main path's first BatchNorm
+    and of the down-sampling path's cross the ranks in ONE all-gather (round 5).  A one-rank stand-in communicator counts the
+    collectives of a training-mode forward + backward pass: one all-gather per BatchNorm minus one per down-sampling block (3),
+    one all-reduce per BatchNorm in the backward pass; losses equal the unsynchronised run."""
+    from synth import synth_batch, synth_state_dict
+
+    from auto_avsr_amd import functional as AF
+    from auto_avsr_amd.e2e import E2E
+
+    class Comm:
+        world, rank = 1, 0
+
+        def __init__(self):
+            self.gathers, self.reduces = [], 0
+
+        def all_gather(self, out, mine):
+            self.gathers.append(mine.numel())
+            out.copy_(mine.reshape(-1))
+
+        def all_reduce(self, t):
+            self.reduces += 1
+            return t
+
+    torch.manual_seed(0)
+    AF.invalidate_weight_cache()
+    m = no_dropout(E2E(40, "video", adim=128, aheads=2, eunits=64, elayers=1, dunits=64, dlayers=1, cnn_module_kernel=7))
+    sd = synth_state_dict(m.state_dict(), 5)
+    x, lens, y = synth_batch("video", 2, 7, 3, 40, seed=2)
+    res = {}
+    for sync in (False, True):
+        m.load_state_dict(sd)
+        m.to(dev).train()
+        comm = Comm()
+        AF.set_bn_sync("stand-in group" if sync else None, comm=comm if sync else None)
+        try:
+            with AF.precise():
+                loss, *_ = m.forward_tensors(x.to(dev), lens.to(dev), y.to(dev))
+                loss.backward()
+        finally:
+            AF.set_bn_sync(None)
+        res[sync] = (float(loss), comm)
+        m.zero_grad(set_to_none=True)
+    n_bn = sum(isinstance(mod, torch.nn.modules.batchnorm._BatchNorm) for mod in m.modules())
+    comm = res[True][1]
+    assert n_bn == 1 + 16 + 3 + 1  # stem, 8 blocks x 2, 3 down-sampling paths, the convolution module's
+    assert len(comm.gathers) == n_bn - 3 and comm.reduces == n_bn, (len(comm.gathers), comm.reduces, n_bn)
+    assert sum(1 for n in comm.gathers if n in (2 * (3 * 128 + 1), 2 * (3 * 256 + 1), 2 * (3 * 512 + 1))) == 3  # the three paired payloads
+    assert abs(res[True][0] - res[False][0]) < 1e-5 * abs(res[False][0])
+    AF.invalidate_weight_cache()
