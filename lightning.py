@@ -80,11 +80,19 @@ class ModelModule(_Base):
 
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             AF.set_bn_sync(dist.group.WORLD)
+        # the numerical mode of the hot path under a Lightning Trainer too: train.py's --numerics (default "mixed": what bench.py
+        # times -- the cheapest arithmetic whose logits stay within 1e-3 of the fp32 reference); hipGraph replay per batch shape is
+        # the native loop's (auto_avsr_amd.train_native): a Trainer drives backward / optimizer itself
+        self._mode_before_fit = AF._save_mode()
+        AF.set_mode(getattr(self.args, "numerics", None) or "mixed")
 
     def on_fit_end(self):
         from auto_avsr_amd import functional as AF
 
         AF.set_bn_sync(None)
+        if getattr(self, "_mode_before_fit", None) is not None:
+            AF._restore_mode(self._mode_before_fit)
+            self._mode_before_fit = None
 
     # ---- optimisation (lightning.py:48-52): AdamW(betas .9/.98) + per-step warm-up cosine
     def make_optimizer(self, steps_per_epoch):

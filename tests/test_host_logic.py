@@ -201,3 +201,21 @@ def test_qkv_bias_packing_with_adjacent_separate_storages():
     assert bq.untyped_storage().data_ptr() == bv.untyped_storage().data_ptr()
     assert AF._bias3(bq, bk, bv).data_ptr() == bq.data_ptr()
     assert torch.equal(AF._bias3(bq, bk, bv), torch.cat(vals))
+
+
+def test_model_module_fit_hooks_set_the_benchmarked_numerics():
+    """lightning.ModelModule under a Trainer: on_fit_start puts the hot path into train.py's --numerics mode (default: mixed, the
+    benchmarked one), on_fit_end restores what was there (the entry points ran in a mode nothing had benchmarked)."""
+    import types
+
+    import lightning as LM
+    from auto_avsr_amd import functional as AF
+
+    mod = LM.ModelModule.__new__(LM.ModelModule)
+    for numerics, want in ((None, "mixed"), ("hpf", "hpf")):
+        mod.args = types.SimpleNamespace(numerics=numerics)
+        assert AF.mode() == "bf16"
+        LM.ModelModule.on_fit_start(mod)
+        assert AF.mode() == want
+        LM.ModelModule.on_fit_end(mod)
+        assert AF.mode() == "bf16" and AF._state["bn_sync"] is None
