@@ -123,6 +123,11 @@ bool launch_tile_h16x2(int tile, Params& p, int split_k, hipStream_t stream) {
         case 4: launch_fast<128, 128, 2, CV, 2, 2, 0, 1, 1, 2>(p, split_k, stream); return true;
         case 7: launch_fast<128, 64, 2, CV, 2, 2, 0, 1, 1, 2>(p, split_k, stream); return true;
         case 2: launch_fast<128, 64, 3, CV, 2, 2, 0, 1, 1, 2>(p, split_k, stream); return true;
+        // 8 waves (two per SIMD), one block per CU: half (5) / three quarters (8, 22) of the operand bytes per MFMA of the 128x64 tile
+        case 5: launch_fast<256, 128, 2, CV, 4, 2, 0, 1, 1, 2>(p, split_k, stream); return true;
+        case 8: launch_fast<256, 64, 2, CV, 4, 2, 0, 1, 1, 2>(p, split_k, stream); return true;
+        case 22: launch_fast<128, 128, 2, CV, 2, 4, 0, 1, 1, 2>(p, split_k, stream); return true;
+        case 23: launch_fast<256, 64, 3, CV, 4, 2, 0, 1, 1, 2>(p, split_k, stream); return true;
         default: return false;
     }
 }
@@ -175,7 +180,11 @@ static int gemm16_nt_impl(int f16, const void* A, int lda, const void* B, const 
             const long t12864 = (long)((M + 127) / 128) * ((N + 63) / 64);
             // measured (tools/microbench_h16x2.py, us): 1600x768x768 11.5 (64x64) / 12.9 (128x64); 1600x3072x768 35.2 / 28.2;
             // 1600x768x3072 35.4 / 32.2 with the 3-stage 128x64 ring (a long k loop amortises the fewer, fatter blocks)
-            tile = g_tune[17] > 0 ? g_tune[17] : (t12864 >= 256 ? 7 : (K >= 2048 && t12864 >= 128 ? 2 : 1));
+            // round 6: 256x128 on 8 waves (two per SIMD, half the operand bytes per MFMA of the 128x64 tile) once the grid has
+            // >= 160 of them: 1600x3072x768 29.5 -> 27.6 us, 1600x9216x768 67.6 -> 61.1 (profiles/r6_microbench_h16x2.txt);
+            // the 126 tiles of the fused Q/K/V projection are slower (26 vs 19 us)
+            const long t256 = (long)((M + 255) / 256) * ((N + 127) / 128);
+            tile = g_tune[17] > 0 ? g_tune[17] : (t256 >= 160 ? 5 : (t12864 >= 256 ? 7 : (K >= 2048 && t12864 >= 128 ? 2 : 1)));
         }
         AVSR_REQUIRE(launch_tile_h16x2<0>(tile, p, split_k, stream), "gemm_h16_nt: unknown tile code (two weight planes)");
         AVSR_CHECK_LAUNCH("gemm_h16_nt");
@@ -314,7 +323,10 @@ extern "C" int avsr_conv2d_h16(const void* x, const void* wp, const void* wp_lo,
     p.cls_h[0] = OH; p.cls_w[0] = OW; p.cls_nkh[0] = KH; p.cls_nkw[0] = KW;
     if (wp_lo) {
         // two filter planes: 128x64 tiles keep two blocks per CU (64 KB each); knob 18: A/B against 128x128 (one block per CU)
-        const int tile = g_tune[18] > 0 ? g_tune[18] : 7;
+        // round 6: 256x128 tiles on 8 waves (one block per CU, two waves per SIMD) wherever the output is >= 128 channels wide and
+        // the grid fills the chip: stage 3 / 4 convolutions 182 -> 159, 164 -> 140, 119 -> 90, 92 -> 80 us
+        const long t256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
+        const int tile = g_tune[18] > 0 ? g_tune[18] : (p.N % 128 == 0 && t256 >= 200 ? 5 : 7);
         AVSR_REQUIRE(launch_tile_h16x2<1>(tile, p, 1, stream), "conv2d_h16: tile (two filter planes)");
     } else
         AVSR_REQUIRE(launch_tile_h16<1>(p.N >= 128 ? 4 : 7, p, 1, stream), "conv2d_h16: tile");

@@ -40,8 +40,10 @@ class _NullCtx:
 
 class GradBuckets:
     def __init__(self, params, group=None, bucket_mb=None, comm=None, wire=None, spare=72):
-        """bucket_mb: bucket size in MB of f32 gradients (default 64, environment AVSR_BUCKET_MB overrides: sweep hook).
-        wire: "f32" (default) or "bf16" (environment AVSR_GRAD_WIRE): the format the buckets travel in.  bf16 halves the bytes
+        """spare: captured step shapes this object can serve (one pinned pointer table per bucket and shape); size it to the
+        owner's graph capacity (train_native: StepGraphs max_graphs + 8).
+        bucket_mb: bucket size in MB of f32 gradients (default 64, environment AVSR_BUCKET_MB overrides: sweep hook).
+        wire: "f32" (default) or "bf16" (environment AVSR_GRAD_WIRE when the argument is None): the format the buckets travel in.  bf16 halves the bytes
         per xGMI link -- the exchange of 1.0 GB of f32 gradients is per-link bound on a ring -- at the
         price of bf16 sums across the ranks (8 significant bits; the bf16 / mixed modes compute their gradients from bf16
         operands anyway); the reduced bucket is widened back to f32 for the optimizer on the exchange's own stream."""
@@ -49,7 +51,9 @@ class GradBuckets:
 
         if bucket_mb is None:
             bucket_mb = float(os.environ.get("AVSR_BUCKET_MB", "64"))
-        self.wire = os.environ.get("AVSR_GRAD_WIRE") or wire or "f32"  # (the environment wins: sweep hook)
+        # an explicit argument wins; the environment only replaces the default (sweep hook).  The default is f32 -- the reference's
+        # all-reduce (train.py:30-42: torch DDP sums f32 gradients); bf16 is an opt-in (round-5 advisor finding)
+        self.wire = wire or os.environ.get("AVSR_GRAD_WIRE") or "f32"
         assert self.wire in ("f32", "bf16"), self.wire
         if self.wire == "bf16" and comm is None:
             self.wire = "f32"  # the narrow format needs a stream communicator; torch.distributed groups travel as f32
@@ -117,15 +121,20 @@ class GradBuckets:
         other bucket leaves as soon as its layers are done.  Call once, after the first (eager) step, with the gradients
         cleared, before any hipGraph capture; every rank must call it (rank 0's order is broadcast: one order for all)."""
         assert not self._captured and all(n == len(m) for n, m in zip(self._left, self.members)), "rebuild between steps, before captures"
-        order = list(self._arrival)
+        order = list(self._arrival) if self._arrival is not None else []  # (None: finish() dropped a record older than one step)
         self._arrival = None
         self.rebuilt = True
-        if sorted(order) != list(range(len(self.params))):
-            return False  # (a step that did not touch every parameter exactly once: keep the first assignment)
+        valid = sorted(order) == list(range(len(self.params)))  # a step that touched every parameter exactly once
         if self.world > 1 and self.group is not None and dist.is_initialized():
-            t = torch.tensor(order, dtype=torch.int64, device=self.device if dist.get_backend(self.group) != "gloo" else "cpu")
+            # ONE decision for all ranks, taken collectively BEFORE anybody may leave: rank 0's order (all -1 when rank 0 has no
+            # valid record) is broadcast; a rank whose own record is unusable still takes part and adopts rank 0's
+            t = torch.tensor(order if valid else [-1] * len(self.params), dtype=torch.int64,
+                             device=self.device if dist.get_backend(self.group) != "gloo" else "cpu")
             dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not dist.group.WORLD else 0, group=self.group)
             order = t.tolist()
+            valid = sorted(order) == list(range(len(self.params)))
+        if not valid:
+            return False  # keep the first assignment (every rank decides the same way)
         for p in self.params:
             assert p.grad is None, "rebuild_by_arrival: clear the gradients first (they are views of the old buckets)"
         self._assign(order)
@@ -180,10 +189,12 @@ class GradBuckets:
             if ent is None:
                 if not self._spare[b]:
                     raise RuntimeError("GradBuckets: out of pre-pinned table buffers under hipGraph capture (`spare` captured step shapes per bucket)")
+                from .graph_step import capture_token
+
                 host, dev, _ = self._spare[b].pop()
                 fill(host)
-                ent = self._captured[(b,) + ptrs] = (host, dev, blocks)
-            host, dev, _ = ent
+                ent = self._captured[(b,) + ptrs] = (host, dev, blocks, capture_token())
+            host, dev = ent[0], ent[1]
         else:
             slot = self._ring[b][self._ring_pos[b]]
             self._ring_pos[b] = (self._ring_pos[b] + 1) % len(self._ring[b])
@@ -244,6 +255,34 @@ class GradBuckets:
             ops.cast_into(self.narrow[b], self.flat[b])   # back to the f32 views the optimizer reads
         else:
             self.comm.all_reduce(self.flat[b])
+
+    def abort_step(self):
+        """A step died between begin_step() and finish() (an exception in the backward pass, a hipGraph capture that failed
+        half way): forget its partial bucket counts, pending reductions and stream bookkeeping, so that the next step starts
+        clean -- otherwise the buckets that had already counted some gradients in would never flush again and finish() would
+        raise on this rank while the others wait in a collective.  The caller clears the parameters' gradients (they may be
+        views of the buckets or live in a dead graph's pool)."""
+        self._left = [len(m) for m in self.members]
+        self._works.clear()
+        self._side_used = False
+        for s in self._seen:
+            s.clear()
+        if self._arrival is not None and not self.rebuilt:
+            self._arrival = []
+        if self._side is not None and self.device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream().wait_stream(self._side)  # nothing of the dead step may still be queued behind us
+
+    def release_captured(self, token):
+        """The hipGraph captured under graph_step.capture_token() == token is gone: its pinned pointer tables return to the
+        spare lists (StepGraphs on_evict)."""
+        if token is None:
+            return
+        for k in [k for k, e in self._captured.items() if len(e) > 3 and e[3] == token]:
+            host, dev = self._captured.pop(k)[:2]
+            self._spare[k[0]].append([host, dev, None])
+
+    def spare_left(self):
+        return min(len(s) for s in self._spare) if self._spare else 0
 
     def begin_step(self):
         """Before the forward pass, on the thread / stream that issues the step: remembers the compute stream, so that every

@@ -133,12 +133,24 @@ class FusedAdamW:
             host = self._free_host.pop()
             host.numpy()[:blob.size] = blob  # plain host memcpy into the pinned buffer
             dev = torch.empty(host.numel(), dtype=torch.uint8, device=self.device)
+            from .graph_step import capture_token
+
             ent = self._tables[key] = (host, dev, len(self.params), blk,
-                                       torch.empty(blk, dtype=torch.float32, device=self.device), capturing)
+                                       torch.empty(blk, dtype=torch.float32, device=self.device), capturing,
+                                       capture_token() if capturing else None)
             # (re)sent on every use below: under hipGraph capture the copy becomes a node reading THIS pinned buffer
-        host, dev, n, blk, partial, _ = ent
+        host, dev, n, blk, partial = ent[:5]
         dev.copy_(host, non_blocking=True)
         return dev, n, blk, partial
+
+    def release_captured(self, token):
+        """A hipGraph captured under graph_step.capture_token() == token is gone (evicted, or its capture failed): its pinned
+        pointer table goes back to the free list (StepGraphs on_evict).  The caller guarantees the graph no longer runs."""
+        for k in [k for k, e in self._tables.items() if e[5] and e[6] == token and token is not None]:
+            self._free_host.append(self._tables.pop(k)[0])
+
+    def captured_tables(self):
+        return sum(1 for e in self._tables.values() if e[5])
 
     @torch.no_grad()
     def step(self):

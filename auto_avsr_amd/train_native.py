@@ -176,6 +176,12 @@ def fit(model, args, dev, rank=0, world=1, backend="nccl", log=print):
         AF.set_bn_sync(None)
 
 
+def _max_graphs():
+    """hipGraphs (batch shapes) the loop keeps: 384 distinct (B, T, L) shapes at max-frames 1600 on the synthetic corpus; one
+    graph holds ~50 MB of static inputs, the activations' pool is shared."""
+    return int(os.environ.get("AVSR_MAX_GRAPHS", "512"))
+
+
 def _fit(model, args, dev, rank, world, backend, log, held):
     from . import functional as AF
     from .optim import FusedAdamW
@@ -200,8 +206,11 @@ def _fit(model, args, dev, rank, world, backend, log, held):
                 comm_bn, comm_grads = StreamComm.from_process_group(), StreamComm.from_process_group()
                 held["comms"] += [comm_bn, comm_grads]
                 AF.set_bn_sync(dist.group.WORLD, comm=comm_bn)
-            wire = "f32" if (getattr(args, "numerics", None) or AF.mode()) == "precise" else "bf16"  # (bf16 backward: bf16 wire)
-            buckets = held["buckets"] = GradBuckets(model.parameters(), group=dist.group.WORLD, comm=comm_grads, wire=wire)
+            # wire format of the gradient buckets: f32 like the reference's DDP all-reduce unless asked otherwise
+            # (--grad-wire bf16 / AVSR_GRAD_WIRE=bf16: half the bytes per xGMI link, bf16 sums across the ranks)
+            wire = getattr(args, "grad_wire", None) or os.environ.get("AVSR_GRAD_WIRE") or "f32"
+            buckets = held["buckets"] = GradBuckets(model.parameters(), group=dist.group.WORLD, comm=comm_grads, wire=wire,
+                                                    spare=_max_graphs() + 8)
         else:
             hot = torch.nn.parallel.DistributedDataParallel(
                 hot, device_ids=[dev.index] if dev.type == "cuda" else None, find_unused_parameters=False,
@@ -214,7 +223,7 @@ def _fit(model, args, dev, rank, world, backend, log, held):
     # per-step warm-up cosine; step count / lr / gradient norm stay on the device
     opt = FusedAdamW(model.parameters(), lr=args.lr, betas=(0.9, 0.98), weight_decay=args.weight_decay, max_grad_norm=10.0,
                      warmup_steps=args.warmup_epochs * steps_per_epoch, total_steps=args.max_epochs * steps_per_epoch,
-                     cast_weights=dev.type == "cuda", graph_shapes=int(os.environ.get("AVSR_MAX_GRAPHS", "64")))
+                     cast_weights=dev.type == "cuda", graph_shapes=_max_graphs())
     folder = os.path.join(args.exp_dir, args.exp_name) if getattr(args, "exp_dir", None) else None
     start_epoch, global_step = 0, 0
     if getattr(args, "ckpt_path", None):
@@ -264,9 +273,25 @@ def _fit(model, args, dev, rank, world, backend, log, held):
 
     graph_ok = dev.type == "cuda" and not getattr(args, "no_graph", False) and \
         (world == 1 or (buckets is not None and buckets.comm is not None))
-    stepper = StepGraphs(full_step, enabled=graph_ok, capture_after=1, thread_local=world > 1,
-                         max_graphs=int(os.environ.get("AVSR_MAX_GRAPHS", "64")),
-                         on_fail=lambda e: log(f"[rank {rank}] hipGraph capture failed ({type(e).__name__}: {str(e)[:160]}); eager from here on"))
+    def capture_failed(e):
+        # a capture that dies mid-backward leaves partial bucket counts, pending reductions and gradients that live in the dead
+        # graph's pool: reset all of it, or the eager retry never flushes those buckets and finish() raises on this rank while
+        # the others wait in a collective (round-5 advisor finding)
+        log(f"[rank {rank}] hipGraph capture failed ({type(e).__name__}: {str(e)[:160]}); eager from here on")
+        for p in params:
+            p.grad = None
+        if buckets is not None:
+            buckets.abort_step()
+
+    def released(key):  # a graph is gone: its pinned pointer tables go back to their owners
+        opt.release_captured(key)
+        if buckets is not None:
+            buckets.release_captured(key)
+
+    # capacity: the first AVSR_MAX_GRAPHS (default 512) shapes that show up twice are captured and kept for the run -- no
+    # eviction (graph_step.py); the optimizer's and the buckets' pre-pinned tables are sized for exactly that many captures
+    stepper = StepGraphs(full_step, enabled=graph_ok, capture_after=1, thread_local=world > 1, max_graphs=_max_graphs(),
+                         on_fail=capture_failed, on_evict=released)
     held["stepper"] = stepper
     tail, t_tail = int(getattr(args, "time_last", 0) or 0), None
     if mode is not None:

@@ -370,9 +370,9 @@ def main():
         # AVSR_GRAD_WIRE=bf16: the buckets travel as bf16 (half the bytes per link; stated in config.grad_wire).
         from auto_avsr_amd.ddp import GradBuckets
 
-        # wire format: bf16 whenever the backward pass computes its gradients from bf16 operands anyway (every mode but
-        # "precise") and a stream communicator carries the buckets -- half the bytes per xGMI link; AVSR_GRAD_WIRE overrides
-        buckets = GradBuckets(model.parameters(), group=dist.group.WORLD, comm=comm_grads, wire="f32" if mode == "precise" else "bf16")
+        # wire format: f32, the reference's DDP all-reduce (and train.py's default); AVSR_GRAD_WIRE=bf16 opts into half the bytes
+        # per xGMI link with bf16 sums across the ranks
+        buckets = GradBuckets(model.parameters(), group=dist.group.WORLD, comm=comm_grads, wire=os.environ.get("AVSR_GRAD_WIRE") or "f32")
 
     if dp and rank == 0:
         print(f"[bench] data-parallel mode: --ddp {args.ddp}" + (" (RCCL C-API communicators, hipGraph replay)" if comm is not None else ""),
@@ -462,8 +462,7 @@ def main():
               f"{str(e)[:200]}); continuing with eager launches", file=sys.stderr, flush=True)
         clear_grads()
         if buckets is not None:
-            buckets._works.clear()
-            buckets._left = [len(m) for m in buckets.members]
+            buckets.abort_step()
 
     # (N > 1: the process group's watchdog thread queries events while this thread captures -> thread-local capture mode; a
     # failed capture is fatal at N = 1 and a fall-back to eager launches at N > 1)

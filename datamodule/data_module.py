@@ -70,9 +70,9 @@ class DeviceBatches:
         if hasattr(smp, "set_epoch"):
             # a trainer that found the sampler (Lightning, through `.sampler`) has already called set_epoch(current_epoch):
             # never override an epoch set from outside
-            if smp.epoch == self._seen:
+            if getattr(smp, "epoch", None) == self._seen:  # (a custom sampler may have set_epoch() without an epoch attribute)
                 smp.set_epoch(self.epoch)
-            self._seen = smp.epoch
+            self._seen = getattr(smp, "epoch", None)
         self.epoch += 1
         for item in self.loader:
             if self.single:

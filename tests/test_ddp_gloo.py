@@ -283,7 +283,7 @@ def test_bench_main_two_ranks(emu_lib_path, tmp_path, launch):
     assert "gradient all-reduce overlapped with backward (auto_avsr_amd.ddp) + SyncBN" in c["workload"] and "eager launches" in c["workload"]
     assert c["rccl_ranks"] == 2
     if launch == "torchrun-auto":
-        assert c["ddp_mode"] == "buckets-graph1" and c["attempt"] == 0 and c["communicators"] == 1 and c["grad_wire"] == "bf16"
+        assert c["ddp_mode"] == "buckets-graph1" and c["attempt"] == 0 and c["communicators"] == 1 and c["grad_wire"] == "f32"  # (round 6: f32 wire by default, bf16 opt-in)
     elif launch == "plain-hang-fallback":
         assert c["ddp_mode"] == "buckets" and c["attempt"] == 1 and c["communicators"] == 0 and c["grad_wire"] == "f32"
         assert "hang guard" in r.stderr and "falling back to --ddp buckets" in r.stderr
@@ -380,6 +380,93 @@ def test_grad_buckets_match_torch_ddp(emu_lib_path, tmp_path, transport, wire):
     port = 29500 + (os.getpid() + 7 + 13 * len(transport + wire)) % 2000
     mp.spawn(_worker_buckets, args=(2, port, emu_lib_path, str(tmp_path), transport, wire), nprocs=2, join=True)
     assert os.path.exists(os.path.join(tmp_path, "ok"))
+
+
+def test_grad_buckets_abort_step_and_stale_arrival_record(emu_lib_path):
+    """Round-5 advisor findings.  (1) A step that dies in its backward pass (a hipGraph capture that fails half way) leaves some
+    buckets partially counted; without abort_step() they never flush again and the next finish() raises on this rank while its
+    peers wait in a collective.  With it the next step is a normal step.  (2) rebuild_by_arrival() on a record finish() has
+    already dropped (more than one step without a rebuild) keeps the first assignment instead of raising."""
+    sys.path.insert(0, ROOT)
+    from auto_avsr_amd import _lib
+    from auto_avsr_amd.ddp import GradBuckets
+
+    _lib._install_for_tests(emu_lib_path)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(37, 64), torch.nn.ReLU(), torch.nn.Linear(64, 129), torch.nn.ReLU(),
+                              torch.nn.Linear(129, 5, bias=False))
+    gb = GradBuckets(net.parameters(), bucket_mb=0.02)
+    assert len(gb.flat) >= 3
+    x = torch.randn(6, 37)
+    # the dead step: only the first layer receives gradients, then the step is abandoned
+    gb.begin_step()
+    net[0](x).sum().backward()
+    assert any(0 < n < len(m) or (n == 0) for n, m in zip(gb._left, gb.members))
+    assert gb._left != [len(m) for m in gb.members]
+    for p in net.parameters():
+        p.grad = None
+    gb.abort_step()
+    assert gb._left == [len(m) for m in gb.members] and not gb._works
+    # the next step is a normal one: gradients equal plain autograd's
+    ref = [torch.autograd.grad(net(x).square().mean(), list(net.parameters()))]
+    gb.begin_step()
+    net(x).square().mean().backward()
+    gb.finish()
+    for p, g in zip(net.parameters(), ref[0]):
+        assert torch.allclose(p.grad, g, rtol=1e-6, atol=1e-7)
+    # a second step without a rebuild in between drops the arrival record ...
+    for p in net.parameters():
+        p.grad = None
+    gb.begin_step()
+    net(x).square().mean().backward()
+    gb.finish()
+    assert gb._arrival is None
+    for p in net.parameters():
+        p.grad = None
+    before = [list(m) for m in gb.members]
+    # ... and a late rebuild keeps the assignment
+    assert gb.rebuild_by_arrival() is False and gb.rebuilt and [list(m) for m in gb.members] == before
+    gb.remove()
+
+
+def test_step_graphs_capacity_policy():
+    """graph_step.StepGraphs bookkeeping without a device (the capture itself is stubbed): by default the first max_graphs shapes
+    are kept and later shapes run eagerly (no thrash on a corpus with more shapes than capacity); evict=True is an LRU that
+    reports every dropped key to on_evict."""
+    sys.path.insert(0, ROOT)
+    from auto_avsr_amd.graph_step import StepGraphs
+
+    class Fake:
+        def replay(self):
+            pass
+
+    def make(**kw):
+        st = StepGraphs(lambda x, l, y: (x.sum(),), capture_after=1, **kw)
+
+        def fake_capture(key, x, lens, y):
+            st.graphs[key] = (Fake(), x.clone(), lens.clone(), y.clone(), (x.sum(),))
+            st.stats["captured"] += 1
+            while len(st.graphs) > st.max_graphs:
+                old, _ = st.graphs.popitem(last=False)
+                st.stats["evicted"] += 1
+                if st.on_evict is not None:
+                    st.on_evict(old)
+        st._capture = fake_capture
+        return st
+
+    shapes = [torch.zeros(b, 3) for b in (1, 2, 3, 4, 5)]
+    st = make(max_graphs=2)
+    for _ in range(4):
+        for x in shapes:
+            st(x, torch.zeros(1), torch.zeros(1))
+    assert st.stats["captured"] == 2 and st.stats["evicted"] == 0 and st.stats["full"] == 9, st.stats
+    assert st.stats["replayed"] == 2 * 3 and st.stats["eager"] == 5 + 9, st.stats
+    dropped = []
+    st = make(max_graphs=2, evict=True, on_evict=dropped.append)
+    for _ in range(3):
+        for x in shapes:
+            st(x, torch.zeros(1), torch.zeros(1))
+    assert st.stats["captured"] == 10 and st.stats["evicted"] == 8 and len(dropped) == 8, st.stats
 
 
 def test_stream_comm_needs_the_gpu_library(emu_lib_path):

@@ -204,6 +204,76 @@ def test_native_fit_graph_replay_equals_eager(tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_native_fit_more_shapes_than_graphs(tmp_path, monkeypatch):
+    """Round-5 advisor findings: more batch shapes than graph capacity.  Default policy: the first AVSR_MAX_GRAPHS shapes are
+    captured and kept, every further shape runs eagerly -- no eviction, no capture after the budget, and the optimizer holds
+    exactly one pinned table per captured graph.  The losses equal the all-eager run's."""
+    import auto_avsr_amd.synthetic as S
+    from auto_avsr_amd import functional as AF
+    from auto_avsr_amd import train_native as TN
+
+    dev = torch.device("cuda")
+    monkeypatch.setattr(S, "utterance_lengths", lambda n=6, seed=42, lo=12, hi=400: torch.tensor([12, 14, 20, 22, 30, 33, 40, 41, 48, 47]).numpy())
+    runs = {}
+    for tag, cap in (("eager", None), ("cap2", "2")):
+        AF.invalidate_weight_cache()
+        if cap is None:
+            monkeypatch.delenv("AVSR_MAX_GRAPHS", raising=False)
+        else:
+            monkeypatch.setenv("AVSR_MAX_GRAPHS", cap)
+        m = small_e2e().to(dev).train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        args = _args(tmp_path / tag, max_frames=48, train_num_buckets=5, max_epochs=4, synthetic_utterances=10, numerics="mixed",
+                     no_graph=cap is None, val_batches=0, exp_dir=None)
+        runs[tag] = (TN.fit(m, args, dev, log=lambda s: None), TN.fit.last_stats)
+    (le, se), (lg, sg) = runs["eager"], runs["cap2"]
+    assert sg["captured"] == 2 and sg["evicted"] == 0 and sg["full"] >= 2 and sg["replayed"] >= 4, sg
+    assert len(le) == len(lg)
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 5e-3 * abs(a), (le, lg)
+    AF.invalidate_weight_cache()
+
+
+@pytest.mark.gpu
+def test_step_graphs_eviction_returns_per_capture_resources():
+    """evict=True: the LRU drops graphs beyond max_graphs and on_evict hands the optimizer's pinned pointer table of the dropped
+    graph back -- 12 captures through a capacity of 2 never hold more than 2 (+ the one in progress) captured tables, where
+    round 5 leaked one per capture until 'out of pre-pinned table buffers'."""
+    from auto_avsr_amd import functional as AF
+    from auto_avsr_amd.graph_step import StepGraphs
+    from auto_avsr_amd.optim import FusedAdamW
+
+    dev = torch.device("cuda")
+    AF.invalidate_weight_cache()
+    torch.manual_seed(0)
+    w = [torch.nn.Parameter(torch.randn(64, 64, device=dev)), torch.nn.Parameter(torch.randn(64, device=dev))]
+    opt = FusedAdamW(w, lr=1e-2, graph_shapes=2)  # 2 + 24 pinned tables in all
+
+    def step(x, lens, y):
+        for p in w:
+            p.grad = None
+        loss = ((x @ w[0] + w[1]) ** 2).mean()
+        loss.backward()
+        opt.step()
+        return (loss.detach(),)
+
+    st = StepGraphs(step, capture_after=0, max_graphs=2, evict=True, on_evict=opt.release_captured, warm=lambda *a: step(*a))
+    work = torch.cuda.Stream()
+    with torch.cuda.stream(work):
+        for rep in range(3):
+            for b in (2, 3, 4, 5):  # four shapes cycling through two slots: every visit is a capture
+                x = torch.randn(b, 64, device=dev)
+                out = st(x, torch.zeros(b, device=dev), torch.zeros(b, device=dev))
+                assert torch.isfinite(out[0]).item()
+                assert opt.captured_tables() <= 2, (opt.captured_tables(), st.stats)
+    torch.cuda.synchronize()
+    assert st.stats["captured"] == 12 and st.stats["evicted"] == 10, st.stats
+    AF.invalidate_weight_cache()
+
+
+@pytest.mark.gpu
 def test_train_py_runs_at_bench_speed():
     """the shipped training entry point runs the benchmarked configuration.  `train.py --synthetic` (full-size
     video model, default --numerics mixed, the native loop's per-shape hipGraph replay, a NEW batch every step) against `bench.py`

@@ -40,6 +40,9 @@ def parse_args(argv=None):
                    help="numerical mode of the hot path (auto_avsr_amd.functional.set_mode); default: the mode bench.py times, "
                         "the cheapest one whose logits stay within 1e-3 of the fp32 reference")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of one replayed hipGraph per batch shape")
+    p.add_argument("--grad-wire", default=None, choices=["f32", "bf16"],
+                   help="format of the gradient buckets on the xGMI links (AVSR_DDP=buckets): f32 = the reference's DDP all-reduce "
+                        "(default), bf16 = half the bytes per link, bf16 sums across the ranks")
     p.add_argument("--log-every", default=10, type=int)
     p.add_argument("--time-last", default=0, type=int, help="report the wall clock per step of the last N of --steps steps")
     return p.parse_args(argv)
