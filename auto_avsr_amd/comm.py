@@ -67,6 +67,16 @@ class StreamComm:
         ops.call("avsr_comm_all_gather_f32", self.slot, ops._ptr(mine), ops._ptr(out), mine.numel(), ops._stream(out))
         return out
 
+    def reduce_scatter(self, full, mine=None):
+        """mine (default: this rank's slice of `full`, in place) = sum over the ranks of their `full`'s slice `rank`."""
+        n = full.numel() // self.world
+        assert full.numel() == n * self.world and full.is_contiguous() and full.dtype in (torch.float32, torch.bfloat16)
+        if mine is None:
+            mine = full[self.rank * n:(self.rank + 1) * n]
+        ops.call("avsr_comm_reduce_scatter", self.slot, ops._ptr(full), ops._ptr(mine), n, 0 if full.dtype == torch.float32 else 1,
+                 ops._stream(full), nbytes=float(full.numel() * full.element_size()))
+        return mine
+
     def close(self):
         if StreamComm._live.get(self.slot) is self:
             _lib.lib().call("avsr_comm_destroy", self.slot)
@@ -100,6 +110,8 @@ class GroupComm:
 
     def all_gather(self, out, mine):
         assert out.numel() == self.world * mine.numel()
+        if mine.untyped_storage().data_ptr() == out.untyped_storage().data_ptr():
+            mine = mine.clone()  # (in-place form -- `mine` is this rank's slice of `out`: c10d wants disjoint buffers)
         if out.is_cuda and self._dist.get_backend(self.group) == "gloo":
             # (gloo has no all-gather on device tensors: sum of one-hot placements)
             out.zero_()
@@ -108,6 +120,16 @@ class GroupComm:
             return out
         self._dist.all_gather_into_tensor(out, mine, group=self.group)
         return out
+
+    def reduce_scatter(self, full, mine=None):
+        """(gloo has no reduce-scatter: the all-reduce, of which this rank keeps its slice)"""
+        n = full.numel() // self.world
+        self.all_reduce(full)
+        sl = full[self.rank * n:(self.rank + 1) * n]
+        if mine is not None and mine.data_ptr() != sl.data_ptr():
+            mine.copy_(sl)
+            return mine
+        return sl
 
     def ranks(self):
         return self.world

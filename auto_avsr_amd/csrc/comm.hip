@@ -34,6 +34,7 @@ struct Api {
     int (*CommDestroy)(NcclComm) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, NcclComm, hipStream_t) = nullptr;
+    int (*ReduceScatter)(const void*, void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 } g_api;
 constexpr int kSlots = 4;
@@ -57,6 +58,7 @@ bool load_api() {
     a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
     a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(h, "ncclAllGather"));
+    a.ReduceScatter = reinterpret_cast<decltype(a.ReduceScatter)>(dlsym(h, "ncclReduceScatter"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
     if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.AllGather) {
         avsr_set_error("comm: librccl.so lacks the NCCL entry points");
@@ -133,6 +135,18 @@ extern "C" int avsr_comm_all_gather_f32(int slot, const void* send, void* recv, 
     return check(g_api.AllGather(send, recv, (size_t)count_per_rank, kNcclFloat32, g_comm[slot], stream), "ncclAllGather");
 }
 
+// recv[0 .. count_per_rank) = sum over ranks of their send[rank * count_per_rank ..) -- the gradient exchange of the sharded optimizer
+// (ddp.GradBuckets shard=True): half the wire traffic of an all-reduce inside the backward pass; recv may be send + rank * count
+// (in place).  dtype 0 = f32, 1 = bf16.
+extern "C" int avsr_comm_reduce_scatter(int slot, const void* send, void* recv, int64_t count_per_rank, int dtype, hipStream_t stream) {
+    AVSR_REQUIRE(slot >= 0 && slot < kSlots && g_comm[slot] != nullptr, "comm_reduce_scatter: no communicator in this slot (avsr_comm_init)");
+    AVSR_REQUIRE(dtype == 0 || dtype == 1, "comm_reduce_scatter: dtype must be 0 (f32) or 1 (bf16)");
+    AVSR_REQUIRE(g_api.ReduceScatter != nullptr, "comm_reduce_scatter: librccl.so lacks ncclReduceScatter");
+    if (count_per_rank <= 0) return 0;
+    return check(g_api.ReduceScatter(send, recv, (size_t)count_per_rank, dtype == 1 ? kNcclBfloat16 : kNcclFloat32, kNcclSum, g_comm[slot],
+                                     stream), "ncclReduceScatter");
+}
+
 #else  // host emulator build (CPU test suite): there is no RCCL; the data-parallel tests run on torch.distributed / gloo
 
 extern "C" int avsr_comm_unique_id(void*) { avsr_set_error("comm: not available in the emulator build"); return 1; }
@@ -142,5 +156,6 @@ extern "C" int64_t avsr_comm_size(int) { return 0; }
 extern "C" int avsr_comm_all_reduce_f32(int, void*, int64_t, hipStream_t) { avsr_set_error("comm: not available in the emulator build"); return 1; }
 extern "C" int avsr_comm_all_reduce(int, void*, int64_t, int, hipStream_t) { avsr_set_error("comm: not available in the emulator build"); return 1; }
 extern "C" int avsr_comm_all_gather_f32(int, const void*, void*, int64_t, hipStream_t) { avsr_set_error("comm: not available in the emulator build"); return 1; }
+extern "C" int avsr_comm_reduce_scatter(int, const void*, void*, int64_t, int, hipStream_t) { avsr_set_error("comm: not available in the emulator build"); return 1; }
 
 #endif

@@ -76,6 +76,7 @@ struct Params {
     // stores (a first version accumulated into 64 slots with float atomics: 774 k L2 atomics per first-stage convolution cost
     // what the removed statistics pass had cost)
     float* colstat;
+    int colstat_rows;  // rows the caller allocated (128-row tiles); kernels with taller tiles zero the rows they do not fill
     float* colsum_a;  // TN tile kernel only: colsum_a[m] += sum_k A[k][m] -- the bias gradient of the Linear whose weight
                       // gradient this contraction is (A = its output gradient), taken from the staged A tiles
     int cN, xcd_order, ncls;

@@ -184,7 +184,8 @@ static int gemm16_nt_impl(int f16, const void* A, int lda, const void* B, const 
             // >= 160 of them: 1600x3072x768 29.5 -> 27.6 us, 1600x9216x768 67.6 -> 61.1 (profiles/r6_microbench_h16x2.txt);
             // the 126 tiles of the fused Q/K/V projection are slower (26 vs 19 us)
             const long t256 = (long)((M + 255) / 256) * ((N + 127) / 128);
-            tile = g_tune[17] > 0 ? g_tune[17] : (t256 >= 160 ? 5 : (t12864 >= 256 ? 7 : (K >= 2048 && t12864 >= 128 ? 2 : 1)));
+            // (knob 17 = -1: the round-5 rule, without the 256x128 tile -- same-box A/B runs)
+            tile = g_tune[17] > 0 ? g_tune[17] : (t256 >= 160 && g_tune[17] == 0 ? 5 : (t12864 >= 256 ? 7 : (K >= 2048 && t12864 >= 128 ? 2 : 1)));
         }
         AVSR_REQUIRE(launch_tile_h16x2<0>(tile, p, split_k, stream), "gemm_h16_nt: unknown tile code (two weight planes)");
         AVSR_CHECK_LAUNCH("gemm_h16_nt");

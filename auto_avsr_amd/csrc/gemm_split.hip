@@ -40,15 +40,19 @@ using avsr_gemm_impl::Params;
 // BSP: B is in the split8 layout.  ACV = 1: the staged A tile is converted to split8 in place, once per stage, by all threads;
 // ACV = 2 (round 5): A ARRIVES in the split8 layout -- its producer (a BatchNorm + activation pass) wrote it that way, the same
 // bytes as the f32 tensor -- so the stage needs no conversion pass and no second barrier.
-// WGM x WGN: wave grid (4 waves).
+// WGM x WGN: wave grid -- 4 waves, or (round 6) 8 waves = two per SIMD on 256-row tiles: the A tile of a convolution is the
+// im2col gather (every input pixel crosses L2 -> LDS once per filter tap), so a 256 x 64 tile moves 40 KB per k-tile where two
+// 128 x 64 tiles move 48, a 256 x 128 tile 48 KB where two 128 x 128 tiles move 64 -- and these launches are bound by exactly
+// that delivery (gemm_fast.hip, round-6 note).
 template <int BM, int BN, int STAGES, int CV, bool BSP = false, int WGM = 2, int WGN = 2, int ACV = 0>
 struct SplitKernel {
-    static constexpr int BK = 32, NW = 4, NTHR = 256;
-    static_assert(WGM * WGN == NW, "four waves");
+    static constexpr int BK = 32, NW = WGM * WGN, NTHR = 64 * NW;
+    static_assert(NW == 4 || NW == 8, "four or eight waves");
     static constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32 x 32");
     static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
-    static constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;  // wave-instructions (8 rows each) per wave per stage
+    static constexpr int A_LOADS = BM / (8 * NW), B_LOADS = BN / (8 * NW);  // wave-instructions (8 rows each) per wave per stage
+    static_assert(A_LOADS >= 1 && B_LOADS >= 1 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile / wave-count mismatch");
     static constexpr int LPT = A_LOADS + B_LOADS;
     static constexpr size_t RING_BYTES = (size_t)STAGES * STAGE_BYTES, EPI_BYTES = (size_t)BM * (BN + 4) * 4;
     static constexpr size_t LDS_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
@@ -245,6 +249,13 @@ struct SplitKernel {
             Params q = p;
             q.gate = nullptr;  // in conv mode the field carries the zero page, not an activation gate
             avsr_gemm_impl::epilogue_lds<BM, BN, TM, TN, NTHR, 1>(acc, q, m0, n0, wm * WM, wn * WN, zs, 0, smem);
+            // the caller sized the statistics buffer for 128-row tiles: a taller tile fills fewer rows, and the rows behind them
+            // must read as zero for the fold (block (0, by) clears row gridDim.y + by: every tail row exactly once)
+            if (BM > 128 && p.colstat && blockIdx.x == 0) {
+                const int r2 = (int)gridDim.y + (int)blockIdx.y;
+                if (r2 < p.colstat_rows)
+                    for (int i = threadIdx.x; i < 2 * p.N; i += NTHR) p.colstat[(size_t)r2 * 2 * p.N + i] = 0.f;
+            }
         } else {
             avsr_gemm_impl::epilogue_lds<BM, BN, TM, TN, NTHR, 1>(acc, p, m0, n0, wm * WM, wn * WN, zs, 0, smem);
         }
@@ -252,7 +263,7 @@ struct SplitKernel {
 };
 
 template <int BM, int BN, int STAGES, int CV, bool BSP, int WGM, int WGN, int ACV>
-__global__ __launch_bounds__(256) void gemm_split_kernel(Params p) {
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_split_kernel(Params p) {
     AVSR_DYN_SMEM(smem);
     SplitKernel<BM, BN, STAGES, CV, BSP, WGM, WGN, ACV>::run(p, smem);
 }
@@ -290,6 +301,12 @@ bool launch_tile(int tile, Params& p, int split_k, hipStream_t stream) {
         case 24: if constexpr (BSP) { launch_split<128, 128, 2, CV, BSP, 2, 2, 2>(p, split_k, stream); return true; } return false;
         case 25: if constexpr (BSP) { launch_split<128, 64, 3, CV, BSP, 2, 2, 2>(p, split_k, stream); return true; } return false;
         case 26: if constexpr (BSP) { launch_split<128, 128, 3, CV, BSP, 2, 2, 2>(p, split_k, stream); return true; } return false;
+        // 27 .. 30 (round 6): 256-row tiles on 8 waves, A pre-split: 256x64 / 2 stages (80 KB: two blocks per CU), 256x64 / 3,
+        // 256x128 / 3 stages (144 KB), 256x128 / 2
+        case 27: if constexpr (BSP) { launch_split<256, 64, 2, CV, BSP, 4, 2, 2>(p, split_k, stream); return true; } return false;
+        case 28: if constexpr (BSP) { launch_split<256, 64, 3, CV, BSP, 4, 2, 2>(p, split_k, stream); return true; } return false;
+        case 29: if constexpr (BSP) { launch_split<256, 128, 3, CV, BSP, 4, 2, 2>(p, split_k, stream); return true; } return false;
+        case 30: if constexpr (BSP) { launch_split<256, 128, 2, CV, BSP, 4, 2, 2>(p, split_k, stream); return true; } return false;
         case 1: launch_split<64, 64, 3, CV, BSP>(p, split_k, stream); return true;
         case 2: launch_split<64, 64, 2, CV, BSP>(p, split_k, stream); return true;
         case 3: launch_split<128, 64, 2, CV, BSP>(p, split_k, stream); return true;
@@ -411,8 +428,16 @@ static int conv2d_f32s_impl(const float* x, const float* wp, float* y, const voi
     p.M = N * OH * OW; p.N = Cout; p.ldc = Cout;
     p.cH = H; p.cW = W; p.cOH = OH; p.cOW = OW;
     p.colstat = stats_part;
+    p.colstat_rows = stats_tiles;
     if (tile == 0) tile = Cout >= 128 ? 14 : 13;
-    AVSR_REQUIRE(stats_part == nullptr || tile == 13 || tile == 14 || (tile >= 23 && tile <= 26), "conv2d_f32s: statistics need a 128-row tile");
+    // pre-split A (codes 23 / 24 = "the caller's activation is in the split8 layout, 128-row default"): knobs 21 (Cout < 128) /
+    // 22 (Cout >= 128) force a tile for A/B runs
+    // round 6: stage-1 geometry (Cout = 64, >= 65 k output rows): 256 x 64 tiles on 8 waves, two blocks per CU: 293 -> 264 us
+    // (profiles/r6_microbench_presplit.txt); the 256 x 128 tiles of the 128-channel stage measured slower (200 vs 171 us)
+    if (tile == 23 && avsr_tune_knobs[21] == 0 && Cout == 64 && (long)N * OH * OW >= 65536) tile = 27;
+    if (tile == 23 && avsr_tune_knobs[21] > 0) tile = avsr_tune_knobs[21];
+    if (tile == 24 && avsr_tune_knobs[22] > 0) tile = avsr_tune_knobs[22];
+    AVSR_REQUIRE(stats_part == nullptr || tile == 13 || tile == 14 || (tile >= 23 && tile <= 30), "conv2d_f32s: statistics need a 128- or 256-row tile");
     const bool ok = w_split ? launch_tile<1, true>(tile, p, 1, stream) : launch_tile<1, false>(tile, p, 1, stream);
     AVSR_REQUIRE(ok, "conv2d_f32s: unknown tile code");
     AVSR_CHECK_LAUNCH("conv2d_f32s");

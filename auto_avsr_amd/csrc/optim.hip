@@ -316,6 +316,44 @@ extern "C" int avsr_adamw_step(const void* table, int n, int total_blocks, float
     return 0;
 }
 
+// The step in two halves, for an optimizer SHARDED over the data-parallel ranks (optim.ShardedAdamW: every rank owns 1 / N of every
+// gradient bucket after a reduce-scatter and updates only that slice of the flat parameter buffers -- lightning.py:48-52 /
+// train.py:41 semantics, 1 / N of the optimizer's HBM traffic per rank).  The global gradient norm needs the other ranks' shares:
+//   avsr_multi_sumsq   sumsq[0] = sum of squares of this rank's gradient slices (table as above; partial: total_blocks floats)
+//   [all-reduce of the one float across the ranks -- the caller]
+//   avsr_adamw_apply   clip coefficient + step counter + learning rate from that global sum, then AdamW on the table's slices
+__global__ __launch_bounds__(1024) void sum_partials_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ out) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 1024) s += (double)partial[i];
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < 16; w++) tot += red[w];
+        out[0] = (float)tot;
+    }
+}
+extern "C" int avsr_multi_sumsq(const void* table, int n, int total_blocks, float* partial, float* sumsq, hipStream_t stream) {
+    AVSR_REQUIRE(table && partial && sumsq && n > 0 && total_blocks > 0, "multi_sumsq: bad arguments");
+    AVSR_LAUNCH(multi_sumsq_kernel, dim3(total_blocks), dim3(256), 0, stream, reinterpret_cast<const OptEntry*>(table), n, partial);
+    AVSR_LAUNCH(sum_partials_kernel, dim3(1), dim3(1024), 0, stream, (const float*)partial, total_blocks, sumsq);
+    AVSR_CHECK_LAUNCH("multi_sumsq");
+    return 0;
+}
+extern "C" int avsr_adamw_apply(const void* table, int n, int total_blocks, const float* sumsq, float* state, float base_lr,
+                                float beta1, float beta2, float eps, float weight_decay, float max_grad_norm, int64_t warmup_steps,
+                                int64_t total_steps, hipStream_t stream) {
+    AVSR_REQUIRE(table && sumsq && state && n > 0 && total_blocks > 0, "adamw_apply: bad arguments");
+    AVSR_LAUNCH(clip_coef_kernel, dim3(1), dim3(1024), 0, stream, sumsq, 1, max_grad_norm, base_lr, (float)warmup_steps,
+                (float)total_steps, state);
+    AVSR_LAUNCH(multi_adamw_kernel, dim3(total_blocks), dim3(256), 0, stream, reinterpret_cast<const OptEntry*>(table), n,
+                (const float*)state, beta1, beta2, eps, weight_decay);
+    AVSR_CHECK_LAUNCH("adamw_apply");
+    return 0;
+}
+
 // The same step with the bf16 operand copies of the 2-D weights refreshed in the update pass:
 //   table / n / total_blocks   every parameter (48-byte entries as above): gradient norm
 //   lin_table / lin_n / lin_blocks   the parameters updated by the linear kernel (same entry format, own blk0 numbering)

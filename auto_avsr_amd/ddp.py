@@ -39,8 +39,13 @@ class _NullCtx:
 
 
 class GradBuckets:
-    def __init__(self, params, group=None, bucket_mb=None, comm=None, wire=None, spare=72):
-        """spare: captured step shapes this object can serve (one pinned pointer table per bucket and shape); size it to the
+    def __init__(self, params, group=None, bucket_mb=None, comm=None, wire=None, spare=72, shard=False):
+        """shard (round 6, optim.ShardedAdamW): the exchange is a REDUCE-SCATTER -- after it a rank holds the averaged gradients of
+        its 1 / world slice of every bucket only -- and the parameters themselves live in flat per-bucket buffers laid out like
+        the gradient buckets (`pflat`; `p.data` re-pointed at its slice), so that the sharded optimizer can update a contiguous
+        slice and all-gather the buffer.  Half the wire bytes of the all-reduce inside the backward pass; the other half is the
+        all-gather of the updated weights after the optimizer.
+        spare: captured step shapes this object can serve (one pinned pointer table per bucket and shape); size it to the
         owner's graph capacity (train_native: StepGraphs max_graphs + 8).
         bucket_mb: bucket size in MB of f32 gradients (default 64, environment AVSR_BUCKET_MB overrides: sweep hook).
         wire: "f32" (default) or "bf16" (environment AVSR_GRAD_WIRE when the argument is None): the format the buckets travel in.  bf16 halves the bytes
@@ -68,11 +73,27 @@ class GradBuckets:
         self.device = self.params[0].device
         self._cap = max(1, int(bucket_mb * (1 << 20) / 4))
         self._n_spare = spare
+        self.shard = bool(shard)
+        self.rank = comm.rank if comm is not None else (dist.get_rank(group) if dist.is_initialized() else 0)
+        if self.shard:
+            assert self.wire == "f32", "sharded optimizer: f32 wire"
         # first assignment: the parameters in reverse registration order (roughly the order their gradients become ready); the
         # first step records the REAL arrival order and rebuild_by_arrival() re-buckets by it (see there)
         self._arrival = []
         self.rebuilt = False
         self._assign(list(reversed(range(len(self.params)))))
+        if self.shard:
+            # flat parameter buffers, same offsets as the gradient buckets; the parameters become views of them (their identity,
+            # hence state_dict / autograd, is untouched; cached operand copies keyed by address are not: the caller invalidates)
+            self.rebuilt = True  # (the layout is fixed from here on: no re-bucketing by arrival order)
+            self._arrival = None
+            self.pflat = [torch.zeros_like(f) for f in self.flat]
+            with torch.no_grad():
+                for i, p in enumerate(self.params):
+                    b, o = self.bucket_of[i], self.offset[i]
+                    v = self.pflat[b][o:o + p.numel()].view_as(p)
+                    v.copy_(p.data)
+                    p.data = v
         self.compute_stream = None  # set by begin_step(): the stream the step's kernels are issued on
         self._side = torch.cuda.Stream(device=self.device) if (comm is not None and self.device.type == "cuda") else None
         self._side_used = False
@@ -93,6 +114,9 @@ class GradBuckets:
             cur_n += n
         members.append(cur)
         sizes.append(cur_n)
+        if getattr(self, "shard", False):  # every rank's slice of a bucket starts 16-byte aligned
+            q = 4 * self.world
+            sizes = [(n + q - 1) // q * q for n in sizes]
         self.members = members
         self.flat = [torch.zeros(n, dtype=torch.float32, device=self.device) for n in sizes]
         self.narrow = [torch.zeros(n, dtype=torch.bfloat16, device=self.device) for n in sizes] if self.wire == "bf16" else None
@@ -245,10 +269,19 @@ class GradBuckets:
                         self._reduce(b)
                 self._side_used = self._side is not None
             elif self.world > 1 or self.group is not None:
+                # (torch.distributed transport: gloo has no reduce-scatter -- in shard mode the all-reduce, of which the optimizer
+                # reads this rank's slice only)
                 self._works.append(dist.all_reduce(self.flat[b], group=self.group, async_op=True))
 
+    def shard_range(self, b):
+        n = self.flat[b].numel() // self.world
+        return self.rank * n, (self.rank + 1) * n
+
     def _reduce(self, b):
-        """The all-reduce of bucket b on the current stream, in the wire format."""
+        """The all-reduce of bucket b on the current stream, in the wire format (shard mode: the reduce-scatter)."""
+        if self.shard:
+            self.comm.reduce_scatter(self.flat[b])
+            return
         if self.wire == "bf16":
             # (the bucket is already bf16: the gather launch wrote it -- no pass over an f32 image of the local gradients)
             self.comm.all_reduce(self.narrow[b])

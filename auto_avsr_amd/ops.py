@@ -58,6 +58,8 @@ zeros_f32 = lambda shape, device: torch.zeros(shape, dtype=torch.float32, device
 PROFILE = None  # bench.py: list collecting (entry point, start event, end event, flops) per launch
 RECORD = None   # bench.py: (entry points, list) -- the argument tuples of every launch of those entry points
 TRACE = None    # tools/pmc_step.py: list collecting (entry point, algorithmic flops, algorithmic bytes) of every launch
+PAIR_RECORD = None  # bench.py: list collecting, per paired launch (paired() below), the [(entry point, args, flops, bytes), ...] inside it
+_pair_cur = None
 
 
 def call(name, *args, flops=0.0, nbytes=0.0):
@@ -67,6 +69,8 @@ def call(name, *args, flops=0.0, nbytes=0.0):
         TRACE.append((name, flops, nbytes))
     if RECORD is not None and name in RECORD[0]:
         RECORD[1].append((name, args, flops, nbytes))
+    if _pair_cur is not None:
+        _pair_cur.append((name, args, flops, nbytes))
     if PROFILE is None:
         return _lib.lib().call(name, *args)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -94,12 +98,18 @@ def paired():
     if not PAIR_GEMMS or PROFILE is not None or RECORD is not None:
         yield
         return
+    global _pair_cur
     L = _lib.lib()
+    if PAIR_RECORD is not None:
+        _pair_cur = []
     L.call("avsr_gemm_pair_begin")
     try:
         yield
     finally:
         L.call("avsr_gemm_pair_end")
+        if PAIR_RECORD is not None and _pair_cur is not None:
+            PAIR_RECORD.append(_pair_cur)
+        _pair_cur = None
 
 
 TWIN = None  # functional.py ("hpf" / "mixed" modes): callable(f32 / f16 tensor) -> bf16 twin buffer to fill alongside it, or None

@@ -26,7 +26,7 @@ class _Hot(torch.nn.Module):
         return self.m.forward_tensors(x, lens, y)
 
 
-def save_checkpoint(folder, epoch, model, opt, global_step, keep=10):
+def save_checkpoint(folder, epoch, model, opt, global_step, keep=10, opt_state=None):
     """rank 0: `epoch=N.ckpt` in the layout average_checkpoints.py / lightning.py:44 read ({"state_dict": {"model.<key>"}}),
     the `keep` newest kept (ModelCheckpoint(monitor="monitoring_step", mode="max", save_top_k=10): the monitored value
     is the global step, so "top 10" = the ten latest), plus last.ckpt with the optimizer state."""
@@ -34,7 +34,9 @@ def save_checkpoint(folder, epoch, model, opt, global_step, keep=10):
     sd = {"model." + k: v.detach().cpu() for k, v in model.state_dict().items()}
     meta = {"epoch": epoch, "global_step": global_step}
     torch.save({"state_dict": sd, **meta}, os.path.join(folder, f"epoch={epoch}.ckpt"))
-    torch.save({"state_dict": sd, "optimizer": opt.state_dict(), **meta}, os.path.join(folder, "last.ckpt"))
+    # (opt_state: the optimizer state gathered beforehand by ALL ranks -- a sharded optimizer's state_dict() is a collective)
+    torch.save({"state_dict": sd, "optimizer": opt_state if opt_state is not None else opt.state_dict(), **meta},
+               os.path.join(folder, "last.ckpt"))
     old = os.path.join(folder, f"epoch={epoch - keep}.ckpt")
     if os.path.exists(old):
         os.remove(old)
@@ -151,7 +153,7 @@ def fit(model, args, dev, rank=0, world=1, backend="nccl", log=print):
     starts clean instead of running two hook sets on stale communicators."""
     from . import functional as AF
 
-    held = {"buckets": None, "comms": [], "stepper": None}
+    held = {"native": None, "stepper": None}
     old_mode = AF._save_mode()
     # The whole loop runs on a stream of its own, never on the legacy default stream: gradient-accumulation nodes remember the
     # stream they were created on, and a hipGraph capture must not meet work bound to the default stream (it would have to
@@ -169,10 +171,8 @@ def fit(model, args, dev, rank=0, world=1, backend="nccl", log=print):
     finally:
         AF._restore_mode(old_mode)
         fit.last_stats = dict(held["stepper"].stats, tail_ms=held.get("tail_ms")) if held["stepper"] is not None else None
-        if held["buckets"] is not None:
-            held["buckets"].remove()
-        for c in held["comms"]:
-            c.close()
+        if held["native"] is not None:
+            held["native"].close()
         AF.set_bn_sync(None)
 
 
@@ -182,48 +182,157 @@ def _max_graphs():
     return int(os.environ.get("AVSR_MAX_GRAPHS", "512"))
 
 
+class NativeStepper:
+    """ONE training step as one callable: forward + backward + (data-parallel exchange, cross-rank BatchNorm, W / sum(B)) + fused
+    global-norm clip / AdamW / warm-up cosine + the per-step weight re-casts -- what `bench.py` times -- replayed as a hipGraph
+    per batch shape from a shape's second visit on (graph_step.StepGraphs).  Two drivers: `fit()` below (train.py's native
+    loop) and `lightning.ModelModule` in its manual-optimisation mode (`--trainer-step native`: a Lightning `Trainer` then only
+    feeds batches and runs callbacks, lightning.py:86-114 / train.py:30-42), so that the Trainer path runs at the speed of the
+    benchmarked step instead of eager launches + torch's foreach AdamW.
+
+    stepper(x, lens, y) -> (loss, loss_ctc, loss_att, n_correct, n_tokens) as device scalars (static tensors of the graph when
+    replayed: read them before the next step of the same shape).  close() removes the hooks / communicators it installed."""
+
+    def __init__(self, model, args, dev, rank, world, steps_per_epoch, log=print, seed_offset=0):
+        from . import functional as AF
+        from .graph_step import StepGraphs
+        from .optim import FusedAdamW
+
+        self.model, self.args, self.dev, self.rank, self.world = model, args, dev, rank, world
+        self.comms, self.buckets, self.shard = [], None, False
+        AF.manual_seed(42 + rank)
+        self.seed_dev = seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        AF.set_seed_tensor(seed_dev)
+        hot = _Hot(model)
+        buckets = None
+        if world > 1:
+            # train.py:31,37: cross-rank BatchNorm (the kernels' own statistics exchange) + DDP gradient averaging
+            AF.set_bn_sync(dist.group.WORLD)
+            if os.environ.get("AVSR_DDP", "torch") == "buckets":
+                # this build's own bucketed RCCL all-reduce (ddp.GradBuckets); on GPUs every collective of the step -- gradient
+                # buckets, BatchNorm statistics -- goes straight to RCCL's C API (comm.StreamComm: a ctypes call instead of a
+                # c10d Work object per collective; 64 BatchNorm collectives per step make that the larger share of the host time)
+                from .ddp import GradBuckets
+
+                comm_grads = None
+                if dev.type == "cuda":
+                    from .comm import StreamComm
+
+                    comm_bn, comm_grads = StreamComm.from_process_group(), StreamComm.from_process_group()
+                    self.comms += [comm_bn, comm_grads]
+                    AF.set_bn_sync(dist.group.WORLD, comm=comm_bn)
+                # wire format of the gradient buckets: f32 like the reference's DDP all-reduce unless asked otherwise
+                # (--grad-wire bf16 / AVSR_GRAD_WIRE=bf16: half the bytes per xGMI link, bf16 sums across the ranks)
+                wire = getattr(args, "grad_wire", None) or os.environ.get("AVSR_GRAD_WIRE") or "f32"
+                # AVSR_SHARD_OPT=1: reduce-scatter instead of all-reduce, the optimizer on this rank's 1 / world slice of every
+                # bucket, all-gather of the updated flat parameter buffers (optim.ShardedAdamW; opt-in, see there)
+                self.shard = os.environ.get("AVSR_SHARD_OPT", "0") == "1"
+                buckets = self.buckets = GradBuckets(model.parameters(), group=dist.group.WORLD, comm=comm_grads, wire=wire,
+                                                     spare=_max_graphs() + 8, shard=self.shard)
+                if self.shard:
+                    AF.invalidate_weight_cache()  # (the parameters moved into the flat buffers: cached copies are keyed by address)
+            else:
+                hot = torch.nn.parallel.DistributedDataParallel(
+                    hot, device_ids=[dev.index] if dev.type == "cuda" else None, find_unused_parameters=False,
+                    broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=64)
+        # lightning.py:48-52 + train.py:41 + cosine.py as one fused multi-tensor step (optim.py): AdamW(.9/.98), clip 10,
+        # per-step warm-up cosine; step count / lr / gradient norm stay on the device
+        if buckets is not None and buckets.shard:
+            from .optim import ShardedAdamW
+
+            opt = self.opt = ShardedAdamW(buckets, lr=args.lr, betas=(0.9, 0.98), weight_decay=args.weight_decay, max_grad_norm=10.0,
+                                          warmup_steps=int(args.warmup_epochs * steps_per_epoch),
+                                          total_steps=int(args.max_epochs * steps_per_epoch))
+        else:
+            opt = self.opt = FusedAdamW(model.parameters(), lr=args.lr, betas=(0.9, 0.98), weight_decay=args.weight_decay,
+                                        max_grad_norm=10.0, warmup_steps=int(args.warmup_epochs * steps_per_epoch),
+                                        total_steps=int(args.max_epochs * steps_per_epoch), cast_weights=dev.type == "cuda",
+                                        graph_shapes=_max_graphs())
+        params = list(model.parameters())
+
+        def full_step(x, lens, y):
+            """ONE training step, start to end, with no host decision that depends on the batch's values: what runs eagerly the
+            first time a batch shape shows up and what a hipGraph of that shape replays afterwards (graph_step.StepGraphs)."""
+            for p in params:  # (gradients of a replayed step live in the graph's pool: never accumulate into them)
+                p.grad = None
+            seed_dev.add_(1)
+            AF.manual_seed(42 + rank)  # restart the per-site counter: mask = f(rank, site index, seed_dev = global step)
+            if buckets is not None:
+                buckets.begin_step()
+            AF.new_step()
+            AF.refresh_weight_cache()  # conv-weight permutes; the Linear copies were rewritten by the optimizer step itself
+            loss, loss_ctc, loss_att, hits, ntok = hot(x, lens, y)
+            if world > 1:
+                bs = torch.full((1,), float(x.shape[0]), device=dev)
+                allb = torch.empty(world, device=dev)
+                if buckets is not None and buckets.comm is not None:
+                    AF._state["bn_comm"].all_gather(allb, bs)
+                else:
+                    dist.all_gather_into_tensor(allb, bs)
+                loss = loss * (world / allb.sum())  # lightning.py:88-90
+            loss.backward()
+            if buckets is not None:
+                buckets.finish()
+            opt.step()
+            if buckets is not None and not buckets.rebuilt and not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+                for p in params:  # (after the first step: buckets in the order the gradients arrived -- ddp.GradBuckets.rebuild_by_arrival)
+                    p.grad = None
+                buckets.rebuild_by_arrival()
+            return loss.detach(), loss_ctc.detach(), loss_att.detach(), hits, ntok
+
+        # hipGraph replay per batch shape (what bench.py times): single-rank runs, and data-parallel runs whose collectives are all
+        # stream operations on RCCL's C API (AVSR_DDP=buckets on GPUs); torch's DDP reducer cannot be captured
+        graph_ok = dev.type == "cuda" and not getattr(args, "no_graph", False) and \
+            (world == 1 or (buckets is not None and buckets.comm is not None))
+
+        def capture_failed(e):
+            # a capture that dies mid-backward leaves partial bucket counts, pending reductions and gradients that live in the dead
+            # graph's pool: reset all of it, or the eager retry never flushes those buckets and finish() raises on this rank while
+            # the others wait in a collective (round-5 advisor finding)
+            log(f"[rank {rank}] hipGraph capture failed ({type(e).__name__}: {str(e)[:160]}); eager from here on")
+            for p in params:
+                p.grad = None
+            if buckets is not None:
+                buckets.abort_step()
+
+        def released(key):  # a graph is gone: its pinned pointer tables go back to their owners
+            opt.release_captured(key)
+            if buckets is not None:
+                buckets.release_captured(key)
+
+        # capacity: the first AVSR_MAX_GRAPHS (default 512) shapes that show up twice are captured and kept for the run -- no
+        # eviction (graph_step.py); the optimizer's and the buckets' pre-pinned tables are sized for exactly that many captures
+        self.stepper = StepGraphs(full_step, enabled=graph_ok, capture_after=1, thread_local=world > 1, max_graphs=_max_graphs(),
+                                  on_fail=capture_failed, on_evict=released)
+
+    @property
+    def stats(self):
+        return self.stepper.stats
+
+    def __call__(self, x, lens, y):
+        return self.stepper(x, lens, y)
+
+    def close(self):
+        from . import functional as AF
+
+        if self.buckets is not None:
+            self.buckets.remove()
+            self.buckets = None
+        for c in self.comms:
+            c.close()
+        self.comms = []
+        AF.set_bn_sync(None)
+
+
 def _fit(model, args, dev, rank, world, backend, log, held):
     from . import functional as AF
-    from .optim import FusedAdamW
-    AF.manual_seed(42 + rank)
-    seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
-    AF.set_seed_tensor(seed_dev)
-    hot = _Hot(model)
-    buckets = None
-    if world > 1:
-        # train.py:31,37: cross-rank BatchNorm (the kernels' own statistics exchange) + DDP gradient averaging
-        AF.set_bn_sync(dist.group.WORLD)
-        if os.environ.get("AVSR_DDP", "torch") == "buckets":
-            # this build's own bucketed RCCL all-reduce (ddp.GradBuckets); on GPUs every collective of the step -- gradient
-            # buckets, BatchNorm statistics -- goes straight to RCCL's C API (comm.StreamComm: a ctypes call instead of a
-            # c10d Work object per collective; 64 BatchNorm collectives per step make that the larger share of the host time)
-            from .ddp import GradBuckets
-
-            comm_grads = None
-            if dev.type == "cuda":
-                from .comm import StreamComm
-
-                comm_bn, comm_grads = StreamComm.from_process_group(), StreamComm.from_process_group()
-                held["comms"] += [comm_bn, comm_grads]
-                AF.set_bn_sync(dist.group.WORLD, comm=comm_bn)
-            # wire format of the gradient buckets: f32 like the reference's DDP all-reduce unless asked otherwise
-            # (--grad-wire bf16 / AVSR_GRAD_WIRE=bf16: half the bytes per xGMI link, bf16 sums across the ranks)
-            wire = getattr(args, "grad_wire", None) or os.environ.get("AVSR_GRAD_WIRE") or "f32"
-            buckets = held["buckets"] = GradBuckets(model.parameters(), group=dist.group.WORLD, comm=comm_grads, wire=wire,
-                                                    spare=_max_graphs() + 8)
-        else:
-            hot = torch.nn.parallel.DistributedDataParallel(
-                hot, device_ids=[dev.index] if dev.type == "cuda" else None, find_unused_parameters=False,
-                broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=64)
     source = _batch_source(args, model, dev, rank, world)
     # every rank sees the same number of batches per epoch (DistributedSampler pads): the schedule lengths below and the
     # number of collectives per epoch are identical on all ranks
     steps_per_epoch = source.steps_per_epoch
-    # lightning.py:48-52 + train.py:41 + cosine.py as one fused multi-tensor step (optim.py): AdamW(.9/.98), clip 10,
-    # per-step warm-up cosine; step count / lr / gradient norm stay on the device
-    opt = FusedAdamW(model.parameters(), lr=args.lr, betas=(0.9, 0.98), weight_decay=args.weight_decay, max_grad_norm=10.0,
-                     warmup_steps=args.warmup_epochs * steps_per_epoch, total_steps=args.max_epochs * steps_per_epoch,
-                     cast_weights=dev.type == "cuda", graph_shapes=_max_graphs())
+    ns = held["native"] = NativeStepper(model, args, dev, rank, world, steps_per_epoch, log=log)
+    opt, seed_dev, stepper = ns.opt, ns.seed_dev, ns.stepper
+    held["stepper"] = stepper
     folder = os.path.join(args.exp_dir, args.exp_name) if getattr(args, "exp_dir", None) else None
     start_epoch, global_step = 0, 0
     if getattr(args, "ckpt_path", None):
@@ -234,65 +343,7 @@ def _fit(model, args, dev, rank, world, backend, log, held):
     losses = []
     t0 = time.time()
     done = False
-    params = list(model.parameters())
     mode = getattr(args, "numerics", None)  # train.py: --numerics, default "mixed" (what bench.py times); None: the caller's mode
-
-    def full_step(x, lens, y):
-        """ONE training step, start to end, with no host decision that depends on the batch's values: what runs eagerly the
-        first time a batch shape shows up and what a hipGraph of that shape replays afterwards (graph_step.StepGraphs)."""
-        for p in params:  # (gradients of a replayed step live in the graph's pool: never accumulate into them)
-            p.grad = None
-        seed_dev.add_(1)
-        AF.manual_seed(42 + rank)  # restart the per-site counter: mask = f(rank, site index, seed_dev = global step)
-        if buckets is not None:
-            buckets.begin_step()
-        AF.new_step()
-        AF.refresh_weight_cache()  # conv-weight permutes; the Linear copies were rewritten by the optimizer step itself
-        loss, loss_ctc, loss_att, hits, ntok = hot(x, lens, y)
-        if world > 1:
-            bs = torch.full((1,), float(x.shape[0]), device=dev)
-            allb = torch.empty(world, device=dev)
-            if buckets is not None and buckets.comm is not None:
-                AF._state["bn_comm"].all_gather(allb, bs)
-            else:
-                dist.all_gather_into_tensor(allb, bs)
-            loss = loss * (world / allb.sum())  # lightning.py:88-90
-        loss.backward()
-        if buckets is not None:
-            buckets.finish()
-        opt.step()
-        if buckets is not None and not buckets.rebuilt and not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
-            for p in params:  # (after the first step: buckets in the order the gradients arrived -- ddp.GradBuckets.rebuild_by_arrival)
-                p.grad = None
-            buckets.rebuild_by_arrival()
-        return loss.detach(), loss_ctc.detach(), loss_att.detach(), hits, ntok
-
-    # hipGraph replay per batch shape (what bench.py times): single-rank runs, and data-parallel runs whose collectives are all
-    # stream operations on RCCL's C API (AVSR_DDP=buckets on GPUs); torch's DDP reducer cannot be captured
-    from .graph_step import StepGraphs
-
-    graph_ok = dev.type == "cuda" and not getattr(args, "no_graph", False) and \
-        (world == 1 or (buckets is not None and buckets.comm is not None))
-    def capture_failed(e):
-        # a capture that dies mid-backward leaves partial bucket counts, pending reductions and gradients that live in the dead
-        # graph's pool: reset all of it, or the eager retry never flushes those buckets and finish() raises on this rank while
-        # the others wait in a collective (round-5 advisor finding)
-        log(f"[rank {rank}] hipGraph capture failed ({type(e).__name__}: {str(e)[:160]}); eager from here on")
-        for p in params:
-            p.grad = None
-        if buckets is not None:
-            buckets.abort_step()
-
-    def released(key):  # a graph is gone: its pinned pointer tables go back to their owners
-        opt.release_captured(key)
-        if buckets is not None:
-            buckets.release_captured(key)
-
-    # capacity: the first AVSR_MAX_GRAPHS (default 512) shapes that show up twice are captured and kept for the run -- no
-    # eviction (graph_step.py); the optimizer's and the buckets' pre-pinned tables are sized for exactly that many captures
-    stepper = StepGraphs(full_step, enabled=graph_ok, capture_after=1, thread_local=world > 1, max_graphs=_max_graphs(),
-                         on_fail=capture_failed, on_evict=released)
-    held["stepper"] = stepper
     tail, t_tail = int(getattr(args, "time_last", 0) or 0), None
     if mode is not None:
         AF.set_mode(mode)
@@ -325,8 +376,9 @@ def _fit(model, args, dev, rank, world, backend, log, held):
         metrics = validate(model, val, world)
         if rank == 0 and metrics:
             log(f"epoch {epoch} validation: " + " ".join(f"{k} {v:.4f}" for k, v in metrics.items()))
+        opt_state = opt.state_dict() if (folder and getattr(opt, "collective_state", False)) else None  # (every rank: a collective)
         if rank == 0 and folder:
-            save_checkpoint(folder, epoch, model, opt, global_step)
+            save_checkpoint(folder, epoch, model, opt, global_step, opt_state=opt_state)
         if world > 1:
             dist.barrier()
         if done:

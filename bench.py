@@ -565,7 +565,15 @@ def main():
             out["config"]["bucket_overlap"] = rep
     if rank == 0 and not dp and not args.no_roofline:
         # (N > 1: an extra rank-0-only step would dead-lock the DDP / BatchNorm collectives; the kernels are the same)
-        out["roofline"], hbm = roofline(model, data[args.warmup], ops)
+        fwd, hbm, pair = roofline(model, data[args.warmup], ops)
+        # `roofline` = the dominant kernel family BY TIME of the replayed step: the paired backward launches when they outweigh the
+        # forward entry points (they do: ~4.0 vs ~3.1 ms); the other one is reported beside it
+        if pair is not None and pair["total_ms"] >= fwd.get("total_ms", 0.0):
+            out["roofline"], out["roofline_fwd"] = pair, fwd
+        else:
+            out["roofline"] = fwd
+            if pair is not None:
+                out["roofline_pair"] = pair
         if hbm is not None:
             out["roofline_hbm"] = hbm
     if rank == 0 and not dp and not args.no_parity and args.modality == "video":
@@ -710,6 +718,46 @@ def roofline(model, batch, ops):
             "event_bracketed_sum_ms": round(tot * 1e3, 3),  # (sum over launches INCLUDING ~3 us of event-pair overhead each: not kernel time)
             "share_of_kernel_time": round(t_ev / tot, 3),
             "families_ms": {k: round(v[0] * 1e3, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:8]}}
+    # The largest line of the step by time is not an entry point of its own: every Linear backward issues its data-gradient (NT)
+    # and weight-gradient (TN) contraction between avsr_gemm_pair_begin / _end and they leave as ONE launch (gemm_pair_kernel).
+    # Pairing is off while the per-launch hooks above are installed, so the pairs are recorded in a pass of their own (ops.PAIR_RECORD:
+    # the calls inside every paired block) and re-issued back to back as pairs.
+    ops.PAIR_RECORD = []
+    loss, *_ = model.forward_tensors(x, lens, y)
+    loss.backward()
+    torch.cuda.synchronize()
+    pairs, ops.PAIR_RECORD = ops.PAIR_RECORD, None
+    model.zero_grad(set_to_none=True)
+    pair = None
+    if pairs:
+        def replay_pairs(reps=3):
+            def once():
+                for blk in pairs:
+                    lib.call("avsr_gemm_pair_begin")
+                    for nm, a, _f, _b in blk:
+                        lib.call(nm, *a)
+                    lib.call("avsr_gemm_pair_end")
+            once()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                once()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e-3 / reps
+
+        tp = replay_pairs()
+        flp = sum(c[2] for blk in pairs for c in blk)
+        algp = sum(c[3] for blk in pairs for c in blk) / len(pairs)
+        traffic_p, src_p = counter_traffic(r"^gemm_pair_kernel")
+        achp = flp / tp / 1e12 if tp > 0 else 0.0
+        pair = {"bound": "mfma", "kernel": "gemm_pair_kernel (avsr_gemm_pair_begin / _end: the data-gradient NT tiles and the weight-gradient TN "
+                                           "tiles of one Linear backward in ONE grid)",
+                "launches": len(pairs), "avg_us": round(tp / len(pairs) * 1e6, 2), "total_ms": round(tp * 1e3, 3),
+                "achieved": round(achp, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achp / peak, 4), "traffic": traffic_p,
+                "traffic_unit": "HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, calibrated)", "traffic_source": src_p,
+                "algorithmic_bytes_per_launch": round(algp)}
+    main["total_ms"] = round(t * 1e3, 3)
     bn = [c for c in rec2 if c[0] in BN_FAMILY]
     hbm = None
     if bn:
@@ -723,7 +771,7 @@ def roofline(model, batch, ops):
                "traffic": traffic_b, "traffic_unit": "HBM-side bytes per KERNEL launch (an entry point may launch two)",
                "traffic_source": src_b,
                "share_of_kernel_time": round(sum(fam[k][0] for k in fam if k in BN_FAMILY) / tot, 3)}
-    return main, hbm
+    return main, hbm, pair
 
 
 if __name__ == "__main__":

@@ -367,6 +367,10 @@ int avsr_comm_all_reduce_f32(int slot, void* buf, int64_t count, avsr_stream_t s
 /* the same for dtype 0 = f32 / 1 = bf16 (narrow wire format of the gradient buckets: half the bytes per xGMI link) */
 int avsr_comm_all_reduce(int slot, void* buf, int64_t count, int dtype, avsr_stream_t stream);                          /* in place, sum */
 int avsr_comm_all_gather_f32(int slot, const void* send, void* recv, int64_t count_per_rank, avsr_stream_t stream); /* recv: nranks x count */
+/* recv[0 .. count_per_rank) = sum over ranks of send[rank * count_per_rank ..) (ncclReduceScatter; dtype 0 = f32, 1 = bf16; recv may
+ * alias its own slice of send): the gradient exchange of the sharded optimizer -- train.py:30-42 (DDP averaging) at half the wire bytes
+ * inside the backward pass, the other half being the all-gather of the updated weights */
+int avsr_comm_reduce_scatter(int slot, const void* send, void* recv, int64_t count_per_rank, int dtype, avsr_stream_t stream);
 /* Tuning knobs of the tuned kernels (process-wide; meant for benchmarks, defaults are the measured best):
  * knob 0 = tile code forced on avsr_conv2d_bf16 (0 = auto), 1 = XCD-aware tile order (0 = automatic: on for the 64x64 GEMM tile, whose
  * operands are not cache-resident in the training step; 1 = always on; 2 = always off),
@@ -383,7 +387,9 @@ int avsr_comm_all_gather_f32(int slot, const void* send, void* recv, int64_t cou
  * avsr_gemm_bf16_nt problems whose 64x64 grid has 257..512 tiles (0 = auto), 15 = block-count target of avsr_conv3x3_wgrad_bf16
  * (0 = one resident set: 512 blocks for the default variant, 256 for the others), 16 = variant of avsr_conv3x3_wgrad_bf16 (0 / 1 =
  * four thin waves, two blocks per CU; 2 = four fat waves in two k groups, one block per CU; 3 = eight thin waves in two k groups --
- * both measured slower, kept for A/B runs).  Knobs 0..23 exist. */
+ * both measured slower, kept for A/B runs), 17 / 18 = tile code forced on the two-plane f16 GEMM / convolution (avsr_gemm_h16_nt with
+ * B_lo, avsr_conv2d_h16 with wp_lo), 21 / 22 = tile code forced on avsr_conv2d_f32s(_stats) calls whose activation arrives in the
+ * split8 layout (Cout < 128 / Cout >= 128: 23 .. 30, see gemm_split.hip).  Knobs 0..23 exist. */
 int avsr_tune(int knob, int value);
 /* bf16 implicit-GEMM convolution on the tuned LDS-DMA kernel: dgrad = 0 forward, 1 data gradient (see
  * avsr_conv2d_fwd / avsr_conv2d_dgrad for the tensor conventions); gathered channel count % 64 == 0; stride 1 or 2
@@ -500,6 +506,14 @@ int avsr_beam_fetch_yseq(int64_t handle, int64_t* host_yseq, int* ldy_out, int* 
 int avsr_adamw_step(const void* table, int n, int total_blocks, float* partial, float* state, float base_lr, float beta1,
                     float beta2, float eps, float weight_decay, float max_grad_norm, int64_t warmup_steps,
                     int64_t total_steps, avsr_stream_t stream);
+/* The same step in two halves for an optimizer sharded over the data-parallel ranks (every rank updates 1 / N of every flat bucket;
+ * lightning.py:48-52, train.py:37,41): avsr_multi_sumsq leaves the sum of squares of THIS rank's gradient slices in sumsq[0]; the
+ * caller all-reduces that float; avsr_adamw_apply derives clip coefficient / step / learning rate from the global sum and runs
+ * AdamW on the table's slices.  Same table format and state as avsr_adamw_step. */
+int avsr_multi_sumsq(const void* table, int n, int total_blocks, float* partial, float* sumsq, avsr_stream_t stream);
+int avsr_adamw_apply(const void* table, int n, int total_blocks, const float* sumsq, float* state, float base_lr, float beta1,
+                     float beta2, float eps, float weight_decay, float max_grad_norm, int64_t warmup_steps, int64_t total_steps,
+                     avsr_stream_t stream);
 /* dst_i = scale * src_i for n f32 tensors in ONE launch: table entries as above with p = dst, g = src (m, v unused).  The
  * data-parallel gradient exchange gathers a bucket's gradients into its flat RCCL all-reduce buffer with it (train.py:37
  * DDPStrategy: gradient averaging = scale 1 / world). */

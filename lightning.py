@@ -67,6 +67,15 @@ class ModelModule(_Base):
         self.token_list = self.text_transform.token_list
         self.model = E2E(len(self.token_list), self.modality, ctc_weight=getattr(args, "ctc_weight", 0.1))
         load_pretrained(self.model, args)
+        # train.py --trainer-step native: Lightning's MANUAL optimisation -- training_step runs the whole step itself (forward,
+        # backward, data-parallel exchange, fused clip + AdamW + schedule) through auto_avsr_amd.train_native.NativeStepper, i.e.
+        # one replayed hipGraph per batch shape, the step bench.py times; the Trainer only feeds batches and runs its callbacks.
+        # Default ("auto"): Lightning's automatic optimisation as in the reference (eager launches, torch AdamW, Trainer-side
+        # clipping) -- measured 25.4 ms / step against 23.1 replayed in round 5.
+        self.native_step = getattr(args, "trainer_step", "auto") == "native"
+        self._native = None
+        if self.native_step:
+            self.automatic_optimization = False
 
     # ---- cross-rank BatchNorm (train.py:31 `sync_batchnorm=True`)
     def on_fit_start(self):
@@ -85,10 +94,24 @@ class ModelModule(_Base):
         # the native loop's (auto_avsr_amd.train_native): a Trainer drives backward / optimizer itself
         self._mode_before_fit = AF._save_mode()
         AF.set_mode(getattr(self.args, "numerics", None) or "mixed")
+        if getattr(self, "native_step", False):
+            from auto_avsr_amd.train_native import NativeStepper
+
+            tr = self.trainer
+            world = tr.num_devices * tr.num_nodes
+            dev = next(self.model.parameters()).device
+            n = steps_per_epoch(tr.datamodule.train_dataloader(), world)
+            self._native = NativeStepper(self.model, self.args, dev, getattr(tr, "global_rank", 0), world, n)
+            if getattr(self, "_native_opt_state", None) is not None:  # (a checkpoint loaded before the fit started)
+                self._native.opt.load_state_dict(self._native_opt_state)
+                self._native_opt_state = None
 
     def on_fit_end(self):
         from auto_avsr_amd import functional as AF
 
+        if getattr(self, "_native", None) is not None:
+            self._native.close()
+            self._native = None
         AF.set_bn_sync(None)
         if getattr(self, "_mode_before_fit", None) is not None:
             AF._restore_mode(self._mode_before_fit)
@@ -102,6 +125,8 @@ class ModelModule(_Base):
         return opt, sched
 
     def configure_optimizers(self):
+        if self.native_step:
+            return None  # manual optimisation: the fused optimizer lives inside the replayed step (on_fit_start); Lightning runs "with no optimizer"
         n = steps_per_epoch(self.trainer.datamodule.train_dataloader(), self.trainer.num_devices * self.trainer.num_nodes)
         opt, sched = self.make_optimizer(n)
         return [opt], [{"scheduler": sched, "interval": "step"}]
@@ -121,9 +146,34 @@ class ModelModule(_Base):
                 self.log("monitoring_step", torch.tensor(self.global_step, dtype=torch.float32))
         return loss
 
+    def on_save_checkpoint(self, checkpoint):
+        if self._native is not None:  # (Lightning saves no optimizer state under manual optimisation without optimizers)
+            checkpoint["native_optimizer"] = self._native.opt.state_dict()
+
+    def on_load_checkpoint(self, checkpoint):
+        sd = checkpoint.get("native_optimizer")
+        if sd is not None:
+            if self._native is not None:
+                self._native.opt.load_state_dict(sd)
+            else:
+                self._native_opt_state = sd
+
+    def _native_training_step(self, batch):
+        loss, loss_ctc, loss_att, hits, ntok = self._native(batch["inputs"], batch["input_lengths"], batch["targets"])
+        if HAVE_LIGHTNING:
+            bs = len(batch["inputs"])
+            self.log("loss", loss, on_step=True, on_epoch=True, batch_size=bs)
+            self.log("loss_ctc", loss_ctc, on_step=False, on_epoch=True, batch_size=bs, sync_dist=True)
+            self.log("loss_att", loss_att, on_step=False, on_epoch=True, batch_size=bs, sync_dist=True)
+            self.log("decoder_acc", hits / ntok.clamp_min(1), on_step=True, on_epoch=True, batch_size=bs, sync_dist=True)
+            self.log("monitoring_step", torch.tensor(self.global_step, dtype=torch.float32))
+        return loss
+
     def training_step(self, batch, batch_idx):
         from auto_avsr_amd import functional as AF
 
+        if self._native is not None:
+            return self._native_training_step(batch)
         AF.new_step()  # per-step registries of the kernels' autograd glue (zero-scratch arena, twin / hand-over tables)
         loss = self._step(batch, batch_idx, "train")
         if HAVE_LIGHTNING:

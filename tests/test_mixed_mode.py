@@ -180,7 +180,7 @@ def _planes(w):
     return hi, ((w - hi.float()) * 2048.0).half()
 
 
-@pytest.mark.parametrize("tile", [0, 1, 21, 7, 2, 4])
+@pytest.mark.parametrize("tile", [0, 1, 21, 7, 2, 4, 5, 8])
 @pytest.mark.parametrize("shape", [(150, 70, 192), (257, 300, 448), (130, 136, 64)])
 def test_gemm_h16x2_nt(dev, tile, shape, twins):
     """Two weight planes (round 5): products with the EXACT f32 weight up to ~2^-22, f16 activations.  Against float64 math on
@@ -217,7 +217,7 @@ def test_gemm_h16x2_nt(dev, tile, shape, twins):
 
 
 @pytest.mark.parametrize("geom", [(3, 11, 11, 64, 128, 3, 2), (2, 6, 6, 128, 128, 3, 1), (3, 11, 11, 64, 128, 1, 2), (2, 22, 22, 64, 64, 3, 1)])
-@pytest.mark.parametrize("tile", [0, 4])
+@pytest.mark.parametrize("tile", [0, 4, 5])
 def test_conv2d_h16x2(dev, geom, tile, twins):
     """Implicit-GEMM convolution with two filter planes: exact filter, f16 activations (float64 math on the same data)."""
     N, H, W, Cin, Cout, KH, stride = geom
@@ -317,7 +317,7 @@ def test_split8_activations(dev, twins):
     split-plane convolution stages it without its in-LDS conversion pass -- bit-identical to the conversion it replaces -- and
     the cast kernel reads it back (component boundaries)."""
     torch.manual_seed(3)
-    N, H, W, C, Cout = 3, 11, 11, 64, 128
+    N, H, W, C, Cout = 8, 11, 11, 64, 128  # (8 x 6 x 6 = 288 output rows: three 128-row tiles, two 256-row tiles)
     rows = N * H * W
     c = torch.randn(rows, C)
     res = torch.randn(rows, C)
@@ -355,6 +355,23 @@ def test_split8_activations(dev, twins):
     assert torch.equal(y_pre.cpu(), y_pre2.cpu())
     ref = torch.nn.functional.conv2d(back.view(N, H, W, C).double().permute(0, 3, 1, 2), w.double(), stride=2, padding=1).permute(0, 2, 3, 1)
     assert rel(y_pre, ref) < 3e-5
+    # round 6: the 256-row tiles on 8 waves (knobs 21 / 22) give the same convolution, and their statistics rows -- half as many,
+    # the tail of the caller's 128-row-sized buffer zeroed by the kernel -- fold to the same sums
+    want_sum = y_pre.double().sum(dim=(0, 1, 2)).cpu()
+    want_sq = (y_pre.double() ** 2).sum(dim=(0, 1, 2)).cpu()
+    for knob, tiles in ((22, (29, 30)), (21, (27, 28))):
+        Co = Cout if knob == 22 else 64
+        wq = ops.conv_weight_permute_split(w[:Co].to(dev).contiguous())
+        for t in tiles:
+            ops.tune(knob, t)
+            try:
+                st2 = torch.full((ops.bn_stat_tiles(N * 6 * 6), 2, Co), float("nan"), device=dev)
+                y_t = ops.conv2d_fwd(a.view(N, H, W, C), wq, N, H, W, C, Co, 3, 3, 2, 1, 1, True, stats=st2)
+            finally:
+                ops.tune(knob, 0)
+            assert rel(y_t, y_pre[..., :Co]) < 1e-6, t
+            got = st2.double().sum(0).cpu()
+            assert torch.allclose(got[0], want_sum[:Co], rtol=1e-5, atol=1e-4) and torch.allclose(got[1], want_sq[:Co], rtol=1e-5, atol=1e-4), t
     # a consumer that cannot read the layout fails loudly
     with pytest.raises(TypeError):
         ops.bn_stats(a, rows, C)

@@ -1,4 +1,4 @@
-"""GPU ablation (round 5): the split-plane convolution of ResNet stages 1 - 2 with the A tile converted to split8 in LDS (tiles 13 /
+"""GPU ablation (round 5; round 6: tiles 27 - 30 = 256-row tiles on 8 waves): the split-plane convolution of ResNet stages 1 - 2 with the A tile converted to split8 in LDS (tiles 13 /
 14: what the mixed mode runs) against the same kernel on an A operand that ARRIVES pre-split (tiles 23 - 26: no conversion pass,
 one barrier per k-tile).  Timing only (the f32 input is read as if it were split8).  -> gpurun_out/microbench_presplit.json"""
 import json
@@ -38,7 +38,7 @@ for name, H, W, Cin, Cout, K, s, p in [("l1", 22, 22, 64, 64, 3, 1, 1), ("l2a", 
     y2 = torch.empty(N, OH, OH, Cout, device=dev, dtype=torch.bfloat16)
     st = torch.empty(ops.bn_stat_tiles(N * OH * OH), 2, Cout, device=dev)
     res = {}
-    for tile in ((13, 23, 25) if Cout < 128 else (14, 24, 26, 13, 23)):
+    for tile in ((13, 23, 25, 27, 28) if Cout < 128 else (14, 24, 26, 13, 23, 27, 29, 30)):
         def f(i, tile=tile):
             ops.call("avsr_conv2d_f32s_stats", ops._ptr(xs[i % 3]), ops._ptr(wp), ops._ptr(y), ops._ptr(ops.zero_page(dev)), N, H, W, Cin,
                      Cout, K, K, s, p, p, tile, 1, ops._ptr(y2), ops._ptr(st), st.shape[0], ops._stream(y))

@@ -40,6 +40,10 @@ def parse_args(argv=None):
                    help="numerical mode of the hot path (auto_avsr_amd.functional.set_mode); default: the mode bench.py times, "
                         "the cheapest one whose logits stay within 1e-3 of the fp32 reference")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of one replayed hipGraph per batch shape")
+    p.add_argument("--trainer-step", default="auto", choices=["auto", "native"],
+                   help="under a pytorch_lightning Trainer: auto = Lightning's automatic optimisation as in the reference (eager "
+                        "launches, torch AdamW); native = manual optimisation, training_step replays the whole fused step as one "
+                        "hipGraph per batch shape (auto_avsr_amd.train_native.NativeStepper: what bench.py times)")
     p.add_argument("--grad-wire", default=None, choices=["f32", "bf16"],
                    help="format of the gradient buckets on the xGMI links (AVSR_DDP=buckets): f32 = the reference's DDP all-reduce "
                         "(default), bf16 = half the bytes per link, bf16 sums across the ranks")
@@ -60,7 +64,9 @@ def get_trainer(args):
                    num_nodes=args.num_nodes, devices=args.gpus, accelerator="gpu",
                    strategy=DDPStrategy(find_unused_parameters=False),
                    callbacks=[ckpt, LearningRateMonitor(logging_interval="step")],
-                   reload_dataloaders_every_n_epochs=1, gradient_clip_val=10.0)
+                   reload_dataloaders_every_n_epochs=1,
+                   # (manual optimisation: Lightning refuses gradient_clip_val; the fused step clips at 10 itself)
+                   gradient_clip_val=None if getattr(args, "trainer_step", "auto") == "native" else 10.0)
 
 
 def cli_main(argv=None):
