@@ -31,6 +31,7 @@ struct KvParams {
     int lds, ldo, ldq, ldk, ldv, ldpos;
     long sbo, sbq, sbk, sbv;
     int B, H, Tq, Tk, skip;
+    int det;  // deterministic mode: the position term of head h is formed by the blocks of batch item 0, which walk every batch item
 };
 
 
@@ -52,6 +53,9 @@ AVSR_DEV void kv_block(const KvParams& p, char* smem) {
     const int b = blockIdx.y / p.H, h = blockIdx.y - b * p.H;
     const int M = which < 2 ? p.Tk : 2 * p.Tq - 1, K = p.Tq;
     if (m0 >= M) return;
+    // (deterministic mode, which == 2: ONE block per (head, band tile) adds to dpos -- it contracts all batch items, in order)
+    const int nb = (which == 2 && p.det) ? p.B : 1;
+    if (which == 2 && p.det && b != 0) return;
     int t_lo = 0, nt = (K + 63) / 64;
     if (which == 2) {
         // band rows m0 .. m0+63 only meet queries q with a key index j = m + q - (Tq-1) in [0, Tk): skip the k-tiles outside
@@ -66,6 +70,7 @@ AVSR_DEV void kv_block(const KvParams& p, char* smem) {
 
     const int kr0 = threadIdx.x >> 3, chunk = (threadIdx.x & 7) * 8;  // this thread's two k-rows (kr0, kr0 + 32), 8 columns
     bf16x8 ra[2], rb[2];
+    int bcur = b;  // batch item of the tile being fetched (which == 2 in deterministic mode: 0 .. B-1)
     auto fetch = [&](int t) {
 #pragma unroll
         for (int i = 0; i < 2; i++) {
@@ -76,7 +81,7 @@ AVSR_DEV void kv_block(const KvParams& p, char* smem) {
                 if (m0 + chunk < p.lds) ra[i] = *reinterpret_cast<const bf16x8*>(Abase + (long)k * p.lds + m0 + chunk);
                 rb[i] = *reinterpret_cast<const bf16x8*>(Bbase + (long)k * ldb + chunk);
             } else {
-                const int bb = b, q = k;
+                const int bb = bcur, q = k;
                 const bf16_t* row = p.ds + (((long)bb * p.H + h) * p.Tq + q) * p.lds;
                 const int j = m0 + chunk + q - (p.Tq - 1);  // key index of band column m0 + chunk for this query
                 const int jb = j & ~1;  // even element index: a 4-byte-aligned address (rows start 16-byte aligned)
@@ -125,16 +130,22 @@ AVSR_DEV void kv_block(const KvParams& p, char* smem) {
     f32x16 acc[1][1];
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[0][0][r] = 0.f;
-    fetch(t_lo);
-    commit(smem + (t_lo & 1) * KV_STAGE_BYTES);
+    // flat iteration over (batch item, k-tile): it -> (bb0 + it / span, t_lo + it % span); one batch item unless deterministic
+    const int span = nt - t_lo, n_it = nb * span;
+    auto fetch_it = [&](int it) {
+        bcur = (nb > 1 ? it / span : b);
+        fetch(t_lo + it % span);
+    };
+    fetch_it(0);
+    commit(smem);
     __syncthreads();
-    for (int t = t_lo; t < nt; t++) {
-        const char* As = smem + (t & 1) * KV_STAGE_BYTES;
+    for (int it = 0; it < n_it; it++) {
+        const char* As = smem + (it & 1) * KV_STAGE_BYTES;
         const char* Bs = As + KV_OP_BYTES;
-        if (t + 1 < nt) fetch(t + 1);  // in flight during the multiply
+        if (it + 1 < n_it) fetch_it(it + 1);  // in flight during the multiply
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) acc[0][0] = mfma32(frag(As, wm * 32, ks), frag(Bs, wn * 32, ks), acc[0][0]);
-        if (t + 1 < nt) commit(smem + ((t + 1) & 1) * KV_STAGE_BYTES);
+        if (it + 1 < n_it) commit(smem + ((it + 1) & 1) * KV_STAGE_BYTES);
         __syncthreads();
     }
 
@@ -169,6 +180,7 @@ int avsr_attention_bwd_kv_fast(const void* pd, const void* ds, int lds, const vo
     p.lds = lds; p.ldo = ldo; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldpos = ldpos;
     p.sbo = sbo; p.sbq = sbq; p.sbk = sbk; p.sbv = sbv;
     p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk; p.skip = avsr_tune_knobs[11];
+    p.det = avsr_det() ? 1 : 0;
     const int mt_kv = (Tk + 63) / 64, mt_pos = dpos ? (2 * Tq - 1 + 63) / 64 : 0;
     dim3 grid(mt_kv > mt_pos ? mt_kv : mt_pos, B * H, dpos ? 3 : 2), block(256);
     AVSR_LAUNCH(attn_bwd_kv_fast_kernel, grid, block, KV_LDS_BYTES, stream, p);

@@ -235,6 +235,7 @@ extern "C" int avsr_dwconv_wgrad(const void* x, const void* dy, int dtype, float
     int chunks = (512 + cblocks - 1) / cblocks;  // about two blocks per CU
     if (chunks > items) chunks = items;
     if (chunks > 8) chunks = 8;
+    if (avsr_det()) chunks = 1;  // deterministic mode: one block per channel group walks every (utterance, tile) item in order
     dim3 grid(cblocks, chunks), block(256);
     if (dtype == 0)
         AVSR_LAUNCH((dwconv_wgrad_kernel<float>), grid, block, 0, stream, (const float*)x, (const float*)dy, dw, db, B, T, C, K,

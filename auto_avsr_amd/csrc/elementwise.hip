@@ -244,13 +244,71 @@ extern "C" int avsr_head_bias_fwd_h16(const void* x, int64_t ldx, const float* b
 
 // dq[r, :] (row stride ldo) = d1 + d2 (d2 may be NULL; dq may be NULL); db1 += colsum(d1); db2 += colsum(d2).
 // With d2 = dq = db2 = NULL this is the plain bias-gradient column sum.
+namespace {
+// deterministic column sums: thread = (8-column chunk, row lane); 32 chunks x 8 row lanes per block; fixed summation order
+template <class T>
+__global__ __launch_bounds__(256) void colsum_det_kernel(const T* __restrict__ src, long ld, long rows, int cols, float* __restrict__ out) {
+    __shared__ float red[256 * 8];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c0 = (blockIdx.x * 32 + cl) * 8;
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) s[e] = 0.f;
+    if (c0 < cols) {
+        const bool vec = c0 + 8 <= cols && (ld % 8 == 0);
+        for (long r = rl; r < rows; r += 8) {
+            float v[8];
+            if (vec) load8(src + r * ld + c0, v);
+            else
+                for (int e = 0; e < 8; e++) v[e] = c0 + e < cols ? Elem<T>::ld(src + r * ld + c0 + e) : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) s[e] += v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) red[threadIdx.x * 8 + e] = s[e];
+    __syncthreads();
+    if (rl == 0 && c0 < cols) {
+        for (int q = 1; q < 8; q++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) s[e] += red[(q * 32 + cl) * 8 + e];
+        for (int e = 0; e < 8 && c0 + e < cols; e++) out[c0 + e] += s[e];
+    }
+}
+// deterministic row sums of a bf16 matrix: one wave per row, lanes stride the columns, butterfly in a fixed order
+__global__ __launch_bounds__(256) void rowsum_det_kernel(const bf16_t* __restrict__ src, long ld, long rows, long cols, float* __restrict__ out) {
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    float s = 0.f;
+    for (long c = lane; c < cols; c += 64) s += bf2f(src[r * ld + c]);
+    s = wave_sum(s);
+    if (lane == 0) out[r] += s;
+}
+}  // namespace
+
+int avsr_colsum_det(const void* src, int dtype, long ld, long rows, int cols, float* out, hipStream_t stream) {
+    if (rows <= 0 || cols <= 0) return 0;
+    dim3 grid((cols + 255) / 256), block(256);
+    if (dtype == 0) AVSR_LAUNCH((colsum_det_kernel<float>), grid, block, 0, stream, (const float*)src, ld, rows, cols, out);
+    else if (dtype == 1) AVSR_LAUNCH((colsum_det_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)src, ld, rows, cols, out);
+    else AVSR_LAUNCH((colsum_det_kernel<f16_t>), grid, block, 0, stream, (const f16_t*)src, ld, rows, cols, out);
+    return 0;
+}
+int avsr_rowsum_det_bf16(const void* src, long ld, long rows, long cols, float* out, hipStream_t stream) {
+    if (rows <= 0 || cols <= 0) return 0;
+    AVSR_LAUNCH(rowsum_det_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)src, ld, rows, cols, out);
+    return 0;
+}
+
 extern "C" int avsr_head_bias_bwd(const void* d1, const void* d2, int dtype, void* dq, int64_t ldo, float* db1,
                                   float* db2, int64_t rows, int cols, hipStream_t stream) {
     AVSR_REQUIRE(cols % 8 == 0 && (dq == nullptr || ldo % 8 == 0), "head_bias_bwd: cols/ldo must be multiples of 8");
     if (rows <= 0) return 0;
     const int cv = cols >> 3;
     const int CL = cv >= 32 ? 32 : (cv >= 16 ? 16 : 8);
-    const int rpb = 8 * (EW_THREADS / CL);  // 8 rows per thread
+    // deterministic mode: ONE block per column group walks all rows (a single writer per bias-gradient element)
+    const int rpb = avsr_det() ? (int)rows : 8 * (EW_THREADS / CL);  // 8 rows per thread
     dim3 grid((cv + CL - 1) / CL, (unsigned)((rows + rpb - 1) / rpb)), block(EW_THREADS);
     if (dtype == 0)
         AVSR_LAUNCH((head_bias_bwd_kernel<float>), grid, block, 0, stream, (const float*)d1, (const float*)d2,

@@ -48,6 +48,7 @@ extern "C" int avsr_gemm(int layout, const void* A, int a_dtype, int lda, const 
     p.sAb = p.sAh = p.sBb = p.sBh = p.sCb = p.sCh = 0;
     p.a_skew = 0; p.skew_off = 0; p.skew_lim = 0;
     int rc;
+    if (avsr_det()) split_k = 1;  // deterministic mode: one block per output element
     if (layout == 0) rc = avsr_gemm_impl::run_nt(p, a_dtype, b_dtype, precise, force_tile, split_k, stream);
     else if (layout == 1) rc = avsr_gemm_impl::run_nn(p, a_dtype, b_dtype, precise, force_tile, split_k, stream);
     else rc = avsr_gemm_impl::run_tn(p, a_dtype, b_dtype, precise, force_tile, split_k, stream);

@@ -660,7 +660,7 @@ int launch(const Params& p0, int force_tile, int split_k, hipStream_t stream) {
     const long big_tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     const bool big = force_tile == 128 || (force_tile == 0 && big_tiles >= 192);
     const int BMN = big ? 128 : 64;
-    if (split_k < 1) split_k = 1;
+    if (split_k < 1 || avsr_det()) split_k = 1;  // (deterministic mode: one block per output element, prims.h)
     int kc = (p.K + split_k - 1) / split_k;
     kc = ((kc + BK - 1) / BK) * BK;
     split_k = (p.K + kc - 1) / kc;

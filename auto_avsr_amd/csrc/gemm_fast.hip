@@ -128,6 +128,14 @@ bool launch_tile_h16x2(int tile, Params& p, int split_k, hipStream_t stream) {
         case 8: launch_fast<256, 64, 2, CV, 4, 2, 0, 1, 1, 2>(p, split_k, stream); return true;
         case 22: launch_fast<128, 128, 2, CV, 2, 4, 0, 1, 1, 2>(p, split_k, stream); return true;
         case 23: launch_fast<256, 64, 3, CV, 4, 2, 0, 1, 1, 2>(p, split_k, stream); return true;
+        // ablations of the three default two-plane GEMM tiles (benchmarks only, wrong results): 31 / 33 / 35 = operand stream only (no
+        // LDS reads, no MFMA) of the 64x64 / 128x64 / 256x128 tile, 32 / 34 / 36 = LDS reads + MFMA only (no operand loads after the prologue)
+        case 31: if (CV == 0) { launch_fast<64, 64, 3, 0, 2, 2, 1, 1, 1, 2>(p, split_k, stream); return true; } return false;
+        case 32: if (CV == 0) { launch_fast<64, 64, 3, 0, 2, 2, 2, 1, 1, 2>(p, split_k, stream); return true; } return false;
+        case 33: if (CV == 0) { launch_fast<128, 64, 2, 0, 2, 2, 1, 1, 1, 2>(p, split_k, stream); return true; } return false;
+        case 34: if (CV == 0) { launch_fast<128, 64, 2, 0, 2, 2, 2, 1, 1, 2>(p, split_k, stream); return true; } return false;
+        case 35: if (CV == 0) { launch_fast<256, 128, 2, 0, 4, 2, 1, 1, 1, 2>(p, split_k, stream); return true; } return false;
+        case 36: if (CV == 0) { launch_fast<256, 128, 2, 0, 4, 2, 2, 1, 1, 2>(p, split_k, stream); return true; } return false;
         default: return false;
     }
 }
@@ -164,6 +172,17 @@ static int gemm16_nt_impl(int f16, const void* A, int lda, const void* B, const 
     p.C2 = c2; p.ldc2 = ldc2;
     p.nsplit = 1; p.batch_h = 1; p.nbatch = 1;
     if (split_k < 1) split_k = 1;
+    // deterministic mode (prims.h avsr_det): no k split (an accumulating output then has ONE block adding to each element), no
+    // pairing, and the bias-gradient column sums from an ordered pass over the stored result instead of per-tile atomics
+    float* colsum_det = nullptr;
+    if (avsr_det()) {
+        split_k = 1;
+        if (colsum) {
+            AVSR_REQUIRE(ldc == N, "gemm_*_nt (deterministic mode): colsum needs a dense output");
+            colsum_det = colsum;
+            p.colsum = nullptr;
+        }
+    }
     const bool auto_tile = tile == 0;
     if (tile == 0) {
         const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
@@ -188,17 +207,20 @@ static int gemm16_nt_impl(int f16, const void* A, int lda, const void* B, const 
             tile = g_tune[17] > 0 ? g_tune[17] : (t256 >= 160 && g_tune[17] == 0 ? 5 : (t12864 >= 256 ? 7 : (K >= 2048 && t12864 >= 128 ? 2 : 1)));
         }
         AVSR_REQUIRE(launch_tile_h16x2<0>(tile, p, split_k, stream), "gemm_h16_nt: unknown tile code (two weight planes)");
+        if (colsum_det) avsr_colsum_det(C, c_dtype, ldc, M, N, colsum_det, stream);
         AVSR_CHECK_LAUNCH("gemm_h16_nt");
         return 0;
     }
     if (f16) {
         if (tile != 1 && tile != 4 && tile != 7) tile = 1;
         AVSR_REQUIRE(launch_tile_h16<0>(tile, p, split_k, stream), "gemm_h16_nt: unknown tile code");
+        if (colsum_det) avsr_colsum_det(C, c_dtype, ldc, M, N, colsum_det, stream);
         AVSR_CHECK_LAUNCH("gemm_h16_nt");
         return 0;
     }
-    if (avsr_pair::stash_nt(p, tile, split_k, stream)) return 0;  // launched by avsr_gemm_pair_end (gemm_pair.hip)
+    if (!avsr_det() && avsr_pair::stash_nt(p, tile, split_k, stream)) return 0;  // launched by avsr_gemm_pair_end (gemm_pair.hip)
     AVSR_REQUIRE(launch_tile<0>(tile, p, split_k, stream), "gemm_bf16_nt: unknown tile code");
+    if (colsum_det) avsr_colsum_det(C, c_dtype, ldc, M, N, colsum_det, stream);
     AVSR_CHECK_LAUNCH("gemm_bf16_nt");
     return 0;
 }
@@ -442,12 +464,23 @@ extern "C" int avsr_cast_transpose_colsum(const void* src, int src_dtype, int64_
     if (R <= 0 || C <= 0) return 0;
     const long rows_cover = dstT ? ld_dstT : R;
     dim3 grid((C + 63) / 64, (unsigned)((rows_cover + 63) / 64)), block(256);
+    // deterministic mode: the column sums of the bf16-rounded values from an ordered pass over the copy just written
+    float* colsum_det = nullptr;
+    if (avsr_det() && colsum) {
+        AVSR_REQUIRE(dst != nullptr || dstT != nullptr, "cast_transpose_colsum (deterministic mode): colsum needs one of the copies");
+        colsum_det = colsum;
+        colsum = nullptr;
+    }
     if (src_dtype == 0)
         AVSR_LAUNCH((transpose_cast_kernel<float>), grid, block, 0, stream, (const float*)src, (long)ld_src, (bf16_t*)dst, (bf16_t*)dstT,
                     (long)ld_dstT, colsum, R, C, alpha, alpha_dev, drop_p, seed, seed_dev);
     else
         AVSR_LAUNCH((transpose_cast_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)src, (long)ld_src, (bf16_t*)dst, (bf16_t*)dstT,
                     (long)ld_dstT, colsum, R, C, alpha, alpha_dev, drop_p, seed, seed_dev);
+    if (colsum_det) {
+        if (dst) avsr_colsum_det(dst, 1, C, R, C, colsum_det, stream);
+        else avsr_rowsum_det_bf16(dstT, ld_dstT, C, R, colsum_det, stream);
+    }
     AVSR_CHECK_LAUNCH("cast_transpose_colsum");
     return 0;
 }

@@ -392,6 +392,15 @@ extern "C" int avsr_gemm_f32s_nt(const float* A, int lda, const float* B, int ld
     p.C2 = c2; p.ldc2 = ldc2;
     p.nsplit = 1; p.batch_h = 1; p.nbatch = 1;
     if (split_k < 1) split_k = 1;
+    float* colsum_det = nullptr;  // deterministic mode: as avsr_gemm_bf16_nt
+    if (avsr_det()) {
+        split_k = 1;
+        if (colsum) {
+            AVSR_REQUIRE(ldc == N, "gemm_f32s_nt (deterministic mode): colsum needs a dense output");
+            colsum_det = colsum;
+            p.colsum = nullptr;
+        }
+    }
     if (tile == 0) {
         const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
         const long t12864 = (long)((M + 127) / 128) * ((N + 63) / 64);
@@ -399,6 +408,7 @@ extern "C" int avsr_gemm_f32s_nt(const float* A, int lda, const float* B, int ld
     }
     const bool ok = b_split ? launch_tile<0, true>(tile, p, split_k, stream) : launch_tile<0, false>(tile, p, split_k, stream);
     AVSR_REQUIRE(ok, "gemm_f32s_nt: unknown tile code");
+    if (colsum_det) avsr_colsum_det(C, c_dtype, ldc, M, N, colsum_det, stream);
     AVSR_CHECK_LAUNCH("gemm_f32s_nt");
     return 0;
 }

@@ -50,6 +50,15 @@ extern "C" int avsr_gemm_bf16_tn(const void* A, int lda, const void* B, int ldb,
     p.C = C; p.c_dtype = 0; p.ldc = ldc; p.accumulate = accumulate;
     p.colsum_a = colsum_a;
     p.nsplit = 1; p.batch_h = 1; p.nbatch = 1;
+    if (avsr_det()) {
+        // deterministic mode: one block per weight-gradient tile walks all of K in order (no k split, no pairing); the bias gradient
+        // from an ordered column-sum pass over A
+        p.colsum_a = nullptr;
+        launch_tn<0>(p, 1, stream);
+        if (colsum_a) avsr_colsum_det(A, 1, lda, K, M, colsum_a, stream);
+        AVSR_CHECK_LAUNCH("gemm_bf16_tn");
+        return 0;
+    }
     if (avsr_pair::stash_tn(p, split_k, stream)) return 0;  // launched by avsr_gemm_pair_end (gemm_pair.hip)
     launch_tn<0>(p, split_k, stream);
     AVSR_CHECK_LAUNCH("gemm_bf16_tn");
@@ -75,7 +84,7 @@ extern "C" int avsr_conv2d_wgrad_bf16(const void* dy, const void* x, float* dwp,
     const long tiles = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
     long split = 1024 / (tiles < 1 ? 1 : tiles);
     if (split > p.K / 512) split = p.K / 512;
-    if (split < 1) split = 1;
+    if (split < 1 || avsr_det()) split = 1;
     launch_tn<3>(p, (int)split, stream);
     AVSR_CHECK_LAUNCH("conv2d_wgrad_bf16");
     return 0;

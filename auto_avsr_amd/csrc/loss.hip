@@ -244,13 +244,21 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
         for (int v = threadIdx.x; v < V; v += 256) Elem<T>::st(g + v, 0.f);
         return;
     }
+    // occupancy per extended state into LDS, then summed per label in a FIXED order (round 6: LDS float atomics from the states
+    // that share a label -- every blank, repeated characters -- committed in a run-dependent order): thread 0 adds the blank
+    // states (even s), thread 64 the label states (odd s), each walking its states in sequence; S <= 2 L + 1 is ~130
+    float* val = occ + V;  // [Smax]
     for (int v = threadIdx.x; v < V; v += 256) occ[v] = 0.f;
-    __syncthreads();
     const int S = 2 * lens[b] + 1;
     for (int s = threadIdx.x; s < S; s += 256) {
         const long o = bt * Smax + s;
         const float lo = alpha[o] + beta[o] - lpg[o] + nl;  // log occupancy of state s at time t
-        if (lo > -80.f) atomicAdd(&occ[ext[(long)b * Smax + s]], avsr_exp(lo));
+        val[s] = lo > -80.f ? avsr_exp(lo) : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 || threadIdx.x == 64) {
+        const int* e = ext + (long)b * Smax;
+        for (int s = threadIdx.x ? 1 : 0; s < S; s += 2) occ[e[s]] += val[s];
     }
     __syncthreads();
     const float l = lse[bt];
@@ -423,11 +431,23 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
                                                         float p, uint64_t seed0, const uint64_t* seed_dev) {
     const uint64_t seed = seed0 + (seed_dev ? *seed_dev : 0ull);
     const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    // rows that carry the same token add into the same table row: the FIRST such row sums all of them in row order and is the only
+    // writer (round 6: was one float atomic per element, committed in a run-dependent order); rows is a few hundred
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * D; i += (long)gridDim.x * 256) {
         const long r = i / D;
         const int c = (int)(i % D);
-        const float g = dout[i] * scale * dropout_scale(seed, (uint64_t)i, p, inv_keep);
-        atomicAdd(dtable + ids[r] * D + c, g);
+        const int64_t id = ids[r];
+        bool first = true;
+        for (long q = 0; q < r; q++)
+            if (ids[q] == id) {
+                first = false;
+                break;
+            }
+        if (!first) continue;
+        float g = 0.f;
+        for (long q = r; q < rows; q++)
+            if (ids[q] == id) g += dout[q * D + c] * scale * dropout_scale(seed, (uint64_t)(q * D + c), p, inv_keep);
+        dtable[id * D + c] += g;
     }
 }
 
@@ -482,7 +502,7 @@ extern "C" int avsr_ctc_loss(const void* logits, int dtype, int64_t ld, const in
 #undef AVSR_CTC_AB
     }
     if (grad) {
-        const size_t sm = (size_t)V * sizeof(float);
+        const size_t sm = ((size_t)V + Smax) * sizeof(float);  // label occupancies + per-state values
         if (dtype == 0)
             AVSR_LAUNCH((ctc_grad_kernel<float>), dim3(B * T), dim3(256), sm, stream, (const float*)logits, (long)ld, lse, lpg, alpha, beta,
                         nll, ext, lens, in_lens, (float*)grad, (long)ldg, T, V, Smax);

@@ -295,11 +295,18 @@ extern "C" int avsr_layernorm_bwd(const void* dy, int dy_dtype, const float* x, 
     AVSR_REQUIRE(gsum == nullptr || gout != nullptr, "layernorm_bwd: gsum needs gout");
     if (rows == 0) return 0;
     // with a column-sum output two rows per wave once the grid fills the chip anyway: half the atomics per launch
+    // deterministic mode: one parameter-gradient block per column group (all rows, fixed order), and the column sums of gout from an
+    // ordered pass over the stored values instead of one atomic per block and column
+    float* gsum_det = nullptr;
+    if (avsr_det() && gsum) {
+        gsum_det = gsum;
+        gsum = nullptr;
+    }
     const int rpw = (gsum && rows > 1024) ? 2 : 1;
     const int ndx = (rows + LN_WAVES * rpw - 1) / (LN_WAVES * rpw);
     const int cv = cols >> 3;
     const int CL = cv >= 32 ? 32 : (cv >= 16 ? 16 : 8);
-    const int rpb = 8 * (LN_THREADS / CL);  // 64 rows per block; 32 was measured slower (more colliding atomics per column)
+    const int rpb = avsr_det() ? rows : 8 * (LN_THREADS / CL);  // 64 rows per block; 32 was measured slower (more colliding atomics per column)
     const int npx = (cv + CL - 1) / CL, npy = (rows + rpb - 1) / rpb;
     dim3 grid(npx * npy + ndx), block(LN_THREADS);
     size_t lds = (size_t)LN_THREADS * 16 * sizeof(float);
@@ -310,6 +317,7 @@ extern "C" int avsr_layernorm_bwd(const void* dy, int dy_dtype, const float* x, 
     else
         AVSR_LAUNCH((layernorm_bwd_kernel<bf16_t>), grid, block, lds, stream, (const bf16_t*)dy, x, gamma, mean, rstd, dres,
                     dx, dgamma, dbeta, (bf16_t*)gout, gsum, alpha, drop_p, seed, seed_dev, rows, cols, rpb, CL, npx, npy, rpw);
+    if (gsum_det) avsr_colsum_det(gout, 1, cols, rows, cols, gsum_det, stream);
     AVSR_CHECK_LAUNCH("layernorm_bwd");
     return 0;
 }

@@ -534,6 +534,16 @@ AVSR_DEV float dropout_scale(uint64_t seed, uint64_t idx, float p, float inv_kee
 
 // ---------------------------------------------------------------- status plumbing
 extern int avsr_tune_knobs[24];  // common.hip (avsr_tune)
+// Deterministic mode (avsr_tune knob 23 = 1; AVSR_DETERMINISTIC=1 / train.py --deterministic, round 6): every sum that the default
+// build forms with floating-point atomics from SEVERAL blocks -- split-K weight gradients, bias / LayerNorm / depthwise parameter
+// gradients, the position-projection gradient -- is formed by ONE block per output element in a fixed order instead (grid
+// policies of the entry points: no k split, one block per column group) or by an ordered column-sum pass over the stored
+// values (avsr_colsum_det); DESIGN.md lists the sites.  Two runs then give bit-identical losses and weights; it costs speed.
+inline bool avsr_det() { return avsr_tune_knobs[23] != 0; }
+// out[c] += sum_r src[r * ld + c] for c < cols, in a fixed order (one block per 256 columns): src f32 / bf16 / f16 (dtype 0 / 1 / 2)
+int avsr_colsum_det(const void* src, int dtype, long ld, long rows, int cols, float* out, hipStream_t stream);
+// out[r] += sum_c src[r * ld + c] for r < rows (bf16 source), fixed order
+int avsr_rowsum_det_bf16(const void* src, long ld, long rows, long cols, float* out, hipStream_t stream);
 extern "C" void avsr_set_error(const char* msg);
 extern "C" void avsr_set_error2(const char* where, const char* what);
 #define AVSR_CHECK_LAUNCH(name)                                                   \

@@ -84,6 +84,23 @@ def mode() -> str:
     return "mixed" if _state["mixed"] else ("hpf" if _state["hpf"] else ("precise" if _state["precise"] else "bf16"))
 
 
+def set_deterministic(on: bool):
+    """Deterministic mode (round 6; `AVSR_DETERMINISTIC=1`, `train.py --deterministic`, `bench.py --deterministic`): the reference
+    seeds everything (train.py:18 `seed_everything(42)`) and its CPU path is reproducible; the default build of the hot path is not
+    bit-reproducible, because several parameter-gradient sums are formed with floating-point atomics from many blocks (DESIGN.md
+    section 4 names the sites).  With the switch on, the library forms every such sum in a fixed order (csrc/prims.h avsr_det: no k
+    split, one block per column group, ordered column-sum passes; paired launches off) and the attention backward leaves dqu / dqv to
+    an ordered pass instead of adding the position-bias gradients block by block: two runs of the same steps give bit-identical
+    losses and weights.  It costs speed (tests/test_deterministic.py prints the ratio); a graph captured in one setting must not be
+    replayed in the other (StepGraphs.reset())."""
+    _state["det"] = bool(on)
+    ops.tune(23, 1 if on else 0)
+
+
+def deterministic() -> bool:
+    return bool(_state.get("det", False))
+
+
 @contextlib.contextmanager
 def component(name):
     """Scope of one model component (nets.py / frontend.py wrap their forward passes in it): in the "mixed" mode the forward

@@ -357,10 +357,15 @@ class MhaSublayerFn(torch.autograd.Function):
             dq = dqkv if fused else torch.empty(B * Tq, D, dtype=T, device=x.device)
             du = _zeros(D, x.device)
             dv_bias = _zeros(D, x.device)
-            outs = dict(outs, dq_sum=d5[:, :, 0] if fused else dq.view(B, Tq, H, dk), du=du, dv_bias=dv_bias)
+            if not _state.get("det", False):
+                outs = dict(outs, dq_sum=d5[:, :, 0] if fused else dq.view(B, Tq, H, dk), du=du, dv_bias=dv_bias)
         dqu, dqv, dk_, dv_, dpos = ops.attention_bwd(
             qu, qv, k4, v4, pproj, m, ctxv, lse, dctx, 1.0 / math.sqrt(dk), precise=_state["precise"],
             drop_p=pa, seed=sa, seed_dev=sda, **outs)
+        if relpos and _state.get("det", False):
+            # deterministic mode: the kernel leaves dqu / dqv; ONE ordered pass (a single block per column group) forms
+            # dq = dqu + dqv -- straight into the q third of the fused d(qkv) buffer -- and the two position-bias gradients
+            ops.head_bias_bwd(dqu.view(B * Tq, D), dqv.view(B * Tq, D), dq, 3 * D if fused else D, du, dv_bias, B * Tq, D)
         if relpos:
             du, dv_bias = du.view(H, dk), dv_bias.view(H, dk)
             dwpos = _wgrad(dpos, pe, pe.shape[0], D, D) if ctx.pp is None else None

@@ -60,6 +60,7 @@ RECORD = None   # bench.py: (entry points, list) -- the argument tuples of every
 TRACE = None    # tools/pmc_step.py: list collecting (entry point, algorithmic flops, algorithmic bytes) of every launch
 PAIR_RECORD = None  # bench.py: list collecting, per paired launch (paired() below), the [(entry point, args, flops, bytes), ...] inside it
 _pair_cur = None
+_in_pair = 0  # > 0 inside a paired() block, also while pairing itself is switched off by the profiling hooks
 
 
 def call(name, *args, flops=0.0, nbytes=0.0):
@@ -68,7 +69,7 @@ def call(name, *args, flops=0.0, nbytes=0.0):
     if TRACE is not None:
         TRACE.append((name, flops, nbytes))
     if RECORD is not None and name in RECORD[0]:
-        RECORD[1].append((name, args, flops, nbytes))
+        RECORD[1].append((name, args, flops, nbytes, _in_pair > 0))
     if _pair_cur is not None:
         _pair_cur.append((name, args, flops, nbytes))
     if PROFILE is None:
@@ -95,10 +96,14 @@ def paired():
     """The data-gradient (NT) and weight-gradient (TN) GEMM issued inside the block leave as ONE launch whose grid holds
     the tiles of both (csrc/gemm_pair.hip) -- at M = B*T <= 1600 either one alone cannot fill the 256 CUs.  The two must
     be independent.  Switched off while bench.py's per-launch profiling hooks are installed."""
+    global _pair_cur, _in_pair
     if not PAIR_GEMMS or PROFILE is not None or RECORD is not None:
-        yield
+        _in_pair += 1
+        try:
+            yield
+        finally:
+            _in_pair -= 1
         return
-    global _pair_cur
     L = _lib.lib()
     if PAIR_RECORD is not None:
         _pair_cur = []

@@ -193,13 +193,22 @@ class NativeStepper:
     stepper(x, lens, y) -> (loss, loss_ctc, loss_att, n_correct, n_tokens) as device scalars (static tensors of the graph when
     replayed: read them before the next step of the same shape).  close() removes the hooks / communicators it installed."""
 
-    def __init__(self, model, args, dev, rank, world, steps_per_epoch, log=print, seed_offset=0):
+    def __init__(self, model, args, dev, rank, world, steps_per_epoch, log=print, own_stream=True):
         from . import functional as AF
         from .graph_step import StepGraphs
         from .optim import FusedAdamW
 
         self.model, self.args, self.dev, self.rank, self.world = model, args, dev, rank, world
         self.comms, self.buckets, self.shard = [], None, False
+        # own_stream: run every step on a stream of this object, joined to the caller's stream before and after.  A hipGraph capture
+        # must never meet work bound to the legacy default stream (gradient-accumulation nodes remember the stream they were
+        # created on), and a Lightning Trainer calls training_step on the default stream; fit() below already runs its whole loop
+        # on a side stream and passes False
+        self._work = torch.cuda.Stream(device=dev) if (own_stream and dev.type == "cuda") else None
+        # train.py --deterministic / AVSR_DETERMINISTIC=1: every gradient sum in a fixed order (functional.set_deterministic)
+        self._det_before = AF.deterministic()
+        if getattr(args, "deterministic", False) or os.environ.get("AVSR_DETERMINISTIC", "0") == "1":
+            AF.set_deterministic(True)
         AF.manual_seed(42 + rank)
         self.seed_dev = seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         AF.set_seed_tensor(seed_dev)
@@ -310,7 +319,14 @@ class NativeStepper:
         return self.stepper.stats
 
     def __call__(self, x, lens, y):
-        return self.stepper(x, lens, y)
+        if self._work is None:
+            return self.stepper(x, lens, y)
+        cur = torch.cuda.current_stream(self.dev)
+        self._work.wait_stream(cur)
+        with torch.cuda.stream(self._work):
+            out = self.stepper(x, lens, y)
+        cur.wait_stream(self._work)
+        return out
 
     def close(self):
         from . import functional as AF
@@ -322,6 +338,8 @@ class NativeStepper:
             c.close()
         self.comms = []
         AF.set_bn_sync(None)
+        if AF.deterministic() != self._det_before:
+            AF.set_deterministic(self._det_before)
 
 
 def _fit(model, args, dev, rank, world, backend, log, held):
@@ -330,7 +348,7 @@ def _fit(model, args, dev, rank, world, backend, log, held):
     # every rank sees the same number of batches per epoch (DistributedSampler pads): the schedule lengths below and the
     # number of collectives per epoch are identical on all ranks
     steps_per_epoch = source.steps_per_epoch
-    ns = held["native"] = NativeStepper(model, args, dev, rank, world, steps_per_epoch, log=log)
+    ns = held["native"] = NativeStepper(model, args, dev, rank, world, steps_per_epoch, log=log, own_stream=False)
     opt, seed_dev, stepper = ns.opt, ns.seed_dev, ns.stepper
     held["stepper"] = stepper
     folder = os.path.join(args.exp_dir, args.exp_name) if getattr(args, "exp_dir", None) else None

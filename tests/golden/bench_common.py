@@ -127,7 +127,9 @@ def measure(model, case, device):
         cos.append(c)
         samp.append(se)
         if se >= max(samp):
-            worst = {"worst_sample_tensor": k}
+            worst["worst_sample_tensor"] = k
+        if c <= min(cos):
+            worst["worst_cos_tensor"] = f"{k} (reference norm {ref_n / gmax:.1e} of the largest)"
     out.update(grad_tensors=len(norm_err), grad_norm_rel_err_max=max(norm_err),
                grad_norm_rel_err_median=statistics.median(norm_err), grad_sample_cos_min=min(cos),
                grad_sample_cos_mean=sum(cos) / len(cos), grad_sample_rel_l2_max=max(samp),

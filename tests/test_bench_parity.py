@@ -65,12 +65,30 @@ def test_bench_shape_parity(gold, tag, mode):
     if mode in ("precise", "hpf"):
         assert full < 1e-4 and raw < 1e-4 and enc < 1e-4
     elif mode == "mixed":
-        # THE BENCHMARKED MODE: the whole decoder-logit tensor inside the north star's 1e-3 with >= 20 % in hand at every
-        # benchmarked shape (CPU model of the policy, tools/precision_study.py "mixed=f16a": 5.4e-4 / 6.3e-4 at A / B).  The
-        # raw CTC logits and the encoder output carry the encoder's accumulated f16 activation rounding (~2e-3; the CTC LOSS,
-        # which the bound names, is at 1e-5): bounded here so that a regression shows
-        assert full < 8e-4, full
-        assert raw < 3e-3 and enc < 3e-3
+        # THE BENCHMARKED MODE: the whole decoder-logit tensor inside the north star's 1e-3 at every benchmarked shape.  The figure
+        # is a sum of ~10^2 independent f16 rounding contributions and RE-ROLLS by up to ~10 % with any change of summation order
+        # upstream (round 6: a different tile shape in the first ResNet stage -- bit-compatible MFMA order, BatchNorm partial sums
+        # grouped by 256 instead of 128 rows -- moved batch B from 7.34e-4 to 7.65e-4 and batch A from 5.3e-4 to 6.0e-4 with no
+        # change of arithmetic).  So the regression tripwire is the MEDIAN of three such rolls (the default tiles and two
+        # alternative tile choices of the front-end, avsr_tune knobs 21 / 18) < 8e-4, and EVERY roll must be inside the north
+        # star's 1e-3.  The raw CTC logits and the encoder output carry the encoder's accumulated f16 activation rounding (measured
+        # 1.9e-3 / 1.7e-3 / 2.0e-3 at A / B / AA; the CTC LOSS, which the bound names, is at 1e-5): bounded at measured + 15 %
+        from auto_avsr_amd import ops
+
+        rolls = [full]
+        for knob, val in ((21, 23), (18, 7)):
+            ops.tune(knob, val)
+            try:
+                mm = _model(case["seed"], case.get("modality", "video"))
+                with AF.numerics(mode):
+                    rolls.append(BC.measure(mm, case, torch.device("cuda"))["dec_logits_full_rel_l2"])
+            finally:
+                ops.tune(knob, 0)
+                AF.invalidate_weight_cache()
+        print(f"PARITY batch {tag} mixed: dec_logits_full_rel_l2 over three summation orders: {[round(v, 7) for v in rolls]}")
+        assert max(rolls) < 1e-3, rolls
+        assert sorted(rolls)[1] < 8e-4, rolls
+        assert raw < 2.3e-3 and enc < 2.3e-3, (raw, enc)
     else:
         assert full < 1.5e-2 and raw < 4e-2 and enc < 4e-2
     if mode == "precise":
@@ -91,7 +109,11 @@ def test_bench_shape_parity(gold, tag, mode):
         assert r["dec_logits_rel_l2"] < 1e-3 and r["ctc_logp_rel_l2"] < 1e-3
         assert r["enc_rel_l2"] < 1.5e-2  # (a 32-channel slice of the encoder output: ~10x the logits' relative error in every mode)
         assert r["acc"] == pytest.approx(r["acc_ref"], abs=1e-6)
-        assert r["grad_sample_cos_min"] > 0.99 and r["grad_sample_rel_l2_median"] < 3e-2 and r["grad_norm_rel_err_median"] < 5e-3
+        # gradient tolerance of the benchmarked mode (bf16 backward on bf16 twins of the f16 / split-plane forward; stated in
+        # DESIGN.md section 2): per tensor, 64 sampled elements -- median relative L2 <= 2e-2 (measured 1.1e-2 / 1.4e-2 at A / B),
+        # cosine >= 0.99 on every tensor whose gradient is not numerically zero, median norm error <= 5e-3
+        assert r["grad_sample_cos_min"] > 0.99, r.get("worst_cos_tensor")
+        assert r["grad_sample_rel_l2_median"] < 2e-2 and r["grad_norm_rel_err_median"] < 5e-3
     else:
         # bf16 operands everywhere (8 significant bits): measured on MI355X decoder logits 7.4e-3, CTC log-probs 4.2e-3, encoder
         # slice 4e-2 at batch A (batch B within 1.5x) -- 7x / 4x OUTSIDE the north-star bound, which is why it is not the

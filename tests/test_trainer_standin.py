@@ -162,9 +162,8 @@ def test_trainer_native_step_replays_hipgraphs(monkeypatch):
         orig_close(self)
 
     monkeypatch.setattr(TN.NativeStepper, "close", close)
-    work = torch.cuda.Stream()
-    with torch.cuda.stream(work):  # (a capture must not meet the legacy default stream -- train_native.fit's rule)
-        losses = StandInTrainer(data, max_epochs=4, gradient_clip_val=None).fit(mod)
+    # (on the DEFAULT stream, as a Lightning Trainer would call it: the stepper moves the step onto a stream of its own)
+    losses = StandInTrainer(data, max_epochs=4, gradient_clip_val=None).fit(mod)
     torch.cuda.synchronize()
     assert seen["captured"] == 2 and seen["replayed"] >= 6 and seen["eager"] == 2, seen
     assert all(l == l for l in losses) and losses[-1] < losses[0]

@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 from oracle import avsr_oracle as O  # noqa: E402
 from bench_common import BATCHES, FIXTURE, ODIM, bench_batch, bench_state_dict, full_errors, load_full, rel  # noqa: E402
 
-GROUPS = ["stem", "trunk", "trunk1", "trunk2", "trunk3", "trunk4", "proj", "enc_ffn", "enc_attn_proj", "enc_attn_q", "enc_attn_k", "enc_attn_v",
+GROUPS = ["stem", "trunk", "trunk1", "trunk2", "trunk3", "trunk4", "proj", "enc_ffn", "enc_ffn_w1", "enc_ffn_w2", "enc_attn_proj", "enc_attn_q", "enc_attn_k", "enc_attn_v",
           "enc_attn_out", "enc_attn_pos", "enc_attn_core", "enc_conv", "enc_conv_pw1", "enc_conv_dw", "enc_conv_pw2", "ctc_head", "dec", "dec_out"]
 CFG = {}
 STATS = {}
@@ -60,7 +60,8 @@ def group_of(pre):
     if pre.startswith("decoder."):
         return "dec"
     if ".feed_forward" in pre:
-        return "enc_ffn"
+        fine = "enc_ffn_" + ("w1" if ".w_1." in pre else "w2")  # refine "enc_ffn" when named explicitly (round 6: per-input ablation)
+        return fine if fine in CFG else "enc_ffn"
     if ".self_attn." in pre:
         fine = "enc_attn_" + pre.rstrip(".").rsplit("linear_", 1)[-1]  # q / k / v / out refine "enc_attn_proj" when named explicitly
         return fine if fine in CFG else "enc_attn_proj"
@@ -223,7 +224,7 @@ def parse(spec):
         k, v = item.split("=")
         if k == "all":
             for g in GROUPS:
-                if not g[-1].isdigit() and g not in ("enc_attn_q", "enc_attn_k", "enc_attn_v", "enc_attn_out", "enc_attn_pos", "enc_conv_dw"):  # refinements: only when named explicitly
+                if not g[-1].isdigit() and g not in ("enc_attn_q", "enc_attn_k", "enc_attn_v", "enc_attn_out", "enc_attn_pos", "enc_conv_dw", "enc_conv_pw1", "enc_conv_pw2"):  # refinements: only when named explicitly
                     cfg[g] = v
         elif k == "mixed":  # the round-4 default policy with format v
             for g in ("trunk3", "trunk4", "enc_ffn", "enc_attn_proj", "enc_attn_core", "enc_conv", "dec"):
@@ -244,7 +245,17 @@ if __name__ == "__main__":
     ap.add_argument("--config", action="append", default=None)
     ap.add_argument("--batch", default="A")
     ap.add_argument("--layers", action="store_true")
+    ap.add_argument("--ablate", action="store_true",
+                    help="round 6 (VERDICT r5 item 4): the default mixed policy (f16 activations x exact weights) with ONE contraction "
+                         "input of the encoder at a time kept exact in all 12 layers -- what a hi + lo split of that activation would buy "
+                         "on the encoder output / raw CTC logits / decoder logits")
     args = ap.parse_args()
+    if args.ablate:
+        base = "mixed=f16a"
+        args.config = [base] + [f"{base},{g}=f32" for g in ("enc_ffn_w1", "enc_ffn_w2", "enc_attn_q", "enc_attn_k", "enc_attn_v", "enc_attn_out",
+                                                            "enc_attn_pos", "enc_attn_core", "enc_conv_pw1", "enc_conv_dw", "enc_conv_pw2",
+                                                            "enc_ffn", "enc_attn_proj", "enc_conv", "dec", "trunk3", "trunk4")] + \
+                      [f"{base},enc_ffn=f32,enc_attn_proj=f32,enc_attn_core=f32,enc_conv=f32"]
     torch.set_num_threads(os.cpu_count() or 8)
     if args.layers:
         install_trace()  # (innermost: the recorded outputs are those of the quantised blocks)

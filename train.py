@@ -44,6 +44,9 @@ def parse_args(argv=None):
                    help="under a pytorch_lightning Trainer: auto = Lightning's automatic optimisation as in the reference (eager "
                         "launches, torch AdamW); native = manual optimisation, training_step replays the whole fused step as one "
                         "hipGraph per batch shape (auto_avsr_amd.train_native.NativeStepper: what bench.py times)")
+    p.add_argument("--deterministic", action="store_true",
+                   help="bit-reproducible training steps (the reference seeds everything, train.py:18): every gradient sum the default "
+                        "build forms with floating-point atomics is formed in a fixed order instead; slower")
     p.add_argument("--grad-wire", default=None, choices=["f32", "bf16"],
                    help="format of the gradient buckets on the xGMI links (AVSR_DDP=buckets): f32 = the reference's DDP all-reduce "
                         "(default), bf16 = half the bytes per link, bf16 sums across the ranks")
