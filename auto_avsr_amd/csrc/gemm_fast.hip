@@ -142,6 +142,9 @@ bool launch_tile_h16x2(int tile, Params& p, int split_k, hipStream_t stream) {
 
 }  // namespace
 
+int avsr_conv_patch_supported(int N, int H, int W, int Cg, int Cout_eff, int KH, int KW, int stride, int pad_h, int pad_w);
+int avsr_conv_patch_launch(int mode, const void* src, const void* w, const void* w_lo, int ldw, const void* resid, void* out, void* out2,
+                           const void* zero_page, int N, int H, int W, int Cg, int Cout_eff, hipStream_t stream);
 int avsr_conv3x3_c64_supported(int H, int W);
 int avsr_conv3x3_c64_launch(int flip, const void* src, const void* wq, const void* resid, void* out, const void* zero_page, int N,
                             int H, int W, hipStream_t stream);
@@ -267,6 +270,13 @@ extern "C" int avsr_conv2d_bf16(int dgrad, const void* src, const void* wp, cons
         AVSR_CHECK_LAUNCH("conv2d_bf16");
         return 0;
     }
+    // 128 - 512 channels on small images (stages 2 - 4), 3x3 / stride 1: whole-image tiles with the input PATCH staged once per
+    // 64-channel chunk instead of one im2col tile per filter tap (conv_patch.hip, round 6)
+    if (g_tune[0] == 0 && avsr_conv_patch_supported(N, H, W, Cg, dgrad ? Cin : Cout, KH, KW, stride, pad_h, pad_w)) {
+        avsr_conv_patch_launch(dgrad ? 1 : 0, src, wp, nullptr, 0, resid, out, nullptr, zero_page, N, H, W, Cg, dgrad ? Cin : Cout, stream);
+        AVSR_CHECK_LAUNCH("conv2d_bf16");
+        return 0;
+    }
     Params p{};
     p.A = src; p.B = wp;
     p.K = KH * KW * Cg; p.lda = Cg; p.ldb = p.K;
@@ -330,6 +340,12 @@ extern "C" int avsr_conv2d_h16(const void* x, const void* wp, const void* wp_lo,
     AVSR_REQUIRE(stride == 1 || (stride == 2 && KH <= 8 && KW <= 8), "conv2d_h16: stride must be 1 or 2");
     AVSR_REQUIRE((long)N * H * W < (1l << 31) && (long)N * OH * OW < (1l << 31), "conv2d_h16: pixel count exceeds int32");
     if (N <= 0) return 0;
+    AVSR_REQUIRE((ldw ? ldw : KH * KW * Cin) >= KH * KW * Cin && (ldw % 8) == 0, "conv2d_h16: bad filter pitch");
+    if (g_tune[18] == 0 && avsr_conv_patch_supported(N, H, W, Cin, Cout, KH, KW, stride, pad_h, pad_w)) {  // conv_patch.hip (round 6)
+        avsr_conv_patch_launch(2, x, wp, wp_lo, ldw, nullptr, y, y2, zero_page, N, H, W, Cin, Cout, stream);
+        AVSR_CHECK_LAUNCH("conv2d_h16");
+        return 0;
+    }
     Params p{};
     p.A = x; p.B = wp; p.B2 = wp_lo;
     p.K = KH * KW * Cin; p.lda = Cin; p.ldb = ldw ? ldw : p.K;

@@ -278,6 +278,63 @@ def test_conv3x3_c64_persistent(dev, cfg):
     assert (y - yt).abs().max() < 2e-2 * max(1.0, y_ref.abs().max().item()) and (dx - dxt).abs().max() < 4e-2 * max(1.0, x.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("cfg", [(31, 3, 3, 128, 128), (9, 6, 6, 64, 256), (5, 11, 11, 128, 128), (30, 3, 3, 192, 384), (3, 5, 7, 64, 128)])
+def test_conv_patch_staged(dev, cfg):
+    """Round 6, conv_patch.hip: 3x3 / stride-1 convolutions on whole-image tiles with the input patch staged once per 64-channel
+    chunk (forward, data gradient + residual in bf16; f16 forward with one and two weight planes) against torch conv2d on the
+    same rounded operands and against the tiled kernel it replaces (knob 20): several tiles, a ragged last tile (fewer images
+    than a tile holds), rows beyond the tile's images, two output-column tiles, odd image shapes."""
+    from auto_avsr_amd import functional as AF
+
+    N, H, W, Cin, Cout = cfg
+    torch.manual_seed(N * 10 + H)
+    x = torch.randn(N, Cin, H, W).bfloat16().float().requires_grad_()
+    w = torch.randn(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5
+    wq = w.bfloat16().float()
+    y_ref = F.conv2d(x, wq, stride=1, padding=1)
+    dy = torch.randn_like(y_ref).bfloat16().float()
+    y_ref.backward(dy)
+    xd = nhwc(x.detach()).bfloat16().to(dev)
+    dyd = nhwc(dy).bfloat16().to(dev)
+    res = torch.randn(N, H, W, Cin).bfloat16()
+    wp = ops.conv_weight_permute(w.to(dev), torch.bfloat16)
+    wpd = ops.conv_weight_permute(w.to(dev), torch.bfloat16, to_dgrad=True)
+    outs = []
+    try:
+        for knob in (2, 1, 3):  # 2 / 3 = the patch-staged kernel (two / three weight stages) whatever the grid size, 1 = the tiled kernel
+            ops.tune(20, knob)
+            y = ops.conv2d_fwd(xd, wp, N, H, W, Cin, Cout, 3, 3, 1, 1, 1, False)
+            dx = ops.conv2d_dgrad(dyd, wpd, res.to(dev), N, H, W, Cin, Cout, 3, 3, 1, 1, 1, False) if Cin % 128 == 0 else None
+            outs.append((y.float().cpu(), dx.float().cpu() if dx is not None else None))
+    finally:
+        ops.tune(20, 0)
+    (y, dx), (yt, dxt), (y3, dx3) = outs
+    assert torch.equal(y3, y) and (dx is None or torch.equal(dx3, dx))  # the ring depth changes no arithmetic
+    assert (y - nhwc(y_ref.detach())).abs().max() < 2e-2 * max(1.0, y_ref.abs().max().item())
+    assert (y - yt).abs().max() < 2e-2 * max(1.0, y_ref.abs().max().item())
+    if dx is not None:
+        assert (dx - nhwc(x.grad) - res.float()).abs().max() < 4e-2 * max(1.0, x.grad.abs().max().item())
+        assert (dx - dxt).abs().max() < 4e-2 * max(1.0, x.grad.abs().max().item())
+    # f16 forward, one and two weight planes (the mixed mode's trunk stages 3 - 4)
+    AF.invalidate_weight_cache()
+    xh = nhwc(x.detach()).half()
+    buf = AF._w_conv_h16(w.to(dev))
+    ref2 = F.conv2d(xh.double().permute(0, 3, 1, 2), w.double(), stride=1, padding=1).permute(0, 2, 3, 1)
+    ref1 = F.conv2d(xh.double().permute(0, 3, 1, 2), w.half().double(), stride=1, padding=1).permute(0, 2, 3, 1)
+    try:
+        ops.tune(20, 2)
+        y2 = ops.conv2d_fwd(xh.to(dev), buf, N, H, W, Cin, Cout, 3, 3, 1, 1, 1, False, wp_planes=2)
+        y1 = ops.conv2d_fwd(xh.to(dev), buf, N, H, W, Cin, Cout, 3, 3, 1, 1, 1, False, wp_planes=1)
+    finally:
+        ops.tune(20, 0)
+        AF.invalidate_weight_cache()
+
+    def rel(a, b):
+        return float((a.double().cpu() - b).norm() / b.norm())
+
+    assert y2.dtype == torch.float16 and rel(y2, ref2) < 2.5e-4 and rel(y1, ref1) < 2.5e-4  # (the f16 rounding of the output)
+
+
 def test_multi_weight_permute_matches_single(dev):
     """All conv-weight copies of a model in ONE launch (LDS-transposed tiles: 8 co x 64 ci forward copies, 64 co x 8 ci
     data-gradient copies, all taps) == the per-tensor permute, bit for bit; ragged channel counts and 1 / 3 / 9 taps included."""
