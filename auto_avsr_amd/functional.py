@@ -870,7 +870,12 @@ class _ZeroArena:
             t = torch.zeros(n, dtype=torch.float32, device=device)
             return t
         ent = self.buf.get(device)
-        if ent is None or ent[1] + n_al > ent[0].numel() or (cap and not ent[2]):
+        # A chunk is only ever continued in the regime it was allocated in.  Eager -> capture: a captured step must not bake in slices of
+        # a chunk whose fill happened outside the capture.  Capture -> eager (round 6, found by an order-dependent test): the tail of a
+        # chunk allocated UNDER capture is NOT zero for an eager step -- graphs share one memory pool and re-zero their chunks at the
+        # start of their own replays, so the pool hands the same memory to other graphs' allocations in between; an eager step that
+        # continued such a chunk accumulated its gradients onto whatever the last replay left there (16 M non-zero floats measured)
+        if ent is None or ent[1] + n_al > ent[0].numel() or (cap != ent[2]):
             ent = self.buf[device] = [torch.zeros(self.CHUNK, dtype=torch.float32, device=device), 0, cap]
             if cap:
                 self.keep.append(ent[0])

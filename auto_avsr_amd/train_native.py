@@ -338,6 +338,8 @@ class NativeStepper:
             c.close()
         self.comms = []
         AF.set_bn_sync(None)
+        if AF._state.get("seed_dev") is self.seed_dev:
+            AF.set_seed_tensor(None)  # (the per-step dropout counter of THIS loop: not the next caller's)
         if AF.deterministic() != self._det_before:
             AF.set_deterministic(self._det_before)
 

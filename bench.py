@@ -631,7 +631,7 @@ BN_FAMILY = ("avsr_bn_stats", "avsr_bn_stats_finalize", "avsr_bn_act_fwd", "avsr
              "avsr_bn_act_pool_fwd", "avsr_bn_pool_bwd_reduce", "avsr_bn_pool_bwd_apply", "avsr_bn_small_fwd", "avsr_bn_small_bwd",
              "avsr_bn_act_fwd2", "avsr_bn_act_fwd_h16", "avsr_bn_small_fwd2", "avsr_bn_small_fwd_h16")
 # C-ABI entry point -> the kernel names it launches, as rocprofv3 prints them (profiles/*_hbm_traffic.json keys)
-KERNELS_OF = {"avsr_gemm_bf16_nt": r"^gemm_fast_kernel<\d+, \d+, \d+, 0,", "avsr_conv2d_bf16": r"^(gemm_fast_kernel<\d+, \d+, \d+, [12],|conv3x3_c64_kernel)",
+KERNELS_OF = {"avsr_gemm_bf16_nt": r"^gemm_fast_kernel<\d+, \d+, \d+, 0,", "avsr_conv2d_bf16": r"^(gemm_fast_kernel<\d+, \d+, \d+, [12],|conv3x3_c64_kernel|conv_patch_kernel)",
               "avsr_conv3x3_wgrad_bf16": r"^(conv3x3_wgrad_kernel|wgrad_reduce_kernel)", "avsr_gemm_bf16_tn": r"^gemm_tn_fast_kernel",
               "bn": r"^bn_(colreduce|bwd_apply|act_fwd|partial_finalize|partial_sum|act_pool3?_fwd|pool_bwd_reduce|pool3?_bwd_apply|stats|small_fwd|small_bwd)"}
 
@@ -643,9 +643,9 @@ def counter_traffic(pattern):
     passes are separate runs, as the profiling guide prescribes.  None when the summary is absent."""
     import re
 
-    path = os.path.join(ROOT, "profiles", "r5_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r6_hbm_traffic.json")  # (tools/r6_pmc.sh)
     if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r4_hbm_traffic.json")
+        path = os.path.join(ROOT, "profiles", "r5_hbm_traffic.json")
     if not os.path.exists(path):
         return None, None
     tr = json.load(open(path))

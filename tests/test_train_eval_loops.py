@@ -237,6 +237,43 @@ def test_native_fit_more_shapes_than_graphs(tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_zero_scratch_after_a_capture_is_zero():
+    """Round 6 (found through an order-dependent failure: a native fit, then an eager backward pass in the same process gave
+    gradients with garbage in them): the zero-initialised scratch arena must not continue, in an EAGER step, a chunk that was
+    allocated under hipGraph capture -- graphs share one memory pool and only re-zero their chunks inside their own replays, so the
+    tail of such a chunk holds whatever other graphs left there."""
+    from auto_avsr_amd import functional as AF
+
+    dev = torch.device("cuda")
+    work = torch.cuda.Stream()
+    with torch.cuda.stream(work):
+        AF.new_step()
+        pool = torch.cuda.graph_pool_handle()
+        graphs = []
+        for k in range(2):  # two graphs in one pool, as StepGraphs keeps them
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                AF.new_step()
+                z = AF._zeros(100_000, dev)
+                junk = torch.full((20_000_000,), 3.0 + k, device=dev)  # pool memory that the other graph's replay dirties
+                z.add_(junk[:100_000])
+            del junk
+            graphs.append((g, z))
+        for g, _ in graphs + graphs:
+            g.replay()
+        torch.cuda.synchronize()
+        captured_chunk = AF._arena.buf[dev][0]
+        assert AF._arena.buf[dev][2]  # the current chunk is a capture-time one
+        AF.new_step()  # an eager step follows
+        t = AF._zeros(3_000_000, dev)
+        torch.cuda.synchronize()
+        assert t.untyped_storage().data_ptr() != captured_chunk.untyped_storage().data_ptr()
+        assert float(t.abs().max()) == 0.0
+        assert float(graphs[1][1].min()) == 4.0 == float(graphs[1][1].max())  # (the replayed graph's own slice: zero fill + its add)
+    AF._arena.buf.clear()
+
+
+@pytest.mark.gpu
 def test_step_graphs_eviction_returns_per_capture_resources():
     """evict=True: the LRU drops graphs beyond max_graphs and on_evict hands the optimizer's pinned pointer table of the dropped
     graph back -- 12 captures through a capacity of 2 never hold more than 2 (+ the one in progress) captured tables, where
