@@ -176,11 +176,12 @@ template <bool RELPOS>
 struct TilePrefetch {
     static constexpr int PB_CH = RELPOS ? (PB_ROWS * 8 + 255) / 256 : 0;  // 16-byte chunks per thread
     bf16x8 rk[2], rv[2], rp[PB_CH > 0 ? PB_CH : 1];
+    int tid = threadIdx.x & 255;  // thread index inside the 256-thread group that shares the staged tile
     AVSR_DEV void fetch(const bf16_t* kk, long ldk, const bf16_t* vv, long ldv, const bf16_t* pos, long ldp, int j0, int Tk,
                         int prow0, int plim) {
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            const int id = threadIdx.x + 256 * c, r = id >> 3, ch = (id & 7) * 8, gr = j0 + r;
+            const int id = tid + 256 * c, r = id >> 3, ch = (id & 7) * 8, gr = j0 + r;
             rk[c] = rv[c] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             if (gr < Tk) {
                 rk[c] = *reinterpret_cast<const bf16x8*>(kk + (long)gr * ldk + ch);
@@ -190,7 +191,7 @@ struct TilePrefetch {
         if (RELPOS) {
 #pragma unroll
             for (int c = 0; c < PB_CH; c++) {
-                const int id = threadIdx.x + 256 * c, r = id >> 3, ch = (id & 7) * 8, gr = prow0 + r;
+                const int id = tid + 256 * c, r = id >> 3, ch = (id & 7) * 8, gr = prow0 + r;
                 rp[c] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
                 if (id < PB_ROWS * 8 && gr >= 0 && gr < plim) rp[c] = *reinterpret_cast<const bf16x8*>(pos + (long)gr * ldp + ch);
             }
@@ -199,14 +200,14 @@ struct TilePrefetch {
     AVSR_DEV void commit(bf16_t* Ks, bf16_t* Vs, bf16_t* Pb) const {
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            const int id = threadIdx.x + 256 * c, r = id >> 3, ch = (id & 7) * 8;
+            const int id = tid + 256 * c, r = id >> 3, ch = (id & 7) * 8;
             *reinterpret_cast<bf16x8*>(Ks + r * PITCH + ch) = rk[c];
             *reinterpret_cast<bf16x8*>(Vs + r * PITCH + ch) = rv[c];
         }
         if (RELPOS) {
 #pragma unroll
             for (int c = 0; c < PB_CH; c++) {
-                const int id = threadIdx.x + 256 * c, r = id >> 3, ch = (id & 7) * 8;
+                const int id = tid + 256 * c, r = id >> 3, ch = (id & 7) * 8;
                 if (id < PB_ROWS * 8) *reinterpret_cast<bf16x8*>(Pb + r * PITCH + ch) = rp[c];
             }
         }
@@ -594,20 +595,28 @@ struct Attn {
 // arithmetic (online softmax in f32, dropout keep mask by (row, key) index), so the backward kernel pairs with it unchanged.
 // F16 = 1: q / k / v / position band and the probabilities are IEEE half (v_mfma_f32_16x16x32_f16) -- the mixed mode's forward;
 // `out` is then f16 and out2 (optional) its bf16 twin for the backward pass.
-template <bool RELPOS, int F16 = 0>
+// KSP = 2 (round 6): the KEY range is split over two groups of four waves (512 threads): group g runs the loop below over its half of
+// the key tiles on LDS buffers of its own, and the two (m, l, O) states meet through LDS at the end.  A block's time is the serial
+// chain over its key tiles (7 at T = 400) at one or two waves per SIMD -- 336 blocks for 256 CUs leave most wave slots empty -- so
+// halving the chain is worth more than the merge costs (T = 400 forward: profiles/r6_attention_ksplit.txt).
+template <bool RELPOS, int F16 = 0, int KSP = 1>
 struct AttnFwdT {
     static constexpr int KS_E = KT * PITCH, VS_E = KT * PITCH, PB_E = RELPOS ? PB_ROWS * PITCH : 0;
     static constexpr int G_F = RELPOS ? 4 * 16 * G_PITCH : 0;  // f32, per wave [16 q][G_PITCH]
-    static constexpr size_t LDS_BYTES = (size_t)(KS_E + VS_E + PB_E) * 2 + (size_t)(G_F + KT) * 4;
+    static constexpr size_t GROUP_BYTES = (size_t)(KS_E + VS_E + PB_E) * 2 + (size_t)(G_F + KT) * 4;
+    static constexpr int MERGE_F = 20;  // floats a lane of group 1 hands over: 16 accumulators, running maximum, row sum (+ 2: 16-byte aligned rows)
+    static constexpr size_t LDS_BYTES = KSP * GROUP_BYTES + (KSP > 1 ? (size_t)256 * MERGE_F * 4 : 0);
+    static_assert(GROUP_BYTES % 16 == 0, "group buffers stay 16-byte aligned");
 
     static AVSR_DEV void run(const AttnParams& p, char* smem) {
-        bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
+        const int grp = KSP > 1 ? (int)(threadIdx.x >> 8) : 0, tid = threadIdx.x & 255;
+        bf16_t* Ks = reinterpret_cast<bf16_t*>(smem + grp * GROUP_BYTES);
         bf16_t* Vs = Ks + KS_E;
         bf16_t* Pb = Vs + VS_E;
         float* Gs = reinterpret_cast<float*>(Pb + PB_E);
         float* bias = Gs + G_F;  // [KT] additive key mask of the staged tile (0 / NEG_BIG)
 
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const int lane = tid & 63, w = tid >> 6;
         const int quad = lane >> 4, lc = lane & 15;
         const int i0 = blockIdx.x * QT, h = blockIdx.y, b = blockIdx.z;
         const int Tq = p.Tq, Tk = p.Tk;
@@ -643,28 +652,36 @@ struct AttnFwdT {
         const long mrow = row_mask ? (long)b * p.mask_sb + (long)(q_ok ? qrow : 0) * p.mask_sq : 0;
         const uint64_t drop_row = (((uint64_t)b * p.H + h) * Tq + (q_ok ? qrow : 0)) * (uint64_t)Tk;
         TilePrefetch<RELPOS> tp;  // next tile's K / V / band rows in registers while this one is multiplied
+        tp.tid = tid;
         float rbias = 0.f;
         auto fetch_bias = [&](int j0) {
-            if (threadIdx.x < KT) {
-                const int jg = j0 + threadIdx.x;
+            if (tid < KT) {
+                const int jg = j0 + tid;
                 bool ok = jg < Tk;
                 if (ok && p.mask && !row_mask) ok = p.mask[(long)b * p.mask_sb + jg] != 0;
                 rbias = ok ? 0.f : NEG_BIG;
             }
         };
-        tp.fetch(kk, p.ldk, vv, p.ldv, pos, p.ldp, 0, Tk, -i0 + Tq - 1 - 63, 2 * Tq - 1);
-        fetch_bias(0);
-        for (int kt = 0; kt < ntiles; kt++) {
-            const int j0 = kt * KT;
+        // this group's key tiles [kt_begin, kt_end); every group makes `per` trips (the barriers are block-wide)
+        const int per = (ntiles + KSP - 1) / KSP, kt_begin = grp * per, kt_end = min(ntiles, kt_begin + per);
+        if (kt_begin < kt_end) {
+            tp.fetch(kk, p.ldk, vv, p.ldv, pos, p.ldp, kt_begin * KT, Tk, kt_begin * KT - i0 + Tq - 1 - 63, 2 * Tq - 1);
+            fetch_bias(kt_begin * KT);
+        }
+        for (int it = 0; it < per; it++) {
+            const int kt = kt_begin + it, j0 = kt * KT;
+            const bool live = kt < kt_end;
             __syncthreads();  // every wave is done reading the previous tile
-            tp.commit(Ks, Vs, Pb);
-            if (threadIdx.x < KT) bias[threadIdx.x] = rbias;
+            if (live) {
+                tp.commit(Ks, Vs, Pb);
+                if (tid < KT) bias[tid] = rbias;
+            }
             __syncthreads();
-            if (kt + 1 < ntiles) {
+            if (kt + 1 < kt_end) {
                 tp.fetch(kk, p.ldk, vv, p.ldv, pos, p.ldp, j0 + KT, Tk, j0 + KT - i0 + Tq - 1 - 63, 2 * Tq - 1);
                 fetch_bias(j0 + KT);
             }
-            if (!wave_active) continue;  // wave-uniform: this wave's 16 query rows are all past Tq
+            if (!wave_active || !live) continue;  // wave-uniform: this wave's 16 query rows are all past Tq / no tile left for this group
 
             // ---- S^T tiles: st[j][r] = score(key 16j + 4quad + r, query lc)
             f32x4 st[4];
@@ -760,6 +777,30 @@ struct AttnFwdT {
         float l = l_part;
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);
+        if (KSP > 1) {
+            // the two key halves meet: group 1 hands (O, m, l) over through LDS, group 0 rescales both to the common maximum
+            float* mb = reinterpret_cast<float*>(smem + KSP * GROUP_BYTES) + tid * MERGE_F;
+            if (grp == 1) {
+#pragma unroll
+                for (int n = 0; n < 4; n++) *reinterpret_cast<f32x4*>(mb + 4 * n) = acc[n];
+                mb[16] = m_run;
+                mb[17] = l;
+            }
+            __syncthreads();
+            if (grp == 1) return;
+            const float m1 = mb[16], l1 = mb[17];
+            const float m_new = fmaxf(m_run, m1);
+            const float m_safe = m_new <= 0.5f * NEG_BIG ? 0.f : m_new;
+            const float c0 = exp2f(m_run - m_safe), c1 = exp2f(m1 - m_safe);
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(mb + 4 * n);
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[n][r] = acc[n][r] * c0 + a1[r] * c1;
+            }
+            l = l * c0 + l1 * c1;
+            m_run = m_new;
+        }
         if (!q_ok) return;
         const float inv = l > 0.f ? 1.f / l : 0.f;
         bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + b * p.sbo + (long)qrow * p.ldo + h * DK;
@@ -780,10 +821,10 @@ struct AttnFwdT {
     }
 };
 
-template <bool RELPOS, int F16 = 0>
-__global__ __launch_bounds__(256) void attn_fwd_t_kernel(AttnParams p) {
+template <bool RELPOS, int F16 = 0, int KSP = 1>
+__global__ __launch_bounds__(256 * KSP) void attn_fwd_t_kernel(AttnParams p) {
     AVSR_DYN_SMEM(smem);
-    AttnFwdT<RELPOS, F16>::run(p, smem);
+    AttnFwdT<RELPOS, F16, KSP>::run(p, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -857,6 +898,7 @@ struct AttnBwdT {
         bf16_t* ds_g = reinterpret_cast<bf16_t*>(p.ds) + (((long)b * p.H + h) * Tq + (q_ok ? qrow : 0)) * p.lds;
 
         TilePrefetch<RELPOS> tp;
+        tp.tid = threadIdx.x;
         float rbias = 0.f;
         auto fetch_bias = [&](int j0) {
             if (threadIdx.x < KT) {
@@ -1036,7 +1078,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
 
 template <bool BWD>
 int launch_attn(const AttnParams& p, int dtype, int precise, bool relpos, hipStream_t stream) {
-    dim3 grid((p.Tq + QT - 1) / QT, p.H, p.B), block(256);
+    dim3 grid((p.Tq + QT - 1) / QT, p.H, p.B), block(256), block2(512);
+    // forward, 16-bit operands: split the key range over two wave groups once a block walks >= 4 key tiles (knob 8 = 2: never; 3: always)
+    // Only where the grid leaves CUs idle AND two blocks still fit a CU: the plain (decoder) form -- source attention has
+    // ceil(65 / 64) x B x H = 96 blocks walking 7 key tiles.  The relative-position form needs 61 KB per group (position band +
+    // per-wave skew scratch): two groups = one block per CU, and its ~330 blocks would then run in two rounds of half-length
+    // blocks -- nothing gained (knob 8 = 3 forces the split there too, for measurements).
+    const bool ksp2 = !BWD && avsr_tune_knobs[8] != 2 &&
+                      (avsr_tune_knobs[8] == 3 || (p.pos == nullptr && (p.Tk + KT - 1) / KT >= 4 && (long)grid.x * grid.y * grid.z <= 256));
 #define AVSR_ATTN_GO(TT, NSV, RP)                                                                        \
     AVSR_LAUNCH((attn_kernel<TT, NSV, RP, BWD>), grid, block, (Attn<TT, NSV, RP, BWD>::LDS_BYTES), stream, p)
     if (precise) {
@@ -1044,7 +1093,9 @@ int launch_attn(const AttnParams& p, int dtype, int precise, bool relpos, hipStr
         if (relpos) AVSR_ATTN_GO(float, 2, true); else AVSR_ATTN_GO(float, 2, false);
     } else if (dtype == 1) {
         if (!BWD && avsr_tune_knobs[8] != 1) {  // knob 8 = 1: the generic kernel (A/B runs)
-            if (relpos) AVSR_LAUNCH((attn_fwd_t_kernel<true>), grid, block, (AttnFwdT<true>::LDS_BYTES), stream, p);
+            if (ksp2 && relpos) AVSR_LAUNCH((attn_fwd_t_kernel<true, 0, 2>), grid, block2, (AttnFwdT<true, 0, 2>::LDS_BYTES), stream, p);
+            else if (ksp2) AVSR_LAUNCH((attn_fwd_t_kernel<false, 0, 2>), grid, block2, (AttnFwdT<false, 0, 2>::LDS_BYTES), stream, p);
+            else if (relpos) AVSR_LAUNCH((attn_fwd_t_kernel<true>), grid, block, (AttnFwdT<true>::LDS_BYTES), stream, p);
             else AVSR_LAUNCH((attn_fwd_t_kernel<false>), grid, block, (AttnFwdT<false>::LDS_BYTES), stream, p);
         } else if (BWD && avsr_tune_knobs[9] != 1) {  // knob 9 = 1: the generic backward kernel
             if (relpos) AVSR_LAUNCH((attn_bwd_t_kernel<true>), grid, block, (AttnBwdT<true>::LDS_BYTES), stream, p);
@@ -1053,7 +1104,9 @@ int launch_attn(const AttnParams& p, int dtype, int precise, bool relpos, hipStr
         else AVSR_ATTN_GO(bf16_t, 1, false);
     } else if (dtype == 2) {  // f16 (forward only: the backward pass of the mixed mode runs on the bf16 twins)
         if (BWD) return -1;
-        if (relpos) AVSR_LAUNCH((attn_fwd_t_kernel<true, 1>), grid, block, (AttnFwdT<true, 1>::LDS_BYTES), stream, p);
+        if (ksp2 && relpos) AVSR_LAUNCH((attn_fwd_t_kernel<true, 1, 2>), grid, block2, (AttnFwdT<true, 1, 2>::LDS_BYTES), stream, p);
+        else if (ksp2) AVSR_LAUNCH((attn_fwd_t_kernel<false, 1, 2>), grid, block2, (AttnFwdT<false, 1, 2>::LDS_BYTES), stream, p);
+        else if (relpos) AVSR_LAUNCH((attn_fwd_t_kernel<true, 1>), grid, block, (AttnFwdT<true, 1>::LDS_BYTES), stream, p);
         else AVSR_LAUNCH((attn_fwd_t_kernel<false, 1>), grid, block, (AttnFwdT<false, 1>::LDS_BYTES), stream, p);
     } else {
         if (relpos) AVSR_ATTN_GO(float, 1, true); else AVSR_ATTN_GO(float, 1, false);

@@ -297,6 +297,35 @@ def _kv_fast_vs_generic(dev, relpos, B, T, Tk, H):
         assert rel(dp0, dp1) < 1e-5, rel(dp0, dp1)
 
 
+@pytest.mark.parametrize("relpos,mkind,T,Tk,dtype", [(False, "pad", 70, 300, torch.bfloat16), (False, "pad", 33, 257, torch.float16),
+                                                   (True, "pad", 130, 130, torch.bfloat16), (False, "causal", 200, 200, torch.float16)])
+def test_attention_fwd_key_split(dev, relpos, mkind, T, Tk, dtype):
+    """Round 6: the forward kernel with the key range split over two wave groups (source attention of the decoder: few blocks, long
+    key chains) against the unsplit kernel and float64 math: same output and log-sum-exp up to the rounding of the merge -- ragged
+    halves, a group with no tile at all, padding masks, rows past Tq; avsr_tune knob 8 = 3 forces the split, 2 forbids it."""
+    B, H, D = 2, 2, 64
+    torch.manual_seed(T + Tk)
+    qu, qv = torch.randn(B, T, H, D).to(dtype), torch.randn(B, T, H, D).to(dtype)
+    k, v = torch.randn(B, Tk, H, D).to(dtype), torch.randn(B, Tk, H, D).to(dtype)
+    pos = torch.randn(2 * T - 1, H * D).to(dtype) if relpos else None
+    mask = make_mask(mkind, B, T, Tk)
+    scale = 1 / math.sqrt(D)
+    d = lambda t: None if t is None else t.to(dev)
+    res = {}
+    try:
+        for knob in (2, 3):
+            ops.tune(8, knob)
+            out, lse = ops.attention_fwd(d(qu), d(qv) if relpos else None, d(k), d(v), d(pos), d(mask), scale)
+            res[knob] = (out.float().cpu(), lse.float().cpu())
+    finally:
+        ops.tune(8, 0)
+    ref = ref_attn(qu.double(), qv.double() if relpos else None, k.double(), v.double(), None if pos is None else pos.double(), mask, scale)
+    rel = lambda a, b: float((a.double() - b).norm() / b.norm())
+    assert rel(res[3][0], ref) < 1e-2 and rel(res[2][0], ref) < 1e-2
+    assert rel(res[3][0], res[2][0].double()) < 4e-3                  # one 16-bit rounding of the output apart
+    assert (res[3][1] - res[2][1]).abs().max() < 1e-4                  # the log-sum-exp the backward pass reads
+
+
 def test_attention_dropout_consistency(dev):
     """Dropout on the probabilities: forward and backward must draw the same keep-mask (finite-difference free
     check: with V = I-like probes the output equals the dropped probabilities that the backward re-creates)."""

@@ -49,3 +49,18 @@ case("enc relpos B4 T400 H12", 4, 400, 400, 12, True, False, 0.1)
 case("enc relpos B64 T25 H12", 64, 25, 25, 12, True, False, 0.1)
 case("dec self B16 L40 H12", 16, 40, 40, 12, False, True, 0.1)
 case("dec src B16 L40 T100 H12", 16, 40, 100, 12, False, False, 0.1)
+# round 6: the forward kernel with the key range split over two wave groups (knob 8: 2 = never, 3 = always, 0 = the rule of launch_attn)
+for tag, B, Tq, Tk, H, rp in (("dec src B4 L65 T400", 4, 65, 400, 12, False), ("dec src B7 L34 T214", 7, 34, 214, 12, False),
+                              ("enc relpos B4 T400", 4, 400, 400, 12, True)):
+    for knob in (2, 3, 0):
+        ops.tune(8, knob)
+        D = 64
+        g = lambda *s: (torch.randn(*s, device=dev) * 0.5).half()
+        qu, k, v = g(B, Tq, H, D), g(B, Tk, H, D), g(B, Tk, H, D)
+        qv = g(B, Tq, H, D) if rp else None
+        pos = g(2 * Tq - 1, H * D) if rp else None
+        lens = torch.randint(Tk // 2, Tk + 1, (B,), device=dev)
+        mask = (torch.arange(Tk, device=dev)[None] < lens[:, None]).unsqueeze(1).contiguous()
+        f = timeit(lambda: ops.attention_fwd(qu, qv, k, v, pos, mask, 0.125, drop_p=0.1 if not rp else 0.0, seed=3))
+        print(f"{tag:24s} f16 forward, key-split knob {knob}: {f:7.1f} us")
+ops.tune(8, 0)
