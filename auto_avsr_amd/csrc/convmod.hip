@@ -164,8 +164,11 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
         __syncthreads();
         if (it + (int)gridDim.y < items) fetch(it + gridDim.y);  // in flight during the sums below
         float a4[4] = {0.f, 0.f, 0.f, 0.f}, s4 = 0.f;
+        // only the rows the utterance has: beyond them the dy rows are zeros (round 6: at T ~ 100 a 256-step tile spent 60 % of
+        // its sum on them -- 26.9 -> 15.0 us per launch, profiles/r6_microbench_convmod.txt; same bits: the skipped terms were exact zeros)
+        const int tcur = (it - (it / tiles_t) * tiles_t) * DW_W2, tlim = min(DW_W2, (Tlen - tcur + 3) & ~3);
 #pragma unroll 4
-        for (int t = 0; t < DW_W2; t += 4) {
+        for (int t = 0; t < tlim; t += 4) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const float g = ds[(t + u) * DW_P2 + cl];

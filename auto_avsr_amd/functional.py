@@ -323,6 +323,11 @@ def _rows(x):
 # ([in][out_padded_to_64], data gradient).  Copies are cached per parameter version: an optimizer step bumps
 # `_version`, so they are rebuilt exactly once per training step (bench.py invalidates explicitly).
 _BN_SMALL = os.environ.get("AVSR_BN_SMALL", "1") != "0"  # A/B switch: single-launch BatchNorm1d of the convolution module
+# A/B switch (round 6): GLU -> depthwise conv -> BatchNorm -> SiLU of the convolution module as one launch each way
+# (csrc/convmod_fused.hip).  OFF by default -- measured SLOWER than the launches it merges: a block must own every frame of its 8
+# channels, so the grid is 96 blocks and the 31-tap stencils run out of 96 CUs' LDS ports instead of 256 CUs' (forward 29.7 vs 22.5 us,
+# backward 112 vs 38.4 us per layer at 1600 x 768; replayed step 23.76 vs 22.82 ms: profiles/r6_microbench_convmod.txt)
+_CONVMOD_FUSED = os.environ.get("AVSR_CONVMOD_FUSED", "0") != "0"
 _FUSE_QKV = os.environ.get("AVSR_FUSE_QKV", "1") != "0"  # A/B switch for the fused self-attention projections
 # fused BN + SiLU + max-pool of the video stem (forward: the full-resolution activation is never written; backward: the
 # reduce pass runs on the pooled tensors, the apply pass gathers the pooled gradient).  Measured on MI355X (round 2):

@@ -135,9 +135,21 @@ class ConvSublayerFn(torch.autograd.Function):
         # a[:, :D] * sigmoid(a[:, D:]) on the fly, the GLU output is never written
         gl = None
         wdw = w_dw.view(D, K)
-        c = ops.dwconv(a, wdw, b_dw, B, Tn, D, K, glu_in=True)
         one_launch = training and AF._BN_SMALL and _state["bn_sync"] is None and rows <= ops.BN_SMALL_MAX_ROWS
-        if one_launch:  # statistics + running stats + normalise + Swish in one pass (no cross-rank merge to wait for)
+        # round 6 experiment (AVSR_CONVMOD_FUSED=1, off by default: slower, functional.py _CONVMOD_FUSED): the whole element-wise
+        # middle (GLU, depthwise conv, BatchNorm statistics + running stats + normalise, Swish) as ONE launch -- a block owns 8
+        # channels and every frame (csrc/convmod_fused.hip)
+        middle = one_launch and AF._CONVMOD_FUSED
+        ctx.middle = middle
+        if middle:
+            s, c, bmean, binv = ops.convmod_dwbn_fwd(a, wdw, b_dw, B, Tn, D, K, bn_w, bn_b, bn_eps, momentum, bn_rm, bn_rv, bn_nbt,
+                                                     out_dtype=T if Tc != T else None)
+            counts = None
+        else:
+            c = ops.dwconv(a, wdw, b_dw, B, Tn, D, K, glu_in=True)
+        if middle:
+            pass
+        elif one_launch:  # statistics + running stats + normalise + Swish in one pass
             s, bmean, binv = ops.bn_small_fwd(c, rows, D, bn_w, bn_b, bn_eps, momentum, bn_rm, bn_rv, bn_nbt, 1,
                                               out_dtype=T if Tc != T else None)
             counts = None
@@ -175,7 +187,12 @@ class ConvSublayerFn(torch.autograd.Function):
         with ops.paired():
             dw2 = _wgrad(g, s, rows, D, D, bias_out=db2).view(D, D, 1)
             _gemm_nn(g, w_pw2.view(D, D), rows, D, D, ds)
-        if training and AF._BN_SMALL and _state["bn_sync"] is None and rows <= ops.BN_SMALL_MAX_ROWS:
+        dwdw = _zeros((D, K), x.device)
+        dbdw = _zeros(D, x.device)
+        if ctx.middle:  # BatchNorm + Swish backward, depthwise weight / data gradient, GLU backward: one launch
+            da, dbn_w, dbn_b = ops.convmod_dwbn_bwd(a, c, ds, bmean, binv, bn_w, bn_b, wdw, B, Tn, D, K, dwdw, dbdw)
+            dc = None
+        elif training and AF._BN_SMALL and _state["bn_sync"] is None and rows <= ops.BN_SMALL_MAX_ROWS:
             dc, dbn_w, dbn_b = ops.bn_small_bwd(c, ds, rows, D, bmean, binv, bn_w, bn_b, 1)
         else:
             sums = ops.bn_bwd_reduce(c, ds, None, bmean, binv, bn_w, bn_b, rows, D, 1)
@@ -185,11 +202,10 @@ class ConvSublayerFn(torch.autograd.Function):
             else:
                 sums_dx, inv_n, n_dev = torch.zeros_like(sums), 0.0, None
             dc, _ = ops.bn_bwd_apply(c, ds, None, bmean, binv, bn_w, bn_b, sums_dx, inv_n, rows, D, 1, False, n_dev=n_dev)
-        dwdw = _zeros((D, K), x.device)
-        dbdw = _zeros(D, x.device)
-        ops.dwconv_wgrad(a, dc, dwdw, dbdw, B, Tn, D, K, glu_in=True)
-        # data gradient of the depthwise convolution with the GLU backward as its epilogue: d glu never reaches HBM
-        da = ops.dwconv(dc, wdw, None, B, Tn, D, K, flip=True, glu_a=a).view(rows, 2 * D)
+        if dc is not None:
+            ops.dwconv_wgrad(a, dc, dwdw, dbdw, B, Tn, D, K, glu_in=True)
+            # data gradient of the depthwise convolution with the GLU backward as its epilogue: d glu never reaches HBM
+            da = ops.dwconv(dc, wdw, None, B, Tn, D, K, flip=True, glu_a=a).view(rows, 2 * D)
         db1 = _zeros(2 * D, x.device)
         if fused:
             dh = torch.empty(rows, D, dtype=T, device=x.device)

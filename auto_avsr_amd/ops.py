@@ -417,6 +417,36 @@ def bn_small_bwd(x, dy, rows, C, mean, invstd, gamma, beta, act):
     return dx, dgamma, dbeta
 
 
+def convmod_dwbn_fwd(a, wdw, bdw, B, T, C, K, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked,
+                     out_dtype=None):
+    """GLU -> depthwise conv -> BatchNorm (batch statistics) -> SiLU of a [B*T, 2C] in ONE launch (csrc/convmod_fused.hip):
+    (s, c_saved, mean, invstd); c_saved is the depthwise output the backward pass reads -- its bf16 twin when the mode keeps twins
+    (the f32 tensor itself is then never written), the tensor in a's dtype otherwise."""
+    rows = B * T
+    s = torch.empty(rows, C, dtype=out_dtype or a.dtype, device=a.device)
+    s2 = _twin(s)
+    c2 = torch.empty(rows, C, dtype=torch.bfloat16, device=a.device) if (s2 is not None and a.dtype == torch.float32) else None
+    c = torch.empty(rows, C, dtype=a.dtype, device=a.device) if c2 is None else None
+    mean = torch.empty(C, dtype=torch.float32, device=a.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=a.device)
+    call("avsr_convmod_dwbn_fwd", _ptr(a), dt(a), _ptr(wdw), _ptr(bdw), B, T, C, K, _ptr(gamma), _ptr(beta), eps, momentum,
+         _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _ptr(c), _ptr(c2), _ptr(s), dt(s), _ptr(s2), _ptr(mean),
+         _ptr(invstd), _stream(a), nbytes=_nb(a, c, c2, s, s2))
+    return s, (c2 if c2 is not None else c), mean, invstd
+
+
+def convmod_dwbn_bwd(a, c, ds, mean, invstd, gamma, beta, wdw, B, T, C, K, dwdw, dbdw):
+    """Backward of convmod_dwbn_fwd in ONE launch: (da [B*T, 2C], dgamma, dbeta); dwdw [C, K] / dbdw [C] are added to."""
+    assert a.dtype == c.dtype == ds.dtype, (a.dtype, c.dtype, ds.dtype)
+    rows = B * T
+    da = torch.empty(rows, 2 * C, dtype=a.dtype, device=a.device)
+    dgamma = torch.empty(C, dtype=torch.float32, device=a.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=a.device)
+    call("avsr_convmod_dwbn_bwd", _ptr(a), _ptr(c), _ptr(ds), dt(a), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(wdw),
+         B, T, C, K, _ptr(da), _ptr(dwdw), _ptr(dbdw), _ptr(dgamma), _ptr(dbeta), _stream(a), nbytes=_nb(a, c, ds, da))
+    return da, dgamma, dbeta
+
+
 def bn_finalize(stats, counts, world, C, eps, momentum, running_mean, running_var, num_batches_tracked=None,
                 stats_stride=0, counts_stride=0, n_total=None):
     """counts: tensor or raw device address of the first count."""

@@ -183,6 +183,23 @@ int avsr_bn_small_fwd2(const float* x, int64_t rows, int C, const float* gamma, 
 int avsr_bn_small_bwd(const void* x, const void* dy, int dtype, int64_t rows, int C, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, int act, void* dx, float* dgamma, float* dbeta,
                       avsr_stream_t stream);
+/* The element-wise middle of the Conformer ConvolutionModule as ONE launch each way on a single rank (round 6;
+ * conformer_encoder.py:32-34 `glu` -> `depthwise_conv` -> `norm` -> `activation`): a [B*T, 2C] (dtype 0 f32 / 1 bf16) -> GLU ->
+ * depthwise Conv1d(K odd <= 31, weights wdw [C][K], bias bdw or NULL) -> BatchNorm1d over all B*T <= avsr_convmod_fused_max_rows()
+ * frames (running statistics / batch counter updated, may be NULL) -> SiLU -> s [B*T, C] (s_dtype 0 f32 / 1 bf16 / 2 f16) + its
+ * bf16 twin s2 (may be NULL).  The depthwise output the backward needs leaves as c_out (dtype of a) and / or c2 (bf16), either may
+ * be NULL; mean / invstd [C].  Same arithmetic as avsr_dwconv_fwd(glu_in) + avsr_bn_small_fwd.
+ * avsr_convmod_dwbn_bwd: ds -> BatchNorm + SiLU backward -> depthwise weight / bias gradient (ADDED to dwdw [C][K] / dbdw [C]) and
+ * data gradient -> GLU backward -> da [B*T, 2C]; dgamma / dbeta [C] overwritten (avsr_bn_small_bwd + avsr_dwconv_wgrad +
+ * avsr_dwconv_fwd(flip, glu_a) in one launch; a / c / ds / da share `dtype`). */
+int avsr_convmod_fused_max_rows(void);
+int avsr_convmod_dwbn_fwd(const void* a, int dtype, const float* wdw, const float* bdw, int B, int T, int C, int K,
+                          const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                          float* running_var, int64_t* num_batches_tracked, void* c_out, void* c2, void* s, int s_dtype, void* s2,
+                          float* mean, float* invstd, avsr_stream_t stream);
+int avsr_convmod_dwbn_bwd(const void* a, const void* c, const void* ds, int dtype, const float* mean, const float* invstd,
+                          const float* gamma, const float* beta, const float* wdw, int B, int T, int C, int K, void* da,
+                          float* dwdw, float* dbdw, float* dgamma, float* dbeta, avsr_stream_t stream);
 /* y = act(gamma*(x-mean)*invstd + beta (+ add)); act 0 none, 1 SiLU */
 int avsr_bn_act_fwd(const void* x, const void* add, int dtype, const float* mean, const float* invstd,
                     const float* gamma, const float* beta, void* y, int64_t rows, int C, int act,

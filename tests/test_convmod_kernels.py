@@ -340,3 +340,66 @@ def test_batchnorm_single_launch_small(dev, rows, C, dtype):
     assert (dx.float() - dx2.float()).abs().max() < (1e-5 if dtype == torch.float32 else 2e-2) * scale
     assert (dgamma - sums[1]).abs().max() < 1e-3 * max(1.0, float(sums[1].abs().max()))
     assert (dbeta - sums[0]).abs().max() < 1e-3 * max(1.0, float(sums[0].abs().max()))
+
+
+@pytest.mark.parametrize("B,T,C,K,dtype,sdtype", [
+    (3, 37, 16, 31, torch.float32, torch.float32),
+    (2, 75, 40, 7, torch.float32, torch.float16),
+    (16, 100, 64, 31, torch.bfloat16, torch.bfloat16),
+    (1, 1, 8, 31, torch.float32, torch.float32),
+    (4, 512, 8, 15, torch.bfloat16, torch.bfloat16),
+])
+def test_convmod_fused_middle(dev, B, T, C, K, dtype, sdtype):
+    """avsr_convmod_dwbn_fwd / _bwd (round 6: GLU -> depthwise conv -> BatchNorm -> SiLU and its backward, one launch each) vs the
+    launches they replace on the same input -- bit-equal wherever the summation order is the same (everything but the depthwise
+    weight / bias gradient) -- and vs torch autograd in fp64 (conformer_encoder.py:32-34)."""
+    torch.manual_seed(B * 1000 + T + C + K)
+    rows = B * T
+    a = (torch.randn(rows, 2 * C) * 1.3).to(dtype)
+    wdw = (torch.randn(C, K) * 0.3)
+    bdw = torch.randn(C) * 0.2
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C) * 0.1
+    eps, mom = 1e-5, 0.1
+    ad, wd, bd, gd, btd = a.to(dev), wdw.to(dev), bdw.to(dev), gamma.to(dev), beta.to(dev)
+    rm1, rv1 = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    rm2, rv2 = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    n1, n2 = torch.zeros((), dtype=torch.int64, device=dev), torch.zeros((), dtype=torch.int64, device=dev)
+    # the separate launches
+    c_ref = ops.dwconv(ad, wd, bd, B, T, C, K, glu_in=True).view(rows, C)
+    s_ref, m_ref, i_ref = ops.bn_small_fwd(c_ref, rows, C, gd, btd, eps, mom, rm1, rv1, n1, 1,
+                                           out_dtype=sdtype if sdtype != dtype else None)
+    s, c, mean, invstd = ops.convmod_dwbn_fwd(ad, wd, bd, B, T, C, K, gd, btd, eps, mom, rm2, rv2, n2,
+                                              out_dtype=sdtype if sdtype != dtype else None)
+    assert s.dtype == sdtype and c.dtype == dtype
+    assert torch.equal(c, c_ref) and torch.equal(mean, m_ref) and torch.equal(invstd, i_ref)
+    assert torch.equal(s, s_ref) and torch.equal(rm1, rm2) and torch.equal(rv1, rv2) and int(n2) == 1
+    # backward
+    ds = torch.randn(rows, C).to(dtype).to(dev)
+    dc_ref, dg_ref, db_ref = ops.bn_small_bwd(c_ref, ds, rows, C, m_ref, i_ref, gd, btd, 1)
+    dw_ref, dbias_ref = torch.zeros(C, K, device=dev), torch.zeros(C, device=dev)
+    ops.dwconv_wgrad(ad, dc_ref, dw_ref, dbias_ref, B, T, C, K, glu_in=True)
+    da_ref = ops.dwconv(dc_ref, wd, None, B, T, C, K, flip=True, glu_a=ad).view(rows, 2 * C)
+    dw, dbias = torch.zeros(C, K, device=dev), torch.zeros(C, device=dev)
+    da, dg, db = ops.convmod_dwbn_bwd(ad, c, ds, mean, invstd, gd, btd, wd, B, T, C, K, dw, dbias)
+    assert torch.equal(da, da_ref) and torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
+    sc = max(1.0, float(dw_ref.abs().max()))
+    assert (dw - dw_ref).abs().max() < 2e-5 * sc * max(1, rows // 256), float((dw - dw_ref).abs().max())
+    assert (dbias - dbias_ref).abs().max() < 2e-5 * max(1.0, float(dbias_ref.abs().max())) * max(1, rows // 256)
+    if rows > 1 and dtype == torch.float32:  # and against autograd
+        a64 = a.double().requires_grad_()
+        w64, b64 = wdw.double().requires_grad_(), bdw.double().requires_grad_()
+        bn = torch.nn.BatchNorm1d(C, eps=eps, momentum=mom).double().train()
+        with torch.no_grad():
+            bn.weight.copy_(gamma)
+            bn.bias.copy_(beta)
+        g64 = F.glu(a64, dim=1).view(B, T, C).transpose(1, 2)
+        c64 = F.conv1d(g64, w64.view(C, 1, K), b64, padding=(K - 1) // 2, groups=C)
+        s64 = F.silu(bn(c64)).transpose(1, 2).reshape(rows, C)
+        s64.backward(ds.cpu().double())
+        rel = lambda x, r: float((x.cpu().double() - r).norm() / (r.norm() + 1e-30))
+        tol = 2e-5 if sdtype == torch.float32 else 1e-3
+        assert rel(s, s64.detach()) < tol
+        assert rel(da, a64.grad) < 1e-4 and rel(dw, w64.grad) < 1e-4
+        assert dbias.abs().max() < 1e-4  # (a bias in front of a BatchNorm has no gradient: b64.grad is rounding noise)
+        assert rel(dg, bn.weight.grad) < 1e-4 and rel(db, bn.bias.grad) < 1e-4
+        assert (rm2.cpu().double() - bn.running_mean).abs().max() < 1e-5
