@@ -180,6 +180,11 @@ class GradBuckets:
                 # same stream for every parameter of the bucket (nodes that survived from an earlier iteration keep theirs)
                 st = torch.cuda.current_stream()
                 self._seen[b][st.cuda_stream] = st
+                if self.compute_stream is not None and st != self.compute_stream:
+                    # (round 6) a branch of the step that ran on a second stream (E2E's CTC branch): its gradients were produced
+                    # there, the gather below is issued on the compute stream -- order the two now (the bucket may complete much
+                    # later, from the compute stream)
+                    self.compute_stream.wait_stream(st)
             self._left[b] -= 1
             if self._left[b] == 0:
                 self._flush(b)

@@ -36,6 +36,17 @@ class E2E(nn.Module):
         self.ctc = nets.CTC(odim, adim, 0.1, reduce=True)
         self.criterion = nets.LabelSmoothingLoss(self.odim, self.ignore_id, 0.1, False)
 
+    def _side_stream(self, t):
+        """The second stream of the training step on t's device (None on the CPU / emulator)."""
+        if t.device.type != "cuda":
+            return None
+        st = getattr(self, "_side_streams", None)
+        if st is None:
+            st = self._side_streams = {}
+        if t.device not in st:
+            st[t.device] = torch.cuda.Stream(t.device)
+        return st[t.device]
+
     def scorers(self):
         """e2e_asr_conformer.py:60-61: the scorers of hybrid CTC / attention beam search."""
         from .decoding import CTCPrefixScorer
@@ -52,13 +63,25 @@ class E2E(nn.Module):
         padding_mask = nets.non_pad_mask_device(lengths, feats.shape[1])
         h = AF.linear(feats, self.proj_encoder.weight, self.proj_encoder.bias, out_dtype=torch.float32)
         enc, _ = self.encoder(h, padding_mask)
-        loss_ctc, _ = self.ctc(enc, lengths, label)
+        # The CTC branch and the decoder branch share nothing between here and the weighted sum (e2e_asr_conformer.py:130-147): the
+        # CTC branch runs on a second stream (functional._SIDE_BRANCH), forward and -- autograd keeps a node on its forward's
+        # stream -- backward, beside the decoder's many small launches
+        side = self._side_stream(enc) if (AF._SIDE_BRANCH and torch.is_grad_enabled()) else None
+        if side is not None:
+            main = torch.cuda.current_stream(enc.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                loss_ctc, _ = self.ctc(enc, lengths, label)
+        else:
+            loss_ctc, _ = self.ctc(enc, lengths, label)
         # add_sos_eos + target_mask (e2e_asr_conformer.py:138-139) with the static width Lmax + 1, and the token count of
         # th_accuracy's denominator: one launch (csrc/loss.hip prepare_targets_kernel; nets.add_sos_eos_static /
         # nets.target_mask are the torch statement of the same, kept as the test reference)
         ys_in, ys_out, ys_mask, n_tok = ops.prepare_targets(label.to(feats.device), self.sos, self.eos, self.ignore_id)
         pred, _ = self.decoder(ys_in, ys_mask, enc, padding_mask)
         loss_att = self.criterion(pred, ys_out)
+        if side is not None:
+            main.wait_stream(side)
         loss = self.ctc_weight * loss_ctc + (1 - self.ctc_weight) * loss_att
         return loss, loss_ctc, loss_att, self.criterion.last_hits, n_tok[0]
 

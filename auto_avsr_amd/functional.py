@@ -328,6 +328,15 @@ _BN_SMALL = os.environ.get("AVSR_BN_SMALL", "1") != "0"  # A/B switch: single-la
 # channels, so the grid is 96 blocks and the 31-tap stencils run out of 96 CUs' LDS ports instead of 256 CUs' (forward 29.7 vs 22.5 us,
 # backward 112 vs 38.4 us per layer at 1600 x 768; replayed step 23.76 vs 22.82 ms: profiles/r6_microbench_convmod.txt)
 _CONVMOD_FUSED = os.environ.get("AVSR_CONVMOD_FUSED", "0") != "0"
+# A/B switch (round 6): the CTC branch of the loss (ctc.py:32-38: dropout -> ctc_lo -> log-softmax -> alpha / beta recursion -> gradient)
+# is independent of the decoder branch between the encoder output and the final weighted sum; its long pole is a recursion over time on
+# B blocks (136 us on 4 CUs).  With the switch on, E2E.forward_tensors issues that branch on a second stream (forked after the encoder,
+# joined before the sum): autograd runs each backward node on the stream of its forward, so the branch's backward overlaps the
+# decoder's too, and under hipGraph capture the fork / join become graph edges -- the replayed step runs the two branches concurrently.
+# OFF by default -- MEASURED SLOWER on ROCm 7.2: the replayed step takes 22.38 ms with the fork against 22.03 ms without (same box,
+# profiles/r6_ab_side_branch.txt): a forked hipGraph leaves the single-stream replay path and its cross-stream edges cost more than the
+# ~0.35 ms of CTC work they hide.  Bit-identical results either way (tests/test_deterministic.py).
+_SIDE_BRANCH = os.environ.get("AVSR_SIDE_BRANCH", "0") != "0"
 _FUSE_QKV = os.environ.get("AVSR_FUSE_QKV", "1") != "0"  # A/B switch for the fused self-attention projections
 # fused BN + SiLU + max-pool of the video stem (forward: the full-resolution activation is never written; backward: the
 # reduce pass runs on the pooled tensors, the apply pass gathers the pooled gradient).  Measured on MI355X (round 2):
@@ -880,10 +889,19 @@ class _ZeroArena:
         # chunk allocated UNDER capture is NOT zero for an eager step -- graphs share one memory pool and re-zero their chunks at the
         # start of their own replays, so the pool hands the same memory to other graphs' allocations in between; an eager step that
         # continued such a chunk accumulated its gradients onto whatever the last replay left there (16 M non-zero floats measured)
+        cuda = device.type == "cuda"
+        cur = torch.cuda.current_stream(device) if cuda else None
         if ent is None or ent[1] + n_al > ent[0].numel() or (cap != ent[2]):
-            ent = self.buf[device] = [torch.zeros(self.CHUNK, dtype=torch.float32, device=device), 0, cap]
+            ent = self.buf[device] = [torch.zeros(self.CHUNK, dtype=torch.float32, device=device), 0, cap, cur, None]
             if cap:
                 self.keep.append(ent[0])
+            if cuda:  # (round 6) the fill is ordered on `cur` only: a taker on another stream waits for this event
+                ent[4] = torch.cuda.Event()
+                ent[4].record(cur)
+        elif cuda and cur != ent[3]:
+            # a second stream of the step (E2E's CTC branch, _SIDE_BRANCH) takes scratch from a chunk another stream zero-filled:
+            # stream order does not cover the fill -- wait for it (an event wait; a graph edge under capture)
+            cur.wait_event(ent[4])
         out = ent[0][ent[1]: ent[1] + n]
         ent[1] += n_al
         return out

@@ -60,3 +60,24 @@ def test_two_runs_bit_identical(dev, tmp_path, monkeypatch):
     for x, y in zip(a[0][:3], c[0][:3]):
         assert abs(x - y) <= 2e-2 * abs(x), (a[0], c[0])
     print(f"\ndeterministic {a[2]:.2f} s / {b[2]:.2f} s, default {c[2]:.2f} s; default == deterministic bitwise: {torch.equal(a[1], c[1])}")
+
+
+def test_ctc_branch_on_a_second_stream_same_bits(dev, tmp_path, monkeypatch):
+    """Round 6: E2E.forward_tensors issues the CTC branch (ctc.py:32-38) on a second stream beside the decoder
+    (functional._SIDE_BRANCH); autograd runs the branch's backward there too and the hipGraph capture turns fork / join into graph
+    edges.  Same kernels on the same operands, only concurrent: in the deterministic mode the losses and the trained weights are
+    bit-identical with the branch on one stream or two."""
+    import pytest
+
+    from auto_avsr_amd import functional as AF
+
+    if dev.type != "cuda":
+        pytest.skip("streams: GPU only")
+    epochs = 4
+    monkeypatch.setattr(AF, "_SIDE_BRANCH", True)
+    a = _run(dev, tmp_path, True, epochs, monkeypatch)
+    monkeypatch.setattr(AF, "_SIDE_BRANCH", False)
+    b = _run(dev, tmp_path, True, epochs, monkeypatch)
+    assert a[3]["replayed"] > 0 and len(a[0]) >= 8
+    assert a[0] == b[0], (a[0], b[0])
+    assert torch.equal(a[1], b[1])
