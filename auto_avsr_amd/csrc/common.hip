@@ -25,9 +25,9 @@ extern "C" int avsr_take_launch_error(void) {
 extern "C" const char* avsr_last_error(void) { return g_err; }
 extern "C" int avsr_abi_version(void) { return 1; }
 // process-wide tuning knobs (benchmarks; see avsr_tune in avsr_hip.h)
-int avsr_tune_knobs[24] = {0};
+int avsr_tune_knobs[32] = {0};
 extern "C" int avsr_tune(int knob, int value) {
-    if (knob < 0 || knob >= 24) {
+    if (knob < 0 || knob >= 32) {
         avsr_set_error("tune: unknown knob");
         return 1;
     }

@@ -82,7 +82,11 @@ extern "C" int avsr_conv2d_wgrad_bf16(const void* dy, const void* x, float* dwp,
     p.cH = H; p.cW = W; p.cC = Cin; p.cOH = OH; p.cOW = OW; p.cKH = KH; p.cKW = KW; p.cS = stride; p.cPH = pad_h; p.cPW = pad_w;
     p.cT = 1; p.cKT = 1;
     const long tiles = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
-    long split = 1024 / (tiles < 1 ? 1 : tiles);
+    // target block count (knob 24: A/B).  Measured on the audio trunk's Conv1d shapes (tools/microbench_wgrad1d.py ->
+    // profiles/r6_microbench_wgrad1d.txt): 3 - 12 tiles 41 -> 35 us at 512 blocks (fewer colliding atomics per element), 192 tiles
+    // 173 -> 163 us at 2048
+    const long target = avsr_tune_knobs[24] > 0 ? avsr_tune_knobs[24] : (tiles <= 12 ? 512 : (tiles >= 96 ? 2048 : 1024));
+    long split = target / (tiles < 1 ? 1 : tiles);
     if (split > p.K / 512) split = p.K / 512;
     if (split < 1 || avsr_det()) split = 1;
     launch_tn<3>(p, (int)split, stream);

@@ -533,7 +533,7 @@ AVSR_DEV float dropout_scale(uint64_t seed, uint64_t idx, float p, float inv_kee
 }
 
 // ---------------------------------------------------------------- status plumbing
-extern int avsr_tune_knobs[24];  // common.hip (avsr_tune)
+extern int avsr_tune_knobs[32];  // common.hip (avsr_tune)
 // Deterministic mode (avsr_tune knob 23 = 1; AVSR_DETERMINISTIC=1 / train.py --deterministic, round 6): every sum that the default
 // build forms with floating-point atomics from SEVERAL blocks -- split-K weight gradients, bias / LayerNorm / depthwise parameter
 // gradients, the position-projection gradient -- is formed by ONE block per output element in a fixed order instead (grid
