@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void weight_permute_split_kernel(const float* 
 struct AvsrPermEntry {
     const float* w;
     bf16_t* out;
-    int Cout, Cin, taps, to_dgrad, blk0, pad0, pad1, pad2;  // pad0 = 2: `out` is the two-plane IEEE-half image [Cout][2][taps][Cin] (mixed mode forward copies), else bf16
+    int Cout, Cin, taps, to_dgrad, blk0, pad0, pad1, pad2;  // pad0 = 2: `out` is the two-plane IEEE-half image [Cout][2][taps][Cin] (mixed mode forward copies), 3: the split8 layout of the dense order (split-plane forward copies), else bf16
 };
 // One block = one (co tile, ci tile) x all taps, transposed through LDS: the source w[co][ci][tap] is read in runs of
 // TCI * taps consecutive floats per co, the output [a][tap][b] is written in runs of 64 consecutive bf16 (128 bytes).
@@ -126,6 +126,12 @@ __global__ __launch_bounds__(256) void multi_weight_permute_kernel(const AvsrPer
                 f16_t* o16 = reinterpret_cast<f16_t*>(e.out) + ((long)(2 * a) * e.taps + tap) * Bc + b;
                 o16[0] = f2h(v);
                 o16[(long)e.taps * Bc] = f2h_lo(v);
+            } else if (e.pad0 == 3) {  // split8 layout (gemm_split.hip): every 8 consecutive elements of the dense order as 8 hi + 8 lo bf16
+                bf16_t pl[2];
+                split_bf16<2>(v, pl);
+                bf16_t* blk8 = e.out + (o >> 3) * 16 + (o & 7);
+                blk8[0] = pl[0];
+                blk8[8] = pl[1];
             } else e.out[o] = f2bf(v);
         }
     }

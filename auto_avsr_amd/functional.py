@@ -366,11 +366,31 @@ _wsplit_conv = {}  # (data_ptr, shape) -> [version, Split8 permuted copy, conv w
 _wsplit_table = {"n": 0, "dev": None, "blocks": 0, "built_for": -1}
 
 
+_wsplit_conv_table = {"n": 0, "dev": None, "blocks": 0, "built_for": -1, "max_taps": 1}
+
+
 def _refresh_split_weights():
     _wgen["split_gen"] = _wgen["gen"]
-    for ent in _wsplit_conv.values():
-        ops.conv_weight_permute_split(ent[2], out=ent[1])
-        ent[0] = ent[2]._version
+    if _wsplit_conv:
+        # round 6: every permuted split8 conv copy in ONE launch of the table kernel (csrc/gemm_conv.hip, entry code 3) -- until
+        # round 5 one 5 us launch per convolution weight at the start of every step
+        if _wsplit_conv_table["built_for"] != len(_wsplit_conv):
+            import struct
+
+            blob, blk, max_taps = b"", 0, 1
+            for (ptr, shape), ent in _wsplit_conv.items():
+                Cout, Cin = shape[0], shape[1]
+                taps = ent[2][0, 0].numel()
+                blob += struct.pack("<QQiiiiiiii", ent[2].data_ptr(), ent[1].data_ptr(), Cout, Cin, taps, 0, blk, 3, 0, 0)
+                blk += ops.weight_permute_blocks(Cout, Cin, False)
+                max_taps = max(max_taps, taps)
+            dev = next(iter(_wsplit_conv.values()))[2].device
+            host = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+            _wsplit_conv_table.update(n=len(_wsplit_conv), dev=host.to(dev), blocks=blk, built_for=len(_wsplit_conv), max_taps=max_taps)
+        ops.multi_weight_permute(_wsplit_conv_table["dev"], _wsplit_conv_table["n"], _wsplit_conv_table["blocks"],
+                                 _wsplit_conv_table["max_taps"])
+        for ent in _wsplit_conv.values():
+            ent[0] = ent[2]._version
     if not _wsplit:
         return
     if _wsplit_table["built_for"] != len(_wsplit):
@@ -642,6 +662,7 @@ def invalidate_weight_cache():
     _wconv.clear()
     _wsplit.clear()
     _wsplit_conv.clear()
+    _wsplit_conv_table.update(n=0, dev=None, blocks=0, built_for=-1, max_taps=1)
     _wsplit_table.update(n=0, dev=None, blocks=0, built_for=-1)
     _wh16.clear()
     _wh16_cat.clear()

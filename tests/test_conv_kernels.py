@@ -356,3 +356,25 @@ def test_multi_weight_permute_matches_single(dev):
     for (Cout, Cin, taps, dg), w, o in zip(shapes, ws, outs):
         ref = ops.conv_weight_permute(w.view(Cout, Cin, taps, 1), torch.bfloat16, to_dgrad=bool(dg))
         assert torch.equal(o.cpu().view(-1), ref.cpu().view(-1)), (Cout, Cin, taps, dg)
+
+
+def test_multi_weight_permute_split8_matches_single(dev):
+    """Round 6: the split8 (hi + lo bf16 planes) permuted copies of the split-plane forward convolutions leave the same table
+    launch (entry code 3) -- bit for bit the per-tensor avsr_conv_weight_permute(out_dtype = 2) they replace."""
+    import struct
+
+    torch.manual_seed(12)
+    shapes = [(64, 64, 9), (128, 64, 9), (128, 64, 1), (128, 128, 3), (72, 64, 9)]
+    ws, outs, blob, blk = [], [], b"", 0
+    for (Cout, Cin, taps) in shapes:
+        w = torch.randn(Cout, Cin, taps, 1, device=dev)
+        o = ops.conv_weight_permute_split(torch.zeros_like(w))
+        blob += struct.pack("<QQiiiiiiii", w.data_ptr(), o.data_ptr(), Cout, Cin, taps, 0, blk, 3, 0, 0)
+        blk += ops.weight_permute_blocks(Cout, Cin, False)
+        ws.append(w)
+        outs.append(o)
+    table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    ops.multi_weight_permute(table, len(shapes), blk, 9)
+    for w, o in zip(ws, outs):
+        ref = ops.conv_weight_permute_split(w)
+        assert torch.equal(o.as_subclass(torch.Tensor).cpu().view(torch.int32), ref.as_subclass(torch.Tensor).cpu().view(torch.int32)), w.shape
