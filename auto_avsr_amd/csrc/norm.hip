@@ -177,7 +177,7 @@ AVSR_DEV void layernorm_bwd_param_block(
 #pragma unroll
     for (int e = 0; e < 8; e++) pg[e] = pb[e] = 0.f;
     if (cc < cv) {
-        constexpr int U = 4;  // independent rows in flight per thread: the loop is a chain of HBM/L2 round trips otherwise
+        constexpr int U = 4;  // independent rows in flight per thread: the loop is a chain of HBM/L2 round trips otherwise (8: no gain, round 6)
         for (int rb = r0 + rl; rb < r1; rb += U * RL) {
             float xv[U][8], dv[U][8], m[U], rs[U];
 #pragma unroll
@@ -302,7 +302,7 @@ extern "C" int avsr_layernorm_bwd(const void* dy, int dy_dtype, const float* x, 
         gsum_det = gsum;
         gsum = nullptr;
     }
-    const int rpw = (gsum && rows > 1024) ? 2 : 1;
+    const int rpw = avsr_tune_knobs[25] > 0 ? avsr_tune_knobs[25] : ((gsum && rows > 1024) ? 2 : 1);  // knob 25: rows per wave of the dx blocks (A/B)
     const int ndx = (rows + LN_WAVES * rpw - 1) / (LN_WAVES * rpw);
     const int cv = cols >> 3;
     const int CL = cv >= 32 ? 32 : (cv >= 16 ? 16 : 8);

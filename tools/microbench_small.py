@@ -45,6 +45,12 @@ for name, dy in (("bf16 dy", torch.randn(rows, D, device=dev).bfloat16()), ("f32
     nogs = t(lambda: ops.layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=dres, gout=gout, alpha=0.5, drop_p=0.1, seed=3))
     plain = t(lambda: ops.layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=dres))
     print(f"layernorm_bwd {name}: with gout + gsum {full:6.1f}   with gout {nogs:6.1f}   dx + dgamma/dbeta only {plain:6.1f}")
+    for rpw in (1, 2, 3, 4, 8):  # knob 25: rows per wave of the dx blocks
+        ops.tune(25, rpw)
+        full = t(lambda: ops.layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=dres, gout=gout, gsum=gsum, alpha=0.5, drop_p=0.1, seed=3))
+        nogs = t(lambda: ops.layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=dres, gout=gout, alpha=0.5, drop_p=0.1, seed=3))
+        print(f"   rows per wave {rpw}: with gout + gsum {full:6.1f}   with gout {nogs:6.1f}")
+    ops.tune(25, 0)
 
 B, T, K = 4, 400, 31
 a = torch.randn(B, T, 2 * D, device=dev).bfloat16()
