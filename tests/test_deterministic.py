@@ -54,6 +54,8 @@ def test_two_runs_bit_identical(dev, tmp_path, monkeypatch):
     assert torch.equal(a[1], b[1])               # weights AND BatchNorm buffers: bit for bit
     if dev.type == "cuda":
         assert a[3]["replayed"] > 0               # ... under hipGraph replay
+    if dev.type != "cuda":
+        return  # (the third run costs the emulator another 50 s; the comparison below is about the GPU's atomics)
     # the default mode trains alike (same arithmetic up to summation order) -- and is free to differ in the last bits
     c = _run(dev, tmp_path, False, epochs, monkeypatch)
     assert len(c[0]) == len(a[0])
