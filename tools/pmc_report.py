@@ -52,8 +52,8 @@ FAMILIES = [
     ("transformer GEMMs (Linear fwd NT on f16 / bf16 / split planes, dgrad NT, wgrad TN, paired launches)",
      r"^(gemm_fast_kernel<\d+, \d+, \d+, 0,|gemm_pair_kernel|gemm_tn_fast_kernel<3, 0>|gemm_split_kernel<\d+, \d+, \d+, 0,)",
      ("avsr_gemm_bf16_nt", "avsr_gemm_bf16_tn", "avsr_gemm_h16_nt", "avsr_gemm_f32s_nt")),
-    ("ResNet conv fwd / dgrad (implicit GEMM on f16 / bf16 / split planes + the patch-staged 64-channel kernel)",
-     r"^(gemm_fast_kernel<\d+, \d+, \d+, [12],|conv3x3_c64_kernel|gemm_split_kernel<\d+, \d+, \d+, 1,)", ("avsr_conv2d_bf16", "avsr_conv2d_h16", "avsr_conv2d_f32s")),
+    ("ResNet conv fwd / dgrad (implicit GEMM on f16 / bf16 / split planes + the patch-staged kernels)",
+     r"^(gemm_fast_kernel<\d+, \d+, \d+, [12],|conv3x3_c64_kernel|conv_patch_kernel|gemm_split_kernel<\d+, \d+, \d+, 1,)", ("avsr_conv2d_bf16", "avsr_conv2d_h16", "avsr_conv2d_f32s")),
     ("ResNet 3x3 conv wgrad", r"^(conv3x3_wgrad_kernel|wgrad_reduce_kernel)", ("avsr_conv3x3_wgrad_bf16",)),
     ("BatchNorm passes", r"^bn_", ("avsr_bn_stats", "avsr_bn_stats_finalize", "avsr_bn_act_fwd", "avsr_bn_bwd_reduce", "avsr_bn_bwd_apply",
                                   "avsr_bn_act_pool_fwd", "avsr_bn_pool_bwd_reduce", "avsr_bn_pool_bwd_apply", "avsr_bn_small_fwd",

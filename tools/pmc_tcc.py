@@ -18,7 +18,7 @@ FAMILIES = [("transformer GEMM fwd (f16 NT tiles)", r"^gemm_fast_kernel<\d+, \d+
             ("transformer GEMM (bf16 NT tiles)", r"^gemm_fast_kernel<\d+, \d+, \d+, 0, .*, 0>$|^gemm_fast_kernel<\d+, \d+, \d+, 0, \d, \d, \d, \d>$"),
             ("paired dgrad + wgrad GEMMs", r"^gemm_pair_kernel"), ("TN wgrad GEMM", r"^gemm_tn_fast_kernel"),
             ("split-plane GEMM / conv (precise forward)", r"^gemm_split_kernel"),
-            ("trunk conv fwd / dgrad (tiled)", r"^gemm_fast_kernel<\d+, \d+, \d+, [12],"), ("conv3x3 c64", r"^conv3x3_c64_kernel"),
+            ("trunk conv fwd / dgrad (tiled)", r"^gemm_fast_kernel<\d+, \d+, \d+, [12],"), ("trunk conv fwd / dgrad (patch-staged)", r"^conv_patch_kernel"), ("conv3x3 c64", r"^conv3x3_c64_kernel"),
             ("3x3 wgrad", r"^conv3x3_wgrad_kernel|^wgrad_reduce"), ("video stem", r"^stem_"), ("attention", r"^attn_"), ("BatchNorm", r"^bn_"),
             ("LayerNorm", r"^layernorm"), ("depthwise conv", r"^dwconv"), ("optimizer", r"^multi_adamw|^multi_sumsq|^clip_coef")]
 
