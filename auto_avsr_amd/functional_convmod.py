@@ -141,14 +141,11 @@ class ConvSublayerFn(torch.autograd.Function):
         # channels and every frame (csrc/convmod_fused.hip)
         middle = one_launch and AF._CONVMOD_FUSED
         ctx.middle = middle
+        c = None if middle else ops.dwconv(a, wdw, b_dw, B, Tn, D, K, glu_in=True)
         if middle:
             s, c, bmean, binv = ops.convmod_dwbn_fwd(a, wdw, b_dw, B, Tn, D, K, bn_w, bn_b, bn_eps, momentum, bn_rm, bn_rv, bn_nbt,
                                                      out_dtype=T if Tc != T else None)
             counts = None
-        else:
-            c = ops.dwconv(a, wdw, b_dw, B, Tn, D, K, glu_in=True)
-        if middle:
-            pass
         elif one_launch:  # statistics + running stats + normalise + Swish in one pass
             s, bmean, binv = ops.bn_small_fwd(c, rows, D, bn_w, bn_b, bn_eps, momentum, bn_rm, bn_rv, bn_nbt, 1,
                                               out_dtype=T if Tc != T else None)

@@ -339,6 +339,40 @@ def test_stem_fused_pool_switch_equivalence(dev):
         assert rel(g1[k], g0[k]) < 2e-2 or float(g0[k].abs().max()) < 1e-7, k
 
 
+@pytest.mark.parametrize("mode", ["bf16", "mixed"])
+def test_convmod_fused_middle_switch_equivalence(dev, mode):
+    """AVSR_CONVMOD_FUSED (round 6, opt-in: GLU -> depthwise conv -> BatchNorm -> SiLU of the convolution module and its backward as
+    one launch each): the same losses, gradients and BatchNorm running statistics as the launches it merges -- the kernels are
+    bit-equal but for the summation order of the depthwise weight gradient."""
+    was_mode, was_fused = AF.mode(), AF._CONVMOD_FUSED
+    odim = 40
+    res = []
+    try:
+        AF.set_mode(mode)
+        for fused in (False, True):
+            AF._CONVMOD_FUSED = fused
+            AF.invalidate_weight_cache()
+            torch.manual_seed(0)
+            m = no_dropout(E2E(odim, "audio", adim=64, aheads=1, eunits=64, elayers=2, dunits=64, dlayers=1, cnn_module_kernel=7))
+            m.load_state_dict(synth_state_dict(m.state_dict(), 3), strict=True)
+            m.to(dev).train()
+            x, lengths, y = (t.to(dev) for t in synth_batch("audio", 2, 7, 3, odim, seed=2))
+            loss, loss_ctc, loss_att, _ = m(x, lengths, y)
+            loss.backward()
+            bn = m.encoder.encoders[0].conv_module.norm
+            res.append((float(loss_ctc), float(loss_att), {k: p.grad.cpu().clone() for k, p in m.named_parameters()},
+                        bn.running_mean.cpu().clone(), bn.running_var.cpu().clone(), int(bn.num_batches_tracked)))
+    finally:
+        AF._CONVMOD_FUSED = was_fused
+        AF.set_mode(was_mode)
+        AF.invalidate_weight_cache()
+    (c0, a0, g0, rm0, rv0, n0), (c1, a1, g1, rm1, rv1, n1) = res
+    assert c0 == c1 and a0 == a1 and n0 == n1 == 1
+    assert torch.equal(rm0, rm1) and torch.equal(rv0, rv1)
+    for k in g0:
+        assert rel(g1[k], g0[k]) < 1e-4 or float(g0[k].abs().max()) < 1e-7, k
+
+
 def test_residual_gradient_handoff_equivalence(dev):
     """The backward prologue of a sub-layer's output Linear produced inside the NEXT sub-layer's LayerNorm backward
     (functional._chain_*) vs the stand-alone cast / column-sum launch: same gradients (dropout ON -- both paths must draw
