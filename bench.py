@@ -639,7 +639,7 @@ KERNELS_OF = {"avsr_gemm_bf16_nt": r"^gemm_fast_kernel<\d+, \d+, \d+, 0,", "avsr
 def counter_traffic(pattern):
     """HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, calibrated) of the kernels matching `pattern`, from the committed
     summary of the two rocprofv3 --pmc passes over one eager step of this workload (tools/pmc_step.py, tools/pmc_report.py ->
-    profiles/r5_hbm_traffic.json, taken on the SAME batch shape the roofline legs re-issue their launches on; tools/r5_pmc.sh is the recipe; the round-4 summary is the fall-back).  PMC counters cannot be read from inside this process; the
+    profiles/r6_hbm_traffic.json, taken on the SAME batch shape the roofline legs re-issue their launches on; tools/r6_pmc.sh is the recipe; the round-5 summary is the fall-back).  PMC counters cannot be read from inside this process; the
     passes are separate runs, as the profiling guide prescribes.  None when the summary is absent."""
     import re
 
