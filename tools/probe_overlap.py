@@ -117,3 +117,30 @@ def serial():
 for name, fn in (("front-end forward alone", front_only), ("optimizer alone", opt_only), ("one after the other", serial),
                  ("together on two streams", both)):
     print(f"{name:28s} {timed(fn):7.3f} ms", flush=True)
+
+# ---- the same with the optimizer's stream restricted to a subset of the CUs (hipExtStreamCreateWithCUMask): a deterministic split
+# of the chip instead of the dispatcher's time slicing
+import ctypes
+
+hip = ctypes.CDLL("libamdhip64.so")
+for label, bits in (("every 8th CU (32)", [i for i in range(256) if i % 8 == 0]), ("every 4th CU (64)", [i for i in range(256) if i % 4 == 0]),
+                    ("CUs 0..31", list(range(32))), ("CUs 0..63", list(range(64)))):
+    words = (ctypes.c_uint32 * 8)()
+    for b in bits:
+        words[b // 32] |= 1 << (b % 32)
+    h = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, words)
+    if rc != 0:
+        print(f"hipExtStreamCreateWithCUMask rc={rc}")
+        continue
+    s2 = torch.cuda.ExternalStream(h.value)
+    print(f"optimizer stream on {label}: alone {timed(opt_only):7.3f} ms   together {timed(both):7.3f} ms", flush=True)
+    words_f = (ctypes.c_uint32 * 8)()
+    for b in range(256):
+        if b not in set(bits):
+            words_f[b // 32] |= 1 << (b % 32)
+    hf = ctypes.c_void_p()
+    if hip.hipExtStreamCreateWithCUMask(ctypes.byref(hf), 8, words_f) == 0:
+        s1_old, s1 = s1, torch.cuda.ExternalStream(hf.value)
+        print(f"   ... and the front end on the complement: alone {timed(front_only):7.3f} ms   together {timed(both):7.3f} ms", flush=True)
+        s1 = s1_old
