@@ -244,8 +244,10 @@ extern "C" int avsr_gemm_h16_nt(const void* A, int lda, const void* B, const voi
                                 int act, float drop_p, uint64_t seed, const uint64_t* seed_dev, float alpha, const void* resid,
                                 int resid_dtype, int ldr, void* C, int c_dtype, int ldc, int tile, void* c2, int ldc2,
                                 hipStream_t stream) {
+    // knob 26 (probe, tools/microbench_splitk.py): > 1 = k split of that many ways with f32 atomics onto a ZEROED f32 C (no twin)
+    const int sk = (g_tune[26] > 1 && c_dtype == 0 && c2 == nullptr) ? g_tune[26] : 1;
     return gemm16_nt_impl(1, A, lda, B, B_lo, ldb, M, N, K, bias, act, nullptr, 0, 0, 1.f, drop_p, seed, seed_dev, alpha, nullptr, resid,
-                          resid_dtype, ldr, C, c_dtype, ldc, 0, 1, tile, nullptr, c2, ldc2, stream);
+                          resid_dtype, ldr, C, c_dtype, ldc, sk > 1 ? 1 : 0, sk, tile, nullptr, c2, ldc2, stream);
 }
 
 // bf16 implicit-GEMM convolution on the tuned kernel: forward (dgrad = 0: x[N,H,W,Cin] * wp[Cout][KH][KW][Cin] ->

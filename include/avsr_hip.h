@@ -409,7 +409,8 @@ int avsr_comm_reduce_scatter(int slot, const void* send, void* recv, int64_t cou
  * split8 layout (Cout < 128 / Cout >= 128: 23 .. 30, see gemm_split.hip), 20 = the patch-staged 3x3 kernel of conv_patch.hip (1 = off:
  * keep the tiled kernel; 2 = on whatever the grid size), 23 = deterministic mode (see auto_avsr_amd.functional.set_deterministic),
  * 24 = block-count target of avsr_conv2d_wgrad_bf16's k split (0 = by tile count: 512 / 1024 / 2048), 25 = rows per wave of
- * avsr_layernorm_bwd's dx blocks (0 = 1, or 2 with a column-sum output on > 1024 rows; tools/microbench_small.py).  Knobs 0..31 exist. */
+ * avsr_layernorm_bwd's dx blocks (0 = 1, or 2 with a column-sum output on > 1024 rows; tools/microbench_small.py), 26 = k split of
+ * avsr_gemm_h16_nt with f32 atomics onto a ZEROED f32 C (probe: tools/microbench_splitk.py; slower at M = 1600).  Knobs 0..31 exist. */
 int avsr_tune(int knob, int value);
 /* bf16 implicit-GEMM convolution on the tuned LDS-DMA kernel: dgrad = 0 forward, 1 data gradient (see
  * avsr_conv2d_fwd / avsr_conv2d_dgrad for the tensor conventions); gathered channel count % 64 == 0; stride 1 or 2
