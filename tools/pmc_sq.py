@@ -1,7 +1,7 @@
 """Where do the waves of each kernel spend their cycles?  One rocprofv3 pass over tools/pmc_step.py with
   --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_LDS_UNALIGNED_STALL
 (guide, "rocprofv3 PMC slots": WAIT_ANY = wave parked on s_waitcnt / barrier; WAIT_INST_ANY = issue stall; the three
-are disjoint shares of WAVE_CYCLES).    python tools/pmc_sq.py <dir or .db> [out.txt]"""
+are disjoint shares of WAVE_CYCLES).    python tools/pmc_sq.py <dir or .db>[,<dir>...] [out.txt]   (tools/r6_pmc_sq.sh: two passes of four counters)"""
 import sqlite3
 import sys
 import os
@@ -16,10 +16,16 @@ NAMES = ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_AN
 def main():
     per = {}
     base = None
+    dirs = sys.argv[1].split(",")  # (one directory per rocprofv3 pass: the counters are looked up in each)
     for nm in NAMES:
-        try:
-            rows = P.load(sys.argv[1], nm)
-        except AssertionError:
+        rows = None
+        for d in dirs:
+            try:
+                rows = P.load(d, nm)
+                break
+            except (AssertionError, Exception):
+                continue
+        if rows is None:
             continue
         _, step = P.split(rows)
         if base is None:
