@@ -140,6 +140,68 @@ def _child(emu_path, case, q):
         ys[0, L // 2:] = -1
         r = ops.prepare_targets(guarded(ys), 60, 60, -1)
         q.put(float(r[3].sum()))
+    elif kind == "conv_patch":  # round 6, csrc/conv_patch.hip: whole-image tiles, ragged last tile, zero slot, offset tables
+        _, N, H, Cin, Cout = case
+        bf = torch.bfloat16
+        w = torch.randn(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5
+        x = guarded(torch.randn(N, H, H, Cin).to(bf))
+        dy = guarded(torch.randn(N, H, H, Cout).to(bf))
+        res = guarded(torch.randn(N, H, H, Cin).to(bf))
+        wp = guarded(ops.conv_weight_permute(w, bf))
+        wpd = guarded(ops.conv_weight_permute(w, bf, to_dgrad=True))
+        xh = guarded(torch.randn(N, H, H, Cin).half())
+        w16 = guarded((0.05 * torch.randn(Cout, 2, 9 * Cin)).half())
+        tot = 0.0
+        try:
+            for knob in (2, 3):  # the patch-staged kernel whatever the grid size, two / three weight stages
+                ops.tune(20, knob)
+                y = ops.conv2d_fwd(x, wp, N, H, H, Cin, Cout, 3, 3, 1, 1, 1, False)
+                y2 = ops.conv2d_fwd(xh, w16, N, H, H, Cin, Cout, 3, 3, 1, 1, 1, False, wp_planes=2)
+                y1 = ops.conv2d_fwd(xh, w16, N, H, H, Cin, Cout, 3, 3, 1, 1, 1, False, wp_planes=1)
+                tot += float(y.float().abs().sum()) + float(y2.float().abs().sum()) + float(y1.float().abs().sum())
+                if Cin % 128 == 0:
+                    dx = ops.conv2d_dgrad(dy, wpd, res, N, H, H, Cin, Cout, 3, 3, 1, 1, 1, False)
+                    tot += float(dx.float().abs().sum())
+        finally:
+            ops.tune(20, 0)
+        q.put(tot)
+    elif kind == "convmod_fused":  # round 6, csrc/convmod_fused.hip (opt-in)
+        _, B, T, C, K, dtype = case
+        rows = B * T
+        a = guarded((torch.randn(rows, 2 * C) * 1.2).to(dtype))
+        w, bias = guarded(torch.randn(C, K) * 0.3), guarded(torch.randn(C) * 0.1)
+        g, b = guarded(torch.rand(C) + 0.5), guarded(torch.randn(C) * 0.1)
+        rm, rv = guarded(torch.zeros(C)), guarded(torch.ones(C))
+        nbt = guarded(torch.zeros(1, dtype=torch.int64))
+        s_, c, mean, invstd = ops.convmod_dwbn_fwd(a, w, bias, B, T, C, K, g, b, 1e-5, 0.1, rm, rv, nbt)
+        ds = guarded(torch.randn(rows, C).to(dtype))
+        dw, dbias = guarded(torch.zeros(C, K)), guarded(torch.zeros(C))
+        da, dg, db = ops.convmod_dwbn_bwd(a, guarded(c), ds, guarded(mean), guarded(invstd), g, b, w, B, T, C, K, dw, dbias)
+        q.put(float(da.float().abs().sum()) + float(s_.float().abs().sum()))
+    elif kind == "attn_ksplit":  # round 6: key range split over two wave groups (forced: knob 8 = 3), source-attention geometry
+        _, B, T, Tk, H = case
+        D = 64
+        bf = torch.bfloat16
+        qu = guarded(torch.randn(B, T, H, D).to(bf))
+        k, v = guarded(torch.randn(B, Tk, H, D).to(bf)), guarded(torch.randn(B, Tk, H, D).to(bf))
+        m = torch.ones(B, 1, Tk, dtype=torch.bool)
+        m[-1, 0, Tk - 37:] = False
+        try:
+            ops.tune(8, 3)
+            out, lse = ops.attention_fwd(qu, None, k, v, None, guarded(m), 0.125)
+        finally:
+            ops.tune(8, 0)
+        q.put(float(out.float().abs().sum()))
+    elif kind == "permute_split8":  # round 6: split8 conv-weight copies from the table launch
+        import struct
+
+        _, Cout, Cin, taps = case
+        w = guarded(torch.randn(Cout, Cin, taps))
+        o = guarded(torch.zeros(Cout, taps * Cin))
+        blob = struct.pack("<QQiiiiiiii", w.data_ptr(), o.data_ptr(), Cout, Cin, taps, 0, 0, 3, 0, 0)
+        table = guarded(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+        ops.multi_weight_permute(table, 1, ops.weight_permute_blocks(Cout, Cin, False), taps)
+        q.put(float(o.abs().sum()))
     else:
         raise AssertionError(kind)
 
@@ -160,6 +222,11 @@ CASES = [
     ("layernorm", 37, 256), ("layernorm", 1030, 768),
     ("dwconv", 2, 50, 64, 31), ("dwconv", 3, 129, 128, 7),
     ("ctc", 2, 40, 53, 9), ("ctc", 1, 150, 301, 70),
+    # round 6
+    ("conv_patch", 30, 3, 128, 128), ("conv_patch", 5, 6, 64, 128), ("conv_patch", 9, 6, 128, 256), ("conv_patch", 3, 11, 128, 128),
+    ("convmod_fused", 3, 37, 16, 31, "f32"), ("convmod_fused", 4, 512, 8, 15, "bf16"), ("convmod_fused", 1, 1, 8, 31, "f32"),
+    ("attn_ksplit", 2, 33, 300, 2), ("attn_ksplit", 1, 65, 257, 1),
+    ("permute_split8", 72, 64, 9), ("permute_split8", 128, 128, 3),
 ]
 
 
