@@ -240,8 +240,10 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
     T* g = grad + bt * ldg;
     const float nl = nll[b];
     const bool live = t < (int)in_lens[b] && nl < INFINITY;  // zero_infinity=True
+    // (round 6: columns [V, ldg) -- the pitch padding the data-gradient GEMM contracts over -- are written here as zeros: no
+    // fill launch over the whole buffer)
     if (!live) {
-        for (int v = threadIdx.x; v < V; v += 256) Elem<T>::st(g + v, 0.f);
+        for (int v = threadIdx.x; v < (int)ldg; v += 256) Elem<T>::st(g + v, 0.f);
         return;
     }
     // occupancy per extended state into LDS, then summed per label in a FIXED order (round 6: LDS float atomics from the states
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
     __syncthreads();
     const float l = lse[bt];
     const T* x = logits + bt * ld;
-    for (int v = threadIdx.x; v < V; v += 256) Elem<T>::st(g + v, avsr_exp(Elem<T>::ld(x + v) - l) - occ[v]);
+    for (int v = threadIdx.x; v < (int)ldg; v += 256) Elem<T>::st(g + v, v < V ? avsr_exp(Elem<T>::ld(x + v) - l) - occ[v] : 0.f);
 }
 
 // ---- label-smoothing CE: one block per row
@@ -333,9 +335,9 @@ __global__ __launch_bounds__(256) void ce_smooth_kernel(const T* __restrict__ lo
     }
     if (grad) {
         T* g = grad + r * ldg;
-        for (int v = threadIdx.x; v < V; v += 256) {
+        for (int v = threadIdx.x; v < (int)ldg; v += 256) {  // (columns [V, ldg): zeros, as in ctc_grad_kernel)
             float gv = 0.f;
-            if (!ignored) gv = avsr_exp(Elem<T>::ld(x + v) - lse) - (v == (int)y ? conf : eps);
+            if (!ignored && v < V) gv = avsr_exp(Elem<T>::ld(x + v) - lse) - (v == (int)y ? conf : eps);
             Elem<T>::st(g + v, gv);
         }
     }

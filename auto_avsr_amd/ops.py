@@ -550,7 +550,7 @@ def ctc_loss(logits, ld, labels, in_lens, B, T, V, want_grad=True, ignore_id=-1)
     ws_bytes = call("avsr_ctc_workspace_bytes", B, T, Lmax)
     ws = torch.empty(ws_bytes // 4 + 1, dtype=torch.float32, device=logits.device)
     nll = torch.empty(B, dtype=torch.float32, device=logits.device)
-    grad = torch.zeros(B * T, ld, dtype=logits.dtype, device=logits.device) if want_grad else None
+    grad = torch.empty(B * T, ld, dtype=logits.dtype, device=logits.device) if want_grad else None  # (the kernel writes the pad columns too)
     call("avsr_ctc_loss", _ptr(logits), dt(logits), ld, _ptr(labels), Lmax, ignore_id, _ptr(in_lens), _ptr(nll),
          _ptr(grad), ld, _ptr(ws), B, T, V, _stream(logits))
     return nll, grad
@@ -560,7 +560,7 @@ def ce_smooth(logits, ld, target, V, smoothing, want_grad=True, ignore_id=-1):
     rows = target.numel()
     row_loss = torch.empty(rows, dtype=torch.float32, device=logits.device)
     row_hit = torch.empty(rows, dtype=torch.float32, device=logits.device)
-    grad = torch.zeros(rows, ld, dtype=logits.dtype, device=logits.device) if want_grad else None
+    grad = torch.empty(rows, ld, dtype=logits.dtype, device=logits.device) if want_grad else None  # (the kernel writes the pad columns too)
     call("avsr_ce_smooth", _ptr(logits), dt(logits), ld, _ptr(target), ignore_id, V, smoothing, _ptr(row_loss),
          _ptr(row_hit), _ptr(grad), ld, rows, _stream(logits))
     return row_loss, row_hit, grad
@@ -772,7 +772,7 @@ def conv2d_wgrad(dy, x, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise, tor
         return dwp
     if torch_layout:
         return conv_weight_unpermute(conv2d_wgrad(dy, x, N, H, W, Cin, Cout, KH, KW, stride, ph, pw, precise), (Cout, Cin, KH, KW))
-    dwp = torch.zeros(Cout, KH * KW * Cin, dtype=torch.float32, device=x.device)
+    dwp = zeros_f32((Cout, KH * KW * Cin), x.device)  # (the zero-scratch arena: no fill launch per weight gradient)
     if bf and Cin % 64 == 0 and Cout % 8 == 0:
         call("avsr_conv2d_wgrad_bf16", _ptr(dy), _ptr(x), _ptr(dwp), _ptr(zero_page(x.device)), N, H, W, Cin, Cout, KH,
              KW, stride, ph, pw, _stream(x), flops=2.0 * N * OH * OW * Cout * KH * KW * Cin, nbytes=_nb(dy, x, dwp))

@@ -249,12 +249,13 @@ int avsr_row_lse(const void* x, int dtype, int64_t ld, float* lse, int64_t rows,
 int64_t avsr_ctc_workspace_bytes(int B, int T, int Lmax);
 /* CTC (ctc.py:32-38,54-63; blank 0): logits [B,T,V] rows of pitch ld; labels int64 [B,Lmax] padded with
  * ignore_id; in_lens int64 [B].  nll[b] = -log p (inf if infeasible); grad (same dtype, pitch ldg, may be
- * NULL) = d nll[b]/d logits, zero for t >= in_lens[b] and for infeasible targets (zero_infinity). */
+ * NULL) = d nll[b]/d logits, zero for t >= in_lens[b] and for infeasible targets (zero_infinity); the pad columns [V, ldg) of
+ * every row are written as zeros (round 6: the buffer need not be initialised). */
 int avsr_ctc_loss(const void* logits, int dtype, int64_t ld, const int64_t* labels, int Lmax, int ignore_id,
                   const int64_t* in_lens, float* nll, void* grad, int64_t ldg, void* workspace, int B, int T,
                   int V, avsr_stream_t stream);
 /* label-smoothing KL (label_smoothing_loss.py:41-63) per row + argmax hit (nets_utils.py:272-292);
- * grad = softmax - smoothed target (zero rows for ignored targets), may be NULL */
+ * grad = softmax - smoothed target (zero rows for ignored targets; pad columns [V, ldg) written as zeros), may be NULL */
 int avsr_ce_smooth(const void* logits, int dtype, int64_t ld, const int64_t* target, int ignore_id, int V,
                    float smoothing, float* row_loss, float* row_hit, void* grad, int64_t ldg, int64_t rows,
                    avsr_stream_t stream);

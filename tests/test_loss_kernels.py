@@ -150,3 +150,33 @@ def _targets_vs_golden(dev):
         assert torch.equal(mask.cpu()[:, :w, :w], c["mask"])
         assert bool((ys_out.cpu()[:, w:] == -1).all()) and bool((ys_in.cpu()[:, w:] == c["eos"]).all())
         assert int(n_tok) == c["n_tokens"]
+
+
+def test_loss_gradients_write_their_pad_columns(dev):
+    """Round 6: the CTC / label-smoothing gradient kernels write the pitch-padding columns [V, ld) of every row as zeros themselves
+    (the data-gradient GEMM of the head contracts over the padded width): the buffer may start as garbage -- no fill launch."""
+    from auto_avsr_amd import ops
+
+    torch.manual_seed(5)
+    B, T, V, L = 2, 9, 37, 4
+    ld = 40
+    logits = torch.zeros(B * T, ld)
+    logits[:, :V] = torch.randn(B * T, V)
+    logits = logits.to(dev)
+    labels = torch.randint(1, V, (B, L)).to(dev)
+    in_lens = torch.tensor([T, T - 3], dtype=torch.int64, device=dev)
+    ws = torch.empty(ops.call("avsr_ctc_workspace_bytes", B, T, L) // 4 + 1, dtype=torch.float32, device=dev)
+    nll = torch.empty(B, dtype=torch.float32, device=dev)
+    grad = torch.full((B * T, ld), float("nan"), device=dev)
+    ops.call("avsr_ctc_loss", ops._ptr(logits), 0, ld, ops._ptr(labels), L, -1, ops._ptr(in_lens), ops._ptr(nll), ops._ptr(grad), ld,
+             ops._ptr(ws), B, T, V, ops._stream(logits))
+    g = grad.cpu()
+    assert torch.isfinite(g).all() and (g[:, V:] == 0).all() and g[:, :V].abs().sum() > 0
+    assert (g[T + T - 3:, :] == 0).all()  # frames past the second utterance's length: zero rows, pads included
+    tgt = torch.tensor([3, -1, 5, 7] + [1] * (B * T - 4), dtype=torch.int64, device=dev)
+    rl, rh = torch.empty(B * T, device=dev), torch.empty(B * T, device=dev)
+    grad2 = torch.full((B * T, ld), float("nan"), device=dev)
+    ops.call("avsr_ce_smooth", ops._ptr(logits), 0, ld, ops._ptr(tgt), -1, V, 0.1, ops._ptr(rl), ops._ptr(rh), ops._ptr(grad2), ld, B * T,
+             ops._stream(logits))
+    g2 = grad2.cpu()
+    assert torch.isfinite(g2).all() and (g2[:, V:] == 0).all() and (g2[1] == 0).all() and g2[0, :V].abs().sum() > 0
